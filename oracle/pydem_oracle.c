@@ -1,0 +1,925 @@
+/*
+ * pydem_oracle.c -- CPU restatement of pyDEM's per-tile hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity checker for the HIP path and the
+ * `cpu_baseline` leg of bench.py.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline may load it; the product package (pydem_amd/) never does.
+ *
+ * It restates, in plain C99 doubles with the reference's operation order, the algorithms of
+ * creare-com/pydem v1.2.1 (reference checkout: /root/reference).  Every function cites the
+ * reference lines it follows.  Third-party arithmetic the reference leans on and that is
+ * restated here from its published behaviour:
+ *   - numpy 2.2.6 `np.add.reduce` pairwise summation (numpy/_core/src/umath/loops_utils.h.src,
+ *     `@TYPE@_pairwise_sum`: <8 sequential, <=128 eight accumulators, else split) -- pinned
+ *     empirically against np.sum on 3000 random vectors;
+ *   - scipy.ndimage.label raster-order label numbering (8-connectivity);
+ *   - scipy.sparse COO->CSC conversion (column-major, row-sorted, duplicates summed).
+ * Pinned against: tests/golden (npz files), captured from the unmodified reference by
+ * oracle/ref_harness/gen_golden.py (numpy forced onto glibc libm, so atan2/log == this file's
+ * libm calls bit for bit).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fno-fast-math; no -march so no FMA).
+ * All arrays are C-order, row = i (n rows), col = j (m cols), linear id = i*m + j
+ * (reference: dem_processing.py:1083-1084, cyutils.pyx:207-226).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* facet tables: dem_processing.py:173-182 (facets) and :184-193 (ang_adj) */
+static const int E1[8][2] = {{0, 1}, {-1, 0}, {-1, 0}, {0, -1}, {0, -1}, {1, 0}, {1, 0}, {0, 1}};
+static const int E2[8][2] = {{-1, 1}, {-1, 1}, {-1, -1}, {-1, -1}, {1, -1}, {1, -1}, {1, 1}, {1, 1}};
+static const int ANG0[8] = {0, 1, 1, 2, 2, 3, 3, 4};
+static const int ANG1[8] = {1, -1, 1, -1, 1, -1, 1, -1};
+
+void oracle_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------------------------
+ * numpy pairwise summation (see header).  Used wherever the reference calls .sum()/.mean()
+ * on a float64 vector (dem_processing.py:1348, 1367, 1370, 1997).
+ * ---------------------------------------------------------------------------------------- */
+static double np_pairwise_sum(const double *a, int64_t n)
+{
+    if (n < 8) {
+        double res = 0.;
+        for (int64_t i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        int64_t i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; k++) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        int64_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A1  Tarboton D-infinity slope + direction.
+ * Reference: _tarboton_slopes_directions dem_processing.py:1753-1903,
+ *            _get_d1_d2 :1905-1938, _calc_direction :1942-1991.
+ * ---------------------------------------------------------------------------------------- */
+
+/* _get_d1_d2 with topbot == None: per-row spacing for interior/left/right cells of row i.
+ * (:1912-1924)  facets 0,3,4,7: d1 = dX[r], d2 = dY[r], r from e2's row offset;
+ *               facets 1,2,5,6: d1 = dY[r], d2 = dX[r], r from e1's row offset. */
+static void spacing_row_raw(const double *dX, const double *dY, int k, int64_t i, double *d1, double *d2)
+{
+    if (k == 0 || k == 3 || k == 4 || k == 7) {
+        int64_t r = (E2[k][0] == -1) ? i - 1 : i;
+        *d1 = dX[r];
+        *d2 = dY[r];
+    } else {
+        int64_t r = (E1[k][0] == -1) ? i - 1 : i;
+        *d1 = dY[r];
+        *d2 = dX[r];
+    }
+}
+
+/* _get_d1_d2 with topbot 'top' (idx 0) / 'bot' (idx n-2)  (:1925-1934); theta :1936 */
+static void spacing_fixed(const double *dX, const double *dY, int k, int64_t idx, double *d1, double *d2, double *theta)
+{
+    if (k == 0 || k == 3 || k == 4 || k == 7) {
+        *d1 = dX[idx];
+        *d2 = dY[idx];
+    } else {
+        *d2 = dX[idx];
+        *d1 = dY[idx];
+    }
+    *theta = atan2(*d2, *d1);
+}
+
+/* per-row theta = arctan2(d2, d1) (:1936) is computed once per row and facet, as the
+ * reference's vectorised code does; TH[k*n + i] is valid for rows 1..n-2 */
+static double *row_theta_table(const double *dX, const double *dY, int64_t n)
+{
+    double *tab = (double *)malloc(8 * n * sizeof(double));
+    for (int k = 0; k < 8; k++)
+        for (int64_t i = 1; i < n - 1; i++) {
+            double d1, d2;
+            spacing_row_raw(dX, dY, k, i, &d1, &d2);
+            tab[k * n + i] = atan2(d2, d1);
+        }
+    return tab;
+}
+#define spacing_row(dX, dY, k, i, d1, d2, th) do { spacing_row_raw(dX, dY, k, i, d1, d2); *(th) = TH[(k) * n + (i)]; } while (0)
+
+/* _calc_direction for one cell and one facet (:1954-1989). */
+static void facet_update(double z0, double z1, double z2, double d1, double d2, double theta, int k,
+                         double *mag, double *dir)
+{
+    double s1 = (z0 - z1) / d1;                  /* :1958 */
+    double s2 = (z1 - z2) / d2;                  /* :1959 */
+    double s1_2 = s1 * s1;                       /* :1960 */
+    double sd = (z0 - z2) / sqrt(d1 * d1 + d2 * d2); /* :1962 */
+    double r = atan2(s2, s1);                    /* :1963 */
+    double rad2 = s1_2 + s2 * s2;                /* :1964 */
+    int b_s1_lte0 = s1 <= 0, b_s2_lte0 = s2 <= 0, b_s1_gt0 = s1 > 0, b_s2_gt0 = s2 > 0;
+    if ((b_s1_lte0 && b_s2_gt0) || (r > theta)) { /* I1 :1973-1976 */
+        rad2 = sd * sd;
+        r = theta;
+    }
+    if ((b_s1_gt0 && b_s2_lte0) || (r < 0)) {     /* I2 :1978-1981 */
+        rad2 = s1_2;
+        r = 0;
+    }
+    if (b_s1_lte0 && (b_s2_lte0 || (b_s2_gt0 && (sd <= 0)))) /* I3 :1983-1984 */
+        rad2 = -1;
+    if (rad2 > *mag) {                            /* I4 :1986-1989 */
+        *mag = rad2;
+        *dir = r * (double)ANG1[k] + (double)ANG0[k] * M_PI / 2;
+    }
+}
+
+#define Z(i, j) elev[(i) * m + (j)]
+
+int oracle_slopes_directions(const double *elev, int64_t n, int64_t m,
+                             const double *dX, const double *dY,
+                             double *mag, double *dir)
+{
+    if (n < 3 || m < 3) return -1;
+    int64_t NN = n * m;
+    for (int64_t c = 0; c < NN; c++) { mag[c] = -1; dir[c] = -1; } /* :1761-1762 */
+    double *TH = row_theta_table(dX, dY, n);
+
+    /* interior, facets in order 0..7 (:1764-1777) */
+    for (int64_t i = 1; i < n - 1; i++)
+        for (int64_t j = 1; j < m - 1; j++) {
+            int64_t c = i * m + j;
+            for (int k = 0; k < 8; k++) {
+                double d1, d2, th;
+                spacing_row(dX, dY, k, i, &d1, &d2, &th);
+                facet_update(Z(i, j), Z(i + E1[k][0], j + E1[k][1]), Z(i + E2[k][0], j + E2[k][1]),
+                             d1, d2, th, k, &mag[c], &dir[c]);
+            }
+        }
+
+    /* copy-from-interior rules, in the reference's order (:1782-1795) */
+    for (int64_t i = 0; i < n; i++) {
+        double d = dir[i * m + 1];
+        if (d > M_PI / 2 && d < 3 * M_PI / 2) { dir[i * m] = d; mag[i * m] = mag[i * m + 1]; }
+    }
+    for (int64_t i = 0; i < n; i++) {
+        double d = dir[i * m + m - 2];
+        if (d < M_PI / 2 || d > 3 * M_PI / 2) { dir[i * m + m - 1] = d; mag[i * m + m - 1] = mag[i * m + m - 2]; }
+    }
+    for (int64_t j = 0; j < m; j++) {
+        double d = dir[1 * m + j];
+        if (d > 0 && d < M_PI) { dir[j] = d; mag[j] = mag[m + j]; }
+    }
+    for (int64_t j = 0; j < m; j++) {
+        double d = dir[(n - 2) * m + j];
+        if (d > M_PI && d < 2 * M_PI) { dir[(n - 1) * m + j] = d; mag[(n - 1) * m + j] = mag[(n - 2) * m + j]; }
+    }
+
+    static const int LEFT[4] = {0, 1, 6, 7}, RIGHT[4] = {2, 3, 4, 5}, TOP[4] = {4, 5, 6, 7}, BOT[4] = {0, 1, 2, 3};
+    /* left edge (:1801-1810) */
+    for (int q = 0; q < 4; q++) {
+        int k = LEFT[q];
+        for (int64_t i = 1; i < n - 1; i++) {
+            double d1, d2, th;
+            spacing_row(dX, dY, k, i, &d1, &d2, &th);
+            facet_update(Z(i, 0), Z(i + E1[k][0], E1[k][1]), Z(i + E2[k][0], E2[k][1]), d1, d2, th, k,
+                         &mag[i * m], &dir[i * m]);
+        }
+    }
+    /* right edge (:1812-1823) */
+    for (int q = 0; q < 4; q++) {
+        int k = RIGHT[q];
+        for (int64_t i = 1; i < n - 1; i++) {
+            double d1, d2, th;
+            spacing_row(dX, dY, k, i, &d1, &d2, &th);
+            facet_update(Z(i, m - 1), Z(i + E1[k][0], m - 1 + E1[k][1]), Z(i + E2[k][0], m - 1 + E2[k][1]),
+                         d1, d2, th, k, &mag[i * m + m - 1], &dir[i * m + m - 1]);
+        }
+    }
+    /* top edge (:1825-1834) */
+    for (int q = 0; q < 4; q++) {
+        int k = TOP[q];
+        double d1, d2, th;
+        spacing_fixed(dX, dY, k, 0, &d1, &d2, &th);
+        for (int64_t j = 1; j < m - 1; j++)
+            facet_update(Z(0, j), Z(E1[k][0], j + E1[k][1]), Z(E2[k][0], j + E2[k][1]), d1, d2, th, k,
+                         &mag[j], &dir[j]);
+    }
+    /* bottom edge (:1836-1847) */
+    for (int q = 0; q < 4; q++) {
+        int k = BOT[q];
+        double d1, d2, th;
+        spacing_fixed(dX, dY, k, n - 2, &d1, &d2, &th);
+        for (int64_t j = 1; j < m - 1; j++)
+            facet_update(Z(n - 1, j), Z(n - 1 + E1[k][0], j + E1[k][1]), Z(n - 1 + E2[k][0], j + E2[k][1]),
+                         d1, d2, th, k, &mag[(n - 1) * m + j], &dir[(n - 1) * m + j]);
+    }
+    /* corners (:1849-1899): TL facets 6,7 'top'; TR 4,5 'top'; BL 0,1 'bot'; BR 2,3 'bot' */
+    {
+        static const int CK[4][2] = {{6, 7}, {4, 5}, {0, 1}, {2, 3}};
+        int64_t ci[4] = {0, 0, n - 1, n - 1}, cj[4] = {0, m - 1, 0, m - 1};
+        int64_t sidx[4] = {0, 0, n - 2, n - 2};
+        for (int cc = 0; cc < 4; cc++)
+            for (int q = 0; q < 2; q++) {
+                int k = CK[cc][q];
+                double d1, d2, th;
+                spacing_fixed(dX, dY, k, sidx[cc], &d1, &d2, &th);
+                int64_t i = ci[cc], j = cj[cc];
+                facet_update(Z(i, j), Z(i + E1[k][0], j + E1[k][1]), Z(i + E2[k][0], j + E2[k][1]),
+                             d1, d2, th, k, &mag[i * m + j], &dir[i * m + j]);
+            }
+    }
+    for (int64_t c = 0; c < NN; c++)
+        if (mag[c] > 0) mag[c] = sqrt(mag[c]);    /* :1901 */
+    free(TH);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * 8-neighbour helper: utils.get_adjacent_index (utils.py:270-311) for one cell.
+ * Order of the reference's concatenation is irrelevant to its users (they use it as a set).
+ * ---------------------------------------------------------------------------------------- */
+static int adjacent8(int64_t c, int64_t n, int64_t m, int64_t *out)
+{
+    int64_t i = c / m, j = c % m;
+    int cnt = 0;
+    for (int di = -1; di <= 1; di++)
+        for (int dj = -1; dj <= 1; dj++) {
+            if (!di && !dj) continue;
+            int64_t ii = i + di, jj = j + dj;
+            if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+            out[cnt++] = ii * m + jj;
+        }
+    return cnt;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A2  _find_flats_edges (dem_processing.py:657-680) + epilogue of calc_slopes_directions
+ * (:610-613).  scipy.ndimage.label numbering = raster order of each region's first cell,
+ * reproduced by flood-filling from unlabeled cells in raster order.  Regions are processed
+ * in label order and later regions overwrite earlier marks (f[J] = ... at :677).
+ * On return flats[] holds the extended mask and mag/dir are set to -1 there.
+ * ---------------------------------------------------------------------------------------- */
+int oracle_flats_edges(const double *elev, double *mag, double *dir, int64_t n, int64_t m, uint8_t *flats)
+{
+    int64_t NN = n * m;
+    uint8_t *flat0 = (uint8_t *)malloc(NN);
+    uint8_t *seen = (uint8_t *)calloc(NN, 1);
+    int64_t *stack = (int64_t *)malloc(NN * sizeof(int64_t));
+    int64_t *region = (int64_t *)malloc(NN * sizeof(int64_t));
+    if (!flat0 || !seen || !stack || !region) return -1;
+    for (int64_t c = 0; c < NN; c++) { flat0[c] = (mag[c] == -1); flats[c] = flat0[c]; }  /* :667, :671 */
+    for (int64_t c0 = 0; c0 < NN; c0++) {
+        if (!flat0[c0] || seen[c0]) continue;
+        int64_t nr = 0, sp = 0;
+        stack[sp++] = c0;
+        seen[c0] = 1;
+        while (sp) {
+            int64_t c = stack[--sp];
+            region[nr++] = c;
+            int64_t nb[8];
+            int k = adjacent8(c, n, m, nb);
+            for (int q = 0; q < k; q++)
+                if (flat0[nb[q]] && !seen[nb[q]]) { seen[nb[q]] = 1; stack[sp++] = nb[q]; }
+        }
+        /* I[0] is the raster-first cell of the region == c0 (:675, :677) */
+        double e0 = elev[c0];
+        for (int64_t q = 0; q < nr; q++) {
+            int64_t nb[8];
+            int k = adjacent8(region[q], n, m, nb);
+            for (int t = 0; t < k; t++) flats[nb[t]] = (elev[nb[t]] == e0);
+        }
+    }
+    for (int64_t c = 0; c < NN; c++)
+        if (flats[c]) { dir[c] = -1; mag[c] = -1; }   /* :611-612 */
+    free(flat0); free(seen); free(stack); free(region);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A3  _calc_uca_section_proportion (dem_processing.py:1021-1070)
+ * theta per row: facet-0 spacing of rows 1..n-2 with first/last duplicated (:1031-1033).
+ * ---------------------------------------------------------------------------------------- */
+static double section_theta_row(const double *dX, const double *dY, int64_t n, int64_t i)
+{
+    /* theta array has n-2 entries t[r] = atan2(dY[r], dX[r]), r = 0..n-3; row i uses
+     * t[clamp(i-1, 0, n-3)] when dX.size > 1 (:1032-1033); with dX.size == 1 (n == 2) it is
+     * the single value (not supported here: n >= 3). */
+    int64_t r = i - 1;
+    if (r < 0) r = 0;
+    if (r > n - 3) r = n - 3;
+    return atan2(dY[r], dX[r]);
+}
+
+int oracle_section_proportion(const double *dir, const uint8_t *flats, int64_t n, int64_t m,
+                              const double *dX, const double *dY,
+                              int8_t *section, double *proportion)
+{
+    static const int adjust[8] = {1, -1, 1, -1, 1, -1, 1, -1};  /* ang_adj[:,1] :1029 */
+    if (n < 3) return -1;
+    for (int64_t i = 0; i < n; i++) {
+        double theta = section_theta_row(dX, dY, n, i);
+        for (int64_t j = 0; j < m; j++) {
+            int64_t c = i * m + j;
+            double d = dir[c];
+            int sec0 = (int)(int8_t)floor(d / M_PI * 2.0);              /* :1035 */
+            double quadrant = d - M_PI / 2.0 * (double)sec0;             /* :1037 */
+            int mod2 = ((sec0 % 2) + 2) % 2;                             /* python modulo */
+            int sec = sec0 * 2 + ((quadrant > theta) && (mod2 == 0))
+                      + ((quadrant > (M_PI / 2 - theta)) && (mod2 == 1)); /* :1040-1043 */
+            sec = (int)(int8_t)sec;
+            double p = NAN;
+            int I1 = (sec == 0) || (sec == 1) || (sec == 4) || (sec == 5);  /* :1050 */
+            if (I1 && quadrant <= theta) p = quadrant / theta;               /* :1052-1053 */
+            if (I1 && quadrant > theta) p = (quadrant - theta) / (M_PI / 2 - theta);  /* :1054-1056 */
+            if (!I1 && quadrant <= (M_PI / 2 - theta)) p = quadrant / (M_PI / 2 - theta); /* :1057-1059 */
+            if (!I1 && quadrant > (M_PI / 2 - theta)) p = (quadrant - (M_PI / 2 - theta)) / theta; /* :1060-1062 */
+            if (flats[c]) { sec = -1; p = NAN; }                         /* :1064-1065 */
+            if (sec == 8) sec = 0;                                       /* :1067 */
+            int a = adjust[((sec % 8) + 8) % 8];                         /* numpy negative index wrap */
+            proportion[c] = (1 + a) / 2.0 - (double)a * p;               /* :1068 */
+            section[c] = (int8_t)sec;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A5  _mk_connectivity_pits (dem_processing.py:1269-1382), with utils.get_border_index
+ * (utils.py:313-340) and _get_dX_mean (:1993-1997).
+ * Pits are visited in ascending elevation (np.argsort :1286; ties: the reference's order is
+ * implementation-defined, here ascending index -- per-pit results are independent of the
+ * visiting order, only the order of the output triplets depends on it).
+ * Output triplets are malloc'ed; release with oracle_free.  mag/flats are patched in place
+ * (:1369-1371).  Returns number of triplets, or <0 on error.  *n_warn = pits without drain.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { double e; int64_t idx; } esort_t;
+static int esort_cmp(const void *a, const void *b)
+{
+    const esort_t *x = (const esort_t *)a, *y = (const esort_t *)b;
+    if (x->e < y->e) return -1;
+    if (x->e > y->e) return 1;
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+static int i64_cmp(const void *a, const void *b)
+{
+    int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+    return (x > y) - (x < y);
+}
+
+static double dX_mean(const double *dX, int64_t ndX, int64_t i1, int64_t i2)
+{
+    if (i1 == i2) return dX[i1 < ndX - 1 ? i1 : ndX - 1];            /* :1994-1995 */
+    int64_t a = i1 < i2 ? i1 : i2, b = i1 < i2 ? i2 : i1;            /* make_slice utils.py:404 */
+    if (b > ndX) b = ndX;
+    if (a > ndX) a = ndX;
+    return np_pairwise_sum(dX + a, b - a) / (double)(b - a);          /* .mean() :1997 */
+}
+
+int64_t oracle_pit_edges(const double *elev, uint8_t *flats, double *mag, int64_t n, int64_t m,
+                         const double *dX, const double *dY,
+                         int64_t max_iter, int64_t max_dist, double max_dist_XY, int min_border,
+                         int64_t **out_i, int64_t **out_j, double **out_prop, int64_t *n_warn)
+{
+    int64_t NN = n * m, ndX = n - 1;
+    uint8_t *pits_bool = (uint8_t *)malloc(NN);
+    int64_t npits = 0;
+    for (int64_t c = 0; c < NN; c++) { pits_bool[c] = flats[c] && (elev[c] > 0); npits += pits_bool[c]; } /* :1284 */
+    esort_t *order = (esort_t *)malloc((npits + 1) * sizeof(esort_t));
+    int64_t q = 0;
+    for (int64_t c = 0; c < NN; c++) if (pits_bool[c]) { order[q].e = elev[c]; order[q].idx = c; q++; }
+    qsort(order, npits, sizeof(esort_t), esort_cmp);                 /* :1286 */
+
+    /* stamp[c] == 2*pitno+1: in pit_area; == 2*pitno+2: in border */
+    int64_t *stamp = (int64_t *)calloc(NN, sizeof(int64_t));
+    int64_t cap_b = 1024, cap_o = 1024, nout = 0;
+    int64_t *border = (int64_t *)malloc(cap_b * sizeof(int64_t));
+    int64_t *newc = (int64_t *)malloc(cap_b * sizeof(int64_t));
+    int64_t *oi = (int64_t *)malloc(cap_o * sizeof(int64_t));
+    int64_t *oj = (int64_t *)malloc(cap_o * sizeof(int64_t));
+    double *op = (double *)malloc(cap_o * sizeof(double));
+    int64_t cap_d = 1024;
+    int64_t *drain = (int64_t *)malloc(cap_d * sizeof(int64_t));
+    double *dxy = (double *)malloc(cap_d * sizeof(double));
+    double *s = (double *)malloc(cap_d * sizeof(double));
+    int64_t warn = 0;
+
+    for (int64_t pn = 0; pn < npits; pn++) {
+        int64_t pit = order[pn].idx;
+        int64_t st_area = 2 * pn + 1, st_border = 2 * pn + 2;
+        double epit = elev[pit];
+        int64_t nb = 0, ndrain = -1;
+        /* pit_area = [pit]; border = get_border_index(pit_area) (:1289-1292) */
+        stamp[pit] = st_area;
+        {
+            int64_t a8[8];
+            int k = adjacent8(pit, n, m, a8);
+            for (int t = 0; t < k; t++) { stamp[a8[t]] = st_border; border[nb++] = a8[t]; }
+        }
+        double epit_border = epit;
+        if (min_border) {                                           /* :1294-1295 */
+            epit_border = INFINITY;
+            for (int64_t t = 0; t < nb; t++) if (elev[border[t]] < epit_border) epit_border = elev[border[t]];
+        }
+        for (int64_t it = 0; it < max_iter; it++) {                  /* :1300 */
+            if (nb == 0) break;                                      /* :1304-1305 */
+            qsort(border, nb, sizeof(int64_t), i64_cmp);             /* setdiff1d is sorted */
+            double emin = INFINITY, emin_np = INFINITY, emin_p = INFINITY;
+            int has_np = 0, has_p = 0;
+            for (int64_t t = 0; t < nb; t++) {
+                double e = elev[border[t]];
+                if (e < emin) emin = e;
+                if (pits_bool[border[t]]) { has_p = 1; if (e < emin_p) emin_p = e; }
+                else { has_np = 1; if (e < emin_np) emin_np = e; }
+            }
+            if (has_np && emin_np < epit_border) {                   /* :1312-1316 */
+                ndrain = 0;
+                for (int64_t t = 0; t < nb; t++)
+                    if (!pits_bool[border[t]] && elev[border[t]] < epit_border) {
+                        if (ndrain >= cap_d) { cap_d *= 2; drain = realloc(drain, cap_d * 8); dxy = realloc(dxy, cap_d * 8); s = realloc(s, cap_d * 8); }
+                        drain[ndrain++] = border[t];
+                    }
+                break;
+            }
+            if (has_p && emin_p < epit) {                            /* :1317-1320 */
+                ndrain = 0;
+                for (int64_t t = 0; t < nb; t++)
+                    if (pits_bool[border[t]] && elev[border[t]] < epit) {
+                        if (ndrain >= cap_d) { cap_d *= 2; drain = realloc(drain, cap_d * 8); dxy = realloc(dxy, cap_d * 8); s = realloc(s, cap_d * 8); }
+                        drain[ndrain++] = border[t];
+                    }
+                break;
+            }
+            /* grow: pit_area += border[eborder == emin] (:1322-1323) */
+            int64_t nnew = 0, keep = 0;
+            for (int64_t t = 0; t < nb; t++) {
+                if (elev[border[t]] == emin) { newc[nnew++] = border[t]; stamp[border[t]] = st_area; }
+                else border[keep++] = border[t];
+            }
+            nb = keep;
+            if (nnew == 0) break;  /* NaN elevations: nothing equals emin; the reference would spin to max_iter */
+            for (int64_t t = 0; t < nnew; t++) {
+                int64_t a8[8];
+                int k = adjacent8(newc[t], n, m, a8);
+                for (int u = 0; u < k; u++) {
+                    int64_t c = a8[u];
+                    if (stamp[c] == st_area || stamp[c] == st_border) continue;
+                    stamp[c] = st_border;
+                    if (nb + 8 >= cap_b) { cap_b *= 2; border = realloc(border, cap_b * 8); newc = realloc(newc, cap_b * 8); }
+                    border[nb++] = c;
+                }
+            }
+        }
+        if (ndrain < 0) { warn++; continue; }                        /* :1327-1329 */
+        int64_t ipit = pit / m, jpit = pit % m;                      /* :1331 */
+        if (max_dist) {                                              /* :1335-1343 */
+            int64_t keep = 0;
+            for (int64_t t = 0; t < ndrain; t++) {
+                int64_t di = ipit - drain[t] / m, dj = jpit - drain[t] % m;
+                double dij = sqrt((double)(di * di + dj * dj));
+                if (dij <= (double)max_dist) drain[keep++] = drain[t];
+            }
+            if (!keep) { warn++; continue; }
+            ndrain = keep;
+        }
+        for (int64_t t = 0; t < ndrain; t++) {                       /* :1346-1349 */
+            int64_t idr = drain[t] / m, jdr = drain[t] % m;
+            double dx = dX_mean(dX, ndX, ipit, idr) * (double)(jpit - jdr);
+            int64_t a = ipit < idr ? ipit : idr, b = ipit < idr ? idr : ipit;
+            double dy = np_pairwise_sum(dY + a, b - a);
+            dxy[t] = sqrt(dx * dx + dy * dy);
+        }
+        if (!isnan(max_dist_XY) && max_dist_XY != 0) {               /* :1352-1358 */
+            int64_t keep = 0;
+            for (int64_t t = 0; t < ndrain; t++)
+                if (dxy[t] <= max_dist_XY) { drain[keep] = drain[t]; dxy[keep] = dxy[t]; keep++; }
+            if (!keep) { warn++; continue; }
+            ndrain = keep;
+        }
+        for (int64_t t = 0; t < ndrain; t++) s[t] = fabs(elev[pit] - elev[drain[t]]) / dxy[t];  /* :1361 */
+        double ssum = np_pairwise_sum(s, ndrain);
+        if (nout + ndrain >= cap_o) {
+            while (nout + ndrain >= cap_o) cap_o *= 2;
+            oi = realloc(oi, cap_o * 8); oj = realloc(oj, cap_o * 8); op = realloc(op, cap_o * 8);
+        }
+        for (int64_t t = 0; t < ndrain; t++) {                       /* :1365-1367 */
+            oi[nout] = pit; oj[nout] = drain[t]; op[nout] = s[t] / ssum; nout++;
+        }
+        mag[pit] = ssum / (double)ndrain;                            /* np.mean :1370 */
+        flats[pit] = 0;                                              /* :1371 */
+    }
+    free(pits_bool); free(order); free(stamp); free(border); free(newc); free(drain); free(dxy); free(s);
+    *out_i = oi; *out_j = oj; *out_prop = op;
+    if (n_warn) *n_warn = warn;
+    return nout;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A4  _mk_adjacency_matrix (dem_processing.py:1072-1153) + _mk_connectivity (:1155-1267).
+ * Builds the CSC matrix (col = from cell, row = to cell) exactly as scipy would: entries
+ * grouped by column, rows ascending.  The tile-edge rules of _mk_connectivity (which facets
+ * assign j1/j2 on each edge/corner) reduce to "target must be inside the tile": verified
+ * facet by facet against :1183-1265 (every facet omitted there has its target outside).
+ * Arrays are malloc'ed; release with oracle_free.  Returns nnz or <0.
+ * ---------------------------------------------------------------------------------------- */
+int64_t oracle_adjacency(const int8_t *section, const double *proportion, const double *elev,
+                         int64_t n, int64_t m,
+                         const int64_t *pit_i, const int64_t *pit_j, const double *pit_prop, int64_t npit,
+                         int32_t **out_indptr, int32_t **out_indices, double **out_data)
+{
+    int64_t NN = n * m;
+    if (NN >= INT32_MAX) return -2;
+    int64_t *j1 = (int64_t *)malloc(NN * 8), *j2 = (int64_t *)malloc(NN * 8);
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < m; j++) {
+            int64_t c = i * m + j;
+            j1[c] = j2[c] = -1;                                       /* :1085-1086 */
+            int k = section[c];
+            if (k < 0 || k > 7) continue;
+            int64_t i1 = i + E1[k][0], c1 = j + E1[k][1], i2 = i + E2[k][0], c2 = j + E2[k][1];
+            if (i1 >= 0 && i1 < n && c1 >= 0 && c1 < m) j1[c] = i1 * m + c1;
+            if (i2 >= 0 && i2 < n && c2 >= 0 && c2 < m) j2[c] = i2 * m + c2;
+        }
+    for (int64_t t = 0; t < npit; t++) { j1[pit_i[t]] = -1; j2[pit_i[t]] = -1; }  /* :1099-1100 */
+
+    int32_t *indptr = (int32_t *)calloc(NN + 1, sizeof(int32_t));
+    /* pass 1: count per column; filter :1136-1137 */
+#define KEEP(w, jj, ii) (!isnan(w) && (jj) != -1 && (w) > 1e-8 && (elev[jj] <= elev[ii]))
+    for (int64_t c = 0; c < NN; c++) {
+        double w1 = proportion[c], w2 = 1 - proportion[c];           /* :1082 */
+        if (KEEP(w1, j1[c], c)) indptr[c + 1]++;
+        if (KEEP(w2, j2[c], c)) indptr[c + 1]++;
+    }
+    for (int64_t t = 0; t < npit; t++)
+        if (KEEP(pit_prop[t], pit_j[t], pit_i[t])) indptr[pit_i[t] + 1]++;
+    for (int64_t c = 0; c < NN; c++) indptr[c + 1] += indptr[c];
+    int64_t nnz = indptr[NN];
+    int32_t *indices = (int32_t *)malloc((nnz + 1) * sizeof(int32_t));
+    double *data = (double *)malloc((nnz + 1) * sizeof(double));
+    int32_t *fill = (int32_t *)malloc((NN + 1) * sizeof(int32_t));
+    memcpy(fill, indptr, (NN + 1) * sizeof(int32_t));
+    for (int64_t c = 0; c < NN; c++) {
+        double w1 = proportion[c], w2 = 1 - proportion[c];
+        if (KEEP(w1, j1[c], c)) { indices[fill[c]] = (int32_t)j1[c]; data[fill[c]++] = w1; }
+        if (KEEP(w2, j2[c], c)) { indices[fill[c]] = (int32_t)j2[c]; data[fill[c]++] = w2; }
+    }
+    for (int64_t t = 0; t < npit; t++)
+        if (KEEP(pit_prop[t], pit_j[t], pit_i[t])) {
+            int64_t c = pit_i[t];
+            indices[fill[c]] = (int32_t)pit_j[t]; data[fill[c]++] = pit_prop[t];
+        }
+#undef KEEP
+    /* sort rows within each column, sum duplicates (scipy sum_duplicates) */
+    int64_t w = 0;
+    int32_t *newptr = (int32_t *)calloc(NN + 1, sizeof(int32_t));
+    for (int64_t c = 0; c < NN; c++) {
+        int32_t a = indptr[c], b = indptr[c + 1];
+        for (int32_t x = a + 1; x < b; x++) {          /* insertion sort */
+            int32_t ri = indices[x]; double rd = data[x]; int32_t y = x - 1;
+            while (y >= a && indices[y] > ri) { indices[y + 1] = indices[y]; data[y + 1] = data[y]; y--; }
+            indices[y + 1] = ri; data[y + 1] = rd;
+        }
+        int64_t start = w;
+        for (int32_t x = a; x < b; x++) {
+            if (w > start && indices[w - 1] == indices[x]) data[w - 1] += data[x];
+            else { indices[w] = indices[x]; data[w] = data[x]; w++; }
+        }
+        newptr[c + 1] = (int32_t)w;
+    }
+    free(indptr); free(fill); free(j1); free(j2);
+    *out_indptr = newptr; *out_indices = indices; *out_data = data;
+    return w;
+}
+
+/* CSC -> CSR index structure (A.tocsr(), dem_processing.py:879): for each row (target cell),
+ * the source cells in ascending order. */
+int oracle_tocsr(const int32_t *col_indptr, const int32_t *col_indices, int64_t NN,
+                 int32_t *row_indptr, int32_t *row_indices)
+{
+    int64_t nnz = col_indptr[NN];
+    memset(row_indptr, 0, (NN + 1) * sizeof(int32_t));
+    for (int64_t k = 0; k < nnz; k++) row_indptr[col_indices[k] + 1]++;
+    for (int64_t c = 0; c < NN; c++) row_indptr[c + 1] += row_indptr[c];
+    int32_t *fill = (int32_t *)malloc((NN + 1) * sizeof(int32_t));
+    memcpy(fill, row_indptr, (NN + 1) * sizeof(int32_t));
+    for (int64_t c = 0; c < NN; c++)
+        for (int32_t k = col_indptr[c]; k < col_indptr[c + 1]; k++)
+            row_indices[fill[col_indices[k]]++] = (int32_t)c;
+    free(fill);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A7  cyutils._drain_area (cyutils.pyx:119-187) and helpers (:193-226).
+ * edge_todo / edge_todo_no_mask may be NULL (do_edge_todo = 0).
+ * Returns the number of level-synchronous rounds executed.
+ * ---------------------------------------------------------------------------------------- */
+static int on_edge(int64_t id, int64_t n_rows, int64_t n_cols)
+{
+    if (id < n_cols) return 1;
+    if (id >= n_cols * n_rows - n_cols) return 1;
+    if (id % n_cols == 0) return 1;
+    if (id % n_cols == n_cols - 1) return 1;
+    return 0;
+}
+
+int64_t oracle_drain_area(double *area, uint8_t *done, uint8_t *ids,
+                          const int32_t *col_indptr, const int32_t *col_indices, const double *col_data,
+                          const int32_t *row_indptr, const int32_t *row_indices,
+                          int64_t n_rows, int64_t n_cols,
+                          double *edge_todo, double *edge_todo_no_mask, int skip_edge)
+{
+    int64_t N = n_rows * n_cols, rounds = 0;
+    uint8_t *buf = (uint8_t *)calloc(N, 1);
+    uint8_t *cur = ids, *old = buf;
+    int keep_going = 1;
+    while (keep_going) {
+        for (int64_t i = 0; i < N; i++) if (cur[i]) done[i] = 1;         /* :138-140 */
+        uint8_t *tmp = old; old = cur; cur = tmp;                        /* :144-146 */
+        memset(cur, 0, N);                                               /* :149 */
+        for (int64_t i = 0; i < N; i++) {
+            if (!old[i]) continue;
+            for (int32_t j = col_indptr[i]; j < col_indptr[i + 1]; j++) {
+                int64_t row = col_indices[j];
+                double factor = col_data[j];
+                if ((skip_edge || done[row]) && on_edge(row, n_rows, n_cols)) continue;  /* :159-161 */
+                area[row] += area[i] * factor;                            /* :163 */
+                if (edge_todo) edge_todo[row] += edge_todo[i] * factor;
+                if (edge_todo_no_mask) edge_todo_no_mask[row] += edge_todo_no_mask[i] * factor;
+                int wait = 0;
+                for (int32_t k = row_indptr[row]; k < row_indptr[row + 1]; k++)
+                    if (done[row_indices[k]] < 1) { wait = 1; break; }    /* :173-179 */
+                if (!wait) cur[row] = 1;
+                if (edge_todo) done[i] = 1;
+            }
+        }
+        keep_going = memcmp(cur, old, N) != 0;                            /* :187, :193-200 */
+        rounds++;
+    }
+    /* the Cython routine leaves the final frontier in whichever buffer `ids` ended on; the
+     * callers overwrite ids afterwards (dem_processing.py:962), so only area/done matter */
+    if (cur != ids) memcpy(ids, cur, N);
+    free(buf);
+    return rounds;
+}
+
+/* A8  cyutils._drain_connections (cyutils.pyx:49-72) */
+int64_t oracle_drain_connections(uint8_t *arr, uint8_t *ids, const int32_t *indptr, const int32_t *indices,
+                                 int64_t N, uint8_t set_to)
+{
+    uint8_t *buf = (uint8_t *)calloc(N, 1);
+    uint8_t *cur = ids, *old = buf;
+    int keep_going = 1;
+    int64_t rounds = 0;
+    while (keep_going) {
+        uint8_t *tmp = old; old = cur; cur = tmp;
+        memset(cur, 0, N);
+        for (int64_t i = 0; i < N; i++) {
+            if (!old[i]) continue;
+            for (int32_t j = indptr[i]; j < indptr[i + 1]; j++) {
+                int64_t row = indices[j];
+                cur[row] += arr[row] != set_to;                           /* :69 */
+                arr[row] = set_to;                                        /* :70 */
+            }
+        }
+        keep_going = memcmp(cur, old, N) != 0;
+        rounds++;
+    }
+    if (cur != ids) memcpy(ids, cur, N);
+    free(buf);
+    return rounds;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A6  _calc_uca_chunk (dem_processing.py:864-987) given the adjacency of A4.
+ * Outputs: uca[NN] (NaN on flats), edge_todo_i[NN] (initial inlet edges, :937),
+ * edge_done[NN] (:974-980).  stats[0] = drain_area calls, stats[1] = total rounds,
+ * stats[2] = cells not done at exit, stats[3] = min_area (twi_min_area candidate :898).
+ * ---------------------------------------------------------------------------------------- */
+static int isin4(int v, int a, int b, int c, int d) { return v == a || v == b || v == c || v == d; }
+
+int oracle_uca_chunk(const double *elev, const int8_t *section, const uint8_t *flats,
+                     int64_t n, int64_t m, const double *dX2, const double *dY2,
+                     const int32_t *A_indptr, const int32_t *A_indices, const double *A_data,
+                     int64_t circular_ref_maxcount, int apply_uca_limit_edges, double uca_saturation_limit,
+                     double *uca, uint8_t *edge_todo_i, uint8_t *edge_done, double *stats)
+{
+    int64_t NN = n * m, nnz = A_indptr[NN];
+    int32_t *B_indptr = (int32_t *)malloc((NN + 1) * sizeof(int32_t));
+    int32_t *B_indices = (int32_t *)malloc((nnz + 1) * sizeof(int32_t));
+    oracle_tocsr(A_indptr, A_indices, NN, B_indptr, B_indices);          /* :879 */
+    double *insum = (double *)calloc(NN, sizeof(double));                 /* A.sum(1) :882 */
+    for (int64_t c = 0; c < NN; c++)
+        for (int32_t k = A_indptr[c]; k < A_indptr[c + 1]; k++) insum[A_indices[k]] += A_data[k];
+    uint8_t *ids = (uint8_t *)malloc(NN), *done = (uint8_t *)malloc(NN);
+    for (int64_t c = 0; c < NN; c++) { ids[c] = (insum[c] == 0); done[c] = ids[c]; }   /* :883, :903-904 */
+    double *area = uca;
+    double min_area = INFINITY;
+    for (int64_t i = 0; i < n; i++) {
+        double a = dX2[i] * dY2[i];                                        /* :885 */
+        if (a < min_area) min_area = a;                                    /* nanmin :898 */
+        for (int64_t j = 0; j < m; j++) area[i * m + j] = a;               /* :901 */
+    }
+#define OUTSUM(c) ({ double s_ = 0; for (int32_t k_ = A_indptr[c]; k_ < A_indptr[(c) + 1]; k_++) s_ += A_data[k_]; s_; })
+    const double TOL = 1e-2;                                               /* :911 */
+    uint8_t *todo = (uint8_t *)calloc(NN, 1);
+    for (int64_t i = 0; i < n; i++) {                                      /* left :913, right :915 */
+        int64_t c = i * m;
+        todo[c] = (OUTSUM(c) > TOL) && isin4(section[c], 6, 7, 0, 1);
+    }
+    for (int64_t i = 0; i < n; i++) {
+        int64_t c = i * m + m - 1;
+        todo[c] = (OUTSUM(c) > TOL) && isin4(section[c], 2, 3, 4, 5);
+    }
+    for (int64_t j = 0; j < m; j++) {                                      /* top :917 */
+        int64_t c = j;
+        todo[c] = (OUTSUM(c) > TOL) && isin4(section[c], 4, 5, 6, 7);
+    }
+    for (int64_t j = 0; j < m; j++) {                                      /* bottom :919 */
+        int64_t c = (n - 1) * m + j;
+        todo[c] = (OUTSUM(c) > TOL) && isin4(section[c], 0, 1, 2, 3);
+    }
+    {
+        int64_t corners[4] = {0, m - 1, (n - 1) * m, (n - 1) * m + m - 1};   /* :924-930 */
+        for (int q = 0; q < 4; q++) {
+            int64_t c = corners[q];
+            todo[c] |= (OUTSUM(c) > TOL) || (insum[c] < TOL);
+        }
+    }
+#undef OUTSUM
+    double *et = (double *)malloc(NN * sizeof(double)), *etnm = (double *)malloc(NN * sizeof(double));
+    for (int64_t c = 0; c < NN; c++) {
+        etnm[c] = todo[c];                                                  /* :933-934, :945 */
+        if (isnan(elev[c])) todo[c] = 0;                                    /* :935 */
+        edge_todo_i[c] = todo[c];                                           /* :937 */
+        et[c] = todo[c];                                                    /* :944 */
+    }
+    int64_t count = 1, done_sum = 0, calls = 0, rounds = 0;                 /* :939-950 */
+    for (;;) {
+        int64_t ds = 0, any_undone = 0;
+        for (int64_t c = 0; c < NN; c++) { ds += done[c]; any_undone |= !done[c]; }
+        if (!(any_undone && count < circular_ref_maxcount && done_sum != ds)) break;   /* :951-952 */
+        done_sum = ds;
+        count++;
+        rounds += oracle_drain_area(area, done, ids, A_indptr, A_indices, A_data, B_indptr, B_indices,
+                                    n, m, et, etnm, 0);                     /* :956-960 */
+        calls++;
+        memset(ids, 0, NN);                                                 /* :962 */
+        double max_elev = -INFINITY;
+        for (int64_t c = 0; c < NN; c++) {                                  /* :963 (max propagates NaN) */
+            double v = elev[c] * (double)(!done[c]);
+            if (isnan(v)) { max_elev = NAN; break; }
+            if (v > max_elev) max_elev = v;
+        }
+        for (int64_t c = 0; c < NN; c++) {
+            double v = elev[c] * (double)(!done[c]);
+            if ((v - max_elev) / max_elev > -0.01) ids[c] = 1;              /* :964 */
+        }
+    }
+    int64_t undone = 0;
+    for (int64_t c = 0; c < NN; c++) undone += !done[c];
+    for (int64_t c = 0; c < NN; c++) {
+        uint8_t t = (et[c] != 0);                                           /* astype(bool) :969 */
+        if (flats[c]) area[c] = NAN;                                        /* :972 */
+        edge_done[c] = !t;                                                  /* :974 */
+        if (isnan(elev[c])) edge_done[c] = 1;                               /* :975 */
+        if (apply_uca_limit_edges && area[c] > uca_saturation_limit * 2 * min_area) edge_done[c] = 1; /* :977-980 */
+    }
+    if (stats) { stats[0] = (double)calls; stats[1] = (double)rounds; stats[2] = (double)undone; stats[3] = min_area; }
+    free(B_indptr); free(B_indices); free(insum); free(ids); free(done); free(todo); free(et); free(etnm);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A9  calc_uca(uca_init=..., edge_init_data=...) (dem_processing.py:720-740, 757-771) +
+ * _calc_uca_chunk_update (:778-862), given the adjacency.
+ * Strips: for side s in {left,right,top,bottom} the caller passes data/done/todo vectors
+ * (length n for left/right, m for top/bottom).  uca[] holds uca_init on entry and
+ * uca_init + delta on exit (self.uca += area :769); edge_todo_out = e2doi (:770, = todo & ~done
+ * as seeded), edge_done_out (:771, :856).
+ * ---------------------------------------------------------------------------------------- */
+int oracle_uca_update(const double *elev, const uint8_t *flats, int64_t n, int64_t m,
+                      const int32_t *A_indptr, const int32_t *A_indices, const double *A_data,
+                      const double *const strip_data[4], const uint8_t *const strip_done[4],
+                      const uint8_t *const strip_todo[4],
+                      double *uca, uint8_t *edge_todo_out, uint8_t *edge_done_out)
+{
+    int64_t NN = n * m, nnz = A_indptr[NN];
+    double *init = (double *)calloc(NN, sizeof(double));
+    uint8_t *e_done = (uint8_t *)calloc(NN, 1), *e_todo = (uint8_t *)calloc(NN, 1);
+    /* slices in dict order left, right, top, bottom (:726-737) */
+    for (int s = 0; s < 4; s++) {
+        int64_t len = (s < 2) ? n : m;
+        for (int64_t t = 0; t < len; t++) {
+            int64_t c = (s == 0) ? t * m : (s == 1) ? t * m + m - 1 : (s == 2) ? t : (n - 1) * m + t;
+            e_done[c] = e_done[c] | strip_done[s][t];
+            init[c] += strip_data[s][t] * (double)strip_done[s][t];
+            e_todo[c] = e_todo[c] | strip_todo[s][t];
+        }
+    }
+    for (int64_t c = 0; c < NN; c++) if (on_edge(c, n, m) && !e_done[c]) init[c] = 0;   /* :738-739 */
+
+    int32_t *C_indptr = (int32_t *)malloc((NN + 1) * sizeof(int32_t));
+    int32_t *C_indices = (int32_t *)malloc((nnz + 1) * sizeof(int32_t));
+    oracle_tocsr(A_indptr, A_indices, NN, C_indptr, C_indices);            /* :793 */
+    uint8_t *ids = (uint8_t *)malloc(NN), *ids0 = (uint8_t *)malloc(NN), *done = (uint8_t *)malloc(NN);
+    double *area = (double *)calloc(NN, sizeof(double));
+    for (int64_t c = 0; c < NN; c++) {
+        ids[c] = e_done[c] && e_todo[c];                                    /* :798 */
+        edge_todo_out[c] = e_todo[c] && !e_done[c];                          /* :799, :817 */
+    }
+    /* :806-809, order: left col, right col, bottom row, top row */
+    for (int64_t i = 0; i < n; i++) if (e_done[i * m]) area[i * m] = init[i * m] - uca[i * m];
+    for (int64_t i = 0; i < n; i++) { int64_t c = i * m + m - 1; if (e_done[c]) area[c] = init[c] - uca[c]; }
+    for (int64_t j = 0; j < m; j++) { int64_t c = (n - 1) * m + j; if (e_done[c]) area[c] = init[c] - uca[c]; }
+    for (int64_t j = 0; j < m; j++) { int64_t c = j; if (e_done[c]) area[c] = init[c] - uca[c]; }
+    memcpy(ids0, ids, NN);                                                   /* :813 */
+    for (int64_t c = 0; c < NN; c++) { if (flats[c]) area[c] = NAN; done[c] = !ids[c]; }  /* :815, :820-821 */
+    oracle_drain_connections(done, ids, A_indptr, A_indices, NN, 0);         /* :823-825 */
+    for (int64_t c = 0; c < NN; c++) {
+        if (isnan(elev[c])) done[c] = 1;                                     /* :827 */
+        if (ids0[c]) done[c] = 1;                                            /* :831 */
+    }
+    memcpy(ids, ids0, NN);                                                   /* :833 */
+    oracle_drain_area(area, done, ids, A_indptr, A_indices, A_data, C_indptr, C_indices, n, m, NULL, NULL, 0); /* :836-842 */
+    uint8_t *todo = (uint8_t *)malloc(NN);
+    for (int64_t c = 0; c < NN; c++) { todo[c] = edge_todo_out[c]; ids[c] = todo[c]; }   /* :848 */
+    oracle_drain_connections(todo, ids, A_indptr, A_indices, NN, 1);          /* :850-853 */
+    for (int64_t c = 0; c < NN; c++) {
+        if (flats[c]) area[c] = NAN;                                          /* :855 */
+        edge_done_out[c] = !todo[c];                                          /* :856 */
+        uca[c] += area[c];                                                    /* :769 */
+    }
+    free(init); free(e_done); free(e_todo); free(C_indptr); free(C_indices); free(ids); free(ids0);
+    free(done); free(area); free(todo);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A10  calc_twi (dem_processing.py:1647-1677).  Writes the un-scaled value (the function's
+ * return value :1677); the attribute self.twi is 10x that (:1674).
+ * ---------------------------------------------------------------------------------------- */
+int oracle_twi(const double *uca, const double *mag, int64_t NN, double twi_min_slope,
+               double twi_min_area, double uca_saturation_limit,
+               int apply_twi_limits, int apply_twi_limits_on_uca, double *twi)
+{
+    for (int64_t c = 0; c < NN; c++) {
+        double t = uca[c];
+        if (apply_twi_limits_on_uca && t > uca_saturation_limit * twi_min_area)
+            t = uca_saturation_limit * twi_min_area;                          /* :1663-1665 */
+        t = log(t / (mag[c] + twi_min_slope));                                /* :1667 */
+        if (apply_twi_limits) {
+            double sat = log(uca_saturation_limit * twi_min_area / twi_min_slope);  /* :1670-1672 */
+            if (t > sat) t = sat;
+        }
+        twi[c] = t;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Deterministic value-noise DEM (inputs only).  Mirrors pydem_amd/synth.py:fractal_unit op
+ * for op; the HIP generator (pydem_amd/csrc) is the third copy.  Not from the reference.
+ * ---------------------------------------------------------------------------------------- */
+static double hash01(uint32_t ix, uint32_t iy, uint32_t seed)
+{
+    uint32_t h = (ix * 0x9E3779B1u) ^ (iy * 0x85EBCA77u) ^ (seed * 0xC2B2AE3Du);
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return (double)h * 0x1p-32;
+}
+
+int oracle_synth_fractal(double *z, int64_t n, int64_t m, uint32_t seed, int64_t row0, int64_t col0,
+                         int n_octaves, int top_shift, double zmin, double zrange)
+{
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < m; j++) {
+            uint32_t gi = (uint32_t)(i + row0), gj = (uint32_t)(j + col0);
+            double acc = 0.0, amp = 1.0, norm = 0.0;
+            for (int o = 0; o < n_octaves; o++) {
+                int s = top_shift - o;
+                uint32_t mask = (1u << s) - 1u;
+                double inv = ldexp(1.0, -s);
+                uint32_t iy = gi >> s, ix = gj >> s;
+                double fy = (double)(gi & mask) * inv, fx = (double)(gj & mask) * inv;
+                double ty = (fy * fy) * (3.0 - 2.0 * fy), tx = (fx * fx) * (3.0 - 2.0 * fx);
+                uint32_t sd = (uint32_t)(((uint64_t)seed * 1000003u + (uint64_t)o) & 0xFFFFFFFFu);
+                double v00 = hash01(ix, iy, sd), v10 = hash01(ix + 1, iy, sd);
+                double v01 = hash01(ix, iy + 1, sd), v11 = hash01(ix + 1, iy + 1, sd);
+                double a = v00 + tx * (v10 - v00), b = v01 + tx * (v11 - v01);
+                double nse = a + ty * (b - a);
+                acc = acc + amp * nse;
+                norm = norm + amp;
+                amp = amp * 0.57;
+            }
+            z[i * m + j] = zmin + zrange * (acc / norm);
+        }
+    return 0;
+}

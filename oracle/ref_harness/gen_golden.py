@@ -1,0 +1,192 @@
+"""Generate golden vectors under tests/golden/ by running the UNMODIFIED reference
+(/root/reference, creare-com/pydem v1.2.1) on small deterministic inputs.
+
+Run in the build container only:   oracle/ref_harness/run.sh oracle/ref_harness/gen_golden.py
+Fixtures hold data only (inputs + the reference's outputs); no reference source.
+
+Every case records, for one DEMProcessor(elev=..., **kw).calc_twi() run of the reference
+(call stack: SURVEY.md section 3.1), the intermediate arrays at the boundaries the
+oracle/HIP path reproduce.
+"""
+import hashlib
+import os
+import sys
+import warnings
+
+from load_reference import load_reference
+pydem = load_reference()
+
+import numpy as np  # noqa: E402
+from pydem.dem_processing import DEMProcessor  # noqa: E402
+from pydem import dem_processing as refmod  # noqa: E402
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
+sys.path.insert(0, REPO)
+from pydem_amd import synth  # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+
+
+def run_case(elev, dX=None, dY=None, **kw):
+    """Run the reference end to end, capturing intermediates by wrapping its methods."""
+    rec = {}
+    kwargs = dict(kw)
+    if dX is not None:
+        kwargs['dX'] = dX
+    if dY is not None:
+        kwargs['dY'] = dY
+    dp = DEMProcessor(elev=elev.copy(), **kwargs)
+    rec['in_elev'] = elev.copy()
+    rec['in_dX'] = np.array(dp.dX, 'float64')
+    rec['in_dY'] = np.array(dp.dY, 'float64')
+    rec['in_dX2'] = np.array(dp.dX2, 'float64')
+    rec['in_dY2'] = np.array(dp.dY2, 'float64')
+
+    def wrap(name, post):
+        orig = getattr(dp, name)
+
+        def f(*a, **k):
+            r = orig(*a, **k)
+            post(r, a, k)
+            return r
+        # instance attribute shadows the class method
+        object.__setattr__(dp, name, f)
+
+    wrap('calc_fill_pit_artifacts', lambda r, a, k: rec.__setitem__('elev_artifacts', np.array(dp.elev).copy()))
+    wrap('calc_fill_flats', lambda r, a, k: rec.__setitem__('elev_filled', np.array(dp.elev).copy()))
+    wrap('calc_pit_drain_paths', lambda r, a, k: rec.__setitem__('elev_drained', np.array(dp.elev).copy()))
+
+    def post_sd(r, a, k):
+        rec['mag'] = r[0].copy()
+        rec['direction'] = r[1].copy()
+        rec['flats'] = dp.flats.copy()
+    wrap('calc_slopes_directions', post_sd)
+
+    def post_raw(r, a, k):
+        rec['mag_raw'] = r[0].copy()
+        rec['direction_raw'] = r[1].copy()
+    wrap('_slopes_directions', post_raw)
+
+    def post_sp(r, a, k):
+        rec['section'] = r[0].copy()
+        rec['proportion'] = r[1].copy()
+    wrap('_calc_uca_section_proportion', post_sp)
+
+    def post_pits(r, a, k):
+        rec['pit_i'], rec['pit_j'], rec['pit_prop'] = [np.array(x) for x in r[:3]]
+    wrap('_mk_connectivity_pits', post_pits)
+
+    def post_A(r, a, k):
+        A = r.copy()
+        A.sort_indices()
+        rec['A_indptr'] = A.indptr.copy()
+        rec['A_indices'] = A.indices.copy()
+        rec['A_data'] = A.data.copy()
+    wrap('_mk_adjacency_matrix', post_A)
+
+    calls = []
+    orig_da = refmod.cyutils.drain_area
+
+    class _Cy:
+        drain_connections = staticmethod(refmod.cyutils.drain_connections)
+
+        @staticmethod
+        def drain_area(*a, **k):
+            calls.append(1)
+            return orig_da(*a, **k)
+    saved = refmod.cyutils
+    refmod.cyutils = _Cy
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            twi = dp.calc_twi()
+    finally:
+        refmod.cyutils = saved
+    rec['n_drain_area_calls'] = np.int64(len(calls))
+    rec['elev_final'] = np.array(dp.elev).copy()
+    rec['mag_final'] = dp.mag.copy()
+    rec['flats_final'] = dp.flats.copy()
+    rec['uca'] = dp.uca.copy()
+    rec['edge_todo'] = dp.edge_todo.copy()
+    rec['edge_done'] = dp.edge_done.copy()
+    rec['twi_ret'] = twi.copy()
+    rec['twi_attr'] = dp.twi.copy()
+    rec['twi_min_area'] = np.float64(dp.twi_min_area)
+    return rec
+
+
+def save(name, rec, kw):
+    os.makedirs(OUT, exist_ok=True)
+    rec = dict(rec)
+    rec['kwargs_repr'] = np.array(repr(sorted(kw.items())))
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **rec)
+    print('%-34s %8.1f KiB  drain_area calls=%d' % (name, os.path.getsize(path) / 1024., int(rec['n_drain_area_calls'])))
+
+
+def read_tif32():
+    """Decode the reference test fixture pydem/test/test_NN032_033_elev.tif
+    (32x32 float64, uncompressed, single strip) with struct -- no rasterio."""
+    import struct
+    b = open('/root/reference/pydem/test/test_NN032_033_elev.tif', 'rb').read()
+    assert b[:2] == b'II'
+    off = struct.unpack('<I', b[4:8])[0]
+    n = struct.unpack('<H', b[off:off + 2])[0]
+    tags = {}
+    for k in range(n):
+        tag, typ, cnt, val = struct.unpack('<HHII', b[off + 2 + 12 * k: off + 14 + 12 * k])
+        tags[tag] = (typ, cnt, val)
+    w, h = tags[256][2], tags[257][2]
+    assert tags[258][2] == 64 and tags[259][2] == 1 and tags[339][2] == 3
+    strip = tags[273][2]
+    return np.frombuffer(b[strip:strip + w * h * 8], '<f8').reshape(h, w).copy()
+
+
+def main():
+    cases = []
+    # G1: the reference's own known-answer inputs (test_end_to_end.py:153-158, 221-226)
+    card = np.array([[1] * 5, [2] * 5, [3] * 5, [4] * 5, [5] * 5])
+    diag = np.add.outer(np.arange(5), np.arange(5)) + 1
+    for nm, e in (('g1_cardinal', card), ('g1_diagonal', diag)):
+        for sym, f in (('id', lambda a: a), ('rev', lambda a: a[::-1]), ('t', lambda a: a.T),
+                       ('trev', lambda a: a[::-1, ::-1].T)):
+            cases.append(('%s_%s' % (nm, sym), np.ascontiguousarray(f(e)), None, None, dict(fill_flats=False)))
+    # G2: cone
+    cases.append(('g2_cone64', synth.cone(64), None, None, dict(fill_flats=False)))
+    cases.append(('g2_cone64_nopit', synth.cone(64), None, None,
+                  dict(fill_flats=False, drain_pits=False, drain_pits_path=False)))
+    cases.append(('g2_conescaled32_dxy', synth.cone_scaled(32), 1.0, 1.0, dict(fill_flats=False)))
+    # G3: the reference's GeoTIFF fixture, decoded, dX=dY=1
+    cases.append(('g3_tif32', read_tif32(), 1.0, 1.0, dict(fill_flats=False)))
+    # G4: fractal fp64, several option sets; non-square pixels, varying per-row spacing
+    fr = synth.fractal(96, 128, seed=0, top_shift=6, n_octaves=6)
+    cases.append(('g4_fractal_nopits', fr, 30.0, 30.0,
+                  dict(fill_flats=False, drain_pits=False, drain_pits_path=False)))
+    cases.append(('g4_fractal_pits', fr, 30.0, 30.0, dict(fill_flats=False, drain_pits_path=False)))
+    cases.append(('g4_fractal_defaults_noff', fr, 30.0, 30.0, dict(fill_flats=False)))
+    n = 80
+    fr2 = synth.fractal(n, 72, seed=5, top_shift=5, n_octaves=5, zrange=300.0)
+    dXv = 25.0 + 0.05 * np.arange(n - 1)
+    dYv = 31.0 - 0.01 * np.arange(n - 1)
+    cases.append(('g4_fractal_varspacing', fr2, dXv, dYv, dict(fill_flats=False, drain_pits_path=False)))
+    # G5: int16 SRTM-like, all defaults (fill_flats=True)
+    sr = synth.srtm_int16(96, 96, seed=3, top_shift=6, n_octaves=6, zrange=400.0, lake_level=150)
+    cases.append(('g5_int16_defaults', sr, 30.0, 30.0, dict()))
+    cases.append(('g5_int16_noff_nopath', sr, 30.0, 30.0, dict(fill_flats=False, drain_pits_path=False)))
+    quant = np.rint(synth.fractal(64, 64, seed=9, top_shift=5, n_octaves=5, zrange=60.0)).astype(np.float64)
+    cases.append(('g5_quant_f64_pits', quant, 10.0, 10.0, dict(fill_flats=False, drain_pits_path=False)))
+
+    for name, elev, dX, dY, kw in cases:
+        rec = run_case(elev, dX, dY, **kw)
+        save(name, rec, kw)
+
+    # manifest with sha256 of every fixture
+    lines = []
+    for fn in sorted(os.listdir(OUT)):
+        if fn.endswith('.npz'):
+            lines.append('%s  %s' % (hashlib.sha256(open(os.path.join(OUT, fn), 'rb').read()).hexdigest(), fn))
+    open(os.path.join(OUT, 'SHA256SUMS'), 'w').write('\n'.join(lines) + '\n')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,83 @@
+"""The CPU oracle (oracle/pydem_oracle.c) against golden vectors captured from the unmodified
+reference (tests/golden/, generator: oracle/ref_harness/gen_golden.py).  CPU only.
+
+Bar: bit-exact for every array (integer, bool and float64) -- the oracle repeats the
+reference's operation order and libm calls.  The only relaxation is the ORDER of the pit->drain
+triplets when pits tie in elevation (np.argsort's tie order is implementation-defined,
+dem_processing.py:1286); the set of triplets must still be identical.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from oracle import oracle as O
+
+
+def _run(g):
+    kw = g['kwargs']
+    o = O.OracleDEM(g['elev_final'], dX=g['in_dX'], dY=g['in_dY'], dX2=g['in_dX2'], dY2=g['in_dY2'],
+                    drain_pits=kw.get('drain_pits', True))
+    o.calc_slopes_directions()
+    return o
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_oracle_matches_reference(name):
+    g = load_golden(name)
+    o = _run(g)
+    assert np.array_equal(o.mag_raw, g['mag_raw'])
+    assert np.array_equal(o.direction_raw, g['direction_raw'])
+    assert np.array_equal(o.mag, g['mag'])
+    assert np.array_equal(o.direction, g['direction'])
+    assert np.array_equal(o.flats.astype(bool), g['flats'])
+    o.calc_uca()
+    assert np.array_equal(o.section, g['section'])
+    assert np.array_equal(o.proportion, g['proportion'], equal_nan=True)
+    if 'pit_i' in g:
+        ref = sorted(zip(g['pit_i'].tolist(), g['pit_j'].tolist(), g['pit_prop'].tolist()))
+        mine = sorted(zip(o.pit_i.tolist(), o.pit_j.tolist(), o.pit_prop.tolist()))
+        assert ref == mine
+    for a, b in zip(o.A, (g['A_indptr'], g['A_indices'], g['A_data'])):
+        assert np.array_equal(a, b)
+    assert np.array_equal(o.mag, g['mag_final'])
+    assert np.array_equal(o.flats.astype(bool), g['flats_final'])
+    assert np.array_equal(o.uca, g['uca'], equal_nan=True)
+    assert np.array_equal(o.edge_todo, g['edge_todo'])
+    assert np.array_equal(o.edge_done, g['edge_done'])
+    t = o.calc_twi()
+    assert np.array_equal(t, g['twi_ret'], equal_nan=True)
+    assert np.array_equal(o.twi, g['twi_attr'], equal_nan=True)
+    assert o.twi_min_area == float(g['twi_min_area'])
+    assert o.stats[0] == int(g['n_drain_area_calls'])
+
+
+def test_reference_known_answers():
+    """The literal expected arrays of the reference's own tests
+    (pydem/test/test_end_to_end.py:164-182 and :232-251), to 6 decimals as there."""
+    nan = np.nan
+    card = np.array([[1] * 5, [2] * 5, [3] * 5, [4] * 5, [5] * 5], float)
+    o = O.OracleDEM(card); o.calc_twi()
+    h = np.pi / 2
+    np.testing.assert_array_almost_equal(o.mag, [[-1, -1, 1, -1, -1]] + [[1] * 5] * 4)
+    np.testing.assert_array_almost_equal(o.direction, [[-1, -1, h, -1, -1]] + [[h] * 5] * 4)
+    np.testing.assert_array_almost_equal(o.uca, [[nan, nan, 5, nan, nan], [4] * 5, [3] * 5, [2] * 5, [1] * 5])
+    diag = np.add.outer(np.arange(5.), np.arange(5.)) + 1
+    o = O.OracleDEM(diag); o.calc_twi()
+    r2 = np.sqrt(2)
+    mag = np.full((5, 5), r2); mag[0, 4] = 1; mag[4, 0] = 1
+    ang = np.full((5, 5), 0.75 * np.pi); ang[0, 4] = np.pi; ang[4, 0] = np.pi / 2
+    np.testing.assert_array_almost_equal(o.mag, mag)
+    np.testing.assert_array_almost_equal(o.direction, ang)
+    np.testing.assert_array_almost_equal(o.uca, [[5, 4, 3, 3, 1], [4, 4, 3, 2, 1], [3, 3, 3, 2, 1],
+                                                 [3, 2, 2, 2, 1], [1, 1, 1, 1, 1]])
+
+
+def test_synth_generators_agree():
+    """numpy generator == C generator bit for bit (the HIP one is checked in the gpu tests)."""
+    from pydem_amd import synth
+    a = synth.fractal(40, 56, seed=7, row0=1000, col0=33, top_shift=6, n_octaves=6)
+    b = O.synth_fractal(40, 56, seed=7, row0=1000, col0=33, top_shift=6, n_octaves=6)
+    assert np.array_equal(a, b)
+    a = synth.fractal(33, 31, seed=1)
+    b = O.synth_fractal(33, 31, seed=1)
+    assert np.array_equal(a, b)
