@@ -1,0 +1,129 @@
+/*
+ * pydem_hip.h -- C-ABI of libpydem_hip.so: the MI355X (gfx950) implementation of pyDEM's
+ * per-tile terrain hot path.  Plain pointers and sizes only; every call returns 0 on success
+ * and a negative code on failure, with the message available from pydem_hip_last_error().
+ *
+ * What each entry point replaces in the reference (creare-com/pydem v1.2.1; paths relative to
+ * the reference checkout):
+ *
+ *   pydem_slopes_directions   DEMProcessor.calc_slopes_directions  pydem/dem_processing.py:587-619
+ *                             (= _tarboton_slopes_directions :1753-1903, _find_flats_edges :657-680)
+ *   pydem_find_flats          DEMProcessor.find_flats              pydem/dem_processing.py:305-306
+ *   pydem_uca                 DEMProcessor.calc_uca (uca_init=None) pydem/dem_processing.py:682-776,
+ *                             _calc_uca_chunk :864-987, _calc_uca_section_proportion :1021-1070,
+ *                             _mk_adjacency_matrix :1072-1153, _mk_connectivity_pits :1269-1382 and
+ *                             the native loop cyutils.drain_area   pydem/cyfuncs/cyutils.pyx:78-187
+ *   pydem_uca_edge_update     DEMProcessor.calc_uca(uca_init=, edge_init_data=) :724-771,
+ *                             _calc_uca_chunk_update :778-862, cyutils.drain_connections
+ *                             pydem/cyfuncs/cyutils.pyx:35-72
+ *   pydem_twi                 DEMProcessor.calc_twi                pydem/dem_processing.py:1647-1677
+ *   pydem_drain_area /        the reference's only native boundary, kept callable with flat arrays:
+ *   pydem_drain_connections   cyutils.drain_area / drain_connections (cyutils.pyx:78-116, :35-46)
+ *
+ * Ownership: the caller owns every host buffer it passes; the library owns device memory behind
+ * the opaque pydem_tile handle (create / upload / run / download / destroy).  Nothing allocated
+ * by the library is ever returned to the caller.  One HIP stream per handle; calls on different
+ * handles may run from different host threads.
+ */
+#ifndef PYDEM_HIP_H
+#define PYDEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pydem_tile pydem_tile;
+
+/* device-resident per-tile fields, for pydem_tile_upload / pydem_tile_download */
+enum pydem_field {
+    PYDEM_ELEV = 0,        /* float64 [n,m]  conditioned elevation                              */
+    PYDEM_MAG = 1,         /* float64 [n,m]  slope magnitude, -1 on flats                       */
+    PYDEM_DIRECTION = 2,   /* float64 [n,m]  D-infinity direction (rad), -1 on flats            */
+    PYDEM_FLATS = 3,       /* uint8   [n,m]  flats mask                                         */
+    PYDEM_SECTION = 4,     /* int8    [n,m]  facet index 0..7, -1 on flats                      */
+    PYDEM_PROPORTION = 5,  /* float64 [n,m]  share of flow to the facet's first neighbour       */
+    PYDEM_UCA = 6,         /* float64 [n,m]  upstream contributing area, NaN on flats           */
+    PYDEM_TWI = 7,         /* float64 [n,m]  ln(uca / (mag + min_slope)) (un-scaled)            */
+    PYDEM_EDGE_TODO = 8,   /* uint8   [n,m]  inlet edge cells still waiting for a neighbour     */
+    PYDEM_EDGE_DONE = 9,   /* uint8   [n,m]                                                    */
+    PYDEM_FIELD_COUNT = 10
+};
+
+/* element types accepted by pydem_tile_upload for PYDEM_ELEV (converted to float64 on device) */
+enum pydem_dtype { PYDEM_F64 = 0, PYDEM_F32 = 1, PYDEM_I16 = 2, PYDEM_I32 = 3, PYDEM_U8 = 4, PYDEM_I8 = 5 };
+
+/* options of the hot path; names and defaults follow the DEMProcessor traits
+ * (pydem/dem_processing.py:105-154) */
+typedef struct pydem_options {
+    int32_t drain_pits;              /* 1   :112 */
+    int32_t drain_pits_min_border;   /* 0   :114 */
+    int32_t drain_pits_max_iter;     /* 300 :117 */
+    int32_t drain_pits_max_dist;     /* 32  :118 (0 = None) */
+    double  drain_pits_max_dist_XY;  /* NaN = None :119 */
+    int32_t apply_uca_limit_edges;   /* 0   :123 */
+    int32_t apply_twi_limits;        /* 0   :125 */
+    int32_t apply_twi_limits_on_uca; /* 0   :127 */
+    int32_t circular_ref_maxcount;   /* 50  :151 */
+    double  uca_saturation_limit;    /* 32  :146 */
+    double  twi_min_slope;           /* 1e-3 :147 */
+    double  twi_min_area;            /* +inf :148 (in/out: min(dX2*dY2) is folded in by pydem_uca) */
+} pydem_options;
+
+/* per-stage device time of the last call of each stage, milliseconds (hipEvent pairs) */
+typedef struct pydem_timings {
+    double slopes_directions_ms;  /* stencil + perimeter                      */
+    double stencil_kernel_ms;     /* the interior 3x3 stencil kernel alone    */
+    double flats_ms;              /* flats-edge labelling                     */
+    double graph_ms;              /* section/proportion + pits + in-degree    */
+    double pits_ms;               /* pit -> drain assignment alone            */
+    double sweep_ms;              /* frontier sweep                           */
+    double twi_ms;
+    int64_t sweep_rounds;         /* frontier rounds of the last sweep        */
+    int64_t sweep_kernel_launches;
+    int64_t n_flats;              /* cells in the flats mask after slopes_directions */
+    int64_t n_pit_edges;          /* pit -> drain edges built                  */
+    int64_t n_pits_undrained;     /* the reference's "pits had no place to drain" count */
+    int64_t n_unresolved;         /* cells the sweep could not reach (cyclic drainage) */
+} pydem_timings;
+
+const char *pydem_hip_last_error(void);
+int pydem_hip_device_count(int *count);
+int pydem_hip_device_name(int device, char *buf, int buflen);
+
+int pydem_tile_create(int64_t n_rows, int64_t n_cols, int device, pydem_tile **out);
+int pydem_tile_destroy(pydem_tile *t);
+/* dX, dY: n_rows-1 values; dX2, dY2: n_rows values (DEMProcessor.__init__ :229-258) */
+int pydem_tile_set_spacing(pydem_tile *t, const double *dX, const double *dY,
+                           const double *dX2, const double *dY2);
+int pydem_tile_upload(pydem_tile *t, int field, const void *src, int dtype);
+int pydem_tile_download(pydem_tile *t, int field, void *dst);
+int pydem_tile_synchronize(pydem_tile *t);
+int pydem_tile_timings(pydem_tile *t, pydem_timings *out);
+int64_t pydem_tile_device_bytes(pydem_tile *t);
+
+/* deterministic synthetic fractal DEM written straight into the tile's elevation
+ * (bit-identical to pydem_amd/synth.py:fractal; bench / test input only) */
+int pydem_tile_synth_fractal(pydem_tile *t, uint32_t seed, int64_t row0, int64_t col0,
+                             int n_octaves, int top_shift, double zmin, double zrange);
+
+int pydem_slopes_directions(pydem_tile *t);
+int pydem_find_flats(pydem_tile *t);
+int pydem_uca(pydem_tile *t, pydem_options *opt);
+/* strips in the order left, right, top, bottom; left/right have n_rows entries, top/bottom
+ * n_cols; data = neighbour uca (+uca_edges), done/todo = uint8 (process_manager.py:252-255) */
+int pydem_uca_edge_update(pydem_tile *t, pydem_options *opt,
+                          const double *const data[4], const uint8_t *const done[4],
+                          const uint8_t *const todo[4]);
+int pydem_twi(pydem_tile *t, pydem_options *opt);
+
+/* Kernel-only timing hook for bench.py: runs the interior stencil `iters` times on the tile's
+ * resident elevation and returns the average kernel time (ms) measured with hipEvents on the
+ * tile's stream. */
+int pydem_bench_stencil(pydem_tile *t, int iters, double *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYDEM_HIP_H */

@@ -1,0 +1,177 @@
+"""ctypes binding of libpydem_hip.so (C-ABI declared in include/pydem_hip.h).
+
+The product path has no CPU fallback: if the library is missing or no MI355X is visible the
+calls raise.  Nothing here imports torch or the oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpydem_hip.so')
+
+# enum pydem_field
+ELEV, MAG, DIRECTION, FLATS, SECTION, PROPORTION, UCA, TWI, EDGE_TODO, EDGE_DONE = range(10)
+FIELD_DTYPE = {ELEV: np.float64, MAG: np.float64, DIRECTION: np.float64, FLATS: np.uint8,
+               SECTION: np.int8, PROPORTION: np.float64, UCA: np.float64, TWI: np.float64,
+               EDGE_TODO: np.uint8, EDGE_DONE: np.uint8}
+# enum pydem_dtype
+_DTYPES = {np.dtype('float64'): 0, np.dtype('float32'): 1, np.dtype('int16'): 2, np.dtype('int32'): 3,
+           np.dtype('uint8'): 4, np.dtype('int8'): 5, np.dtype('bool'): 4}
+
+
+class Options(C.Structure):
+    """struct pydem_options (defaults = DEMProcessor traits, reference dem_processing.py:105-154)"""
+    _fields_ = [('drain_pits', C.c_int32), ('drain_pits_min_border', C.c_int32),
+                ('drain_pits_max_iter', C.c_int32), ('drain_pits_max_dist', C.c_int32),
+                ('drain_pits_max_dist_XY', C.c_double), ('apply_uca_limit_edges', C.c_int32),
+                ('apply_twi_limits', C.c_int32), ('apply_twi_limits_on_uca', C.c_int32),
+                ('circular_ref_maxcount', C.c_int32), ('uca_saturation_limit', C.c_double),
+                ('twi_min_slope', C.c_double), ('twi_min_area', C.c_double)]
+
+
+class Timings(C.Structure):
+    """struct pydem_timings"""
+    _fields_ = [('slopes_directions_ms', C.c_double), ('stencil_kernel_ms', C.c_double),
+                ('flats_ms', C.c_double), ('graph_ms', C.c_double), ('pits_ms', C.c_double),
+                ('sweep_ms', C.c_double), ('twi_ms', C.c_double), ('sweep_rounds', C.c_int64),
+                ('sweep_kernel_launches', C.c_int64), ('n_flats', C.c_int64), ('n_pit_edges', C.c_int64),
+                ('n_pits_undrained', C.c_int64), ('n_unresolved', C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/pydem_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+SYMBOLS = {
+    'pydem_hip_last_error': (C.c_char_p, []),
+    'pydem_hip_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'pydem_hip_device_name': (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    'pydem_tile_create': (C.c_int, [C.c_int64, C.c_int64, C.c_int, _PP]),
+    'pydem_tile_destroy': (C.c_int, [_P]),
+    'pydem_tile_set_spacing': (C.c_int, [_P, _P, _P, _P, _P]),
+    'pydem_tile_upload': (C.c_int, [_P, C.c_int, _P, C.c_int]),
+    'pydem_tile_download': (C.c_int, [_P, C.c_int, _P]),
+    'pydem_tile_synchronize': (C.c_int, [_P]),
+    'pydem_tile_timings': (C.c_int, [_P, C.POINTER(Timings)]),
+    'pydem_tile_device_bytes': (C.c_int64, [_P]),
+    'pydem_tile_synth_fractal': (C.c_int, [_P, C.c_uint32, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                           C.c_double, C.c_double]),
+    'pydem_slopes_directions': (C.c_int, [_P]),
+    'pydem_find_flats': (C.c_int, [_P]),
+    'pydem_uca': (C.c_int, [_P, C.POINTER(Options)]),
+    'pydem_uca_edge_update': (C.c_int, [_P, C.POINTER(Options), _PP, _PP, _PP]),
+    'pydem_twi': (C.c_int, [_P, C.POINTER(Options)]),
+    'pydem_bench_stencil': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library and bind every declared symbol (fails loudly if anything is missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libpydem_hip.so is not built (%s); run `python -m pydem_amd.build`. "
+                               "There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)   # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise HipError("libpydem_hip error %d: %s" % (rc, load().pydem_hip_last_error().decode()))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(load().pydem_hip_device_count(C.byref(n)))
+    return n.value
+
+
+class Tile(object):
+    """Owns one device-resident tile handle."""
+
+    def __init__(self, n_rows, n_cols, device=0):
+        self.lib = load()
+        self.shape = (int(n_rows), int(n_cols))
+        self._h = C.c_void_p()
+        check(self.lib.pydem_tile_create(n_rows, n_cols, device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self.lib.pydem_tile_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_spacing(self, dX, dY, dX2, dY2):
+        arrs = [np.ascontiguousarray(a, np.float64) for a in (dX, dY, dX2, dY2)]
+        n = self.shape[0]
+        assert arrs[0].size == n - 1 and arrs[1].size == n - 1 and arrs[2].size == n and arrs[3].size == n
+        check(self.lib.pydem_tile_set_spacing(self._h, *[a.ctypes.data_as(_P) for a in arrs]))
+
+    def upload(self, field, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.shape == self.shape, (arr.shape, self.shape)
+        if FIELD_DTYPE[field] != np.float64:
+            arr = np.ascontiguousarray(arr.astype(FIELD_DTYPE[field], copy=False))
+            dt = _DTYPES[arr.dtype]
+        else:
+            if arr.dtype not in _DTYPES or arr.dtype == np.bool_:
+                arr = np.ascontiguousarray(arr, np.float64)
+            dt = _DTYPES[arr.dtype]
+        check(self.lib.pydem_tile_upload(self._h, field, arr.ctypes.data_as(_P), dt))
+
+    def download(self, field):
+        out = np.empty(self.shape, FIELD_DTYPE[field])
+        check(self.lib.pydem_tile_download(self._h, field, out.ctypes.data_as(_P)))
+        return out
+
+    def synth_fractal(self, seed=0, row0=0, col0=0, n_octaves=12, top_shift=12, zmin=1.0, zrange=1000.0):
+        check(self.lib.pydem_tile_synth_fractal(self._h, seed, row0, col0, n_octaves, top_shift, zmin, zrange))
+
+    def slopes_directions(self):
+        check(self.lib.pydem_slopes_directions(self._h))
+
+    def find_flats(self):
+        check(self.lib.pydem_find_flats(self._h))
+
+    def uca(self, opt):
+        check(self.lib.pydem_uca(self._h, C.byref(opt)))
+
+    def twi(self, opt):
+        check(self.lib.pydem_twi(self._h, C.byref(opt)))
+
+    def bench_stencil(self, iters):
+        ms = C.c_double(0)
+        check(self.lib.pydem_bench_stencil(self._h, iters, C.byref(ms)))
+        return ms.value
+
+    def synchronize(self):
+        check(self.lib.pydem_tile_synchronize(self._h))
+
+    def timings(self):
+        tm = Timings()
+        check(self.lib.pydem_tile_timings(self._h, C.byref(tm)))
+        return tm.as_dict()
+
+    def device_bytes(self):
+        return self.lib.pydem_tile_device_bytes(self._h)

@@ -1,0 +1,178 @@
+// flats.hip -- K2: flats mask with its one-pixel downstream extension.
+//
+// Replaces _find_flats_edges (reference pydem/dem_processing.py:657-680, helper
+// utils.get_adjacent_index pydem/utils.py:270-311) and the epilogue of calc_slopes_directions
+// (:610-613).  The reference labels the 8-connected regions of `mag == -1` with
+// scipy.ndimage.label and, region by region in label order, overwrites the mask on every
+// 8-neighbour J of the region's cells with `elev[J] == elev[first cell of the region]`.
+// scipy numbers regions by the raster position of their first cell, and later regions
+// overwrite earlier ones, so the final value of J is decided by the neighbouring region whose
+// first (= minimum-index) cell is largest.  Here: union-find labelling with min-index roots
+// over the compacted list of flat cells, then every neighbour of a flat cell takes
+// `elev[J] == elev[root]` of the max-root region touching it.  Integer/bool work: bit-exact.
+#include "internal.h"
+
+namespace {
+
+#define RLX_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// stream compaction of flat0 != 0 into a list of cell ids: per-wave ballot + one atomic per wave
+__global__ __launch_bounds__(256) void k_compact_flats(const uint8_t *__restrict__ flat0, int64_t NN,
+                                                       int32_t *__restrict__ list, int32_t *__restrict__ count)
+{
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane)); base < NN;
+         base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = base + lane;
+        const bool f = (c < NN) && flat0[c];
+        const unsigned long long bal = __ballot(f);
+        if (bal == 0ull) continue;
+        int32_t off = 0;
+        if (lane == 0) off = atomicAdd(count, (int32_t)__popcll(bal));
+        off = __shfl(off, 0);
+        if (f) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)c;
+    }
+}
+
+__global__ void k_label_init(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *labels)
+{
+    const int32_t nf = *count;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) labels[list[q]] = list[q];
+}
+
+__device__ __forceinline__ int32_t uf_find(int32_t *L, int32_t x)
+{
+    int32_t p = RLX_LOAD(&L[x]);
+    while (p != x) { x = p; p = RLX_LOAD(&L[x]); }
+    return x;
+}
+
+// lock-free union with min-index roots (labels only ever decrease)
+__device__ __forceinline__ void uf_union(int32_t *L, int32_t a, int32_t b)
+{
+    for (;;) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a > b) { const int32_t t = a; a = b; b = t; }
+        const int32_t old = atomicMin(&L[b], a);     // link the larger root under the smaller
+        if (old == b) return;
+        b = old;                                      // someone else moved b meanwhile: retry
+    }
+}
+
+__global__ void k_label_union(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
+                              const uint8_t *__restrict__ flat0, int32_t *labels, int n, int m)
+{
+    const int32_t nf = *count;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
+        const int32_t c = list[q];
+        const int i = c / m, j = c - i * m;
+        // forward half of the 8-neighbourhood: E, SW, S, SE (each pair is visited once)
+        if (j + 1 < m && flat0[c + 1]) uf_union(labels, c, c + 1);
+        if (i + 1 < n) {
+            if (j > 0 && flat0[c + m - 1]) uf_union(labels, c, c + m - 1);
+            if (flat0[c + m]) uf_union(labels, c, c + m);
+            if (j + 1 < m && flat0[c + m + 1]) uf_union(labels, c, c + m + 1);
+        }
+    }
+}
+
+__global__ void k_label_flatten(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *labels)
+{
+    const int32_t nf = *count;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
+        const int32_t c = list[q];
+        const int32_t r = uf_find(labels, c);
+        if (r != c) __hip_atomic_store(&labels[c], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// For every neighbour J of every flat cell: flats[J] = (elev[J] == elev[root of the max-root flat
+// region adjacent to J]).  Several threads may compute the same J; they all write the same value.
+__global__ void k_flats_extend(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
+                               const uint8_t *__restrict__ flat0, const int32_t *__restrict__ labels,
+                               const double *__restrict__ elev, uint8_t *__restrict__ flats, int n, int m)
+{
+    const int32_t nf = *count;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf * 8; q += gridDim.x * blockDim.x) {
+        const int32_t c = list[q >> 3];
+        int d = q & 7;
+        d += (d >= 4);                                   // skip the centre of the 3x3
+        const int i = c / m + d / 3 - 1, j = c % m + d % 3 - 1;
+        if (i < 0 || i >= n || j < 0 || j >= m) continue;
+        const int32_t J = i * m + j;
+        int32_t best = -1;
+        for (int dd = 0; dd < 9; dd++) {
+            if (dd == 4) continue;
+            const int ii = i + dd / 3 - 1, jj = j + dd % 3 - 1;
+            if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+            const int32_t nb = ii * m + jj;
+            if (flat0[nb]) { const int32_t r = labels[nb]; best = r > best ? r : best; }
+        }
+        flats[J] = (elev[J] == elev[best]);
+    }
+}
+
+// direction[flats] = mag[flats] = -1 (dem_processing.py:611-612), only near flat cells
+__global__ void k_flats_patch(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
+                              const uint8_t *__restrict__ flats, double *__restrict__ mag, double *__restrict__ dir,
+                              int n, int m)
+{
+    const int32_t nf = *count;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf * 9; q += gridDim.x * blockDim.x) {
+        const int32_t c = list[q / 9];
+        const int d = q % 9;
+        const int i = c / m + d / 3 - 1, j = c % m + d % 3 - 1;
+        if (i < 0 || i >= n || j < 0 || j >= m) continue;
+        const int32_t J = i * m + j;
+        if (flats[J]) { mag[J] = -1.0; dir[J] = -1.0; }
+    }
+}
+
+__global__ void k_count_flats(const uint8_t *__restrict__ flats, int64_t NN, int32_t *count)
+{
+    int32_t local = 0;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < NN; c += (int64_t)gridDim.x * blockDim.x)
+        local += flats[c] != 0;
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+}
+
+}  // namespace
+
+int stage_flats(pydem_tile *t)
+{
+    const int n = (int)t->n, m = (int)t->m;
+    PYDEM_TRY(tile_alloc(t, &t->labels, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->flatlist, (size_t)t->NN));
+    HIP_TRY(hipEventRecord(t->ev[3], t->stream));
+    HIP_TRY(hipMemsetAsync(t->counters, 0, 64 * sizeof(int32_t), t->stream));
+    int32_t *cnt = t->counters;          // [0] number of flat0 cells, [1] final flats count
+    const int big = (int)(cdiv(t->NN, 256) < 4096 ? cdiv(t->NN, 256) : 4096);
+    hipLaunchKernelGGL(k_compact_flats, dim3(big), dim3(256), 0, t->stream, t->flat0, t->NN, t->flatlist, cnt);
+    HIP_TRY(hipMemcpyAsync(t->flats, t->flat0, (size_t)t->NN, hipMemcpyDeviceToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    const int32_t nf = t->h_counters[0];
+    if (nf > 0) {
+        const int g1 = (int)(cdiv(nf, 256) < 2048 ? cdiv(nf, 256) : 2048);
+        const int g8 = (int)(cdiv((int64_t)nf * 9, 256) < 4096 ? cdiv((int64_t)nf * 9, 256) : 4096);
+        hipLaunchKernelGGL(k_label_init, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, t->labels);
+        hipLaunchKernelGGL(k_label_union, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, t->flat0, t->labels, n, m);
+        hipLaunchKernelGGL(k_label_flatten, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, t->labels);
+        hipLaunchKernelGGL(k_flats_extend, dim3(g8), dim3(256), 0, t->stream, t->flatlist, cnt, t->flat0, t->labels,
+                           t->elev, t->flats, n, m);
+        hipLaunchKernelGGL(k_flats_patch, dim3(g8), dim3(256), 0, t->stream, t->flatlist, cnt, t->flats, t->mag, t->dir, n, m);
+    }
+    hipLaunchKernelGGL(k_count_flats, dim3(big), dim3(256), 0, t->stream, t->flats, t->NN, cnt + 1);
+    HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipEventRecord(t->ev[4], t->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventSynchronize(t->ev[4]));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, t->ev[3], t->ev[4]));
+    t->tm.flats_ms = ms;
+    t->tm.n_flats = t->h_counters[1];
+    return 0;
+}

@@ -1,0 +1,101 @@
+// internal.h -- shared declarations of libpydem_hip.so (gfx950 only; HIP, no compatibility layers)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <initializer_list>
+#include "../../include/pydem_hip.h"
+
+// ---- error plumbing -----------------------------------------------------------------------
+void pydem_set_error(const char *fmt, ...);
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            pydem_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return -1;                                                                         \
+        }                                                                                      \
+    } while (0)
+#define PYDEM_TRY(expr)            \
+    do {                           \
+        int r_ = (expr);           \
+        if (r_ != 0) return r_;    \
+    } while (0)
+
+// ---- facet tables (reference: dem_processing.py:173-193) ------------------------------------
+// facet k: first neighbour e1 (cardinal), second neighbour e2 (diagonal); (row offset, col offset)
+__host__ __device__ constexpr int fe1r(int k) { return k == 1 || k == 2 ? -1 : (k == 5 || k == 6 ? 1 : 0); }
+__host__ __device__ constexpr int fe1c(int k) { return k == 0 || k == 7 ? 1 : (k == 3 || k == 4 ? -1 : 0); }
+__host__ __device__ constexpr int fe2r(int k) { return k <= 3 ? -1 : 1; }
+__host__ __device__ constexpr int fe2c(int k) { return (k == 0 || k == 1 || k == 6 || k == 7) ? 1 : -1; }
+
+// per-spacing-row table entry: row r of dX/dY (r = 0..n-2)
+struct RowTab {
+    double dX, dY;    // fence-grid spacing of row r
+    double hyp;       // sqrt(dX*dX + dY*dY)            (dem_processing.py:1962 denominator)
+    double thA;       // atan2(dY, dX): facets 0,3,4,7  (dem_processing.py:1936)
+    double thB;       // atan2(dX, dY): facets 1,2,5,6
+    double pad[3];
+};
+
+// pit -> drain edges (COO, sorted by pit then drain) and their CSR-by-target view
+struct PitGraph {
+    int64_t n_edges = 0;
+    int32_t *src = nullptr;      // [n_edges] pit cell
+    int32_t *dst = nullptr;      // [n_edges] drain cell
+    double *w = nullptr;         // [n_edges] weight
+    // in-edge view, grouped by target cell
+    int32_t *in_cell = nullptr;  // [n_in_cells] distinct target cells (ascending)
+    int32_t *in_ptr = nullptr;   // [n_in_cells+1]
+    int32_t *in_src = nullptr;   // [n_edges] source pit of each in-edge
+    double *in_w = nullptr;      // [n_edges]
+    int64_t n_in_cells = 0;
+};
+
+struct pydem_tile {
+    int64_t n = 0, m = 0, NN = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    // fields
+    double *elev = nullptr, *mag = nullptr, *dir = nullptr, *prop = nullptr, *uca = nullptr, *twi = nullptr;
+    uint8_t *flats = nullptr, *edge_todo = nullptr, *edge_done = nullptr, *flat0 = nullptr;
+    int8_t *section = nullptr;
+    bool have[PYDEM_FIELD_COUNT] = {};
+    // spacing
+    double *dX = nullptr, *dY = nullptr, *dX2 = nullptr, *dY2 = nullptr;   // device copies
+    RowTab *rowtab = nullptr;                                              // [n-1]
+    double *sec_theta = nullptr;                                           // [n] theta per row for section/proportion
+    double *row_area = nullptr;                                            // [n] dX2*dY2
+    std::vector<double> h_dX, h_dY, h_dX2, h_dY2;
+    bool spacing_set = false;
+    // graph / sweep scratch
+    uint8_t *inmask = nullptr, *gflags = nullptr, *todo_work = nullptr;
+    int32_t *indeg = nullptr, *queue[2] = {nullptr, nullptr}, *labels = nullptr, *flatlist = nullptr;
+    int32_t *counters = nullptr;       // device scalars
+    int32_t *h_counters = nullptr;     // pinned host mirror
+    PitGraph pits;
+    void *scratch = nullptr; size_t scratch_bytes = 0;
+    int64_t device_bytes = 0;
+    pydem_timings tm = {};
+};
+
+template <typename T>
+int tile_alloc(pydem_tile *t, T **p, size_t count);
+
+int ensure_fields(pydem_tile *t, std::initializer_list<int> fields);
+
+// stage entry points implemented in the .hip files
+int stage_stencil(pydem_tile *t);
+int stage_flats(pydem_tile *t);
+int stage_section_graph(pydem_tile *t, const pydem_options *opt);
+int stage_pits(pydem_tile *t, const pydem_options *opt);
+int stage_sweep(pydem_tile *t, const pydem_options *opt);
+int stage_twi(pydem_tile *t, const pydem_options *opt);
+int stage_synth(pydem_tile *t, uint32_t seed, int64_t row0, int64_t col0, int n_oct, int top_shift,
+                double zmin, double zrange);
+int bench_stencil(pydem_tile *t, int iters, double *avg_ms);
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,293 @@
+// stencil.hip -- K1: Tarboton D-infinity slope magnitude + direction (3x3 stencil, 8 facets).
+//
+// Replaces _tarboton_slopes_directions (reference pydem/dem_processing.py:1753-1903) with its
+// helpers _get_d1_d2 (:1905-1938) and _calc_direction (:1942-1991).  The reference makes 8
+// full-array numpy passes (one per facet) plus 4 edge and 4 corner passes; here one kernel
+// handles every interior cell (all 8 facets in registers, elevation staged through an LDS halo
+// tile) and a second O(perimeter) kernel applies the edge/corner rules.
+//
+// Bounded by HBM: algorithmic traffic 24 B/cell (read elev 8, write mag 8 + direction 8), plus
+// 1 B/cell for the flat0 mask consumed by the flats stage.  No MFMA: there is no contraction.
+// Compiled with -ffp-contract=off: the facet arithmetic must round exactly like numpy's
+// separate multiply/add ufuncs or exact ties on integer DEMs break differently.
+#include "internal.h"
+#include <float.h>
+
+#define PI_D 3.141592653589793
+
+namespace {
+
+constexpr int TX = 64;    // tile columns (one wavefront wide: 512 B rows)
+constexpr int TY = 32;    // tile rows
+constexpr int RPT = 8;    // rows marched per thread (256 threads = 64 x 4)
+constexpr int LW = TX + 2;
+
+// winner bookkeeping across the 8 facets: `rad2 > mag` with strict '>' so the first facet wins
+// exact ties (dem_processing.py:1986-1989)
+struct Best {
+    double rad2;   // best squared magnitude so far (-1 = none)
+    double s1, s2; // slopes of the winning facet (for the final atan2)
+    double theta;  // table angle of the winning facet
+    int k;         // winning facet
+    int kind;      // 1: r = 0 (cardinal), 2: r = theta (diagonal), 3: r = atan2(s2, s1)
+};
+
+// One facet of _calc_direction (:1958-1989).  s1, s2, sd are the three slopes; d1, d2 the
+// spacings (only used to decide r > theta by cross-multiplication instead of an arctangent:
+// for s1 > 0, s2 > 0: atan2(s2, s1) > atan2(d2, d1)  <=>  s2*d1 > s1*d2; when the two
+// products agree to within a few ulps the comparison is re-done with atan2 exactly as the
+// reference does, so exact ties (s1 == s2, d1 == d2 on integer DEMs) resolve identically).
+__device__ __forceinline__ void facet(double s1, double s2, double sd, double d1, double d2,
+                                      double theta, int k, Best &b)
+{
+    const double s1_2 = s1 * s1;
+    const bool s1le = s1 <= 0, s2le = s2 <= 0, s1gt = s1 > 0, s2gt = s2 > 0;
+    double rad2 = s1_2 + s2 * s2;
+    int kind = 3;
+    bool rgt = false;
+    if (s1gt && s2gt) {
+        const double a = s2 * d1, c = s1 * d2;
+        rgt = a > c;
+        if (fabs(a - c) <= 8.0 * DBL_EPSILON * fmax(a, c)) rgt = atan2(s2, s1) > theta;
+    }
+    if ((s1le && s2gt) || rgt) { rad2 = sd * sd; kind = 2; }           // I1 :1973-1976
+    if (s1gt && s2le) { rad2 = s1_2; kind = 1; }                       // I2 :1978-1981 (r < 0 implies s2 < 0)
+    if (s1le && (s2le || (s2gt && sd <= 0))) rad2 = -1.0;              // I3 :1983-1984
+    if (rad2 > b.rad2) {                                               // I4 :1986-1989
+        b.rad2 = rad2; b.s1 = s1; b.s2 = s2; b.theta = theta; b.k = k; b.kind = kind;
+    }
+}
+
+// direction of the winner: r * ang[1] + ang[0] * pi / 2 (:1989); ang_adj table :184-193
+__device__ __forceinline__ double winner_direction(const Best &b)
+{
+    if (b.k < 0) return -1.0;
+    const int a0 = (b.k + 1) >> 1;                 // 0,1,1,2,2,3,3,4
+    const double a1 = (b.k & 1) ? -1.0 : 1.0;      // 1,-1,1,-1,...
+    double r = 0.0;
+    if (b.kind == 2) r = b.theta;
+    else if (b.kind == 3) r = atan2(b.s2, b.s1);
+    return r * a1 + (double)a0 * PI_D / 2;
+}
+
+// all 8 facets of an interior cell.  tn = spacing row i-1 (facets 0-3), ts = row i (facets 4-7)
+// (_get_d1_d2 :1912-1924: facets 0,3,4,7 use d1 = dX, d2 = dY; facets 1,2,5,6 d1 = dY, d2 = dX)
+__device__ __forceinline__ void eight_facets(double z0, double zN, double zS, double zE, double zW,
+                                             double zNE, double zNW, double zSW, double zSE,
+                                             const RowTab &tn, const RowTab &ts, Best &b)
+{
+    const double sdNE = (z0 - zNE) / tn.hyp, sdNW = (z0 - zNW) / tn.hyp;
+    const double sdSW = (z0 - zSW) / ts.hyp, sdSE = (z0 - zSE) / ts.hyp;
+    const double s1N = (z0 - zN) / tn.dY, s1S = (z0 - zS) / ts.dY;
+    facet((z0 - zE) / tn.dX, (zE - zNE) / tn.dY, sdNE, tn.dX, tn.dY, tn.thA, 0, b);
+    facet(s1N, (zN - zNE) / tn.dX, sdNE, tn.dY, tn.dX, tn.thB, 1, b);
+    facet(s1N, (zN - zNW) / tn.dX, sdNW, tn.dY, tn.dX, tn.thB, 2, b);
+    facet((z0 - zW) / tn.dX, (zW - zNW) / tn.dY, sdNW, tn.dX, tn.dY, tn.thA, 3, b);
+    facet((z0 - zW) / ts.dX, (zW - zSW) / ts.dY, sdSW, ts.dX, ts.dY, ts.thA, 4, b);
+    facet(s1S, (zS - zSW) / ts.dX, sdSW, ts.dY, ts.dX, ts.thB, 5, b);
+    facet(s1S, (zS - zSE) / ts.dX, sdSE, ts.dY, ts.dX, ts.thB, 6, b);
+    facet((z0 - zE) / ts.dX, (zE - zSE) / ts.dY, sdSE, ts.dX, ts.dY, ts.thA, 7, b);
+}
+
+__device__ __forceinline__ Best best_init()
+{
+    Best b; b.rad2 = -1.0; b.s1 = 0; b.s2 = 0; b.theta = 0; b.k = -1; b.kind = 0;
+    return b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// interior kernel: block = 64 x 4 threads, tile = 64 columns x 32 rows, LDS halo tile 66 x 34.
+// Tiles are column-aligned to multiples of 64 so each wavefront stores whole 512 B row segments.
+// XCD-aware tile order: consecutive block ids land on different XCDs (b % 8), so block b is
+// remapped to tile (b % 8) * tiles_per_xcd + b / 8: each XCD walks a contiguous band of tiles
+// and neighbouring tiles share halo lines in the same L2.
+// ---------------------------------------------------------------------------------------------
+template <bool XCD_SWIZZLE>
+__global__ __launch_bounds__(256) void k_stencil_interior(const double *__restrict__ elev, int n, int m,
+                                                          const RowTab *__restrict__ rowtab,
+                                                          double *__restrict__ mag, double *__restrict__ dir,
+                                                          uint8_t *__restrict__ flat0, int tiles_x, int tiles_total)
+{
+    __shared__ double tile[(TY + 2) * LW];
+    int tid = blockIdx.x;
+    if (XCD_SWIZZLE) {
+        const int per = (tiles_total + 7) >> 3;
+        tid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (tid >= tiles_total) return;
+    }
+    const int by = tid / tiles_x, bx = tid - by * tiles_x;
+    const int j0 = bx * TX, i0 = by * TY;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+
+    for (int idx = threadIdx.x; idx < (TY + 2) * LW; idx += 256) {
+        const int lr = idx / LW, lc = idx - lr * LW;
+        const int gi = i0 - 1 + lr, gj = j0 - 1 + lc;
+        double v = 0.0;
+        if (gi >= 0 && gi < n && gj >= 0 && gj < m) v = elev[(size_t)gi * m + gj];
+        tile[idx] = v;
+    }
+    __syncthreads();
+
+    const int j = j0 + tx;
+    const int lc = tx + 1;
+    int lr = ty * RPT + 1;                       // LDS row of the first cell of this thread
+    // 3x3 window, rolled down the column
+    double aW = tile[(lr - 1) * LW + lc - 1], a0 = tile[(lr - 1) * LW + lc], aE = tile[(lr - 1) * LW + lc + 1];
+    double cW = tile[lr * LW + lc - 1], c0 = tile[lr * LW + lc], cE = tile[lr * LW + lc + 1];
+#pragma unroll
+    for (int q = 0; q < RPT; q++, lr++) {
+        const int i = i0 + ty * RPT + q;
+        const double bW = tile[(lr + 1) * LW + lc - 1], b0 = tile[(lr + 1) * LW + lc], bE = tile[(lr + 1) * LW + lc + 1];
+        if (i >= 1 && i < n - 1 && j >= 1 && j < m - 1) {
+            const RowTab tn = rowtab[i - 1], ts = rowtab[i];
+            Best b = best_init();
+            eight_facets(c0, a0, b0, cE, cW, aE, aW, bW, bE, tn, ts, b);
+            const size_t c = (size_t)i * m + j;
+            mag[c] = b.rad2 > 0 ? sqrt(b.rad2) : b.rad2;           // :1901
+            dir[c] = winner_direction(b);
+            flat0[c] = (b.rad2 == -1.0);
+        }
+        aW = cW; a0 = c0; aE = cE;
+        cW = bW; c0 = b0; cE = bE;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// perimeter kernel: one thread per edge/corner cell (dem_processing.py:1779-1899).
+// ---------------------------------------------------------------------------------------------
+__device__ void interior_cell(const double *elev, int n, int m, const RowTab *rowtab, int i, int j,
+                              double &rad2, double &d)
+{
+    // pre-sqrt magnitude and direction of interior cell (i, j) recomputed from global memory;
+    // cells that are not interior still hold the initial -1 at the time of the copy rules
+    rad2 = -1.0; d = -1.0;
+    if (i < 1 || i > n - 2 || j < 1 || j > m - 2) return;
+    const double *r0 = elev + (size_t)(i - 1) * m + j, *r1 = r0 + m, *r2 = r1 + m;
+    Best b = best_init();
+    eight_facets(r1[0], r0[0], r2[0], r1[1], r1[-1], r0[1], r0[-1], r2[-1], r2[1], rowtab[i - 1], rowtab[i], b);
+    rad2 = b.rad2; d = winner_direction(b);
+}
+
+// one facet of an edge cell; mode 0: per-row spacing (left/right edges, topbot == None),
+// mode 1: fixed spacing row `sr` ('top' -> 0, 'bot' -> n-2) (:1925-1934)
+__device__ void edge_facet(const double *elev, int n, int m, const RowTab *rowtab, int i, int j, int k,
+                           int mode, int sr, Best &b)
+{
+    int r;
+    if (mode == 1) r = sr;
+    else r = (k <= 3) ? i - 1 : i;   // facets 0-3 reference spacing row i-1, 4-7 row i (:1914-1921)
+    const RowTab t = rowtab[r];
+    const bool A = (k == 0 || k == 3 || k == 4 || k == 7);
+    const double d1 = A ? t.dX : t.dY, d2 = A ? t.dY : t.dX, th = A ? t.thA : t.thB;
+    const double z0 = elev[(size_t)i * m + j];
+    const double z1 = elev[(size_t)(i + fe1r(k)) * m + (j + fe1c(k))];
+    const double z2 = elev[(size_t)(i + fe2r(k)) * m + (j + fe2c(k))];
+    facet((z0 - z1) / d1, (z1 - z2) / d2, (z0 - z2) / t.hyp, d1, d2, th, k, b);
+}
+
+__global__ void k_stencil_perimeter(const double *__restrict__ elev, int n, int m,
+                                    const RowTab *__restrict__ rowtab,
+                                    double *__restrict__ mag, double *__restrict__ dir, uint8_t *__restrict__ flat0)
+{
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
+    if (p >= nper) return;
+    int i, j;
+    if (p < m) { i = 0; j = (int)p; }
+    else if (p < 2 * (int64_t)m) { i = n - 1; j = (int)(p - m); }
+    else if (p < 2 * (int64_t)m + (n - 2)) { i = (int)(p - 2 * (int64_t)m) + 1; j = 0; }
+    else { i = (int)(p - 2 * (int64_t)m - (n - 2)) + 1; j = m - 1; }
+
+    const double HP = PI_D / 2, P32 = 3 * PI_D / 2, TWOPI = 2 * PI_D;
+    double rad2 = -1.0, d = -1.0;
+    // --- copy-from-interior rules in the reference's order: left, right, top, bottom (:1782-1795).
+    // For a corner the value can arrive through two hops (side copy on row 1 / n-2, then the
+    // top / bottom copy).
+    const bool top = (i == 0), bot = (i == n - 1), left = (j == 0), right = (j == m - 1);
+    if ((left || right) && !top && !bot) {
+        double r2, dd;
+        interior_cell(elev, n, m, rowtab, i, left ? 1 : m - 2, r2, dd);
+        const bool take = left ? (dd > HP && dd < P32) : (dd < HP || dd > P32);
+        if (take) { rad2 = r2; d = dd; }
+    } else {
+        // row 0 copies from row 1, row n-1 from row n-2; on the corner columns row 1 / n-2 itself
+        // holds whatever the side copy put there
+        const int ii = top ? 1 : n - 2;
+        double r2 = -1.0, dd = -1.0;
+        if (left || right) {
+            double r3, d3;
+            interior_cell(elev, n, m, rowtab, ii, left ? 1 : m - 2, r3, d3);
+            const bool take1 = left ? (d3 > HP && d3 < P32) : (d3 < HP || d3 > P32);
+            if (take1) { r2 = r3; dd = d3; }
+        } else {
+            interior_cell(elev, n, m, rowtab, ii, j, r2, dd);
+        }
+        const bool take = top ? (dd > 0 && dd < PI_D) : (dd > PI_D && dd < TWOPI);
+        if (take) { rad2 = r2; d = dd; }
+    }
+    // --- inward facets (:1800-1899); the copied value competes through the same strict '>'
+    Best b = best_init();
+    b.rad2 = rad2;
+    int copied = (rad2 > -1.0) || (d != -1.0);
+    (void)copied;
+    const int sr = top ? 0 : n - 2;
+    if (top && left) { edge_facet(elev, n, m, rowtab, i, j, 6, 1, sr, b); edge_facet(elev, n, m, rowtab, i, j, 7, 1, sr, b); }
+    else if (top && right) { edge_facet(elev, n, m, rowtab, i, j, 4, 1, sr, b); edge_facet(elev, n, m, rowtab, i, j, 5, 1, sr, b); }
+    else if (bot && left) { edge_facet(elev, n, m, rowtab, i, j, 0, 1, sr, b); edge_facet(elev, n, m, rowtab, i, j, 1, 1, sr, b); }
+    else if (bot && right) { edge_facet(elev, n, m, rowtab, i, j, 2, 1, sr, b); edge_facet(elev, n, m, rowtab, i, j, 3, 1, sr, b); }
+    else if (left) { const int ks[4] = {0, 1, 6, 7}; for (int q = 0; q < 4; q++) edge_facet(elev, n, m, rowtab, i, j, ks[q], 0, 0, b); }
+    else if (right) { const int ks[4] = {2, 3, 4, 5}; for (int q = 0; q < 4; q++) edge_facet(elev, n, m, rowtab, i, j, ks[q], 0, 0, b); }
+    else if (top) { const int ks[4] = {4, 5, 6, 7}; for (int q = 0; q < 4; q++) edge_facet(elev, n, m, rowtab, i, j, ks[q], 1, sr, b); }
+    else { const int ks[4] = {0, 1, 2, 3}; for (int q = 0; q < 4; q++) edge_facet(elev, n, m, rowtab, i, j, ks[q], 1, sr, b); }
+    const double dout = (b.k >= 0) ? winner_direction(b) : d;   // no facet beat the copied value
+    const size_t c = (size_t)i * m + j;
+    mag[c] = b.rad2 > 0 ? sqrt(b.rad2) : b.rad2;
+    dir[c] = dout;
+    flat0[c] = (b.rad2 == -1.0);
+}
+
+template <bool SW>
+int launch_interior(pydem_tile *t)
+{
+    const int tiles_x = (int)cdiv(t->m, TX), tiles_y = (int)cdiv(t->n, TY);
+    const int total = tiles_x * tiles_y;
+    const int grid = SW ? ((total + 7) / 8) * 8 : total;
+    hipLaunchKernelGGL(k_stencil_interior<SW>, dim3(grid), dim3(256), 0, t->stream, t->elev, (int)t->n, (int)t->m,
+                       t->rowtab, t->mag, t->dir, t->flat0, tiles_x, total);
+    return 0;
+}
+
+}  // namespace
+
+int stage_stencil(pydem_tile *t)
+{
+    HIP_TRY(hipEventRecord(t->ev[0], t->stream));
+    launch_interior<true>(t);
+    HIP_TRY(hipEventRecord(t->ev[1], t->stream));
+    const int64_t nper = 2 * t->m + 2 * (t->n - 2);
+    hipLaunchKernelGGL(k_stencil_perimeter, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, t->elev,
+                       (int)t->n, (int)t->m, t->rowtab, t->mag, t->dir, t->flat0);
+    HIP_TRY(hipEventRecord(t->ev[2], t->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventSynchronize(t->ev[2]));
+    float a = 0, b = 0;
+    HIP_TRY(hipEventElapsedTime(&a, t->ev[0], t->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b, t->ev[0], t->ev[2]));
+    t->tm.stencil_kernel_ms = a;
+    t->tm.slopes_directions_ms = b;
+    return 0;
+}
+
+int bench_stencil(pydem_tile *t, int iters, double *avg_ms)
+{
+    launch_interior<true>(t);   // warm-up
+    HIP_TRY(hipEventRecord(t->ev[0], t->stream));
+    for (int q = 0; q < iters; q++) launch_interior<true>(t);
+    HIP_TRY(hipEventRecord(t->ev[1], t->stream));
+    HIP_TRY(hipEventSynchronize(t->ev[1]));
+    HIP_TRY(hipGetLastError());
+    float a = 0;
+    HIP_TRY(hipEventElapsedTime(&a, t->ev[0], t->ev[1]));
+    *avg_ms = (double)a / iters;
+    return 0;
+}

@@ -1,0 +1,347 @@
+// tile.hip -- handle management, spacing tables, upload/download and the extern "C" surface.
+#include "internal.h"
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+static thread_local char g_err[1024] = "";
+
+void pydem_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+template <typename T>
+int tile_alloc(pydem_tile *t, T **p, size_t count)
+{
+    if (*p) return 0;
+    void *q = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {
+        pydem_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return -1;
+    }
+    t->device_bytes += (int64_t)bytes;
+    *p = (T *)q;
+    return 0;
+}
+template int tile_alloc<double>(pydem_tile *, double **, size_t);
+template int tile_alloc<uint8_t>(pydem_tile *, uint8_t **, size_t);
+template int tile_alloc<int8_t>(pydem_tile *, int8_t **, size_t);
+template int tile_alloc<int32_t>(pydem_tile *, int32_t **, size_t);
+template int tile_alloc<RowTab>(pydem_tile *, RowTab **, size_t);
+template int tile_alloc<uint16_t>(pydem_tile *, uint16_t **, size_t);
+
+namespace {
+
+template <typename S>
+__global__ void k_convert_to_f64(const S *__restrict__ src, double *__restrict__ dst, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = (double)src[i];
+}
+
+__global__ void k_find_flats(const double *__restrict__ mag, uint8_t *__restrict__ flats, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) flats[i] = (mag[i] == -1.0);    // dem_processing.py:305-306
+}
+
+size_t dtype_size(int dt)
+{
+    switch (dt) {
+        case PYDEM_F64: return 8;
+        case PYDEM_F32: return 4;
+        case PYDEM_I16: return 2;
+        case PYDEM_I32: return 4;
+        case PYDEM_U8: return 1;
+        case PYDEM_I8: return 1;
+    }
+    return 0;
+}
+
+int field_ptr(pydem_tile *t, int field, void ***pp, size_t *elem)
+{
+    switch (field) {
+        case PYDEM_ELEV: *pp = (void **)&t->elev; *elem = 8; return 0;
+        case PYDEM_MAG: *pp = (void **)&t->mag; *elem = 8; return 0;
+        case PYDEM_DIRECTION: *pp = (void **)&t->dir; *elem = 8; return 0;
+        case PYDEM_FLATS: *pp = (void **)&t->flats; *elem = 1; return 0;
+        case PYDEM_SECTION: *pp = (void **)&t->section; *elem = 1; return 0;
+        case PYDEM_PROPORTION: *pp = (void **)&t->prop; *elem = 8; return 0;
+        case PYDEM_UCA: *pp = (void **)&t->uca; *elem = 8; return 0;
+        case PYDEM_TWI: *pp = (void **)&t->twi; *elem = 8; return 0;
+        case PYDEM_EDGE_TODO: *pp = (void **)&t->edge_todo; *elem = 1; return 0;
+        case PYDEM_EDGE_DONE: *pp = (void **)&t->edge_done; *elem = 1; return 0;
+    }
+    pydem_set_error("unknown field id %d", field);
+    return -2;
+}
+
+int ensure_field(pydem_tile *t, int field)
+{
+    void **pp; size_t elem;
+    PYDEM_TRY(field_ptr(t, field, &pp, &elem));
+    if (*pp) return 0;
+    if (elem == 8) return tile_alloc(t, (double **)pp, (size_t)t->NN);
+    return tile_alloc(t, (uint8_t **)pp, (size_t)t->NN);
+}
+
+}  // namespace
+
+int ensure_fields(pydem_tile *t, std::initializer_list<int> fields)
+{
+    for (int f : fields) PYDEM_TRY(ensure_field(t, f));
+    return 0;
+}
+
+extern "C" {
+
+const char *pydem_hip_last_error(void) { return g_err; }
+
+int pydem_hip_device_count(int *count)
+{
+    HIP_TRY(hipGetDeviceCount(count));
+    return 0;
+}
+
+int pydem_hip_device_name(int device, char *buf, int buflen)
+{
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return 0;
+}
+
+int pydem_tile_create(int64_t n_rows, int64_t n_cols, int device, pydem_tile **out)
+{
+    if (n_rows < 3 || n_cols < 3) { pydem_set_error("tile must be at least 3x3 (got %lld x %lld)", (long long)n_rows, (long long)n_cols); return -2; }
+    if (n_rows * n_cols >= (int64_t)INT32_MAX) { pydem_set_error("tile too large for int32 cell ids"); return -2; }
+    HIP_TRY(hipSetDevice(device));
+    pydem_tile *t = new pydem_tile();
+    t->n = n_rows; t->m = n_cols; t->NN = n_rows * n_cols; t->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 8; i++) HIP_TRY(hipEventCreate(&t->ev[i]));
+    PYDEM_TRY(tile_alloc(t, &t->counters, 64));
+    HIP_TRY(hipHostMalloc((void **)&t->h_counters, 64 * sizeof(int32_t), hipHostMallocDefault));
+    *out = t;
+    return 0;
+}
+
+int pydem_tile_destroy(pydem_tile *t)
+{
+    if (!t) return 0;
+    (void)hipSetDevice(t->device);
+    (void)hipStreamSynchronize(t->stream);
+    void *ptrs[] = {t->elev, t->mag, t->dir, t->prop, t->uca, t->twi, t->flats, t->edge_todo, t->edge_done,
+                    t->flat0, t->section, t->dX, t->dY, t->dX2, t->dY2, t->rowtab, t->sec_theta, t->row_area, t->inmask,
+                    t->gflags, t->todo_work, t->indeg, t->queue[0], t->queue[1], t->labels, t->flatlist,
+                    t->counters, t->scratch, t->pits.src, t->pits.dst, t->pits.w, t->pits.in_cell,
+                    t->pits.in_ptr, t->pits.in_src, t->pits.in_w};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (t->h_counters) (void)hipHostFree(t->h_counters);
+    for (int i = 0; i < 8; i++) if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
+    if (t->stream) (void)hipStreamDestroy(t->stream);
+    delete t;
+    return 0;
+}
+
+int pydem_tile_set_spacing(pydem_tile *t, const double *dX, const double *dY, const double *dX2, const double *dY2)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    const int64_t n = t->n;
+    t->h_dX.assign(dX, dX + n - 1); t->h_dY.assign(dY, dY + n - 1);
+    t->h_dX2.assign(dX2, dX2 + n); t->h_dY2.assign(dY2, dY2 + n);
+    std::vector<RowTab> tab((size_t)(n - 1));
+    for (int64_t r = 0; r < n - 1; r++) {
+        RowTab &e = tab[(size_t)r];
+        e.dX = dX[r]; e.dY = dY[r];
+        e.hyp = sqrt(dX[r] * dX[r] + dY[r] * dY[r]);   // np.sqrt(d1**2 + d2**2), dem_processing.py:1962
+        e.thA = atan2(dY[r], dX[r]);                    // np.arctan2(d2, d1), :1936 (host libm == numpy)
+        e.thB = atan2(dX[r], dY[r]);
+        e.pad[0] = e.pad[1] = e.pad[2] = 0;
+    }
+    // theta per row for section/proportion: facet-0 spacing of rows 1..n-2 with the first and last
+    // entries duplicated (dem_processing.py:1031-1033)
+    std::vector<double> st((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        int64_t r = i - 1;
+        if (r < 0) r = 0;
+        if (r > n - 3) r = n - 3;
+        st[(size_t)i] = atan2(dY[r], dX[r]);
+    }
+    PYDEM_TRY(tile_alloc(t, &t->dX, (size_t)n)); PYDEM_TRY(tile_alloc(t, &t->dY, (size_t)n));
+    PYDEM_TRY(tile_alloc(t, &t->dX2, (size_t)n)); PYDEM_TRY(tile_alloc(t, &t->dY2, (size_t)n));
+    PYDEM_TRY(tile_alloc(t, &t->rowtab, (size_t)n)); PYDEM_TRY(tile_alloc(t, &t->sec_theta, (size_t)n));
+    HIP_TRY(hipMemcpyAsync(t->dX, dX, (n - 1) * 8, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->dY, dY, (n - 1) * 8, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->dX2, dX2, n * 8, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->dY2, dY2, n * 8, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->rowtab, tab.data(), (n - 1) * sizeof(RowTab), hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->sec_theta, st.data(), n * 8, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    t->spacing_set = true;
+    return 0;
+}
+
+int pydem_tile_upload(pydem_tile *t, int field, const void *src, int dtype)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    void **pp; size_t elem;
+    PYDEM_TRY(field_ptr(t, field, &pp, &elem));
+    PYDEM_TRY(ensure_field(t, field));
+    const size_t ds = dtype_size(dtype);
+    if (!ds) { pydem_set_error("unknown dtype %d", dtype); return -2; }
+    if (ds == elem && (elem == 1 || dtype == PYDEM_F64)) {
+        HIP_TRY(hipMemcpyAsync(*pp, src, (size_t)t->NN * elem, hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+    } else {
+        if (elem != 8) { pydem_set_error("dtype conversion is only supported for float64 fields"); return -2; }
+        const size_t bytes = (size_t)t->NN * ds;
+        if (t->scratch_bytes < bytes) {
+            if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->device_bytes -= (int64_t)t->scratch_bytes; }
+            HIP_TRY(hipMalloc(&t->scratch, bytes));
+            t->scratch_bytes = bytes; t->device_bytes += (int64_t)bytes;
+        }
+        HIP_TRY(hipMemcpyAsync(t->scratch, src, bytes, hipMemcpyHostToDevice, t->stream));
+        const int grid = (int)(cdiv(t->NN, 256) < 8192 ? cdiv(t->NN, 256) : 8192);
+        double *dst = (double *)*pp;
+        switch (dtype) {
+            case PYDEM_F32: hipLaunchKernelGGL(k_convert_to_f64<float>, dim3(grid), dim3(256), 0, t->stream, (const float *)t->scratch, dst, t->NN); break;
+            case PYDEM_I16: hipLaunchKernelGGL(k_convert_to_f64<int16_t>, dim3(grid), dim3(256), 0, t->stream, (const int16_t *)t->scratch, dst, t->NN); break;
+            case PYDEM_I32: hipLaunchKernelGGL(k_convert_to_f64<int32_t>, dim3(grid), dim3(256), 0, t->stream, (const int32_t *)t->scratch, dst, t->NN); break;
+            case PYDEM_U8: hipLaunchKernelGGL(k_convert_to_f64<uint8_t>, dim3(grid), dim3(256), 0, t->stream, (const uint8_t *)t->scratch, dst, t->NN); break;
+            case PYDEM_I8: hipLaunchKernelGGL(k_convert_to_f64<int8_t>, dim3(grid), dim3(256), 0, t->stream, (const int8_t *)t->scratch, dst, t->NN); break;
+            default: pydem_set_error("bad dtype"); return -2;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(t->stream));
+    }
+    t->have[field] = true;
+    return 0;
+}
+
+int pydem_tile_download(pydem_tile *t, int field, void *dst)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    void **pp; size_t elem;
+    PYDEM_TRY(field_ptr(t, field, &pp, &elem));
+    if (!*pp || !t->have[field]) { pydem_set_error("field %d has not been computed or uploaded", field); return -3; }
+    HIP_TRY(hipMemcpyAsync(dst, *pp, (size_t)t->NN * elem, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+int pydem_tile_synchronize(pydem_tile *t)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+int pydem_tile_timings(pydem_tile *t, pydem_timings *out) { *out = t->tm; return 0; }
+int64_t pydem_tile_device_bytes(pydem_tile *t) { return t->device_bytes; }
+
+int pydem_tile_synth_fractal(pydem_tile *t, uint32_t seed, int64_t row0, int64_t col0, int n_octaves,
+                             int top_shift, double zmin, double zrange)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(ensure_field(t, PYDEM_ELEV));
+    PYDEM_TRY(stage_synth(t, seed, row0, col0, n_octaves, top_shift, zmin, zrange));
+    t->have[PYDEM_ELEV] = true;
+    for (int f = PYDEM_MAG; f < PYDEM_FIELD_COUNT; f++) t->have[f] = false;
+    return 0;
+}
+
+static int need(pydem_tile *t, int field, const char *what)
+{
+    if (!t->have[field]) { pydem_set_error("%s: required input field %d is missing", what, field); return -3; }
+    return 0;
+}
+
+int pydem_slopes_directions(pydem_tile *t)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_slopes_directions"));
+    if (!t->spacing_set) { pydem_set_error("pydem_slopes_directions: call pydem_tile_set_spacing first"); return -3; }
+    PYDEM_TRY(ensure_fields(t, {PYDEM_MAG, PYDEM_DIRECTION, PYDEM_FLATS}));
+    PYDEM_TRY(tile_alloc(t, &t->flat0, (size_t)t->NN));
+    PYDEM_TRY(stage_stencil(t));
+    PYDEM_TRY(stage_flats(t));
+    t->have[PYDEM_MAG] = t->have[PYDEM_DIRECTION] = t->have[PYDEM_FLATS] = true;
+    return 0;
+}
+
+int pydem_find_flats(pydem_tile *t)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(need(t, PYDEM_MAG, "pydem_find_flats"));
+    PYDEM_TRY(ensure_field(t, PYDEM_FLATS));
+    const int grid = (int)(cdiv(t->NN, 256) < 8192 ? cdiv(t->NN, 256) : 8192);
+    hipLaunchKernelGGL(k_find_flats, dim3(grid), dim3(256), 0, t->stream, t->mag, t->flats, t->NN);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    t->have[PYDEM_FLATS] = true;
+    return 0;
+}
+
+int pydem_uca(pydem_tile *t, pydem_options *opt)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_uca"));
+    PYDEM_TRY(need(t, PYDEM_MAG, "pydem_uca"));
+    PYDEM_TRY(need(t, PYDEM_DIRECTION, "pydem_uca"));
+    PYDEM_TRY(need(t, PYDEM_FLATS, "pydem_uca"));
+    if (!t->spacing_set) { pydem_set_error("pydem_uca: call pydem_tile_set_spacing first"); return -3; }
+    PYDEM_TRY(ensure_fields(t, {PYDEM_SECTION, PYDEM_PROPORTION, PYDEM_UCA, PYDEM_EDGE_TODO, PYDEM_EDGE_DONE}));
+    PYDEM_TRY(stage_section_graph(t, opt));
+    PYDEM_TRY(stage_sweep(t, opt));
+    // record minimum area (dem_processing.py:897-899)
+    double mn = opt->twi_min_area;
+    for (int64_t i = 0; i < t->n; i++) {
+        const double a = t->h_dX2[(size_t)i] * t->h_dY2[(size_t)i];
+        if (a < mn) mn = a;
+    }
+    opt->twi_min_area = mn;
+    t->have[PYDEM_SECTION] = t->have[PYDEM_PROPORTION] = t->have[PYDEM_UCA] = true;
+    t->have[PYDEM_EDGE_TODO] = t->have[PYDEM_EDGE_DONE] = true;
+    return 0;
+}
+
+int pydem_uca_edge_update(pydem_tile *t, pydem_options *opt, const double *const data[4],
+                          const uint8_t *const done[4], const uint8_t *const todo[4])
+{
+    (void)t; (void)opt; (void)data; (void)done; (void)todo;
+    pydem_set_error("pydem_uca_edge_update: not implemented yet");
+    return -4;
+}
+
+int pydem_twi(pydem_tile *t, pydem_options *opt)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(need(t, PYDEM_UCA, "pydem_twi"));
+    PYDEM_TRY(need(t, PYDEM_MAG, "pydem_twi"));
+    PYDEM_TRY(ensure_field(t, PYDEM_TWI));
+    PYDEM_TRY(stage_twi(t, opt));
+    t->have[PYDEM_TWI] = true;
+    return 0;
+}
+
+int pydem_bench_stencil(pydem_tile *t, int iters, double *avg_ms)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_bench_stencil"));
+    if (!t->spacing_set) { pydem_set_error("pydem_bench_stencil: call pydem_tile_set_spacing first"); return -3; }
+    PYDEM_TRY(ensure_fields(t, {PYDEM_MAG, PYDEM_DIRECTION}));
+    PYDEM_TRY(tile_alloc(t, &t->flat0, (size_t)t->NN));
+    return bench_stencil(t, iters, avg_ms);
+}
+
+}  // extern "C"

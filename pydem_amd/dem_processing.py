@@ -1,0 +1,267 @@
+"""Drop-in `DEMProcessor` for the per-tile hot path, backed by the HIP library.
+
+Mirrors the public surface of the reference class (creare-com/pydem v1.2.1,
+pydem/dem_processing.py:98-258): same option names and defaults (:105-154), same constructor
+normalisation of scalar `dX`/`dY` (:229-242), same methods and result attributes
+(`mag, direction, flats, uca, twi, edge_todo, edge_done, section, proportion, twi_min_area`)
+and the same quirks (`calc_twi()` returns the un-scaled value while `self.twi` is x10, :1674-1677).
+The reference declares its options with traitlets; that package is not a dependency here, the
+options are plain attributes.
+
+All arithmetic runs on the GPU through the C-ABI (include/pydem_hip.h); arrays are uploaded once,
+stay resident, and are downloaded lazily the first time the corresponding attribute is read.
+"""
+import logging
+import warnings
+
+import numpy as np
+
+from . import _ffi
+
+logger = logging.getLogger(__name__)
+
+FLAT_ID = np.nan
+FLAT_ID_INT = -1
+
+_FIELD_OF = {'elev': _ffi.ELEV, 'mag': _ffi.MAG, 'direction': _ffi.DIRECTION, 'flats': _ffi.FLATS,
+             'section': _ffi.SECTION, 'proportion': _ffi.PROPORTION, 'uca': _ffi.UCA,
+             'edge_todo': _ffi.EDGE_TODO, 'edge_done': _ffi.EDGE_DONE}
+_BOOL_FIELDS = ('flats', 'edge_todo', 'edge_done')
+
+
+class _Resident(object):
+    """Attribute whose value lives on the device until somebody reads it."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __get__(self, obj, objtype=None):
+        if obj is None:
+            return self
+        if self.name not in obj._host and self.name in obj._on_device:
+            arr = obj._tile.download(_FIELD_OF[self.name])
+            if self.name in _BOOL_FIELDS:
+                arr = arr.astype(bool)
+            obj._host[self.name] = arr
+        return obj._host.get(self.name)
+
+    def __set__(self, obj, value):
+        obj._on_device.discard(self.name)
+        if value is None:
+            obj._host.pop(self.name, None)
+        else:
+            obj._host[self.name] = np.asarray(value)
+
+
+class DEMProcessor(object):
+    """Slope magnitude, D-infinity direction, upstream contributing area and TWI of one DEM tile."""
+
+    # ---- options: names and defaults of the reference (dem_processing.py:105-154) ----
+    fill_flats = True
+    fill_flats_below_sea = False
+    fill_flats_source_tol = 1
+    fill_flats_peaks = True
+    fill_flats_pits = True
+    fill_flats_max_iter = 10
+
+    drain_pits = True
+    drain_pits_path = True
+    drain_pits_min_border = False
+    drain_pits_spill = False
+    drain_flats = False
+    drain_pits_max_iter = 300
+    drain_pits_max_dist = 32
+    drain_pits_max_dist_XY = None
+
+    apply_uca_limit_edges = False
+    apply_twi_limits = False
+    apply_twi_limits_on_uca = False
+
+    plotflag = False
+    uca_saturation_limit = 32.0
+    twi_min_slope = 1e-3
+    twi_min_area = np.inf
+    circular_ref_maxcount = 50
+    maximum_pit_area = 32.0
+
+    # facet geometry, identical to the reference tables (:173-193)
+    facets = [
+        [(0, 0), (0, 1), (-1, 1)],
+        [(0, 0), (-1, 0), (-1, 1)],
+        [(0, 0), (-1, 0), (-1, -1)],
+        [(0, 0), (0, -1), (-1, -1)],
+        [(0, 0), (0, -1), (1, -1)],
+        [(0, 0), (1, 0), (1, -1)],
+        [(0, 0), (1, 0), (1, 1)],
+        [(0, 0), (0, 1), (1, 1)],
+    ]
+    ang_adj = np.array([[0, 1], [1, -1], [1, 1], [2, -1], [2, 1], [3, -1], [3, 1], [4, -1]])
+
+    _OPTION_NAMES = ('fill_flats', 'fill_flats_below_sea', 'fill_flats_source_tol', 'fill_flats_peaks',
+                     'fill_flats_pits', 'fill_flats_max_iter', 'drain_pits', 'drain_pits_path',
+                     'drain_pits_min_border', 'drain_pits_spill', 'drain_flats', 'drain_pits_max_iter',
+                     'drain_pits_max_dist', 'drain_pits_max_dist_XY', 'apply_uca_limit_edges',
+                     'apply_twi_limits', 'apply_twi_limits_on_uca', 'plotflag', 'uca_saturation_limit',
+                     'twi_min_slope', 'twi_min_area', 'circular_ref_maxcount', 'maximum_pit_area',
+                     'bounds', 'transform', 'done')
+
+    elev = _Resident('elev')
+    mag = _Resident('mag')
+    direction = _Resident('direction')
+    flats = _Resident('flats')
+    section = _Resident('section')
+    proportion = _Resident('proportion')
+    uca = _Resident('uca')
+    edge_todo = _Resident('edge_todo')
+    edge_done = _Resident('edge_done')
+
+    def __init__(self, elev_fn=None, device=0, **kwargs):
+        if elev_fn:
+            raise NotImplementedError("raster IO is outside the accelerated path: pass elev=array, dX=, dY= "
+                                      "(reference: utils.dem_processor_from_raster_kwargs)")
+        if kwargs.get('elev') is None:
+            raise ValueError("DEMProcessor needs an elevation array (elev=...)")
+        n_rows = np.shape(kwargs['elev'])[0]
+        # scalar / missing spacing -> per-row arrays (reference :233-240, defaults :244-258)
+        if not isinstance(kwargs.get('dX'), np.ndarray):
+            if 'dX2' not in kwargs:
+                kwargs['dX2'] = np.ones(n_rows) * kwargs.get('dX', 1)
+            kwargs['dX'] = np.ones(n_rows - 1) * kwargs.get('dX', 1)
+        if not isinstance(kwargs.get('dY'), np.ndarray):
+            if 'dY2' not in kwargs:
+                kwargs['dY2'] = np.ones(n_rows) * kwargs.get('dY', 1)
+            kwargs['dY'] = np.ones(n_rows - 1) * kwargs.get('dY', 1)
+        self._host = {}
+        self._on_device = set()
+        self._uploaded = set()
+        self._tile = None
+        self._device = device
+        self.twi = None
+        self.A = None
+        self.bounds = []
+        self.transform = []
+        self.done = None
+        self.dX = np.array(kwargs.pop('dX'), dtype='float64')
+        self.dY = np.array(kwargs.pop('dY'), dtype='float64')
+        self.dX2 = np.array(kwargs.pop('dX2', np.ones(n_rows)), dtype='float64')
+        self.dY2 = np.array(kwargs.pop('dY2', np.ones(n_rows)), dtype='float64')
+        for k, v in kwargs.items():
+            if k in _FIELD_OF:
+                setattr(self, k, v)
+            elif k == 'twi':
+                self.twi = None if v is None else np.asarray(v)
+            elif k in self._OPTION_NAMES:
+                setattr(self, k, v)
+            # unknown keywords are dropped, as traitlets' HasTraits.__init__ does
+
+    # ------------------------------------------------------------------ device plumbing
+    def _ensure_tile(self):
+        if self._tile is None:
+            n, m = self.elev.shape
+            self._tile = _ffi.Tile(n, m, self._device)
+        # the reference lets callers overwrite dX/dY after construction (process_manager.py:59-63)
+        self._tile.set_spacing(self.dX, self.dY, self.dX2, self.dY2)
+        return self._tile
+
+    def _push(self, *names):
+        """Upload host-side fields that the device does not hold yet."""
+        tile = self._tile
+        for nm in names:
+            if nm in self._on_device:
+                continue
+            arr = self._host.get(nm)
+            if arr is None:
+                raise RuntimeError("field %r is required but has not been set or computed" % nm)
+            tile.upload(_FIELD_OF[nm], arr)
+            self._on_device.add(nm)
+
+    def _produced(self, *names):
+        for nm in names:
+            self._host.pop(nm, None)
+            self._on_device.add(nm)
+
+    def _options(self):
+        o = _ffi.Options()
+        o.drain_pits = int(bool(self.drain_pits))
+        o.drain_pits_min_border = int(bool(self.drain_pits_min_border))
+        o.drain_pits_max_iter = int(self.drain_pits_max_iter)
+        o.drain_pits_max_dist = int(self.drain_pits_max_dist or 0)
+        o.drain_pits_max_dist_XY = float(self.drain_pits_max_dist_XY) if self.drain_pits_max_dist_XY else float('nan')
+        o.apply_uca_limit_edges = int(bool(self.apply_uca_limit_edges))
+        o.apply_twi_limits = int(bool(self.apply_twi_limits))
+        o.apply_twi_limits_on_uca = int(bool(self.apply_twi_limits_on_uca))
+        o.circular_ref_maxcount = int(self.circular_ref_maxcount)
+        o.uca_saturation_limit = float(self.uca_saturation_limit)
+        o.twi_min_slope = float(self.twi_min_slope)
+        o.twi_min_area = float(self.twi_min_area)
+        return o
+
+    def _has(self, name):
+        return name in self._on_device or self._host.get(name) is not None
+
+    @property
+    def timings(self):
+        return self._tile.timings() if self._tile is not None else {}
+
+    # ------------------------------------------------------------------ reference API
+    def find_flats(self):
+        """flats = (mag == -1)  (reference :305-306)"""
+        self._ensure_tile()
+        self._push('mag')
+        self._tile.find_flats()
+        self._produced('flats')
+
+    def calc_fill_flats(self):
+        raise NotImplementedError("elevation conditioning (calc_fill_flats, reference :551-579) is not part of "
+                                  "the device path yet; construct with fill_flats=False")
+
+    def calc_pit_drain_paths(self):
+        raise NotImplementedError("elevation conditioning (calc_pit_drain_paths, reference :428-548) is not part "
+                                  "of the device path yet; construct with drain_pits_path=False")
+
+    def calc_slopes_directions(self, plotflag=False):
+        """Slope magnitude and D-infinity direction (reference :587-619)."""
+        if self.fill_flats:
+            self.calc_fill_flats()
+        if self.drain_pits_path:
+            self.calc_pit_drain_paths()
+        self._ensure_tile()
+        self._push('elev')
+        logger.info("Starting slope/direction calculation")
+        self._tile.slopes_directions()
+        self._produced('mag', 'direction', 'flats')
+        return self.mag, self.direction
+
+    def calc_uca(self, plotflag=False, edge_init_data=None, uca_init=None):
+        """Upstream contributing area (reference :682-776)."""
+        if not self._has('direction'):
+            self.calc_slopes_directions()
+        if uca_init is not None or edge_init_data is not None:
+            raise NotImplementedError("edge-resolution rounds (uca_init / edge_init_data) are not on the device yet")
+        self._ensure_tile()
+        self._push('elev', 'mag', 'direction', 'flats')
+        opt = self._options()
+        logger.info("Starting uca calculation")
+        self._tile.uca(opt)
+        tm = self._tile.timings()
+        if tm['n_unresolved']:
+            raise RuntimeError("%d cells lie on or below a circular drainage pattern; the reference's re-seeding "
+                               "loop (dem_processing.py:951-964) is not reproduced on the device yet"
+                               % tm['n_unresolved'])
+        if tm['n_pits_undrained']:
+            warnings.warn("Warning %d pits had no place to drain to in this chunk" % tm['n_pits_undrained'])
+        self.twi_min_area = min(self.twi_min_area, opt.twi_min_area)
+        # pits that found a drain are patched into mag/flats by the graph stage (reference :1369-1371)
+        self._produced('section', 'proportion', 'uca', 'edge_todo', 'edge_done', 'mag', 'flats')
+        return self.uca
+
+    def calc_twi(self):
+        """Topographic wetness index; returns the un-scaled array, stores 10x in self.twi (:1647-1677)."""
+        if not self._has('uca'):
+            self.calc_uca()
+        self._ensure_tile()
+        self._push('uca', 'mag')
+        self._tile.twi(self._options())
+        twi = self._tile.download(_ffi.TWI)
+        self.twi = twi * 10
+        return twi
