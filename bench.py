@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark: Mcells/s of the per-tile terrain hot path
+(slope + aspect + flats + section/proportion + UCA sweep + TWI) on synthetic DEM tiles.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json: the metric is quoted on the 16384x16384 fp64 tile, configs[2]): every
+rank owns ONE 16384x16384 float64 fractal tile (deterministic generator, evaluated at the tile's
+global mosaic coordinates, generated on the device so the input is HBM-resident before the timed
+region).  One step = one full pass of the hot path over the resident tile
+(pydem_slopes_directions + pydem_uca + pydem_twi through the C-ABI).  Tiles are independent
+units: weak scaling, no data-path collective in the timed region (the cross-tile edge fix-up is
+a separate, latency-bound exchange -- DESIGN.md).
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live: the interior stencil kernel is
+re-launched `--roof-iters` times on the tile's own HIP stream between hipEvents
+(pydem_bench_stencil); algorithmic bytes = 24 B/cell (read elev 8 + write mag 8 + direction 8,
+SURVEY.md section 8d).  `cpu_baseline` times the CPU oracle (a port of the reference algorithm,
+bit-exact against golden vectors of the reference) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+STENCIL_BYTES_PER_CELL = 24.0
+E2E_BYTES_PER_CELL = 40.0      # read elev 8 + write mag, direction, uca, twi 32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--size', type=int, default=16384, help='tile edge (cells)')
+    ap.add_argument('--drain-pits', type=int, default=int(os.environ.get('PYDEM_BENCH_DRAIN_PITS', '0')))
+    ap.add_argument('--roof-iters', type=int, default=20)
+    ap.add_argument('--cpu-sample', type=int, default=2560, help='edge of the CPU-baseline sample tile (0 = skip)')
+    return ap.parse_args()
+
+
+def make_options(_ffi, drain_pits):
+    o = _ffi.Options()
+    o.drain_pits = int(drain_pits)
+    o.drain_pits_min_border = 0
+    o.drain_pits_max_iter = 300
+    o.drain_pits_max_dist = 32
+    o.drain_pits_max_dist_XY = float('nan')
+    o.apply_uca_limit_edges = 0
+    o.apply_twi_limits = 0
+    o.apply_twi_limits_on_uca = 0
+    o.circular_ref_maxcount = 50
+    o.uca_saturation_limit = 32.0
+    o.twi_min_slope = 1e-3
+    o.twi_min_area = float('inf')
+    return o
+
+
+def cpu_baseline(size, seed, drain_pits):
+    """The oracle (port of the reference's algorithm) on one size x size tile of the same generator."""
+    from oracle import oracle as O
+    z = O.synth_fractal(size, size, seed=seed)
+    t0 = time.perf_counter()
+    o = O.OracleDEM(z, dX=30.0, dY=30.0, drain_pits=bool(drain_pits))
+    o.calc_twi()
+    dt = time.perf_counter() - t0
+    return {"value": size * size / dt / 1e6, "unit": "Mcells/s", "cores": 1, "kind": "port",
+            "sample": "one %dx%d fp64 fractal tile (seed %d), full path, %.1f s, single thread "
+                      "(the reference is single-threaded per tile); host has %d cores"
+                      % (size, size, seed, dt, os.cpu_count())}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        # process-group plumbing only (barrier + max over ranks); the data path never touches torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+
+    from pydem_amd import _ffi
+    n = m = args.size
+    ndev = _ffi.device_count()
+    tile = _ffi.Tile(n, m, device=local_rank % ndev)
+    import numpy as np
+    tile.set_spacing(np.full(n - 1, 30.0), np.full(n - 1, 30.0), np.full(n, 30.0), np.full(n, 30.0))
+    # rank r owns mosaic tile (r // 4, r % 4) of a 2 x 4 grid with a one-pixel overlap (config 4 layout)
+    row0 = (rank // 4) * (n - 1)
+    col0 = (rank % 4) * (m - 1)
+    tile.synth_fractal(seed=1, row0=row0, col0=col0)
+    opt = make_options(_ffi, args.drain_pits)
+
+    def step():
+        tile.slopes_directions()
+        tile.uca(opt)
+        tile.twi(opt)
+
+    def barrier():
+        tile.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    tile.synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    tm = tile.timings()
+    if tm['n_unresolved']:
+        raise SystemExit("bench: %d cells unresolved (cyclic drainage) -- result invalid" % tm['n_unresolved'])
+
+    if rank == 0:
+        cells = float(n) * m
+        value = world * cells * args.steps / dt / 1e6
+        st_ms = tile.bench_stencil(args.roof_iters)
+        achieved = STENCIL_BYTES_PER_CELL * cells / (st_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mcells/s (slope+aspect+UCA+TWI end-to-end) per tile; % HBM roofline",
+            "value": value, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%dx%d fp64 fractal tile per GPU (seed 1, dX=dY=30 m), fill_flats=False, "
+                                   "drain_pits_path=False, drain_pits=%s: slopes_directions + uca + twi"
+                                   % (n, m, bool(args.drain_pits)),
+                       "tile": [n, m], "tiles_per_gpu": 1, "parallelism": "tile-per-gpu x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_stencil_interior", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_kernel_ms": st_ms, "algorithmic_bytes_per_cell": STENCIL_BYTES_PER_CELL},
+            "end_to_end_GBs": E2E_BYTES_PER_CELL * cells * args.steps / dt / 1e9,
+            "stages_ms": {k: tm[k] for k in ('slopes_directions_ms', 'stencil_kernel_ms', 'flats_ms', 'graph_ms',
+                                              'pits_ms', 'sweep_ms', 'twi_ms')},
+            "sweep": {"rounds": tm['sweep_rounds'], "kernel_launches": tm['sweep_kernel_launches'],
+                      "n_flats": tm['n_flats'], "n_pit_edges": tm['n_pit_edges']},
+            "device_bytes": tile.device_bytes(),
+        }
+        if args.cpu_sample:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1, args.drain_pits)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

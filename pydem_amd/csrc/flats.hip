@@ -16,21 +16,51 @@ namespace {
 
 #define RLX_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-// stream compaction of flat0 != 0 into a list of cell ids: per-wave ballot + one atomic per wave
+// stream compaction of flat0 != 0 into a list of cell ids.  Each thread reads 16 mask bytes with
+// one 16 B load; ranks come from a wavefront prefix (shuffles) plus a per-block LDS prefix over
+// the 4 waves, and the block reserves its output range with ONE global atomic per 4096 cells
+// (a first version issued one atomic per wavefront on a single address: 22 ms at 16384^2).
 __global__ __launch_bounds__(256) void k_compact_flats(const uint8_t *__restrict__ flat0, int64_t NN,
                                                        int32_t *__restrict__ list, int32_t *__restrict__ count)
 {
-    const int lane = threadIdx.x & 63;
-    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + (threadIdx.x - lane)); base < NN;
-         base += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t c = base + lane;
-        const bool f = (c < NN) && flat0[c];
-        const unsigned long long bal = __ballot(f);
-        if (bal == 0ull) continue;
-        int32_t off = 0;
-        if (lane == 0) off = atomicAdd(count, (int32_t)__popcll(bal));
-        off = __shfl(off, 0);
-        if (f) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)c;
+    __shared__ int32_t wave_tot[4];
+    __shared__ int32_t blk_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 4096; base < NN; base += (int64_t)gridDim.x * 4096) {
+        const int64_t c0 = base + (int64_t)threadIdx.x * 16;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (c0 + 16 <= NN) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(flat0 + c0);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+            for (int k = 0; k < 16; k++)
+                if (c0 + k < NN && flat0[c0 + k]) w[k >> 2] |= 1u << (8 * (k & 3));
+        }
+        uint32_t bits = 0;   // bit k set <=> cell c0+k is flat
+#pragma unroll
+        for (int k = 0; k < 16; k++) bits |= (((w[k >> 2] >> (8 * (k & 3))) & 0xffu) ? 1u : 0u) << k;
+        const int32_t mine = __popc(bits);
+        int32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            blk_base = tot ? atomicAdd(count, tot) : 0;
+        }
+        __syncthreads();
+        int32_t off = blk_base + incl - mine;
+        for (int k = 0; k < wave; k++) off += wave_tot[k];
+        while (bits) {
+            const int k = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            list[off++] = (int32_t)(c0 + k);
+        }
+        __syncthreads();
     }
 }
 

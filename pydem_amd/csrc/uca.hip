@@ -73,7 +73,7 @@ __device__ __forceinline__ bool keep_edge(double w, double z_to, double z_from)
 __global__ __launch_bounds__(256) void k_build_graph(const int8_t *__restrict__ section, const double *__restrict__ prop,
                                                      const double *__restrict__ elev, int n, int m,
                                                      uint8_t *__restrict__ inmask, uint8_t *__restrict__ gflags,
-                                                     int32_t *__restrict__ indeg, uint8_t *__restrict__ todo0,
+                                                     int32_t *__restrict__ level, uint8_t *__restrict__ todo0,
                                                      uint8_t *__restrict__ todo_work, double *__restrict__ corner_sums)
 {
     const int64_t NN = (int64_t)n * m;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_build_graph(const int8_t *__restrict__ 
         }
         inmask[c] = im;
         gflags[c] = gf;
-        indeg[c] = __popc((unsigned)im);
+        level[c] = im ? 0x7fffffff : 0;   // sources (no in-edges) are round 0
         // inlet-edge detection (_calc_uca_chunk :909-930); interior cells are never 'todo'
         const bool top = i == 0, bot = i == n - 1, left = j == 0, right = j == m - 1;
         if (top || bot || left || right) {
@@ -133,11 +133,11 @@ __global__ __launch_bounds__(256) void k_build_graph(const int8_t *__restrict__ 
 // pit edges contribute to in-degrees, flags and the corner sums
 __global__ void k_graph_add_pits(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
                                  const double *__restrict__ w, int64_t ne, int n, int m,
-                                 uint8_t *gflags, int32_t *indeg, double *corner_sums)
+                                 uint8_t *gflags, int32_t *level, double *corner_sums)
 {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (int64_t)gridDim.x * blockDim.x) {
         const int32_t s = src[e], d = dst[e];
-        atomicAdd(&indeg[d], 1);
+        level[d] = 0x7fffffff;   // a pit drains here: not a source
         atomicOr((unsigned *)(gflags + (s & ~3)), (unsigned)GF_PIT_OUT << (8 * (s & 3)));
         atomicOr((unsigned *)(gflags + (d & ~3)), (unsigned)GF_PIT_IN << (8 * (d & 3)));
         const int corners[4] = {0, m - 1, (n - 1) * m, (n - 1) * m + m - 1};
@@ -164,18 +164,18 @@ __global__ void k_corner_todo(const double *__restrict__ corner_sums, const doub
 }
 
 // ------------------------------------------------------------------------------- K5
-// wave-aggregated append to the next frontier: one atomic per wavefront
-__device__ __forceinline__ void frontier_push(bool pred, int32_t cell, int32_t *__restrict__ q, int32_t *cnt)
-{
-    const unsigned long long bal = __ballot(pred);
-    if (bal == 0ull) return;
-    const int lane = (int)__lane_id();
-    const int leader = __ffsll((long long)bal) - 1;
-    int32_t base = 0;
-    if (lane == leader) base = atomicAdd(cnt, (int32_t)__popcll(bal));
-    base = __shfl(base, leader);
-    if (pred) q[base + __popcll(bal & ((1ull << lane) - 1ull))] = cell;
-}
+// Frontier bookkeeping without per-edge atomics.  level[c] is the round in which cell c is
+// processed (0 for sources, LEVEL_INF while unknown).  When cell u (level r) is final it looks at
+// each target t: t is ready for round r+1 iff every upstream cell of t has level <= r, and exactly
+// one of t's upstream cells with level == r -- the one with the largest cell id -- appends t to
+// the next frontier and stamps level[t] = r+1.  All level-r stamps were written by the previous
+// launch, so the test reads only settled values; the in-degree counters (and their ~1.4 device
+// atomics per cell) of a textbook Kahn sweep disappear.  The frontier itself is appended through
+// an LDS staging buffer: wavefront ballot + popcount prefix, one LDS atomic per wave, and one
+// global atomic per ~1.5k cells when the buffer is flushed.
+constexpr int32_t LEVEL_INF = 0x7fffffff;
+constexpr int STAGE_CAP = 2048;      // LDS staging entries per block
+constexpr int STAGE_FLUSH = 1536;    // flush when fewer than 2*256 slots remain
 
 struct SweepArgs {
     const uint8_t *inmask, *gflags;
@@ -183,7 +183,7 @@ struct SweepArgs {
     const double *prop, *a0;     // a0[i] = dX2[i]*dY2[i]
     double *area;
     uint8_t *todo_work;
-    int32_t *indeg;
+    int32_t *level;
     int n, m;
     // pit side lists
     const int32_t *pit_src, *pit_dst;   // out-edges sorted by src
@@ -198,23 +198,86 @@ __device__ __forceinline__ int64_t lower_bound_i32(const int32_t *a, int64_t n, 
     return lo;
 }
 
-// after cell c is final: release its out-edges; targets whose in-degree drops to 0 join `qn`
-__device__ __forceinline__ void release_targets(const SweepArgs &A, bool active, int32_t c, uint8_t gf, int s,
-                                                int32_t *__restrict__ qn, int32_t *cn)
+struct Stage {
+    int32_t buf[STAGE_CAP];
+    int32_t cnt;
+    int32_t base;
+};
+
+// wave-aggregated append into the block's LDS staging buffer
+__device__ __forceinline__ void stage_push(Stage &S, bool pred, int32_t cell)
+{
+    const unsigned long long bal = __ballot(pred);
+    if (bal == 0ull) return;
+    const int lane = (int)__lane_id();
+    const int leader = __ffsll((long long)bal) - 1;
+    int32_t base = 0;
+    if (lane == leader) base = atomicAdd(&S.cnt, (int32_t)__popcll(bal));
+    base = __shfl(base, leader);
+    if (pred) S.buf[base + __popcll(bal & ((1ull << lane) - 1ull))] = cell;
+}
+
+// block-wide: move the staged cells to the global frontier (call from uniform control flow)
+__device__ __forceinline__ void stage_flush(Stage &S, int32_t *__restrict__ qn, int32_t *cn, bool force)
+{
+    __syncthreads();
+    const int32_t c = S.cnt;
+    if (c > 0 && (force || c > STAGE_FLUSH)) {
+        if (threadIdx.x == 0) S.base = atomicAdd(cn, c);
+        __syncthreads();
+        const int32_t b = S.base;
+        for (int32_t k = threadIdx.x; k < c; k += blockDim.x) qn[b + k] = S.buf[k];
+        __syncthreads();
+        if (threadIdx.x == 0) S.cnt = 0;
+    }
+    __syncthreads();
+}
+
+// does upstream cell u (level r) own the hand-off of target t to round r+1?
+__device__ __forceinline__ bool owns_target(const SweepArgs &A, int32_t t, int32_t u, int32_t r)
+{
+    const uint8_t im = A.inmask[t];
+    int32_t owner = -1;
+    bool ready = true;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        if (im & (1u << d)) {
+            const int32_t v = t + NB_DI[d] * A.m + NB_DJ[d];
+            const int32_t lv = A.level[v];
+            ready = ready && (lv <= r);
+            if (lv == r) owner = v > owner ? v : owner;
+        }
+    }
+    if (A.gflags[t] & GF_PIT_IN) {
+        const int64_t k = lower_bound_i32(A.pin_cell, A.n_pin_cells, t);
+        for (int32_t e = A.pin_ptr[k]; e < A.pin_ptr[k + 1]; e++) {
+            const int32_t v = A.pin_src[e];
+            const int32_t lv = A.level[v];
+            ready = ready && (lv <= r);
+            if (lv == r) owner = v > owner ? v : owner;
+        }
+    }
+    return ready && owner == u;
+}
+
+// after cell c (level r) is final: hand its ready targets to the next frontier
+__device__ __forceinline__ void release_targets(const SweepArgs &A, Stage &S, bool active, int32_t c, uint8_t gf, int s,
+                                                int32_t r, int32_t *__restrict__ qn, int32_t *cn)
 {
     const int m = A.m;
     int32_t t1 = -1, t2 = -1;
     if (active && (gf & GF_OUT1)) t1 = c + fe1r(s) * m + fe1c(s);
     if (active && (gf & GF_OUT2)) t2 = c + fe2r(s) * m + fe2c(s);
-    bool r1 = false, r2 = false;
-    if (t1 >= 0) r1 = atomicSub(&A.indeg[t1], 1) == 1;
-    if (t2 >= 0) r2 = atomicSub(&A.indeg[t2], 1) == 1;
-    frontier_push(r1, t1, qn, cn);
-    frontier_push(r2, t2, qn, cn);
+    const bool r1 = t1 >= 0 && owns_target(A, t1, c, r);
+    const bool r2 = t2 >= 0 && owns_target(A, t2, c, r);
+    if (r1) A.level[t1] = r + 1;
+    if (r2) A.level[t2] = r + 1;
+    stage_push(S, r1, t1);
+    stage_push(S, r2, t2);
     if (active && (gf & GF_PIT_OUT)) {                                           // rare: drained pit
         for (int64_t e = lower_bound_i32(A.pit_src, A.n_pit, c); e < A.n_pit && A.pit_src[e] == c; e++) {
             const int32_t t = A.pit_dst[e];
-            if (atomicSub(&A.indeg[t], 1) == 1) qn[atomicAdd(cn, 1)] = t;
+            if (owns_target(A, t, c, r)) { A.level[t] = r + 1; qn[atomicAdd(cn, 1)] = t; }
         }
     }
 }
@@ -222,25 +285,30 @@ __device__ __forceinline__ void release_targets(const SweepArgs &A, bool active,
 // round 0: every cell without in-edges is a source (ids = colsum == 0, :882-883): area = dX2*dY2
 __global__ __launch_bounds__(256) void k_sweep_sources(SweepArgs A, int32_t *__restrict__ qn, int32_t *cn, int32_t *nsrc)
 {
+    __shared__ Stage S;
+    if (threadIdx.x == 0) S.cnt = 0;
+    __syncthreads();
     const int64_t NN = (int64_t)A.n * A.m;
-    const int64_t nwork = (NN + 63) & ~63ll;            // whole wavefronts so ballots see all lanes
     int32_t mine = 0;
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < nwork; c += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < NN; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = base + threadIdx.x;
         bool src = false;
         uint8_t gf = 0; int s = -1;
         if (c < NN) {
-            gf = A.gflags[c];
-            src = (A.inmask[c] == 0) && !(gf & GF_PIT_IN);
-            if (src) { A.area[c] = A.a0[c / A.m]; s = A.section[c]; mine++; }
+            src = A.level[c] == 0;
+            if (src) { gf = A.gflags[c]; A.area[c] = A.a0[c / A.m]; s = A.section[c]; mine++; }
         }
-        release_targets(A, src, (int32_t)c, gf, s, qn, cn);
+        release_targets(A, S, src, (int32_t)c, gf, s, 0, qn, cn);
+        stage_flush(S, qn, cn, false);
     }
+    stage_flush(S, qn, cn, true);
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(nsrc, mine);
 }
 
 // rounds >= 1: pull, store, release
-__device__ __forceinline__ void process_cell(const SweepArgs &A, bool active, int32_t c, int32_t *__restrict__ qn, int32_t *cn)
+__device__ __forceinline__ void process_cell(const SweepArgs &A, Stage &S, bool active, int32_t c, int32_t r,
+                                             int32_t *__restrict__ qn, int32_t *cn)
 {
     uint8_t gf = 0; int s = -1;
     if (active) {
@@ -273,23 +341,28 @@ __device__ __forceinline__ void process_cell(const SweepArgs &A, bool active, in
         A.area[c] = acc;
         A.todo_work[c] = td;
     }
-    release_targets(A, active, c, gf, s, qn, cn);
+    release_targets(A, S, active, c, gf, s, r, qn, cn);
 }
 
 // one frontier round; counters rotate over 3 slots: in = r%3, out = (r+1)%3, (r+2)%3 is cleared
 __global__ __launch_bounds__(256) void k_sweep_round(SweepArgs A, const int32_t *__restrict__ qc, int32_t *__restrict__ qn,
                                                      int32_t *cnt3, int r, int32_t *total)
 {
+    __shared__ Stage S;
     const int32_t nq = cnt3[r % 3];
     if (blockIdx.x == 0 && threadIdx.x == 0) { cnt3[(r + 2) % 3] = 0; if (nq) { atomicAdd(total, nq); atomicAdd(total + 2, 1); } }
     if (nq == 0) return;
+    if (threadIdx.x == 0) S.cnt = 0;
+    __syncthreads();
     int32_t *cn = &cnt3[(r + 1) % 3];
-    const int32_t nwork = (nq + 63) & ~63;
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nwork; q += gridDim.x * blockDim.x) {
+    for (int32_t base = blockIdx.x * blockDim.x; base < nq; base += gridDim.x * blockDim.x) {
+        const int32_t q = base + threadIdx.x;
         const bool active = q < nq;
         const int32_t c = active ? qc[q] : 0;
-        process_cell(A, active, c, qn, cn);
+        process_cell(A, S, active, c, r, qn, cn);
+        stage_flush(S, qn, cn, false);
     }
+    stage_flush(S, qn, cn, true);
 }
 
 __global__ void k_row_area(const double *__restrict__ dX2, const double *__restrict__ dY2, int n, double *a0)
@@ -382,7 +455,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     hipLaunchKernelGGL(k_row_area, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, t->stream, t->dX2, t->dY2, n, t->row_area);
     SweepArgs A;
     A.inmask = t->inmask; A.gflags = t->gflags; A.section = t->section; A.prop = t->prop; A.a0 = t->row_area;
-    A.area = t->uca; A.todo_work = t->todo_work; A.indeg = t->indeg; A.n = n; A.m = m;
+    A.area = t->uca; A.todo_work = t->todo_work; A.level = t->indeg; A.n = n; A.m = m;
     A.pit_src = t->pits.src; A.pit_dst = t->pits.dst; A.n_pit = t->pits.n_edges;
     A.pin_cell = t->pits.in_cell; A.pin_ptr = t->pits.in_ptr; A.pin_src = t->pits.in_src; A.pin_w = t->pits.in_w;
     A.n_pin_cells = t->pits.n_in_cells;
