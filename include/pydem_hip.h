@@ -17,8 +17,6 @@
  *                             _calc_uca_chunk_update :778-862, cyutils.drain_connections
  *                             pydem/cyfuncs/cyutils.pyx:35-72
  *   pydem_twi                 DEMProcessor.calc_twi                pydem/dem_processing.py:1647-1677
- *   pydem_drain_area /        the reference's only native boundary, kept callable with flat arrays:
- *   pydem_drain_connections   cyutils.drain_area / drain_connections (cyutils.pyx:78-116, :35-46)
  *
  * Ownership: the caller owns every host buffer it passes; the library owns device memory behind
  * the opaque pydem_tile handle (create / upload / run / download / destroy).  Nothing allocated
@@ -117,6 +115,11 @@ int pydem_uca_edge_update(pydem_tile *t, pydem_options *opt,
                           const double *const data[4], const uint8_t *const done[4],
                           const uint8_t *const todo[4]);
 int pydem_twi(pydem_tile *t, pydem_options *opt);
+
+/* The pit -> drain triplets built by the last pydem_uca (the reference's local pit_i, pit_j,
+ * pit_prop, pydem/dem_processing.py:1378-1380), in emission order.  Call with src == NULL to get
+ * the count. */
+int pydem_tile_pit_edges(pydem_tile *t, int64_t *n, int32_t *src, int32_t *dst, double *w);
 
 /* Kernel-only timing hook for bench.py: runs the interior stencil `iters` times on the tile's
  * resident elevation and returns the average kernel time (ms) measured with hipEvents on the

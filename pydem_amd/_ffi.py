@@ -65,6 +65,7 @@ SYMBOLS = {
     'pydem_uca': (C.c_int, [_P, C.POINTER(Options)]),
     'pydem_uca_edge_update': (C.c_int, [_P, C.POINTER(Options), _PP, _PP, _PP]),
     'pydem_twi': (C.c_int, [_P, C.POINTER(Options)]),
+    'pydem_tile_pit_edges': (C.c_int, [_P, C.POINTER(C.c_int64), _P, _P, _P]),
     'pydem_bench_stencil': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
 }
 
@@ -159,6 +160,16 @@ class Tile(object):
 
     def twi(self, opt):
         check(self.lib.pydem_twi(self._h, C.byref(opt)))
+
+    def pit_edges(self):
+        """(pit, drain, weight) triplets of the last uca() call, in emission order."""
+        n = C.c_int64(0)
+        check(self.lib.pydem_tile_pit_edges(self._h, C.byref(n), None, None, None))
+        src = np.empty(n.value, np.int32); dst = np.empty(n.value, np.int32); w = np.empty(n.value, np.float64)
+        if n.value:
+            check(self.lib.pydem_tile_pit_edges(self._h, C.byref(n), src.ctypes.data_as(_P), dst.ctypes.data_as(_P),
+                                                w.ctypes.data_as(_P)))
+        return src, dst, w
 
     def bench_stencil(self, iters):
         ms = C.c_double(0)

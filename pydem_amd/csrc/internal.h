@@ -40,18 +40,14 @@ struct RowTab {
     double pad[3];
 };
 
-// pit -> drain edges (COO, sorted by pit then drain) and their CSR-by-target view
+// pit -> drain edges: raw triplets as emitted (the reference's pit_i, pit_j, pit_prop) and two
+// sorted views of the edges that survive the adjacency keep-filter
 struct PitGraph {
-    int64_t n_edges = 0;
-    int32_t *src = nullptr;      // [n_edges] pit cell
-    int32_t *dst = nullptr;      // [n_edges] drain cell
-    double *w = nullptr;         // [n_edges] weight
-    // in-edge view, grouped by target cell
-    int32_t *in_cell = nullptr;  // [n_in_cells] distinct target cells (ascending)
-    int32_t *in_ptr = nullptr;   // [n_in_cells+1]
-    int32_t *in_src = nullptr;   // [n_edges] source pit of each in-edge
-    double *in_w = nullptr;      // [n_edges]
-    int64_t n_in_cells = 0;
+    int32_t *raw_src = nullptr, *raw_dst = nullptr; double *raw_w = nullptr;
+    int64_t raw_cap = 0, n_raw = 0;
+    int64_t n_edges = 0, sorted_cap = 0;       // kept edges
+    int32_t *src = nullptr, *dst = nullptr; double *w = nullptr;            // sorted by (src, dst)
+    int32_t *in_src = nullptr, *in_dst = nullptr; double *in_w = nullptr;   // sorted by (dst, src)
 };
 
 struct pydem_tile {

@@ -1,9 +1,540 @@
-// pits.hip -- pit -> drain assignment (placeholder until the device implementation lands)
+// pits.hip -- pit -> drain assignment on the device.
+//
+// Replaces _mk_connectivity_pits (reference pydem/dem_processing.py:1269-1382) with its helpers
+// utils.get_border_index (pydem/utils.py:313-340) and _get_dX_mean (:1993-1997).  The reference
+// walks the pits one by one in Python (402 k border recomputations with np.setdiff1d at 1024^2);
+// each pit is independent of the others, so here one WAVEFRONT owns one pit: the growing region
+// and its border live as bitmaps over a 64x64 cell window in LDS (a region can grow by at most one
+// cell of Chebyshev radius per iteration), lanes scan their slice of the window, minima are
+// wave-reduced with shuffles, and border updates use LDS atomics.  Pits whose region leaves the
+// window (or with too many drains) are re-run by a whole WORKGROUP with a 640x640 window -- large
+// enough for drain_pits_max_iter <= 300 always.  Integer work (which cells drain where) is exact;
+// weights use numpy's pairwise summation order so they match the reference bit for bit.
 #include "internal.h"
+#include <hipcub/hipcub.hpp>
+#include <math.h>
+
+namespace {
+
+// numpy pairwise sum (np.add.reduce on a contiguous float64 vector), see oracle/pydem_oracle.c
+__device__ double np_pairwise_sum(const double *a, int n)
+{
+    if (n < 8) {
+        double res = 0.;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        int i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; k++) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+    }
+}
+
+struct PitParams {
+    const double *elev;
+    const uint8_t *pitmask;     // flats & (elev > 0), frozen before any pit is patched (:1284)
+    const double *dX, *dY;      // fence spacing, n-1 entries
+    double *mag;                // patched: mag[pit] = mean(s)  (:1370)
+    uint8_t *flats;             // patched: flats[pit] = False   (:1371)
+    int n, m;
+    int max_iter, max_dist, min_border;
+    double max_dist_XY;         // NaN = None
+    // raw output triplets (pit, drain, weight), appended per pit in ascending drain order
+    int32_t *out_src, *out_dst; double *out_w;
+    int32_t *out_count;         // [0] edges, [1] pits without drain, [2] overflow pits, [3] capacity errors
+    int32_t out_cap;
+    int32_t *overflow_list;     // pits to re-run with the large window
+};
+
+// group = the threads that own one pit: a wavefront (NT = 64) or a whole workgroup (NT = 256)
+template <int NT>
+__device__ __forceinline__ void group_sync()
+{
+    if (NT == 64) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ double group_min(double v, double *red, int gl)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    if (NT == 64) return v;
+    group_sync<NT>();
+    if ((gl & 63) == 0) red[gl >> 6] = v;
+    group_sync<NT>();
+    double r = red[0];
+    for (int k = 1; k < NT / 64; k++) r = fmin(r, red[k]);
+    group_sync<NT>();
+    return r;
+}
+
+template <int NT>
+__device__ __forceinline__ int group_sum(int v, int *red, int gl, int *excl)
+{
+    // inclusive wave scan, then (for workgroups) offsets across waves; returns total, *excl = exclusive prefix
+    const int lane = gl & 63;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+    if (NT == 64) { *excl = incl - v; return __shfl(incl, 63); }
+    group_sync<NT>();
+    if (lane == 63) red[gl >> 6] = incl;
+    group_sync<NT>();
+    int base = 0, tot = 0;
+    for (int k = 0; k < NT / 64; k++) { if (k < (gl >> 6)) base += red[k]; tot += red[k]; }
+    group_sync<NT>();
+    *excl = base + incl - v;
+    return tot;
+}
+
+// One pit.  W = window edge (multiple of 32), MAXD = drain list capacity.
+// region / border / promote: W*W-bit bitmaps; dlist/dxy/sv: drain scratch.
+template <int NT, int W, int MAXD>
+__device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *region, uint32_t *border, uint32_t *promote,
+                          int32_t *dlist, double *dxy, double *sv, double *redd, int *redi, int *flag)
+{
+    constexpr int WORDS = W * W / 32;
+    constexpr int WPR = W / 32;                    // words per window row
+    const int n = P.n, m = P.m;
+    const int ipit = pit / m, jpit = pit - ipit * m;
+    // window origin: centred on the pit, clipped to the tile
+    int r0 = ipit - W / 2, c0 = jpit - W / 2;
+    if (r0 > n - W) r0 = n - W;
+    if (c0 > m - W) c0 = m - W;
+    if (r0 < 0) r0 = 0;
+    if (c0 < 0) c0 = 0;
+    for (int w = gl; w < WORDS; w += NT) { region[w] = 0; border[w] = 0; promote[w] = 0; }
+    if (gl == 0) { flag[0] = 0; flag[1] = 0; }
+    group_sync<NT>();
+    const double epit = P.elev[pit];
+    // pit_area = [pit]; border = its 8 neighbours inside the tile (:1289-1292)
+    if (gl == 0) {
+        const int wr = ipit - r0, wc = jpit - c0;
+        region[wr * WPR + (wc >> 5)] |= 1u << (wc & 31);
+        for (int di = -1; di <= 1; di++)
+            for (int dj = -1; dj <= 1; dj++) {
+                if (!di && !dj) continue;
+                const int ii = ipit + di, jj = jpit + dj;
+                if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+                const int r = ii - r0, c = jj - c0;
+                if (r < 0 || r >= W || c < 0 || c >= W) { flag[0] = 1; continue; }
+                border[r * WPR + (c >> 5)] |= 1u << (c & 31);
+            }
+    }
+    group_sync<NT>();
+    double epit_border = epit;
+    if (P.min_border) {                                                          // :1294-1295
+        double mn = INFINITY;
+        for (int w = gl; w < WORDS; w += NT) {
+            uint32_t b = border[w];
+            while (b) {
+                const int k = __ffs((int)b) - 1; b &= b - 1;
+                const int r = w / WPR, c = (w % WPR) * 32 + k;
+                mn = fmin(mn, P.elev[(int64_t)(r0 + r) * m + (c0 + c)]);
+            }
+        }
+        epit_border = group_min<NT>(mn, redd, gl);
+    }
+    int ndrain = -1;        // -1: none found
+    for (int it = 0; it < P.max_iter; it++) {                                    // :1300
+        if (flag[0]) break;                                                      // left the window
+        // --- scan the border: minima of all / non-pit / pit cells
+        double mn = INFINITY, mn_np = INFINITY, mn_p = INFINITY;
+        int any = 0;
+        for (int w = gl; w < WORDS; w += NT) {
+            uint32_t b = border[w];
+            while (b) {
+                const int k = __ffs((int)b) - 1; b &= b - 1;
+                const int r = w / WPR, c = (w % WPR) * 32 + k;
+                const int64_t cell = (int64_t)(r0 + r) * m + (c0 + c);
+                const double e = P.elev[cell];
+                any = 1;
+                mn = fmin(mn, e);
+                if (P.pitmask[cell]) mn_p = fmin(mn_p, e); else mn_np = fmin(mn_np, e);
+            }
+        }
+        mn = group_min<NT>(mn, redd, gl);
+        mn_np = group_min<NT>(mn_np, redd, gl);
+        mn_p = group_min<NT>(mn_p, redd, gl);
+        (void)any;
+        if (mn == INFINITY) break;                                               // empty border (:1304-1305)
+        int mode = 0;                                                            // 1: non-pit drains, 2: pit drains
+        if (mn_np < epit_border) mode = 1;                                       // :1312-1316
+        else if (mn_p < epit) mode = 2;                                          // :1317-1320
+        if (mode) {
+            // collect drains in ascending cell order (window scan order == ascending id)
+            int cnt = 0;
+            // each thread owns a contiguous run of words so the concatenation over threads is ordered
+            const int per = (WORDS + NT - 1) / NT;
+            const int w_lo = gl * per, w_hi = (w_lo + per < WORDS) ? w_lo + per : WORDS;
+            for (int w = w_lo; w < w_hi; w++) {
+                uint32_t b = border[w];
+                while (b) {
+                    const int k = __ffs((int)b) - 1; b &= b - 1;
+                    const int r = w / WPR, c = (w % WPR) * 32 + k;
+                    const int64_t cell = (int64_t)(r0 + r) * m + (c0 + c);
+                    const double e = P.elev[cell];
+                    const bool isp = P.pitmask[cell];
+                    if (mode == 1 ? (!isp && e < epit_border) : (isp && e < epit)) cnt++;
+                }
+            }
+            int excl;
+            const int tot = group_sum<NT>(cnt, redi, gl, &excl);
+            if (tot > MAXD) { if (gl == 0) flag[0] = 1; group_sync<NT>(); break; }
+            int pos = excl;
+            for (int w = w_lo; w < w_hi; w++) {
+                uint32_t b = border[w];
+                while (b) {
+                    const int k = __ffs((int)b) - 1; b &= b - 1;
+                    const int r = w / WPR, c = (w % WPR) * 32 + k;
+                    const int64_t cell = (int64_t)(r0 + r) * m + (c0 + c);
+                    const double e = P.elev[cell];
+                    const bool isp = P.pitmask[cell];
+                    if (mode == 1 ? (!isp && e < epit_border) : (isp && e < epit)) dlist[pos++] = (int32_t)cell;
+                }
+            }
+            ndrain = tot;
+            group_sync<NT>();
+            break;
+        }
+        // --- grow: pit_area += border[eborder == emin] (:1322-1323)
+        for (int w = gl; w < WORDS; w += NT) {
+            uint32_t b = border[w], pr = 0;
+            while (b) {
+                const int k = __ffs((int)b) - 1; b &= b - 1;
+                const int r = w / WPR, c = (w % WPR) * 32 + k;
+                if (P.elev[(int64_t)(r0 + r) * m + (c0 + c)] == mn) pr |= 1u << k;
+            }
+            promote[w] = pr;
+            if (pr) region[w] |= pr;        // word w is owned by this thread in this phase
+        }
+        group_sync<NT>();
+        for (int w = gl; w < WORDS; w += NT) {
+            uint32_t pr = promote[w];
+            while (pr) {
+                const int k = __ffs((int)pr) - 1; pr &= pr - 1;
+                const int r = w / WPR, c = (w % WPR) * 32 + k;
+                for (int di = -1; di <= 1; di++)
+                    for (int dj = -1; dj <= 1; dj++) {
+                        if (!di && !dj) continue;
+                        const int ii = r0 + r + di, jj = c0 + c + dj;
+                        if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+                        const int rr = r + di, cc = c + dj;
+                        if (rr < 0 || rr >= W || cc < 0 || cc >= W) { flag[0] = 1; continue; }
+                        const int ww = rr * WPR + (cc >> 5);
+                        const uint32_t bit = 1u << (cc & 31);
+                        if (!((region[ww] | border[ww]) & bit)) atomicOr(&border[ww], bit);
+                    }
+            }
+        }
+        group_sync<NT>();
+        for (int w = gl; w < WORDS; w += NT) {
+            const uint32_t pr = promote[w];
+            if (pr) border[w] &= ~pr;
+        }
+        group_sync<NT>();
+    }
+    group_sync<NT>();
+    if (flag[0]) {                                                               // hand over to the large-window pass
+        if (gl == 0) {
+            if (P.overflow_list) P.overflow_list[atomicAdd(&P.out_count[2], 1)] = pit;
+            else atomicAdd(&P.out_count[3], 1);
+        }
+        return;
+    }
+    if (ndrain < 0) { if (gl == 0) atomicAdd(&P.out_count[1], 1); return; }      // :1327-1329
+    // --- filters and weights: serial on one thread (drain counts are tiny), numpy operation order
+    if (gl == 0) {
+        int nd = ndrain;
+        if (P.max_dist) {                                                        // :1335-1343
+            int keep = 0;
+            for (int t = 0; t < nd; t++) {
+                const int di = ipit - dlist[t] / m, dj = jpit - dlist[t] % m;
+                const double dij = sqrt((double)(di * di + dj * dj));
+                if (dij <= (double)P.max_dist) dlist[keep++] = dlist[t];
+            }
+            nd = keep;
+        }
+        if (nd > 0) {
+            const int ndX = n - 1;
+            for (int t = 0; t < nd; t++) {                                       // :1346-1349
+                const int idr = dlist[t] / m, jdr = dlist[t] % m;
+                double dxm;
+                if (ipit == idr) dxm = P.dX[ipit < ndX - 1 ? ipit : ndX - 1];    // _get_dX_mean :1994-1995
+                else {
+                    const int a = ipit < idr ? ipit : idr, b = ipit < idr ? idr : ipit;
+                    dxm = np_pairwise_sum(P.dX + a, b - a) / (double)(b - a);   // .mean() :1997
+                }
+                const double dx = dxm * (double)(jpit - jdr);
+                const int a = ipit < idr ? ipit : idr, b = ipit < idr ? idr : ipit;
+                const double dy = np_pairwise_sum(P.dY + a, b - a);
+                dxy[t] = sqrt(dx * dx + dy * dy);
+            }
+            if (!isnan(P.max_dist_XY) && P.max_dist_XY != 0) {                   // :1352-1358
+                int keep = 0;
+                for (int t = 0; t < nd; t++)
+                    if (dxy[t] <= P.max_dist_XY) { dlist[keep] = dlist[t]; dxy[keep] = dxy[t]; keep++; }
+                nd = keep;
+            }
+        }
+        if (nd == 0) { atomicAdd(&P.out_count[1], 1); }
+        else {
+            for (int t = 0; t < nd; t++) sv[t] = fabs(epit - P.elev[dlist[t]]) / dxy[t];   // :1361
+            const double ssum = np_pairwise_sum(sv, nd);
+            const int32_t base = atomicAdd(&P.out_count[0], nd);
+            if (base + nd <= P.out_cap) {
+                for (int t = 0; t < nd; t++) {                                   // :1365-1367
+                    P.out_src[base + t] = pit; P.out_dst[base + t] = dlist[t]; P.out_w[base + t] = sv[t] / ssum;
+                }
+            } else atomicAdd(&P.out_count[3], 1);
+            P.mag[pit] = ssum / (double)nd;                                      // np.mean(s) :1370
+            P.flats[pit] = 0;                                                    // :1371
+        }
+    }
+}
+
+constexpr int W_SMALL = 64, MAXD_SMALL = 64;
+constexpr int W_LARGE = 640, MAXD_LARGE = 2048;
+
+// wave-per-pit: 4 pits per 256-thread block
+__global__ __launch_bounds__(256) void k_pits_wave(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits)
+{
+    constexpr int WORDS = W_SMALL * W_SMALL / 32;
+    __shared__ uint32_t s_bits[4][3][WORDS];
+    __shared__ int32_t s_dl[4][MAXD_SMALL];
+    __shared__ double s_dxy[4][MAXD_SMALL], s_sv[4][MAXD_SMALL];
+    __shared__ int s_flag[4][2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int32_t np = *npits;
+    for (int32_t q = blockIdx.x * 4 + wave; q < np; q += gridDim.x * 4)
+        solve_pit<64, W_SMALL, MAXD_SMALL>(P, pits[q], lane, s_bits[wave][0], s_bits[wave][1], s_bits[wave][2], s_dl[wave],
+                                           s_dxy[wave], s_sv[wave], nullptr, nullptr, s_flag[wave]);
+}
+
+// workgroup-per-pit with the full-radius window in dynamic LDS (3 * 640*640/8 = 153.6 KB)
+__global__ __launch_bounds__(256) void k_pits_block(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits,
+                                                    int32_t *g_dl, double *g_dxy, double *g_sv)
+{
+    constexpr int WORDS = W_LARGE * W_LARGE / 32;
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
+    __shared__ double redd[4];
+    __shared__ int redi[4];
+    __shared__ int flag[2];
+    const int32_t np = *npits;
+    for (int32_t q = blockIdx.x; q < np; q += gridDim.x) {
+        solve_pit<256, W_LARGE, MAXD_LARGE>(P, pits[q], threadIdx.x, dyn, dyn + WORDS, dyn + 2 * WORDS,
+                                             g_dl + (size_t)blockIdx.x * MAXD_LARGE, g_dxy + (size_t)blockIdx.x * MAXD_LARGE,
+                                             g_sv + (size_t)blockIdx.x * MAXD_LARGE, redd, redi, flag);
+        __syncthreads();
+    }
+}
+
+__global__ void k_pitmask(const uint8_t *__restrict__ flats, const double *__restrict__ elev, int64_t NN, uint8_t *pitmask)
+{
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < NN; c += (int64_t)gridDim.x * blockDim.x)
+        pitmask[c] = flats[c] && (elev[c] > 0);                                  // :1284
+}
+
+// same block-aggregated compaction as the flats stage (mask -> list of cell ids)
+__global__ __launch_bounds__(256) void k_compact_mask(const uint8_t *__restrict__ mask, int64_t NN,
+                                                      int32_t *__restrict__ list, int32_t *__restrict__ count)
+{
+    __shared__ int32_t wave_tot[4];
+    __shared__ int32_t blk_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 4096; base < NN; base += (int64_t)gridDim.x * 4096) {
+        const int64_t c0 = base + (int64_t)threadIdx.x * 16;
+        uint32_t bits = 0;
+        for (int k = 0; k < 16; k++)
+            if (c0 + k < NN && mask[c0 + k]) bits |= 1u << k;
+        const int32_t mine = __popc(bits);
+        int32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            blk_base = tot ? atomicAdd(count, tot) : 0;
+        }
+        __syncthreads();
+        int32_t off = blk_base + incl - mine;
+        for (int k = 0; k < wave; k++) off += wave_tot[k];
+        while (bits) { const int k = __ffs((int)bits) - 1; bits &= bits - 1; list[off++] = (int32_t)(c0 + k); }
+        __syncthreads();
+    }
+}
+
+// keep-filter of _mk_adjacency_matrix applied to the pit edges (:1136-1137) + 64-bit sort keys
+__global__ void k_pit_keys(const int32_t *__restrict__ src, const int32_t *__restrict__ dst, const double *__restrict__ w,
+                           const double *__restrict__ elev, int32_t ne, uint64_t *key_out, uint64_t *key_in, int32_t *idx)
+{
+    for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
+        const bool keep = !isnan(w[e]) && w[e] > 1e-8 && elev[dst[e]] <= elev[src[e]];
+        // dropped edges sort to the end
+        key_out[e] = keep ? (((uint64_t)(uint32_t)src[e] << 32) | (uint32_t)dst[e]) : ~0ull;
+        key_in[e] = keep ? (((uint64_t)(uint32_t)dst[e] << 32) | (uint32_t)src[e]) : ~0ull;
+        idx[e] = e;
+    }
+}
+
+__global__ void k_pit_gather(const uint64_t *__restrict__ keys, const int32_t *__restrict__ idx, const double *__restrict__ w,
+                             int32_t ne, int swap, int32_t *a, int32_t *b, double *wo, int32_t *nkept)
+{
+    for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
+        const uint64_t k = keys[e];
+        if (k == ~0ull) { a[e] = 0x7fffffff; b[e] = 0x7fffffff; wo[e] = 0; continue; }
+        const int32_t hi = (int32_t)(k >> 32), lo = (int32_t)(k & 0xffffffffu);
+        a[e] = swap ? lo : hi;      // a = src, b = dst in both views
+        b[e] = swap ? hi : lo;
+        wo[e] = w[idx[e]];
+        if (nkept && (e + 1 == ne || keys[e + 1] == ~0ull)) *nkept = e + 1;
+    }
+}
+
+template <typename T>
+int dev_realloc(pydem_tile *t, T **p, size_t count)
+{
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    return tile_alloc(t, p, count);
+}
+
+}  // namespace
 
 int stage_pits(pydem_tile *t, const pydem_options *opt)
 {
-    (void)t; (void)opt;
-    pydem_set_error("drain_pits=True is not implemented on the device yet");
-    return -4;
+    const int n = (int)t->n, m = (int)t->m;
+    if (opt->drain_pits_max_iter > 300) {
+        pydem_set_error("drain_pits_max_iter > 300 is not supported by the device window (got %d)", opt->drain_pits_max_iter);
+        return -2;
+    }
+    HIP_TRY(hipEventRecord(t->ev[4], t->stream));
+    PYDEM_TRY(tile_alloc(t, &t->flat0, (size_t)t->NN));       // reused as the frozen pit mask
+    PYDEM_TRY(tile_alloc(t, &t->flatlist, (size_t)t->NN));    // reused as the pit list
+    PYDEM_TRY(tile_alloc(t, &t->labels, (size_t)t->NN));      // reused as the overflow list
+    int32_t *cnt = t->counters + 40;                            // [0] npits, [1..4] out_count, scratch
+    HIP_TRY(hipMemsetAsync(cnt, 0, 16 * sizeof(int32_t), t->stream));
+    const int big = (int)(cdiv(t->NN, 256) < 8192 ? cdiv(t->NN, 256) : 8192);
+    hipLaunchKernelGGL(k_pitmask, dim3(big), dim3(256), 0, t->stream, t->flats, t->elev, t->NN, t->flat0);
+    hipLaunchKernelGGL(k_compact_mask, dim3((unsigned)(cdiv(t->NN, 4096) < 4096 ? cdiv(t->NN, 4096) : 4096)), dim3(256), 0,
+                       t->stream, t->flat0, t->NN, t->flatlist, cnt);
+    HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    const int32_t npits = t->h_counters[0];
+    t->tm.n_pit_edges = 0; t->tm.n_pits_undrained = 0;
+    t->pits.n_edges = 0;
+    if (npits == 0) { t->tm.pits_ms = 0; return 0; }
+
+    // raw triplets; capacity grows until everything fits
+    int64_t cap = (int64_t)npits * 2 + 1024;
+    for (int attempt = 0;; attempt++) {
+        if (t->pits.raw_cap < cap) {
+            PYDEM_TRY(dev_realloc(t, &t->pits.raw_src, (size_t)cap));
+            PYDEM_TRY(dev_realloc(t, &t->pits.raw_dst, (size_t)cap));
+            PYDEM_TRY(dev_realloc(t, &t->pits.raw_w, (size_t)cap));
+            t->pits.raw_cap = cap;
+        }
+        HIP_TRY(hipMemsetAsync(cnt + 1, 0, 8 * sizeof(int32_t), t->stream));
+        PitParams P;
+        P.elev = t->elev; P.pitmask = t->flat0; P.dX = t->dX; P.dY = t->dY; P.mag = t->mag; P.flats = t->flats;
+        P.n = n; P.m = m; P.max_iter = opt->drain_pits_max_iter; P.max_dist = opt->drain_pits_max_dist;
+        P.min_border = opt->drain_pits_min_border; P.max_dist_XY = opt->drain_pits_max_dist_XY;
+        P.out_src = t->pits.raw_src; P.out_dst = t->pits.raw_dst; P.out_w = t->pits.raw_w;
+        P.out_count = cnt + 1; P.out_cap = (int32_t)(t->pits.raw_cap < INT32_MAX ? t->pits.raw_cap : INT32_MAX);
+        P.overflow_list = t->labels;
+        const int gw = (int)(cdiv(npits, 4) < 16384 ? cdiv(npits, 4) : 16384);
+        hipLaunchKernelGGL(k_pits_wave, dim3(gw), dim3(256), 0, t->stream, P, t->flatlist, cnt);
+        HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        const int32_t n_over = t->h_counters[3];
+        if (n_over > 0) {
+            // second pass: workgroup per pit, 640x640 window in LDS
+            const int gb = n_over < 1024 ? n_over : 1024;
+            const size_t dyn = (size_t)3 * W_LARGE * W_LARGE / 8;
+            static bool attr_set = false;
+            if (!attr_set) {
+                HIP_TRY(hipFuncSetAttribute((const void *)k_pits_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+                attr_set = true;
+            }
+            const size_t need = (size_t)gb * MAXD_LARGE * (4 + 8 + 8);
+            if (t->scratch_bytes < need) {
+                if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->device_bytes -= (int64_t)t->scratch_bytes; }
+                HIP_TRY(hipMalloc(&t->scratch, need));
+                t->scratch_bytes = need; t->device_bytes += (int64_t)need;
+            }
+            double *g_dxy = (double *)t->scratch;
+            double *g_sv = g_dxy + (size_t)gb * MAXD_LARGE;
+            int32_t *g_dl = (int32_t *)(g_sv + (size_t)gb * MAXD_LARGE);
+            P.overflow_list = nullptr;
+            hipLaunchKernelGGL(k_pits_block, dim3(gb), dim3(256), dyn, t->stream, P, t->labels, cnt + 3, g_dl, g_dxy, g_sv);
+            HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+        }
+        HIP_TRY(hipGetLastError());
+        const int64_t ne = t->h_counters[1];
+        if (t->h_counters[4] > 0 && ne <= t->pits.raw_cap) {
+            pydem_set_error("pit->drain: %d pits exceeded the device window/drain capacity", t->h_counters[4]);
+            return -5;
+        }
+        if (ne > t->pits.raw_cap) {       // not everything fitted: the patches are idempotent, rerun with room
+            if (attempt > 3) { pydem_set_error("pit edge buffer keeps overflowing"); return -5; }
+            cap = ne + 1024;
+            continue;
+        }
+        t->pits.n_raw = ne;
+        t->tm.n_pits_undrained = t->h_counters[2];
+        break;
+    }
+    // sorted views of the kept edges: by (src,dst) for releasing targets, by (dst,src) for the pull
+    const int32_t ne = (int32_t)t->pits.n_raw;
+    t->tm.n_pit_edges = ne;
+    if (ne > 0) {
+        if (t->pits.sorted_cap < ne) {
+            PYDEM_TRY(dev_realloc(t, &t->pits.src, (size_t)ne)); PYDEM_TRY(dev_realloc(t, &t->pits.dst, (size_t)ne));
+            PYDEM_TRY(dev_realloc(t, &t->pits.w, (size_t)ne)); PYDEM_TRY(dev_realloc(t, &t->pits.in_src, (size_t)ne));
+            PYDEM_TRY(dev_realloc(t, &t->pits.in_dst, (size_t)ne)); PYDEM_TRY(dev_realloc(t, &t->pits.in_w, (size_t)ne));
+            t->pits.sorted_cap = ne;
+        }
+        uint64_t *k1 = nullptr, *k2 = nullptr, *k1s = nullptr, *k2s = nullptr; int32_t *idx = nullptr, *i1 = nullptr, *i2 = nullptr;
+        void *tmp = nullptr; size_t tmp_bytes = 0, tb2 = 0;
+        HIP_TRY(hipMalloc(&k1, ne * 8)); HIP_TRY(hipMalloc(&k2, ne * 8)); HIP_TRY(hipMalloc(&k1s, ne * 8)); HIP_TRY(hipMalloc(&k2s, ne * 8));
+        HIP_TRY(hipMalloc(&idx, ne * 4)); HIP_TRY(hipMalloc(&i1, ne * 4)); HIP_TRY(hipMalloc(&i2, ne * 4));
+        const int g = (int)(cdiv(ne, 256) < 1024 ? cdiv(ne, 256) : 1024);
+        hipLaunchKernelGGL(k_pit_keys, dim3(g), dim3(256), 0, t->stream, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w, t->elev,
+                           ne, k1, k2, idx);
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k1, k1s, idx, i1, ne, 0, 64, t->stream));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, k2, k2s, idx, i2, ne, 0, 64, t->stream));
+        if (tb2 > tmp_bytes) tmp_bytes = tb2;
+        HIP_TRY(hipMalloc(&tmp, tmp_bytes));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k1, k1s, idx, i1, ne, 0, 64, t->stream));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k2, k2s, idx, i2, ne, 0, 64, t->stream));
+        HIP_TRY(hipMemsetAsync(cnt + 10, 0, sizeof(int32_t), t->stream));
+        hipLaunchKernelGGL(k_pit_gather, dim3(g), dim3(256), 0, t->stream, k1s, i1, t->pits.raw_w, ne, 0, t->pits.src, t->pits.dst,
+                           t->pits.w, cnt + 10);
+        hipLaunchKernelGGL(k_pit_gather, dim3(g), dim3(256), 0, t->stream, k2s, i2, t->pits.raw_w, ne, 1, t->pits.in_src,
+                           t->pits.in_dst, t->pits.in_w, (int32_t *)nullptr);
+        HIP_TRY(hipMemcpyAsync(t->h_counters, cnt + 10, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        HIP_TRY(hipGetLastError());
+        t->pits.n_edges = t->h_counters[0];     // kept edges (a prefix of both sorted views)
+        (void)hipFree(k1); (void)hipFree(k2); (void)hipFree(k1s); (void)hipFree(k2s); (void)hipFree(idx); (void)hipFree(i1);
+        (void)hipFree(i2); (void)hipFree(tmp);
+    }
+    HIP_TRY(hipEventRecord(t->ev[5], t->stream));
+    HIP_TRY(hipEventSynchronize(t->ev[5]));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, t->ev[4], t->ev[5]));
+    t->tm.pits_ms = ms;
+    return 0;
 }

@@ -143,8 +143,8 @@ int pydem_tile_destroy(pydem_tile *t)
     void *ptrs[] = {t->elev, t->mag, t->dir, t->prop, t->uca, t->twi, t->flats, t->edge_todo, t->edge_done,
                     t->flat0, t->section, t->dX, t->dY, t->dX2, t->dY2, t->rowtab, t->sec_theta, t->row_area, t->inmask,
                     t->gflags, t->todo_work, t->indeg, t->queue[0], t->queue[1], t->labels, t->flatlist,
-                    t->counters, t->scratch, t->pits.src, t->pits.dst, t->pits.w, t->pits.in_cell,
-                    t->pits.in_ptr, t->pits.in_src, t->pits.in_w};
+                    t->counters, t->scratch, t->pits.src, t->pits.dst, t->pits.w, t->pits.in_src,
+                    t->pits.in_dst, t->pits.in_w, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     for (int i = 0; i < 8; i++) if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
@@ -331,6 +331,18 @@ int pydem_twi(pydem_tile *t, pydem_options *opt)
     PYDEM_TRY(ensure_field(t, PYDEM_TWI));
     PYDEM_TRY(stage_twi(t, opt));
     t->have[PYDEM_TWI] = true;
+    return 0;
+}
+
+int pydem_tile_pit_edges(pydem_tile *t, int64_t *n, int32_t *src, int32_t *dst, double *w)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    *n = t->pits.n_raw;
+    if (!src || t->pits.n_raw == 0) return 0;
+    HIP_TRY(hipMemcpyAsync(src, t->pits.raw_src, t->pits.n_raw * 4, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(dst, t->pits.raw_dst, t->pits.n_raw * 4, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(w, t->pits.raw_w, t->pits.n_raw * 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
     return 0;
 }
 

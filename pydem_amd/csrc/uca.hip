@@ -174,8 +174,8 @@ __global__ void k_corner_todo(const double *__restrict__ corner_sums, const doub
 // an LDS staging buffer: wavefront ballot + popcount prefix, one LDS atomic per wave, and one
 // global atomic per ~1.5k cells when the buffer is flushed.
 constexpr int32_t LEVEL_INF = 0x7fffffff;
-constexpr int STAGE_CAP = 2048;      // LDS staging entries per block
-constexpr int STAGE_FLUSH = 1536;    // flush when fewer than 2*256 slots remain
+constexpr int STAGE_CAP = 8192;      // LDS staging entries per block (32 KiB)
+constexpr int STAGE_FLUSH = STAGE_CAP - 512;    // flush when fewer than 2*256 slots remain
 
 struct SweepArgs {
     const uint8_t *inmask, *gflags;
@@ -188,7 +188,7 @@ struct SweepArgs {
     // pit side lists
     const int32_t *pit_src, *pit_dst;   // out-edges sorted by src
     int64_t n_pit;
-    const int32_t *pin_cell, *pin_ptr, *pin_src; const double *pin_w; int64_t n_pin_cells;
+    const int32_t *pin_dst, *pin_src; const double *pin_w;   // in-edges sorted by (dst, src)
 };
 
 __device__ __forceinline__ int64_t lower_bound_i32(const int32_t *a, int64_t n, int32_t key)
@@ -249,8 +249,7 @@ __device__ __forceinline__ bool owns_target(const SweepArgs &A, int32_t t, int32
         }
     }
     if (A.gflags[t] & GF_PIT_IN) {
-        const int64_t k = lower_bound_i32(A.pin_cell, A.n_pin_cells, t);
-        for (int32_t e = A.pin_ptr[k]; e < A.pin_ptr[k + 1]; e++) {
+        for (int64_t e = lower_bound_i32(A.pin_dst, A.n_pit, t); e < A.n_pit && A.pin_dst[e] == t; e++) {
             const int32_t v = A.pin_src[e];
             const int32_t lv = A.level[v];
             ready = ready && (lv <= r);
@@ -332,8 +331,7 @@ __device__ __forceinline__ void process_cell(const SweepArgs &A, Stage &S, bool 
             }
         }
         if (gf & GF_PIT_IN) {
-            const int64_t k = lower_bound_i32(A.pin_cell, A.n_pin_cells, c);
-            for (int32_t e = A.pin_ptr[k]; e < A.pin_ptr[k + 1]; e++) {
+            for (int64_t e = lower_bound_i32(A.pin_dst, A.n_pit, c); e < A.n_pit && A.pin_dst[e] == c; e++) {
                 acc += A.area[A.pin_src[e]] * A.pin_w[e];
                 td |= A.todo_work[A.pin_src[e]];
             }
@@ -417,7 +415,7 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt)
                        t->section, t->prop);
     HIP_TRY(hipEventRecord(t->ev[1], t->stream));
     t->tm.n_pit_edges = 0; t->tm.n_pits_undrained = 0; t->tm.pits_ms = 0;
-    t->pits.n_edges = 0; t->pits.n_in_cells = 0;
+    t->pits.n_edges = 0; t->pits.n_raw = 0;
     if (opt->drain_pits) PYDEM_TRY(stage_pits(t, opt));
     HIP_TRY(hipEventRecord(t->ev[2], t->stream));
     double *corner_sums = (double *)(t->counters + 16);                          // 12 doubles inside the counter block
@@ -457,8 +455,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     A.inmask = t->inmask; A.gflags = t->gflags; A.section = t->section; A.prop = t->prop; A.a0 = t->row_area;
     A.area = t->uca; A.todo_work = t->todo_work; A.level = t->indeg; A.n = n; A.m = m;
     A.pit_src = t->pits.src; A.pit_dst = t->pits.dst; A.n_pit = t->pits.n_edges;
-    A.pin_cell = t->pits.in_cell; A.pin_ptr = t->pits.in_ptr; A.pin_src = t->pits.in_src; A.pin_w = t->pits.in_w;
-    A.n_pin_cells = t->pits.n_in_cells;
+    A.pin_dst = t->pits.in_dst; A.pin_src = t->pits.in_src; A.pin_w = t->pits.in_w;
     hipLaunchKernelGGL(k_sweep_sources, dim3(grid_for(t->NN, 4096)), dim3(256), 0, t->stream, A, t->queue[1], &cnt3[1], nsrc);
     int64_t launches = 1;
     int r = 1;

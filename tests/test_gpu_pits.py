@@ -1,0 +1,76 @@
+"""GPU parity of the pit -> drain assignment (reference _mk_connectivity_pits, dem_processing.py:1269-1382)
+and of everything downstream of it (patched mag/flats, UCA through non-adjacent edges, TWI).
+Bar: the set of (pit, drain) pairs is bit-exact; weights follow numpy's summation order and are
+compared at 1e-14 relative; float fields as in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from test_gpu_parity import _close
+
+pytestmark = pytest.mark.gpu
+
+
+def _pit_cases():
+    return [nm for nm in golden_names() if load_golden(nm)['kwargs'].get('drain_pits', True)]
+
+
+def _check_pits(dp, pit_i, pit_j, pit_prop):
+    src, dst, w = dp._tile.pit_edges()
+    ref = sorted(zip(pit_i.tolist(), pit_j.tolist(), pit_prop.tolist()))
+    got = sorted(zip(src.tolist(), dst.tolist(), w.tolist()))
+    assert [r[:2] for r in ref] == [g[:2] for g in got], "pit -> drain assignments differ"
+    if ref:
+        np.testing.assert_allclose([g[2] for g in got], [r[2] for r in ref], rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize('name', _pit_cases())
+def test_hip_pits_vs_reference_golden(name):
+    g = load_golden(name)
+    from pydem_amd import DEMProcessor
+    dp = DEMProcessor(elev=g['elev_final'], dX=g['in_dX'], dY=g['in_dY'], dX2=g['in_dX2'], dY2=g['in_dY2'],
+                      fill_flats=False, drain_pits_path=False, drain_pits=True)
+    dp.calc_slopes_directions()
+    assert np.array_equal(dp.flats, g['flats'])
+    uca = dp.calc_uca()
+    _check_pits(dp, g['pit_i'], g['pit_j'], g['pit_prop'])
+    assert np.array_equal(dp.section, g['section'])
+    _close(dp.mag, g['mag_final'], 'mag after pit patch')
+    assert np.array_equal(dp.flats, g['flats_final'])
+    _close(uca, g['uca'], 'uca')
+    assert np.array_equal(dp.edge_todo, g['edge_todo'])
+    assert np.array_equal(dp.edge_done, g['edge_done'])
+    twi = dp.calc_twi()
+    _close(twi, g['twi_ret'], 'twi')
+
+
+@pytest.mark.parametrize('shape,seed,quant', [((400, 333), 31, None), ((1024, 1024), 32, None), ((300, 300), 33, 25.0),
+                                              ((257, 129), 34, 8.0)])
+def test_hip_pits_vs_oracle_synthetic(shape, seed, quant):
+    """quant: round elevations to integers over a small range -> large plateaus, many tied pits,
+    regions that outgrow the 64x64 wave window (exercises the workgroup pass)."""
+    from oracle import oracle as O
+    from pydem_amd import DEMProcessor, synth
+    n, m = shape
+    if quant is None:
+        elev = synth.fractal(n, m, seed=seed, top_shift=7, n_octaves=7)
+    else:
+        elev = np.rint(synth.fractal(n, m, seed=seed, top_shift=6, n_octaves=6, zrange=quant))
+    kw = dict(dX=25.0 + 0.01 * np.arange(n - 1), dY=31.0 - 0.004 * np.arange(n - 1),
+              dX2=25.0 + 0.01 * np.arange(n), dY2=31.0 - 0.004 * np.arange(n))
+    o = O.OracleDEM(elev, drain_pits=True, **kw)
+    o.calc_twi()
+    dp = DEMProcessor(elev=elev, fill_flats=False, drain_pits_path=False, drain_pits=True, **kw)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        twi = dp.calc_twi()
+    _check_pits(dp, o.pit_i, o.pit_j, o.pit_prop)
+    assert dp.timings['n_pits_undrained'] == o.n_warn
+    _close(dp.mag, o.mag, 'mag')
+    assert np.array_equal(dp.flats, o.flats.astype(bool))
+    assert np.array_equal(dp.section, o.section)
+    _close(dp.uca, o.uca, 'uca')
+    assert np.array_equal(dp.edge_todo, o.edge_todo)
+    assert np.array_equal(dp.edge_done, o.edge_done)
+    _close(twi, o.twi / 10, 'twi')
