@@ -167,6 +167,26 @@ def drain_connections(arr, ids, indptr, indices, set_to=0):
     return arr
 
 
+def uca_update(elev, flats, A, strips_data, strips_done, strips_todo, uca_init):
+    """One edge-resolution round (oracle_uca_update).  strips_*: dicts keyed left/right/top/bottom.
+    Returns (uca, edge_todo, edge_done)."""
+    n, m = elev.shape
+    keys = ('left', 'right', 'top', 'bottom')
+    d = [np.ascontiguousarray(strips_data[k], np.float64).ravel() for k in keys]
+    dn = [np.ascontiguousarray(strips_done[k]).astype(np.uint8).ravel() for k in keys]
+    td = [np.ascontiguousarray(strips_todo[k]).astype(np.uint8).ravel() for k in keys]
+    arr = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data_as(C.c_void_p) for x in xs])
+    uca = np.ascontiguousarray(uca_init, np.float64).copy()
+    todo = np.empty((n, m), np.uint8); done = np.empty((n, m), np.uint8)
+    indptr, indices, data = A
+    idx = indices if indices.size else np.zeros(1, np.int32)
+    dat = data if data.size else np.zeros(1)
+    rc = lib().oracle_uca_update(np.ascontiguousarray(elev, np.float64), np.ascontiguousarray(flats, np.uint8), n, m,
+                                 indptr, idx, dat, arr(d), arr(dn), arr(td), uca, todo, done)
+    assert rc == 0
+    return uca, todo.astype(bool), done.astype(bool)
+
+
 def twi(uca, mag, twi_min_slope=1e-3, twi_min_area=np.inf, uca_saturation_limit=32.0,
         apply_twi_limits=False, apply_twi_limits_on_uca=False):
     out = np.empty(uca.shape)

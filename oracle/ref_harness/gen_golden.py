@@ -142,7 +142,46 @@ def read_tif32():
     return np.frombuffer(b[strip:strip + w * h * 8], '<f8').reshape(h, w).copy()
 
 
+def run_edge_update_case(name, elev, dX, dY, seed, **kw):
+    """A9: one edge-resolution round exactly as process_manager.calc_uca_ec drives it
+    (process_manager.py:224-284): a FRESH DEMProcessor built from stored elev/aspect/slope,
+    find_flats(), then calc_uca(uca_init=..., edge_init_data=[data, done, todo])."""
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        dp0 = DEMProcessor(elev=elev.copy(), dX=dX, dY=dY, fill_flats=False, drain_pits_path=False, **kw)
+        mag0, dir0 = dp0.calc_slopes_directions()
+        mag0 = mag0.copy(); dir0 = dir0.copy()        # what the aspect/slope workers store (before the pit patch)
+        dp0.calc_uca()
+        uca0 = dp0.uca.copy(); todo0 = dp0.edge_todo.copy(); done0 = dp0.edge_done.copy()
+        rng = np.random.default_rng(seed)
+        n, m = elev.shape
+        sides = {'left': (slice(None), 0), 'right': (slice(None), -1), 'top': (0, slice(None)), 'bottom': (-1, slice(None))}
+        data, dn, td = {}, {}, {}
+        for k, sl in sides.items():
+            L = uca0[sl].size
+            data[k] = np.nan_to_num(uca0[sl], nan=1.0) + rng.random(L) * 50000.0 * (rng.random(L) < 0.7)
+            dn[k] = rng.random(L) < 0.6
+            td[k] = todo0[sl].copy()
+        dp = DEMProcessor(elev=elev.copy(), dX=dX, dY=dY, mag=mag0.copy(), direction=dir0.copy(), fill_flats=False,
+                          drain_pits_path=False, **kw)
+        dp.find_flats()
+        uca1 = dp.calc_uca(uca_init=uca0.copy(), edge_init_data=[{k: v.copy() for k, v in data.items()},
+                                                                  {k: v.copy() for k, v in dn.items()},
+                                                                  {k: v.copy() for k, v in td.items()}]).copy()
+    rec = dict(in_elev=elev, in_dX=np.array(dp.dX, float), in_dY=np.array(dp.dY, float), in_dX2=np.array(dp.dX2, float),
+               in_dY2=np.array(dp.dY2, float), in_mag=mag0, in_direction=dir0, uca_init=uca0, edge_todo_init=todo0,
+               edge_done_init=done0, uca=uca1, edge_todo=dp.edge_todo.copy(), edge_done=dp.edge_done.copy(),
+               n_drain_area_calls=np.int64(0))
+    for k in sides:
+        rec['strip_data_' + k] = data[k]; rec['strip_done_' + k] = dn[k]; rec['strip_todo_' + k] = td[k]
+    save(name, rec, kw)
+
+
 def main():
+    if '--only-edge' in sys.argv:
+        edge_cases()
+        write_manifest()
+        return
     cases = []
     # G1: the reference's own known-answer inputs (test_end_to_end.py:153-158, 221-226)
     card = np.array([[1] * 5, [2] * 5, [3] * 5, [4] * 5, [5] * 5])
@@ -180,6 +219,20 @@ def main():
         rec = run_case(elev, dX, dY, **kw)
         save(name, rec, kw)
 
+    edge_cases()
+    write_manifest()
+
+
+def edge_cases():
+    fr = synth.fractal(96, 128, seed=0, top_shift=6, n_octaves=6)
+    run_edge_update_case('g6_edge_update_nopits', fr, 30.0, 30.0, 1, drain_pits=False)
+    run_edge_update_case('g6_edge_update_pits', fr, 30.0, 30.0, 2, drain_pits=True)
+    run_edge_update_case('g6_edge_update_cone', synth.cone_scaled(48), 1.0, 1.0, 3, drain_pits=True)
+    quant = np.rint(synth.fractal(64, 64, seed=9, top_shift=5, n_octaves=5, zrange=60.0)).astype(np.float64)
+    run_edge_update_case('g6_edge_update_quant', quant, 10.0, 10.0, 4, drain_pits=True)
+
+
+def write_manifest():
     # manifest with sha256 of every fixture
     lines = []
     for fn in sorted(os.listdir(OUT)):

@@ -158,6 +158,18 @@ class Tile(object):
     def uca(self, opt):
         check(self.lib.pydem_uca(self._h, C.byref(opt)))
 
+    def uca_edge_update(self, opt, data, done, todo):
+        """data/done/todo: sequences (left, right, top, bottom) of 1-D arrays."""
+        n, m = self.shape
+        lens = (n, n, m, m)
+        d = [np.ascontiguousarray(np.asarray(a, np.float64).ravel()) for a in data]
+        dn = [np.ascontiguousarray(np.asarray(a).ravel().astype(np.uint8)) for a in done]
+        td = [np.ascontiguousarray(np.asarray(a).ravel().astype(np.uint8)) for a in todo]
+        for arrs in (d, dn, td):
+            assert [a.size for a in arrs] == list(lens), "edge strips must have n_rows / n_cols entries"
+        pack = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data_as(C.c_void_p) for x in xs])
+        check(self.lib.pydem_uca_edge_update(self._h, C.byref(opt), pack(d), pack(dn), pack(td)))
+
     def twi(self, opt):
         check(self.lib.pydem_twi(self._h, C.byref(opt)))
 

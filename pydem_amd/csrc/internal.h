@@ -73,6 +73,11 @@ struct pydem_tile {
     int32_t *counters = nullptr;       // device scalars
     int32_t *h_counters = nullptr;     // pinned host mirror
     PitGraph pits;
+    // edge-resolution rounds
+    int32_t *estamp = nullptr; double *edelta = nullptr, *p_delta = nullptr, *s_data = nullptr;
+    uint8_t *p_flags = nullptr, *s_flags = nullptr;
+    int32_t eepoch = 0;
+    bool graph_valid = false;   // inmask/gflags/section/prop/pit lists match the resident elev/dir/flats
     void *scratch = nullptr; size_t scratch_bytes = 0;
     int64_t device_bytes = 0;
     pydem_timings tm = {};
@@ -90,6 +95,8 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt);
 int stage_pits(pydem_tile *t, const pydem_options *opt);
 int stage_sweep(pydem_tile *t, const pydem_options *opt);
 int stage_twi(pydem_tile *t, const pydem_options *opt);
+int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *const data[4], const uint8_t *const done[4],
+                      const uint8_t *const todo[4]);
 int stage_synth(pydem_tile *t, uint32_t seed, int64_t row0, int64_t col0, int n_oct, int top_shift,
                 double zmin, double zrange);
 int bench_stencil(pydem_tile *t, int iters, double *avg_ms);

@@ -144,7 +144,8 @@ int pydem_tile_destroy(pydem_tile *t)
                     t->flat0, t->section, t->dX, t->dY, t->dX2, t->dY2, t->rowtab, t->sec_theta, t->row_area, t->inmask,
                     t->gflags, t->todo_work, t->indeg, t->queue[0], t->queue[1], t->labels, t->flatlist,
                     t->counters, t->scratch, t->pits.src, t->pits.dst, t->pits.w, t->pits.in_src,
-                    t->pits.in_dst, t->pits.in_w, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w};
+                    t->pits.in_dst, t->pits.in_w, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w,
+                    t->estamp, t->edelta, t->p_delta, t->s_data, t->p_flags, t->s_flags};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     for (int i = 0; i < 8; i++) if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
@@ -225,6 +226,7 @@ int pydem_tile_upload(pydem_tile *t, int field, const void *src, int dtype)
         HIP_TRY(hipStreamSynchronize(t->stream));
     }
     t->have[field] = true;
+    if (field == PYDEM_ELEV || field == PYDEM_MAG || field == PYDEM_DIRECTION || field == PYDEM_FLATS) t->graph_valid = false;
     return 0;
 }
 
@@ -253,6 +255,7 @@ int pydem_tile_synth_fractal(pydem_tile *t, uint32_t seed, int64_t row0, int64_t
                              int top_shift, double zmin, double zrange)
 {
     HIP_TRY(hipSetDevice(t->device));
+    t->graph_valid = false;
     PYDEM_TRY(ensure_field(t, PYDEM_ELEV));
     PYDEM_TRY(stage_synth(t, seed, row0, col0, n_octaves, top_shift, zmin, zrange));
     t->have[PYDEM_ELEV] = true;
@@ -273,6 +276,7 @@ int pydem_slopes_directions(pydem_tile *t)
     if (!t->spacing_set) { pydem_set_error("pydem_slopes_directions: call pydem_tile_set_spacing first"); return -3; }
     PYDEM_TRY(ensure_fields(t, {PYDEM_MAG, PYDEM_DIRECTION, PYDEM_FLATS}));
     PYDEM_TRY(tile_alloc(t, &t->flat0, (size_t)t->NN));
+    t->graph_valid = false;
     PYDEM_TRY(stage_stencil(t));
     PYDEM_TRY(stage_flats(t));
     t->have[PYDEM_MAG] = t->have[PYDEM_DIRECTION] = t->have[PYDEM_FLATS] = true;
@@ -302,6 +306,7 @@ int pydem_uca(pydem_tile *t, pydem_options *opt)
     if (!t->spacing_set) { pydem_set_error("pydem_uca: call pydem_tile_set_spacing first"); return -3; }
     PYDEM_TRY(ensure_fields(t, {PYDEM_SECTION, PYDEM_PROPORTION, PYDEM_UCA, PYDEM_EDGE_TODO, PYDEM_EDGE_DONE}));
     PYDEM_TRY(stage_section_graph(t, opt));
+    t->graph_valid = true;
     PYDEM_TRY(stage_sweep(t, opt));
     // record minimum area (dem_processing.py:897-899)
     double mn = opt->twi_min_area;
@@ -318,9 +323,24 @@ int pydem_uca(pydem_tile *t, pydem_options *opt)
 int pydem_uca_edge_update(pydem_tile *t, pydem_options *opt, const double *const data[4],
                           const uint8_t *const done[4], const uint8_t *const todo[4])
 {
-    (void)t; (void)opt; (void)data; (void)done; (void)todo;
-    pydem_set_error("pydem_uca_edge_update: not implemented yet");
-    return -4;
+    HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(need(t, PYDEM_UCA, "pydem_uca_edge_update"));
+    PYDEM_TRY(need(t, PYDEM_FLATS, "pydem_uca_edge_update"));
+    PYDEM_TRY(ensure_fields(t, {PYDEM_EDGE_TODO, PYDEM_EDGE_DONE}));
+    if (!t->graph_valid) {
+        // a tile rebuilt from stored elev/aspect/slope (process_manager.calc_uca_ec :227-240): build the graph once
+        PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_uca_edge_update"));
+        PYDEM_TRY(need(t, PYDEM_MAG, "pydem_uca_edge_update"));
+        PYDEM_TRY(need(t, PYDEM_DIRECTION, "pydem_uca_edge_update"));
+        if (!t->spacing_set) { pydem_set_error("pydem_uca_edge_update: call pydem_tile_set_spacing first"); return -3; }
+        PYDEM_TRY(ensure_fields(t, {PYDEM_SECTION, PYDEM_PROPORTION}));
+        PYDEM_TRY(stage_section_graph(t, opt));
+        t->graph_valid = true;
+        t->have[PYDEM_SECTION] = t->have[PYDEM_PROPORTION] = true;
+    }
+    PYDEM_TRY(stage_edge_update(t, opt, data, done, todo));
+    t->have[PYDEM_EDGE_TODO] = t->have[PYDEM_EDGE_DONE] = true;
+    return 0;
 }
 
 int pydem_twi(pydem_tile *t, pydem_options *opt)

@@ -398,6 +398,219 @@ __global__ __launch_bounds__(256) void k_twi(const double *__restrict__ uca, con
     }
 }
 
+// ------------------------------------------------------------------------------- K7
+// Edge-resolution round for one tile: DEMProcessor.calc_uca(uca_init=..., edge_init_data=...)
+// (reference pydem/dem_processing.py:720-771) and _calc_uca_chunk_update (:778-862) with the
+// native floods cyutils.drain_connections (cyutils.pyx:35-72) and drain_area (:78-187).
+// The reference rebuilds section/proportion/adjacency on every call (:787-793); here the graph
+// built by pydem_uca is still resident and is reused.  Only cells downstream of the seeds are
+// touched: stamp[c] == epoch marks membership, so nothing of size NN is cleared per round except
+// the two byte masks that are outputs.
+struct EdgeArgs {
+    SweepArgs G;             // graph (area/todo_work/level are re-pointed: see stage_edge_update)
+    int32_t *stamp;          // [NN] epoch stamps: (epoch << 2) | bit1 reached-or-seed
+    double *delta;           // [NN] area delta of this round (valid where stamped)
+    const uint8_t *flats;
+    uint8_t *edge_done;      // output mask
+    int32_t epoch;
+    // perimeter tables, index p: top row (m), bottom row (m), left col rows 1..n-2, right col rows 1..n-2
+    uint8_t *p_done, *p_seed;
+    double *p_delta;
+    int32_t *rlist, *rcount; // cells whose uca must be updated at the end
+};
+
+__device__ __forceinline__ int64_t perim_index(int i, int j, int n, int m)
+{
+    if (i == 0) return j;
+    if (i == n - 1) return (int64_t)m + j;
+    if (j == 0) return 2 * (int64_t)m + (i - 1);
+    if (j == m - 1) return 2 * (int64_t)m + (n - 2) + (i - 1);
+    return -1;
+}
+
+// base value of a cell's delta: edge cells initialised from a finished neighbour start from
+// (neighbour value - own uca) (:806-809); flats are NaN (:815); everything else 0 (:802)
+__device__ __forceinline__ double edge_base(const EdgeArgs &E, int32_t c)
+{
+    if (E.flats[c]) return NAN;
+    const int i = c / E.G.m, j = c - i * E.G.m;
+    const int64_t p = perim_index(i, j, E.G.n, E.G.m);
+    if (p >= 0 && E.p_done[p]) return E.p_delta[p];
+    return 0.0;
+}
+
+// strips -> per-perimeter-cell state (:726-739, :798-809); seeds start the reach flood, cells
+// that stay 'todo' start the todo flood
+__global__ void k_edge_init(EdgeArgs E, const double *__restrict__ sdata, const uint8_t *__restrict__ sdone,
+                            const uint8_t *__restrict__ stodo, int L, const double *__restrict__ uca,
+                            uint8_t *__restrict__ edge_todo, int32_t *q_seed, int32_t *n_seed, int32_t *q_todo, int32_t *n_todo)
+{
+    const int n = E.G.n, m = E.G.m;
+    const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nper) return;
+    int i, j;
+    if (p < m) { i = 0; j = (int)p; }
+    else if (p < 2 * (int64_t)m) { i = n - 1; j = (int)(p - m); }
+    else if (p < 2 * (int64_t)m + (n - 2)) { i = (int)(p - 2 * (int64_t)m) + 1; j = 0; }
+    else { i = (int)(p - 2 * (int64_t)m - (n - 2)) + 1; j = m - 1; }
+    const int32_t c = i * m + j;
+    bool dn = false, td = false;
+    double init = 0.0;
+    // dict order of the reference: left, right, top, bottom
+    if (j == 0) { dn |= sdone[0 * L + i] != 0; init += sdata[0 * L + i] * (double)(sdone[0 * L + i] != 0); td |= stodo[0 * L + i] != 0; }
+    if (j == m - 1) { dn |= sdone[1 * L + i] != 0; init += sdata[1 * L + i] * (double)(sdone[1 * L + i] != 0); td |= stodo[1 * L + i] != 0; }
+    if (i == 0) { dn |= sdone[2 * L + j] != 0; init += sdata[2 * L + j] * (double)(sdone[2 * L + j] != 0); td |= stodo[2 * L + j] != 0; }
+    if (i == n - 1) { dn |= sdone[3 * L + j] != 0; init += sdata[3 * L + j] * (double)(sdone[3 * L + j] != 0); td |= stodo[3 * L + j] != 0; }
+    if (!dn) init = 0.0;                                                         // :738-739
+    const bool seed = dn && td;                                                  // :798
+    const bool todo_out = td && !dn;                                             // :799
+    E.p_done[p] = dn;
+    E.p_seed[p] = seed;
+    E.p_delta[p] = dn ? init - uca[c] : 0.0;                                     // :806-809
+    edge_todo[c] = todo_out;                                                     // returned as edge_todo_i (:817, :862)
+    if (todo_out) { E.edge_done[c] = 0; q_todo[atomicAdd(n_todo, 1)] = c; }
+    if (seed) {
+        E.stamp[c] = (E.epoch << 2) | 2;
+        E.G.level[c] = 0;
+        q_seed[atomicAdd(n_seed, 1)] = c;
+        E.rlist[atomicAdd(E.rcount, 1)] = c;
+    }
+}
+
+template <typename F>
+__device__ __forceinline__ void for_each_target(const SweepArgs &A, int32_t c, F f)
+{
+    const uint8_t gf = A.gflags[c];
+    const int s = A.section[c];
+    if (gf & GF_OUT1) f(c + fe1r(s) * A.m + fe1c(s));
+    if (gf & GF_OUT2) f(c + fe2r(s) * A.m + fe2c(s));
+    if (gf & GF_PIT_OUT)
+        for (int64_t e = lower_bound_i32(A.pit_src, A.n_pit, c); e < A.n_pit && A.pit_src[e] == c; e++) f(A.pit_dst[e]);
+}
+
+// breadth-first flood along out-edges.  MODE 0: mark cells downstream of the seeds (done = False,
+// :820-825) and prepare their delta/level; MODE 1: propagate edge_todo (:848-853)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_edge_flood(EdgeArgs E, const int32_t *__restrict__ qc, int32_t *__restrict__ qn,
+                                                    int32_t *cnt3, int r)
+{
+    const int32_t nq = cnt3[r % 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt3[(r + 2) % 3] = 0;
+    if (nq == 0) return;
+    int32_t *cn = &cnt3[(r + 1) % 3];
+    const int32_t tag = ((E.epoch + MODE) << 2) | 2;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        const int32_t u = qc[q];
+        for_each_target(E.G, u, [&](int32_t t) {
+            const int32_t old = atomicExch(&E.stamp[t], tag);
+            if (old == tag) return;
+            if (MODE == 0) {
+                E.G.level[t] = 0x7fffffff;
+                E.rlist[atomicAdd(E.rcount, 1)] = t;
+            } else {
+                E.edge_done[t] = 0;                                              // edge_done = ~edge_todo (:856)
+            }
+            qn[atomicAdd(cn, 1)] = t;
+        });
+    }
+}
+
+__device__ __forceinline__ bool edge_in_set(const EdgeArgs &E, int32_t v) { return E.stamp[v] == ((E.epoch << 2) | 2); }
+
+// ownership test restricted to the stamped sub-graph (unstamped upstream cells count as done)
+__device__ __forceinline__ bool edge_owns(const EdgeArgs &E, int32_t t, int32_t u, int32_t r)
+{
+    const SweepArgs &A = E.G;
+    const uint8_t im = A.inmask[t];
+    int32_t owner = -1;
+    bool ready = true;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        if (im & (1u << d)) {
+            const int32_t v = t + NB_DI[d] * A.m + NB_DJ[d];
+            if (!edge_in_set(E, v)) continue;
+            const int32_t lv = A.level[v];
+            ready = ready && (lv <= r);
+            if (lv == r) owner = v > owner ? v : owner;
+        }
+    }
+    if (A.gflags[t] & GF_PIT_IN)
+        for (int64_t e = lower_bound_i32(A.pin_dst, A.n_pit, t); e < A.n_pit && A.pin_dst[e] == t; e++) {
+            const int32_t v = A.pin_src[e];
+            if (!edge_in_set(E, v)) continue;
+            const int32_t lv = A.level[v];
+            ready = ready && (lv <= r);
+            if (lv == r) owner = v > owner ? v : owner;
+        }
+    return ready && owner == u;
+}
+
+// seeded sweep (drain_area with skip_edge=False on the flooded sub-graph, :836-842): round 0 =
+// seeds (their delta is the edge value itself), later rounds pull from stamped upstream cells
+__global__ __launch_bounds__(256) void k_edge_sweep(EdgeArgs E, const int32_t *__restrict__ qc, int32_t *__restrict__ qn,
+                                                    int32_t *cnt3, int r)
+{
+    const int32_t nq = cnt3[r % 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt3[(r + 2) % 3] = 0;
+    if (nq == 0) return;
+    int32_t *cn = &cnt3[(r + 1) % 3];
+    const SweepArgs &A = E.G;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        const int32_t c = qc[q];
+        double acc = edge_base(E, c);
+        if (r > 0) {
+            const uint8_t im = A.inmask[c];
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                if (im & (1u << d)) {
+                    const int32_t u = c + NB_DI[d] * A.m + NB_DJ[d];
+                    if (!edge_in_set(E, u)) continue;
+                    const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
+                    const double pu = A.prop[u];
+                    acc += E.delta[u] * (cardinal ? pu : 1 - pu);
+                }
+            }
+            if (A.gflags[c] & GF_PIT_IN)
+                for (int64_t e = lower_bound_i32(A.pin_dst, A.n_pit, c); e < A.n_pit && A.pin_dst[e] == c; e++)
+                    if (edge_in_set(E, A.pin_src[e])) acc += E.delta[A.pin_src[e]] * A.pin_w[e];
+        }
+        E.delta[c] = acc;
+        for_each_target(A, c, [&](int32_t t) {
+            // seeds never receive: a done cell on the tile edge is skipped (cyutils.pyx:159-161)
+            if (A.level[t] == 0 && edge_in_set(E, t)) return;
+            if (edge_owns(E, t, c, r)) { A.level[t] = r + 1; qn[atomicAdd(cn, 1)] = t; }
+        });
+    }
+}
+
+// self.uca += area (:769) on the touched cells, plus the finished edge cells the flood never reached
+__global__ void k_edge_apply(EdgeArgs E, double *__restrict__ uca, const int32_t *nr)
+{
+    const int32_t n = *nr;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        const int32_t c = E.rlist[q];
+        // cells the sweep never reached (cyclic drainage) keep their initial value, like the reference
+        const bool processed = E.G.level[c] != 0x7fffffff;
+        uca[c] += processed ? E.delta[c] : edge_base(E, c);
+    }
+}
+
+__global__ void k_edge_apply_perimeter(EdgeArgs E, double *__restrict__ uca)
+{
+    const int n = E.G.n, m = E.G.m;
+    const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nper) return;
+    int i, j;
+    if (p < m) { i = 0; j = (int)p; }
+    else if (p < 2 * (int64_t)m) { i = n - 1; j = (int)(p - m); }
+    else if (p < 2 * (int64_t)m + (n - 2)) { i = (int)(p - 2 * (int64_t)m) + 1; j = 0; }
+    else { i = (int)(p - 2 * (int64_t)m - (n - 2)) + 1; j = m - 1; }
+    const int32_t c = i * m + j;
+    if (E.p_done[p] && !edge_in_set(E, c)) uca[c] += edge_base(E, c);
+}
+
 int grid_for(int64_t work, int cap) { const int64_t g = cdiv(work, 256); return (int)(g < cap ? (g > 0 ? g : 1) : cap); }
 
 }  // namespace
@@ -504,5 +717,104 @@ int stage_twi(pydem_tile *t, const pydem_options *opt)
     float a = 0;
     HIP_TRY(hipEventElapsedTime(&a, t->ev[0], t->ev[1]));
     t->tm.twi_ms = a;
+    return 0;
+}
+
+int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *const data[4], const uint8_t *const done[4],
+                      const uint8_t *const todo[4])
+{
+    (void)opt;
+    const int n = (int)t->n, m = (int)t->m;
+    PYDEM_TRY(tile_alloc(t, &t->row_area, (size_t)t->n));
+    const int L = n > m ? n : m;
+    const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
+    PYDEM_TRY(tile_alloc(t, &t->estamp, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->edelta, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->labels, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->flatlist, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->queue[0], (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->queue[1], (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->p_delta, (size_t)nper));
+    PYDEM_TRY(tile_alloc(t, &t->p_flags, (size_t)nper * 2));
+    PYDEM_TRY(tile_alloc(t, &t->s_data, (size_t)L * 4));
+    PYDEM_TRY(tile_alloc(t, &t->s_flags, (size_t)L * 8));
+    if (t->eepoch == 0) HIP_TRY(hipMemsetAsync(t->estamp, 0, (size_t)t->NN * 4, t->stream));
+    t->eepoch += 2;
+    if (t->eepoch > (1 << 28)) { t->eepoch = 2; HIP_TRY(hipMemsetAsync(t->estamp, 0, (size_t)t->NN * 4, t->stream)); }
+    // strips -> device (left, right, top, bottom), padded to L entries each
+    std::vector<double> hd((size_t)L * 4, 0.0);
+    std::vector<uint8_t> hf((size_t)L * 8, 0);
+    for (int s = 0; s < 4; s++) {
+        const int len = s < 2 ? n : m;
+        for (int k = 0; k < len; k++) {
+            hd[(size_t)s * L + k] = data[s][k];
+            hf[(size_t)s * L + k] = done[s][k] != 0;
+            hf[(size_t)(4 + s) * L + k] = todo[s][k] != 0;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(t->s_data, hd.data(), hd.size() * 8, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->s_flags, hf.data(), hf.size(), hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
+    HIP_TRY(hipMemsetAsync(t->edge_todo, 0, (size_t)t->NN, t->stream));
+    HIP_TRY(hipMemsetAsync(t->edge_done, 1, (size_t)t->NN, t->stream));
+    EdgeArgs E;
+    SweepArgs &A = E.G;
+    A.inmask = t->inmask; A.gflags = t->gflags; A.section = t->section; A.prop = t->prop; A.a0 = t->row_area;
+    A.area = t->uca; A.todo_work = t->todo_work; A.level = t->indeg; A.n = n; A.m = m;
+    A.pit_src = t->pits.src; A.pit_dst = t->pits.dst; A.n_pit = t->pits.n_edges;
+    A.pin_dst = t->pits.in_dst; A.pin_src = t->pits.in_src; A.pin_w = t->pits.in_w;
+    E.stamp = t->estamp; E.delta = t->edelta; E.flats = t->flats; E.edge_done = t->edge_done; E.epoch = t->eepoch;
+    E.p_done = t->p_flags; E.p_seed = t->p_flags + nper; E.p_delta = t->p_delta;
+    E.rlist = t->labels; E.rcount = t->counters + 6;
+    int32_t *cnt3 = t->counters;      // rotating frontier sizes
+    int32_t *n_todo = t->counters + 7;
+    // seeds enter queue[1] as "output of round -1" => cnt3[0] is the input of round 0 (queue index 0 % 2 ... see below)
+    // round r reads queue[r % 2] / cnt3[r % 3]; so seeds go to queue[0], cnt3[0]
+    hipLaunchKernelGGL(k_edge_init, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, E, t->s_data, t->s_flags,
+                       t->s_flags + (size_t)4 * L, L, t->uca, t->edge_todo, t->queue[0], &cnt3[0], t->flatlist, n_todo);
+    HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    const int32_t nseed = t->h_counters[0], ntodo = t->h_counters[7];
+    auto run_rounds = [&](int which, int32_t first) -> int {
+        // which: 0 reach flood, 1 seeded sweep, 2 todo flood.  Frontier of round 0 is in queue[0]/cnt3[0].
+        int r = 0;
+        int32_t last = first;
+        while (last > 0) {
+            const int batch = last > 4096 ? 8 : 32;
+            const int grid = grid_for(last, 1024);
+            for (int b = 0; b < batch; b++, r++) {
+                if (which == 0) hipLaunchKernelGGL(k_edge_flood<0>, dim3(grid), dim3(256), 0, t->stream, E, t->queue[r % 2], t->queue[(r + 1) % 2], cnt3, r);
+                else if (which == 1) hipLaunchKernelGGL(k_edge_sweep, dim3(grid), dim3(256), 0, t->stream, E, t->queue[r % 2], t->queue[(r + 1) % 2], cnt3, r);
+                else hipLaunchKernelGGL(k_edge_flood<1>, dim3(grid), dim3(256), 0, t->stream, E, t->queue[r % 2], t->queue[(r + 1) % 2], cnt3, r);
+            }
+            HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            last = t->h_counters[r % 3];
+            if (r > (1 << 24)) { pydem_set_error("edge update did not terminate"); return -5; }
+        }
+        return 0;
+    };
+    if (nseed > 0) {
+        // keep a copy of the seeds: the flood consumes queue[0]
+        HIP_TRY(hipMemcpyAsync(t->flatlist + ntodo, t->queue[0], (size_t)nseed * 4, hipMemcpyDeviceToDevice, t->stream));
+        PYDEM_TRY(run_rounds(0, nseed));
+        int32_t three[3] = {nseed, 0, 0};
+        HIP_TRY(hipMemcpyAsync(t->queue[0], t->flatlist + ntodo, (size_t)nseed * 4, hipMemcpyDeviceToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(cnt3, three, sizeof(three), hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        PYDEM_TRY(run_rounds(1, nseed));
+        hipLaunchKernelGGL(k_edge_apply, dim3(grid_for(t->NN < (1 << 20) ? t->NN : (1 << 20), 1024)), dim3(256), 0, t->stream, E, t->uca,
+                           t->counters + 6);
+    }
+    hipLaunchKernelGGL(k_edge_apply_perimeter, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, E, t->uca);
+    if (ntodo > 0) {
+        int32_t three[3] = {ntodo, 0, 0};
+        HIP_TRY(hipMemcpyAsync(t->queue[0], t->flatlist, (size_t)ntodo * 4, hipMemcpyDeviceToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(cnt3, three, sizeof(three), hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        PYDEM_TRY(run_rounds(2, ntodo));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));
     return 0;
 }

@@ -236,8 +236,8 @@ class DEMProcessor(object):
         """Upstream contributing area (reference :682-776)."""
         if not self._has('direction'):
             self.calc_slopes_directions()
-        if uca_init is not None or edge_init_data is not None:
-            raise NotImplementedError("edge-resolution rounds (uca_init / edge_init_data) are not on the device yet")
+        if uca_init is not None:
+            return self._calc_uca_edge_round(uca_init, edge_init_data)
         self._ensure_tile()
         self._push('elev', 'mag', 'direction', 'flats')
         opt = self._options()
@@ -253,6 +253,29 @@ class DEMProcessor(object):
         self.twi_min_area = min(self.twi_min_area, opt.twi_min_area)
         # pits that found a drain are patched into mag/flats by the graph stage (reference :1369-1371)
         self._produced('section', 'proportion', 'uca', 'edge_todo', 'edge_done', 'mag', 'flats')
+        return self.uca
+
+    def _calc_uca_edge_round(self, uca_init, edge_init_data):
+        """calc_uca(uca_init=..., edge_init_data=[data, done, todo]) of the reference (:724-771):
+        only the contributions entering through finished neighbour edges are propagated."""
+        keys = ('left', 'right', 'top', 'bottom')
+        n, m = self.elev.shape
+        lens = dict(left=n, right=n, top=m, bottom=m)
+        if edge_init_data is None:
+            data = {k: np.zeros(lens[k]) for k in keys}
+            done = {k: np.zeros(lens[k], bool) for k in keys}
+            todo = {k: np.zeros(lens[k], bool) for k in keys}
+        else:
+            data, done, todo = edge_init_data
+        self._ensure_tile()
+        if not self._has('flats'):
+            self.find_flats()
+        self.uca = np.asarray(uca_init).astype('float64')                     # :744
+        self._push('elev', 'mag', 'direction', 'flats', 'uca')
+        opt = self._options()
+        logger.info("Starting edge resolution round")
+        self._tile.uca_edge_update(opt, [data[k] for k in keys], [done[k] for k in keys], [todo[k] for k in keys])
+        self._produced('uca', 'edge_todo', 'edge_done', 'mag', 'flats', 'section', 'proportion')
         return self.uca
 
     def calc_twi(self):

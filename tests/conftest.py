@@ -15,8 +15,10 @@ def pytest_configure(config):
 GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
 
 
-def golden_names(prefix=''):
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and f.startswith(prefix))
+def golden_names(prefix='', exclude='g6_'):
+    """Per-tile goldens by default; the edge-update goldens (g6_*) have their own tests."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and f.startswith(prefix)
+                  and not (exclude and f.startswith(exclude) and not prefix))
 
 
 def load_golden(name):
