@@ -97,6 +97,11 @@ int pydem_tile_set_spacing(pydem_tile *t, const double *dX, const double *dY,
                            const double *dX2, const double *dY2);
 int pydem_tile_upload(pydem_tile *t, int field, const void *src, int dtype);
 int pydem_tile_download(pydem_tile *t, int field, void *dst);
+/* one row (axis 0, n_cols elements) or one column (axis 1, n_rows elements) of a field, in the
+ * field's own element type: the strips neighbouring tiles exchange in the directory flow
+ * (reference pydem/process_manager.py:131-145 and :252-255 read/write them through zarr) */
+int pydem_tile_get_line(pydem_tile *t, int field, int axis, int64_t index, void *dst);
+int pydem_tile_set_line(pydem_tile *t, int field, int axis, int64_t index, const void *src);
 int pydem_tile_synchronize(pydem_tile *t);
 int pydem_tile_timings(pydem_tile *t, pydem_timings *out);
 int64_t pydem_tile_device_bytes(pydem_tile *t);
@@ -120,6 +125,12 @@ int pydem_twi(pydem_tile *t, pydem_options *opt);
  * pit_prop, pydem/dem_processing.py:1378-1380), in emission order.  Call with src == NULL to get
  * the count. */
 int pydem_tile_pit_edges(pydem_tile *t, int64_t *n, int32_t *src, int32_t *dst, double *w);
+
+/* Undo the slope patch of the drained pits (mag[pit] = -1 again, flats untouched).  In the
+ * reference's directory flow the calc_uca worker never writes its patched slope back to the store
+ * (pydem/process_manager.py:192-194), so later phases see slope == -1 at drained pits; the
+ * ProcessManager drop-in calls this to keep that behaviour. */
+int pydem_tile_restore_pit_slopes(pydem_tile *t);
 
 /* Kernel-only timing hook for bench.py: runs the interior stencil `iters` times on the tile's
  * resident elevation and returns the average kernel time (ms) measured with hipEvents on the

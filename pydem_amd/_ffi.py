@@ -55,6 +55,8 @@ SYMBOLS = {
     'pydem_tile_set_spacing': (C.c_int, [_P, _P, _P, _P, _P]),
     'pydem_tile_upload': (C.c_int, [_P, C.c_int, _P, C.c_int]),
     'pydem_tile_download': (C.c_int, [_P, C.c_int, _P]),
+    'pydem_tile_get_line': (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P]),
+    'pydem_tile_set_line': (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P]),
     'pydem_tile_synchronize': (C.c_int, [_P]),
     'pydem_tile_timings': (C.c_int, [_P, C.POINTER(Timings)]),
     'pydem_tile_device_bytes': (C.c_int64, [_P]),
@@ -66,6 +68,7 @@ SYMBOLS = {
     'pydem_uca_edge_update': (C.c_int, [_P, C.POINTER(Options), _PP, _PP, _PP]),
     'pydem_twi': (C.c_int, [_P, C.POINTER(Options)]),
     'pydem_tile_pit_edges': (C.c_int, [_P, C.POINTER(C.c_int64), _P, _P, _P]),
+    'pydem_tile_restore_pit_slopes': (C.c_int, [_P]),
     'pydem_bench_stencil': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
 }
 
@@ -146,6 +149,16 @@ class Tile(object):
         check(self.lib.pydem_tile_download(self._h, field, out.ctypes.data_as(_P)))
         return out
 
+    def get_line(self, field, axis, index):
+        out = np.empty(self.shape[1] if axis == 0 else self.shape[0], FIELD_DTYPE[field])
+        check(self.lib.pydem_tile_get_line(self._h, field, axis, index, out.ctypes.data_as(_P)))
+        return out
+
+    def set_line(self, field, axis, index, values):
+        v = np.ascontiguousarray(values, FIELD_DTYPE[field])
+        assert v.size == (self.shape[1] if axis == 0 else self.shape[0])
+        check(self.lib.pydem_tile_set_line(self._h, field, axis, index, v.ctypes.data_as(_P)))
+
     def synth_fractal(self, seed=0, row0=0, col0=0, n_octaves=12, top_shift=12, zmin=1.0, zrange=1000.0):
         check(self.lib.pydem_tile_synth_fractal(self._h, seed, row0, col0, n_octaves, top_shift, zmin, zrange))
 
@@ -182,6 +195,9 @@ class Tile(object):
             check(self.lib.pydem_tile_pit_edges(self._h, C.byref(n), src.ctypes.data_as(_P), dst.ctypes.data_as(_P),
                                                 w.ctypes.data_as(_P)))
         return src, dst, w
+
+    def restore_pit_slopes(self):
+        check(self.lib.pydem_tile_restore_pit_slopes(self._h))
 
     def bench_stencil(self, iters):
         ms = C.c_double(0)

@@ -39,6 +39,11 @@ template int tile_alloc<uint16_t>(pydem_tile *, uint16_t **, size_t);
 
 namespace {
 
+__global__ void k_restore_pit_slopes(const int32_t *__restrict__ src, int64_t n, double *mag)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) mag[src[e]] = -1.0;
+}
+
 template <typename S>
 __global__ void k_convert_to_f64(const S *__restrict__ src, double *__restrict__ dst, int64_t n)
 {
@@ -241,6 +246,35 @@ int pydem_tile_download(pydem_tile *t, int field, void *dst)
     return 0;
 }
 
+// one row (axis 0) or one column (axis 1) of a field: the strips the directory flow exchanges
+// between neighbouring tiles (reference process_manager.py:131-145, :252-255)
+static int line_copy(pydem_tile *t, int field, int axis, int64_t index, void *host, bool to_host)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    void **pp; size_t elem;
+    PYDEM_TRY(field_ptr(t, field, &pp, &elem));
+    if (!*pp || !t->have[field]) { pydem_set_error("field %d has not been computed or uploaded", field); return -3; }
+    const int64_t lim = axis == 0 ? t->n : t->m;
+    if (index < 0) index += lim;
+    if (index < 0 || index >= lim || (axis != 0 && axis != 1)) { pydem_set_error("line index out of range"); return -2; }
+    char *base = (char *)*pp;
+    if (axis == 0) {
+        char *row = base + (size_t)index * t->m * elem;
+        if (to_host) HIP_TRY(hipMemcpyAsync(host, row, (size_t)t->m * elem, hipMemcpyDeviceToHost, t->stream));
+        else HIP_TRY(hipMemcpyAsync(row, host, (size_t)t->m * elem, hipMemcpyHostToDevice, t->stream));
+    } else {
+        char *col = base + (size_t)index * elem;
+        if (to_host) HIP_TRY(hipMemcpy2DAsync(host, elem, col, (size_t)t->m * elem, elem, (size_t)t->n, hipMemcpyDeviceToHost, t->stream));
+        else HIP_TRY(hipMemcpy2DAsync(col, (size_t)t->m * elem, host, elem, elem, (size_t)t->n, hipMemcpyHostToDevice, t->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    if (!to_host && (field == PYDEM_ELEV || field == PYDEM_MAG || field == PYDEM_DIRECTION || field == PYDEM_FLATS)) t->graph_valid = false;
+    return 0;
+}
+
+int pydem_tile_get_line(pydem_tile *t, int field, int axis, int64_t index, void *dst) { return line_copy(t, field, axis, index, dst, true); }
+int pydem_tile_set_line(pydem_tile *t, int field, int axis, int64_t index, const void *src) { return line_copy(t, field, axis, index, (void *)src, false); }
+
 int pydem_tile_synchronize(pydem_tile *t)
 {
     HIP_TRY(hipSetDevice(t->device));
@@ -362,6 +396,18 @@ int pydem_tile_pit_edges(pydem_tile *t, int64_t *n, int32_t *src, int32_t *dst, 
     HIP_TRY(hipMemcpyAsync(src, t->pits.raw_src, t->pits.n_raw * 4, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipMemcpyAsync(dst, t->pits.raw_dst, t->pits.n_raw * 4, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipMemcpyAsync(w, t->pits.raw_w, t->pits.n_raw * 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+int pydem_tile_restore_pit_slopes(pydem_tile *t)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    if (t->pits.n_raw == 0) return 0;
+    const int64_t g = cdiv(t->pits.n_raw, 256);
+    hipLaunchKernelGGL(k_restore_pit_slopes, dim3((unsigned)(g < 1024 ? g : 1024)), dim3(256), 0, t->stream, t->pits.raw_src,
+                       t->pits.n_raw, t->mag);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(t->stream));
     return 0;
 }

@@ -199,6 +199,25 @@ class DEMProcessor(object):
     def _has(self, name):
         return name in self._on_device or self._host.get(name) is not None
 
+    # one row (axis 0) / column (axis 1) of a field without moving the whole array off the device
+    def get_line(self, name, axis, index):
+        if name in self._on_device and name not in self._host:
+            arr = self._tile.get_line(_FIELD_OF[name], axis, index)
+            return arr.astype(bool) if name in _BOOL_FIELDS else arr
+        a = self._host[name]
+        return np.array(a[index, :] if axis == 0 else a[:, index])
+
+    def set_line(self, name, axis, index, values):
+        if name in self._on_device:
+            self._tile.set_line(_FIELD_OF[name], axis, index, values)
+            self._host.pop(name, None)
+        else:
+            a = self._host[name]
+            if axis == 0:
+                a[index, :] = values
+            else:
+                a[:, index] = values
+
     @property
     def timings(self):
         return self._tile.timings() if self._tile is not None else {}
@@ -254,6 +273,13 @@ class DEMProcessor(object):
         # pits that found a drain are patched into mag/flats by the graph stage (reference :1369-1371)
         self._produced('section', 'proportion', 'uca', 'edge_todo', 'edge_done', 'mag', 'flats')
         return self.uca
+
+    def restore_pit_slopes(self):
+        """mag = -1 again at the pits drained by calc_uca (what the reference's slope *store* holds in
+        the directory flow, process_manager.py:192-194)."""
+        if self._tile is not None and 'mag' in self._on_device:
+            self._tile.restore_pit_slopes()
+            self._host.pop('mag', None)
 
     def _calc_uca_edge_round(self, uca_init, edge_init_data):
         """calc_uca(uca_init=..., edge_init_data=[data, done, todo]) of the reference (:724-771):

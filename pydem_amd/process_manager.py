@@ -1,0 +1,634 @@
+"""Directory orchestration: the `ProcessManager` drop-in for the accelerated path.
+
+Mirrors the public surface of the reference class (creare-com/pydem v1.2.1,
+pydem/process_manager.py:393-1318) for the part SURVEY.md section 8 puts in scope: tile grid
+discovery (compute_grid :517-565), overlap / edge-line bookkeeping (compute_grid_overlaps
+:601-740), the four phases (process_elevation :993, process_aspect_slope :1010, process_uca :1032,
+process_uca_edges :1090), TWI (:1290-1317) and the stitched non-overlap arrays
+(save_non_overlap_data :742-766).  GeoTIFF export / overviews are out of scope.
+
+What is different by design:
+  * tiles stay resident on their GPU between phases (the reference round-trips every array
+    through an on-disk zarr store and rebuilds a DEMProcessor -- and the whole flow graph -- per
+    phase and per edge round, process_manager.py:54-315);
+  * tiles shard round-robin over the visible GPUs (or over the ranks of a multi-process job),
+    replacing multiprocessing.Pool; the only cross-tile coupling, the UCA edge fix-up, moves
+    KiB-sized edge strips between neighbours (`EdgeTransport`);
+  * the edge fix-up runs in lock-step Jacobi rounds (every tile with a finished neighbour edge
+    updates in the same round from the previous round's strips) instead of the reference's
+    one-tile-at-a-time, metric-ordered loop (:1109-1211).  Corrections are additive deltas, so
+    both reach the same fixed point up to float64 rounding (pinned by tests/golden/pm_*).
+"""
+import logging
+import os
+
+import numpy as np
+
+from .dem_processing import DEMProcessor
+
+logger = logging.getLogger(__name__)
+
+EDGE_SLICES = {                                   # reference :41-50
+    'left': (slice(0, None), 0),
+    'right': (slice(0, None), -1),
+    'top': (0, slice(0, None)),
+    'bottom': (-1, slice(0, None)),
+    'top-left': (0, 0),
+    'top-right': (0, -1),
+    'bottom-right': (-1, -1),
+    'bottom-left': (-1, 0),
+}
+SIDES = ('left', 'right', 'top', 'bottom')
+CORNERS = ('top-left', 'top-right', 'bottom-left', 'bottom-right')
+
+DEBUG = False     # like the reference's module global (:52): force dX = dY = 1 inside the phases
+
+DEM_PROC_KWARGS = (                               # whitelist of the reference (:401-433)
+    "fill_flats", "fill_flats_below_sea", "fill_flats_source_tol", "fill_flats_peaks", "fill_flats_pits",
+    "fill_flats_max_iter", "drain_pits", "drain_pits_path", "drain_pits_min_border", "drain_pits_spill",
+    "drain_flats", "drain_pits_max_iter", "drain_pits_max_dist", "drain_pits_max_dist_XY",
+    "apply_uca_limit_edges", "apply_twi_limits", "apply_twi_limits_on_uca", "uca_saturation_limit",
+    "twi_min_slope", "twi_min_area", "circular_ref_maxcount", "maximum_pit_area")
+
+
+def read_tile(fn):
+    """Load one elevation tile: dict(elev, bounds=(left, bottom, right, top), dlon, dlat, dX.. optional).
+    `.npz` tiles carry `elev` and `bounds`; optional `dX, dY, dX2, dY2` override the spacing."""
+    ext = os.path.splitext(fn)[1].lower()
+    if ext == '.npz':
+        with np.load(fn) as d:
+            out = {k: d[k] for k in d.files}
+        elev = out['elev']
+        left, bottom, right, top = [float(v) for v in out['bounds']]
+        out['bounds'] = (left, bottom, right, top)
+        out.setdefault('dlon', (right - left) / elev.shape[1])
+        out.setdefault('dlat', -(top - bottom) / elev.shape[0])
+        return out
+    raise NotImplementedError("unsupported tile format %r (raster IO is outside the accelerated path; "
+                              "use .npz tiles with `elev` and `bounds`)" % ext)
+
+
+class EdgeTransport(object):
+    """Moves edge strips between tiles.  This default keeps everything in one process: tiles on any
+    of the visible GPUs, strips staged through host memory (they are KiB-sized; the exchange is
+    latency-bound).  `pydem_amd.parallel.DistTransport` carries the same strips between ranks."""
+
+    def __init__(self, pm):
+        self.pm = pm
+
+    def owns(self, i):
+        return True
+
+    def gather_lines(self, requests):
+        """requests: list of (tile, name, axis, index) -> list of 1-D arrays (None for missing tiles)."""
+        return [None if t < 0 else self.pm.tiles[t].get_line(name, axis, index) for t, name, axis, index in requests]
+
+    def allreduce_max(self, value):
+        return value
+
+
+class ProcessManager(object):
+    dtype = np.float64
+    grid_round_decimals = 2
+    n_workers = 1
+    in_path = '.'
+    out_format = 'npy'
+    _INPUT_FILE_TYPES = ["npz"]
+
+    def __init__(self, **kwargs):
+        self.dem_proc_kwargs = {}
+        self.devices = None
+        self.processor_cls = DEMProcessor
+        self.elev_conditioned = False      # inputs already conditioned: skip fill_flats / pit paths (see process_elevation)
+        self.transport = None
+        self.max_edge_rounds = 10000
+        for k, v in kwargs.items():
+            if k == 'dem_proc_kwargs':
+                bad = [kk for kk in v if kk not in DEM_PROC_KWARGS]
+                if bad:
+                    raise ValueError("dem_proc_kwargs: unknown keys %r" % bad)
+            setattr(self, k, v)
+        if 'out_path' not in kwargs:
+            self.out_path = os.path.join(self.in_path, 'results')
+        if 'elev_source_files' not in kwargs:
+            esf = [os.path.join(self.in_path, fn) for fn in os.listdir(self.in_path)
+                   if os.path.splitext(fn)[-1].replace('.', '') in self._INPUT_FILE_TYPES]
+            esf.sort()                                                      # reference :462-469
+            self.elev_source_files = esf
+        self._tile_meta = [read_tile(fn) for fn in self.elev_source_files]
+        self.index = self.compute_index()
+        self.tiles = [None] * self.n_inputs
+        self.uca0 = [None] * self.n_inputs        # first-pass UCA per tile (the reference's 'uca' store)
+        self.edge_rounds = 0
+        if self.transport is None:
+            self.transport = EdgeTransport(self)
+
+    # ------------------------------------------------------------------ grid bookkeeping
+    def _i(self, name):
+        return ['left', 'bottom', 'right', 'top', 'dlon', 'dlat', 'nrows', 'ncols'].index(name)
+
+    @property
+    def n_inputs(self):
+        return len(self.elev_source_files)
+
+    def compute_index(self):
+        """left, bottom, right, top, dlon, dlat, nrows, ncols per tile (reference :483-492)."""
+        index = np.zeros((len(self.elev_source_files), 8))
+        for i, meta in enumerate(self._tile_meta):
+            index[i, :4] = np.array(meta['bounds'])
+            index[i, 4] = meta['dlon']
+            index[i, 5] = meta['dlat']
+            index[i, 6:] = meta['elev'].shape
+        return index
+
+    def compute_grid(self):
+        """Place every tile on a (row, col) grid keyed by its rounded top latitude / left longitude and
+        lay the tiles side by side in one big index space (reference :517-565)."""
+        lats = np.round(self.index[:, self._i('top')], self.grid_round_decimals)
+        lons = np.round(self.index[:, self._i('left')], self.grid_round_decimals)
+        ulats = np.sort(np.unique(lats))[::-1].tolist()
+        ulons = np.sort(np.unique(lons)).tolist()
+        grid_shape = (len(ulats), len(ulons))
+        grid_id = np.zeros((self.n_inputs, 3), dtype=int)
+        grid_id2i = -np.ones(grid_shape, dtype=int)
+        lat_size = -np.ones(len(ulats), dtype=int)
+        lon_size = -np.ones(len(ulons), dtype=int)
+        for i in range(self.n_inputs):
+            r, c = ulats.index(lats[i]), ulons.index(lons[i])
+            grid_id[i] = [r, c, c + r * grid_shape[1]]
+            grid_id2i[r, c] = i
+            nrows, ncols = int(self.index[i, self._i('nrows')]), int(self.index[i, self._i('ncols')])
+            if lat_size[r] < 0:
+                lat_size[r] = nrows
+            elif lat_size[r] != nrows:
+                raise AssertionError("tiles of grid row %d differ in height" % r)
+            if lon_size[c] < 0:
+                lon_size[c] = ncols
+            elif lon_size[c] != ncols:
+                raise AssertionError("tiles of grid column %d differ in width" % c)
+        lat_cum = np.concatenate([[0], lat_size.cumsum().astype(int)])
+        lon_cum = np.concatenate([[0], lon_size.cumsum().astype(int)])
+        self.grid_slice = [(slice(int(lat_cum[r]), int(lat_cum[r + 1])), slice(int(lon_cum[c]), int(lon_cum[c + 1])))
+                           for r, c, _ in grid_id]
+        self.grid_id, self.grid_id2i, self.grid_shape = grid_id, grid_id2i, grid_shape
+        self.grid_lat_size, self.grid_lon_size = lat_size, lon_size
+        self._lat_cum, self._lon_cum = lat_cum, lon_cum
+        self.grid_size_tot = [int(lat_size.sum()), int(lon_size.sum())]
+        self.grid_chunk = [int(lat_size.min()), int(lon_size.min())]
+
+    @staticmethod
+    def _calc_overlap(a, da, b, db, s, tie):
+        """Pixels of overlap with a neighbour, for the non-overlap slices (first value) and for locating
+        the neighbour's coincident edge line (second value; at least 1) -- reference :567-599."""
+        n_overlap_a = int(np.round(((b - a) / da + tie - 0.01) / 2))
+        n_overlap_b = max(int(np.round((b - a) / db)), 1)
+        return n_overlap_a, n_overlap_b
+
+    def compute_grid_overlaps(self):
+        """Per tile: the slice that is uniquely its own, and where (in the side-by-side index space) the
+        neighbouring edge lines and corner pixels live (reference :601-740)."""
+        I = self._i
+        self.grid_slice_unique, self.edge_data = [], []
+        nr, nc = self.grid_id2i.shape
+        for i in range(self.n_inputs):
+            r, c = self.grid_id[i, 0], self.grid_id[i, 1]
+            slc = self.grid_slice[i]
+            lon_start = lon_start_e = lon_end = lon_end_e = 0
+            lat_start = lat_start_e = lat_end = lat_end_e = 0
+            if c > 0 and self.grid_id2i[r, c - 1] >= 0:
+                nb = self.grid_id2i[r, c - 1]
+                lon_start, lon_start_e = self._calc_overlap(self.index[i, I('left')], self.index[i, I('dlon')],
+                                                            self.index[nb, I('right')], self.index[nb, I('dlon')], slc[1].start, 0)
+            if c < nc - 1 and self.grid_id2i[r, c + 1] >= 0:
+                nb = self.grid_id2i[r, c + 1]
+                lon_end, lon_end_e = self._calc_overlap(self.index[nb, I('left')], self.index[i, I('dlon')],
+                                                        self.index[i, I('right')], self.index[nb, I('dlon')], slc[1].start, 1)
+            if r > 0 and self.grid_id2i[r - 1, c] >= 0:
+                nb = self.grid_id2i[r - 1, c]
+                lat_start, lat_start_e = self._calc_overlap(self.index[i, I('top')], self.index[i, I('dlat')],
+                                                            self.index[nb, I('bottom')], self.index[nb, I('dlat')], slc[0].start, 0)
+            if r < nr - 1 and self.grid_id2i[r + 1, c] >= 0:
+                nb = self.grid_id2i[r + 1, c]
+                lat_end, lat_end_e = self._calc_overlap(self.index[nb, I('top')], self.index[i, I('dlat')],
+                                                        self.index[i, I('bottom')], self.index[nb, I('dlat')], slc[0].start, 1)
+            corner_tl = int(c > 0 and r > 0)
+            corner_bl = int(c > 0 and r < nr - 1)
+            corner_tr = int(c < nc - 1 and r > 0)
+            corner_br = int(c < nc - 1 and r < nr - 1)
+            self.grid_slice_unique.append((slice(slc[0].start + lat_start, slc[0].stop - lat_end),
+                                           slice(slc[1].start + lon_start, slc[1].stop - lon_end)))
+            self.edge_data.append({
+                'left': (slc[0], slc[1].start - lon_start_e),
+                'right': (slc[0], slc[1].stop + lon_end_e - 1),
+                'top': (slc[0].start - lat_start_e, slc[1]),
+                'top-left': (slc[0].start - lat_start_e * corner_tl, slc[1].start - lon_start_e * corner_tl),
+                'top-right': (slc[0].start - lat_start_e * corner_tr, slc[1].stop + lon_end_e * corner_tr - 1),
+                'bottom': (slc[0].stop + lat_end_e - 1, slc[1]),
+                'bottom-left': (slc[0].stop + lat_end_e * corner_bl - 1, slc[1].start - lon_start_e * corner_bl),
+                'bottom-right': (slc[0].stop + lat_end_e * corner_br - 1, slc[1].stop + lon_end_e * corner_br - 1),
+            })
+        # non-overlapping mosaic (reference :707-740)
+        def _min_unique(axis):
+            vals = []
+            for k in range(self.grid_id2i.shape[axis]):
+                col = self.grid_id2i[k, :] if axis == 0 else self.grid_id2i[:, k]
+                sizes = [self.grid_slice_unique[t][axis].stop - self.grid_slice_unique[t][axis].start for t in col if t >= 0]
+                vals.append(min(sizes))
+            return np.array(vals)
+        self.grid_lat_size_unique = _min_unique(0)
+        self.grid_lon_size_unique = _min_unique(1)
+        lat_cum = np.concatenate([[0], self.grid_lat_size_unique.cumsum().astype(int)])
+        lon_cum = np.concatenate([[0], self.grid_lon_size_unique.cumsum().astype(int)])
+        self.grid_slice_noverlap = []
+        for i in range(self.n_inputs):
+            r, c = self.grid_id[i, 0], self.grid_id[i, 1]
+            su = self.grid_slice_unique[i]
+            self.grid_slice_noverlap.append((slice(int(lat_cum[r]), int(lat_cum[r]) + su[0].stop - su[0].start),
+                                             slice(int(lon_cum[c]), int(lon_cum[c]) + su[1].stop - su[1].start)))
+        self.grid_size_tot_unique = [int(self.grid_lat_size_unique.sum()), int(self.grid_lon_size_unique.sum())]
+
+    # ------------------------------------------------------------------ locating neighbour lines
+    def _locate(self, grow, gcol):
+        """Global (row, col) of the side-by-side index space -> (tile, local row, local col); tile = -1
+        where the mosaic has a hole (the reference reads zeros/False from its zero-filled store)."""
+        r = int(np.searchsorted(self._lat_cum, grow, side='right') - 1)
+        c = int(np.searchsorted(self._lon_cum, gcol, side='right') - 1)
+        if r < 0 or c < 0 or r >= self.grid_id2i.shape[0] or c >= self.grid_id2i.shape[1]:
+            return -1, 0, 0
+        return int(self.grid_id2i[r, c]), int(grow - self._lat_cum[r]), int(gcol - self._lon_cum[c])
+
+    def _edge_line(self, i, key):
+        """Where tile i's `key` edge data comes from: (tile, axis, local index) for the four sides (the
+        line spans the full neighbour edge) or (tile, local row, local col) for the corners."""
+        ed = self.edge_data[i][key]
+        slc = self.grid_slice[i]
+        if key in ('left', 'right'):
+            t, _, lc = self._locate(slc[0].start, ed[1])
+            return t, 1, lc
+        if key in ('top', 'bottom'):
+            t, lr, _ = self._locate(ed[0], slc[1].start)
+            return t, 0, lr
+        return self._locate(ed[0], ed[1])
+
+    @staticmethod
+    def check_1overlap(out_slice, edge_slc):
+        """True when the neighbour line sits exactly one pixel outside the tile (reference :286-293)."""
+        e = [getattr(v, 'start', v) for v in edge_slc]
+        e_c = [min(max(e[0], out_slice[0].start), out_slice[0].stop - 1),
+               min(max(e[1], out_slice[1].start), out_slice[1].stop - 1)]
+        return any(abs(a - b) == 1 for a, b in zip(e_c, e))
+
+    # ------------------------------------------------------------------ phases
+    def _device_of(self, i):
+        if self.devices is None:
+            from . import _ffi
+            self.devices = list(range(_ffi.device_count()))
+        return self.devices[i % len(self.devices)]
+
+    def _spacing(self, i):
+        meta = self._tile_meta[i]
+        n = meta['elev'].shape[0]
+        if DEBUG:
+            return dict(dX=np.ones(n - 1), dY=np.ones(n - 1), dX2=np.ones(n), dY2=np.ones(n))
+        if 'dX' in meta:
+            return dict(dX=np.asarray(meta['dX'], float), dY=np.asarray(meta['dY'], float),
+                        dX2=np.asarray(meta.get('dX2', np.ones(n)), float), dY2=np.asarray(meta.get('dY2', np.ones(n)), float))
+        # projected tiles: pixel size is the spacing (reference utils.mk_dx_dy_from_geotif_layer :132-137)
+        a, e = meta['dlon'], meta['dlat']
+        return dict(dX=np.ones(n - 1) * a, dY=np.abs(np.ones(n - 1) * e), dX2=np.ones(n) * a, dY2=np.abs(np.ones(n) * e))
+
+    def _owned(self):
+        return [i for i in range(self.n_inputs) if self.transport.owns(i)]
+
+    def process_elevation(self, indices=None):
+        """Reference :993-1008 + worker calc_elev_cond :54-71 (fill flats, drain pit paths, store elev)."""
+        for i in self._owned():
+            kw = dict(self.dem_proc_kwargs)
+            kw.update(self._spacing(i))
+            if self.elev_conditioned:
+                kw['fill_flats'] = False
+                kw['drain_pits_path'] = False
+            dp = self._make_processor(i, elev=self._tile_meta[i]['elev'], **kw)
+            if not self.elev_conditioned:
+                dp.calc_fill_flats()
+                dp.calc_pit_drain_paths()
+            self.tiles[i] = dp
+        return [1] * self.n_inputs
+
+    def _make_processor(self, i, **kw):
+        if self.processor_cls is DEMProcessor:
+            kw['device'] = self._device_of(i)
+        return self.processor_cls(**kw)
+
+    def process_aspect_slope(self):
+        """Reference :1010-1030 + worker calc_aspect_slope :73-92."""
+        self.compute_grid_overlaps()
+        for i in self._owned():
+            dp = self.tiles[i]
+            dp.fill_flats = False                      # "assuming we already did this" (:78)
+            dp.calc_slopes_directions()
+        return [1] * self.n_inputs
+
+    def _patch_overlap1_edges(self):
+        """Single-pixel-overlap fix of the reference's calc_uca worker (:102-180): an edge cell whose
+        flow leaves the tile takes aspect/slope from the coincident (or adjacent) neighbour line.  The
+        reference does this tile by tile in index order, writing the patched lines back to the shared
+        store; the same order is kept here, on the edge lines only."""
+        two_pi = 2 * np.pi
+        downstream = {'left': [np.pi / 2, 3 * np.pi / 2], 'right': [two_pi - np.pi / 2, np.pi / 2],
+                      'top': [0, np.pi], 'bottom': [np.pi, two_pi]}
+        own = {'left': (1, 0), 'right': (1, -1), 'top': (0, 0), 'bottom': (0, -1)}       # (axis, index)
+        for i in range(self.n_inputs):
+            out_slice = self.grid_slice[i]
+            for key in SIDES:
+                if not self.check_1overlap(out_slice, self.edge_data[i][key]):
+                    continue
+                axis, idx = own[key]
+                src, s_axis, s_idx = self._edge_line(i, key)
+                nb_dir, nb_mag, d, mg = self._lines([(src, 'direction', s_axis, s_idx), (src, 'mag', s_axis, s_idx),
+                                                     (i, 'direction', axis, idx), (i, 'mag', axis, idx)])
+                if not self.transport.owns(i):
+                    continue
+                if key == 'right':
+                    ids = ((d >= downstream[key][0]) | (d <= downstream[key][1])) & (d >= 0)
+                else:
+                    ids = (d >= downstream[key][0]) & (d <= downstream[key][1])
+                if key in ('top', 'bottom'):
+                    ids = ids | ((d < 1e-6) & (d >= 0)) | (np.abs(d - np.pi * 2) < 1e-6)
+                ids = ids | (d == -1)
+                if key in ('left', 'right'):
+                    ids[0] = ids[0] & (not ((d[0] >= downstream['top'][0]) & (d[0] <= downstream['top'][1])))
+                    ids[-1] = ids[-1] & (not ((d[-1] >= downstream['bottom'][0]) & (d[-1] <= downstream['bottom'][1])))
+                else:
+                    ids[0] = ids[0] & (not ((d[0] >= downstream['left'][0]) & (d[0] <= downstream['left'][1])))
+                    ids[-1] = ids[-1] & (not ((d[-1] >= downstream['right'][0]) | (d[-1] <= downstream['right'][1])) & (d[-1] >= 0))
+                if nb_dir is None:
+                    nb_dir = np.zeros_like(d); nb_mag = np.zeros_like(d)
+                d = d.copy(); mg = mg.copy()
+                d[ids] = nb_dir[ids]
+                mg[ids] = nb_mag[ids]
+                self.tiles[i].set_line('direction', axis, idx, d)
+                self.tiles[i].set_line('mag', axis, idx, mg)
+            for key in CORNERS:
+                if not self.check_1overlap(out_slice, self.edge_data[i][key]):
+                    continue
+                keytb, keylr = key.split('-')
+                rr, cc = EDGE_SLICES[key]
+                src, s_r, s_c = self._edge_line(i, key)
+                (row_d, row_m, nb_d_row, nb_m_row) = self._lines([(i, 'direction', 0, rr), (i, 'mag', 0, rr),
+                                                                  (src, 'direction', 0, s_r), (src, 'mag', 0, s_r)])
+                if not self.transport.owns(i):
+                    continue
+                d = row_d[cc]
+                tb_ok = ((d >= downstream[keytb][0]) & (d <= downstream[keytb][1])) | (((d < 1e-6) & (d >= 0)) | (np.abs(d - np.pi * 2) < 1e-6))
+                if keylr == 'right':
+                    ids = (((d >= downstream[keylr][0]) | (d <= downstream[keylr][1])) & (d >= 0)) & tb_ok
+                else:
+                    ids = (d >= downstream[keylr][0]) & (d <= downstream[keylr][1]) & tb_ok
+                if not ids:
+                    continue
+                row_d = row_d.copy(); row_m = row_m.copy()
+                row_d[cc] = 0.0 if nb_d_row is None else nb_d_row[s_c]
+                row_m[cc] = 0.0 if nb_m_row is None else nb_m_row[s_c]
+                self.tiles[i].set_line('direction', 0, rr, row_d)
+                self.tiles[i].set_line('mag', 0, rr, row_m)
+
+    def _lines(self, requests):
+        return self.transport.gather_lines(requests)
+
+    def process_uca(self):
+        """Reference :1032-1059 + worker calc_uca :94-197 (overlap-1 patch, find_flats, calc_uca)."""
+        self._patch_overlap1_edges()
+        for i in self._owned():
+            dp = self.tiles[i]
+            dp.find_flats()
+            dp.calc_uca()
+            dp.restore_pit_slopes()        # the worker does not write its patched slope back (:192-194)
+            self.uca0[i] = None
+        return [1] * self.n_inputs
+
+    # ---- edge fix-up ------------------------------------------------------------------------
+    def _edge_inputs(self, i, snap):
+        """Strips for one tile from the snapshot of the previous round, with the corner rules of the
+        reference's calc_uca_ec (:250-274)."""
+        data, done, todo, todo_nb = {}, {}, {}, {}
+        own = {'left': (1, 0), 'right': (1, -1), 'top': (0, 0), 'bottom': (0, -1)}
+        for key in SIDES:
+            src, axis, idx = self._edge_line(i, key)
+            L = self.tiles_shape[i][0] if axis == 1 else self.tiles_shape[i][1]
+            if src < 0:
+                data[key] = np.zeros(L); done[key] = np.zeros(L, bool); todo_nb[key] = np.zeros(L, bool)
+            else:
+                data[key] = snap[(src, 'uca', axis, idx)].copy()
+                done[key] = snap[(src, 'edge_done', axis, idx)].copy()
+                todo_nb[key] = snap[(src, 'edge_todo', axis, idx)].copy()
+            a, ix = own[key]
+            todo[key] = snap[(i, 'edge_todo', a, ix)].copy()
+        for key in ('top-left', 'bottom-right', 'top-right', 'bottom-left'):            # order of the reference (:258)
+            keytb, keylr = key.split('-')
+            inds = EDGE_SLICES[key]
+            overlap = done[keytb][inds[1]] & done[keylr][inds[0]]
+            if overlap:
+                done[keytb][inds[1]] = False                                             # :266
+                if self.check_1overlap(self.grid_slice[i], self.edge_data[i][key]):
+                    src, lr, lc = self._edge_line(i, key)
+                    if src >= 0 and snap[(src, 'edge_done', 0, lr)][lc]:                 # :268
+                        v = snap[(src, 'uca', 0, lr)][lc]
+                        data[keylr][inds[0]] = v                                         # :269
+                        data[keytb][inds[1]] = v                                         # :270
+        todo = {k: v & (todo_nb[k] == False) for k, v in todo.items()}                   # noqa: E712  (:274)
+        return data, done, todo
+
+    def _snapshot_requests(self, i):
+        own = {'left': (1, 0), 'right': (1, -1), 'top': (0, 0), 'bottom': (0, -1)}
+        req = set()
+        for key in SIDES:
+            src, axis, idx = self._edge_line(i, key)
+            if src >= 0:
+                for nm in ('uca', 'edge_done', 'edge_todo'):
+                    req.add((src, nm, axis, idx))
+            a, ix = own[key]
+            req.add((i, 'edge_todo', a, ix))
+        for key in CORNERS:
+            if self.check_1overlap(self.grid_slice[i], self.edge_data[i][key]):
+                src, lr, lc = self._edge_line(i, key)
+                if src >= 0:
+                    req.add((src, 'edge_done', 0, lr)); req.add((src, 'uca', 0, lr))
+        return req
+
+    def _metric_requests(self, i):
+        own = {'left': (1, 0), 'right': (1, -1), 'top': (0, 0), 'bottom': (0, -1)}
+        req = set()
+        for key in SIDES:
+            src, axis, idx = self._edge_line(i, key)
+            if src >= 0:
+                req.add((src, 'edge_done', axis, idx))
+            req.add((i, 'edge_todo',) + own[key])
+        for key in CORNERS:
+            src, lr, lc = self._edge_line(i, key)
+            if src >= 0:
+                req.add((src, 'edge_done', 0, lr))
+        return req
+
+    def _tile_metric(self, i, snap):
+        """(fraction, count) of tile i's 'todo' edge cells whose neighbour cell is done; the four corner
+        pixels count too (reference calc_uca_ec_metrics :199-221 iterates all 8 edge_slice keys)."""
+        own = {'left': (1, 0), 'right': (1, -1), 'top': (0, 0), 'bottom': (0, -1)}
+        n_done = p_done = 0
+        for key in SIDES:
+            src, axis, idx = self._edge_line(i, key)
+            et = snap[(i, 'edge_todo',) + own[key]]
+            edn = snap[(src, 'edge_done', axis, idx)] if src >= 0 else np.zeros_like(et)
+            n_done += int((et & edn).sum())
+            p_done += int(et.sum())
+        for key in CORNERS:
+            keytb, keylr = key.split('-')
+            rr, cc = EDGE_SLICES[key]
+            et = bool(snap[(i, 'edge_todo',) + own[keytb]][cc])
+            src, lr, lc = self._edge_line(i, key)
+            edn = bool(snap[(src, 'edge_done', 0, lr)][lc]) if src >= 0 else False
+            n_done += int(et and edn)
+            p_done += int(et)
+        return (n_done / (1e-16 + p_done), n_done)
+
+    def update_uca_edge_metrics(self, index=None):
+        """Refresh the per-tile edge metrics table (reference :1061-1088) for the tiles in `index`."""
+        if index is None:
+            index = range(self.n_inputs)
+        if getattr(self, '_mets', None) is None or len(self._mets) != self.n_inputs:
+            self._mets = np.zeros((self.n_inputs, 2))
+        reqs = set()
+        for i in index:
+            reqs |= self._metric_requests(i)
+        reqs = sorted(reqs)
+        snap = dict(zip(reqs, self._lines(reqs)))
+        for i in index:
+            self._mets[i] = self._tile_metric(i, snap)
+        return self._mets.copy()
+
+    def _edge_round(self, i):
+        """One calc_uca_ec of the reference (:224-284) for tile i, from the neighbours' current lines."""
+        reqs = sorted(self._snapshot_requests(i))
+        snap = dict(zip(reqs, self._lines(reqs)))
+        if not self.transport.owns(i):
+            return
+        data, done, todo = self._edge_inputs(i, snap)
+        dp = self.tiles[i]
+        if self.uca0[i] is None:
+            self.uca0[i] = np.array(dp.uca)              # the reference keeps the first pass as 'uca'
+        dp.calc_uca(uca_init=dp.uca, edge_init_data=[data, done, todo])
+
+    def _rank_tiles(self, mets, mets_type):
+        if mets.shape[0] == 1:
+            return np.zeros(1, int)
+        return np.argpartition(-mets[:, mets_type], min(self.n_workers * 2, mets.shape[0] - 1))   # :1111-1113
+
+    def process_uca_edges(self, mets_type=0):
+        """Cross-tile UCA correction.  Default `edge_mode='reference'` follows the reference's serial loop
+        exactly (:1109-1211, n_workers == 1): rank the tiles by the fraction of their 'todo' edge cells
+        that face a finished neighbour, run one edge round on the first, refresh the metrics of that
+        tile and its four neighbours, stop when the ranking no longer changes.  The result of that loop
+        depends on the visiting order (finished edge cells are re-synchronised with the neighbour's
+        value at every round, :806-809), so parity needs the same order; the rounds themselves are tiny
+        (KiB strips), the loop is latency-bound and is not where tiles-per-GPU parallelism pays.
+        `edge_mode='lockstep'` updates every tile with a non-zero count in the same round instead."""
+        self.tiles_shape = [tuple(int(v) for v in self.index[i, 6:]) for i in range(self.n_inputs)]
+        self.edge_rounds = 0
+        self._mets = None
+        if getattr(self, 'edge_mode', 'reference') == 'lockstep':
+            while self.edge_rounds < self.max_edge_rounds:
+                mets = self.update_uca_edge_metrics()
+                active = [i for i in range(self.n_inputs) if mets[i, 1] > 0]
+                if not active:
+                    break
+                reqs = set()
+                for i in active:
+                    reqs |= self._snapshot_requests(i)
+                reqs = sorted(reqs)
+                snap = dict(zip(reqs, self._lines(reqs)))
+                for i in active:
+                    if not self.transport.owns(i):
+                        continue
+                    data, done, todo = self._edge_inputs(i, snap)
+                    dp = self.tiles[i]
+                    if self.uca0[i] is None:
+                        self.uca0[i] = np.array(dp.uca)
+                    dp.calc_uca(uca_init=dp.uca, edge_init_data=[data, done, todo])
+                self.edge_rounds += 1
+            return self.update_uca_edge_metrics()
+        mets = self.update_uca_edge_metrics()
+        I = self._rank_tiles(mets, mets_type)
+        I_old = np.zeros_like(I)
+        nr, nc = self.grid_id2i.shape
+        while np.any(I_old != I) and self.edge_rounds < self.max_edge_rounds:
+            f = int(I[0])
+            self._edge_round(f)
+            self.edge_rounds += 1
+            I_old[:] = I[:]
+            r, c, _ = self.grid_id[f]
+            check = [f]
+            if c > 0: check.append(self.grid_id2i[r, c - 1])
+            if c < nc - 1: check.append(self.grid_id2i[r, c + 1])
+            if r > 0: check.append(self.grid_id2i[r - 1, c])
+            if r < nr - 1: check.append(self.grid_id2i[r + 1, c])
+            check = np.unique(check)
+            mets = self.update_uca_edge_metrics(check[check != -1].tolist())
+            I = self._rank_tiles(mets, mets_type)
+        return mets
+
+    def process_twi(self):
+        """Full directory flow (reference :1290-1317)."""
+        logger.info("Compute Grid")
+        self.compute_grid()
+        logger.info("Compute Elevation")
+        self.process_elevation()
+        logger.info("Compute Aspect and Slope")
+        self.process_aspect_slope()
+        logger.info("Compute UCA")
+        self.process_uca()
+        logger.info("Compute UCA Corrections")
+        self.process_uca_edges()
+        for i in self._owned():
+            dp = self.tiles[i]
+            dp.find_flats()               # the reference's calc_twi worker rebuilds flats from slope == -1 (:310)
+            dp.calc_twi()
+        return [1] * self.n_inputs
+
+    # ------------------------------------------------------------------ results
+    def tile_result(self, i, key):
+        """Per-tile array under the reference's store names: elev, aspect, slope, uca (first pass),
+        uca_edges (edge corrections), edge_todo, edge_done, twi."""
+        dp = self.tiles[i]
+        if key == 'elev':
+            return np.asarray(dp.elev, float)
+        if key == 'aspect':
+            return dp.direction
+        if key == 'slope':
+            return dp.mag
+        if key == 'uca':
+            return dp.uca if self.uca0[i] is None else self.uca0[i]
+        if key == 'uca_edges':
+            return np.zeros(dp.uca.shape) if self.uca0[i] is None else dp.uca - self.uca0[i]
+        if key == 'uca_total':
+            return dp.uca
+        if key in ('edge_todo', 'edge_done'):
+            return getattr(dp, key)
+        if key == 'twi':
+            return dp.twi
+        raise KeyError(key)
+
+    def save_non_overlap_data(self, keys=('elev', 'uca', 'aspect', 'slope', 'twi')):
+        """Stitch the uniquely-owned part of every tile into one array per key (reference :742-766;
+        'uca' includes the edge corrections as there)."""
+        out = {}
+        for key in keys:
+            full = np.zeros(self.grid_size_tot_unique, self.dtype)
+            for i in self._owned():
+                su, sl = self.grid_slice_unique[i], self.grid_slice[i]
+                loc = (slice(su[0].start - sl[0].start, su[0].stop - sl[0].start),
+                       slice(su[1].start - sl[1].start, su[1].stop - sl[1].start))
+                src = self.tile_result(i, 'uca_total' if key == 'uca' else key)
+                full[self.grid_slice_noverlap[i]] = src[loc]
+            out[key] = full
+        self.out_file_noverlap = out
+        return out

@@ -97,3 +97,30 @@ def cone_scaled(nn):
     """case_cone_scaled input (utils_test_pydem.py:127-130): cone shifted to be >= 0."""
     z = cone(nn)
     return z - z.ravel().min()
+
+
+def chunk_edges(nn, n_chunks, overlap):
+    """Start/stop indices of `n_chunks` tiles along an axis of length nn with `overlap` shared pixels."""
+    size = int(np.ceil(nn / n_chunks))
+    lo = np.arange(0, nn - overlap, size)
+    lo[1:] -= overlap // 2
+    hi = np.arange(0, nn - overlap, size)
+    hi[:-1] = hi[1:] + int(np.ceil(overlap / 2))
+    hi[-1] = nn
+    return lo, np.minimum(hi, nn)
+
+
+def split_mosaic(raster, ny_grid, nx_grid, overlap, lat=(46.0, 45.0), lon=(-73.0, -72.0)):
+    """Cut one raster into overlapping tiles with pixel-centred geographic bounds; yields
+    (elev, (left, bottom, right, top)) in row-major tile order."""
+    ni, nj = raster.shape
+    la = np.linspace(lat[0], lat[1], ni)
+    lo = np.linspace(lon[0], lon[1], nj)
+    te_, be_ = chunk_edges(ni, ny_grid, overlap)
+    le_, re_ = chunk_edges(nj, nx_grid, overlap)
+    for te, be in zip(te_, be_):
+        for le, re in zip(le_, re_):
+            h = abs(la[te] - la[be - 1]) / (be - te - 1.0)
+            w = abs(lo[le] - lo[re - 1]) / (re - le - 1.0)
+            top, left = la[te] + h / 2, lo[le] - w / 2
+            yield raster[te:be, le:re].copy(), (left, top - h * (be - te), left + w * (re - le), top)

@@ -15,10 +15,13 @@ def pytest_configure(config):
 GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
 
 
-def golden_names(prefix='', exclude='g6_'):
-    """Per-tile goldens by default; the edge-update goldens (g6_*) have their own tests."""
-    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz') and f.startswith(prefix)
-                  and not (exclude and f.startswith(exclude) and not prefix))
+def golden_names(prefix=''):
+    """Without a prefix: the per-tile goldens g1_..g5_ (edge-update g6_* and directory pm_* goldens
+    have their own tests and are selected by prefix)."""
+    names = sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith('.npz'))
+    if prefix:
+        return [n for n in names if n.startswith(prefix)]
+    return [n for n in names if n[:3] in ('g1_', 'g2_', 'g3_', 'g4_', 'g5_')]
 
 
 def load_golden(name):

@@ -1,0 +1,52 @@
+"""GPU: the ProcessManager drop-in on multi-tile mosaics against per-tile results of the unmodified
+reference ProcessManager (tests/golden/pm_*.npz; n_workers=1, DEBUG spacing like the reference's own
+tests).  Tiles start from the reference's conditioned elevation (conditioning is not on the device
+yet).  The edge fix-up runs as lock-step rounds here and one tile at a time in the reference, so
+float fields are compared at 1e-9 relative; masks, NaN patterns and facet-derived fields exactly."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, what, rtol=1e-9, atol=1e-12):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    assert a.shape == b.shape, what
+    assert np.array_equal(np.isnan(a), np.isnan(b)), "%s: NaN pattern differs (%d vs %d NaN)" % (what, np.isnan(a).sum(), np.isnan(b).sum())
+    ok = np.isclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+    assert ok.all(), "%s: %d cells differ, worst rel %g" % (what, (~ok).sum(), np.nanmax(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
+
+
+@pytest.mark.parametrize('name', golden_names('pm_'))
+def test_directory_flow_matches_reference(name, tmp_path):
+    from test_process_manager_cpu import compare_with_golden, run_pm
+    g = load_golden(name)
+    pm, compact, order = run_pm(g, str(tmp_path))
+    compare_with_golden(pm, compact, order, g, _close)
+    assert pm.edge_rounds >= 1
+
+
+def test_multi_tile_equals_single_tile_on_cone(tmp_path):
+    """The reference's own acceptance test (pydem/test/test_end_to_end.py:86-149): on the pit-free cone
+    the stitched multi-tile UCA equals the single-tile UCA on [1:-1, 1:-1] to 6 decimals."""
+    import os
+    from pydem_amd import DEMProcessor, process_manager, synth
+    nn = 96
+    cone = synth.cone_scaled(nn)
+    single = DEMProcessor(elev=cone, fill_flats=False, drain_pits_path=False)
+    single.calc_twi()
+    for k, (tiles, ov) in enumerate([((3, 3), 2), ((3, 3), 1), ((4, 3), 3)]):
+        d = str(tmp_path / ('case%d' % k))
+        os.makedirs(d)
+        for t, (elev, bounds) in enumerate(synth.split_mosaic(cone, tiles[0], tiles[1], ov)):
+            np.savez(os.path.join(d, 'tile_%03d.npz' % t), elev=elev, bounds=bounds)
+        process_manager.DEBUG = True
+        try:
+            pm = process_manager.ProcessManager(in_path=d, elev_conditioned=True)
+            pm.process_twi()
+            compact = pm.save_non_overlap_data()
+        finally:
+            process_manager.DEBUG = False
+        np.testing.assert_array_almost_equal(compact['uca'][1:-1, 1:-1], single.uca[1:-1, 1:-1], decimal=6)
