@@ -137,6 +137,21 @@ int pydem_tile_restore_pit_slopes(pydem_tile *t);
  * tile's stream. */
 int pydem_bench_stencil(pydem_tile *t, int iters, double *avg_ms);
 
+/* ---- RCCL transport for the edge strips of the directory flow -------------------------------
+ * Replaces the shared zarr store the reference's workers exchange strips through
+ * (pydem/process_manager.py:243-255, write-verify-retry :362-381).  One communicator per process
+ * (one process per GPU); rank 0 creates the 128-byte id and hands it to the other ranks by any
+ * out-of-band channel.  A gather step is: begin(n) -> pack_line(...) for the lines this rank
+ * owns -> allreduce(sum) -> every rank holds all lines (host copy in host_out). */
+typedef struct pydem_comm pydem_comm;
+int pydem_comm_unique_id(char *out128);
+int pydem_comm_create(int world, int rank, const char *uid128, int device, pydem_comm **out);
+int pydem_comm_destroy(pydem_comm *c);
+int pydem_comm_begin(pydem_comm *c, int64_t n_doubles);
+int pydem_comm_pack_line(pydem_comm *c, pydem_tile *t, int field, int axis, int64_t index, int64_t offset);
+int pydem_comm_put(pydem_comm *c, const double *host_in, int64_t n_doubles, int64_t offset);
+int pydem_comm_allreduce(pydem_comm *c, int64_t n_doubles, int op /* 0 sum, 1 max */, double *host_out);
+
 #ifdef __cplusplus
 }
 #endif

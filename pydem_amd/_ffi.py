@@ -70,6 +70,13 @@ SYMBOLS = {
     'pydem_tile_pit_edges': (C.c_int, [_P, C.POINTER(C.c_int64), _P, _P, _P]),
     'pydem_tile_restore_pit_slopes': (C.c_int, [_P]),
     'pydem_bench_stencil': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
+    'pydem_comm_unique_id': (C.c_int, [C.c_char_p]),
+    'pydem_comm_create': (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, _PP]),
+    'pydem_comm_destroy': (C.c_int, [_P]),
+    'pydem_comm_begin': (C.c_int, [_P, C.c_int64]),
+    'pydem_comm_pack_line': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64]),
+    'pydem_comm_put': (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    'pydem_comm_allreduce': (C.c_int, [_P, C.c_int64, C.c_int, _P]),
 }
 
 _lib = None
@@ -214,3 +221,39 @@ class Tile(object):
 
     def device_bytes(self):
         return self.lib.pydem_tile_device_bytes(self._h)
+
+
+class Comm(object):
+    """RCCL communicator handle (one per process / GPU)."""
+
+    def __init__(self, world, rank, uid, device=0):
+        self.lib = load()
+        self.world, self.rank = world, rank
+        self._h = C.c_void_p()
+        check(self.lib.pydem_comm_create(world, rank, uid, device, C.byref(self._h)))
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(load().pydem_comm_unique_id(buf))
+        return buf.raw
+
+    def close(self):
+        if self._h:
+            self.lib.pydem_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def begin(self, n):
+        check(self.lib.pydem_comm_begin(self._h, n))
+
+    def pack_line(self, tile, field, axis, index, offset):
+        check(self.lib.pydem_comm_pack_line(self._h, tile._h, field, axis, index, offset))
+
+    def put(self, values, offset=0):
+        v = np.ascontiguousarray(values, np.float64)
+        check(self.lib.pydem_comm_put(self._h, v.ctypes.data_as(_P), v.size, offset))
+
+    def allreduce(self, n, op=0):
+        out = np.empty(n, np.float64)
+        check(self.lib.pydem_comm_allreduce(self._h, n, op, out.ctypes.data_as(_P)))
+        return out

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libpydem_hip.so')
-SOURCES = ['tile.hip', 'stencil.hip', 'flats.hip', 'uca.hip', 'pits.hip', 'synth.hip']
+SOURCES = ['tile.hip', 'stencil.hip', 'flats.hip', 'uca.hip', 'pits.hip', 'synth.hip', 'comm.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-fno-fast-math',
          '-Wall', '-Wno-unused-function', '-Wno-unused-result']
@@ -42,7 +42,7 @@ def build(force=False, verbose=True):
         res = list(ex.map(lambda s: _compile(s, force), SOURCES))
     objs = [r[0] for r in res]
     if force or any(r[1] for r in res) or not os.path.exists(LIB):
-        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+        subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-L/opt/rocm/lib', '-lrccl'])
         if verbose:
             print('built', LIB)
     return LIB

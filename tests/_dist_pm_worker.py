@@ -1,0 +1,54 @@
+"""Worker for test_dist_process_manager.py: launched by torch.distributed.run with WORLD_SIZE=2
+(gloo, CPU).  Each rank owns every second tile, strips travel through DistTransport, the per-tile
+arithmetic is the oracle-backed processor; every rank checks its own tiles against the golden."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def main():
+    import torch.distributed as dist
+    dist.init_process_group(backend='gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from conftest import load_golden
+    from oracle_processor import OracleProcessor
+    from pydem_amd import process_manager
+    from pydem_amd.parallel import DistTransport
+    name, path = sys.argv[1], sys.argv[2]
+    g = load_golden(name)
+    dkw = {k: v for k, v in g['kwargs'].items() if k not in ('ny_grid', 'nx_grid', 'overlap')}
+    process_manager.DEBUG = True
+    pm = process_manager.ProcessManager(in_path=path, dem_proc_kwargs=dkw, elev_conditioned=True,
+                                        processor_cls=OracleProcessor, transport=False)
+    pm.transport = DistTransport(pm, rank, world)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        pm.process_twi()
+    order = [int(np.argmin([np.abs(g['t%02d_bounds' % j] - pm.index[i, :4]).sum() for j in range(pm.n_inputs)]))
+             for i in range(pm.n_inputs)]
+    checked = 0
+    for i, j in enumerate(order):
+        if not pm.transport.owns(i):
+            assert pm.tiles[i] is None
+            continue
+        T = lambda key: g['t%02d_%s' % (j, key)]
+        assert np.allclose(pm.tile_result(i, 'uca_total'), T('uca') + T('uca_edges'), rtol=1e-12, atol=1e-13, equal_nan=True), (rank, i)
+        assert np.array_equal(pm.tile_result(i, 'edge_todo'), T('edge_todo')), (rank, i)
+        assert np.array_equal(pm.tile_result(i, 'edge_done'), T('edge_done')), (rank, i)
+        assert np.allclose(pm.tile_result(i, 'twi'), T('twi'), rtol=1e-12, atol=1e-13, equal_nan=True), (rank, i)
+        checked += 1
+    tot = pm.transport.allreduce_max(checked)
+    assert tot >= 1
+    dist.barrier()
+    dist.destroy_process_group()
+    print('rank %d ok: %d tiles checked, %d edge rounds' % (rank, checked, pm.edge_rounds))
+
+
+if __name__ == '__main__':
+    main()

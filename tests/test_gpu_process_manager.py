@@ -50,3 +50,29 @@ def test_multi_tile_equals_single_tile_on_cone(tmp_path):
         finally:
             process_manager.DEBUG = False
         np.testing.assert_array_almost_equal(compact['uca'][1:-1, 1:-1], single.uca[1:-1, 1:-1], decimal=6)
+
+
+def test_rccl_transport_single_rank(tmp_path):
+    """The RCCL strip transport end to end on one GPU (world size 1: the collective still runs):
+    device pack -> ncclAllReduce -> host views must reproduce the in-process transport's result."""
+    from test_process_manager_cpu import compare_with_golden, run_pm
+    from pydem_amd import _ffi
+    from pydem_amd.parallel import RcclTransport
+    g = load_golden('pm_fractal_2x3_ov1')
+    comm = _ffi.Comm(1, 0, _ffi.Comm.unique_id(), 0)
+
+    class T(RcclTransport):
+        def __init__(self, pm):
+            RcclTransport.__init__(self, pm, comm)
+
+    from pydem_amd import process_manager
+    orig = process_manager.EdgeTransport
+    process_manager.EdgeTransport = T          # ProcessManager builds its default transport from this name
+    try:
+        pm, compact, order = run_pm(g, str(tmp_path))
+    finally:
+        process_manager.EdgeTransport = orig
+    assert isinstance(pm.transport, RcclTransport)
+    compare_with_golden(pm, compact, order, g, _close)
+    assert pm.transport.allreduce_max(3.5) == 3.5
+    comm.close()
