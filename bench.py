@@ -40,7 +40,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--size', type=int, default=16384, help='tile edge (cells)')
-    ap.add_argument('--drain-pits', type=int, default=int(os.environ.get('PYDEM_BENCH_DRAIN_PITS', '0')))
+    ap.add_argument('--drain-pits', type=int, default=int(os.environ.get('PYDEM_BENCH_DRAIN_PITS', '1')))
     ap.add_argument('--roof-iters', type=int, default=20)
     ap.add_argument('--cpu-sample', type=int, default=2560, help='edge of the CPU-baseline sample tile (0 = skip)')
     return ap.parse_args()
@@ -77,39 +77,73 @@ def cpu_baseline(size, seed, drain_pits):
                       % (size, size, seed, dt, os.cpu_count())}
 
 
+def tile_specs(world, n, m, px=30.0):
+    """One tile per rank, laid out as a (<=2) x (<=4) mosaic with a one-pixel overlap (BASELINE.json
+    config 4 layout); elevations come from the device generator at global mosaic coordinates."""
+    ncol = min(world, 4)
+    specs = []
+    for t in range(world):
+        r, c = t // ncol, t % ncol
+        row0, col0 = r * (n - 1), c * (m - 1)
+        specs.append({'shape': (n, m), 'synth': dict(seed=1, row0=row0, col0=col0),
+                      'bounds': (col0 * px, -(row0 + n) * px, (col0 + m) * px, -row0 * px)})
+    return specs
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    dist = None
+    import warnings
+    warnings.simplefilter('ignore')
+    from pydem_amd import _ffi, process_manager
+    n = m = args.size
+    ndev = _ffi.device_count()
+    device = local_rank % ndev
+    pm = process_manager.ProcessManager(elev_source_files=tile_specs(world, n, m), elev_conditioned=True,
+                                        dem_proc_kwargs={'drain_pits': bool(args.drain_pits)}, devices=[device],
+                                        keep_first_pass_uca=False)
+    exchange = "in-process"
     if world > 1:
-        # process-group plumbing only (barrier + max over ranks); the data path never touches torch
+        # process-group plumbing only (hands the RCCL id around); the strips themselves travel over RCCL
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-
-    from pydem_amd import _ffi
-    n = m = args.size
-    ndev = _ffi.device_count()
-    tile = _ffi.Tile(n, m, device=local_rank % ndev)
-    import numpy as np
-    tile.set_spacing(np.full(n - 1, 30.0), np.full(n - 1, 30.0), np.full(n, 30.0), np.full(n, 30.0))
-    # rank r owns mosaic tile (r // 4, r % 4) of a 2 x 4 grid with a one-pixel overlap (config 4 layout)
-    row0 = (rank // 4) * (n - 1)
-    col0 = (rank % 4) * (m - 1)
-    tile.synth_fractal(seed=1, row0=row0, col0=col0)
-    opt = make_options(_ffi, args.drain_pits)
+        from pydem_amd import parallel
+        try:
+            pm.transport = parallel.make_rccl_transport(pm, device, dist)
+            exchange = "rccl"
+        except Exception as e:      # keep the scaling run alive and say so in the JSON line
+            sys.stderr.write("bench: RCCL transport unavailable (%s); falling back to gloo host strips\n" % e)
+            pm.transport = parallel.DistTransport(pm, rank, world)
+            exchange = "gloo-host-fallback"
+    pm.compute_grid()
+    pm.process_elevation()          # tiles are generated on their GPU: HBM-resident before the timed region
+    mine = [i for i in range(pm.n_inputs) if pm.transport.owns(i)]
+    phase = {}
 
     def step():
-        tile.slopes_directions()
-        tile.uca(opt)
-        tile.twi(opt)
+        t0 = time.perf_counter()
+        pm.process_aspect_slope()
+        pm.process_uca()
+        for i in mine:
+            pm.tiles[i]._tile.synchronize()
+        t1 = time.perf_counter()
+        pm.process_uca_edges()
+        t2 = time.perf_counter()
+        for i in mine:
+            pm.tiles[i].find_flats()
+            pm.tiles[i].run_twi()
+        t3 = time.perf_counter()
+        phase['tile_ms'] = (t1 - t0 + t3 - t2) * 1e3
+        phase['edge_fixup_ms'] = (t2 - t1) * 1e3
 
     def barrier():
-        tile.synchronize()
-        if dist is not None:
-            dist.barrier()
+        for i in mine:
+            pm.tiles[i]._tile.synchronize()
+        if world > 1:
+            pm.transport.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -117,14 +151,11 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    tile.synchronize()
-    dt = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+    dt = time.perf_counter() - t0
+    if world > 1:
+        dt = pm.transport.allreduce_max(dt)
+    tile = pm.tiles[mine[0]]._tile
     tm = tile.timings()
     if tm['n_unresolved']:
         raise SystemExit("bench: %d cells unresolved (cyclic drainage) -- result invalid" % tm['n_unresolved'])
@@ -139,25 +170,28 @@ def main():
             "value": value, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%dx%d fp64 fractal tile per GPU (seed 1, dX=dY=30 m), fill_flats=False, "
-                                   "drain_pits_path=False, drain_pits=%s: slopes_directions + uca + twi"
-                                   % (n, m, bool(args.drain_pits)),
-                       "tile": [n, m], "tiles_per_gpu": 1, "parallelism": "tile-per-gpu x%d" % world},
+            "config": {"workload": "%dx%d fp64 fractal tile per GPU (seed 1, dX=dY=30 m, %d-tile mosaic with 1-pixel "
+                                   "overlap), fill_flats=False, drain_pits_path=False, drain_pits=%s: "
+                                   "slopes_directions + uca + cross-tile edge fix-up + twi"
+                                   % (n, m, world, bool(args.drain_pits)),
+                       "tile": [n, m], "tiles_per_gpu": 1, "parallelism": "tile-per-gpu x%d" % world,
+                       "edge_exchange": exchange},
             "roofline": {"bound": "hbm", "kernel": "k_stencil_interior", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_kernel_ms": st_ms, "algorithmic_bytes_per_cell": STENCIL_BYTES_PER_CELL},
-            "end_to_end_GBs": E2E_BYTES_PER_CELL * cells * args.steps / dt / 1e9,
-            "stages_ms": {k: tm[k] for k in ('slopes_directions_ms', 'stencil_kernel_ms', 'flats_ms', 'graph_ms',
-                                              'pits_ms', 'sweep_ms', 'twi_ms')},
+            "end_to_end_GBs": E2E_BYTES_PER_CELL * world * cells * args.steps / dt / 1e9,
+            "stages_ms": dict({k: tm[k] for k in ('slopes_directions_ms', 'stencil_kernel_ms', 'flats_ms', 'graph_ms',
+                                                   'pits_ms', 'sweep_ms', 'twi_ms')}, **phase),
             "sweep": {"rounds": tm['sweep_rounds'], "kernel_launches": tm['sweep_kernel_launches'],
-                      "n_flats": tm['n_flats'], "n_pit_edges": tm['n_pit_edges']},
+                      "n_flats": tm['n_flats'], "n_pit_edges": tm['n_pit_edges'], "edge_rounds": pm.edge_rounds},
             "device_bytes": tile.device_bytes(),
         }
         if args.cpu_sample:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1, args.drain_pits)
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
+    if world > 1:
+        pm.transport.barrier()
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -77,6 +77,7 @@ struct pydem_tile {
     int32_t *estamp = nullptr; double *edelta = nullptr, *p_delta = nullptr, *s_data = nullptr;
     uint8_t *p_flags = nullptr, *s_flags = nullptr;
     int32_t eepoch = 0;
+    double *line_stage = nullptr;   // max(n, m) doubles: staging for column get/set
     bool graph_valid = false;   // inmask/gflags/section/prop/pit lists match the resident elev/dir/flats
     void *scratch = nullptr; size_t scratch_bytes = 0;
     int64_t device_bytes = 0;

@@ -39,6 +39,17 @@ template int tile_alloc<uint16_t>(pydem_tile *, uint16_t **, size_t);
 
 namespace {
 
+template <typename T>
+__global__ void k_line_gather(const T *__restrict__ src, int64_t stride, int64_t count, T *__restrict__ dst)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (int64_t)gridDim.x * blockDim.x) dst[k] = src[k * stride];
+}
+template <typename T>
+__global__ void k_line_scatter(const T *__restrict__ src, int64_t stride, int64_t count, T *__restrict__ dst)
+{
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += (int64_t)gridDim.x * blockDim.x) dst[k * stride] = src[k];
+}
+
 __global__ void k_restore_pit_slopes(const int32_t *__restrict__ src, int64_t n, double *mag)
 {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) mag[src[e]] = -1.0;
@@ -150,7 +161,7 @@ int pydem_tile_destroy(pydem_tile *t)
                     t->gflags, t->todo_work, t->indeg, t->queue[0], t->queue[1], t->labels, t->flatlist,
                     t->counters, t->scratch, t->pits.src, t->pits.dst, t->pits.w, t->pits.in_src,
                     t->pits.in_dst, t->pits.in_w, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w,
-                    t->estamp, t->edelta, t->p_delta, t->s_data, t->p_flags, t->s_flags};
+                    t->estamp, t->edelta, t->p_delta, t->s_data, t->p_flags, t->s_flags, t->line_stage};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     for (int i = 0; i < 8; i++) if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
@@ -247,7 +258,9 @@ int pydem_tile_download(pydem_tile *t, int field, void *dst)
 }
 
 // one row (axis 0) or one column (axis 1) of a field: the strips the directory flow exchanges
-// between neighbouring tiles (reference process_manager.py:131-145, :252-255)
+// between neighbouring tiles (reference process_manager.py:131-145, :252-255).  Columns are
+// gathered / scattered by a kernel through a contiguous staging buffer (a strided 2-D memcpy of
+// 1- or 8-byte rows costs one DMA descriptor per element).
 static int line_copy(pydem_tile *t, int field, int axis, int64_t index, void *host, bool to_host)
 {
     HIP_TRY(hipSetDevice(t->device));
@@ -263,9 +276,20 @@ static int line_copy(pydem_tile *t, int field, int axis, int64_t index, void *ho
         if (to_host) HIP_TRY(hipMemcpyAsync(host, row, (size_t)t->m * elem, hipMemcpyDeviceToHost, t->stream));
         else HIP_TRY(hipMemcpyAsync(row, host, (size_t)t->m * elem, hipMemcpyHostToDevice, t->stream));
     } else {
+        const int64_t cnt = t->n;
+        if (!t->line_stage) PYDEM_TRY(tile_alloc(t, &t->line_stage, (size_t)(t->n > t->m ? t->n : t->m)));
+        const int g = (int)(cdiv(cnt, 256) < 64 ? cdiv(cnt, 256) : 64);
         char *col = base + (size_t)index * elem;
-        if (to_host) HIP_TRY(hipMemcpy2DAsync(host, elem, col, (size_t)t->m * elem, elem, (size_t)t->n, hipMemcpyDeviceToHost, t->stream));
-        else HIP_TRY(hipMemcpy2DAsync(col, (size_t)t->m * elem, host, elem, elem, (size_t)t->n, hipMemcpyHostToDevice, t->stream));
+        if (to_host) {
+            if (elem == 8) hipLaunchKernelGGL(k_line_gather<double>, dim3(g), dim3(256), 0, t->stream, (const double *)col, t->m, cnt, t->line_stage);
+            else hipLaunchKernelGGL(k_line_gather<uint8_t>, dim3(g), dim3(256), 0, t->stream, (const uint8_t *)col, t->m, cnt, (uint8_t *)t->line_stage);
+            HIP_TRY(hipMemcpyAsync(host, t->line_stage, (size_t)cnt * elem, hipMemcpyDeviceToHost, t->stream));
+        } else {
+            HIP_TRY(hipMemcpyAsync(t->line_stage, host, (size_t)cnt * elem, hipMemcpyHostToDevice, t->stream));
+            if (elem == 8) hipLaunchKernelGGL(k_line_scatter<double>, dim3(g), dim3(256), 0, t->stream, (const double *)t->line_stage, t->m, cnt, (double *)col);
+            else hipLaunchKernelGGL(k_line_scatter<uint8_t>, dim3(g), dim3(256), 0, t->stream, (const uint8_t *)t->line_stage, t->m, cnt, (uint8_t *)col);
+        }
+        HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(t->stream));
     if (!to_host && (field == PYDEM_ELEV || field == PYDEM_MAG || field == PYDEM_DIRECTION || field == PYDEM_FLATS)) t->graph_valid = false;

@@ -115,13 +115,31 @@ class DEMProcessor(object):
     edge_todo = _Resident('edge_todo')
     edge_done = _Resident('edge_done')
 
+    @property
+    def twi(self):
+        """10 x ln(uca / (mag + min_slope)) (the reference stores the scaled value, :1674); downloaded lazily."""
+        if self._twi10 is None and self._twi_on_device:
+            self._twi10 = self._tile.download(_ffi.TWI) * 10
+        return self._twi10
+
+    @twi.setter
+    def twi(self, value):
+        self._twi10 = None if value is None else np.asarray(value)
+        self._twi_on_device = False
+
     def __init__(self, elev_fn=None, device=0, **kwargs):
         if elev_fn:
             raise NotImplementedError("raster IO is outside the accelerated path: pass elev=array, dX=, dY= "
                                       "(reference: utils.dem_processor_from_raster_kwargs)")
+        self._shape = None
         if kwargs.get('elev') is None:
-            raise ValueError("DEMProcessor needs an elevation array (elev=...)")
-        n_rows = np.shape(kwargs['elev'])[0]
+            if kwargs.get('shape') is None:
+                raise ValueError("DEMProcessor needs an elevation array (elev=...)")
+            self._shape = tuple(int(v) for v in kwargs.pop('shape'))     # elevation will be produced on the device
+            kwargs.pop('elev', None)
+            n_rows = self._shape[0]
+        else:
+            n_rows = np.shape(kwargs['elev'])[0]
         # scalar / missing spacing -> per-row arrays (reference :233-240, defaults :244-258)
         if not isinstance(kwargs.get('dX'), np.ndarray):
             if 'dX2' not in kwargs:
@@ -136,7 +154,8 @@ class DEMProcessor(object):
         self._uploaded = set()
         self._tile = None
         self._device = device
-        self.twi = None
+        self._twi10 = None
+        self._twi_on_device = False
         self.A = None
         self.bounds = []
         self.transform = []
@@ -149,7 +168,7 @@ class DEMProcessor(object):
             if k in _FIELD_OF:
                 setattr(self, k, v)
             elif k == 'twi':
-                self.twi = None if v is None else np.asarray(v)
+                self.twi = v
             elif k in self._OPTION_NAMES:
                 setattr(self, k, v)
             # unknown keywords are dropped, as traitlets' HasTraits.__init__ does
@@ -157,7 +176,7 @@ class DEMProcessor(object):
     # ------------------------------------------------------------------ device plumbing
     def _ensure_tile(self):
         if self._tile is None:
-            n, m = self.elev.shape
+            n, m = self._shape if self._shape is not None else self.elev.shape
             self._tile = _ffi.Tile(n, m, self._device)
         # the reference lets callers overwrite dX/dY after construction (process_manager.py:59-63)
         self._tile.set_spacing(self.dX, self.dY, self.dX2, self.dY2)
@@ -222,6 +241,20 @@ class DEMProcessor(object):
     def timings(self):
         return self._tile.timings() if self._tile is not None else {}
 
+    @classmethod
+    def from_synthetic(cls, shape, synth, device=0, **kwargs):
+        """Tile whose elevation is generated on the device by the deterministic fractal generator
+        (pydem_amd/synth.py:fractal parameters) -- bench / test input, never leaves HBM."""
+        dp = cls(shape=shape, device=device, **kwargs)
+        dp._ensure_tile()
+        dp._tile.synth_fractal(**synth)
+        dp._on_device.add('elev')
+        return dp
+
+    @property
+    def shape(self):
+        return self._shape if self._shape is not None else self.elev.shape
+
     # ------------------------------------------------------------------ reference API
     def find_flats(self):
         """flats = (mag == -1)  (reference :305-306)"""
@@ -240,6 +273,11 @@ class DEMProcessor(object):
 
     def calc_slopes_directions(self, plotflag=False):
         """Slope magnitude and D-infinity direction (reference :587-619)."""
+        self.run_slopes_directions()
+        return self.mag, self.direction
+
+    def run_slopes_directions(self):
+        """calc_slopes_directions without bringing the results back to the host."""
         if self.fill_flats:
             self.calc_fill_flats()
         if self.drain_pits_path:
@@ -249,14 +287,19 @@ class DEMProcessor(object):
         logger.info("Starting slope/direction calculation")
         self._tile.slopes_directions()
         self._produced('mag', 'direction', 'flats')
-        return self.mag, self.direction
 
     def calc_uca(self, plotflag=False, edge_init_data=None, uca_init=None):
         """Upstream contributing area (reference :682-776)."""
+        self.run_uca(edge_init_data=edge_init_data, uca_init=uca_init)
+        return self.uca
+
+    def run_uca(self, edge_init_data=None, uca_init=None, uca_resident=False):
+        """calc_uca without bringing the result back to the host.  `uca_resident=True` (edge rounds only)
+        says uca_init is the tile's own device-resident UCA, so nothing is uploaded."""
         if not self._has('direction'):
-            self.calc_slopes_directions()
-        if uca_init is not None:
-            return self._calc_uca_edge_round(uca_init, edge_init_data)
+            self.run_slopes_directions()
+        if uca_init is not None or uca_resident:
+            return self._calc_uca_edge_round(uca_init, edge_init_data, uca_resident)
         self._ensure_tile()
         self._push('elev', 'mag', 'direction', 'flats')
         opt = self._options()
@@ -272,7 +315,6 @@ class DEMProcessor(object):
         self.twi_min_area = min(self.twi_min_area, opt.twi_min_area)
         # pits that found a drain are patched into mag/flats by the graph stage (reference :1369-1371)
         self._produced('section', 'proportion', 'uca', 'edge_todo', 'edge_done', 'mag', 'flats')
-        return self.uca
 
     def restore_pit_slopes(self):
         """mag = -1 again at the pits drained by calc_uca (what the reference's slope *store* holds in
@@ -281,11 +323,11 @@ class DEMProcessor(object):
             self._tile.restore_pit_slopes()
             self._host.pop('mag', None)
 
-    def _calc_uca_edge_round(self, uca_init, edge_init_data):
+    def _calc_uca_edge_round(self, uca_init, edge_init_data, uca_resident=False):
         """calc_uca(uca_init=..., edge_init_data=[data, done, todo]) of the reference (:724-771):
         only the contributions entering through finished neighbour edges are propagated."""
         keys = ('left', 'right', 'top', 'bottom')
-        n, m = self.elev.shape
+        n, m = self.shape
         lens = dict(left=n, right=n, top=m, bottom=m)
         if edge_init_data is None:
             data = {k: np.zeros(lens[k]) for k in keys}
@@ -296,21 +338,25 @@ class DEMProcessor(object):
         self._ensure_tile()
         if not self._has('flats'):
             self.find_flats()
-        self.uca = np.asarray(uca_init).astype('float64')                     # :744
+        if not (uca_resident and 'uca' in self._on_device):
+            self.uca = np.asarray(uca_init).astype('float64')                 # :744
         self._push('elev', 'mag', 'direction', 'flats', 'uca')
         opt = self._options()
         logger.info("Starting edge resolution round")
         self._tile.uca_edge_update(opt, [data[k] for k in keys], [done[k] for k in keys], [todo[k] for k in keys])
         self._produced('uca', 'edge_todo', 'edge_done', 'mag', 'flats', 'section', 'proportion')
-        return self.uca
 
     def calc_twi(self):
         """Topographic wetness index; returns the un-scaled array, stores 10x in self.twi (:1647-1677)."""
+        self.run_twi()
+        return self._tile.download(_ffi.TWI)
+
+    def run_twi(self):
+        """calc_twi without bringing the result back to the host."""
         if not self._has('uca'):
-            self.calc_uca()
+            self.run_uca()
         self._ensure_tile()
         self._push('uca', 'mag')
         self._tile.twi(self._options())
-        twi = self._tile.download(_ffi.TWI)
-        self.twi = twi * 10
-        return twi
+        self._twi10 = None
+        self._twi_on_device = True

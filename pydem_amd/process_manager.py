@@ -54,6 +54,15 @@ DEM_PROC_KWARGS = (                               # whitelist of the reference (
 def read_tile(fn):
     """Load one elevation tile: dict(elev, bounds=(left, bottom, right, top), dlon, dlat, dX.. optional).
     `.npz` tiles carry `elev` and `bounds`; optional `dX, dY, dX2, dY2` override the spacing."""
+    if isinstance(fn, dict):
+        # in-memory spec: {'elev': array | 'shape': (n, m) + 'synth': generator kwargs, 'bounds': (l, b, r, t)}
+        out = dict(fn)
+        shape = out['elev'].shape if out.get('elev') is not None else tuple(out['shape'])
+        out['shape'] = shape
+        left, bottom, right, top = [float(v) for v in out['bounds']]
+        out.setdefault('dlon', (right - left) / shape[1])
+        out.setdefault('dlat', -(top - bottom) / shape[0])
+        return out
     ext = os.path.splitext(fn)[1].lower()
     if ext == '.npz':
         with np.load(fn) as d:
@@ -63,6 +72,7 @@ def read_tile(fn):
         out['bounds'] = (left, bottom, right, top)
         out.setdefault('dlon', (right - left) / elev.shape[1])
         out.setdefault('dlat', -(top - bottom) / elev.shape[0])
+        out['shape'] = elev.shape
         return out
     raise NotImplementedError("unsupported tile format %r (raster IO is outside the accelerated path; "
                               "use .npz tiles with `elev` and `bounds`)" % ext)
@@ -102,6 +112,7 @@ class ProcessManager(object):
         self.elev_conditioned = False      # inputs already conditioned: skip fill_flats / pit paths (see process_elevation)
         self.transport = None
         self.max_edge_rounds = 10000
+        self.keep_first_pass_uca = True    # keep 'uca' (first pass) and 'uca_edges' separately like the reference's store
         for k, v in kwargs.items():
             if k == 'dem_proc_kwargs':
                 bad = [kk for kk in v if kk not in DEM_PROC_KWARGS]
@@ -138,7 +149,7 @@ class ProcessManager(object):
             index[i, :4] = np.array(meta['bounds'])
             index[i, 4] = meta['dlon']
             index[i, 5] = meta['dlat']
-            index[i, 6:] = meta['elev'].shape
+            index[i, 6:] = meta['shape']
         return index
 
     def compute_grid(self):
@@ -287,7 +298,7 @@ class ProcessManager(object):
 
     def _spacing(self, i):
         meta = self._tile_meta[i]
-        n = meta['elev'].shape[0]
+        n = meta['shape'][0]
         if DEBUG:
             return dict(dX=np.ones(n - 1), dY=np.ones(n - 1), dX2=np.ones(n), dY2=np.ones(n))
         if 'dX' in meta:
@@ -308,7 +319,11 @@ class ProcessManager(object):
             if self.elev_conditioned:
                 kw['fill_flats'] = False
                 kw['drain_pits_path'] = False
-            dp = self._make_processor(i, elev=self._tile_meta[i]['elev'], **kw)
+            meta = self._tile_meta[i]
+            if meta.get('synth') is not None:
+                dp = self.processor_cls.from_synthetic(meta['shape'], meta['synth'], device=self._device_of(i), **kw)
+            else:
+                dp = self._make_processor(i, elev=meta['elev'], **kw)
             if not self.elev_conditioned:
                 dp.calc_fill_flats()
                 dp.calc_pit_drain_paths()
@@ -326,7 +341,7 @@ class ProcessManager(object):
         for i in self._owned():
             dp = self.tiles[i]
             dp.fill_flats = False                      # "assuming we already did this" (:78)
-            dp.calc_slopes_directions()
+            getattr(dp, 'run_slopes_directions', dp.calc_slopes_directions)()
         return [1] * self.n_inputs
 
     def _patch_overlap1_edges(self):
@@ -402,7 +417,7 @@ class ProcessManager(object):
         for i in self._owned():
             dp = self.tiles[i]
             dp.find_flats()
-            dp.calc_uca()
+            getattr(dp, 'run_uca', dp.calc_uca)()
             dp.restore_pit_slopes()        # the worker does not write its patched slope back (:192-194)
             self.uca0[i] = None
         return [1] * self.n_inputs
@@ -514,9 +529,12 @@ class ProcessManager(object):
             return
         data, done, todo = self._edge_inputs(i, snap)
         dp = self.tiles[i]
-        if self.uca0[i] is None:
+        if self.keep_first_pass_uca and self.uca0[i] is None:
             self.uca0[i] = np.array(dp.uca)              # the reference keeps the first pass as 'uca'
-        dp.calc_uca(uca_init=dp.uca, edge_init_data=[data, done, todo])
+        if hasattr(dp, 'run_uca'):
+            dp.run_uca(edge_init_data=[data, done, todo], uca_resident=True)
+        else:
+            dp.calc_uca(uca_init=dp.uca, edge_init_data=[data, done, todo])
 
     def _rank_tiles(self, mets, mets_type):
         if mets.shape[0] == 1:
@@ -551,9 +569,12 @@ class ProcessManager(object):
                         continue
                     data, done, todo = self._edge_inputs(i, snap)
                     dp = self.tiles[i]
-                    if self.uca0[i] is None:
+                    if self.keep_first_pass_uca and self.uca0[i] is None:
                         self.uca0[i] = np.array(dp.uca)
-                    dp.calc_uca(uca_init=dp.uca, edge_init_data=[data, done, todo])
+                    if hasattr(dp, 'run_uca'):
+                        dp.run_uca(edge_init_data=[data, done, todo], uca_resident=True)
+                    else:
+                        dp.calc_uca(uca_init=dp.uca, edge_init_data=[data, done, todo])
                 self.edge_rounds += 1
             return self.update_uca_edge_metrics()
         mets = self.update_uca_edge_metrics()
@@ -591,7 +612,7 @@ class ProcessManager(object):
         for i in self._owned():
             dp = self.tiles[i]
             dp.find_flats()               # the reference's calc_twi worker rebuilds flats from slope == -1 (:310)
-            dp.calc_twi()
+            getattr(dp, 'run_twi', dp.calc_twi)()
         return [1] * self.n_inputs
 
     # ------------------------------------------------------------------ results
