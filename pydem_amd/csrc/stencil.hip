@@ -12,6 +12,8 @@
 // separate multiply/add ufuncs or exact ties on integer DEMs break differently.
 #include "internal.h"
 #include <float.h>
+#include <stdlib.h>
+#include <string.h>
 
 #define PI_D 3.141592653589793
 
@@ -58,16 +60,67 @@ __device__ __forceinline__ void facet(double s1, double s2, double sd, double d1
     }
 }
 
-// direction of the winner: r * ang[1] + ang[0] * pi / 2 (:1989); ang_adj table :184-193
-__device__ __forceinline__ double winner_direction(const Best &b)
+// atan2(y, x) for y > 0, x > 0 (the only case an unclamped facet can produce, see facet()).
+// ocml's general atan2 costs ~130 fp64 operations per cell -- more than a quarter of the whole
+// stencil; this one is ~45: q = min/max in (0, 1], c = nearest multiple of 1/16,
+// atan(q) = atan(c) + atan(u), u = (q - c)/(1 + q*c), |u| <= 1/32, odd Taylor series to u^11
+// (truncation < 1e-19 relative), table of correctly rounded atan(k/16).  Error <= ~1.5 ulp.
+__device__ __constant__ const double ATAN_16[17] = {
+    0, 0.06241880999595735, 0.12435499454676144, 0.18534794999569476, 0.24497866312686414, 0.30288486837497142,
+    0.35877067027057225, 0.41241044159738732, 0.46364760900080609, 0.51238946031073773, 0.55859931534356244,
+    0.60228734613496415, 0.64350110879328437, 0.68231655487474807, 0.71882999962162453, 0.75315128096219441,
+    0.78539816339744828};
+
+__device__ __forceinline__ double atan2_pos(double y, double x)
 {
-    if (b.k < 0) return -1.0;
-    const int a0 = (b.k + 1) >> 1;                 // 0,1,1,2,2,3,3,4
-    const double a1 = (b.k & 1) ? -1.0 : 1.0;      // 1,-1,1,-1,...
+    const bool swap = y > x;
+    const double q = swap ? x / y : y / x;
+    const double kf = rint(q * 16.0);
+    const double c = kf * 0.0625;
+    const double u = (q - c) / __builtin_fma(q, c, 1.0);
+    const double w = u * u;
+    double p = __builtin_fma(w, -1.0 / 11, 1.0 / 9);
+    p = __builtin_fma(w, p, -1.0 / 7);
+    p = __builtin_fma(w, p, 1.0 / 5);
+    p = __builtin_fma(w, p, -1.0 / 3);
+    p = __builtin_fma(w * u, p, u);
+    const double a = ATAN_16[(int)kf] + p;
+    return swap ? PI_D / 2 - a : a;
+}
+
+// direction of the winner: r * ang[1] + ang[0] * pi / 2 (:1989); ang_adj table :184-193
+__device__ __forceinline__ double direction_of(int k, int kind, double s1, double s2, double theta)
+{
+    if (k < 0) return -1.0;
+    const int a0 = (k + 1) >> 1;                   // 0,1,1,2,2,3,3,4
+    const double a1 = (k & 1) ? -1.0 : 1.0;        // 1,-1,1,-1,...
     double r = 0.0;
-    if (b.kind == 2) r = b.theta;
-    else if (b.kind == 3) r = atan2(b.s2, b.s1);
+    if (kind == 2) r = theta;
+    else if (kind == 3) r = atan2_pos(s2, s1);
     return r * a1 + (double)a0 * PI_D / 2;
+}
+
+__device__ __forceinline__ double winner_direction(const Best &b) { return direction_of(b.k, b.kind, b.s1, b.s2, b.theta); }
+
+// Lean facet for the marching kernel: only (rad2, code = 4*k + kind) is tracked; the winner's
+// slopes are re-selected once at the end.  Same decisions as facet() except that `r > theta` is the
+// plain cross-multiplication (exact ties compare equal on both sides and stay unclamped, like
+// atan2(s, s) == atan2(d, d) in the reference).
+struct Acc { double rad2; int code; };
+
+__device__ __forceinline__ void facet_lean(double s1, double s2, double sd, double d1, double d2, int k, Acc &acc)
+{
+    const double s1sq = s1 * s1;
+    const bool s1gt = s1 > 0, s1le = s1 <= 0, s2gt = s2 > 0, s2le = s2 <= 0;
+    const bool rgt = s1gt && s2gt && (s2 * d1 > s1 * d2);
+    const bool diag = (s1le && s2gt) || rgt;                    // I1 :1973-1976
+    const bool card = s1gt && s2le;                             // I2 :1978-1981
+    const bool none = s1le && (s2le || (s2gt && sd <= 0));      // I3 :1983-1984
+    double rad2 = diag ? sd * sd : s1sq + s2 * s2;
+    rad2 = card ? s1sq : rad2;
+    rad2 = none ? -1.0 : rad2;
+    const int code = 4 * k + (card ? 1 : (diag ? 2 : 3));
+    if (rad2 > acc.rad2) { acc.rad2 = rad2; acc.code = code; } // I4 :1986-1989
 }
 
 // all 8 facets of an interior cell.  tn = spacing row i-1 (facets 0-3), ts = row i (facets 4-7)
@@ -149,6 +202,126 @@ __global__ __launch_bounds__(256) void k_stencil_interior(const double *__restri
         }
         aW = cW; a0 = c0; aE = cE;
         cW = bW; c0 = b0; cE = bE;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Variant 2 -- "march": one lane per column, rows marched in registers, quotients shared.
+// Every slope the 8 facets need is an EDGE quotient: (z_a - z_b)/d for two neighbouring cells and
+// a row spacing.  Per cell there are only 5 distinct ones (E-edge over the north and the south
+// spacing, the S-edge, the SE and SW diagonals); the other 13 of the 18 divisions of variant 1 are
+// the same numbers seen from the neighbouring cell (IEEE subtraction and division are sign-
+// symmetric, so -(a-b)/d == (b-a)/d bit for bit).  Each lane computes its 5 quotients when a row
+// enters its 3-row window and fetches the neighbours' copies with wavefront lane shifts; the
+// arithmetic that reaches `facet()` is bit-identical to variant 1.  A wavefront covers 64 columns
+// and produces 62 (lanes 0 and 63 are halo), rows are 512 B coalesced loads, no LDS.
+// ---------------------------------------------------------------------------------------------
+// lane shifts as DPP moves (v_mov_b32_dpp wave_shr:1 / wave_shl:1 -- gfx9 wavefront shifts; 2 VALU
+// moves per double, no LDS crossbar round trip).  The edge lanes keep their own value (halo lanes).
+__device__ __forceinline__ double lane_prev(double x)    // value held by lane-1 (column j-1)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_next(double x)    // value held by lane+1 (column j+1)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+constexpr int MARCH_ROWS = 128;   // output rows per wavefront
+
+__global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict__ elev, int n, int m,
+                                                       const RowTab *__restrict__ rowtab,
+                                                       double *__restrict__ mag, double *__restrict__ dir,
+                                                       uint8_t *__restrict__ flat0, int strips, int chunks)
+{
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);          // wavefront id
+    if (wid >= strips * chunks) return;
+    const int chunk = wid / strips, strip = wid - chunk * strips;  // consecutive waves walk along a row band
+    const int j = strip * 62 + lane;                                // this lane's column (lane 0 / 63 = halo)
+    const int i0 = 1 + chunk * MARCH_ROWS;                          // first output row
+    const int i1 = (i0 + MARCH_ROWS < n - 1) ? i0 + MARCH_ROWS : n - 1;   // one past the last output row
+    const bool colok = j < m;
+    const int jc = colok ? j : m - 1;
+    const double *col = elev + jc;
+
+    // window rows i-1, i (already "entered"), then row i+1 enters at every step
+    double zN = col[(size_t)(i0 - 1) * m], z0 = col[(size_t)i0 * m];
+    // quantities of the rows already in the window, as if they had entered one by one
+    double zE0 = lane_next(z0), zW0 = lane_prev(z0);
+    const RowTab t0 = rowtab[i0 - 1];
+    double hEs_N = (zN - lane_next(zN)) / t0.dX;        // E-edge of row i-1 over its south spacing dX[i-1]
+    double hEn_0 = (z0 - zE0) / t0.dX;                  // E-edge of row i over its north spacing dX[i-1]
+    double v_N = (zN - z0) / t0.dY;                     // vertical edge (i-1) -> i
+    double dSE_N = (zN - zE0) / t0.hyp;                 // diagonal (i-1,j) -> (i,j+1)
+    double dSW_N = (zN - zW0) / t0.hyp;                 // diagonal (i-1,j) -> (i,j-1)
+    double hEs_0 = (i0 <= n - 2) ? (z0 - zE0) / rowtab[i0].dX : 0.0;   // E-edge of row i over its south spacing dX[i]
+    // neighbours' copies
+    double hEs_N_L = lane_prev(hEs_N), dSE_N_L = lane_prev(dSE_N), v_N_L = lane_prev(v_N), v_N_R = lane_next(v_N);
+    double dSW_N_R = lane_next(dSW_N), hEn_0_L = lane_prev(hEn_0), hEs_0_L = lane_prev(hEs_0);
+
+    for (int i = i0; i < i1; i++) {
+        const RowTab tn = rowtab[i - 1], ts = rowtab[i];
+        // ---- row i+1 enters
+        const double zS = col[(size_t)(i + 1) * m];
+        const double zES = lane_next(zS), zWS = lane_prev(zS);
+        const double hEn_S = (zS - zES) / ts.dX;        // E-edge of row i+1 over its north spacing dX[i]
+        const double v_0 = (z0 - zS) / ts.dY;           // vertical edge i -> i+1
+        const double dSE_0 = (z0 - zES) / ts.hyp;
+        const double dSW_0 = (z0 - zWS) / ts.hyp;
+        const double hEs_S = (i + 1 <= n - 2) ? (zS - zES) / rowtab[i + 1].dX : 0.0;
+        const double hEn_S_L = lane_prev(hEn_S), v_0_L = lane_prev(v_0), v_0_R = lane_next(v_0);
+        const double dSE_0_L = lane_prev(dSE_0), dSW_0_R = lane_next(dSW_0), hEs_S_L = lane_prev(hEs_S);
+        // ---- the 8 facets of cell (i, j)
+        Acc acc; acc.rad2 = -1.0; acc.code = -4;
+        const double sdNE = -dSW_N_R, sdNW = -dSE_N_L;
+        const double s1_0 = hEn_0, s2_0 = -v_N_R;          // s1=(z0-zE)/dXn  s2=(zE-zNE)/dYn
+        const double s1_1 = -v_N, s2_1 = hEs_N;            // s1=(z0-zN)/dYn  s2=(zN-zNE)/dXn
+        const double s2_2 = -hEs_N_L;                      //                 s2=(zN-zNW)/dXn
+        const double s1_3 = -hEn_0_L, s2_3 = -v_N_L;       // s1=(z0-zW)/dXn  s2=(zW-zNW)/dYn
+        const double s1_4 = -hEs_0_L, s2_4 = v_0_L;        // s1=(z0-zW)/dXs  s2=(zW-zSW)/dYs
+        const double s1_5 = v_0, s2_5 = -hEn_S_L;          // s1=(z0-zS)/dYs  s2=(zS-zSW)/dXs
+        const double s2_6 = hEn_S;                         //                 s2=(zS-zSE)/dXs
+        const double s1_7 = hEs_0, s2_7 = v_0_R;           // s1=(z0-zE)/dXs  s2=(zE-zSE)/dYs
+        facet_lean(s1_0, s2_0, sdNE, tn.dX, tn.dY, 0, acc);
+        facet_lean(s1_1, s2_1, sdNE, tn.dY, tn.dX, 1, acc);
+        facet_lean(s1_1, s2_2, sdNW, tn.dY, tn.dX, 2, acc);
+        facet_lean(s1_3, s2_3, sdNW, tn.dX, tn.dY, 3, acc);
+        facet_lean(s1_4, s2_4, dSW_0, ts.dX, ts.dY, 4, acc);
+        facet_lean(s1_5, s2_5, dSW_0, ts.dY, ts.dX, 5, acc);
+        facet_lean(s1_5, s2_6, dSE_0, ts.dY, ts.dX, 6, acc);
+        facet_lean(s1_7, s2_7, dSE_0, ts.dX, ts.dY, 7, acc);
+        if (lane >= 1 && lane <= 62 && j >= 1 && j < m - 1) {
+            const int k = acc.code >> 2, kind = acc.code & 3;
+            // slopes / table angle of the winning facet
+            double w1 = s1_0, w2 = s2_0;
+            w1 = k == 1 ? s1_1 : w1; w2 = k == 1 ? s2_1 : w2;
+            w1 = k == 2 ? s1_1 : w1; w2 = k == 2 ? s2_2 : w2;
+            w1 = k == 3 ? s1_3 : w1; w2 = k == 3 ? s2_3 : w2;
+            w1 = k == 4 ? s1_4 : w1; w2 = k == 4 ? s2_4 : w2;
+            w1 = k == 5 ? s1_5 : w1; w2 = k == 5 ? s2_5 : w2;
+            w1 = k == 6 ? s1_5 : w1; w2 = k == 6 ? s2_6 : w2;
+            w1 = k == 7 ? s1_7 : w1; w2 = k == 7 ? s2_7 : w2;
+            const bool kindA = (k == 0) || (k == 3) || (k == 4) || (k == 7);
+            const double th = (k < 4) ? (kindA ? tn.thA : tn.thB) : (kindA ? ts.thA : ts.thB);
+            const size_t c = (size_t)i * m + j;
+            mag[c] = acc.rad2 > 0 ? sqrt(acc.rad2) : acc.rad2;         // :1901
+            dir[c] = direction_of(k, kind, w1, w2, th);
+            flat0[c] = (acc.rad2 == -1.0);
+        }
+        // ---- roll the window
+        zN = z0; z0 = zS;
+        hEs_N = hEs_0; hEs_N_L = hEs_0_L;
+        hEn_0 = hEn_S; hEn_0_L = hEn_S_L;
+        hEs_0 = hEs_S; hEs_0_L = hEs_S_L;
+        v_N = v_0; v_N_L = v_0_L; v_N_R = v_0_R;
+        dSE_N_L = dSE_0_L; dSW_N_R = dSW_0_R;
     }
 }
 
@@ -259,10 +432,26 @@ int launch_interior(pydem_tile *t)
 
 }  // namespace
 
+static int stencil_variant()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("PYDEM_STENCIL"); v = (e && !strcmp(e, "tile")) ? 1 : 2; }
+    return v;
+}
+
+static void launch_stencil(pydem_tile *t)
+{
+    if (stencil_variant() == 1) { launch_interior<true>(t); return; }
+    const int strips = (int)cdiv(t->m - 2, 62), chunks = (int)cdiv(t->n - 2, MARCH_ROWS);
+    const int waves = strips * chunks;
+    hipLaunchKernelGGL(k_stencil_march, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, t->stream, t->elev, (int)t->n, (int)t->m,
+                       t->rowtab, t->mag, t->dir, t->flat0, strips, chunks);
+}
+
 int stage_stencil(pydem_tile *t)
 {
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
-    launch_interior<true>(t);
+    launch_stencil(t);
     HIP_TRY(hipEventRecord(t->ev[1], t->stream));
     const int64_t nper = 2 * t->m + 2 * (t->n - 2);
     hipLaunchKernelGGL(k_stencil_perimeter, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, t->elev,
@@ -280,9 +469,9 @@ int stage_stencil(pydem_tile *t)
 
 int bench_stencil(pydem_tile *t, int iters, double *avg_ms)
 {
-    launch_interior<true>(t);   // warm-up
+    launch_stencil(t);   // warm-up
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
-    for (int q = 0; q < iters; q++) launch_interior<true>(t);
+    for (int q = 0; q < iters; q++) launch_stencil(t);
     HIP_TRY(hipEventRecord(t->ev[1], t->stream));
     HIP_TRY(hipEventSynchronize(t->ev[1]));
     HIP_TRY(hipGetLastError());
