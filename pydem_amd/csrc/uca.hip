@@ -24,7 +24,20 @@
 
 namespace {
 
-enum : uint8_t { GF_OUT1 = 1, GF_OUT2 = 2, GF_PIT_OUT = 4, GF_PIT_IN = 8 };
+// Per-cell graph word `cinfo` (one 32-bit load tells a thread everything static about a cell and its
+// sweep state; the sweep is bound by the number of distinct cache lines it touches per cell):
+//   bits 0-7   inmask: which of the 8 neighbours (NW N NE W E SW S SE) drain into this cell
+//   bit  8/9   regular out-edge to the facet's first / second neighbour survives the keep-filter
+//   bit  10/11 cell has pit out-edges / pit in-edges (side lists)
+//   bits 12-14 facet index (section) when bit 8 or 9 is set
+//   bits 15-31 level: sweep round in which the cell is processed (CI_LEVEL_INF = not yet known)
+constexpr uint32_t CI_OUT1 = 1u << 8, CI_OUT2 = 1u << 9, CI_PIT_OUT = 1u << 10, CI_PIT_IN = 1u << 11;
+constexpr int CI_SEC_SHIFT = 12, CI_LEVEL_SHIFT = 15;
+constexpr uint32_t CI_LEVEL_INF = 0x1FFFFu, CI_STATIC_MASK = 0x7FFFu;
+__device__ __forceinline__ uint32_t ci_level(uint32_t w) { return w >> CI_LEVEL_SHIFT; }
+__device__ __forceinline__ int ci_section(uint32_t w) { return (int)((w >> CI_SEC_SHIFT) & 7u); }
+__device__ __forceinline__ uint32_t ci_with_level(uint32_t w, uint32_t lv) { return (w & CI_STATIC_MASK) | (lv << CI_LEVEL_SHIFT); }
+constexpr int PIT_BLK_SHIFT = 8;     // pit side lists are indexed per block of 256 cells
 
 // 8-neighbour offsets in ascending cell-id order: NW N NE W E SW S SE
 __device__ __constant__ const int NB_DI[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
@@ -72,8 +85,7 @@ __device__ __forceinline__ bool keep_edge(double w, double z_to, double z_from)
 
 __global__ __launch_bounds__(256) void k_build_graph(const int8_t *__restrict__ section, const double *__restrict__ prop,
                                                      const double *__restrict__ elev, int n, int m,
-                                                     uint8_t *__restrict__ inmask, uint8_t *__restrict__ gflags,
-                                                     int32_t *__restrict__ level, uint8_t *__restrict__ todo0,
+                                                     uint32_t *__restrict__ cinfo, uint8_t *__restrict__ todo0,
                                                      uint8_t *__restrict__ todo_work, double *__restrict__ corner_sums)
 {
     const int64_t NN = (int64_t)n * m;
@@ -81,13 +93,13 @@ __global__ __launch_bounds__(256) void k_build_graph(const int8_t *__restrict__ 
         const int i = (int)(c / m), j = (int)(c - (int64_t)i * m);
         const int s = section[c];
         const double p = prop[c], z = elev[c];
-        uint8_t gf = 0;
+        uint32_t gf = 0;
         double outsum = 0.0;
         if (s >= 0 && s <= 7) {
             const int i1 = i + fe1r(s), j1 = j + fe1c(s), i2 = i + fe2r(s), j2 = j + fe2c(s);
             const double w2 = 1 - p;                                             // :1082
-            if (i1 >= 0 && i1 < n && j1 >= 0 && j1 < m && keep_edge(p, elev[(int64_t)i1 * m + j1], z)) { gf |= GF_OUT1; outsum += p; }
-            if (i2 >= 0 && i2 < n && j2 >= 0 && j2 < m && keep_edge(w2, elev[(int64_t)i2 * m + j2], z)) { gf |= GF_OUT2; outsum += w2; }
+            if (i1 >= 0 && i1 < n && j1 >= 0 && j1 < m && keep_edge(p, elev[(int64_t)i1 * m + j1], z)) { gf |= CI_OUT1; outsum += p; }
+            if (i2 >= 0 && i2 < n && j2 >= 0 && j2 < m && keep_edge(w2, elev[(int64_t)i2 * m + j2], z)) { gf |= CI_OUT2; outsum += w2; }
         }
         uint8_t im = 0;
         double insum = 0.0;
@@ -103,9 +115,8 @@ __global__ __launch_bounds__(256) void k_build_graph(const int8_t *__restrict__ 
             const double w = cardinal ? pu : 1 - pu;
             if (keep_edge(w, z, elev[u])) { im |= (uint8_t)(1u << d); insum += w; }
         }
-        inmask[c] = im;
-        gflags[c] = gf;
-        level[c] = im ? 0x7fffffff : 0;   // sources (no in-edges) are round 0
+        // sources (no in-edges) are round 0
+        cinfo[c] = (uint32_t)im | gf | ((uint32_t)(s & 7) << CI_SEC_SHIFT) | ((im ? CI_LEVEL_INF : 0u) << CI_LEVEL_SHIFT);
         // inlet-edge detection (_calc_uca_chunk :909-930); interior cells are never 'todo'
         const bool top = i == 0, bot = i == n - 1, left = j == 0, right = j == m - 1;
         if (top || bot || left || right) {
@@ -133,13 +144,12 @@ __global__ __launch_bounds__(256) void k_build_graph(const int8_t *__restrict__ 
 // pit edges contribute to in-degrees, flags and the corner sums
 __global__ void k_graph_add_pits(const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
                                  const double *__restrict__ w, int64_t ne, int n, int m,
-                                 uint8_t *gflags, int32_t *level, double *corner_sums)
+                                 uint32_t *cinfo, double *corner_sums)
 {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (int64_t)gridDim.x * blockDim.x) {
         const int32_t s = src[e], d = dst[e];
-        level[d] = 0x7fffffff;   // a pit drains here: not a source
-        atomicOr((unsigned *)(gflags + (s & ~3)), (unsigned)GF_PIT_OUT << (8 * (s & 3)));
-        atomicOr((unsigned *)(gflags + (d & ~3)), (unsigned)GF_PIT_IN << (8 * (d & 3)));
+        atomicOr(&cinfo[s], CI_PIT_OUT);
+        atomicOr(&cinfo[d], CI_PIT_IN | (CI_LEVEL_INF << CI_LEVEL_SHIFT));   // a pit drains here: not a source
         const int corners[4] = {0, m - 1, (n - 1) * m, (n - 1) * m + m - 1};
         for (int q = 0; q < 4; q++) {
             if (s == corners[q]) atomicAdd(&corner_sums[q * 3 + 0], w[e]);
@@ -173,29 +183,40 @@ __global__ void k_corner_todo(const double *__restrict__ corner_sums, const doub
 // atomics per cell) of a textbook Kahn sweep disappear.  The frontier itself is appended through
 // an LDS staging buffer: wavefront ballot + popcount prefix, one LDS atomic per wave, and one
 // global atomic per ~1.5k cells when the buffer is flushed.
-constexpr int32_t LEVEL_INF = 0x7fffffff;
 constexpr int STAGE_CAP = 8192;      // LDS staging entries per block (32 KiB)
 constexpr int STAGE_FLUSH = STAGE_CAP - 512;    // flush when fewer than 2*256 slots remain
 
 struct SweepArgs {
-    const uint8_t *inmask, *gflags;
-    const int8_t *section;
+    uint32_t *cinfo;
     const double *prop, *a0;     // a0[i] = dX2[i]*dY2[i]
     double *area;
+    double2 *contrib;            // per cell: (area*w1, area*w2), negated when the cell carries edge_todo taint
     uint8_t *todo_work;
-    int32_t *level;
     int n, m;
-    // pit side lists
-    const int32_t *pit_src, *pit_dst;   // out-edges sorted by src
+    // pit side lists: out-edges sorted by (src, dst), in-edges sorted by (dst, src), block start tables
+    const int32_t *pit_src, *pit_dst;
+    const int32_t *pin_dst, *pin_src; const double *pin_w;
+    const int32_t *pout_blk, *pin_blk;
     int64_t n_pit;
-    const int32_t *pin_dst, *pin_src; const double *pin_w;   // in-edges sorted by (dst, src)
 };
 
-__device__ __forceinline__ int64_t lower_bound_i32(const int32_t *a, int64_t n, int32_t key)
+// first index e >= blk[cell >> 8] with key[e] >= cell (lists are sorted; ~6 entries per block)
+__device__ __forceinline__ int32_t pit_first(const int32_t *__restrict__ key, const int32_t *__restrict__ blk, int32_t cell)
 {
-    int64_t lo = 0, hi = n;
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
-    return lo;
+    int32_t e = blk[cell >> PIT_BLK_SHIFT];
+    const int32_t hi = blk[(cell >> PIT_BLK_SHIFT) + 1];
+    while (e < hi && key[e] < cell) e++;
+    return e;
+}
+
+__global__ void k_pit_block_starts(const int32_t *__restrict__ key, int64_t ne, int32_t nblk, int32_t *__restrict__ blk)
+{
+    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= nblk; b += gridDim.x * blockDim.x) {
+        const int64_t target = (int64_t)b << PIT_BLK_SHIFT;
+        int64_t lo = 0, hi = ne;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (key[mid] < target) lo = mid + 1; else hi = mid; }
+        blk[b] = (int32_t)lo;
+    }
 }
 
 struct Stage {
@@ -233,25 +254,31 @@ __device__ __forceinline__ void stage_flush(Stage &S, int32_t *__restrict__ qn, 
     __syncthreads();
 }
 
-// does upstream cell u (level r) own the hand-off of target t to round r+1?
-__device__ __forceinline__ bool owns_target(const SweepArgs &A, int32_t t, int32_t u, int32_t r)
+// Frontier bookkeeping without per-edge atomics.  The level field of cinfo[c] is the round in which
+// cell c is processed (0 for sources, CI_LEVEL_INF while unknown).  When cell u (level r) is final it
+// looks at each target t: t is ready for round r+1 iff every upstream cell of t has level <= r, and
+// exactly one of t's upstream cells with level == r -- the one with the largest cell id -- appends t
+// to the next frontier and stamps level r+1.  All level-r stamps were written by the previous
+// launch, so the test reads only settled values; the in-degree counters (and their ~1.4 device
+// atomics per cell) of a textbook Kahn sweep disappear.
+__device__ __forceinline__ bool owns_target(const SweepArgs &A, int32_t t, int32_t u, uint32_t r, uint32_t &ct)
 {
-    const uint8_t im = A.inmask[t];
+    ct = A.cinfo[t];
     int32_t owner = -1;
     bool ready = true;
 #pragma unroll
     for (int d = 0; d < 8; d++) {
-        if (im & (1u << d)) {
+        if (ct & (1u << d)) {
             const int32_t v = t + NB_DI[d] * A.m + NB_DJ[d];
-            const int32_t lv = A.level[v];
+            const uint32_t lv = (v == u) ? r : ci_level(A.cinfo[v]);
             ready = ready && (lv <= r);
             if (lv == r) owner = v > owner ? v : owner;
         }
     }
-    if (A.gflags[t] & GF_PIT_IN) {
-        for (int64_t e = lower_bound_i32(A.pin_dst, A.n_pit, t); e < A.n_pit && A.pin_dst[e] == t; e++) {
+    if (ct & CI_PIT_IN) {
+        for (int32_t e = pit_first(A.pin_dst, A.pin_blk, t); e < A.n_pit && A.pin_dst[e] == t; e++) {
             const int32_t v = A.pin_src[e];
-            const int32_t lv = A.level[v];
+            const uint32_t lv = (v == u) ? r : ci_level(A.cinfo[v]);
             ready = ready && (lv <= r);
             if (lv == r) owner = v > owner ? v : owner;
         }
@@ -259,26 +286,44 @@ __device__ __forceinline__ bool owns_target(const SweepArgs &A, int32_t t, int32
     return ready && owner == u;
 }
 
-// after cell c (level r) is final: hand its ready targets to the next frontier
-__device__ __forceinline__ void release_targets(const SweepArgs &A, Stage &S, bool active, int32_t c, uint8_t gf, int s,
-                                                int32_t r, int32_t *__restrict__ qn, int32_t *cn)
+// after cell c (level r, graph word cw) is final: hand its ready targets to the next frontier
+__device__ __forceinline__ void release_targets(const SweepArgs &A, Stage &S, bool active, int32_t c, uint32_t cw,
+                                                uint32_t r, int32_t *__restrict__ qn, int32_t *cn)
 {
     const int m = A.m;
+    const int s = ci_section(cw);
     int32_t t1 = -1, t2 = -1;
-    if (active && (gf & GF_OUT1)) t1 = c + fe1r(s) * m + fe1c(s);
-    if (active && (gf & GF_OUT2)) t2 = c + fe2r(s) * m + fe2c(s);
-    const bool r1 = t1 >= 0 && owns_target(A, t1, c, r);
-    const bool r2 = t2 >= 0 && owns_target(A, t2, c, r);
-    if (r1) A.level[t1] = r + 1;
-    if (r2) A.level[t2] = r + 1;
+    if (active && (cw & CI_OUT1)) t1 = c + fe1r(s) * m + fe1c(s);
+    if (active && (cw & CI_OUT2)) t2 = c + fe2r(s) * m + fe2c(s);
+    uint32_t c1 = 0, c2 = 0;
+    const bool r1 = t1 >= 0 && owns_target(A, t1, c, r, c1);
+    const bool r2 = t2 >= 0 && owns_target(A, t2, c, r, c2);
+    if (r1) A.cinfo[t1] = ci_with_level(c1, r + 1);
+    if (r2) A.cinfo[t2] = ci_with_level(c2, r + 1);
     stage_push(S, r1, t1);
     stage_push(S, r2, t2);
-    if (active && (gf & GF_PIT_OUT)) {                                           // rare: drained pit
-        for (int64_t e = lower_bound_i32(A.pit_src, A.n_pit, c); e < A.n_pit && A.pit_src[e] == c; e++) {
+    if (active && (cw & CI_PIT_OUT)) {                                           // rare: drained pit
+        for (int32_t e = pit_first(A.pit_src, A.pout_blk, c); e < A.n_pit && A.pit_src[e] == c; e++) {
             const int32_t t = A.pit_dst[e];
-            if (owns_target(A, t, c, r)) { A.level[t] = r + 1; qn[atomicAdd(cn, 1)] = t; }
+            uint32_t ct;
+            if (owns_target(A, t, c, r, ct)) { A.cinfo[t] = ci_with_level(ct, r + 1); qn[atomicAdd(cn, 1)] = t; }
         }
     }
+}
+
+// publish a finished cell: area plus the two outgoing contributions (sign carries the todo taint)
+__device__ __forceinline__ void publish_cell(const SweepArgs &A, int32_t c, uint32_t cw, double acc, bool td)
+{
+    A.area[c] = acc;
+    double2 o = make_double2(0.0, 0.0);
+    if (cw & (CI_OUT1 | CI_OUT2)) {
+        const double p = A.prop[c];
+        if (cw & CI_OUT1) o.x = acc * p;                                        // area[i] * factor, cyutils.pyx:163
+        if (cw & CI_OUT2) o.y = acc * (1 - p);
+        if (td) { o.x = -o.x; o.y = -o.y; }
+    }
+    A.contrib[c] = o;
+    if (td) A.todo_work[c] = 1;
 }
 
 // round 0: every cell without in-edges is a source (ids = colsum == 0, :882-883): area = dX2*dY2
@@ -292,12 +337,13 @@ __global__ __launch_bounds__(256) void k_sweep_sources(SweepArgs A, int32_t *__r
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < NN; base += (int64_t)gridDim.x * blockDim.x) {
         const int64_t c = base + threadIdx.x;
         bool src = false;
-        uint8_t gf = 0; int s = -1;
+        uint32_t cw = 0;
         if (c < NN) {
-            src = A.level[c] == 0;
-            if (src) { gf = A.gflags[c]; A.area[c] = A.a0[c / A.m]; s = A.section[c]; mine++; }
+            cw = A.cinfo[c];
+            src = ci_level(cw) == 0;
+            if (src) { publish_cell(A, (int32_t)c, cw, A.a0[c / A.m], A.todo_work[c] != 0); mine++; }
         }
-        release_targets(A, S, src, (int32_t)c, gf, s, 0, qn, cn);
+        release_targets(A, S, src, (int32_t)c, cw, 0, qn, cn);
         stage_flush(S, qn, cn, false);
     }
     stage_flush(S, qn, cn, true);
@@ -306,40 +352,38 @@ __global__ __launch_bounds__(256) void k_sweep_sources(SweepArgs A, int32_t *__r
 }
 
 // rounds >= 1: pull, store, release
-__device__ __forceinline__ void process_cell(const SweepArgs &A, Stage &S, bool active, int32_t c, int32_t r,
+__device__ __forceinline__ void process_cell(const SweepArgs &A, Stage &S, bool active, int32_t c, uint32_t r,
                                              int32_t *__restrict__ qn, int32_t *cn)
 {
-    uint8_t gf = 0; int s = -1;
+    uint32_t cw = 0;
     if (active) {
         const int m = A.m;
-        const int i = c / m;
-        const uint8_t im = A.inmask[c];
-        gf = A.gflags[c];
-        s = A.section[c];
+        cw = A.cinfo[c];
+        const int i = c / m, j = c - i * m;
         double acc = A.a0[i];                                                   // :885, :901
-        uint8_t td = A.todo_work[c];
-        // regular in-edges in ascending source id: NW N NE W E SW S SE
+        // only inlet cells on the tile edge start tainted (:909-930); interior bytes are written later
+        bool td = (i == 0 || i == A.n - 1 || j == 0 || j == m - 1) && A.todo_work[c] != 0;
+        // regular in-edges in ascending source id: NW N NE W E SW S SE; a cardinal neighbour feeds us
+        // through its first slot, a diagonal one through its second
 #pragma unroll
         for (int d = 0; d < 8; d++) {
-            if (im & (1u << d)) {
+            if (cw & (1u << d)) {
                 const int32_t u = c + NB_DI[d] * m + NB_DJ[d];
                 const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
-                const double pu = A.prop[u];
-                const double w = cardinal ? pu : 1 - pu;
-                acc += A.area[u] * w;                                           // cyutils.pyx:163
-                td |= A.todo_work[u];                                           // :165 (float taint -> bool)
+                const double x = cardinal ? A.contrib[u].x : A.contrib[u].y;
+                acc += fabs(x);                                                 // cyutils.pyx:163
+                td = td || (x < 0);                                             // :165 (float taint -> bool)
             }
         }
-        if (gf & GF_PIT_IN) {
-            for (int64_t e = lower_bound_i32(A.pin_dst, A.n_pit, c); e < A.n_pit && A.pin_dst[e] == c; e++) {
+        if (cw & CI_PIT_IN) {
+            for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++) {
                 acc += A.area[A.pin_src[e]] * A.pin_w[e];
-                td |= A.todo_work[A.pin_src[e]];
+                td = td || (A.todo_work[A.pin_src[e]] != 0);
             }
         }
-        A.area[c] = acc;
-        A.todo_work[c] = td;
+        publish_cell(A, c, cw, acc, td);
     }
-    release_targets(A, S, active, c, gf, s, r, qn, cn);
+    release_targets(A, S, active, c, cw, r, qn, cn);
 }
 
 // one frontier round; counters rotate over 3 slots: in = r%3, out = (r+1)%3, (r+2)%3 is cleared
@@ -357,7 +401,7 @@ __global__ __launch_bounds__(256) void k_sweep_round(SweepArgs A, const int32_t 
         const int32_t q = base + threadIdx.x;
         const bool active = q < nq;
         const int32_t c = active ? qc[q] : 0;
-        process_cell(A, S, active, c, r, qn, cn);
+        process_cell(A, S, active, c, (uint32_t)r, qn, cn);
         stage_flush(S, qn, cn, false);
     }
     stage_flush(S, qn, cn, true);
@@ -472,7 +516,7 @@ __global__ void k_edge_init(EdgeArgs E, const double *__restrict__ sdata, const 
     if (todo_out) { E.edge_done[c] = 0; q_todo[atomicAdd(n_todo, 1)] = c; }
     if (seed) {
         E.stamp[c] = (E.epoch << 2) | 2;
-        E.G.level[c] = 0;
+        E.G.cinfo[c] = ci_with_level(E.G.cinfo[c], 0);
         q_seed[atomicAdd(n_seed, 1)] = c;
         E.rlist[atomicAdd(E.rcount, 1)] = c;
     }
@@ -481,12 +525,12 @@ __global__ void k_edge_init(EdgeArgs E, const double *__restrict__ sdata, const 
 template <typename F>
 __device__ __forceinline__ void for_each_target(const SweepArgs &A, int32_t c, F f)
 {
-    const uint8_t gf = A.gflags[c];
-    const int s = A.section[c];
-    if (gf & GF_OUT1) f(c + fe1r(s) * A.m + fe1c(s));
-    if (gf & GF_OUT2) f(c + fe2r(s) * A.m + fe2c(s));
-    if (gf & GF_PIT_OUT)
-        for (int64_t e = lower_bound_i32(A.pit_src, A.n_pit, c); e < A.n_pit && A.pit_src[e] == c; e++) f(A.pit_dst[e]);
+    const uint32_t cw = A.cinfo[c];
+    const int s = ci_section(cw);
+    if (cw & CI_OUT1) f(c + fe1r(s) * A.m + fe1c(s));
+    if (cw & CI_OUT2) f(c + fe2r(s) * A.m + fe2c(s));
+    if (cw & CI_PIT_OUT)
+        for (int32_t e = pit_first(A.pit_src, A.pout_blk, c); e < A.n_pit && A.pit_src[e] == c; e++) f(A.pit_dst[e]);
 }
 
 // breadth-first flood along out-edges.  MODE 0: mark cells downstream of the seeds (done = False,
@@ -506,7 +550,7 @@ __global__ __launch_bounds__(256) void k_edge_flood(EdgeArgs E, const int32_t *_
             const int32_t old = atomicExch(&E.stamp[t], tag);
             if (old == tag) return;
             if (MODE == 0) {
-                E.G.level[t] = 0x7fffffff;
+                E.G.cinfo[t] = ci_with_level(E.G.cinfo[t], CI_LEVEL_INF);
                 E.rlist[atomicAdd(E.rcount, 1)] = t;
             } else {
                 E.edge_done[t] = 0;                                              // edge_done = ~edge_todo (:856)
@@ -519,27 +563,27 @@ __global__ __launch_bounds__(256) void k_edge_flood(EdgeArgs E, const int32_t *_
 __device__ __forceinline__ bool edge_in_set(const EdgeArgs &E, int32_t v) { return E.stamp[v] == ((E.epoch << 2) | 2); }
 
 // ownership test restricted to the stamped sub-graph (unstamped upstream cells count as done)
-__device__ __forceinline__ bool edge_owns(const EdgeArgs &E, int32_t t, int32_t u, int32_t r)
+__device__ __forceinline__ bool edge_owns(const EdgeArgs &E, int32_t t, int32_t u, uint32_t r, uint32_t &ct)
 {
     const SweepArgs &A = E.G;
-    const uint8_t im = A.inmask[t];
+    ct = A.cinfo[t];
     int32_t owner = -1;
     bool ready = true;
 #pragma unroll
     for (int d = 0; d < 8; d++) {
-        if (im & (1u << d)) {
+        if (ct & (1u << d)) {
             const int32_t v = t + NB_DI[d] * A.m + NB_DJ[d];
             if (!edge_in_set(E, v)) continue;
-            const int32_t lv = A.level[v];
+            const uint32_t lv = (v == u) ? r : ci_level(A.cinfo[v]);
             ready = ready && (lv <= r);
             if (lv == r) owner = v > owner ? v : owner;
         }
     }
-    if (A.gflags[t] & GF_PIT_IN)
-        for (int64_t e = lower_bound_i32(A.pin_dst, A.n_pit, t); e < A.n_pit && A.pin_dst[e] == t; e++) {
+    if (ct & CI_PIT_IN)
+        for (int32_t e = pit_first(A.pin_dst, A.pin_blk, t); e < A.n_pit && A.pin_dst[e] == t; e++) {
             const int32_t v = A.pin_src[e];
             if (!edge_in_set(E, v)) continue;
-            const int32_t lv = A.level[v];
+            const uint32_t lv = (v == u) ? r : ci_level(A.cinfo[v]);
             ready = ready && (lv <= r);
             if (lv == r) owner = v > owner ? v : owner;
         }
@@ -560,7 +604,7 @@ __global__ __launch_bounds__(256) void k_edge_sweep(EdgeArgs E, const int32_t *_
         const int32_t c = qc[q];
         double acc = edge_base(E, c);
         if (r > 0) {
-            const uint8_t im = A.inmask[c];
+            const uint32_t im = A.cinfo[c];
 #pragma unroll
             for (int d = 0; d < 8; d++) {
                 if (im & (1u << d)) {
@@ -571,15 +615,16 @@ __global__ __launch_bounds__(256) void k_edge_sweep(EdgeArgs E, const int32_t *_
                     acc += E.delta[u] * (cardinal ? pu : 1 - pu);
                 }
             }
-            if (A.gflags[c] & GF_PIT_IN)
-                for (int64_t e = lower_bound_i32(A.pin_dst, A.n_pit, c); e < A.n_pit && A.pin_dst[e] == c; e++)
+            if (im & CI_PIT_IN)
+                for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++)
                     if (edge_in_set(E, A.pin_src[e])) acc += E.delta[A.pin_src[e]] * A.pin_w[e];
         }
         E.delta[c] = acc;
         for_each_target(A, c, [&](int32_t t) {
             // seeds never receive: a done cell on the tile edge is skipped (cyutils.pyx:159-161)
-            if (A.level[t] == 0 && edge_in_set(E, t)) return;
-            if (edge_owns(E, t, c, r)) { A.level[t] = r + 1; qn[atomicAdd(cn, 1)] = t; }
+            if (edge_in_set(E, t) && ci_level(A.cinfo[t]) == 0) return;
+            uint32_t ct;
+            if (edge_owns(E, t, c, (uint32_t)r, ct)) { A.cinfo[t] = ci_with_level(ct, (uint32_t)r + 1); qn[atomicAdd(cn, 1)] = t; }
         });
     }
 }
@@ -591,7 +636,7 @@ __global__ void k_edge_apply(EdgeArgs E, double *__restrict__ uca, const int32_t
     for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
         const int32_t c = E.rlist[q];
         // cells the sweep never reached (cyclic drainage) keep their initial value, like the reference
-        const bool processed = E.G.level[c] != 0x7fffffff;
+        const bool processed = ci_level(E.G.cinfo[c]) != CI_LEVEL_INF;
         uca[c] += processed ? E.delta[c] : edge_base(E, c);
     }
 }
@@ -618,10 +663,10 @@ int grid_for(int64_t work, int cap) { const int64_t g = cdiv(work, 256); return 
 int stage_section_graph(pydem_tile *t, const pydem_options *opt)
 {
     const int n = (int)t->n, m = (int)t->m;
-    PYDEM_TRY(tile_alloc(t, &t->inmask, (size_t)t->NN));
-    PYDEM_TRY(tile_alloc(t, &t->gflags, (size_t)t->NN + 4));
     PYDEM_TRY(tile_alloc(t, &t->todo_work, (size_t)t->NN));
-    PYDEM_TRY(tile_alloc(t, &t->indeg, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->indeg, (size_t)t->NN));          // the cinfo words
+    const int32_t nblk = (int32_t)(t->NN >> PIT_BLK_SHIFT) + 1;
+    PYDEM_TRY(tile_alloc(t, &t->pit_blk, (size_t)(nblk + 2) * 2));
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
     const int big = grid_for(t->NN, 8192);
     hipLaunchKernelGGL(k_section_proportion, dim3(big), dim3(256), 0, t->stream, t->dir, t->flats, t->sec_theta, t->NN, m,
@@ -635,11 +680,16 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt)
     HIP_TRY(hipMemsetAsync(t->counters, 0, 64 * sizeof(int32_t), t->stream));
     HIP_TRY(hipMemsetAsync(t->edge_todo, 0, (size_t)t->NN, t->stream));
     HIP_TRY(hipMemsetAsync(t->todo_work, 0, (size_t)t->NN, t->stream));
-    hipLaunchKernelGGL(k_build_graph, dim3(big), dim3(256), 0, t->stream, t->section, t->prop, t->elev, n, m, t->inmask,
-                       t->gflags, t->indeg, t->edge_todo, t->todo_work, corner_sums);
-    if (t->pits.n_edges > 0)
+    hipLaunchKernelGGL(k_build_graph, dim3(big), dim3(256), 0, t->stream, t->section, t->prop, t->elev, n, m,
+                       (uint32_t *)t->indeg, t->edge_todo, t->todo_work, corner_sums);
+    if (t->pits.n_edges > 0) {
         hipLaunchKernelGGL(k_graph_add_pits, dim3(grid_for(t->pits.n_edges, 1024)), dim3(256), 0, t->stream, t->pits.src,
-                           t->pits.dst, t->pits.w, t->pits.n_edges, n, m, t->gflags, t->indeg, corner_sums);
+                           t->pits.dst, t->pits.w, t->pits.n_edges, n, m, (uint32_t *)t->indeg, corner_sums);
+        hipLaunchKernelGGL(k_pit_block_starts, dim3(grid_for(nblk + 1, 1024)), dim3(256), 0, t->stream, t->pits.src,
+                           t->pits.n_edges, nblk, t->pit_blk);
+        hipLaunchKernelGGL(k_pit_block_starts, dim3(grid_for(nblk + 1, 1024)), dim3(256), 0, t->stream, t->pits.in_dst,
+                           t->pits.n_edges, nblk, t->pit_blk + nblk + 2);
+    }
     hipLaunchKernelGGL(k_corner_todo, dim3(1), dim3(64), 0, t->stream, corner_sums, t->elev, n, m, t->edge_todo, t->todo_work);
     HIP_TRY(hipEventRecord(t->ev[3], t->stream));
     HIP_TRY(hipGetLastError());
@@ -651,12 +701,23 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt)
     return 0;
 }
 
+static void fill_sweep_args(pydem_tile *t, SweepArgs &A)
+{
+    const int32_t nblk = (int32_t)(t->NN >> PIT_BLK_SHIFT) + 1;
+    A.cinfo = (uint32_t *)t->indeg; A.prop = t->prop; A.a0 = t->row_area; A.area = t->uca;
+    A.contrib = (double2 *)t->contrib; A.todo_work = t->todo_work; A.n = (int)t->n; A.m = (int)t->m;
+    A.pit_src = t->pits.src; A.pit_dst = t->pits.dst; A.n_pit = t->pits.n_edges;
+    A.pin_dst = t->pits.in_dst; A.pin_src = t->pits.in_src; A.pin_w = t->pits.in_w;
+    A.pout_blk = t->pit_blk; A.pin_blk = t->pit_blk ? t->pit_blk + nblk + 2 : nullptr;
+}
+
 int stage_sweep(pydem_tile *t, const pydem_options *opt)
 {
     const int n = (int)t->n, m = (int)t->m;
     PYDEM_TRY(tile_alloc(t, &t->queue[0], (size_t)t->NN));
     PYDEM_TRY(tile_alloc(t, &t->queue[1], (size_t)t->NN));
     PYDEM_TRY(tile_alloc(t, &t->row_area, (size_t)t->n));
+    PYDEM_TRY(tile_alloc(t, &t->contrib, (size_t)t->NN * 2));
     int32_t *cnt3 = t->counters;        // [0..2] rotating frontier sizes
     int32_t *total = t->counters + 3;   // cells processed by rounds >= 1
     int32_t *nsrc = t->counters + 4;    // source cells (round 0)
@@ -665,10 +726,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
     hipLaunchKernelGGL(k_row_area, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, t->stream, t->dX2, t->dY2, n, t->row_area);
     SweepArgs A;
-    A.inmask = t->inmask; A.gflags = t->gflags; A.section = t->section; A.prop = t->prop; A.a0 = t->row_area;
-    A.area = t->uca; A.todo_work = t->todo_work; A.level = t->indeg; A.n = n; A.m = m;
-    A.pit_src = t->pits.src; A.pit_dst = t->pits.dst; A.n_pit = t->pits.n_edges;
-    A.pin_dst = t->pits.in_dst; A.pin_src = t->pits.in_src; A.pin_w = t->pits.in_w;
+    fill_sweep_args(t, A);
     hipLaunchKernelGGL(k_sweep_sources, dim3(grid_for(t->NN, 4096)), dim3(256), 0, t->stream, A, t->queue[1], &cnt3[1], nsrc);
     int64_t launches = 1;
     int r = 1;
@@ -685,7 +743,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         HIP_TRY(hipStreamSynchronize(t->stream));
         last = t->h_counters[r % 3];
         if (last == 0) break;
-        if (r > (1 << 24)) { pydem_set_error("frontier sweep did not terminate"); return -5; }
+        if (r > (int)CI_LEVEL_INF - 256) { pydem_set_error("flow paths longer than %u rounds are not supported", CI_LEVEL_INF); return -5; }
     }
     const int64_t processed = (int64_t)t->h_counters[3] + t->h_counters[4];
     t->tm.n_unresolved = t->NN - processed;
@@ -759,10 +817,7 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
     HIP_TRY(hipMemsetAsync(t->edge_done, 1, (size_t)t->NN, t->stream));
     EdgeArgs E;
     SweepArgs &A = E.G;
-    A.inmask = t->inmask; A.gflags = t->gflags; A.section = t->section; A.prop = t->prop; A.a0 = t->row_area;
-    A.area = t->uca; A.todo_work = t->todo_work; A.level = t->indeg; A.n = n; A.m = m;
-    A.pit_src = t->pits.src; A.pit_dst = t->pits.dst; A.n_pit = t->pits.n_edges;
-    A.pin_dst = t->pits.in_dst; A.pin_src = t->pits.in_src; A.pin_w = t->pits.in_w;
+    fill_sweep_args(t, A);
     E.stamp = t->estamp; E.delta = t->edelta; E.flats = t->flats; E.edge_done = t->edge_done; E.epoch = t->eepoch;
     E.p_done = t->p_flags; E.p_seed = t->p_flags + nper; E.p_delta = t->p_delta;
     E.rlist = t->labels; E.rcount = t->counters + 6;
