@@ -84,6 +84,7 @@ typedef struct pydem_timings {
     int64_t n_pit_edges;          /* pit -> drain edges built                  */
     int64_t n_pits_undrained;     /* the reference's "pits had no place to drain" count */
     int64_t n_unresolved;         /* cells the sweep could not reach (cyclic drainage) */
+    int64_t sweep_tile_passes;    /* LDS tile-local passes run before the queue rounds */
 } pydem_timings;
 
 const char *pydem_hip_last_error(void);

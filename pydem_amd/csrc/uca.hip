@@ -19,6 +19,7 @@
 // Everything here is bounded by HBM (or by launch/atomic latency in the sweep's long tail).
 #include "internal.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define PI_D 3.141592653589793
 
@@ -407,6 +408,193 @@ __global__ __launch_bounds__(256) void k_sweep_round(SweepArgs A, const int32_t 
     stage_flush(S, qn, cn, true);
 }
 
+// ------------------------------------------------------------------------------- K5b
+// Tile-local passes.  A queue round re-streams scattered 64 B lines for every cell it touches, and
+// the first dozens of rounds touch most of the grid again and again.  Here a workgroup stages one
+// 32x32 tile (plus a one-cell halo) of graph words and outgoing contributions in LDS and runs as
+// many level-synchronous rounds as it can ENTIRELY ON CHIP: a cell is final once all its upstream
+// cells are final -- those inside the tile become so during the pass, halo cells only if an earlier
+// pass finished them.  Each pass streams the unfinished tiles once; flow paths that cross tile
+// borders make progress of one tile per pass, so a few passes finish the bulk of the grid and the
+// queue rounds above only see the long river network.  Cells finished in pass p carry level p.
+// The arithmetic per cell (gather order, products) is identical to process_cell().
+constexpr int TT = 32, HW = TT + 2;
+
+__global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total,
+                                                     uint8_t *__restrict__ tile_done, int32_t *n_final)
+{
+    __shared__ uint32_t s_ci[HW * HW];
+    __shared__ double s_cx[HW * HW], s_cy[HW * HW];   // outgoing contributions (tile + halo)
+    __shared__ uint32_t s_pend[HW * HW];              // unfinished upstream cells (tile cells only)
+    __shared__ uint8_t s_state[HW * HW];              // 0 open, 1 final before this pass / outside, 2 finished in this pass
+    __shared__ double s_p[TT * TT], s_area[TT * TT];
+    __shared__ uint16_t s_list[TT * TT];
+    __shared__ int s_n;
+    const int per = (tiles_total + 7) >> 3;
+    const int tid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // XCD-contiguous bands of tiles
+    if (tid >= tiles_total || tile_done[tid]) return;
+    const int by = tid / tiles_x, bx = tid - by * tiles_x;
+    const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
+    const int LOFF[8] = {-HW - 1, -HW, -HW + 1, -1, 1, HW - 1, HW, HW + 1};
+    // ---- stage tile + halo
+    for (int idx = threadIdx.x; idx < HW * HW; idx += 256) {
+        const int li = idx / HW, lj = idx - li * HW;
+        const int gi = i0 - 1 + li, gj = j0 - 1 + lj;
+        uint32_t cw = 0; uint8_t st = 1; double cx = 0.0, cy = 0.0;       // outside the grid: nothing drains from there
+        if (gi >= 0 && gi < n && gj >= 0 && gj < m) {
+            const int64_t g = (int64_t)gi * m + gj;
+            cw = A.cinfo[g];
+            const uint32_t lv = ci_level(cw);
+            st = (lv >= 1 && lv < pass);
+            if (st) { const double2 o = A.contrib[g]; cx = o.x; cy = o.y; }
+        }
+        s_ci[idx] = cw; s_state[idx] = st; s_cx[idx] = cx; s_cy[idx] = cy;
+    }
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    // ---- per-cell setup: proportion, and how many upstream cells are still open
+    for (int cell = threadIdx.x; cell < TT * TT; cell += 256) {
+        const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
+        const int gi = i0 + li - 1, gj = j0 + lj - 1;
+        uint32_t pend = 0;
+        double pv = 0.0;
+        if (gi < n && gj < m && !s_state[idx]) {
+            const uint32_t cw = s_ci[idx];
+            const int32_t c = gi * m + gj;
+            pv = A.prop[c];
+#pragma unroll
+            for (int d = 0; d < 8; d++)
+                if ((cw & (1u << d)) && !s_state[idx + LOFF[d]]) pend++;
+            if (cw & CI_PIT_IN)                                     // pit sources must come from an earlier pass
+                for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++) {
+                    const uint32_t lv = ci_level(A.cinfo[A.pin_src[e]]);
+                    if (!(lv >= 1 && lv < pass)) pend += 64;        // stays blocked for the whole pass
+                }
+            if (pend == 0) s_list[atomicAdd(&s_n, 1)] = (uint16_t)cell;
+        }
+        s_pend[idx] = pend;
+        s_p[cell] = pv;
+    }
+    __syncthreads();
+    // ---- rounds on chip: the ready list is processed, targets whose last upstream cell just finished
+    // form the next list.  Work per round is proportional to the cells that are ready, not to the tile.
+    __shared__ uint16_t s_next[TT * TT];
+    __shared__ int s_nn;
+    int32_t finalized = 0;
+    for (;;) {
+        const int nl = s_n;
+        if (nl == 0) break;
+        if (threadIdx.x == 0) s_nn = 0;
+        __syncthreads();
+        for (int k = threadIdx.x; k < nl; k += 256) {
+            const int cell = s_list[k];
+            const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
+            const int gi = i0 + li - 1, gj = j0 + lj - 1;
+            const int32_t c = gi * m + gj;
+            const uint32_t cw = s_ci[idx];
+            double a = A.a0[gi];
+            bool td = (gi == 0 || gi == n - 1 || gj == 0 || gj == m - 1) && A.todo_work[c] != 0;
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                if (cw & (1u << d)) {
+                    const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
+                    const double x = cardinal ? s_cx[idx + LOFF[d]] : s_cy[idx + LOFF[d]];
+                    a += fabs(x);
+                    td = td || (x < 0);
+                }
+            }
+            if (cw & CI_PIT_IN)
+                for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++) {
+                    a += A.area[A.pin_src[e]] * A.pin_w[e];
+                    td = td || (A.todo_work[A.pin_src[e]] != 0);
+                }
+            double ox = 0.0, oy = 0.0;
+            if (cw & (CI_OUT1 | CI_OUT2)) {
+                const double p = s_p[cell];
+                if (cw & CI_OUT1) ox = a * p;
+                if (cw & CI_OUT2) oy = a * (1 - p);
+                if (td) { ox = -ox; oy = -oy; }
+            }
+            s_cx[idx] = ox; s_cy[idx] = oy; s_area[cell] = td ? -a : a;   // sign of the stored area carries the taint
+            s_state[idx] = 2;
+            finalized++;
+            // release the targets inside the tile
+            const int sct = ci_section(cw);
+            if (cw & CI_OUT1) {
+                const int ti = li + fe1r(sct), tj = lj + fe1c(sct);
+                if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && atomicSub(&s_pend[ti * HW + tj], 1u) == 1u)
+                    s_next[atomicAdd(&s_nn, 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
+            }
+            if (cw & CI_OUT2) {
+                const int ti = li + fe2r(sct), tj = lj + fe2c(sct);
+                if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && atomicSub(&s_pend[ti * HW + tj], 1u) == 1u)
+                    s_next[atomicAdd(&s_nn, 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
+            }
+        }
+        __syncthreads();
+        const int nn = s_nn;
+        for (int k = threadIdx.x; k < nn; k += 256) s_list[k] = s_next[k];
+        if (threadIdx.x == 0) s_n = nn;
+        __syncthreads();
+    }
+    // ---- write back what this pass finished (consecutive threads own consecutive cells)
+    int open_cells = 0;
+    for (int cell = threadIdx.x; cell < TT * TT; cell += 256) {
+        const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
+        const int gi = i0 + li - 1, gj = j0 + lj - 1;
+        if (gi >= n || gj >= m) continue;
+        const uint8_t st = s_state[idx];
+        if (st == 0) { open_cells = 1; continue; }
+        if (st != 2) continue;
+        const int32_t c = gi * m + gj;
+        const double a = s_area[cell];
+        A.area[c] = fabs(a);
+        A.contrib[c] = make_double2(s_cx[idx], s_cy[idx]);
+        A.cinfo[c] = ci_with_level(s_ci[idx], pass);
+        if (a < 0) A.todo_work[c] = 1;
+    }
+    const int still_open = __syncthreads_or(open_cells);
+    for (int off = 32; off > 0; off >>= 1) finalized += __shfl_down(finalized, off);
+    if ((threadIdx.x & 63) == 0 && finalized) atomicAdd(n_final, finalized);
+    if (threadIdx.x == 0 && !still_open) tile_done[tid] = 1;
+}
+
+// after the tile passes: cells that are not final but whose upstream cells all are form the first
+// queue frontier (level `r`)
+__global__ __launch_bounds__(256) void k_sweep_rebuild_frontier(SweepArgs A, uint32_t r, int32_t *__restrict__ qn, int32_t *cn)
+{
+    __shared__ Stage S;
+    if (threadIdx.x == 0) S.cnt = 0;
+    __syncthreads();
+    const int64_t NN = (int64_t)A.n * A.m;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < NN; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = base + threadIdx.x;
+        bool push = false;
+        if (c < NN) {
+            const uint32_t cw = A.cinfo[c];
+            const uint32_t lv = ci_level(cw);
+            if (lv == 0 || lv == CI_LEVEL_INF) {
+                bool ready = true;
+#pragma unroll
+                for (int d = 0; d < 8; d++)
+                    if (cw & (1u << d)) {
+                        const uint32_t lu = ci_level(A.cinfo[c + NB_DI[d] * A.m + NB_DJ[d]]);
+                        ready = ready && (lu >= 1 && lu < r);
+                    }
+                if (ready && (cw & CI_PIT_IN))
+                    for (int32_t e = pit_first(A.pin_dst, A.pin_blk, (int32_t)c); e < A.n_pit && A.pin_dst[e] == (int32_t)c; e++) {
+                        const uint32_t lu = ci_level(A.cinfo[A.pin_src[e]]);
+                        ready = ready && (lu >= 1 && lu < r);
+                    }
+                if (ready) { A.cinfo[c] = ci_with_level(cw, r); push = true; }
+            }
+        }
+        stage_push(S, push, (int32_t)c);
+        stage_flush(S, qn, cn, false);
+    }
+    stage_flush(S, qn, cn, true);
+}
+
 __global__ void k_row_area(const double *__restrict__ dX2, const double *__restrict__ dY2, int n, double *a0)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -727,11 +915,49 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     hipLaunchKernelGGL(k_row_area, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, t->stream, t->dX2, t->dY2, n, t->row_area);
     SweepArgs A;
     fill_sweep_args(t, A);
-    hipLaunchKernelGGL(k_sweep_sources, dim3(grid_for(t->NN, 4096)), dim3(256), 0, t->stream, A, t->queue[1], &cnt3[1], nsrc);
-    int64_t launches = 1;
-    int r = 1;
-    int64_t last = t->NN;   // size of the frontier the next round will read (upper bound until first readback)
+    // ---- tile-local passes until they stop paying, then the queue rounds take over
+    const int tiles_x = (int)cdiv(m, TT), tiles_total = tiles_x * (int)cdiv(n, TT);
+    if (t->scratch_bytes < (size_t)tiles_total) {
+        if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->device_bytes -= (int64_t)t->scratch_bytes; }
+        HIP_TRY(hipMalloc(&t->scratch, (size_t)tiles_total));
+        t->scratch_bytes = (size_t)tiles_total; t->device_bytes += (int64_t)tiles_total;
+    }
+    uint8_t *tile_done = (uint8_t *)t->scratch;
+    HIP_TRY(hipMemsetAsync(tile_done, 0, (size_t)tiles_total, t->stream));
+    int64_t launches = 0;
+    uint32_t pass = 0;
+    int64_t done_prev = 0;
+    // every pass re-stages all tiles that still have an open cell (rivers cross most tiles), so after the
+    // first pass (which finishes ~3/4 of the grid) the queue rounds are cheaper than another pass
+    static int max_passes = -1;
+    if (max_passes < 0) { const char *e = getenv("PYDEM_TILE_PASSES"); max_passes = e ? atoi(e) : 1; if (max_passes < 1) max_passes = 1; }
     for (;;) {
+        pass++;
+        hipLaunchKernelGGL(k_sweep_tiles, dim3((unsigned)(((tiles_total + 7) / 8) * 8)), dim3(256), 0, t->stream, A, pass, tiles_x,
+                           tiles_total, tile_done, total);
+        launches++;
+        HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        const int64_t done_now = t->h_counters[3];
+        const int64_t gained = done_now - done_prev;
+        if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "tile pass %u: +%lld cells (%.2f%%), total %.2f%%, iterations so far %d over %d active tiles\n", pass, (long long)gained, 100.0 * gained / t->NN, 100.0 * done_now / t->NN, t->h_counters[4], t->h_counters[10]);
+        done_prev = done_now;
+        // a pass costs about one streaming read of the unfinished tiles; stop when it finishes < 1.5 % of the grid
+        if (done_now >= t->NN || gained * 64 < t->NN || (int)pass >= max_passes) break;
+    }
+    t->tm.sweep_tile_passes = (int64_t)pass;
+    int r = (int)pass + 1;
+    int64_t last = 0;
+    if (done_prev < t->NN) {
+        hipLaunchKernelGGL(k_sweep_rebuild_frontier, dim3(grid_for(t->NN, 4096)), dim3(256), 0, t->stream, A, (uint32_t)r,
+                           t->queue[r % 2], &cnt3[r % 3]);
+        launches++;
+        HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        last = t->h_counters[r % 3];
+    }
+    (void)nsrc;
+    while (last > 0) {
         const int batch = last > 262144 ? 2 : (last > 4096 ? 8 : 64);
         const int grid = grid_for(last, 2048);
         for (int b = 0; b < batch; b++, r++) {
@@ -742,10 +968,9 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         last = t->h_counters[r % 3];
-        if (last == 0) break;
         if (r > (int)CI_LEVEL_INF - 256) { pydem_set_error("flow paths longer than %u rounds are not supported", CI_LEVEL_INF); return -5; }
     }
-    const int64_t processed = (int64_t)t->h_counters[3] + t->h_counters[4];
+    const int64_t processed = (int64_t)t->h_counters[3];     // tile passes + queue rounds ([4], [10]: tile-pass statistics)
     t->tm.n_unresolved = t->NN - processed;
     t->tm.sweep_kernel_launches = launches;
     double min_area = INFINITY;
