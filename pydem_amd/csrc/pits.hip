@@ -13,6 +13,7 @@
 #include "internal.h"
 #include <hipcub/hipcub.hpp>
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -38,6 +39,8 @@ __device__ double np_pairwise_sum(const double *a, int n)
         return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
     }
 }
+
+constexpr int OUT_CHUNK = 64;   // output slots reserved per global atomic
 
 struct PitParams {
     const double *elev;
@@ -103,7 +106,8 @@ __device__ __forceinline__ int group_sum(int v, int *red, int gl, int *excl)
 // region / border / promote: W*W-bit bitmaps; dlist/dxy/sv: drain scratch.
 template <int NT, int W, int MAXD>
 __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *region, uint32_t *border, uint32_t *promote,
-                          int32_t *dlist, double *dxy, double *sv, double *redd, int *redi, int *flag)
+                          int32_t *dlist, double *dxy, double *sv, double *redd, int *redi, int *flag,
+                          int32_t &chunk_base, int32_t &chunk_left)
 {
     constexpr int WORDS = W * W / 32;
     constexpr int WPR = W / 32;                    // words per window row
@@ -116,7 +120,7 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
     if (r0 < 0) r0 = 0;
     if (c0 < 0) c0 = 0;
     for (int w = gl; w < WORDS; w += NT) { region[w] = 0; border[w] = 0; promote[w] = 0; }
-    if (gl == 0) { flag[0] = 0; flag[1] = 0; }
+    if (gl == 0) { flag[0] = 0; flag[1] = 0; flag[2] = W; flag[3] = -1; }     // [2],[3]: first/last window row in use
     group_sync<NT>();
     const double epit = P.elev[pit];
     // pit_area = [pit]; border = its 8 neighbours inside the tile (:1289-1292)
@@ -131,6 +135,8 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
                 const int r = ii - r0, c = jj - c0;
                 if (r < 0 || r >= W || c < 0 || c >= W) { flag[0] = 1; continue; }
                 border[r * WPR + (c >> 5)] |= 1u << (c & 31);
+                if (r < flag[2]) flag[2] = r;
+                if (r > flag[3]) flag[3] = r;
             }
     }
     group_sync<NT>();
@@ -150,10 +156,11 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
     int ndrain = -1;        // -1: none found
     for (int it = 0; it < P.max_iter; it++) {                                    // :1300
         if (flag[0]) break;                                                      // left the window
+        const int w_first = flag[2] * WPR, w_last = (flag[3] + 1) * WPR;         // rows that hold border / region bits
         // --- scan the border: minima of all / non-pit / pit cells
         double mn = INFINITY, mn_np = INFINITY, mn_p = INFINITY;
         int any = 0;
-        for (int w = gl; w < WORDS; w += NT) {
+        for (int w = w_first + gl; w < w_last; w += NT) {
             uint32_t b = border[w];
             while (b) {
                 const int k = __ffs((int)b) - 1; b &= b - 1;
@@ -177,8 +184,8 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
             // collect drains in ascending cell order (window scan order == ascending id)
             int cnt = 0;
             // each thread owns a contiguous run of words so the concatenation over threads is ordered
-            const int per = (WORDS + NT - 1) / NT;
-            const int w_lo = gl * per, w_hi = (w_lo + per < WORDS) ? w_lo + per : WORDS;
+            const int per = (w_last - w_first + NT - 1) / NT;
+            const int w_lo = w_first + gl * per, w_hi = (w_lo + per < w_last) ? w_lo + per : w_last;
             for (int w = w_lo; w < w_hi; w++) {
                 uint32_t b = border[w];
                 while (b) {
@@ -210,7 +217,7 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
             break;
         }
         // --- grow: pit_area += border[eborder == emin] (:1322-1323)
-        for (int w = gl; w < WORDS; w += NT) {
+        for (int w = w_first + gl; w < w_last; w += NT) {
             uint32_t b = border[w], pr = 0;
             while (b) {
                 const int k = __ffs((int)b) - 1; b &= b - 1;
@@ -221,7 +228,7 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
             if (pr) region[w] |= pr;        // word w is owned by this thread in this phase
         }
         group_sync<NT>();
-        for (int w = gl; w < WORDS; w += NT) {
+        for (int w = w_first + gl; w < w_last; w += NT) {
             uint32_t pr = promote[w];
             while (pr) {
                 const int k = __ffs((int)pr) - 1; pr &= pr - 1;
@@ -235,12 +242,15 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
                         if (rr < 0 || rr >= W || cc < 0 || cc >= W) { flag[0] = 1; continue; }
                         const int ww = rr * WPR + (cc >> 5);
                         const uint32_t bit = 1u << (cc & 31);
-                        if (!((region[ww] | border[ww]) & bit)) atomicOr(&border[ww], bit);
+                        if (!((region[ww] | border[ww]) & bit)) {
+                            atomicOr(&border[ww], bit);
+                            atomicMin(&flag[2], rr); atomicMax(&flag[3], rr);
+                        }
                     }
             }
         }
         group_sync<NT>();
-        for (int w = gl; w < WORDS; w += NT) {
+        for (int w = w_first + gl; w < w_last; w += NT) {
             const uint32_t pr = promote[w];
             if (pr) border[w] &= ~pr;
         }
@@ -293,12 +303,19 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
         else {
             for (int t = 0; t < nd; t++) sv[t] = fabs(epit - P.elev[dlist[t]]) / dxy[t];   // :1361
             const double ssum = np_pairwise_sum(sv, nd);
-            const int32_t base = atomicAdd(&P.out_count[0], nd);
-            if (base + nd <= P.out_cap) {
+            // output slots come in chunks (one global atomic per ~30 pits instead of one per pit: 3.5 M
+            // atomics on a single address cost ~40 ms); unused slots keep src = -1 and are dropped later
+            if (nd > chunk_left) {
+                const int32_t grab = nd > OUT_CHUNK ? nd : OUT_CHUNK;
+                chunk_base = atomicAdd(&P.out_count[0], grab);
+                chunk_left = grab;
+            }
+            if (chunk_base + nd <= P.out_cap) {
                 for (int t = 0; t < nd; t++) {                                   // :1365-1367
-                    P.out_src[base + t] = pit; P.out_dst[base + t] = dlist[t]; P.out_w[base + t] = sv[t] / ssum;
+                    P.out_src[chunk_base + t] = pit; P.out_dst[chunk_base + t] = dlist[t]; P.out_w[chunk_base + t] = sv[t] / ssum;
                 }
             } else atomicAdd(&P.out_count[3], 1);
+            chunk_base += nd; chunk_left -= nd;
             P.mag[pit] = ssum / (double)nd;                                      // np.mean(s) :1370
             P.flats[pit] = 0;                                                    // :1371
         }
@@ -315,12 +332,13 @@ __global__ __launch_bounds__(256) void k_pits_wave(PitParams P, const int32_t *_
     __shared__ uint32_t s_bits[4][3][WORDS];
     __shared__ int32_t s_dl[4][MAXD_SMALL];
     __shared__ double s_dxy[4][MAXD_SMALL], s_sv[4][MAXD_SMALL];
-    __shared__ int s_flag[4][2];
+    __shared__ int s_flag[4][4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t np = *npits;
+    int32_t chunk_base = 0, chunk_left = 0;
     for (int32_t q = blockIdx.x * 4 + wave; q < np; q += gridDim.x * 4)
         solve_pit<64, W_SMALL, MAXD_SMALL>(P, pits[q], lane, s_bits[wave][0], s_bits[wave][1], s_bits[wave][2], s_dl[wave],
-                                           s_dxy[wave], s_sv[wave], nullptr, nullptr, s_flag[wave]);
+                                           s_dxy[wave], s_sv[wave], nullptr, nullptr, s_flag[wave], chunk_base, chunk_left);
 }
 
 // workgroup-per-pit with the full-radius window in dynamic LDS (3 * 640*640/8 = 153.6 KB)
@@ -331,12 +349,13 @@ __global__ __launch_bounds__(256) void k_pits_block(PitParams P, const int32_t *
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
     __shared__ double redd[4];
     __shared__ int redi[4];
-    __shared__ int flag[2];
+    __shared__ int flag[4];
+    int32_t chunk_base = 0, chunk_left = 0;
     const int32_t np = *npits;
     for (int32_t q = blockIdx.x; q < np; q += gridDim.x) {
         solve_pit<256, W_LARGE, MAXD_LARGE>(P, pits[q], threadIdx.x, dyn, dyn + WORDS, dyn + 2 * WORDS,
                                              g_dl + (size_t)blockIdx.x * MAXD_LARGE, g_dxy + (size_t)blockIdx.x * MAXD_LARGE,
-                                             g_sv + (size_t)blockIdx.x * MAXD_LARGE, redd, redi, flag);
+                                             g_sv + (size_t)blockIdx.x * MAXD_LARGE, redd, redi, flag, chunk_base, chunk_left);
         __syncthreads();
     }
 }
@@ -381,7 +400,7 @@ __global__ void k_pit_keys(const int32_t *__restrict__ src, const int32_t *__res
                            const double *__restrict__ elev, int32_t ne, uint64_t *key_out, uint64_t *key_in, int32_t *idx)
 {
     for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
-        const bool keep = !isnan(w[e]) && w[e] > 1e-8 && elev[dst[e]] <= elev[src[e]];
+        const bool keep = src[e] >= 0 && !isnan(w[e]) && w[e] > 1e-8 && elev[dst[e]] <= elev[src[e]];
         // dropped edges sort to the end
         key_out[e] = keep ? (((uint64_t)(uint32_t)src[e] << 32) | (uint32_t)dst[e]) : ~0ull;
         key_in[e] = keep ? (((uint64_t)(uint32_t)dst[e] << 32) | (uint32_t)src[e]) : ~0ull;
@@ -437,7 +456,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
     if (npits == 0) { t->tm.pits_ms = 0; return 0; }
 
     // raw triplets; capacity grows until everything fits
-    int64_t cap = (int64_t)npits * 2 + 1024;
+    int64_t cap = (int64_t)npits * 2 + 16384 * 4 * OUT_CHUNK + 1024;   // + one partly used chunk per wavefront
     for (int attempt = 0;; attempt++) {
         if (t->pits.raw_cap < cap) {
             PYDEM_TRY(dev_realloc(t, &t->pits.raw_src, (size_t)cap));
@@ -446,6 +465,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             t->pits.raw_cap = cap;
         }
         HIP_TRY(hipMemsetAsync(cnt + 1, 0, 8 * sizeof(int32_t), t->stream));
+        HIP_TRY(hipMemsetAsync(t->pits.raw_src, 0xFF, (size_t)t->pits.raw_cap * 4, t->stream));   // -1 = unused slot
         PitParams P;
         P.elev = t->elev; P.pitmask = t->flat0; P.dX = t->dX; P.dY = t->dY; P.mag = t->mag; P.flats = t->flats;
         P.n = n; P.m = m; P.max_iter = opt->drain_pits_max_iter; P.max_dist = opt->drain_pits_max_dist;
@@ -458,6 +478,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         const int32_t n_over = t->h_counters[3];
+        if (getenv("PYDEM_PITS_DEBUG")) fprintf(stderr, "pits: %d candidates, %d left the 64x64 window, %d edges so far, %d undrained\n", npits, n_over, t->h_counters[1], t->h_counters[2]);
         if (n_over > 0) {
             // second pass: workgroup per pit, 640x640 window in LDS
             const int gb = n_over < 1024 ? n_over : 1024;
@@ -528,6 +549,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         HIP_TRY(hipStreamSynchronize(t->stream));
         HIP_TRY(hipGetLastError());
         t->pits.n_edges = t->h_counters[0];     // kept edges (a prefix of both sorted views)
+        t->tm.n_pit_edges = t->pits.n_edges;
         (void)hipFree(k1); (void)hipFree(k2); (void)hipFree(k1s); (void)hipFree(k2s); (void)hipFree(idx); (void)hipFree(i1);
         (void)hipFree(i2); (void)hipFree(tmp);
     }

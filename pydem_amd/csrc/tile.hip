@@ -52,7 +52,8 @@ __global__ void k_line_scatter(const T *__restrict__ src, int64_t stride, int64_
 
 __global__ void k_restore_pit_slopes(const int32_t *__restrict__ src, int64_t n, double *mag)
 {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) mag[src[e]] = -1.0;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        if (src[e] >= 0) mag[src[e]] = -1.0;      // unused output slots hold -1
 }
 
 template <typename S>
@@ -415,12 +416,22 @@ int pydem_twi(pydem_tile *t, pydem_options *opt)
 int pydem_tile_pit_edges(pydem_tile *t, int64_t *n, int32_t *src, int32_t *dst, double *w)
 {
     HIP_TRY(hipSetDevice(t->device));
-    *n = t->pits.n_raw;
-    if (!src || t->pits.n_raw == 0) return 0;
-    HIP_TRY(hipMemcpyAsync(src, t->pits.raw_src, t->pits.n_raw * 4, hipMemcpyDeviceToHost, t->stream));
-    HIP_TRY(hipMemcpyAsync(dst, t->pits.raw_dst, t->pits.n_raw * 4, hipMemcpyDeviceToHost, t->stream));
-    HIP_TRY(hipMemcpyAsync(w, t->pits.raw_w, t->pits.n_raw * 8, hipMemcpyDeviceToHost, t->stream));
-    HIP_TRY(hipStreamSynchronize(t->stream));
+    const int64_t nr = t->pits.n_raw;          // slots handed out, including unused ones (src == -1)
+    std::vector<int32_t> hs((size_t)nr), hd((size_t)nr);
+    std::vector<double> hw((size_t)nr);
+    if (nr) {
+        HIP_TRY(hipMemcpyAsync(hs.data(), t->pits.raw_src, nr * 4, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(hd.data(), t->pits.raw_dst, nr * 4, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(hw.data(), t->pits.raw_w, nr * 8, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+    }
+    int64_t k = 0;
+    for (int64_t e = 0; e < nr; e++) {
+        if (hs[(size_t)e] < 0) continue;
+        if (src) { src[k] = hs[(size_t)e]; dst[k] = hd[(size_t)e]; w[k] = hw[(size_t)e]; }
+        k++;
+    }
+    *n = k;
     return 0;
 }
 
