@@ -17,27 +17,65 @@
 
 namespace {
 
-// numpy pairwise sum (np.add.reduce on a contiguous float64 vector), see oracle/pydem_oracle.c
-__device__ double np_pairwise_sum(const double *a, int n)
+// numpy pairwise sum (np.add.reduce on a contiguous float64 vector), see oracle/pydem_oracle.c.
+// numpy recurses on halves above 128 elements; a recursive device function would give the kernels a
+// dynamic stack (scratch, low occupancy), so the recursion is unrolled as a template of bounded depth
+// (128 * 2^9 elements cover any tile height; slices here are <= drain_pits_max_dist = 32 by default).
+__device__ __forceinline__ double np_pairwise_leaf(const double *a, int n)
 {
     if (n < 8) {
         double res = 0.;
         for (int i = 0; i < n; i++) res += a[i];
         return res;
-    } else if (n <= 128) {
-        double r[8];
-        int i;
-        for (i = 0; i < 8; i++) r[i] = a[i];
-        for (i = 8; i < n - (n % 8); i += 8)
-            for (int k = 0; k < 8; k++) r[k] += a[i + k];
-        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; i++) res += a[i];
-        return res;
-    } else {
-        int n2 = n / 2;
-        n2 -= n2 % 8;
-        return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
     }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+// Slices longer than 128 (only possible when drain_pits_max_dist is disabled) follow numpy's
+// recursive halving with an explicit stack kept in LDS (`stk`: 16 frames of {offset, length, stage,
+// left value}); no device recursion, no dynamic stack.
+struct PwFrame { int off, len, stage, pad; double lval; };
+
+__device__ __forceinline__ double np_pairwise_sum(const double *a, int n, PwFrame *stk)
+{
+    if (n <= 128) return np_pairwise_leaf(a, n);
+    int sp = 0;
+    stk[0].off = 0; stk[0].len = n; stk[0].stage = 0;
+    double ret = 0.0;
+    while (sp >= 0) {
+        PwFrame &f = stk[sp];
+        if (f.len <= 128) {
+            ret = np_pairwise_leaf(a + f.off, f.len);
+            sp--;
+            // hand the value to the parents
+            while (sp >= 0) {
+                PwFrame &p = stk[sp];
+                int n2 = p.len / 2; n2 -= n2 % 8;
+                if (p.stage == 1) {            // left child done: start the right child
+                    p.lval = ret; p.stage = 2;
+                    stk[sp + 1].off = p.off + n2; stk[sp + 1].len = p.len - n2; stk[sp + 1].stage = 0;
+                    sp++;
+                    break;
+                }
+                ret = p.lval + ret;            // both children done
+                sp--;
+            }
+        } else {                               // stage 0: descend into the left child
+            int n2 = f.len / 2; n2 -= n2 % 8;
+            f.stage = 1;
+            stk[sp + 1].off = f.off; stk[sp + 1].len = n2; stk[sp + 1].stage = 0;
+            sp++;
+        }
+    }
+    return ret;
 }
 
 constexpr int OUT_CHUNK = 64;   // output slots reserved per global atomic
@@ -102,12 +140,71 @@ __device__ __forceinline__ int group_sum(int v, int *red, int gl, int *excl)
     return tot;
 }
 
+// filters and weights of one pit: serial on one thread (drain counts are tiny), numpy operation order
+__device__ void finish_pit(const PitParams &P, int32_t pit, int ipit, int jpit, double epit, int ndrain, int32_t *dlist,
+                           double *dxy, double *sv, int32_t &chunk_base, int32_t &chunk_left, PwFrame *stk)
+{
+    const int n = P.n, m = P.m;
+    int nd = ndrain;
+    if (P.max_dist) {                                                        // :1335-1343
+        int keep = 0;
+        for (int t = 0; t < nd; t++) {
+            const int di = ipit - dlist[t] / m, dj = jpit - dlist[t] % m;
+            const double dij = sqrt((double)(di * di + dj * dj));
+            if (dij <= (double)P.max_dist) dlist[keep++] = dlist[t];
+        }
+        nd = keep;
+    }
+    if (nd > 0) {
+        const int ndX = n - 1;
+        for (int t = 0; t < nd; t++) {                                       // :1346-1349
+            const int idr = dlist[t] / m, jdr = dlist[t] % m;
+            double dxm;
+            if (ipit == idr) dxm = P.dX[ipit < ndX - 1 ? ipit : ndX - 1];    // _get_dX_mean :1994-1995
+            else {
+                const int a = ipit < idr ? ipit : idr, b = ipit < idr ? idr : ipit;
+                dxm = np_pairwise_sum(P.dX + a, b - a, stk) / (double)(b - a);   // .mean() :1997
+            }
+            const double dx = dxm * (double)(jpit - jdr);
+            const int a = ipit < idr ? ipit : idr, b = ipit < idr ? idr : ipit;
+            const double dy = np_pairwise_sum(P.dY + a, b - a, stk);
+            dxy[t] = sqrt(dx * dx + dy * dy);
+        }
+        if (!isnan(P.max_dist_XY) && P.max_dist_XY != 0) {                   // :1352-1358
+            int keep = 0;
+            for (int t = 0; t < nd; t++)
+                if (dxy[t] <= P.max_dist_XY) { dlist[keep] = dlist[t]; dxy[keep] = dxy[t]; keep++; }
+            nd = keep;
+        }
+    }
+    if (nd == 0) { atomicAdd(&P.out_count[1], 1); }
+    else {
+        for (int t = 0; t < nd; t++) sv[t] = fabs(epit - P.elev[dlist[t]]) / dxy[t];   // :1361
+        const double ssum = np_pairwise_sum(sv, nd, stk);
+        // output slots come in chunks (one global atomic per ~30 pits instead of one per pit: 3.5 M
+        // atomics on a single address cost ~40 ms); unused slots keep src = -1 and are dropped later
+        if (nd > chunk_left) {
+            const int32_t grab = nd > OUT_CHUNK ? nd : OUT_CHUNK;
+            chunk_base = atomicAdd(&P.out_count[0], grab);
+            chunk_left = grab;
+        }
+        if (chunk_base + nd <= P.out_cap) {
+            for (int t = 0; t < nd; t++) {                                   // :1365-1367
+                P.out_src[chunk_base + t] = pit; P.out_dst[chunk_base + t] = dlist[t]; P.out_w[chunk_base + t] = sv[t] / ssum;
+            }
+        } else atomicAdd(&P.out_count[3], 1);
+        chunk_base += nd; chunk_left -= nd;
+        P.mag[pit] = ssum / (double)nd;                                      // np.mean(s) :1370
+        P.flats[pit] = 0;                                                    // :1371
+    }
+}
+
 // One pit.  W = window edge (multiple of 32), MAXD = drain list capacity.
 // region / border / promote: W*W-bit bitmaps; dlist/dxy/sv: drain scratch.
 template <int NT, int W, int MAXD>
 __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *region, uint32_t *border, uint32_t *promote,
                           int32_t *dlist, double *dxy, double *sv, double *redd, int *redi, int *flag,
-                          int32_t &chunk_base, int32_t &chunk_left)
+                          int32_t &chunk_base, int32_t &chunk_left, PwFrame *stk)
 {
     constexpr int WORDS = W * W / 32;
     constexpr int WPR = W / 32;                    // words per window row
@@ -265,61 +362,161 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
         return;
     }
     if (ndrain < 0) { if (gl == 0) atomicAdd(&P.out_count[1], 1); return; }      // :1327-1329
-    // --- filters and weights: serial on one thread (drain counts are tiny), numpy operation order
-    if (gl == 0) {
-        int nd = ndrain;
-        if (P.max_dist) {                                                        // :1335-1343
-            int keep = 0;
-            for (int t = 0; t < nd; t++) {
-                const int di = ipit - dlist[t] / m, dj = jpit - dlist[t] % m;
-                const double dij = sqrt((double)(di * di + dj * dj));
-                if (dij <= (double)P.max_dist) dlist[keep++] = dlist[t];
+    if (gl == 0) finish_pit(P, pit, ipit, jpit, epit, ndrain, dlist, dxy, sv, chunk_base, chunk_left, stk);
+
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wavefront version (the common case: 99.9 % of the pits).  Same algorithm as solve_pit, but every
+// round first compacts the border bitmap into an ordered list so that each lane owns ONE border cell:
+// the elevation / pit-mask loads of a round are issued in parallel (one memory latency per round
+// instead of one per border cell per lane), minima are shuffle reductions, drains are collected with
+// ballots (list order = ascending cell id, the order of the reference's setdiff1d).
+// ---------------------------------------------------------------------------------------------
+constexpr int WV = 64;            // window edge: lane l owns window row l (two 32-bit words)
+constexpr int WV_LCAP = 256;      // border list capacity
+constexpr int WV_MAXD = 64;       // drain list capacity
+
+__device__ __forceinline__ double wave_min(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, uint32_t *region, uint32_t *border,
+                               uint16_t *blist, double *be, uint8_t *bp, int32_t *dlist, double *dxy, double *sv, int *flag,
+                               int32_t &chunk_base, int32_t &chunk_left, PwFrame *stk)
+{
+    const int n = P.n, m = P.m;
+    const int ipit = pit / m, jpit = pit - ipit * m;
+    int r0 = ipit - WV / 2, c0 = jpit - WV / 2;
+    if (r0 > n - WV) r0 = n - WV;
+    if (c0 > m - WV) c0 = m - WV;
+    if (r0 < 0) r0 = 0;
+    if (c0 < 0) c0 = 0;
+    region[2 * lane] = 0; region[2 * lane + 1] = 0; border[2 * lane] = 0; border[2 * lane + 1] = 0;
+    if (lane == 0) flag[0] = 0;
+    wave_sync();
+    const double epit = P.elev[pit];
+    if (lane == 0) {                                                             // pit_area = [pit], border = its neighbours (:1289-1292)
+        const int wr = ipit - r0, wc = jpit - c0;
+        region[wr * 2 + (wc >> 5)] |= 1u << (wc & 31);
+        for (int di = -1; di <= 1; di++)
+            for (int dj = -1; dj <= 1; dj++) {
+                if (!di && !dj) continue;
+                const int ii = ipit + di, jj = jpit + dj;
+                if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+                const int r = ii - r0, c = jj - c0;
+                if (r < 0 || r >= WV || c < 0 || c >= WV) { flag[0] = 1; continue; }
+                border[r * 2 + (c >> 5)] |= 1u << (c & 31);
             }
-            nd = keep;
-        }
-        if (nd > 0) {
-            const int ndX = n - 1;
-            for (int t = 0; t < nd; t++) {                                       // :1346-1349
-                const int idr = dlist[t] / m, jdr = dlist[t] % m;
-                double dxm;
-                if (ipit == idr) dxm = P.dX[ipit < ndX - 1 ? ipit : ndX - 1];    // _get_dX_mean :1994-1995
-                else {
-                    const int a = ipit < idr ? ipit : idr, b = ipit < idr ? idr : ipit;
-                    dxm = np_pairwise_sum(P.dX + a, b - a) / (double)(b - a);   // .mean() :1997
-                }
-                const double dx = dxm * (double)(jpit - jdr);
-                const int a = ipit < idr ? ipit : idr, b = ipit < idr ? idr : ipit;
-                const double dy = np_pairwise_sum(P.dY + a, b - a);
-                dxy[t] = sqrt(dx * dx + dy * dy);
-            }
-            if (!isnan(P.max_dist_XY) && P.max_dist_XY != 0) {                   // :1352-1358
-                int keep = 0;
-                for (int t = 0; t < nd; t++)
-                    if (dxy[t] <= P.max_dist_XY) { dlist[keep] = dlist[t]; dxy[keep] = dxy[t]; keep++; }
-                nd = keep;
-            }
-        }
-        if (nd == 0) { atomicAdd(&P.out_count[1], 1); }
-        else {
-            for (int t = 0; t < nd; t++) sv[t] = fabs(epit - P.elev[dlist[t]]) / dxy[t];   // :1361
-            const double ssum = np_pairwise_sum(sv, nd);
-            // output slots come in chunks (one global atomic per ~30 pits instead of one per pit: 3.5 M
-            // atomics on a single address cost ~40 ms); unused slots keep src = -1 and are dropped later
-            if (nd > chunk_left) {
-                const int32_t grab = nd > OUT_CHUNK ? nd : OUT_CHUNK;
-                chunk_base = atomicAdd(&P.out_count[0], grab);
-                chunk_left = grab;
-            }
-            if (chunk_base + nd <= P.out_cap) {
-                for (int t = 0; t < nd; t++) {                                   // :1365-1367
-                    P.out_src[chunk_base + t] = pit; P.out_dst[chunk_base + t] = dlist[t]; P.out_w[chunk_base + t] = sv[t] / ssum;
-                }
-            } else atomicAdd(&P.out_count[3], 1);
-            chunk_base += nd; chunk_left -= nd;
-            P.mag[pit] = ssum / (double)nd;                                      // np.mean(s) :1370
-            P.flats[pit] = 0;                                                    // :1371
-        }
     }
+    wave_sync();
+    double epit_border = epit;
+    int ndrain = -1;
+    for (int it = 0; it < P.max_iter; it++) {                                    // :1300
+        if (flag[0]) break;
+        // ---- ordered list of the border cells
+        const uint32_t w0 = border[2 * lane], w1 = border[2 * lane + 1];
+        const int cnt = __popc(w0) + __popc(w1);
+        int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+        const int tot = __shfl(incl, 63);
+        if (tot == 0) break;                                                     // :1304-1305
+        if (tot > WV_LCAP) { if (lane == 0) flag[0] = 1; wave_sync(); break; }
+        {
+            int pos = incl - cnt;
+            uint32_t b = w0;
+            while (b) { const int k = __ffs((int)b) - 1; b &= b - 1; blist[pos++] = (uint16_t)(lane * 64 + k); }
+            b = w1;
+            while (b) { const int k = __ffs((int)b) - 1; b &= b - 1; blist[pos++] = (uint16_t)(lane * 64 + 32 + k); }
+        }
+        wave_sync();
+        // ---- one parallel load per border cell, then the three minima
+        double mn = INFINITY, mn_np = INFINITY, mn_p = INFINITY;
+        for (int base = 0; base < tot; base += 64) {
+            const int k = base + lane;
+            if (k < tot) {
+                const int pos = blist[k];
+                const int64_t cell = (int64_t)(r0 + (pos >> 6)) * m + (c0 + (pos & 63));
+                const double e = P.elev[cell];
+                const uint8_t pm = P.pitmask[cell];
+                be[k] = e; bp[k] = pm;
+                mn = fmin(mn, e);
+                if (pm) mn_p = fmin(mn_p, e); else mn_np = fmin(mn_np, e);
+            }
+        }
+        mn = wave_min(mn); mn_np = wave_min(mn_np); mn_p = wave_min(mn_p);
+        if (it == 0 && P.min_border) epit_border = mn;                           // :1294-1295 (first border)
+        int mode = 0;
+        if (mn_np < epit_border) mode = 1;                                       // :1312-1316
+        else if (mn_p < epit) mode = 2;                                          // :1317-1320
+        wave_sync();
+        if (mode) {
+            int nd = 0;
+            for (int base = 0; base < tot; base += 64) {
+                const int k = base + lane;
+                bool pred = false;
+                int32_t cell = 0;
+                if (k < tot) {
+                    const int pos = blist[k];
+                    cell = (int32_t)((int64_t)(r0 + (pos >> 6)) * m + (c0 + (pos & 63)));
+                    pred = mode == 1 ? (!bp[k] && be[k] < epit_border) : (bp[k] && be[k] < epit);
+                }
+                const unsigned long long bal = __ballot(pred);
+                const int rank = nd + __popcll(bal & ((1ull << lane) - 1ull));
+                if (pred && rank < WV_MAXD) dlist[rank] = cell;
+                nd += __popcll(bal);
+            }
+            if (nd > WV_MAXD) { if (lane == 0) flag[0] = 1; wave_sync(); break; }
+            ndrain = nd;
+            wave_sync();
+            break;
+        }
+        // ---- grow: pit_area += border[eborder == emin] (:1322-1323)
+        for (int base = 0; base < tot; base += 64) {
+            const int k = base + lane;
+            if (k < tot && be[k] == mn) {
+                const int pos = blist[k];
+                const int ww = (pos >> 6) * 2 + ((pos & 63) >> 5);
+                const uint32_t bit = 1u << (pos & 31);
+                atomicOr(&region[ww], bit);
+                atomicAnd(&border[ww], ~bit);
+            }
+        }
+        wave_sync();
+        for (int base = 0; base < tot; base += 64) {
+            const int k = base + lane;
+            if (k < tot && be[k] == mn) {
+                const int pos = blist[k];
+                const int r = pos >> 6, c = pos & 63;
+                for (int di = -1; di <= 1; di++)
+                    for (int dj = -1; dj <= 1; dj++) {
+                        if (!di && !dj) continue;
+                        const int ii = r0 + r + di, jj = c0 + c + dj;
+                        if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+                        const int rr = r + di, cc = c + dj;
+                        if (rr < 0 || rr >= WV || cc < 0 || cc >= WV) { flag[0] = 1; continue; }
+                        const int ww = rr * 2 + (cc >> 5);
+                        const uint32_t bit = 1u << (cc & 31);
+                        if (!((region[ww] | border[ww]) & bit)) atomicOr(&border[ww], bit);
+                    }
+            }
+        }
+        wave_sync();
+    }
+    wave_sync();
+    if (flag[0]) {                                                               // hand over to the large-window pass
+        if (lane == 0) P.overflow_list[atomicAdd(&P.out_count[2], 1)] = pit;
+        return;
+    }
+    if (ndrain < 0) { if (lane == 0) atomicAdd(&P.out_count[1], 1); return; }    // :1327-1329
+    if (lane == 0) finish_pit(P, pit, ipit, jpit, epit, ndrain, dlist, dxy, sv, chunk_base, chunk_left, stk);
 }
 
 constexpr int W_SMALL = 64, MAXD_SMALL = 64;
@@ -328,17 +525,20 @@ constexpr int W_LARGE = 640, MAXD_LARGE = 2048;
 // wave-per-pit: 4 pits per 256-thread block
 __global__ __launch_bounds__(256) void k_pits_wave(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits)
 {
-    constexpr int WORDS = W_SMALL * W_SMALL / 32;
-    __shared__ uint32_t s_bits[4][3][WORDS];
-    __shared__ int32_t s_dl[4][MAXD_SMALL];
-    __shared__ double s_dxy[4][MAXD_SMALL], s_sv[4][MAXD_SMALL];
+    __shared__ uint32_t s_bits[4][2][WV * WV / 32];
+    __shared__ uint16_t s_blist[4][WV_LCAP];
+    __shared__ double s_be[4][WV_LCAP];
+    __shared__ uint8_t s_bp[4][WV_LCAP];
+    __shared__ int32_t s_dl[4][WV_MAXD];
+    __shared__ double s_dxy[4][WV_MAXD], s_sv[4][WV_MAXD];
     __shared__ int s_flag[4][4];
+    __shared__ PwFrame s_stk[4][16];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t np = *npits;
     int32_t chunk_base = 0, chunk_left = 0;
     for (int32_t q = blockIdx.x * 4 + wave; q < np; q += gridDim.x * 4)
-        solve_pit<64, W_SMALL, MAXD_SMALL>(P, pits[q], lane, s_bits[wave][0], s_bits[wave][1], s_bits[wave][2], s_dl[wave],
-                                           s_dxy[wave], s_sv[wave], nullptr, nullptr, s_flag[wave], chunk_base, chunk_left);
+        solve_pit_wave(P, pits[q], lane, s_bits[wave][0], s_bits[wave][1], s_blist[wave], s_be[wave], s_bp[wave], s_dl[wave],
+                       s_dxy[wave], s_sv[wave], s_flag[wave], chunk_base, chunk_left, s_stk[wave]);
 }
 
 // workgroup-per-pit with the full-radius window in dynamic LDS (3 * 640*640/8 = 153.6 KB)
@@ -350,12 +550,13 @@ __global__ __launch_bounds__(256) void k_pits_block(PitParams P, const int32_t *
     __shared__ double redd[4];
     __shared__ int redi[4];
     __shared__ int flag[4];
+    __shared__ PwFrame stk[16];
     int32_t chunk_base = 0, chunk_left = 0;
     const int32_t np = *npits;
     for (int32_t q = blockIdx.x; q < np; q += gridDim.x) {
         solve_pit<256, W_LARGE, MAXD_LARGE>(P, pits[q], threadIdx.x, dyn, dyn + WORDS, dyn + 2 * WORDS,
                                              g_dl + (size_t)blockIdx.x * MAXD_LARGE, g_dxy + (size_t)blockIdx.x * MAXD_LARGE,
-                                             g_sv + (size_t)blockIdx.x * MAXD_LARGE, redd, redi, flag, chunk_base, chunk_left);
+                                             g_sv + (size_t)blockIdx.x * MAXD_LARGE, redd, redi, flag, chunk_base, chunk_left, stk);
         __syncthreads();
     }
 }
