@@ -177,7 +177,45 @@ def run_edge_update_case(name, elev, dX, dY, seed, **kw):
     save(name, rec, kw)
 
 
+def conditioning_cases():
+    """g7: inputs that exercise every branch of the conditioning code (artefact pits, summit plateaus,
+    closed depressions, flats leaving through the tile edge, tiny windows, integer dtype paths)."""
+    rng = np.random.default_rng(7)
+    # integer terraces with one-unit pits of several sizes, plateaus on peaks and against the edges
+    base = np.rint(synth.fractal(72, 80, seed=21, top_shift=5, n_octaves=4, zrange=12.0)).astype(np.int16) + 5
+    for _ in range(25):
+        i, j = rng.integers(2, 68), rng.integers(2, 76)
+        h, w = rng.integers(1, 4), rng.integers(1, 4)
+        lvl = base[i - 1:i + h + 1, j - 1:j + w + 1].min()
+        base[i - 1:i + h + 1, j - 1:j + w + 1] = lvl + 1
+        base[i:i + h, j:j + w] = lvl
+    run_and_save('g7_int16_terraces', base, 30.0, 30.0, dict())
+    run_and_save('g7_int16_terraces_noff', base, 30.0, 30.0, dict(fill_flats=False))
+    # float surface with exact plateaus (lakes), a summit plateau and a plateau cut by the border
+    f = synth.fractal(64, 64, seed=22, top_shift=5, n_octaves=5, zrange=80.0)
+    f = np.maximum(f, np.quantile(f, 0.2))
+    f[5:12, 20:30] = f.max() + 3.0
+    f[:4, 40:52] = f[:4, 40:52].min()
+    f[30:33, -5:] = f[30:33, -5:].min()
+    run_and_save('g7_float_lakes', f, 10.0, 12.0, dict())
+    # many tiny features: 2-level random integers
+    tiny = rng.integers(1, 4, size=(40, 44)).astype(np.float64)
+    run_and_save('g7_tiny_features', tiny, 1.0, 1.0, dict())
+    # conditioning with anisotropic, row-varying spacing
+    n = 56
+    v = np.rint(synth.fractal(n, 48, seed=23, top_shift=4, n_octaves=4, zrange=30.0))
+    run_and_save('g7_varspacing', v, 20.0 + 0.1 * np.arange(n - 1), 35.0 - 0.05 * np.arange(n - 1), dict())
+
+
+def run_and_save(name, elev, dX, dY, kw):
+    save(name, run_case(elev, dX, dY, **kw), kw)
+
+
 def main():
+    if '--only-conditioning' in sys.argv:
+        conditioning_cases()
+        write_manifest()
+        return
     if '--only-edge' in sys.argv:
         edge_cases()
         write_manifest()
@@ -220,6 +258,7 @@ def main():
         save(name, rec, kw)
 
     edge_cases()
+    conditioning_cases()
     write_manifest()
 
 

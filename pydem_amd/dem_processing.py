@@ -263,13 +263,29 @@ class DEMProcessor(object):
         self._tile.find_flats()
         self._produced('flats')
 
+    # ---- elevation conditioning: host side for now (pydem_amd/conditioning.py), see DESIGN.md
+    def calc_fill_pit_artifacts(self):
+        """Fill quantisation pits (reference :396-426)."""
+        from . import conditioning
+        self.elev = conditioning.fill_pit_artifacts(self.elev, self.maximum_pit_area, self.fill_flats_below_sea)
+
     def calc_fill_flats(self):
-        raise NotImplementedError("elevation conditioning (calc_fill_flats, reference :551-579) is not part of "
-                                  "the device path yet; construct with fill_flats=False")
+        """Fill / interpolate flats before the slope stencil (reference :551-579)."""
+        from . import conditioning
+        self.elev = conditioning.fill_flats(self.elev, self.maximum_pit_area, self.fill_flats_below_sea,
+                                            self.fill_flats_source_tol, self.fill_flats_peaks, self.fill_flats_pits)
 
     def calc_pit_drain_paths(self):
-        raise NotImplementedError("elevation conditioning (calc_pit_drain_paths, reference :428-548) is not part "
-                                  "of the device path yet; construct with drain_pits_path=False")
+        """Carve monotone paths from pits to their outlets (reference :428-548).  Works on a copy of the
+        array (the reference edits the caller's array in place)."""
+        from . import conditioning
+        elev = np.array(self.elev)
+        elev, n_failed, used = conditioning.pit_drain_paths(elev, self.dX, self.dY, self.drain_pits_max_iter,
+                                                            self.drain_pits_max_dist, self.drain_pits_max_dist_XY,
+                                                            self.fill_flats_below_sea)
+        logger.info("... done draining pits with maxiter = %d", used)
+        self.elev = elev
+        return elev
 
     def calc_slopes_directions(self, plotflag=False):
         """Slope magnitude and D-infinity direction (reference :587-619)."""

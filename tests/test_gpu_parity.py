@@ -114,3 +114,31 @@ def test_synth_generator_bit_identical():
     a = t.download(_ffi.ELEV)
     b = synth.fractal(100, 140, seed=4, row0=5000, col0=77, n_octaves=8, top_shift=9, zmin=1.0, zrange=500.0)
     assert np.array_equal(a, b)
+
+
+def _default_cases():
+    names = [n for n in golden_names() + golden_names('g7_')]
+    return [n for n in names if load_golden(n)['kwargs'].get('fill_flats', True) or load_golden(n)['kwargs'].get('drain_pits_path', True)]
+
+
+@pytest.mark.parametrize('name', _default_cases())
+def test_full_pipeline_with_conditioning(name):
+    """DEMProcessor with the reference's option set, from the RAW input: host conditioning
+    (fill flats / pit drain paths) then the device path; every output against the reference."""
+    g = load_golden(name)
+    from pydem_amd import DEMProcessor
+    import warnings
+    dp = DEMProcessor(elev=g['in_elev'], dX=g['in_dX'], dY=g['in_dY'], dX2=g['in_dX2'], dY2=g['in_dY2'], **g['kwargs'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        twi = dp.calc_twi()
+    assert np.array_equal(np.asarray(dp.elev, float), g['elev_final'].astype(float))
+    _close(dp.mag, g['mag_final'], 'mag')
+    _close(dp.direction, g['direction'], 'direction')
+    assert np.array_equal(dp.flats, g['flats_final'])
+    assert np.array_equal(dp.section, g['section'])
+    _close(dp.uca, g['uca'], 'uca')
+    assert np.array_equal(dp.edge_todo, g['edge_todo'])
+    assert np.array_equal(dp.edge_done, g['edge_done'])
+    _close(twi, g['twi_ret'], 'twi')
+    _close(dp.twi, g['twi_attr'], 'twi attr')

@@ -10,13 +10,15 @@ from oracle_processor import OracleProcessor
 from test_process_manager_grid import write_tiles
 
 
-def run_pm(g, path, **kw):
+def run_pm(g, path, from_raw=False, **kw):
+    """from_raw: start from the raw input tiles and let process_elevation condition them (reference
+    calc_elev_cond :54-71); otherwise start from the reference's conditioned elevation."""
     from pydem_amd import process_manager
     dkw = {k: v for k, v in g['kwargs'].items() if k not in ('ny_grid', 'nx_grid', 'overlap')}
-    write_tiles(g, path, key='elev')
+    write_tiles(g, path, key='in_elev' if from_raw else 'elev')
     process_manager.DEBUG = True
     try:
-        pm = process_manager.ProcessManager(in_path=path, dem_proc_kwargs=dkw, elev_conditioned=True, **kw)
+        pm = process_manager.ProcessManager(in_path=path, dem_proc_kwargs=dkw, elev_conditioned=not from_raw, **kw)
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
@@ -32,6 +34,7 @@ def run_pm(g, path, **kw):
 def compare_with_golden(pm, compact, order, g, close):
     for i, j in enumerate(order):
         T = lambda key: g['t%02d_%s' % (j, key)]
+        close(pm.tile_result(i, 'elev'), T('elev'), 'tile %d elev' % i)
         close(pm.tile_result(i, 'aspect'), T('aspect'), 'tile %d aspect' % i)
         close(pm.tile_result(i, 'slope'), T('slope'), 'tile %d slope' % i)
         close(pm.tile_result(i, 'uca_total'), T('uca') + T('uca_edges'), 'tile %d uca' % i)
@@ -51,4 +54,12 @@ def _close(a, b, what):
 def test_directory_flow_host_logic(name, tmp_path):
     g = load_golden(name)
     pm, compact, order = run_pm(g, str(tmp_path), processor_cls=OracleProcessor)
+    compare_with_golden(pm, compact, order, g, _close)
+
+
+@pytest.mark.parametrize('name', ['pm_fractal_2x2_ov2', 'pm_cone32_3x3_ov1'])
+def test_directory_flow_from_raw_tiles(name, tmp_path):
+    """process_elevation included: raw tiles -> fill flats -> pit drain paths -> ... like the reference."""
+    g = load_golden(name)
+    pm, compact, order = run_pm(g, str(tmp_path), from_raw=True, processor_cls=OracleProcessor)
     compare_with_golden(pm, compact, order, g, _close)
