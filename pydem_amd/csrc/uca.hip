@@ -723,6 +723,23 @@ __device__ __forceinline__ void for_each_target(const SweepArgs &A, int32_t c, F
 
 // breadth-first flood along out-edges.  MODE 0: mark cells downstream of the seeds (done = False,
 // :820-825) and prepare their delta/level; MODE 1: propagate edge_todo (:848-853)
+template <int MODE, typename Push>
+__device__ __forceinline__ void edge_flood_cell(const EdgeArgs &E, int32_t u, Push push)
+{
+    const int32_t tag = ((E.epoch + MODE) << 2) | 2;
+    for_each_target(E.G, u, [&](int32_t t) {
+        const int32_t old = atomicExch(&E.stamp[t], tag);
+        if (old == tag) return;
+        if (MODE == 0) {
+            E.G.cinfo[t] = ci_with_level(E.G.cinfo[t], CI_LEVEL_INF);
+            E.rlist[atomicAdd(E.rcount, 1)] = t;
+        } else {
+            E.edge_done[t] = 0;                                              // edge_done = ~edge_todo (:856)
+        }
+        push(t);
+    });
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void k_edge_flood(EdgeArgs E, const int32_t *__restrict__ qc, int32_t *__restrict__ qn,
                                                     int32_t *cnt3, int r)
@@ -731,21 +748,8 @@ __global__ __launch_bounds__(256) void k_edge_flood(EdgeArgs E, const int32_t *_
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt3[(r + 2) % 3] = 0;
     if (nq == 0) return;
     int32_t *cn = &cnt3[(r + 1) % 3];
-    const int32_t tag = ((E.epoch + MODE) << 2) | 2;
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
-        const int32_t u = qc[q];
-        for_each_target(E.G, u, [&](int32_t t) {
-            const int32_t old = atomicExch(&E.stamp[t], tag);
-            if (old == tag) return;
-            if (MODE == 0) {
-                E.G.cinfo[t] = ci_with_level(E.G.cinfo[t], CI_LEVEL_INF);
-                E.rlist[atomicAdd(E.rcount, 1)] = t;
-            } else {
-                E.edge_done[t] = 0;                                              // edge_done = ~edge_todo (:856)
-            }
-            qn[atomicAdd(cn, 1)] = t;
-        });
-    }
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x)
+        edge_flood_cell<MODE>(E, qc[q], [&](int32_t t) { qn[atomicAdd(cn, 1)] = t; });
 }
 
 __device__ __forceinline__ bool edge_in_set(const EdgeArgs &E, int32_t v) { return E.stamp[v] == ((E.epoch << 2) | 2); }
@@ -780,6 +784,36 @@ __device__ __forceinline__ bool edge_owns(const EdgeArgs &E, int32_t t, int32_t 
 
 // seeded sweep (drain_area with skip_edge=False on the flooded sub-graph, :836-842): round 0 =
 // seeds (their delta is the edge value itself), later rounds pull from stamped upstream cells
+template <typename Push>
+__device__ __forceinline__ void edge_sweep_cell(const EdgeArgs &E, int32_t c, int r, Push push)
+{
+    const SweepArgs &A = E.G;
+    double acc = edge_base(E, c);
+    if (r > 0) {
+        const uint32_t im = A.cinfo[c];
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            if (im & (1u << d)) {
+                const int32_t u = c + NB_DI[d] * A.m + NB_DJ[d];
+                if (!edge_in_set(E, u)) continue;
+                const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
+                const double pu = A.prop[u];
+                acc += E.delta[u] * (cardinal ? pu : 1 - pu);
+            }
+        }
+        if (im & CI_PIT_IN)
+            for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++)
+                if (edge_in_set(E, A.pin_src[e])) acc += E.delta[A.pin_src[e]] * A.pin_w[e];
+    }
+    E.delta[c] = acc;
+    for_each_target(A, c, [&](int32_t t) {
+        // seeds never receive: a done cell on the tile edge is skipped (cyutils.pyx:159-161)
+        if (edge_in_set(E, t) && ci_level(A.cinfo[t]) == 0) return;
+        uint32_t ct;
+        if (edge_owns(E, t, c, (uint32_t)r, ct)) { A.cinfo[t] = ci_with_level(ct, (uint32_t)r + 1); push(t); }
+    });
+}
+
 __global__ __launch_bounds__(256) void k_edge_sweep(EdgeArgs E, const int32_t *__restrict__ qc, int32_t *__restrict__ qn,
                                                     int32_t *cnt3, int r)
 {
@@ -787,33 +821,42 @@ __global__ __launch_bounds__(256) void k_edge_sweep(EdgeArgs E, const int32_t *_
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt3[(r + 2) % 3] = 0;
     if (nq == 0) return;
     int32_t *cn = &cnt3[(r + 1) % 3];
-    const SweepArgs &A = E.G;
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
-        const int32_t c = qc[q];
-        double acc = edge_base(E, c);
-        if (r > 0) {
-            const uint32_t im = A.cinfo[c];
-#pragma unroll
-            for (int d = 0; d < 8; d++) {
-                if (im & (1u << d)) {
-                    const int32_t u = c + NB_DI[d] * A.m + NB_DJ[d];
-                    if (!edge_in_set(E, u)) continue;
-                    const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
-                    const double pu = A.prop[u];
-                    acc += E.delta[u] * (cardinal ? pu : 1 - pu);
-                }
-            }
-            if (im & CI_PIT_IN)
-                for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++)
-                    if (edge_in_set(E, A.pin_src[e])) acc += E.delta[A.pin_src[e]] * A.pin_w[e];
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x)
+        edge_sweep_cell(E, qc[q], r, [&](int32_t t) { qn[atomicAdd(cn, 1)] = t; });
+}
+
+// Small frontiers: ONE workgroup runs round after round without going back to the host -- a
+// dependent kernel boundary costs ~1.5-5 us and the floods/sweeps downstream of an edge seed are long
+// thin chains (hundreds of rounds of a few cells).  All traffic stays inside one CU, whose L1 is
+// coherent for its own waves, so __syncthreads() is the only synchronisation needed.  The kernel
+// stops when the frontier is empty or outgrows SMALL_CAP and reports where it stopped.
+constexpr int SMALL_CAP = 4096;
+
+template <int WHICH>   // 0 reach flood, 1 seeded sweep, 2 todo flood
+__global__ __launch_bounds__(1024) void k_edge_small(EdgeArgs E, int32_t *q0, int32_t *q1, int32_t *cnt3, int r_start, int32_t *state)
+{
+    __shared__ int s_next;
+    int r = r_start;
+    int32_t nq = cnt3[r % 3];
+    while (nq > 0 && nq <= SMALL_CAP) {
+        if (threadIdx.x == 0) s_next = 0;
+        __syncthreads();
+        const int32_t *qc = (r % 2) ? q1 : q0;
+        int32_t *qn = (r % 2) ? q0 : q1;
+        for (int32_t q = threadIdx.x; q < nq; q += blockDim.x) {
+            auto push = [&](int32_t t) { qn[atomicAdd(&s_next, 1)] = t; };
+            if (WHICH == 0) edge_flood_cell<0>(E, qc[q], push);
+            else if (WHICH == 1) edge_sweep_cell(E, qc[q], r, push);
+            else edge_flood_cell<1>(E, qc[q], push);
         }
-        E.delta[c] = acc;
-        for_each_target(A, c, [&](int32_t t) {
-            // seeds never receive: a done cell on the tile edge is skipped (cyutils.pyx:159-161)
-            if (edge_in_set(E, t) && ci_level(A.cinfo[t]) == 0) return;
-            uint32_t ct;
-            if (edge_owns(E, t, c, (uint32_t)r, ct)) { A.cinfo[t] = ci_with_level(ct, (uint32_t)r + 1); qn[atomicAdd(cn, 1)] = t; }
-        });
+        __syncthreads();
+        nq = s_next;
+        r++;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        cnt3[r % 3] = nq; cnt3[(r + 1) % 3] = 0; cnt3[(r + 2) % 3] = 0;
+        state[0] = r;
     }
 }
 
@@ -1059,8 +1102,19 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
         // which: 0 reach flood, 1 seeded sweep, 2 todo flood.  Frontier of round 0 is in queue[0]/cnt3[0].
         int r = 0;
         int32_t last = first;
+        int32_t *state = t->counters + 12;
         while (last > 0) {
-            const int batch = last > 4096 ? 8 : 32;
+            if (last <= SMALL_CAP) {
+                if (which == 0) hipLaunchKernelGGL(k_edge_small<0>, dim3(1), dim3(1024), 0, t->stream, E, t->queue[0], t->queue[1], cnt3, r, state);
+                else if (which == 1) hipLaunchKernelGGL(k_edge_small<1>, dim3(1), dim3(1024), 0, t->stream, E, t->queue[0], t->queue[1], cnt3, r, state);
+                else hipLaunchKernelGGL(k_edge_small<2>, dim3(1), dim3(1024), 0, t->stream, E, t->queue[0], t->queue[1], cnt3, r, state);
+                HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipStreamSynchronize(t->stream));
+                r = t->h_counters[12];
+                last = t->h_counters[r % 3];
+                continue;
+            }
+            const int batch = last > 65536 ? 4 : 16;
             const int grid = grid_for(last, 1024);
             for (int b = 0; b < batch; b++, r++) {
                 if (which == 0) hipLaunchKernelGGL(k_edge_flood<0>, dim3(grid), dim3(256), 0, t->stream, E, t->queue[r % 2], t->queue[(r + 1) % 2], cnt3, r);
@@ -1070,7 +1124,7 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
             HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
             last = t->h_counters[r % 3];
-            if (r > (1 << 24)) { pydem_set_error("edge update did not terminate"); return -5; }
+            if (r > (int)CI_LEVEL_INF - 256) { pydem_set_error("edge update: flow paths too long"); return -5; }
         }
         return 0;
     };

@@ -411,6 +411,22 @@ class ProcessManager(object):
     def _lines(self, requests):
         return self.transport.gather_lines(requests)
 
+    # During the edge fix-up a tile's lines (uca, edge_done, edge_todo) only change when that tile runs an
+    # edge round, so they are fetched once and kept on the host; metrics refreshes then cost no device or
+    # network round trip at all.
+    def _edge_lines(self, requests):
+        missing = [r for r in requests if r not in self._edge_cache]
+        if missing:
+            # collective transports must be entered by every rank with the same request list
+            fetch = sorted(set(missing))
+            for r, v in zip(fetch, self._lines(fetch)):
+                self._edge_cache[r] = v
+        return [self._edge_cache[r] for r in requests]
+
+    def _edge_cache_drop(self, tile):
+        for key in [k for k in self._edge_cache if k[0] == tile]:
+            del self._edge_cache[key]
+
     def process_uca(self):
         """Reference :1032-1059 + worker calc_uca :94-197 (overlap-1 patch, find_flats, calc_uca)."""
         self._patch_overlap1_edges()
@@ -516,7 +532,7 @@ class ProcessManager(object):
         for i in index:
             reqs |= self._metric_requests(i)
         reqs = sorted(reqs)
-        snap = dict(zip(reqs, self._lines(reqs)))
+        snap = dict(zip(reqs, self._edge_lines(reqs)))
         for i in index:
             self._mets[i] = self._tile_metric(i, snap)
         return self._mets.copy()
@@ -524,10 +540,20 @@ class ProcessManager(object):
     def _edge_round(self, i):
         """One calc_uca_ec of the reference (:224-284) for tile i, from the neighbours' current lines."""
         reqs = sorted(self._snapshot_requests(i))
-        snap = dict(zip(reqs, self._lines(reqs)))
+        snap = dict(zip(reqs, self._edge_lines(reqs)))
+        data, done, todo = self._edge_inputs(i, snap)
+        # An edge round is a pure function of (tile state, strips).  If this tile already ran a round
+        # with exactly these strips and nothing changed since, the round would reproduce the same
+        # state (finished edge cells re-synchronised to the same values, same masks): skip it.  The
+        # reference's loop revisits tiles many times before its ranking settles (:1142-1211).
+        sig = tuple(np.asarray(v[k]).tobytes() for v in (data, done, todo) for k in SIDES)
+        if self._edge_last.get(i) == sig:
+            self.edge_rounds_skipped += 1
+            return
+        self._edge_last[i] = sig
+        self._edge_cache_drop(i)
         if not self.transport.owns(i):
             return
-        data, done, todo = self._edge_inputs(i, snap)
         dp = self.tiles[i]
         if self.keep_first_pass_uca and self.uca0[i] is None:
             self.uca0[i] = np.array(dp.uca)              # the reference keeps the first pass as 'uca'
@@ -542,41 +568,22 @@ class ProcessManager(object):
         return np.argpartition(-mets[:, mets_type], min(self.n_workers * 2, mets.shape[0] - 1))   # :1111-1113
 
     def process_uca_edges(self, mets_type=0):
-        """Cross-tile UCA correction.  Default `edge_mode='reference'` follows the reference's serial loop
-        exactly (:1109-1211, n_workers == 1): rank the tiles by the fraction of their 'todo' edge cells
-        that face a finished neighbour, run one edge round on the first, refresh the metrics of that
-        tile and its four neighbours, stop when the ranking no longer changes.  The result of that loop
-        depends on the visiting order (finished edge cells are re-synchronised with the neighbour's
-        value at every round, :806-809), so parity needs the same order; the rounds themselves are tiny
-        (KiB strips), the loop is latency-bound and is not where tiles-per-GPU parallelism pays.
-        `edge_mode='lockstep'` updates every tile with a non-zero count in the same round instead."""
+        """Cross-tile UCA correction, following the reference's serial loop exactly (:1109-1211,
+        n_workers == 1): rank the tiles by the fraction of their 'todo' edge cells that face a finished
+        neighbour, run one edge round on the first (even when its count is zero), refresh the metrics of
+        that tile and its four neighbours, stop when the ranking no longer changes.  The result depends on
+        the visiting order (finished edge cells are re-synchronised with the neighbour's value at every
+        round, :806-809), so parity needs the same order: updating all tiles with a non-zero count
+        concurrently was tried and does NOT reach the single-tile answer on the reference's own cone
+        test.  The loop is latency-bound (KiB strips, long thin floods) and serial across tiles: it is
+        the Amdahl term of the multi-GPU numbers."""
         self.tiles_shape = [tuple(int(v) for v in self.index[i, 6:]) for i in range(self.n_inputs)]
         self.edge_rounds = 0
+        self.edge_rounds_skipped = 0
         self._mets = None
-        if getattr(self, 'edge_mode', 'reference') == 'lockstep':
-            while self.edge_rounds < self.max_edge_rounds:
-                mets = self.update_uca_edge_metrics()
-                active = [i for i in range(self.n_inputs) if mets[i, 1] > 0]
-                if not active:
-                    break
-                reqs = set()
-                for i in active:
-                    reqs |= self._snapshot_requests(i)
-                reqs = sorted(reqs)
-                snap = dict(zip(reqs, self._lines(reqs)))
-                for i in active:
-                    if not self.transport.owns(i):
-                        continue
-                    data, done, todo = self._edge_inputs(i, snap)
-                    dp = self.tiles[i]
-                    if self.keep_first_pass_uca and self.uca0[i] is None:
-                        self.uca0[i] = np.array(dp.uca)
-                    if hasattr(dp, 'run_uca'):
-                        dp.run_uca(edge_init_data=[data, done, todo], uca_resident=True)
-                    else:
-                        dp.calc_uca(uca_init=dp.uca, edge_init_data=[data, done, todo])
-                self.edge_rounds += 1
-            return self.update_uca_edge_metrics()
+        self._edge_cache = {}
+        self._edge_last = {}
+        self.transport_is_collective = not type(self.transport) is EdgeTransport
         mets = self.update_uca_edge_metrics()
         I = self._rank_tiles(mets, mets_type)
         I_old = np.zeros_like(I)

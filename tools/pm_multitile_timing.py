@@ -1,0 +1,21 @@
+import sys, time, warnings
+import os; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+warnings.simplefilter('ignore')
+import bench
+from pydem_amd import process_manager
+n = int(sys.argv[1]); nt = int(sys.argv[2])
+pm = process_manager.ProcessManager(elev_source_files=bench.tile_specs(nt, n, n), elev_conditioned=True,
+                                    dem_proc_kwargs={'drain_pits': True}, devices=[0], keep_first_pass_uca=False)
+pm.compute_grid(); pm.process_elevation()
+for rep in range(2):
+    t0 = time.perf_counter(); pm.process_aspect_slope(); pm.process_uca()
+    for t in pm.tiles: t._tile.synchronize()
+    t1 = time.perf_counter(); pm.process_uca_edges(); t2 = time.perf_counter()
+    for t in pm.tiles: t.find_flats(); t.run_twi()
+    t3 = time.perf_counter()
+    print('n=%d tiles=%d: tiles %.1f ms, edge fix-up %.1f ms (%d rounds), twi %.1f ms' % (n, nt, (t1-t0)*1e3, (t2-t1)*1e3, pm.edge_rounds, (t3-t2)*1e3))
+if len(sys.argv) > 3:
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable(); pm.process_aspect_slope(); pm.process_uca(); pm.process_uca_edges(); pr.disable()
+    print('skipped rounds', pm.edge_rounds_skipped, 'of', pm.edge_rounds)
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
