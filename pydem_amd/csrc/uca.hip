@@ -262,9 +262,17 @@ __device__ __forceinline__ void stage_flush(Stage &S, int32_t *__restrict__ qn, 
 // to the next frontier and stamps level r+1.  All level-r stamps were written by the previous
 // launch, so the test reads only settled values; the in-degree counters (and their ~1.4 device
 // atomics per cell) of a textbook Kahn sweep disappear.
+__device__ __forceinline__ bool owns_target_pre(const SweepArgs &A, int32_t t, int32_t u, uint32_t r, uint32_t ct);
+
 __device__ __forceinline__ bool owns_target(const SweepArgs &A, int32_t t, int32_t u, uint32_t r, uint32_t &ct)
 {
     ct = A.cinfo[t];
+    return owns_target_pre(A, t, u, r, ct);
+}
+
+// `ct` = graph word of t, loaded by the caller (its static bits never change during a sweep)
+__device__ __forceinline__ bool owns_target_pre(const SweepArgs &A, int32_t t, int32_t u, uint32_t r, uint32_t ct)
+{
     int32_t owner = -1;
     bool ready = true;
 #pragma unroll
@@ -289,16 +297,18 @@ __device__ __forceinline__ bool owns_target(const SweepArgs &A, int32_t t, int32
 
 // after cell c (level r, graph word cw) is final: hand its ready targets to the next frontier
 __device__ __forceinline__ void release_targets(const SweepArgs &A, Stage &S, bool active, int32_t c, uint32_t cw,
-                                                uint32_t r, int32_t *__restrict__ qn, int32_t *cn)
+                                                uint32_t r, int32_t *__restrict__ qn, int32_t *cn,
+                                                int32_t t1 = -2, int32_t t2 = -2, uint32_t c1 = 0, uint32_t c2 = 0)
 {
     const int m = A.m;
     const int s = ci_section(cw);
-    int32_t t1 = -1, t2 = -1;
-    if (active && (cw & CI_OUT1)) t1 = c + fe1r(s) * m + fe1c(s);
-    if (active && (cw & CI_OUT2)) t2 = c + fe2r(s) * m + fe2c(s);
-    uint32_t c1 = 0, c2 = 0;
-    const bool r1 = t1 >= 0 && owns_target(A, t1, c, r, c1);
-    const bool r2 = t2 >= 0 && owns_target(A, t2, c, r, c2);
+    if (t1 == -2) {                     // targets and their graph words not preloaded by the caller
+        t1 = -1; t2 = -1;
+        if (active && (cw & CI_OUT1)) { t1 = c + fe1r(s) * m + fe1c(s); c1 = A.cinfo[t1]; }
+        if (active && (cw & CI_OUT2)) { t2 = c + fe2r(s) * m + fe2c(s); c2 = A.cinfo[t2]; }
+    }
+    const bool r1 = t1 >= 0 && owns_target_pre(A, t1, c, r, c1);
+    const bool r2 = t2 >= 0 && owns_target_pre(A, t2, c, r, c2);
     if (r1) A.cinfo[t1] = ci_with_level(c1, r + 1);
     if (r2) A.cinfo[t2] = ci_with_level(c2, r + 1);
     stage_push(S, r1, t1);
@@ -357,9 +367,16 @@ __device__ __forceinline__ void process_cell(const SweepArgs &A, Stage &S, bool 
                                              int32_t *__restrict__ qn, int32_t *cn)
 {
     uint32_t cw = 0;
+    int32_t t1 = -1, t2 = -1;
+    uint32_t c1 = 0, c2 = 0;
     if (active) {
         const int m = A.m;
         cw = A.cinfo[c];
+        // the long tail of the sweep is a chain of dependent memory round trips per round: start the
+        // loads that only need cw (targets' graph words) before the gather instead of after it
+        const int sct = ci_section(cw);
+        if (cw & CI_OUT1) { t1 = c + fe1r(sct) * m + fe1c(sct); c1 = A.cinfo[t1]; }
+        if (cw & CI_OUT2) { t2 = c + fe2r(sct) * m + fe2c(sct); c2 = A.cinfo[t2]; }
         const int i = c / m, j = c - i * m;
         double acc = A.a0[i];                                                   // :885, :901
         // only inlet cells on the tile edge start tainted (:909-930); interior bytes are written later
@@ -384,7 +401,7 @@ __device__ __forceinline__ void process_cell(const SweepArgs &A, Stage &S, bool 
         }
         publish_cell(A, c, cw, acc, td);
     }
-    release_targets(A, S, active, c, cw, r, qn, cn);
+    release_targets(A, S, active, c, cw, r, qn, cn, t1, t2, c1, c2);
 }
 
 // one frontier round; counters rotate over 3 slots: in = r%3, out = (r+1)%3, (r+2)%3 is cleared
@@ -465,10 +482,16 @@ __global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass,
 #pragma unroll
             for (int d = 0; d < 8; d++)
                 if ((cw & (1u << d)) && !s_state[idx + LOFF[d]]) pend++;
-            if (cw & CI_PIT_IN)                                     // pit sources must come from an earlier pass
+            if (cw & CI_PIT_IN)                                     // pit -> drain edges are short: most sources sit in this tile
                 for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++) {
-                    const uint32_t lv = ci_level(A.cinfo[A.pin_src[e]]);
-                    if (!(lv >= 1 && lv < pass)) pend += 64;        // stays blocked for the whole pass
+                    const int32_t sc = A.pin_src[e];
+                    const int si = sc / m - i0, sj = sc % m - j0;
+                    if (si >= 0 && si < TT && sj >= 0 && sj < TT) {
+                        if (!s_state[(si + 1) * HW + sj + 1]) pend++;          // released on chip when the pit finishes
+                    } else {
+                        const uint32_t lv = ci_level(A.cinfo[sc]);
+                        if (!(lv >= 1 && lv < pass)) pend += 64;               // another tile's business: blocked for this pass
+                    }
                 }
             if (pend == 0) s_list[atomicAdd(&s_n, 1)] = (uint16_t)cell;
         }
@@ -505,8 +528,16 @@ __global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass,
             }
             if (cw & CI_PIT_IN)
                 for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++) {
-                    a += A.area[A.pin_src[e]] * A.pin_w[e];
-                    td = td || (A.todo_work[A.pin_src[e]] != 0);
+                    const int32_t sc = A.pin_src[e];
+                    const int si = sc / m - i0, sj = sc % m - j0;
+                    if (si >= 0 && si < TT && sj >= 0 && sj < TT && s_state[(si + 1) * HW + sj + 1] == 2) {
+                        const double sa = s_area[si * TT + sj];               // finished in this pass: still on chip
+                        a += fabs(sa) * A.pin_w[e];
+                        td = td || (sa < 0);
+                    } else {
+                        a += A.area[sc] * A.pin_w[e];
+                        td = td || (A.todo_work[sc] != 0);
+                    }
                 }
             double ox = 0.0, oy = 0.0;
             if (cw & (CI_OUT1 | CI_OUT2)) {
@@ -530,6 +561,14 @@ __global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass,
                 if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && atomicSub(&s_pend[ti * HW + tj], 1u) == 1u)
                     s_next[atomicAdd(&s_nn, 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
             }
+            if (cw & CI_PIT_OUT)
+                for (int32_t e = pit_first(A.pit_src, A.pout_blk, c); e < A.n_pit && A.pit_src[e] == c; e++) {
+                    const int32_t dc = A.pit_dst[e];
+                    const int ti = dc / m - i0 + 1, tj = dc % m - j0 + 1;
+                    if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && !s_state[ti * HW + tj]
+                        && atomicSub(&s_pend[ti * HW + tj], 1u) == 1u)
+                        s_next[atomicAdd(&s_nn, 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
+                }
         }
         __syncthreads();
         const int nn = s_nn;
