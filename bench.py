@@ -42,7 +42,7 @@ def parse():
     ap.add_argument('--size', type=int, default=16384, help='tile edge (cells)')
     ap.add_argument('--drain-pits', type=int, default=int(os.environ.get('PYDEM_BENCH_DRAIN_PITS', '1')))
     ap.add_argument('--roof-iters', type=int, default=20)
-    ap.add_argument('--cpu-sample', type=int, default=2560, help='edge of the CPU-baseline sample tile (0 = skip)')
+    ap.add_argument('--cpu-sample', type=int, default=4096, help='edge of the CPU-baseline sample tile (0 = skip)')
     return ap.parse_args()
 
 
@@ -75,6 +75,27 @@ def cpu_baseline(size, seed, drain_pits):
             "sample": "one %dx%d fp64 fractal tile (seed %d), full path, %.1f s, single thread "
                       "(the reference is single-threaded per tile); host has %d cores"
                       % (size, size, seed, dt, os.cpu_count())}
+
+
+def pmc_traffic(kernel, size):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*pmc*.csv:
+    separate FETCH_SIZE / WRITE_SIZE runs of this same command at 16384^2).  FETCH_SIZE counts half of
+    the bytes of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section; calibrated on k_twi
+    in profiles/README.md), so bytes = (2 * FETCH_KiB + WRITE_KiB) * 1024.  None when no profile of
+    this tile size is present (PMC counters cannot be read from inside the timed process)."""
+    import csv
+    import glob
+    if size != 16384:
+        return None
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_fetch_write_16384*.csv'))):
+        vals = {}
+        for row in csv.DictReader(open(fn)):
+            if kernel in row['kernel']:
+                vals[row['counter']] = float(row['mean_per_dispatch_KB'])
+        if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
+            best = (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0
+    return best
 
 
 def tile_specs(world, n, m, px=30.0):
@@ -177,7 +198,8 @@ def main():
                        "tile": [n, m], "tiles_per_gpu": 1, "parallelism": "tile-per-gpu x%d" % world,
                        "edge_exchange": exchange},
             "roofline": {"bound": "hbm", "kernel": "k_stencil_march", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_stencil_march", n),
+                         "algorithmic_bytes": STENCIL_BYTES_PER_CELL * cells,
                          "avg_kernel_ms": st_ms, "algorithmic_bytes_per_cell": STENCIL_BYTES_PER_CELL},
             "end_to_end_GBs": E2E_BYTES_PER_CELL * world * cells * args.steps / dt / 1e9,
             "stages_ms": dict({k: tm[k] for k in ('slopes_directions_ms', 'stencil_kernel_ms', 'flats_ms', 'graph_ms',
