@@ -138,6 +138,18 @@ int pydem_tile_restore_pit_slopes(pydem_tile *t);
  * tile's stream. */
 int pydem_bench_stencil(pydem_tile *t, int iters, double *avg_ms);
 
+/* ---- the reference's own native boundary, on a generic scipy CSC/CSR graph ----------------------
+ * Same arguments and in-place behaviour as the Cython functions (host arrays in, updated in place):
+ *   pydem_drain_area         cyutils.drain_area        pydem/cyfuncs/cyutils.pyx:78-116 (loop :119-187)
+ *   pydem_drain_connections  cyutils.drain_connections pydem/cyfuncs/cyutils.pyx:35-46  (loop :49-72)
+ * edge_todo / edge_todo_no_mask may be NULL.  The DEMProcessor entry points above do not use these
+ * (they never materialise the matrix); they exist so code written against cyutils keeps working. */
+int pydem_drain_area(double *area, uint8_t *done, uint8_t *ids, const int32_t *col_indptr, const int32_t *col_indices,
+                     const double *col_data, const int32_t *row_indptr, const int32_t *row_indices, int64_t n_rows,
+                     int64_t n_cols, double *edge_todo, double *edge_todo_no_mask, int skip_edge, int device);
+int pydem_drain_connections(uint8_t *arr, uint8_t *ids, const int32_t *indptr, const int32_t *indices, int64_t n,
+                            uint8_t set_to, int device);
+
 /* ---- RCCL transport for the edge strips of the directory flow -------------------------------
  * Replaces the shared zarr store the reference's workers exchange strips through
  * (pydem/process_manager.py:243-255, write-verify-retry :362-381).  One communicator per process

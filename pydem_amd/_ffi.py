@@ -70,6 +70,8 @@ SYMBOLS = {
     'pydem_tile_pit_edges': (C.c_int, [_P, C.POINTER(C.c_int64), _P, _P, _P]),
     'pydem_tile_restore_pit_slopes': (C.c_int, [_P]),
     'pydem_bench_stencil': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
+    'pydem_drain_area': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, _P, _P, C.c_int, C.c_int]),
+    'pydem_drain_connections': (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_uint8, C.c_int]),
     'pydem_comm_unique_id': (C.c_int, [C.c_char_p]),
     'pydem_comm_create': (C.c_int, [C.c_int, C.c_int, C.c_char_p, C.c_int, _PP]),
     'pydem_comm_destroy': (C.c_int, [_P]),
