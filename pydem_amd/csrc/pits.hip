@@ -14,6 +14,8 @@
 #include <hipcub/hipcub.hpp>
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -94,6 +96,8 @@ struct PitParams {
     int32_t *out_count;         // [0] edges, [1] pits without drain, [2] overflow pits, [3] capacity errors
     int32_t out_cap;
     int32_t *overflow_list;     // pits to re-run with the large window
+    int32_t *lane_overflow;     // pits the lane version hands to the wavefront version (count: out_count[4])
+    int32_t *dbg;               // PYDEM_PITS_DEBUG=2: per-pit {rounds, last border size, hand-over reason, drains}
 };
 
 // group = the threads that own one pit: a wavefront (NT = 64) or a whole workgroup (NT = 256)
@@ -194,6 +198,84 @@ __device__ void finish_pit(const PitParams &P, int32_t pit, int ipit, int jpit, 
             }
         } else atomicAdd(&P.out_count[3], 1);
         chunk_base += nd; chunk_left -= nd;
+        P.mag[pit] = ssum / (double)nd;                                      // np.mean(s) :1370
+        P.flats[pit] = 0;                                                    // :1371
+    }
+}
+
+// Wavefront version of finish_pit: lane t owns drain t (at most 64 drains, slices of at most 63 rows,
+// so every numpy sum is a single pairwise leaf).  Filters compact with ballots (order preserved),
+// the distance / slope arithmetic of the drains runs in parallel, and only the numpy-ordered sum of
+// the slopes is serial.  chunk_base / chunk_left stay wave-uniform.
+__device__ __forceinline__ void finish_pit_wave(const PitParams &P, int32_t pit, int ipit, int jpit, double epit, int ndrain,
+                                                int32_t *dlist, double *dxy, double *sv, int32_t &chunk_base,
+                                                int32_t &chunk_left, int lane)
+{
+    const int n = P.n, m = P.m;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int nd = ndrain;
+    bool live = lane < nd;
+    int32_t cell = live ? dlist[lane] : 0;
+    if (P.max_dist) {                                                        // :1335-1343
+        if (live) {
+            const int di = ipit - cell / m, dj = jpit - cell % m;
+            live = sqrt((double)(di * di + dj * dj)) <= (double)P.max_dist;
+        }
+        const unsigned long long bal = __ballot(live);
+        __builtin_amdgcn_wave_barrier();
+        if (live) dlist[__popcll(bal & lt)] = cell;
+        nd = __popcll(bal);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        live = lane < nd;
+        cell = live ? dlist[lane] : 0;
+    }
+    double d = 0.0;
+    if (live) {                                                              // :1346-1349
+        const int ndX = n - 1;
+        const int idr = cell / m, jdr = cell % m;
+        const int a = ipit < idr ? ipit : idr, b = ipit < idr ? idr : ipit;
+        double dxm;
+        if (ipit == idr) dxm = P.dX[ipit < ndX - 1 ? ipit : ndX - 1];        // _get_dX_mean :1994-1995
+        else dxm = np_pairwise_leaf(P.dX + a, b - a) / (double)(b - a);      // .mean() :1997
+        const double dx = dxm * (double)(jpit - jdr);
+        const double dy = np_pairwise_leaf(P.dY + a, b - a);
+        d = sqrt(dx * dx + dy * dy);
+    }
+    if (!isnan(P.max_dist_XY) && P.max_dist_XY != 0) {                       // :1352-1358
+        const bool keep = live && d <= P.max_dist_XY;
+        const unsigned long long bal = __ballot(keep);
+        __builtin_amdgcn_wave_barrier();
+        if (keep) { const int k = __popcll(bal & lt); dlist[k] = cell; dxy[k] = d; }
+        nd = __popcll(bal);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        live = lane < nd;
+        cell = live ? dlist[lane] : 0;
+        d = live ? dxy[lane] : 0.0;
+    }
+    if (nd == 0) { if (lane == 0) atomicAdd(&P.out_count[1], 1); return; }
+    double s = 0.0;
+    if (live) { s = fabs(epit - P.elev[cell]) / d; sv[lane] = s; }           // :1361
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double ssum = 0.0;
+    if (lane == 0) ssum = np_pairwise_leaf(sv, nd);
+    ssum = __shfl(ssum, 0);
+    if (nd > chunk_left) {                                                   // see finish_pit
+        const int32_t grab = nd > OUT_CHUNK ? nd : OUT_CHUNK;
+        int32_t g = 0;
+        if (lane == 0) g = atomicAdd(&P.out_count[0], grab);
+        chunk_base = __shfl(g, 0);
+        chunk_left = grab;
+    }
+    if (chunk_base + nd <= P.out_cap) {
+        if (live) {                                                          // :1365-1367
+            P.out_src[chunk_base + lane] = pit; P.out_dst[chunk_base + lane] = cell; P.out_w[chunk_base + lane] = s / ssum;
+        }
+    } else if (lane == 0) atomicAdd(&P.out_count[3], 1);
+    chunk_base += nd; chunk_left -= nd;
+    if (lane == 0) {
         P.mag[pit] = ssum / (double)nd;                                      // np.mean(s) :1370
         P.flats[pit] = 0;                                                    // :1371
     }
@@ -367,15 +449,29 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wavefront version (the common case: 99.9 % of the pits).  Same algorithm as solve_pit, but every
-// round first compacts the border bitmap into an ordered list so that each lane owns ONE border cell:
-// the elevation / pit-mask loads of a round are issued in parallel (one memory latency per round
-// instead of one per border cell per lane), minima are shuffle reductions, drains are collected with
-// ballots (list order = ascending cell id, the order of the reference's setdiff1d).
+// Wavefront version (second pass: the ~10 % of the pits the lane version hands over; they average
+// 66 rounds with borders of 50-250 cells).  The border is an incremental, unordered LIST in LDS
+// (elevation, window position, pit flag): a round is one strided scan for the minimum, a ballot
+// that takes the cells equal to it out of the list, and one 64-lane step per 8 promoted cells that
+// tests their 8 neighbours against the region|border bitmap (LDS atomicOr: exactly one lane wins a
+// new cell), loads the new elevations in parallel and appends them with a ballot rank.  As in the
+// lane version the drain tests are evaluated when a cell enters the border.  Promoted slots stay
+// behind as holes and are squeezed out when the list runs short.  Window 128x128 cells; pits that
+// leave it (or exceed the list / drain capacity) go to the workgroup version.
 // ---------------------------------------------------------------------------------------------
-constexpr int WV = 64;            // window edge: lane l owns window row l (two 32-bit words)
-constexpr int WV_LCAP = 256;      // border list capacity
+constexpr int W2 = 128;           // window edge (positions fit 14 bits; 0xFFFF marks a hole)
+constexpr int W2_CAP = 512;       // border list capacity
 constexpr int WV_MAXD = 64;       // drain list capacity
+
+struct WaveLds {
+    uint32_t seen[W2 * W2 / 32];
+    double le[W2_CAP];
+    uint16_t lpos[W2_CAP];
+    uint8_t lpm[W2_CAP];
+    uint16_t pq[64];
+    int32_t dl[WV_MAXD];
+    double dxy[WV_MAXD], sv[WV_MAXD];
+};
 
 __device__ __forceinline__ double wave_min(double v)
 {
@@ -388,157 +484,385 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, uint32_t *region, uint32_t *border,
-                               uint16_t *blist, double *be, uint8_t *bp, int32_t *dlist, double *dxy, double *sv, int *flag,
-                               int32_t &chunk_base, int32_t &chunk_left, PwFrame *stk)
+__device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLds &L, int32_t &chunk_base, int32_t &chunk_left)
 {
     const int n = P.n, m = P.m;
     const int ipit = pit / m, jpit = pit - ipit * m;
-    int r0 = ipit - WV / 2, c0 = jpit - WV / 2;
-    if (r0 > n - WV) r0 = n - WV;
-    if (c0 > m - WV) c0 = m - WV;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int r0 = ipit - W2 / 2, c0 = jpit - W2 / 2;
+    if (r0 > n - W2) r0 = n - W2;
+    if (c0 > m - W2) c0 = m - W2;
     if (r0 < 0) r0 = 0;
     if (c0 < 0) c0 = 0;
-    region[2 * lane] = 0; region[2 * lane + 1] = 0; border[2 * lane] = 0; border[2 * lane + 1] = 0;
-    if (lane == 0) flag[0] = 0;
-    wave_sync();
+    for (int w = lane; w < W2 * W2 / 32; w += 64) L.seen[w] = 0;
     const double epit = P.elev[pit];
-    if (lane == 0) {                                                             // pit_area = [pit], border = its neighbours (:1289-1292)
-        const int wr = ipit - r0, wc = jpit - c0;
-        region[wr * 2 + (wc >> 5)] |= 1u << (wc & 31);
-        for (int di = -1; di <= 1; di++)
-            for (int dj = -1; dj <= 1; dj++) {
-                if (!di && !dj) continue;
-                const int ii = ipit + di, jj = jpit + dj;
-                if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
-                const int r = ii - r0, c = jj - c0;
-                if (r < 0 || r >= WV || c < 0 || c >= WV) { flag[0] = 1; continue; }
-                border[r * 2 + (c >> 5)] |= 1u << (c & 31);
-            }
-    }
-    wave_sync();
     double epit_border = epit;
-    int ndrain = -1;
-    for (int it = 0; it < P.max_iter; it++) {                                    // :1300
-        if (flag[0]) break;
-        // ---- ordered list of the border cells
-        const uint32_t w0 = border[2 * lane], w1 = border[2 * lane + 1];
-        const int cnt = __popc(w0) + __popc(w1);
-        int incl = cnt;
-        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
-        const int tot = __shfl(incl, 63);
-        if (tot == 0) break;                                                     // :1304-1305
-        if (tot > WV_LCAP) { if (lane == 0) flag[0] = 1; wave_sync(); break; }
-        {
-            int pos = incl - cnt;
-            uint32_t b = w0;
-            while (b) { const int k = __ffs((int)b) - 1; b &= b - 1; blist[pos++] = (uint16_t)(lane * 64 + k); }
-            b = w1;
-            while (b) { const int k = __ffs((int)b) - 1; b &= b - 1; blist[pos++] = (uint16_t)(lane * 64 + 32 + k); }
-        }
-        wave_sync();
-        // ---- one parallel load per border cell, then the three minima
-        double mn = INFINITY, mn_np = INFINITY, mn_p = INFINITY;
-        for (int base = 0; base < tot; base += 64) {
-            const int k = base + lane;
-            if (k < tot) {
-                const int pos = blist[k];
-                const int64_t cell = (int64_t)(r0 + (pos >> 6)) * m + (c0 + (pos & 63));
-                const double e = P.elev[cell];
-                const uint8_t pm = P.pitmask[cell];
-                be[k] = e; bp[k] = pm;
-                mn = fmin(mn, e);
-                if (pm) mn_p = fmin(mn_p, e); else mn_np = fmin(mn_np, e);
-            }
-        }
-        mn = wave_min(mn); mn_np = wave_min(mn_np); mn_p = wave_min(mn_p);
-        if (it == 0 && P.min_border) epit_border = mn;                           // :1294-1295 (first border)
-        int mode = 0;
-        if (mn_np < epit_border) mode = 1;                                       // :1312-1316
-        else if (mn_p < epit) mode = 2;                                          // :1317-1320
-        wave_sync();
-        if (mode) {
-            int nd = 0;
-            for (int base = 0; base < tot; base += 64) {
-                const int k = base + lane;
-                bool pred = false;
-                int32_t cell = 0;
-                if (k < tot) {
-                    const int pos = blist[k];
-                    cell = (int32_t)((int64_t)(r0 + (pos >> 6)) * m + (c0 + (pos & 63)));
-                    pred = mode == 1 ? (!bp[k] && be[k] < epit_border) : (bp[k] && be[k] < epit);
-                }
-                const unsigned long long bal = __ballot(pred);
-                const int rank = nd + __popcll(bal & ((1ull << lane) - 1ull));
-                if (pred && rank < WV_MAXD) dlist[rank] = cell;
-                nd += __popcll(bal);
-            }
-            if (nd > WV_MAXD) { if (lane == 0) flag[0] = 1; wave_sync(); break; }
-            ndrain = nd;
-            wave_sync();
-            break;
-        }
-        // ---- grow: pit_area += border[eborder == emin] (:1322-1323)
-        for (int base = 0; base < tot; base += 64) {
-            const int k = base + lane;
-            if (k < tot && be[k] == mn) {
-                const int pos = blist[k];
-                const int ww = (pos >> 6) * 2 + ((pos & 63) >> 5);
-                const uint32_t bit = 1u << (pos & 31);
-                atomicOr(&region[ww], bit);
-                atomicAnd(&border[ww], ~bit);
-            }
-        }
-        wave_sync();
-        for (int base = 0; base < tot; base += 64) {
-            const int k = base + lane;
-            if (k < tot && be[k] == mn) {
-                const int pos = blist[k];
-                const int r = pos >> 6, c = pos & 63;
-                for (int di = -1; di <= 1; di++)
-                    for (int dj = -1; dj <= 1; dj++) {
-                        if (!di && !dj) continue;
-                        const int ii = r0 + r + di, jj = c0 + c + dj;
-                        if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
-                        const int rr = r + di, cc = c + dj;
-                        if (rr < 0 || rr >= WV || cc < 0 || cc >= WV) { flag[0] = 1; continue; }
-                        const int ww = rr * 2 + (cc >> 5);
-                        const uint32_t bit = 1u << (cc & 31);
-                        if (!((region[ww] | border[ww]) & bit)) atomicOr(&border[ww], bit);
+    int nb = 0, n_alive = 0;        // list end / live entries (wave-uniform)
+    bool has_np = false, has_p = false;
+    int over = 0;                   // 1: left the window, 2: list capacity, 3: drain capacity
+    // the unseen neighbours of the nq cells in L.pq join the border
+    auto expand = [&](int nq) {
+        for (int base = 0; base < nq * 8; base += 64) {
+            const int idx = base + lane;
+            bool isnew = false, out = false;
+            double e = 0.0; uint8_t pm = 0; int npos = 0;
+            if (idx < nq * 8) {
+                const int pos = L.pq[idx >> 3], d = idx & 7;
+                const int di = d < 3 ? -1 : (d < 5 ? 0 : 1);
+                const int dj = d < 3 ? d - 1 : (d == 3 ? -1 : (d == 4 ? 1 : d - 6));
+                const int r = pos / W2, c = pos % W2;
+                const int ii = r0 + r + di, jj = c0 + c + dj;
+                if (ii >= 0 && ii < n && jj >= 0 && jj < m) {
+                    const int rr = r + di, cc = c + dj;
+                    if (rr < 0 || rr >= W2 || cc < 0 || cc >= W2) out = true;
+                    else {
+                        npos = rr * W2 + cc;
+                        const uint32_t bit = 1u << (npos & 31);
+                        const uint32_t old = atomicOr(&L.seen[npos >> 5], bit);
+                        if (!(old & bit)) {
+                            isnew = true;
+                            const int64_t cell = (int64_t)ii * m + jj;
+                            e = P.elev[cell]; pm = P.pitmask[cell];
+                        }
                     }
+                }
             }
+            if (__ballot(out)) over = 1;
+            const unsigned long long bal = __ballot(isnew);
+            const int cnt = __popcll(bal);
+            if (nb + cnt > W2_CAP) { over = 2; break; }
+            if (isnew) { const int k = nb + __popcll(bal & lt); L.le[k] = e; L.lpos[k] = (uint16_t)npos; L.lpm[k] = pm; }
+            if (__ballot(isnew && pm && e < epit)) has_p = true;
+            if (__ballot(isnew && !pm && e < epit_border)) has_np = true;
+            nb += cnt; n_alive += cnt;
         }
         wave_sync();
+    };
+    if (lane == 0) {                                                             // pit_area = [pit] (:1289-1292)
+        const int pos = (ipit - r0) * W2 + (jpit - c0);
+        L.seen[pos >> 5] = 1u << (pos & 31);
+        L.pq[0] = (uint16_t)pos;
     }
     wave_sync();
-    if (flag[0]) {                                                               // hand over to the large-window pass
+    expand(1);
+    if (P.min_border) {                                                          // :1294-1295
+        double mn = INFINITY;
+        for (int k = lane; k < nb; k += 64) mn = fmin(mn, L.le[k]);
+        mn = wave_min(mn);
+        if (nb) epit_border = mn;
+        has_np = false;                                                          // nothing is below the minimum
+    }
+    int mode = 0, ndrain = -1, it_used = 0;
+    for (int it = 0; it < P.max_iter; it++) {                                    // :1300
+        if (over) break;
+        if (n_alive == 0) break;                                                 // :1304-1305
+        if (has_np) { mode = 1; break; }                                         // :1312-1316
+        if (has_p) { mode = 2; break; }                                          // :1317-1320
+        it_used = it + 1;
+        if (nb > W2_CAP - 128 && n_alive < nb) {                                 // squeeze the holes out
+            int wr = 0;
+            for (int base = 0; base < nb; base += 64) {
+                const int k = base + lane;
+                const bool alive = k < nb && L.lpos[k] != 0xFFFF;
+                const double e = alive ? L.le[k] : 0.0;
+                const uint16_t ps = alive ? L.lpos[k] : (uint16_t)0;
+                const uint8_t pm = alive ? L.lpm[k] : (uint8_t)0;
+                const unsigned long long bal = __ballot(alive);
+                wave_sync();
+                if (alive) { const int d = wr + __popcll(bal & lt); L.le[d] = e; L.lpos[d] = ps; L.lpm[d] = pm; }
+                wr += __popcll(bal);
+                wave_sync();
+            }
+            nb = wr;
+        }
+        double mn = INFINITY;
+        for (int k = lane; k < nb; k += 64) mn = fmin(mn, L.le[k]);
+        mn = wave_min(mn);
+        // pit_area += border[eborder == emin] (:1322-1323); cells appended below sit beyond nb0
+        const int nb0 = nb;
+        for (int base = 0; base < nb0; base += 64) {
+            const int k = base + lane;
+            const bool match = k < nb0 && L.le[k] == mn && L.lpos[k] != 0xFFFF;
+            const unsigned long long bal = __ballot(match);
+            if (!bal) continue;
+            if (match) { L.pq[__popcll(bal & lt)] = L.lpos[k]; L.le[k] = INFINITY; L.lpos[k] = 0xFFFF; }
+            const int nq = __popcll(bal);
+            n_alive -= nq;
+            wave_sync();
+            expand(nq);
+            if (over) break;
+        }
+    }
+    if (!over && mode) {
+        // drains: ballot-compacted, then rank-sorted into ascending cell order (the order of setdiff1d)
+        int nd = 0;
+        for (int base = 0; base < nb; base += 64) {
+            const int k = base + lane;
+            bool pred = false;
+            int32_t cell = 0;
+            if (k < nb && L.lpos[k] != 0xFFFF) {
+                const int pos = L.lpos[k];
+                const double e = L.le[k];
+                pred = mode == 1 ? (!L.lpm[k] && e < epit_border) : (L.lpm[k] && e < epit);
+                cell = (int32_t)((int64_t)(r0 + pos / W2) * m + (c0 + pos % W2));
+            }
+            const unsigned long long bal = __ballot(pred);
+            const int rank = nd + __popcll(bal & lt);
+            if (pred && rank < WV_MAXD) L.dl[rank] = cell;
+            nd += __popcll(bal);
+        }
+        if (nd > WV_MAXD) over = 3;
+        else {
+            wave_sync();
+            const int32_t key = lane < nd ? L.dl[lane] : INT32_MAX;
+            int rank = 0;
+            for (int t = 0; t < nd; t++) rank += L.dl[t] < key;
+            wave_sync();
+            if (lane < nd) L.dl[rank] = key;
+            wave_sync();
+            ndrain = nd;
+        }
+    }
+    if (lane == 0 && P.dbg) {                                                    // statistics (debug only)
+        const int idx = atomicAdd(&P.out_count[6], 1);
+        P.dbg[4 * idx] = it_used; P.dbg[4 * idx + 1] = n_alive; P.dbg[4 * idx + 2] = over; P.dbg[4 * idx + 3] = ndrain;
+    }
+    if (over) {                                                                  // hand over to the large-window pass
         if (lane == 0) P.overflow_list[atomicAdd(&P.out_count[2], 1)] = pit;
         return;
     }
     if (ndrain < 0) { if (lane == 0) atomicAdd(&P.out_count[1], 1); return; }    // :1327-1329
-    if (lane == 0) finish_pit(P, pit, ipit, jpit, epit, ndrain, dlist, dxy, sv, chunk_base, chunk_left, stk);
+    finish_pit_wave(P, pit, ipit, jpit, epit, ndrain, L.dl, L.dxy, L.sv, chunk_base, chunk_left, lane);
 }
 
-constexpr int W_SMALL = 64, MAXD_SMALL = 64;
+
+// ---------------------------------------------------------------------------------------------
+// Lane version (first pass over ALL pits).  The wavefront version spends ~700 VALU issues per round
+// with 64 lanes serving a border of ~10-20 cells, so it is instruction-bound with most lanes idle.
+// Here every LANE owns one pit: the border is an unordered list (elevation + window position) in
+// LDS, region|border membership is a 16x16-cell bitmap in LDS, and the per-round work is a scan of
+// the list for the minimum plus the 8 neighbours of each promoted cell.  The drain test of the
+// reference ("any non-pit border cell below the pit / any pit cell below the pit", :1312-1320) uses
+// fixed thresholds, so it is evaluated once per cell when the cell ENTERS the border.  Lanes
+// reconverge after their pit; output slots are then allocated with ONE atomic per wavefront
+// (exact prefix sum of the drain counts: no holes).  Pits that leave the window or the list
+// capacity go to the wavefront version.
+// ---------------------------------------------------------------------------------------------
+constexpr int LN_W = 16;          // window edge
+constexpr int LN_B = 32;          // border list capacity (one bit per slot in a 32-bit register)
+constexpr int LN_T = 128;         // threads (= pits) per workgroup
+
+__device__ __forceinline__ double np_pairwise_leaf_strided(const double *a, int stride, int n)
+{
+    if (n < 8) {
+        double res = 0.;
+        for (int i = 0; i < n; i++) res += a[i * stride];
+        return res;
+    }
+    double r0 = a[0], r1 = a[stride], r2 = a[2 * stride], r3 = a[3 * stride], r4 = a[4 * stride], r5 = a[5 * stride],
+           r6 = a[6 * stride], r7 = a[7 * stride];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i * stride]; r1 += a[(i + 1) * stride]; r2 += a[(i + 2) * stride]; r3 += a[(i + 3) * stride];
+        r4 += a[(i + 4) * stride]; r5 += a[(i + 5) * stride]; r6 += a[(i + 6) * stride]; r7 += a[(i + 7) * stride];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i * stride];
+    return res;
+}
+
+__global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits)
+{
+    __shared__ double s_e[LN_B * LN_T];          // [slot][lane]: border elevations, later the drain slopes
+    __shared__ uint8_t s_p[LN_B * LN_T];         // [slot][lane]: window position r*16+c
+    __shared__ uint8_t s_q[LN_B * LN_T];         // [slot][lane]: cells promoted in the current round
+    __shared__ uint32_t s_seen[8 * LN_T];        // [word][lane]: region | border bitmap of the window
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = P.n, m = P.m;
+    const int32_t np = *npits;
+    double *const le = s_e + tid;
+    uint8_t *const lp = s_p + tid, *const lq = s_q + tid;
+    uint32_t *const seen = s_seen + tid;
+    for (int32_t base = blockIdx.x * LN_T; base < np; base += gridDim.x * LN_T) {
+        const int32_t q = base + tid;
+        int nd = 0;                 // drains of this lane's pit, sorted, in slots [0, nd)
+        int status = 0;             // 1: drained, 2: no drain, 3: hand over to the wavefront version
+        int32_t pit = 0;
+        int r0 = 0, c0 = 0;
+        double ssum = 0.0;
+        if (q < np) {
+            pit = pits[q];
+            const int ipit = pit / m, jpit = pit - ipit * m;
+            r0 = ipit - LN_W / 2; c0 = jpit - LN_W / 2;
+            if (r0 > n - LN_W) r0 = n - LN_W;
+            if (c0 > m - LN_W) c0 = m - LN_W;
+            if (r0 < 0) r0 = 0;
+            if (c0 < 0) c0 = 0;
+#pragma unroll
+            for (int w = 0; w < 8; w++) seen[w * LN_T] = 0;
+            const double epit = P.elev[pit];
+            double epit_border = epit;
+            int nb = 0;
+            uint32_t pitbits = 0;
+            bool has_np = false, has_p = false, over = false;
+            // add the unseen neighbours of window cell (r, c) to the border
+            auto add_neighbours = [&](int r, int c) {
+                double e8[8]; uint8_t pm8[8]; int pos8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int di = k < 3 ? -1 : (k < 5 ? 0 : 1);
+                    const int dj = k < 3 ? k - 1 : (k == 3 ? -1 : (k == 4 ? 1 : k - 6));
+                    const int ii = r0 + r + di, jj = c0 + c + dj;
+                    const int rr = r + di, cc = c + dj;
+                    pos8[k] = -1; e8[k] = 0.0; pm8[k] = 0;
+                    if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+                    if (rr < 0 || rr >= LN_W || cc < 0 || cc >= LN_W) { over = true; continue; }
+                    const int pos = rr * LN_W + cc;
+                    const uint32_t bit = 1u << (pos & 31);
+                    const uint32_t wd = seen[(pos >> 5) * LN_T];
+                    if (wd & bit) continue;
+                    seen[(pos >> 5) * LN_T] = wd | bit;
+                    const int64_t cell = (int64_t)ii * m + jj;
+                    e8[k] = P.elev[cell]; pm8[k] = P.pitmask[cell];
+                    pos8[k] = pos;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (pos8[k] < 0) continue;
+                    if (nb == LN_B) { over = true; continue; }
+                    le[nb * LN_T] = e8[k]; lp[nb * LN_T] = (uint8_t)pos8[k];
+                    if (pm8[k]) { pitbits |= 1u << nb; if (e8[k] < epit) has_p = true; }
+                    else { pitbits &= ~(1u << nb); if (e8[k] < epit_border) has_np = true; }
+                    nb++;
+                }
+            };
+            {                                                                    // pit_area = [pit] (:1289-1292)
+                const int pos = (ipit - r0) * LN_W + (jpit - c0);
+                seen[(pos >> 5) * LN_T] = 1u << (pos & 31);
+                add_neighbours(ipit - r0, jpit - c0);
+            }
+            if (P.min_border) {                                                  // :1294-1295
+                double mn = INFINITY;
+                for (int k = 0; k < nb; k++) mn = fmin(mn, le[k * LN_T]);
+                if (nb) epit_border = mn;
+                has_np = false;                                                  // nothing is below the minimum
+            }
+            int mode = 0;
+            status = 2;
+            for (int it = 0; it < P.max_iter; it++) {                            // :1300
+                if (over) break;
+                if (nb == 0) break;                                              // :1304-1305
+                if (has_np) { mode = 1; break; }                                 // :1312-1316
+                if (has_p) { mode = 2; break; }                                  // :1317-1320
+                double mn = INFINITY;
+                for (int k = 0; k < nb; k++) mn = fmin(mn, le[k * LN_T]);
+                // pit_area += border[eborder == emin] (:1322-1323): take them out of the list first ...
+                int nq = 0;
+                for (int k = 0; k < nb;) {
+                    if (le[k * LN_T] == mn) {
+                        lq[nq * LN_T] = lp[k * LN_T]; nq++;
+                        nb--;
+                        le[k * LN_T] = le[nb * LN_T]; lp[k * LN_T] = lp[nb * LN_T];
+                        pitbits = (pitbits & ~(1u << k)) | (((pitbits >> nb) & 1u) << k);
+                    } else k++;
+                }
+                // ... then the new border cells around them
+                for (int j = 0; j < nq; j++) { const int pos = lq[j * LN_T]; add_neighbours(pos >> 4, pos & 15); }
+            }
+            if (over) status = 3;
+            else if (mode) {
+                // drains to the front of the list in ascending cell order (window order == cell order)
+                for (;;) {
+                    int best = -1, bestpos = 256;
+                    for (int k = nd; k < nb; k++) {
+                        const bool isp = (pitbits >> k) & 1u;
+                        const double e = le[k * LN_T];
+                        const bool match = mode == 1 ? (!isp && e < epit_border) : (isp && e < epit);
+                        const int pos = lp[k * LN_T];
+                        if (match && pos < bestpos) { best = k; bestpos = pos; }
+                    }
+                    if (best < 0) break;
+                    const double eb = le[best * LN_T];
+                    const uint32_t bb = (pitbits >> best) & 1u, bn = (pitbits >> nd) & 1u;
+                    le[best * LN_T] = le[nd * LN_T]; lp[best * LN_T] = lp[nd * LN_T];
+                    le[nd * LN_T] = eb; lp[nd * LN_T] = (uint8_t)bestpos;
+                    pitbits = (pitbits & ~((1u << best) | (1u << nd))) | (bn << best) | (bb << nd);
+                    nd++;
+                }
+                // filters and slopes (see finish_pit; every slice is shorter than 16 rows)
+                const int ndX = n - 1;
+                const bool xy = !isnan(P.max_dist_XY) && P.max_dist_XY != 0;
+                int keep = 0;
+                for (int t = 0; t < nd; t++) {
+                    const int pos = lp[t * LN_T];
+                    const int idr = r0 + (pos >> 4), jdr = c0 + (pos & 15);
+                    if (P.max_dist) {                                            // :1335-1343
+                        const int di = ipit - idr, dj = jpit - jdr;
+                        if (!(sqrt((double)(di * di + dj * dj)) <= (double)P.max_dist)) continue;
+                    }
+                    const int a = ipit < idr ? ipit : idr, b = ipit < idr ? idr : ipit;
+                    double dxm;
+                    if (ipit == idr) dxm = P.dX[ipit < ndX - 1 ? ipit : ndX - 1];    // _get_dX_mean :1994-1995
+                    else dxm = np_pairwise_leaf(P.dX + a, b - a) / (double)(b - a);  // .mean() :1997
+                    const double dx = dxm * (double)(jpit - jdr);
+                    const double dy = np_pairwise_leaf(P.dY + a, b - a);
+                    const double d = sqrt(dx * dx + dy * dy);
+                    if (xy && !(d <= P.max_dist_XY)) continue;                   // :1352-1358
+                    le[keep * LN_T] = fabs(epit - le[t * LN_T]) / d;             // :1361
+                    lp[keep * LN_T] = (uint8_t)pos;
+                    keep++;
+                }
+                nd = keep;
+                if (nd > 0) {
+                    ssum = np_pairwise_leaf_strided(le, LN_T, nd);
+                    P.mag[pit] = ssum / (double)nd;                              // np.mean(s) :1370
+                    P.flats[pit] = 0;                                            // :1371
+                    status = 1;
+                }
+            }
+        }
+        // ---- lanes are convergent again: one slot allocation / counter update per wavefront
+        int incl = nd;
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+        const int tot = __shfl(incl, 63);
+        int32_t wbase = 0;
+        if (lane == 0 && tot) wbase = atomicAdd(&P.out_count[0], tot);
+        wbase = __shfl(wbase, 0);
+        if (tot) {
+            if ((int64_t)wbase + tot <= P.out_cap) {
+                const int32_t o = wbase + incl - nd;
+                for (int t = 0; t < nd; t++) {                                   // :1365-1367
+                    const int pos = lp[t * LN_T];
+                    P.out_src[o + t] = pit;
+                    P.out_dst[o + t] = (int32_t)((int64_t)(r0 + (pos >> 4)) * m + (c0 + (pos & 15)));
+                    P.out_w[o + t] = le[t * LN_T] / ssum;
+                }
+            } else if (lane == 0) atomicAdd(&P.out_count[3], 1);
+        }
+        const unsigned long long b_un = __ballot(status == 2), b_ov = __ballot(status == 3);
+        if (lane == 0 && b_un) atomicAdd(&P.out_count[1], __popcll(b_un));       // :1327-1329
+        if (b_ov) {
+            int32_t obase = 0;
+            if (lane == 0) obase = atomicAdd(&P.out_count[4], __popcll(b_ov));
+            obase = __shfl(obase, 0);
+            if (status == 3) P.lane_overflow[obase + __popcll(b_ov & ((1ull << lane) - 1ull))] = pit;
+        }
+    }
+}
+
 constexpr int W_LARGE = 640, MAXD_LARGE = 2048;
 
 // wave-per-pit: 4 pits per 256-thread block
 __global__ __launch_bounds__(256) void k_pits_wave(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits)
 {
-    __shared__ uint32_t s_bits[4][2][WV * WV / 32];
-    __shared__ uint16_t s_blist[4][WV_LCAP];
-    __shared__ double s_be[4][WV_LCAP];
-    __shared__ uint8_t s_bp[4][WV_LCAP];
-    __shared__ int32_t s_dl[4][WV_MAXD];
-    __shared__ double s_dxy[4][WV_MAXD], s_sv[4][WV_MAXD];
-    __shared__ int s_flag[4][4];
-    __shared__ PwFrame s_stk[4][16];
+    __shared__ WaveLds s_l[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t np = *npits;
     int32_t chunk_base = 0, chunk_left = 0;
-    for (int32_t q = blockIdx.x * 4 + wave; q < np; q += gridDim.x * 4)
-        solve_pit_wave(P, pits[q], lane, s_bits[wave][0], s_bits[wave][1], s_blist[wave], s_be[wave], s_bp[wave], s_dl[wave],
-                       s_dxy[wave], s_sv[wave], s_flag[wave], chunk_base, chunk_left, s_stk[wave]);
+    for (int32_t q = blockIdx.x * 4 + wave; q < np; q += gridDim.x * 4) {
+        solve_pit_wave(P, pits[q], lane, s_l[wave], chunk_base, chunk_left);
+        wave_sync();
+    }
 }
 
 // workgroup-per-pit with the full-radius window in dynamic LDS (3 * 640*640/8 = 153.6 KB)
@@ -643,6 +967,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
     PYDEM_TRY(tile_alloc(t, &t->flat0, (size_t)t->NN));       // reused as the frozen pit mask
     PYDEM_TRY(tile_alloc(t, &t->flatlist, (size_t)t->NN));    // reused as the pit list
     PYDEM_TRY(tile_alloc(t, &t->labels, (size_t)t->NN));      // reused as the overflow list
+    PYDEM_TRY(tile_alloc(t, &t->queue[0], (size_t)t->NN));    // (sweep queue, idle here) lane -> wavefront hand-over list
     int32_t *cnt = t->counters + 40;                            // [0] npits, [1..4] out_count, scratch
     HIP_TRY(hipMemsetAsync(cnt, 0, 16 * sizeof(int32_t), t->stream));
     const int big = (int)(cdiv(t->NN, 256) < 8192 ? cdiv(t->NN, 256) : 8192);
@@ -666,20 +991,48 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             t->pits.raw_cap = cap;
         }
         HIP_TRY(hipMemsetAsync(cnt + 1, 0, 8 * sizeof(int32_t), t->stream));
-        HIP_TRY(hipMemsetAsync(t->pits.raw_src, 0xFF, (size_t)t->pits.raw_cap * 4, t->stream));   // -1 = unused slot
         PitParams P;
+        P.dbg = nullptr;
+        const char *dbg_env = getenv("PYDEM_PITS_DEBUG");
+        if (dbg_env && atoi(dbg_env) >= 2) HIP_TRY(hipMalloc(&P.dbg, (size_t)npits * 16));
+        HIP_TRY(hipMemsetAsync(t->pits.raw_src, 0xFF, (size_t)t->pits.raw_cap * 4, t->stream));   // -1 = unused slot
         P.elev = t->elev; P.pitmask = t->flat0; P.dX = t->dX; P.dY = t->dY; P.mag = t->mag; P.flats = t->flats;
         P.n = n; P.m = m; P.max_iter = opt->drain_pits_max_iter; P.max_dist = opt->drain_pits_max_dist;
         P.min_border = opt->drain_pits_min_border; P.max_dist_XY = opt->drain_pits_max_dist_XY;
         P.out_src = t->pits.raw_src; P.out_dst = t->pits.raw_dst; P.out_w = t->pits.raw_w;
         P.out_count = cnt + 1; P.out_cap = (int32_t)(t->pits.raw_cap < INT32_MAX ? t->pits.raw_cap : INT32_MAX);
         P.overflow_list = t->labels;
-        const int gw = (int)(cdiv(npits, 4) < 16384 ? cdiv(npits, 4) : 16384);
-        hipLaunchKernelGGL(k_pits_wave, dim3(gw), dim3(256), 0, t->stream, P, t->flatlist, cnt);
+        P.lane_overflow = t->queue[0];
+        // pass 1: a lane per pit (16x16 window); pass 2: a wavefront per pit it handed over (64x64)
+        const int gl = (int)(cdiv(npits, LN_T) < (1 << 20) ? cdiv(npits, LN_T) : (1 << 20));
+        hipLaunchKernelGGL(k_pits_lane, dim3(gl), dim3(LN_T), 0, t->stream, P, t->flatlist, cnt);
         HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
+        const int32_t n_lane_over = t->h_counters[5];
+        if (n_lane_over > 0) {
+            const int gw = (int)(cdiv(n_lane_over, 4) < 16384 ? cdiv(n_lane_over, 4) : 16384);
+            hipLaunchKernelGGL(k_pits_wave, dim3(gw), dim3(256), 0, t->stream, P, t->queue[0], cnt + 5);
+            HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+        }
         const int32_t n_over = t->h_counters[3];
-        if (getenv("PYDEM_PITS_DEBUG")) fprintf(stderr, "pits: %d candidates, %d left the 64x64 window, %d edges so far, %d undrained\n", npits, n_over, t->h_counters[1], t->h_counters[2]);
+        if (dbg_env) fprintf(stderr, "pits: %d candidates, %d left the 16x16 lane window, %d left the 128x128 window, %d edge slots, %d undrained\n", npits, n_lane_over, n_over, t->h_counters[1], t->h_counters[2]);
+        if (P.dbg) {
+            const int nrec = t->h_counters[7];
+            std::vector<int32_t> rec((size_t)nrec * 4);
+            HIP_TRY(hipMemcpy(rec.data(), P.dbg, rec.size() * 4, hipMemcpyDeviceToHost));
+            (void)hipFree(P.dbg); P.dbg = nullptr;
+            std::vector<int> rounds, border; int reason[4] = {0, 0, 0, 0}; long long tot_rounds = 0;
+            for (int i = 0; i < nrec; i++) {
+                rounds.push_back(rec[4 * i]); border.push_back(rec[4 * i + 1]); reason[rec[4 * i + 2] & 3]++; tot_rounds += rec[4 * i];
+            }
+            std::sort(rounds.begin(), rounds.end()); std::sort(border.begin(), border.end());
+            auto pct = [&](std::vector<int> &v, double q) { return v.empty() ? 0 : v[(size_t)(q * (v.size() - 1))]; };
+            fprintf(stderr, "pits/wave: %d pits, %lld rounds; rounds p50 %d p90 %d p99 %d max %d; last border p50 %d p90 %d p99 %d max %d; "
+                    "ok %d, window exit %d, border cap %d, drain cap %d\n", nrec, tot_rounds, pct(rounds, .5), pct(rounds, .9),
+                    pct(rounds, .99), pct(rounds, 1.), pct(border, .5), pct(border, .9), pct(border, .99), pct(border, 1.),
+                    reason[0], reason[1], reason[2], reason[3]);
+        }
         if (n_over > 0) {
             // second pass: workgroup per pit, 640x640 window in LDS
             const int gb = n_over < 1024 ? n_over : 1024;

@@ -74,3 +74,23 @@ def test_hip_pits_vs_oracle_synthetic(shape, seed, quant):
     assert np.array_equal(dp.edge_todo, o.edge_todo)
     assert np.array_equal(dp.edge_done, o.edge_done)
     _close(twi, o.twi / 10, 'twi')
+
+
+def test_hip_pits_vs_oracle_bench_tile_4096():
+    """The bench generator at 4096^2 (seed 1): 400 k pit edges, ~10 % of the pits outgrow the lane pass and
+    run through the wavefront pass, ~1500 pits never drain.  (tools/check_pits_large.py runs the same check
+    at the full 16384^2 size: 6 491 367 identical assignments, 5 min of oracle time.)"""
+    from oracle import oracle as O
+    from pydem_amd import DEMProcessor
+    z = O.synth_fractal(4096, 4096, seed=1)
+    o = O.OracleDEM(z, dX=30.0, dY=30.0, drain_pits=True)
+    o.calc_uca()
+    dp = DEMProcessor(elev=z, dX=30.0, dY=30.0, fill_flats=False, drain_pits_path=False, drain_pits=True)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        dp.calc_slopes_directions()
+        dp.calc_uca()
+    _check_pits(dp, o.pit_i, o.pit_j, o.pit_prop)
+    assert dp.timings['n_pits_undrained'] == o.n_warn
+    _close(dp.uca, o.uca, 'uca')
