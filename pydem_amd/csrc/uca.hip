@@ -38,7 +38,7 @@ constexpr uint32_t CI_LEVEL_INF = 0x1FFFFu, CI_STATIC_MASK = 0x7FFFu;
 __device__ __forceinline__ uint32_t ci_level(uint32_t w) { return w >> CI_LEVEL_SHIFT; }
 __device__ __forceinline__ int ci_section(uint32_t w) { return (int)((w >> CI_SEC_SHIFT) & 7u); }
 __device__ __forceinline__ uint32_t ci_with_level(uint32_t w, uint32_t lv) { return (w & CI_STATIC_MASK) | (lv << CI_LEVEL_SHIFT); }
-constexpr int PIT_BLK_SHIFT = 8;     // pit side lists are indexed per block of 256 cells
+constexpr int PIT_BLK_SHIFT = 5;     // pit side lists are indexed per block of 32 cells (<1 entry per block: the lookup is two loads)
 
 // 8-neighbour offsets in ascending cell-id order: NW N NE W E SW S SE
 __device__ __constant__ const int NB_DI[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
@@ -184,7 +184,7 @@ __global__ void k_corner_todo(const double *__restrict__ corner_sums, const doub
 // atomics per cell) of a textbook Kahn sweep disappear.  The frontier itself is appended through
 // an LDS staging buffer: wavefront ballot + popcount prefix, one LDS atomic per wave, and one
 // global atomic per ~1.5k cells when the buffer is flushed.
-constexpr int STAGE_CAP = 8192;      // LDS staging entries per block (32 KiB)
+constexpr int STAGE_CAP = 4096;      // LDS staging entries per block (8 B each: 32 KiB)
 constexpr int STAGE_FLUSH = STAGE_CAP - 512;    // flush when fewer than 2*256 slots remain
 
 struct SweepArgs {
@@ -199,6 +199,8 @@ struct SweepArgs {
     const int32_t *pin_dst, *pin_src; const double *pin_w;
     const int32_t *pout_blk, *pin_blk;
     int64_t n_pit;
+    int32_t qcap;                // frontier queue capacity (entries)
+    int32_t *err;                // queue overflow counter
 };
 
 // first index e >= blk[cell >> 8] with key[e] >= cell (lists are sorted; ~6 entries per block)
@@ -220,14 +222,19 @@ __global__ void k_pit_block_starts(const int32_t *__restrict__ key, int64_t ne, 
     }
 }
 
+// A frontier entry carries the cell AND its graph word: the round that processes it starts its
+// gathers straight from the queue load (one dependent memory round trip less per round -- the long
+// tail of the sweep is nothing but such round trips).
+struct QE { int32_t c; uint32_t cw; };
+
 struct Stage {
-    int32_t buf[STAGE_CAP];
+    QE buf[STAGE_CAP];
     int32_t cnt;
     int32_t base;
 };
 
 // wave-aggregated append into the block's LDS staging buffer
-__device__ __forceinline__ void stage_push(Stage &S, bool pred, int32_t cell)
+__device__ __forceinline__ void stage_push(Stage &S, bool pred, int32_t cell, uint32_t cw)
 {
     const unsigned long long bal = __ballot(pred);
     if (bal == 0ull) return;
@@ -236,11 +243,11 @@ __device__ __forceinline__ void stage_push(Stage &S, bool pred, int32_t cell)
     int32_t base = 0;
     if (lane == leader) base = atomicAdd(&S.cnt, (int32_t)__popcll(bal));
     base = __shfl(base, leader);
-    if (pred) S.buf[base + __popcll(bal & ((1ull << lane) - 1ull))] = cell;
+    if (pred) { QE q; q.c = cell; q.cw = cw; S.buf[base + __popcll(bal & ((1ull << lane) - 1ull))] = q; }
 }
 
 // block-wide: move the staged cells to the global frontier (call from uniform control flow)
-__device__ __forceinline__ void stage_flush(Stage &S, int32_t *__restrict__ qn, int32_t *cn, bool force)
+__device__ __forceinline__ void stage_flush(const SweepArgs &A, Stage &S, QE *__restrict__ qn, int32_t *cn, bool force)
 {
     __syncthreads();
     const int32_t c = S.cnt;
@@ -248,11 +255,38 @@ __device__ __forceinline__ void stage_flush(Stage &S, int32_t *__restrict__ qn, 
         if (threadIdx.x == 0) S.base = atomicAdd(cn, c);
         __syncthreads();
         const int32_t b = S.base;
-        for (int32_t k = threadIdx.x; k < c; k += blockDim.x) qn[b + k] = S.buf[k];
+        if ((int64_t)b + c <= A.qcap) { for (int32_t k = threadIdx.x; k < c; k += blockDim.x) qn[b + k] = S.buf[k]; }
+        else if (threadIdx.x == 0) atomicAdd(A.err, 1);
         __syncthreads();
         if (threadIdx.x == 0) S.cnt = 0;
     }
     __syncthreads();
+}
+
+// Pit side lists without a search: until a cell is processed its slot of the area array is unused, so
+// it carries {first in-edge, first out-edge} of the cell (k_pit_stash); the edges of one cell are
+// contiguous in the sorted lists and end where the key changes.  Reading the slot costs one load that
+// travels with the gathers instead of the block-table lookup plus key scan (3+ dependent loads).
+__device__ __forceinline__ int2 pit_stash(const SweepArgs &A, int32_t c) { return reinterpret_cast<const int2 *>(A.area)[c]; }
+
+__global__ void k_pit_stash(const int32_t *__restrict__ pin_dst, const int32_t *__restrict__ pit_src, int64_t ne, double *area)
+{
+    int32_t *slots = reinterpret_cast<int32_t *>(area);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e == 0 || pin_dst[e - 1] != pin_dst[e]) slots[2 * (int64_t)pin_dst[e]] = (int32_t)e;
+        if (e == 0 || pit_src[e - 1] != pit_src[e]) slots[2 * (int64_t)pit_src[e] + 1] = (int32_t)e;
+    }
+}
+
+// graph words of the 8 neighbours of t (row ti, column tj); out-of-tile neighbours read t itself (never used)
+__device__ __forceinline__ void load_upstream_words(const SweepArgs &A, int32_t t, int ti, int tj, uint32_t w[8])
+{
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const int ii = ti + NB_DI[d], jj = tj + NB_DJ[d];
+        const bool ok = ii >= 0 && ii < A.n && jj >= 0 && jj < A.m;
+        w[d] = A.cinfo[ok ? t + NB_DI[d] * A.m + NB_DJ[d] : t];
+    }
 }
 
 // Frontier bookkeeping without per-edge atomics.  The level field of cinfo[c] is the round in which
@@ -262,16 +296,11 @@ __device__ __forceinline__ void stage_flush(Stage &S, int32_t *__restrict__ qn, 
 // to the next frontier and stamps level r+1.  All level-r stamps were written by the previous
 // launch, so the test reads only settled values; the in-degree counters (and their ~1.4 device
 // atomics per cell) of a textbook Kahn sweep disappear.
-__device__ __forceinline__ bool owns_target_pre(const SweepArgs &A, int32_t t, int32_t u, uint32_t r, uint32_t ct);
-
-__device__ __forceinline__ bool owns_target(const SweepArgs &A, int32_t t, int32_t u, uint32_t r, uint32_t &ct)
-{
-    ct = A.cinfo[t];
-    return owns_target_pre(A, t, u, r, ct);
-}
-
-// `ct` = graph word of t, loaded by the caller (its static bits never change during a sweep)
-__device__ __forceinline__ bool owns_target_pre(const SweepArgs &A, int32_t t, int32_t u, uint32_t r, uint32_t ct)
+// `ct` = graph word of t, `w` = graph words of its neighbours (SPEC: all eight were loaded up front;
+// otherwise only those in t's in-mask are fetched here), `in_start` = first pit in-edge of t.
+template <bool SPEC>
+__device__ __forceinline__ bool owns_target(const SweepArgs &A, int32_t t, int32_t u, uint32_t r, uint32_t ct, const uint32_t w[8],
+                                            int32_t in_start)
 {
     int32_t owner = -1;
     bool ready = true;
@@ -279,47 +308,39 @@ __device__ __forceinline__ bool owns_target_pre(const SweepArgs &A, int32_t t, i
     for (int d = 0; d < 8; d++) {
         if (ct & (1u << d)) {
             const int32_t v = t + NB_DI[d] * A.m + NB_DJ[d];
-            const uint32_t lv = (v == u) ? r : ci_level(A.cinfo[v]);
+            const uint32_t lv = (v == u) ? r : ci_level(SPEC ? w[d] : A.cinfo[v]);
             ready = ready && (lv <= r);
             if (lv == r) owner = v > owner ? v : owner;
         }
     }
     if (ct & CI_PIT_IN) {
-        for (int32_t e = pit_first(A.pin_dst, A.pin_blk, t); e < A.n_pit && A.pin_dst[e] == t; e++) {
-            const int32_t v = A.pin_src[e];
-            const uint32_t lv = (v == u) ? r : ci_level(A.cinfo[v]);
-            ready = ready && (lv <= r);
-            if (lv == r) owner = v > owner ? v : owner;
+        for (int32_t e = in_start;; e += 4) {
+            int32_t d4[4], s4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int64_t idx = e + k < A.n_pit ? e + k : A.n_pit - 1;
+                d4[k] = A.pin_dst[idx]; s4[k] = A.pin_src[idx];
+            }
+            uint32_t l4[4];
+            bool v4[4];
+            bool more = true;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                more = more && e + k < A.n_pit && d4[k] == t;
+                v4[k] = more;
+                l4[k] = (more && s4[k] != u) ? ci_level(A.cinfo[s4[k]]) : r;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (v4[k]) {
+                    ready = ready && (l4[k] <= r);
+                    if (l4[k] == r) owner = s4[k] > owner ? s4[k] : owner;
+                }
+            }
+            if (!more) break;
         }
     }
     return ready && owner == u;
-}
-
-// after cell c (level r, graph word cw) is final: hand its ready targets to the next frontier
-__device__ __forceinline__ void release_targets(const SweepArgs &A, Stage &S, bool active, int32_t c, uint32_t cw,
-                                                uint32_t r, int32_t *__restrict__ qn, int32_t *cn,
-                                                int32_t t1 = -2, int32_t t2 = -2, uint32_t c1 = 0, uint32_t c2 = 0)
-{
-    const int m = A.m;
-    const int s = ci_section(cw);
-    if (t1 == -2) {                     // targets and their graph words not preloaded by the caller
-        t1 = -1; t2 = -1;
-        if (active && (cw & CI_OUT1)) { t1 = c + fe1r(s) * m + fe1c(s); c1 = A.cinfo[t1]; }
-        if (active && (cw & CI_OUT2)) { t2 = c + fe2r(s) * m + fe2c(s); c2 = A.cinfo[t2]; }
-    }
-    const bool r1 = t1 >= 0 && owns_target_pre(A, t1, c, r, c1);
-    const bool r2 = t2 >= 0 && owns_target_pre(A, t2, c, r, c2);
-    if (r1) A.cinfo[t1] = ci_with_level(c1, r + 1);
-    if (r2) A.cinfo[t2] = ci_with_level(c2, r + 1);
-    stage_push(S, r1, t1);
-    stage_push(S, r2, t2);
-    if (active && (cw & CI_PIT_OUT)) {                                           // rare: drained pit
-        for (int32_t e = pit_first(A.pit_src, A.pout_blk, c); e < A.n_pit && A.pit_src[e] == c; e++) {
-            const int32_t t = A.pit_dst[e];
-            uint32_t ct;
-            if (owns_target(A, t, c, r, ct)) { A.cinfo[t] = ci_with_level(ct, r + 1); qn[atomicAdd(cn, 1)] = t; }
-        }
-    }
 }
 
 // publish a finished cell: area plus the two outgoing contributions (sign carries the todo taint)
@@ -337,47 +358,67 @@ __device__ __forceinline__ void publish_cell(const SweepArgs &A, int32_t c, uint
     if (td) A.todo_work[c] = 1;
 }
 
-// round 0: every cell without in-edges is a source (ids = colsum == 0, :882-883): area = dX2*dY2
-__global__ __launch_bounds__(256) void k_sweep_sources(SweepArgs A, int32_t *__restrict__ qn, int32_t *cn, int32_t *nsrc)
+// sum over the pit in-edges of cell c (sorted by source id), four edges per batch of loads
+__device__ __forceinline__ void gather_pit_edges(const SweepArgs &A, int32_t c, int32_t in_start, double &acc, bool &td)
 {
-    __shared__ Stage S;
-    if (threadIdx.x == 0) S.cnt = 0;
-    __syncthreads();
-    const int64_t NN = (int64_t)A.n * A.m;
-    int32_t mine = 0;
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < NN; base += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t c = base + threadIdx.x;
-        bool src = false;
-        uint32_t cw = 0;
-        if (c < NN) {
-            cw = A.cinfo[c];
-            src = ci_level(cw) == 0;
-            if (src) { publish_cell(A, (int32_t)c, cw, A.a0[c / A.m], A.todo_work[c] != 0); mine++; }
+    for (int32_t e = in_start;; e += 4) {
+        int32_t d4[4], s4[4]; double w4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t idx = e + k < A.n_pit ? e + k : A.n_pit - 1;
+            d4[k] = A.pin_dst[idx]; s4[k] = A.pin_src[idx]; w4[k] = A.pin_w[idx];
         }
-        release_targets(A, S, src, (int32_t)c, cw, 0, qn, cn);
-        stage_flush(S, qn, cn, false);
+        double a4[4]; uint8_t t4[4];
+        bool more = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            more = more && e + k < A.n_pit && d4[k] == c;
+            a4[k] = more ? A.area[s4[k]] : 0.0;
+            t4[k] = more ? A.todo_work[s4[k]] : (uint8_t)0;
+        }
+        more = true;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            more = more && e + k < A.n_pit && d4[k] == c;
+            if (more) { acc += a4[k] * w4[k]; td = td || (t4[k] != 0); }
+        }
+        if (!more) break;
     }
-    stage_flush(S, qn, cn, true);
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(nsrc, mine);
 }
 
-// rounds >= 1: pull, store, release
-__device__ __forceinline__ void process_cell(const SweepArgs &A, Stage &S, bool active, int32_t c, uint32_t r,
-                                             int32_t *__restrict__ qn, int32_t *cn)
+// rounds >= 1: pull, store, release.  LOWLAT (small frontiers): every load that only needs the queue
+// entry -- in-edge contributions, the targets' graph words, the graph words of ALL their neighbours,
+// the pit slots -- is issued in one batch, so a regular cell costs two dependent memory round trips
+// per round (queue entry, batch).  Large frontiers are bound by the lines they touch, not by latency,
+// and fetch only the neighbours in each target's in-mask.
+// push2(pred, t, ct): called by all lanes together for the two regular targets; pushp(t, ct): called
+// by single lanes for the (rare) pit targets.
+template <bool LOWLAT, typename Push2, typename PushP>
+__device__ __forceinline__ void process_cell(const SweepArgs &A, bool active, QE q, uint32_t r, Push2 push2, PushP pushp)
 {
-    uint32_t cw = 0;
+    const int32_t c = q.c;
+    const uint32_t cw = q.cw;
     int32_t t1 = -1, t2 = -1;
     uint32_t c1 = 0, c2 = 0;
+    bool r1 = false, r2 = false;
+    int32_t out_start = -1;
     if (active) {
         const int m = A.m;
-        cw = A.cinfo[c];
-        // the long tail of the sweep is a chain of dependent memory round trips per round: start the
-        // loads that only need cw (targets' graph words) before the gather instead of after it
-        const int sct = ci_section(cw);
-        if (cw & CI_OUT1) { t1 = c + fe1r(sct) * m + fe1c(sct); c1 = A.cinfo[t1]; }
-        if (cw & CI_OUT2) { t2 = c + fe2r(sct) * m + fe2c(sct); c2 = A.cinfo[t2]; }
         const int i = c / m, j = c - i * m;
+        const int sct = ci_section(cw);
+        uint32_t l1[8], l2[8];
+        int2 s1 = make_int2(-1, -1), s2 = make_int2(-1, -1), sc = make_int2(-1, -1);
+        if (cw & CI_OUT1) {
+            const int dr = fe1r(sct), dc = fe1c(sct);
+            t1 = c + dr * m + dc; c1 = A.cinfo[t1];
+            if (LOWLAT) { load_upstream_words(A, t1, i + dr, j + dc, l1); s1 = pit_stash(A, t1); }
+        }
+        if (cw & CI_OUT2) {
+            const int dr = fe2r(sct), dc = fe2c(sct);
+            t2 = c + dr * m + dc; c2 = A.cinfo[t2];
+            if (LOWLAT) { load_upstream_words(A, t2, i + dr, j + dc, l2); s2 = pit_stash(A, t2); }
+        }
+        if (cw & (CI_PIT_IN | CI_PIT_OUT)) sc = pit_stash(A, c);
         double acc = A.a0[i];                                                   // :885, :901
         // only inlet cells on the tile edge start tainted (:909-930); interior bytes are written later
         bool td = (i == 0 || i == A.n - 1 || j == 0 || j == m - 1) && A.todo_work[c] != 0;
@@ -393,19 +434,52 @@ __device__ __forceinline__ void process_cell(const SweepArgs &A, Stage &S, bool 
                 td = td || (x < 0);                                             // :165 (float taint -> bool)
             }
         }
-        if (cw & CI_PIT_IN) {
-            for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++) {
-                acc += A.area[A.pin_src[e]] * A.pin_w[e];
-                td = td || (A.todo_work[A.pin_src[e]] != 0);
-            }
-        }
+        if (cw & CI_PIT_IN) gather_pit_edges(A, c, sc.x, acc, td);
+        out_start = sc.y;
         publish_cell(A, c, cw, acc, td);
+        if (t1 >= 0) {
+            if (!LOWLAT && (c1 & CI_PIT_IN)) s1 = pit_stash(A, t1);
+            r1 = owns_target<LOWLAT>(A, t1, c, r, c1, l1, s1.x);
+        }
+        if (t2 >= 0) {
+            if (!LOWLAT && (c2 & CI_PIT_IN)) s2 = pit_stash(A, t2);
+            r2 = owns_target<LOWLAT>(A, t2, c, r, c2, l2, s2.x);
+        }
+        if (r1) A.cinfo[t1] = ci_with_level(c1, r + 1);
+        if (r2) A.cinfo[t2] = ci_with_level(c2, r + 1);
     }
-    release_targets(A, S, active, c, cw, r, qn, cn, t1, t2, c1, c2);
+    push2(r1, t1, c1);
+    push2(r2, t2, c2);
+    if (active && (cw & CI_PIT_OUT)) {                                           // rare: drained pit
+        for (int32_t e = out_start;; e += 4) {
+            int32_t s4[4], t4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int64_t idx = e + k < A.n_pit ? e + k : A.n_pit - 1;
+                s4[k] = A.pit_src[idx]; t4[k] = A.pit_dst[idx];
+            }
+            bool more = true;
+            for (int k = 0; k < 4 && more; k++) {
+                more = e + k < A.n_pit && s4[k] == c;
+                if (!more) break;
+                const int32_t t = t4[k];
+                const uint32_t ct = A.cinfo[t];
+                const int2 st = pit_stash(A, t);
+                uint32_t lw[8];
+                load_upstream_words(A, t, t / A.m, t % A.m, lw);
+                if (owns_target<true>(A, t, c, r, ct, lw, st.x)) {
+                    A.cinfo[t] = ci_with_level(ct, r + 1);
+                    pushp(t, ct);
+                }
+            }
+            if (!more) break;
+        }
+    }
 }
 
 // one frontier round; counters rotate over 3 slots: in = r%3, out = (r+1)%3, (r+2)%3 is cleared
-__global__ __launch_bounds__(256) void k_sweep_round(SweepArgs A, const int32_t *__restrict__ qc, int32_t *__restrict__ qn,
+template <bool LOWLAT>
+__global__ __launch_bounds__(256) void k_sweep_round(SweepArgs A, const QE *__restrict__ qc, QE *__restrict__ qn,
                                                      int32_t *cnt3, int r, int32_t *total)
 {
     __shared__ Stage S;
@@ -418,11 +492,64 @@ __global__ __launch_bounds__(256) void k_sweep_round(SweepArgs A, const int32_t 
     for (int32_t base = blockIdx.x * blockDim.x; base < nq; base += gridDim.x * blockDim.x) {
         const int32_t q = base + threadIdx.x;
         const bool active = q < nq;
-        const int32_t c = active ? qc[q] : 0;
-        process_cell(A, S, active, c, (uint32_t)r, qn, cn);
-        stage_flush(S, qn, cn, false);
+        QE qe; qe.c = 0; qe.cw = 0;
+        if (active) qe = qc[q];
+        process_cell<LOWLAT>(A, active, qe, (uint32_t)r,
+                             [&](bool pred, int32_t t, uint32_t ct) { stage_push(S, pred, t, ct); },
+                             [&](int32_t t, uint32_t ct) {
+                                 const int32_t slot = atomicAdd(cn, 1);
+                                 if (slot < A.qcap) { QE e; e.c = t; e.cw = ct; qn[slot] = e; }
+                                 else atomicAdd(A.err, 1);
+                             });
+        stage_flush(A, S, qn, cn, false);
     }
-    stage_flush(S, qn, cn, true);
+    stage_flush(A, S, qn, cn, true);
+}
+
+// Small frontiers: ONE workgroup runs round after round without going back to the host.  A kernel
+// boundary makes every first access of the next round a trip across the fabric (the per-XCD L2s are
+// only coherent at kernel boundaries), ~2 us per dependent load and 4+ of them per round; inside one
+// workgroup the frontier, the graph words and the contributions it wrote a round ago come from its
+// own CU's caches and __syncthreads() is the only synchronisation.  The last ~600 rounds of a
+// 16384^2 tile are rivers of a few hundred cells.  Stops when the frontier is empty or outgrows
+// SWEEP_SMALL_CAP; reports the round it stopped at and what it processed.
+constexpr int SWEEP_SMALL_CAP = 1024;
+
+__global__ __launch_bounds__(1024) void k_sweep_small(SweepArgs A, QE *q0, QE *q1, int32_t *cnt3, int r_start, int r_max,
+                                                      int32_t *total, int32_t *state)
+{
+    __shared__ int s_next;
+    int r = r_start;
+    int32_t nq = cnt3[r % 3];
+    int32_t done = 0, rounds = 0;
+    while (nq > 0 && nq <= SWEEP_SMALL_CAP && r < r_max) {
+        if (threadIdx.x == 0) s_next = 0;
+        __syncthreads();
+        const QE *qc = (r % 2) ? q1 : q0;
+        QE *qn = (r % 2) ? q0 : q1;
+        for (int32_t base = 0; base < nq; base += blockDim.x) {
+            const int32_t q = base + threadIdx.x;
+            const bool active = q < nq;
+            QE qe; qe.c = 0; qe.cw = 0;
+            if (active) qe = qc[q];
+            auto push = [&](int32_t t, uint32_t ct) {
+                const int32_t slot = atomicAdd(&s_next, 1);
+                if (slot < A.qcap) { QE e; e.c = t; e.cw = ct; qn[slot] = e; }
+                else atomicAdd(A.err, 1);
+            };
+            process_cell<true>(A, active, qe, (uint32_t)r, [&](bool pred, int32_t t, uint32_t ct) { if (pred) push(t, ct); }, push);
+        }
+        __syncthreads();
+        done += nq; rounds++;
+        nq = s_next;
+        r++;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        cnt3[r % 3] = nq; cnt3[(r + 1) % 3] = 0; cnt3[(r + 2) % 3] = 0;
+        atomicAdd(total, done); atomicAdd(total + 2, rounds);
+        state[0] = r;
+    }
 }
 
 // ------------------------------------------------------------------------------- K5b
@@ -483,7 +610,7 @@ __global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass,
             for (int d = 0; d < 8; d++)
                 if ((cw & (1u << d)) && !s_state[idx + LOFF[d]]) pend++;
             if (cw & CI_PIT_IN)                                     // pit -> drain edges are short: most sources sit in this tile
-                for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++) {
+                for (int32_t e = pit_stash(A, c).x; e < A.n_pit && A.pin_dst[e] == c; e++) {
                     const int32_t sc = A.pin_src[e];
                     const int si = sc / m - i0, sj = sc % m - j0;
                     if (si >= 0 && si < TT && sj >= 0 && sj < TT) {
@@ -527,7 +654,7 @@ __global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass,
                 }
             }
             if (cw & CI_PIT_IN)
-                for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++) {
+                for (int32_t e = pit_stash(A, c).x; e < A.n_pit && A.pin_dst[e] == c; e++) {
                     const int32_t sc = A.pin_src[e];
                     const int si = sc / m - i0, sj = sc % m - j0;
                     if (si >= 0 && si < TT && sj >= 0 && sj < TT && s_state[(si + 1) * HW + sj + 1] == 2) {
@@ -562,7 +689,7 @@ __global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass,
                     s_next[atomicAdd(&s_nn, 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
             }
             if (cw & CI_PIT_OUT)
-                for (int32_t e = pit_first(A.pit_src, A.pout_blk, c); e < A.n_pit && A.pit_src[e] == c; e++) {
+                for (int32_t e = pit_stash(A, c).y; e < A.n_pit && A.pit_src[e] == c; e++) {
                     const int32_t dc = A.pit_dst[e];
                     const int ti = dc / m - i0 + 1, tj = dc % m - j0 + 1;
                     if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && !s_state[ti * HW + tj]
@@ -600,7 +727,7 @@ __global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass,
 
 // after the tile passes: cells that are not final but whose upstream cells all are form the first
 // queue frontier (level `r`)
-__global__ __launch_bounds__(256) void k_sweep_rebuild_frontier(SweepArgs A, uint32_t r, int32_t *__restrict__ qn, int32_t *cn)
+__global__ __launch_bounds__(256) void k_sweep_rebuild_frontier(SweepArgs A, uint32_t r, QE *__restrict__ qn, int32_t *cn)
 {
     __shared__ Stage S;
     if (threadIdx.x == 0) S.cnt = 0;
@@ -609,8 +736,9 @@ __global__ __launch_bounds__(256) void k_sweep_rebuild_frontier(SweepArgs A, uin
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < NN; base += (int64_t)gridDim.x * blockDim.x) {
         const int64_t c = base + threadIdx.x;
         bool push = false;
+        uint32_t cw = 0;
         if (c < NN) {
-            const uint32_t cw = A.cinfo[c];
+            cw = A.cinfo[c];
             const uint32_t lv = ci_level(cw);
             if (lv == 0 || lv == CI_LEVEL_INF) {
                 bool ready = true;
@@ -621,17 +749,17 @@ __global__ __launch_bounds__(256) void k_sweep_rebuild_frontier(SweepArgs A, uin
                         ready = ready && (lu >= 1 && lu < r);
                     }
                 if (ready && (cw & CI_PIT_IN))
-                    for (int32_t e = pit_first(A.pin_dst, A.pin_blk, (int32_t)c); e < A.n_pit && A.pin_dst[e] == (int32_t)c; e++) {
+                    for (int32_t e = pit_stash(A, (int32_t)c).x; e < A.n_pit && A.pin_dst[e] == (int32_t)c; e++) {
                         const uint32_t lu = ci_level(A.cinfo[A.pin_src[e]]);
                         ready = ready && (lu >= 1 && lu < r);
                     }
                 if (ready) { A.cinfo[c] = ci_with_level(cw, r); push = true; }
             }
         }
-        stage_push(S, push, (int32_t)c);
-        stage_flush(S, qn, cn, false);
+        stage_push(S, push, (int32_t)c, cw);
+        stage_flush(A, S, qn, cn, false);
     }
-    stage_flush(S, qn, cn, true);
+    stage_flush(A, S, qn, cn, true);
 }
 
 __global__ void k_row_area(const double *__restrict__ dX2, const double *__restrict__ dY2, int n, double *a0)
@@ -979,6 +1107,8 @@ static void fill_sweep_args(pydem_tile *t, SweepArgs &A)
     A.pit_src = t->pits.src; A.pit_dst = t->pits.dst; A.n_pit = t->pits.n_edges;
     A.pin_dst = t->pits.in_dst; A.pin_src = t->pits.in_src; A.pin_w = t->pits.in_w;
     A.pout_blk = t->pit_blk; A.pin_blk = t->pit_blk ? t->pit_blk + nblk + 2 : nullptr;
+    A.qcap = (int32_t)(t->NN / 2 < INT32_MAX ? t->NN / 2 : INT32_MAX);      // queue buffers hold NN ints = NN/2 entries
+    A.err = t->counters + 15;
 }
 
 int stage_sweep(pydem_tile *t, const pydem_options *opt)
@@ -991,12 +1121,13 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     int32_t *cnt3 = t->counters;        // [0..2] rotating frontier sizes
     int32_t *total = t->counters + 3;   // cells processed by rounds >= 1
     int32_t *nsrc = t->counters + 4;    // source cells (round 0)
-    int32_t *nrounds = t->counters + 5; // rounds with a non-empty frontier
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
     HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
     hipLaunchKernelGGL(k_row_area, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, t->stream, t->dX2, t->dY2, n, t->row_area);
     SweepArgs A;
     fill_sweep_args(t, A);
+    if (A.n_pit > 0)   // the unused area slots of pit sources / drains carry their edge-list offsets until they are processed
+        hipLaunchKernelGGL(k_pit_stash, dim3(grid_for(A.n_pit, 2048)), dim3(256), 0, t->stream, A.pin_dst, A.pit_src, A.n_pit, t->uca);
     // ---- tile-local passes until they stop paying, then the queue rounds take over
     const int tiles_x = (int)cdiv(m, TT), tiles_total = tiles_x * (int)cdiv(n, TT);
     if (t->scratch_bytes < (size_t)tiles_total) {
@@ -1032,26 +1163,51 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     int64_t last = 0;
     if (done_prev < t->NN) {
         hipLaunchKernelGGL(k_sweep_rebuild_frontier, dim3(grid_for(t->NN, 4096)), dim3(256), 0, t->stream, A, (uint32_t)r,
-                           t->queue[r % 2], &cnt3[r % 3]);
+                           (QE *)t->queue[r % 2], &cnt3[r % 3]);
         launches++;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         last = t->h_counters[r % 3];
+        if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "after rebuild: frontier %lld, processed %d of %lld\n", (long long)last, t->h_counters[3], (long long)t->NN);
     }
     (void)nsrc;
+    static int small_cap = -1;
+    if (small_cap < 0) { const char *e = getenv("PYDEM_SWEEP_SMALL"); small_cap = e ? atoi(e) : SWEEP_SMALL_CAP; }
     while (last > 0) {
+        if (last <= small_cap && last <= SWEEP_SMALL_CAP) {
+            // one workgroup, many rounds (until the frontier is empty or grows past SWEEP_SMALL_CAP)
+            hipLaunchKernelGGL(k_sweep_small, dim3(1), dim3(1024), 0, t->stream, A, (QE *)t->queue[0], (QE *)t->queue[1], cnt3, r,
+                               (int)CI_LEVEL_INF - 256, total, t->counters + 14);
+            launches++;
+            HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            const int r_new = t->h_counters[14];
+            if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "single-workgroup rounds %d..%d, frontier now %d\n", r, r_new, t->h_counters[r_new % 3]);
+            if (r_new == r) { pydem_set_error("sweep made no progress at round %d", r); return -5; }
+            r = r_new;
+            last = t->h_counters[r % 3];
+            if (r >= (int)CI_LEVEL_INF - 256) { pydem_set_error("flow paths longer than %u rounds are not supported", CI_LEVEL_INF); return -5; }
+            continue;
+        }
         const int batch = last > 262144 ? 2 : (last > 4096 ? 8 : 64);
         const int grid = grid_for(last, 2048);
+        const bool lowlat = last <= 262144;       // latency-bound rounds: speculative batched loads
         for (int b = 0; b < batch; b++, r++) {
-            hipLaunchKernelGGL(k_sweep_round, dim3(grid), dim3(256), 0, t->stream, A, t->queue[r % 2], t->queue[(r + 1) % 2],
-                               cnt3, r, total);
+            if (lowlat)
+                hipLaunchKernelGGL(k_sweep_round<true>, dim3(grid), dim3(256), 0, t->stream, A, (const QE *)t->queue[r % 2],
+                                   (QE *)t->queue[(r + 1) % 2], cnt3, r, total);
+            else
+                hipLaunchKernelGGL(k_sweep_round<false>, dim3(grid), dim3(256), 0, t->stream, A, (const QE *)t->queue[r % 2],
+                                   (QE *)t->queue[(r + 1) % 2], cnt3, r, total);
             launches++;
         }
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         last = t->h_counters[r % 3];
+        if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "round %d: frontier %lld, processed %d\n", r, (long long)last, t->h_counters[3]);
         if (r > (int)CI_LEVEL_INF - 256) { pydem_set_error("flow paths longer than %u rounds are not supported", CI_LEVEL_INF); return -5; }
     }
+    if (t->h_counters[15] > 0) { pydem_set_error("sweep frontier exceeded the queue capacity (%lld entries)", (long long)A.qcap); return -5; }
     const int64_t processed = (int64_t)t->h_counters[3];     // tile passes + queue rounds ([4], [10]: tile-pass statistics)
     t->tm.n_unresolved = t->NN - processed;
     t->tm.sweep_kernel_launches = launches;
