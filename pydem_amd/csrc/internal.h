@@ -79,6 +79,9 @@ struct pydem_tile {
     int32_t *estamp = nullptr; double *edelta = nullptr, *p_delta = nullptr, *s_data = nullptr;
     uint8_t *p_flags = nullptr, *s_flags = nullptr;
     int32_t eepoch = 0;
+    int32_t *eseed = nullptr;       // seed frontier of the current edge round (cell, graph word) pairs
+    bool edge_clean = false;        // edge flags / counts are zero and the masks only differ from their defaults on etodo_prev cells
+    int32_t etodo_prev = 0;         // cells whose edge_done byte the previous round cleared (tlist = flatlist)
     double *line_stage = nullptr;   // max(n, m) doubles: staging for column get/set
     bool graph_valid = false;   // inmask/gflags/section/prop/pit lists match the resident elev/dir/flats
     void *scratch = nullptr; size_t scratch_bytes = 0;

@@ -162,7 +162,8 @@ int pydem_tile_destroy(pydem_tile *t)
                     t->gflags, t->todo_work, t->indeg, t->queue[0], t->queue[1], t->labels, t->flatlist,
                     t->counters, t->scratch, t->pits.src, t->pits.dst, t->pits.w, t->pits.in_src,
                     t->pits.in_dst, t->pits.in_w, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w,
-                    t->estamp, t->edelta, t->p_delta, t->s_data, t->p_flags, t->s_flags, t->line_stage, t->contrib, t->pit_blk};
+                    t->estamp, t->edelta, t->p_delta, t->s_data, t->p_flags, t->s_flags, t->line_stage, t->contrib, t->pit_blk,
+                    t->eseed};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     for (int i = 0; i < 8; i++) if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
@@ -211,6 +212,7 @@ int pydem_tile_set_spacing(pydem_tile *t, const double *dX, const double *dY, co
 
 int pydem_tile_upload(pydem_tile *t, int field, const void *src, int dtype)
 {
+    t->edge_clean = false;
     HIP_TRY(hipSetDevice(t->device));
     void **pp; size_t elem;
     PYDEM_TRY(field_ptr(t, field, &pp, &elem));
@@ -330,6 +332,7 @@ static int need(pydem_tile *t, int field, const char *what)
 
 int pydem_slopes_directions(pydem_tile *t)
 {
+    t->edge_clean = false;      // these stages reuse the edge-round work lists
     HIP_TRY(hipSetDevice(t->device));
     PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_slopes_directions"));
     if (!t->spacing_set) { pydem_set_error("pydem_slopes_directions: call pydem_tile_set_spacing first"); return -3; }
@@ -344,6 +347,7 @@ int pydem_slopes_directions(pydem_tile *t)
 
 int pydem_find_flats(pydem_tile *t)
 {
+    t->edge_clean = false;      // these stages reuse the edge-round work lists
     HIP_TRY(hipSetDevice(t->device));
     PYDEM_TRY(need(t, PYDEM_MAG, "pydem_find_flats"));
     PYDEM_TRY(ensure_field(t, PYDEM_FLATS));
@@ -357,6 +361,7 @@ int pydem_find_flats(pydem_tile *t)
 
 int pydem_uca(pydem_tile *t, pydem_options *opt)
 {
+    t->edge_clean = false;      // these stages reuse the edge-round work lists
     HIP_TRY(hipSetDevice(t->device));
     PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_uca"));
     PYDEM_TRY(need(t, PYDEM_MAG, "pydem_uca"));
@@ -437,6 +442,7 @@ int pydem_tile_pit_edges(pydem_tile *t, int64_t *n, int32_t *src, int32_t *dst, 
 
 int pydem_tile_restore_pit_slopes(pydem_tile *t)
 {
+    t->edge_clean = false;      // these stages reuse the edge-round work lists
     HIP_TRY(hipSetDevice(t->device));
     if (t->pits.n_raw == 0) return 0;
     const int64_t g = cdiv(t->pits.n_raw, 256);
@@ -449,6 +455,7 @@ int pydem_tile_restore_pit_slopes(pydem_tile *t)
 
 int pydem_bench_stencil(pydem_tile *t, int iters, double *avg_ms)
 {
+    t->edge_clean = false;      // these stages reuse the edge-round work lists
     HIP_TRY(hipSetDevice(t->device));
     PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_bench_stencil"));
     if (!t->spacing_set) { pydem_set_error("pydem_bench_stencil: call pydem_tile_set_spacing first"); return -3; }

@@ -20,6 +20,7 @@
 #include "internal.h"
 #include <math.h>
 #include <stdlib.h>
+#include <time.h>
 
 #define PI_D 3.141592653589793
 
@@ -199,6 +200,7 @@ struct SweepArgs {
     const int32_t *pin_dst, *pin_src; const double *pin_w;
     const int32_t *pout_blk, *pin_blk;
     int64_t n_pit;
+    int dbg;                     // timing experiments only (PYDEM_TILE_DEBUG)
     int32_t qcap;                // frontier queue capacity (entries)
     int32_t *err;                // queue overflow counter
 };
@@ -564,19 +566,35 @@ __global__ __launch_bounds__(1024) void k_sweep_small(SweepArgs A, QE *q0, QE *q
 // The arithmetic per cell (gather order, products) is identical to process_cell().
 constexpr int TT = 32, HW = TT + 2;
 
-__global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total,
-                                                     uint8_t *__restrict__ tile_done, int32_t *n_final)
+struct TileLds {
+    uint32_t ci[HW * HW];
+    double cx[HW * HW], cy[HW * HW];      // outgoing contributions (tile + halo)
+    uint32_t pend[HW * HW];               // unfinished upstream cells (tile cells only)
+    uint8_t state[HW * HW];               // 0 open, 1 final before this pass / outside, 2 finished in this pass
+    double p[TT * TT], area[TT * TT];
+    uint16_t list[2][TT * TT];            // ready lists (current / next round)
+    double a0[TT];                        // cell area of the tile's rows
+    int n[2];
+    int open_cells;
+};
+
+// the on-chip part runs on ONE wavefront: a round is a handful of LDS operations on (typically) a few
+// ready cells, and a workgroup barrier per round costs more than the round itself
+__device__ __forceinline__ void tile_wave_sync()
 {
-    __shared__ uint32_t s_ci[HW * HW];
-    __shared__ double s_cx[HW * HW], s_cy[HW * HW];   // outgoing contributions (tile + halo)
-    __shared__ uint32_t s_pend[HW * HW];              // unfinished upstream cells (tile cells only)
-    __shared__ uint8_t s_state[HW * HW];              // 0 open, 1 final before this pass / outside, 2 finished in this pass
-    __shared__ double s_p[TT * TT], s_area[TT * TT];
-    __shared__ uint16_t s_list[TT * TT];
-    __shared__ int s_n;
-    const int per = (tiles_total + 7) >> 3;
-    const int tid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);      // XCD-contiguous bands of tiles
-    if (tid >= tiles_total || tile_done[tid]) return;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct TileNext {            // LISTED passes: tiles that must run again in the next pass
+    int32_t *flag;           // per tile: last pass it was listed for
+    int32_t *list, *count;
+};
+
+template <bool LISTED>
+__device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileLds &L, uint32_t pass, int tiles_x, int tid,
+                                               uint8_t *__restrict__ tile_done, int32_t *n_final, const TileNext &N)
+{
     const int by = tid / tiles_x, bx = tid - by * tiles_x;
     const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
     const int LOFF[8] = {-HW - 1, -HW, -HW + 1, -1, 1, HW - 1, HW, HW + 1};
@@ -592,9 +610,10 @@ __global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass,
             st = (lv >= 1 && lv < pass);
             if (st) { const double2 o = A.contrib[g]; cx = o.x; cy = o.y; }
         }
-        s_ci[idx] = cw; s_state[idx] = st; s_cx[idx] = cx; s_cy[idx] = cy;
+        L.ci[idx] = cw; L.state[idx] = st; L.cx[idx] = cx; L.cy[idx] = cy;
     }
-    if (threadIdx.x == 0) s_n = 0;
+    if (threadIdx.x == 0) { L.n[0] = 0; L.n[1] = 0; L.open_cells = 0; }
+    if (threadIdx.x < TT) L.a0[threadIdx.x] = i0 + (int)threadIdx.x < n ? A.a0[i0 + threadIdx.x] : 0.0;
     __syncthreads();
     // ---- per-cell setup: proportion, and how many upstream cells are still open
     for (int cell = threadIdx.x; cell < TT * TT; cell += 256) {
@@ -602,127 +621,181 @@ __global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass,
         const int gi = i0 + li - 1, gj = j0 + lj - 1;
         uint32_t pend = 0;
         double pv = 0.0;
-        if (gi < n && gj < m && !s_state[idx]) {
-            const uint32_t cw = s_ci[idx];
+        if (gi < n && gj < m && !L.state[idx] && !(A.dbg & 2)) {
+            const uint32_t cw = L.ci[idx];
             const int32_t c = gi * m + gj;
             pv = A.prop[c];
 #pragma unroll
             for (int d = 0; d < 8; d++)
-                if ((cw & (1u << d)) && !s_state[idx + LOFF[d]]) pend++;
+                if ((cw & (1u << d)) && !L.state[idx + LOFF[d]]) pend++;
             if (cw & CI_PIT_IN)                                     // pit -> drain edges are short: most sources sit in this tile
                 for (int32_t e = pit_stash(A, c).x; e < A.n_pit && A.pin_dst[e] == c; e++) {
                     const int32_t sc = A.pin_src[e];
                     const int si = sc / m - i0, sj = sc % m - j0;
                     if (si >= 0 && si < TT && sj >= 0 && sj < TT) {
-                        if (!s_state[(si + 1) * HW + sj + 1]) pend++;          // released on chip when the pit finishes
+                        if (!L.state[(si + 1) * HW + sj + 1]) pend++;          // released on chip when the pit finishes
                     } else {
                         const uint32_t lv = ci_level(A.cinfo[sc]);
                         if (!(lv >= 1 && lv < pass)) pend += 64;               // another tile's business: blocked for this pass
                     }
                 }
-            if (pend == 0) s_list[atomicAdd(&s_n, 1)] = (uint16_t)cell;
+            if (pend == 0) L.list[0][atomicAdd(&L.n[0], 1)] = (uint16_t)cell;
         }
-        s_pend[idx] = pend;
-        s_p[cell] = pv;
+        L.pend[idx] = pend;
+        L.p[cell] = pv;
     }
     __syncthreads();
-    // ---- rounds on chip: the ready list is processed, targets whose last upstream cell just finished
-    // form the next list.  Work per round is proportional to the cells that are ready, not to the tile.
-    __shared__ uint16_t s_next[TT * TT];
-    __shared__ int s_nn;
+    // ---- rounds on chip (wavefront 0): the ready list is processed, targets whose last upstream cell just
+    // finished form the next list.  Work per round is proportional to the cells that are ready, not to the tile.
     int32_t finalized = 0;
-    for (;;) {
-        const int nl = s_n;
-        if (nl == 0) break;
-        if (threadIdx.x == 0) s_nn = 0;
-        __syncthreads();
-        for (int k = threadIdx.x; k < nl; k += 256) {
-            const int cell = s_list[k];
-            const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
-            const int gi = i0 + li - 1, gj = j0 + lj - 1;
-            const int32_t c = gi * m + gj;
-            const uint32_t cw = s_ci[idx];
-            double a = A.a0[gi];
-            bool td = (gi == 0 || gi == n - 1 || gj == 0 || gj == m - 1) && A.todo_work[c] != 0;
+    if (threadIdx.x < 64 && !(A.dbg & 1)) {
+        int cur = 0;
+        for (;;) {
+            const int nl = L.n[cur];
+            if (nl == 0) break;
+            const int nxt = cur ^ 1;
+            for (int k = threadIdx.x; k < nl; k += 64) {
+                const int cell = L.list[cur][k];
+                const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
+                const int gi = i0 + li - 1, gj = j0 + lj - 1;
+                const int32_t c = gi * m + gj;
+                const uint32_t cw = L.ci[idx];
+                double a = L.a0[li - 1];
+                bool td = (gi == 0 || gi == n - 1 || gj == 0 || gj == m - 1) && A.todo_work[c] != 0;
 #pragma unroll
-            for (int d = 0; d < 8; d++) {
-                if (cw & (1u << d)) {
-                    const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
-                    const double x = cardinal ? s_cx[idx + LOFF[d]] : s_cy[idx + LOFF[d]];
-                    a += fabs(x);
-                    td = td || (x < 0);
-                }
-            }
-            if (cw & CI_PIT_IN)
-                for (int32_t e = pit_stash(A, c).x; e < A.n_pit && A.pin_dst[e] == c; e++) {
-                    const int32_t sc = A.pin_src[e];
-                    const int si = sc / m - i0, sj = sc % m - j0;
-                    if (si >= 0 && si < TT && sj >= 0 && sj < TT && s_state[(si + 1) * HW + sj + 1] == 2) {
-                        const double sa = s_area[si * TT + sj];               // finished in this pass: still on chip
-                        a += fabs(sa) * A.pin_w[e];
-                        td = td || (sa < 0);
-                    } else {
-                        a += A.area[sc] * A.pin_w[e];
-                        td = td || (A.todo_work[sc] != 0);
+                for (int d = 0; d < 8; d++) {
+                    if (cw & (1u << d)) {
+                        const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
+                        const double x = cardinal ? L.cx[idx + LOFF[d]] : L.cy[idx + LOFF[d]];
+                        a += fabs(x);
+                        td = td || (x < 0);
                     }
                 }
-            double ox = 0.0, oy = 0.0;
-            if (cw & (CI_OUT1 | CI_OUT2)) {
-                const double p = s_p[cell];
-                if (cw & CI_OUT1) ox = a * p;
-                if (cw & CI_OUT2) oy = a * (1 - p);
-                if (td) { ox = -ox; oy = -oy; }
-            }
-            s_cx[idx] = ox; s_cy[idx] = oy; s_area[cell] = td ? -a : a;   // sign of the stored area carries the taint
-            s_state[idx] = 2;
-            finalized++;
-            // release the targets inside the tile
-            const int sct = ci_section(cw);
-            if (cw & CI_OUT1) {
-                const int ti = li + fe1r(sct), tj = lj + fe1c(sct);
-                if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && atomicSub(&s_pend[ti * HW + tj], 1u) == 1u)
-                    s_next[atomicAdd(&s_nn, 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
-            }
-            if (cw & CI_OUT2) {
-                const int ti = li + fe2r(sct), tj = lj + fe2c(sct);
-                if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && atomicSub(&s_pend[ti * HW + tj], 1u) == 1u)
-                    s_next[atomicAdd(&s_nn, 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
-            }
-            if (cw & CI_PIT_OUT)
-                for (int32_t e = pit_stash(A, c).y; e < A.n_pit && A.pit_src[e] == c; e++) {
-                    const int32_t dc = A.pit_dst[e];
-                    const int ti = dc / m - i0 + 1, tj = dc % m - j0 + 1;
-                    if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && !s_state[ti * HW + tj]
-                        && atomicSub(&s_pend[ti * HW + tj], 1u) == 1u)
-                        s_next[atomicAdd(&s_nn, 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
+                if (cw & CI_PIT_IN)
+                    for (int32_t e = pit_stash(A, c).x; e < A.n_pit && A.pin_dst[e] == c; e++) {
+                        const int32_t sc = A.pin_src[e];
+                        const int si = sc / m - i0, sj = sc % m - j0;
+                        if (si >= 0 && si < TT && sj >= 0 && sj < TT && L.state[(si + 1) * HW + sj + 1] == 2) {
+                            const double sa = L.area[si * TT + sj];               // finished in this pass: still on chip
+                            a += fabs(sa) * A.pin_w[e];
+                            td = td || (sa < 0);
+                        } else {
+                            a += A.area[sc] * A.pin_w[e];
+                            td = td || (A.todo_work[sc] != 0);
+                        }
+                    }
+                double ox = 0.0, oy = 0.0;
+                if (cw & (CI_OUT1 | CI_OUT2)) {
+                    const double p = L.p[cell];
+                    if (cw & CI_OUT1) ox = a * p;
+                    if (cw & CI_OUT2) oy = a * (1 - p);
+                    if (td) { ox = -ox; oy = -oy; }
                 }
+                L.cx[idx] = ox; L.cy[idx] = oy; L.area[cell] = td ? -a : a;   // sign of the stored area carries the taint
+                L.state[idx] = 2;
+                finalized++;
+                // release the targets inside the tile
+                const int sct = ci_section(cw);
+                if (cw & CI_OUT1) {
+                    const int ti = li + fe1r(sct), tj = lj + fe1c(sct);
+                    if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && atomicSub(&L.pend[ti * HW + tj], 1u) == 1u)
+                        L.list[nxt][atomicAdd(&L.n[nxt], 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
+                }
+                if (cw & CI_OUT2) {
+                    const int ti = li + fe2r(sct), tj = lj + fe2c(sct);
+                    if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && atomicSub(&L.pend[ti * HW + tj], 1u) == 1u)
+                        L.list[nxt][atomicAdd(&L.n[nxt], 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
+                }
+                if (cw & CI_PIT_OUT)
+                    for (int32_t e = pit_stash(A, c).y; e < A.n_pit && A.pit_src[e] == c; e++) {
+                        const int32_t dc = A.pit_dst[e];
+                        const int ti = dc / m - i0 + 1, tj = dc % m - j0 + 1;
+                        if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && !L.state[ti * HW + tj]
+                            && atomicSub(&L.pend[ti * HW + tj], 1u) == 1u)
+                            L.list[nxt][atomicAdd(&L.n[nxt], 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
+                    }
+            }
+            tile_wave_sync();
+            if (threadIdx.x == 0) L.n[cur] = 0;
+            cur = nxt;
+            tile_wave_sync();
         }
-        __syncthreads();
-        const int nn = s_nn;
-        for (int k = threadIdx.x; k < nn; k += 256) s_list[k] = s_next[k];
-        if (threadIdx.x == 0) s_n = nn;
-        __syncthreads();
     }
+    __syncthreads();
     // ---- write back what this pass finished (consecutive threads own consecutive cells)
     int open_cells = 0;
     for (int cell = threadIdx.x; cell < TT * TT; cell += 256) {
         const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
         const int gi = i0 + li - 1, gj = j0 + lj - 1;
         if (gi >= n || gj >= m) continue;
-        const uint8_t st = s_state[idx];
+        const uint8_t st = L.state[idx];
         if (st == 0) { open_cells = 1; continue; }
         if (st != 2) continue;
         const int32_t c = gi * m + gj;
-        const double a = s_area[cell];
+        const double a = L.area[cell];
+        const uint32_t cw = L.ci[idx];
+        if (LISTED) {
+            // targets outside the tile may be ready now: their tiles run in the next pass.  (Listing a tile whose
+            // cell turns out to wait for somebody else costs one idle staging; whoever finishes last lists it again.)
+            auto wake = [&](int ti, int tj) {
+                if (ti < 0 || ti >= n || tj < 0 || tj >= m) return;
+                const int tt = (ti / TT) * tiles_x + tj / TT;
+                if (tt == tid) return;
+                if (atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tt;
+            };
+            const int sct = ci_section(cw);
+            if (cw & CI_OUT1) wake(gi + fe1r(sct), gj + fe1c(sct));
+            if (cw & CI_OUT2) wake(gi + fe2r(sct), gj + fe2c(sct));
+            if (cw & CI_PIT_OUT)        // the slot still holds the edge offsets: the area is written just below
+                for (int32_t e = pit_stash(A, c).y; e < A.n_pit && A.pit_src[e] == c; e++) wake(A.pit_dst[e] / m, A.pit_dst[e] % m);
+        }
         A.area[c] = fabs(a);
-        A.contrib[c] = make_double2(s_cx[idx], s_cy[idx]);
-        A.cinfo[c] = ci_with_level(s_ci[idx], pass);
+        A.contrib[c] = make_double2(L.cx[idx], L.cy[idx]);
+        A.cinfo[c] = ci_with_level(cw, pass);
         if (a < 0) A.todo_work[c] = 1;
     }
-    const int still_open = __syncthreads_or(open_cells);
+    if (open_cells) L.open_cells = 1;
     for (int off = 32; off > 0; off >>= 1) finalized += __shfl_down(finalized, off);
-    if ((threadIdx.x & 63) == 0 && finalized) atomicAdd(n_final, finalized);
-    if (threadIdx.x == 0 && !still_open) tile_done[tid] = 1;
+    if (threadIdx.x == 0 && finalized) atomicAdd(n_final, finalized);
+    __syncthreads();
+    if (threadIdx.x == 0 && !L.open_cells) tile_done[tid] = 1;
+}
+
+// pass 1: every tile, XCD-contiguous bands of tiles
+__global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total,
+                                                     uint8_t *__restrict__ tile_done, int32_t *n_final)
+{
+    __shared__ TileLds L;
+    const int per = (tiles_total + 7) >> 3;
+    const int tid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tid >= tiles_total || tile_done[tid]) return;
+    TileNext N; N.flag = nullptr; N.list = nullptr; N.count = nullptr;
+    sweep_one_tile<false>(A, L, pass, tiles_x, tid, tile_done, n_final, N);
+}
+
+// later passes: only the listed tiles (those a finished cell of the previous pass drains into); lists the next ones
+__global__ __launch_bounds__(256) void k_sweep_tiles_listed(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
+                                                            const int32_t *n_in, uint8_t *__restrict__ tile_done, int32_t *n_final,
+                                                            TileNext N, int32_t *clear_count)
+{
+    __shared__ TileLds L;
+    const int32_t nt = *n_in;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *clear_count = 0;      // the list of the pass after the next one
+    for (int32_t k = blockIdx.x; k < nt; k += gridDim.x) {
+        sweep_one_tile<true>(A, L, pass, tiles_x, list_in[k], tile_done, n_final, N);
+        __syncthreads();
+    }
+}
+
+// switch from queue rounds to listed tile passes: the tiles that hold the current frontier
+__global__ void k_tiles_of_frontier(const QE *__restrict__ q, const int32_t *nq, int m, int tiles_x, int32_t stamp, TileNext N)
+{
+    const int32_t n = *nq;
+    for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const int32_t c = q[k].c;
+        const int tt = (c / m / TT) * tiles_x + (c % m) / TT;
+        if (atomicExch(&N.flag[tt], stamp) != stamp) N.list[atomicAdd(N.count, 1)] = tt;
+    }
 }
 
 // after the tile passes: cells that are not final but whose upstream cells all are form the first
@@ -805,17 +878,29 @@ __global__ __launch_bounds__(256) void k_twi(const double *__restrict__ uca, con
 // built by pydem_uca is still resident and is reused.  Only cells downstream of the seeds are
 // touched: stamp[c] == epoch marks membership, so nothing of size NN is cleared per round except
 // the two byte masks that are outputs.
+// Per-cell state of a round lives in two words that are ZERO between rounds (the cells a round touched
+// are on its lists and are wiped at its end, so nothing of size NN is cleared per round):
+//   flag[c]   EF_S reached from a seed (or a seed), EF_SEED, EF_T visited by the todo flood, EF_DONE swept
+//   cinfo[c]  the level field (unused after the main sweep) counts the in-edges of c that come from
+//             reached cells; bit 31 marks the seeds.  The reach flood increments it once per edge it
+//             walks, the sweep decrements it once per edge it has pulled over: a cell is ready when
+//             its count returns to zero -- textbook Kahn, but only on the few thousand cells downstream
+//             of an edge, and every step of a level is ONE batch of independent loads/atomics.
+constexpr uint32_t EF_S = 1u, EF_SEED = 2u, EF_T = 4u, EF_DONE = 8u;
+constexpr uint32_t CI_ESEED = 1u << 31, CI_EONE = 1u << CI_LEVEL_SHIFT;
+__device__ __forceinline__ uint32_t ci_ecount(uint32_t w) { return (w >> CI_LEVEL_SHIFT) & 0xFFFFu; }
+
 struct EdgeArgs {
-    SweepArgs G;             // graph (area/todo_work/level are re-pointed: see stage_edge_update)
-    int32_t *stamp;          // [NN] epoch stamps: (epoch << 2) | bit1 reached-or-seed
-    double *delta;           // [NN] area delta of this round (valid where stamped)
+    SweepArgs G;             // graph
+    uint32_t *flag;          // [NN]
+    double *delta;           // [NN] area delta of this round (valid where EF_DONE)
     const uint8_t *flats;
     uint8_t *edge_done;      // output mask
-    int32_t epoch;
     // perimeter tables, index p: top row (m), bottom row (m), left col rows 1..n-2, right col rows 1..n-2
     uint8_t *p_done, *p_seed;
     double *p_delta;
-    int32_t *rlist, *rcount; // cells whose uca must be updated at the end
+    int32_t *rlist, *rcount; // reached cells (seeds first): their uca is updated at the end
+    int32_t *tlist, *tcount; // cells whose edge_done byte this round cleared
 };
 
 __device__ __forceinline__ int64_t perim_index(int i, int j, int n, int m)
@@ -838,11 +923,36 @@ __device__ __forceinline__ double edge_base(const EdgeArgs &E, int32_t c)
     return 0.0;
 }
 
+// one list slot per calling lane, one atomic per wavefront (works in divergent code: the ballot is
+// over the lanes that are executing the call)
+__device__ __forceinline__ int32_t agg_slot(int32_t *count)
+{
+    const unsigned long long bal = __ballot(true);
+    const int lane = (int)__lane_id();
+    const int leader = __ffsll((long long)bal) - 1;
+    int32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (int32_t)__popcll(bal));
+    base = __shfl(base, leader);
+    return base + __popcll(bal & ((1ull << lane) - 1ull));
+}
+
+__global__ void k_edge_clear_levels(uint32_t *__restrict__ cinfo, int64_t NN)
+{
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < NN; c += (int64_t)gridDim.x * blockDim.x)
+        cinfo[c] &= CI_STATIC_MASK;
+}
+
+// undo the previous round's edge_done = 0 bytes (the mask is rebuilt from all-True every round, :812)
+__global__ void k_edge_restore(const int32_t *__restrict__ tlist, int32_t n, uint8_t *__restrict__ edge_done)
+{
+    for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) edge_done[tlist[k]] = 1;
+}
+
 // strips -> per-perimeter-cell state (:726-739, :798-809); seeds start the reach flood, cells
 // that stay 'todo' start the todo flood
 __global__ void k_edge_init(EdgeArgs E, const double *__restrict__ sdata, const uint8_t *__restrict__ sdone,
                             const uint8_t *__restrict__ stodo, int L, const double *__restrict__ uca,
-                            uint8_t *__restrict__ edge_todo, int32_t *q_seed, int32_t *n_seed, int32_t *q_todo, int32_t *n_todo)
+                            uint8_t *__restrict__ edge_todo, QE *q_flood, int32_t *n_flood, QE *q_seed, int32_t *n_seed)
 {
     const int n = E.G.n, m = E.G.m;
     const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
@@ -868,153 +978,145 @@ __global__ void k_edge_init(EdgeArgs E, const double *__restrict__ sdata, const 
     E.p_seed[p] = seed;
     E.p_delta[p] = dn ? init - uca[c] : 0.0;                                     // :806-809
     edge_todo[c] = todo_out;                                                     // returned as edge_todo_i (:817, :862)
-    if (todo_out) { E.edge_done[c] = 0; q_todo[atomicAdd(n_todo, 1)] = c; }
+    if (todo_out) {
+        E.edge_done[c] = 0;
+        E.flag[c] = EF_T;
+        E.tlist[agg_slot(E.tcount)] = c;
+        QE q; q.c = c; q.cw = (E.G.cinfo[c] & CI_STATIC_MASK) | (1u << 31);     // bit 31 of a flood entry: todo flood
+        q_flood[agg_slot(n_flood)] = q;
+    }
     if (seed) {
-        E.stamp[c] = (E.epoch << 2) | 2;
-        E.G.cinfo[c] = ci_with_level(E.G.cinfo[c], 0);
-        q_seed[atomicAdd(n_seed, 1)] = c;
-        E.rlist[atomicAdd(E.rcount, 1)] = c;
+        const uint32_t cw = E.G.cinfo[c] & CI_STATIC_MASK;
+        E.flag[c] = EF_S | EF_SEED;
+        E.G.cinfo[c] = cw | CI_ESEED;
+        E.rlist[agg_slot(E.rcount)] = c;
+        QE q; q.c = c; q.cw = cw;
+        q_flood[agg_slot(n_flood)] = q;
+        q.cw = cw | CI_ESEED;                                                    // bit 31 of a sweep entry: seed
+        q_seed[agg_slot(n_seed)] = q;
     }
 }
 
-template <typename F>
-__device__ __forceinline__ void for_each_target(const SweepArgs &A, int32_t c, F f)
-{
-    const uint32_t cw = A.cinfo[c];
-    const int s = ci_section(cw);
-    if (cw & CI_OUT1) f(c + fe1r(s) * A.m + fe1c(s));
-    if (cw & CI_OUT2) f(c + fe2r(s) * A.m + fe2c(s));
-    if (cw & CI_PIT_OUT)
-        for (int32_t e = pit_first(A.pit_src, A.pout_blk, c); e < A.n_pit && A.pit_src[e] == c; e++) f(A.pit_dst[e]);
-}
-
-// breadth-first flood along out-edges.  MODE 0: mark cells downstream of the seeds (done = False,
-// :820-825) and prepare their delta/level; MODE 1: propagate edge_todo (:848-853)
-template <int MODE, typename Push>
-__device__ __forceinline__ void edge_flood_cell(const EdgeArgs &E, int32_t u, Push push)
-{
-    const int32_t tag = ((E.epoch + MODE) << 2) | 2;
-    for_each_target(E.G, u, [&](int32_t t) {
-        const int32_t old = atomicExch(&E.stamp[t], tag);
-        if (old == tag) return;
-        if (MODE == 0) {
-            E.G.cinfo[t] = ci_with_level(E.G.cinfo[t], CI_LEVEL_INF);
-            E.rlist[atomicAdd(E.rcount, 1)] = t;
-        } else {
-            E.edge_done[t] = 0;                                              // edge_done = ~edge_todo (:856)
-        }
-        push(t);
-    });
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256) void k_edge_flood(EdgeArgs E, const int32_t *__restrict__ qc, int32_t *__restrict__ qn,
-                                                    int32_t *cnt3, int r)
-{
-    const int32_t nq = cnt3[r % 3];
-    if (blockIdx.x == 0 && threadIdx.x == 0) cnt3[(r + 2) % 3] = 0;
-    if (nq == 0) return;
-    int32_t *cn = &cnt3[(r + 1) % 3];
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x)
-        edge_flood_cell<MODE>(E, qc[q], [&](int32_t t) { qn[atomicAdd(cn, 1)] = t; });
-}
-
-__device__ __forceinline__ bool edge_in_set(const EdgeArgs &E, int32_t v) { return E.stamp[v] == ((E.epoch << 2) | 2); }
-
-// ownership test restricted to the stamped sub-graph (unstamped upstream cells count as done)
-__device__ __forceinline__ bool edge_owns(const EdgeArgs &E, int32_t t, int32_t u, uint32_t r, uint32_t &ct)
-{
-    const SweepArgs &A = E.G;
-    ct = A.cinfo[t];
-    int32_t owner = -1;
-    bool ready = true;
-#pragma unroll
-    for (int d = 0; d < 8; d++) {
-        if (ct & (1u << d)) {
-            const int32_t v = t + NB_DI[d] * A.m + NB_DJ[d];
-            if (!edge_in_set(E, v)) continue;
-            const uint32_t lv = (v == u) ? r : ci_level(A.cinfo[v]);
-            ready = ready && (lv <= r);
-            if (lv == r) owner = v > owner ? v : owner;
-        }
-    }
-    if (ct & CI_PIT_IN)
-        for (int32_t e = pit_first(A.pin_dst, A.pin_blk, t); e < A.n_pit && A.pin_dst[e] == t; e++) {
-            const int32_t v = A.pin_src[e];
-            if (!edge_in_set(E, v)) continue;
-            const uint32_t lv = (v == u) ? r : ci_level(A.cinfo[v]);
-            ready = ready && (lv <= r);
-            if (lv == r) owner = v > owner ? v : owner;
-        }
-    return ready && owner == u;
-}
-
-// seeded sweep (drain_area with skip_edge=False on the flooded sub-graph, :836-842): round 0 =
-// seeds (their delta is the edge value itself), later rounds pull from stamped upstream cells
+// Both floods in one breadth-first loop (entry bit 31: 0 = reach flood from the seeds, 1 = todo flood).
+// Reach (:820-825): every edge walked bumps the target's count; the first visitor lists the target and
+// expands it next level.  Todo (:848-853): edge_done = False downstream of the cells that stay 'todo'.
 template <typename Push>
-__device__ __forceinline__ void edge_sweep_cell(const EdgeArgs &E, int32_t c, int r, Push push)
+__device__ __forceinline__ void edge_flood_cell(const EdgeArgs &E, QE q, Push push)
 {
     const SweepArgs &A = E.G;
-    double acc = edge_base(E, c);
-    if (r > 0) {
-        const uint32_t im = A.cinfo[c];
-#pragma unroll
-        for (int d = 0; d < 8; d++) {
-            if (im & (1u << d)) {
-                const int32_t u = c + NB_DI[d] * A.m + NB_DJ[d];
-                if (!edge_in_set(E, u)) continue;
-                const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
-                const double pu = A.prop[u];
-                acc += E.delta[u] * (cardinal ? pu : 1 - pu);
+    const int32_t u = q.c;
+    const uint32_t cw = q.cw;
+    const bool todo = (cw >> 31) != 0;
+    const int s = ci_section(cw);
+    auto visit = [&](int32_t t) {
+        const uint32_t ct = A.cinfo[t];
+        if (!todo) {
+            const uint32_t old = atomicOr(&E.flag[t], EF_S);
+            atomicAdd(&A.cinfo[t], CI_EONE);
+            if (!(old & EF_S)) {
+                E.rlist[agg_slot(E.rcount)] = t;
+                push(t, ct & CI_STATIC_MASK);
+            }
+        } else {
+            const uint32_t old = atomicOr(&E.flag[t], EF_T);
+            if (!(old & EF_T)) {
+                E.edge_done[t] = 0;                                              // edge_done = ~edge_todo (:856)
+                E.tlist[agg_slot(E.tcount)] = t;
+                push(t, (ct & CI_STATIC_MASK) | (1u << 31));
             }
         }
-        if (im & CI_PIT_IN)
-            for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++)
-                if (edge_in_set(E, A.pin_src[e])) acc += E.delta[A.pin_src[e]] * A.pin_w[e];
-    }
-    E.delta[c] = acc;
-    for_each_target(A, c, [&](int32_t t) {
-        // seeds never receive: a done cell on the tile edge is skipped (cyutils.pyx:159-161)
-        if (edge_in_set(E, t) && ci_level(A.cinfo[t]) == 0) return;
-        uint32_t ct;
-        if (edge_owns(E, t, c, (uint32_t)r, ct)) { A.cinfo[t] = ci_with_level(ct, (uint32_t)r + 1); push(t); }
-    });
+    };
+    if (cw & CI_OUT1) visit(u + fe1r(s) * A.m + fe1c(s));
+    if (cw & CI_OUT2) visit(u + fe2r(s) * A.m + fe2c(s));
+    if (cw & CI_PIT_OUT)
+        for (int32_t e = pit_first(A.pit_src, A.pout_blk, u); e < A.n_pit && A.pit_src[e] == u; e++) visit(A.pit_dst[e]);
 }
 
-__global__ __launch_bounds__(256) void k_edge_sweep(EdgeArgs E, const int32_t *__restrict__ qc, int32_t *__restrict__ qn,
-                                                    int32_t *cnt3, int r)
+// Seeded sweep (drain_area with skip_edge=False on the flooded sub-graph, :836-842).  Seeds keep the
+// edge value itself (a done cell on the tile edge never receives, cyutils.pyx:159-161); every other
+// cell pulls from its reached upstream cells in the fixed neighbour order.  All loads and the
+// count-down atomics on the targets depend only on the queue entry: one memory round trip per level.
+template <typename Push>
+__device__ __forceinline__ void edge_sweep_cell(const EdgeArgs &E, QE q, Push push)
+{
+    const SweepArgs &A = E.G;
+    const int32_t c = q.c;
+    const uint32_t cw = q.cw;
+    const int m = A.m;
+    const bool seed = (cw & CI_ESEED) != 0;
+    uint32_t f[8]; double dl[8], pr[8];
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+        const bool has = !seed && (cw & (1u << d));
+        const int32_t u = has ? c + NB_DI[d] * m + NB_DJ[d] : c;
+        f[d] = E.flag[u]; dl[d] = E.delta[u]; pr[d] = A.prop[u];
+    }
+    const int s = ci_section(cw);
+    int32_t t1 = -1, t2 = -1;
+    uint32_t o1 = 0, o2 = 0;
+    if (cw & CI_OUT1) { t1 = c + fe1r(s) * m + fe1c(s); o1 = atomicSub(&A.cinfo[t1], CI_EONE); }
+    if (cw & CI_OUT2) { t2 = c + fe2r(s) * m + fe2c(s); o2 = atomicSub(&A.cinfo[t2], CI_EONE); }
+    double acc = edge_base(E, c);
+    if (!seed) {
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            if ((cw & (1u << d)) && (f[d] & EF_S)) {
+                const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
+                acc += dl[d] * (cardinal ? pr[d] : 1 - pr[d]);
+            }
+        }
+        if (cw & CI_PIT_IN)
+            for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++)
+                if (E.flag[A.pin_src[e]] & EF_S) acc += E.delta[A.pin_src[e]] * A.pin_w[e];
+    }
+    E.delta[c] = acc;
+    atomicOr(&E.flag[c], EF_DONE);
+    if (t1 >= 0 && ci_ecount(o1) == 1u && !(o1 & CI_ESEED)) push(t1, o1 & CI_STATIC_MASK);
+    if (t2 >= 0 && ci_ecount(o2) == 1u && !(o2 & CI_ESEED)) push(t2, o2 & CI_STATIC_MASK);
+    if (cw & CI_PIT_OUT)
+        for (int32_t e = pit_first(A.pit_src, A.pout_blk, c); e < A.n_pit && A.pit_src[e] == c; e++) {
+            const int32_t t = A.pit_dst[e];
+            const uint32_t o = atomicSub(&A.cinfo[t], CI_EONE);
+            if (ci_ecount(o) == 1u && !(o & CI_ESEED)) push(t, o & CI_STATIC_MASK);
+        }
+}
+
+// one level, many workgroups (large frontiers); counters rotate over 3 slots as in the main sweep
+template <int WHICH>   // 0 floods, 1 sweep
+__global__ __launch_bounds__(256) void k_edge_level(EdgeArgs E, const QE *__restrict__ qc, QE *__restrict__ qn, int32_t *cnt3, int r)
 {
     const int32_t nq = cnt3[r % 3];
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt3[(r + 2) % 3] = 0;
     if (nq == 0) return;
     int32_t *cn = &cnt3[(r + 1) % 3];
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x)
-        edge_sweep_cell(E, qc[q], r, [&](int32_t t) { qn[atomicAdd(cn, 1)] = t; });
+    for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nq; k += gridDim.x * blockDim.x) {
+        auto push = [&](int32_t t, uint32_t ct) { QE e; e.c = t; e.cw = ct; qn[agg_slot(cn)] = e; };
+        if (WHICH == 0) edge_flood_cell(E, qc[k], push);
+        else edge_sweep_cell(E, qc[k], push);
+    }
 }
 
-// Small frontiers: ONE workgroup runs round after round without going back to the host -- a
-// dependent kernel boundary costs ~1.5-5 us and the floods/sweeps downstream of an edge seed are long
-// thin chains (hundreds of rounds of a few cells).  All traffic stays inside one CU, whose L1 is
-// coherent for its own waves, so __syncthreads() is the only synchronisation needed.  The kernel
-// stops when the frontier is empty or outgrows SMALL_CAP and reports where it stopped.
+// Small frontiers: ONE workgroup runs level after level without going back to the host (a kernel
+// boundary costs a launch plus a trip across the fabric for every first access; the floods and sweeps
+// downstream of an edge are hundreds of levels of a few cells).  Stops when the frontier is empty
+// or outgrows SMALL_CAP and reports where it stopped.
 constexpr int SMALL_CAP = 4096;
 
-template <int WHICH>   // 0 reach flood, 1 seeded sweep, 2 todo flood
-__global__ __launch_bounds__(1024) void k_edge_small(EdgeArgs E, int32_t *q0, int32_t *q1, int32_t *cnt3, int r_start, int32_t *state)
+template <int WHICH>
+__global__ __launch_bounds__(1024) void k_edge_small(EdgeArgs E, QE *q0, QE *q1, int32_t *cnt3, int r_start, int32_t *state)
 {
-    __shared__ int s_next;
+    __shared__ int32_t s_next;
     int r = r_start;
     int32_t nq = cnt3[r % 3];
     while (nq > 0 && nq <= SMALL_CAP) {
         if (threadIdx.x == 0) s_next = 0;
         __syncthreads();
-        const int32_t *qc = (r % 2) ? q1 : q0;
-        int32_t *qn = (r % 2) ? q0 : q1;
-        for (int32_t q = threadIdx.x; q < nq; q += blockDim.x) {
-            auto push = [&](int32_t t) { qn[atomicAdd(&s_next, 1)] = t; };
-            if (WHICH == 0) edge_flood_cell<0>(E, qc[q], push);
-            else if (WHICH == 1) edge_sweep_cell(E, qc[q], r, push);
-            else edge_flood_cell<1>(E, qc[q], push);
+        const QE *qc = (r % 2) ? q1 : q0;
+        QE *qn = (r % 2) ? q0 : q1;
+        for (int32_t k = threadIdx.x; k < nq; k += blockDim.x) {
+            auto push = [&](int32_t t, uint32_t ct) { QE e; e.c = t; e.cw = ct; qn[agg_slot(&s_next)] = e; };
+            if (WHICH == 0) edge_flood_cell(E, qc[k], push);
+            else edge_sweep_cell(E, qc[k], push);
         }
         __syncthreads();
         nq = s_next;
@@ -1027,18 +1129,18 @@ __global__ __launch_bounds__(1024) void k_edge_small(EdgeArgs E, int32_t *q0, in
     }
 }
 
-// self.uca += area (:769) on the touched cells, plus the finished edge cells the flood never reached
+// self.uca += area (:769) on the reached cells
 __global__ void k_edge_apply(EdgeArgs E, double *__restrict__ uca, const int32_t *nr)
 {
     const int32_t n = *nr;
     for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
         const int32_t c = E.rlist[q];
         // cells the sweep never reached (cyclic drainage) keep their initial value, like the reference
-        const bool processed = ci_level(E.G.cinfo[c]) != CI_LEVEL_INF;
-        uca[c] += processed ? E.delta[c] : edge_base(E, c);
+        uca[c] += (E.flag[c] & EF_DONE) ? E.delta[c] : edge_base(E, c);
     }
 }
 
+// ... plus the finished edge cells the flood never reached
 __global__ void k_edge_apply_perimeter(EdgeArgs E, double *__restrict__ uca)
 {
     const int n = E.G.n, m = E.G.m;
@@ -1051,7 +1153,18 @@ __global__ void k_edge_apply_perimeter(EdgeArgs E, double *__restrict__ uca)
     else if (p < 2 * (int64_t)m + (n - 2)) { i = (int)(p - 2 * (int64_t)m) + 1; j = 0; }
     else { i = (int)(p - 2 * (int64_t)m - (n - 2)) + 1; j = m - 1; }
     const int32_t c = i * m + j;
-    if (E.p_done[p] && !edge_in_set(E, c)) uca[c] += edge_base(E, c);
+    if (E.p_done[p] && !(E.flag[c] & EF_S)) uca[c] += edge_base(E, c);
+}
+
+// wipe the per-round state of every cell this round touched
+__global__ void k_edge_cleanup(EdgeArgs E, const int32_t *nr, const int32_t *nt)
+{
+    const int32_t n_r = *nr, n_t = *nt;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_r + n_t; q += gridDim.x * blockDim.x) {
+        const int32_t c = q < n_r ? E.rlist[q] : E.tlist[q - n_r];
+        E.flag[c] = 0;
+        if (q < n_r) E.G.cinfo[c] &= CI_STATIC_MASK;
+    }
 }
 
 int grid_for(int64_t work, int cap) { const int64_t g = cdiv(work, 256); return (int)(g < cap ? (g > 0 ? g : 1) : cap); }
@@ -1061,6 +1174,7 @@ int grid_for(int64_t work, int cap) { const int64_t g = cdiv(work, 256); return 
 int stage_section_graph(pydem_tile *t, const pydem_options *opt)
 {
     const int n = (int)t->n, m = (int)t->m;
+    t->edge_clean = false;
     PYDEM_TRY(tile_alloc(t, &t->todo_work, (size_t)t->NN));
     PYDEM_TRY(tile_alloc(t, &t->indeg, (size_t)t->NN));          // the cinfo words
     const int32_t nblk = (int32_t)(t->NN >> PIT_BLK_SHIFT) + 1;
@@ -1109,6 +1223,7 @@ static void fill_sweep_args(pydem_tile *t, SweepArgs &A)
     A.pout_blk = t->pit_blk; A.pin_blk = t->pit_blk ? t->pit_blk + nblk + 2 : nullptr;
     A.qcap = (int32_t)(t->NN / 2 < INT32_MAX ? t->NN / 2 : INT32_MAX);      // queue buffers hold NN ints = NN/2 entries
     A.err = t->counters + 15;
+    { const char *e = getenv("PYDEM_TILE_DEBUG"); A.dbg = e ? atoi(e) : 0; }
 }
 
 int stage_sweep(pydem_tile *t, const pydem_options *opt)
@@ -1130,13 +1245,20 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         hipLaunchKernelGGL(k_pit_stash, dim3(grid_for(A.n_pit, 2048)), dim3(256), 0, t->stream, A.pin_dst, A.pit_src, A.n_pit, t->uca);
     // ---- tile-local passes until they stop paying, then the queue rounds take over
     const int tiles_x = (int)cdiv(m, TT), tiles_total = tiles_x * (int)cdiv(n, TT);
-    if (t->scratch_bytes < (size_t)tiles_total) {
+    // scratch: tile_done bytes | per-tile "listed for pass" stamps | two tile lists
+    const size_t tiles_pad = ((size_t)tiles_total + 255) & ~(size_t)255;
+    const size_t scratch_need = tiles_pad * (1 + 4 + 4 + 4);
+    if (t->scratch_bytes < scratch_need) {
         if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->device_bytes -= (int64_t)t->scratch_bytes; }
-        HIP_TRY(hipMalloc(&t->scratch, (size_t)tiles_total));
-        t->scratch_bytes = (size_t)tiles_total; t->device_bytes += (int64_t)tiles_total;
+        HIP_TRY(hipMalloc(&t->scratch, scratch_need));
+        t->scratch_bytes = scratch_need; t->device_bytes += (int64_t)scratch_need;
     }
     uint8_t *tile_done = (uint8_t *)t->scratch;
-    HIP_TRY(hipMemsetAsync(tile_done, 0, (size_t)tiles_total, t->stream));
+    int32_t *tile_flag = (int32_t *)(tile_done + tiles_pad);
+    int32_t *tile_list[2] = {tile_flag + tiles_pad, tile_flag + 2 * tiles_pad};
+    int32_t *cntT = t->counters + 56;          // rotating tile-list sizes
+    HIP_TRY(hipMemsetAsync(tile_done, 0, tiles_pad * 5, t->stream));      // done bytes + stamps
+    HIP_TRY(hipMemsetAsync(cntT, 0, 4 * sizeof(int32_t), t->stream));
     int64_t launches = 0;
     uint32_t pass = 0;
     int64_t done_prev = 0;
@@ -1171,9 +1293,41 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "after rebuild: frontier %lld, processed %d of %lld\n", (long long)last, t->h_counters[3], (long long)t->NN);
     }
     (void)nsrc;
-    static int small_cap = -1;
+    static int small_cap = -1, tile_switch = -1;
     if (small_cap < 0) { const char *e = getenv("PYDEM_SWEEP_SMALL"); small_cap = e ? atoi(e) : SWEEP_SMALL_CAP; }
+    if (tile_switch < 0) { const char *e = getenv("PYDEM_SWEEP_TILE_SWITCH"); tile_switch = e ? atoi(e) : 20000; }
     while (last > 0) {
+        if (last <= tile_switch) {
+            // ---- the rivers: listed tile passes.  A queue round moves every river by ONE cell per kernel
+            // boundary; a listed pass moves it through a whole tile (the on-chip rounds) for the same boundary.
+            int p = r;
+            TileNext N;
+            N.flag = tile_flag; N.list = tile_list[p % 2]; N.count = &cntT[p % 3];
+            hipLaunchKernelGGL(k_tiles_of_frontier, dim3(grid_for(last, 256)), dim3(256), 0, t->stream, (const QE *)t->queue[r % 2],
+                               (const int32_t *)&cnt3[r % 3], m, tiles_x, (int32_t)p, N);
+            launches++;
+            int64_t ntiles = last;      // upper bound for the first batch
+            while (ntiles > 0) {
+                const int batch = 8;
+                const int grid = (int)(ntiles * 2 < 2048 ? (ntiles * 2 > 64 ? ntiles * 2 : 64) : 2048);
+                for (int b = 0; b < batch; b++, p++) {
+                    N.list = tile_list[(p + 1) % 2]; N.count = &cntT[(p + 1) % 3];
+                    hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), 0, t->stream, A, (uint32_t)p, tiles_x,
+                                       (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
+                                       &cntT[(p + 2) % 3]);
+                    launches++;
+                }
+                HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipStreamSynchronize(t->stream));
+                ntiles = t->h_counters[56 + p % 3];
+                if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "listed tile pass %d: %lld tiles listed next, processed %d\n", p, (long long)ntiles, t->h_counters[3]);
+                if (p > (int)CI_LEVEL_INF - 256) { pydem_set_error("flow paths longer than %u passes are not supported", CI_LEVEL_INF); return -5; }
+            }
+            t->tm.sweep_tile_passes += p - r;
+            r = p;
+            last = 0;
+            break;
+        }
         if (last <= small_cap && last <= SWEEP_SMALL_CAP) {
             // one workgroup, many rounds (until the frontier is empty or grows past SWEEP_SMALL_CAP)
             hipLaunchKernelGGL(k_sweep_small, dim3(1), dim3(1024), 0, t->stream, A, (QE *)t->queue[0], (QE *)t->queue[1], cnt3, r,
@@ -1241,27 +1395,51 @@ int stage_twi(pydem_tile *t, const pydem_options *opt)
     return 0;
 }
 
+static double host_now_ms()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *const data[4], const uint8_t *const done[4],
                       const uint8_t *const todo[4])
 {
     (void)opt;
+    const double t_begin = host_now_ms();
     const int n = (int)t->n, m = (int)t->m;
     PYDEM_TRY(tile_alloc(t, &t->row_area, (size_t)t->n));
     const int L = n > m ? n : m;
     const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
     PYDEM_TRY(tile_alloc(t, &t->estamp, (size_t)t->NN));
     PYDEM_TRY(tile_alloc(t, &t->edelta, (size_t)t->NN));
-    PYDEM_TRY(tile_alloc(t, &t->labels, (size_t)t->NN));
-    PYDEM_TRY(tile_alloc(t, &t->flatlist, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->labels, (size_t)t->NN));        // rlist
+    PYDEM_TRY(tile_alloc(t, &t->flatlist, (size_t)t->NN));      // tlist (kept until the next round restores the mask)
     PYDEM_TRY(tile_alloc(t, &t->queue[0], (size_t)t->NN));
     PYDEM_TRY(tile_alloc(t, &t->queue[1], (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->eseed, (size_t)(nper > 0 ? nper : 1) * 2));
     PYDEM_TRY(tile_alloc(t, &t->p_delta, (size_t)nper));
     PYDEM_TRY(tile_alloc(t, &t->p_flags, (size_t)nper * 2));
     PYDEM_TRY(tile_alloc(t, &t->s_data, (size_t)L * 4));
     PYDEM_TRY(tile_alloc(t, &t->s_flags, (size_t)L * 8));
-    if (t->eepoch == 0) HIP_TRY(hipMemsetAsync(t->estamp, 0, (size_t)t->NN * 4, t->stream));
-    t->eepoch += 2;
-    if (t->eepoch > (1 << 28)) { t->eepoch = 2; HIP_TRY(hipMemsetAsync(t->estamp, 0, (size_t)t->NN * 4, t->stream)); }
+    EdgeArgs E;
+    SweepArgs &A = E.G;
+    fill_sweep_args(t, A);
+    E.flag = (uint32_t *)t->estamp; E.delta = t->edelta; E.flats = t->flats; E.edge_done = t->edge_done;
+    E.p_done = t->p_flags; E.p_seed = t->p_flags + nper; E.p_delta = t->p_delta;
+    E.rlist = t->labels; E.rcount = t->counters + 6;
+    E.tlist = t->flatlist; E.tcount = t->counters + 7;
+    if (!t->edge_clean) {
+        // first round after the graph was (re)built: flags and counts to zero, masks to their defaults (:812, :817)
+        HIP_TRY(hipMemsetAsync(t->estamp, 0, (size_t)t->NN * 4, t->stream));
+        hipLaunchKernelGGL(k_edge_clear_levels, dim3(grid_for(t->NN, 8192)), dim3(256), 0, t->stream, A.cinfo, t->NN);
+        HIP_TRY(hipMemsetAsync(t->edge_todo, 0, (size_t)t->NN, t->stream));
+        HIP_TRY(hipMemsetAsync(t->edge_done, 1, (size_t)t->NN, t->stream));
+        t->edge_clean = true;
+    } else if (t->etodo_prev > 0) {
+        hipLaunchKernelGGL(k_edge_restore, dim3(grid_for(t->etodo_prev, 1024)), dim3(256), 0, t->stream, t->flatlist, t->etodo_prev,
+                           t->edge_done);
+    }
     // strips -> device (left, right, top, bottom), padded to L entries each
     std::vector<double> hd((size_t)L * 4, 0.0);
     std::vector<uint8_t> hf((size_t)L * 8, 0);
@@ -1276,74 +1454,62 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
     HIP_TRY(hipMemcpyAsync(t->s_data, hd.data(), hd.size() * 8, hipMemcpyHostToDevice, t->stream));
     HIP_TRY(hipMemcpyAsync(t->s_flags, hf.data(), hf.size(), hipMemcpyHostToDevice, t->stream));
     HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
-    HIP_TRY(hipMemsetAsync(t->edge_todo, 0, (size_t)t->NN, t->stream));
-    HIP_TRY(hipMemsetAsync(t->edge_done, 1, (size_t)t->NN, t->stream));
-    EdgeArgs E;
-    SweepArgs &A = E.G;
-    fill_sweep_args(t, A);
-    E.stamp = t->estamp; E.delta = t->edelta; E.flats = t->flats; E.edge_done = t->edge_done; E.epoch = t->eepoch;
-    E.p_done = t->p_flags; E.p_seed = t->p_flags + nper; E.p_delta = t->p_delta;
-    E.rlist = t->labels; E.rcount = t->counters + 6;
-    int32_t *cnt3 = t->counters;      // rotating frontier sizes
-    int32_t *n_todo = t->counters + 7;
-    // seeds enter queue[1] as "output of round -1" => cnt3[0] is the input of round 0 (queue index 0 % 2 ... see below)
-    // round r reads queue[r % 2] / cnt3[r % 3]; so seeds go to queue[0], cnt3[0]
+    int32_t *cnt3 = t->counters;      // rotating frontier sizes; level r reads queue[r % 2] / cnt3[r % 3]
+    int32_t *n_seed = t->counters + 8;
+    QE *q0 = (QE *)t->queue[0], *q1 = (QE *)t->queue[1];
     hipLaunchKernelGGL(k_edge_init, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, E, t->s_data, t->s_flags,
-                       t->s_flags + (size_t)4 * L, L, t->uca, t->edge_todo, t->queue[0], &cnt3[0], t->flatlist, n_todo);
+                       t->s_flags + (size_t)4 * L, L, t->uca, t->edge_todo, q0, &cnt3[0], (QE *)t->eseed, n_seed);
     HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
-    const int32_t nseed = t->h_counters[0], ntodo = t->h_counters[7];
-    auto run_rounds = [&](int which, int32_t first) -> int {
-        // which: 0 reach flood, 1 seeded sweep, 2 todo flood.  Frontier of round 0 is in queue[0]/cnt3[0].
+    const int32_t nflood = t->h_counters[0], nseed = t->h_counters[8];
+    int dbg_rounds[2] = {0, 0};
+    auto run_levels = [&](int which, int32_t first) -> int {
+        // which: 0 floods, 1 seeded sweep.  The frontier of level 0 is in queue[0] / cnt3[0].
         int r = 0;
         int32_t last = first;
         int32_t *state = t->counters + 12;
         while (last > 0) {
             if (last <= SMALL_CAP) {
-                if (which == 0) hipLaunchKernelGGL(k_edge_small<0>, dim3(1), dim3(1024), 0, t->stream, E, t->queue[0], t->queue[1], cnt3, r, state);
-                else if (which == 1) hipLaunchKernelGGL(k_edge_small<1>, dim3(1), dim3(1024), 0, t->stream, E, t->queue[0], t->queue[1], cnt3, r, state);
-                else hipLaunchKernelGGL(k_edge_small<2>, dim3(1), dim3(1024), 0, t->stream, E, t->queue[0], t->queue[1], cnt3, r, state);
+                if (which == 0) hipLaunchKernelGGL(k_edge_small<0>, dim3(1), dim3(1024), 0, t->stream, E, q0, q1, cnt3, r, state);
+                else hipLaunchKernelGGL(k_edge_small<1>, dim3(1), dim3(1024), 0, t->stream, E, q0, q1, cnt3, r, state);
                 HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
                 HIP_TRY(hipStreamSynchronize(t->stream));
                 r = t->h_counters[12];
                 last = t->h_counters[r % 3];
+                dbg_rounds[which] = r;
                 continue;
             }
             const int batch = last > 65536 ? 4 : 16;
             const int grid = grid_for(last, 1024);
             for (int b = 0; b < batch; b++, r++) {
-                if (which == 0) hipLaunchKernelGGL(k_edge_flood<0>, dim3(grid), dim3(256), 0, t->stream, E, t->queue[r % 2], t->queue[(r + 1) % 2], cnt3, r);
-                else if (which == 1) hipLaunchKernelGGL(k_edge_sweep, dim3(grid), dim3(256), 0, t->stream, E, t->queue[r % 2], t->queue[(r + 1) % 2], cnt3, r);
-                else hipLaunchKernelGGL(k_edge_flood<1>, dim3(grid), dim3(256), 0, t->stream, E, t->queue[r % 2], t->queue[(r + 1) % 2], cnt3, r);
+                if (which == 0) hipLaunchKernelGGL(k_edge_level<0>, dim3(grid), dim3(256), 0, t->stream, E, (r % 2) ? q1 : q0, (r % 2) ? q0 : q1, cnt3, r);
+                else hipLaunchKernelGGL(k_edge_level<1>, dim3(grid), dim3(256), 0, t->stream, E, (r % 2) ? q1 : q0, (r % 2) ? q0 : q1, cnt3, r);
             }
             HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
             last = t->h_counters[r % 3];
-            if (r > (int)CI_LEVEL_INF - 256) { pydem_set_error("edge update: flow paths too long"); return -5; }
+            dbg_rounds[which] = r;
+            if (r > (1 << 24)) { pydem_set_error("edge update: flow paths too long"); return -5; }
         }
         return 0;
     };
+    if (nflood > 0) PYDEM_TRY(run_levels(0, nflood));
     if (nseed > 0) {
-        // keep a copy of the seeds: the flood consumes queue[0]
-        HIP_TRY(hipMemcpyAsync(t->flatlist + ntodo, t->queue[0], (size_t)nseed * 4, hipMemcpyDeviceToDevice, t->stream));
-        PYDEM_TRY(run_rounds(0, nseed));
         int32_t three[3] = {nseed, 0, 0};
-        HIP_TRY(hipMemcpyAsync(t->queue[0], t->flatlist + ntodo, (size_t)nseed * 4, hipMemcpyDeviceToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(q0, t->eseed, (size_t)nseed * sizeof(QE), hipMemcpyDeviceToDevice, t->stream));
         HIP_TRY(hipMemcpyAsync(cnt3, three, sizeof(three), hipMemcpyHostToDevice, t->stream));
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        PYDEM_TRY(run_rounds(1, nseed));
+        PYDEM_TRY(run_levels(1, nseed));
         hipLaunchKernelGGL(k_edge_apply, dim3(grid_for(t->NN < (1 << 20) ? t->NN : (1 << 20), 1024)), dim3(256), 0, t->stream, E, t->uca,
-                           t->counters + 6);
+                           E.rcount);
     }
     hipLaunchKernelGGL(k_edge_apply_perimeter, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, E, t->uca);
-    if (ntodo > 0) {
-        int32_t three[3] = {ntodo, 0, 0};
-        HIP_TRY(hipMemcpyAsync(t->queue[0], t->flatlist, (size_t)ntodo * 4, hipMemcpyDeviceToDevice, t->stream));
-        HIP_TRY(hipMemcpyAsync(cnt3, three, sizeof(three), hipMemcpyHostToDevice, t->stream));
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        PYDEM_TRY(run_rounds(2, ntodo));
-    }
+    hipLaunchKernelGGL(k_edge_cleanup, dim3(256), dim3(256), 0, t->stream, E, (const int32_t *)E.rcount, (const int32_t *)E.tcount);
+    HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(t->stream));
+    t->etodo_prev = t->h_counters[7];
+    if (getenv("PYDEM_EDGE_DEBUG"))
+        fprintf(stderr, "edge round: %d seeds, %d todo cells, %d cells reached; levels: floods %d, sweep %d; %.3f ms\n", nseed,
+                t->h_counters[7], t->h_counters[6], dbg_rounds[0], dbg_rounds[1], host_now_ms() - t_begin);
     return 0;
 }

@@ -178,8 +178,13 @@ class DEMProcessor(object):
         if self._tile is None:
             n, m = self._shape if self._shape is not None else self.elev.shape
             self._tile = _ffi.Tile(n, m, self._device)
-        # the reference lets callers overwrite dX/dY after construction (process_manager.py:59-63)
-        self._tile.set_spacing(self.dX, self.dY, self.dX2, self.dY2)
+        # the reference lets callers overwrite dX/dY after construction (process_manager.py:59-63): re-send them
+        # whenever one of the four attributes was rebound (an edge round calls this ~100 times per tile)
+        cur = (self.dX, self.dY, self.dX2, self.dY2)
+        last = getattr(self, '_spacing_sent', None)
+        if last is None or any(a is not b for a, b in zip(cur, last)):
+            self._tile.set_spacing(*cur)
+            self._spacing_sent = cur
         return self._tile
 
     def _push(self, *names):
