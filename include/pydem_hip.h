@@ -103,6 +103,10 @@ int pydem_tile_download(pydem_tile *t, int field, void *dst);
  * (reference pydem/process_manager.py:131-145 and :252-255 read/write them through zarr) */
 int pydem_tile_get_line(pydem_tile *t, int field, int axis, int64_t index, void *dst);
 int pydem_tile_set_line(pydem_tile *t, int field, int axis, int64_t index, const void *src);
+/* `count` lines at once (fields[k], axes[k], indices[k] -> dsts[k]) with a single synchronisation: what one
+ * calc_uca_ec of the reference reads from its neighbours' stores (process_manager.py:246-274) */
+int pydem_tile_get_lines(pydem_tile *t, int count, const int *fields, const int *axes, const int64_t *indices,
+                         void *const *dsts);
 int pydem_tile_synchronize(pydem_tile *t);
 int pydem_tile_timings(pydem_tile *t, pydem_timings *out);
 int64_t pydem_tile_device_bytes(pydem_tile *t);

@@ -57,6 +57,7 @@ SYMBOLS = {
     'pydem_tile_download': (C.c_int, [_P, C.c_int, _P]),
     'pydem_tile_get_line': (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P]),
     'pydem_tile_set_line': (C.c_int, [_P, C.c_int, C.c_int, C.c_int64, _P]),
+    'pydem_tile_get_lines': (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     'pydem_tile_synchronize': (C.c_int, [_P]),
     'pydem_tile_timings': (C.c_int, [_P, C.POINTER(Timings)]),
     'pydem_tile_device_bytes': (C.c_int64, [_P]),
@@ -162,6 +163,17 @@ class Tile(object):
         out = np.empty(self.shape[1] if axis == 0 else self.shape[0], FIELD_DTYPE[field])
         check(self.lib.pydem_tile_get_line(self._h, field, axis, index, out.ctypes.data_as(_P)))
         return out
+
+    def get_lines(self, requests):
+        """requests: [(field, axis, index)] -> list of 1-D arrays, one device synchronisation for all."""
+        k = len(requests)
+        outs = [np.empty(self.shape[1] if axis == 0 else self.shape[0], FIELD_DTYPE[field]) for field, axis, _ in requests]
+        fields = (C.c_int * k)(*[r[0] for r in requests])
+        axes = (C.c_int * k)(*[r[1] for r in requests])
+        idx = (C.c_int64 * k)(*[r[2] for r in requests])
+        dsts = (C.c_void_p * k)(*[o.ctypes.data for o in outs])
+        check(self.lib.pydem_tile_get_lines(self._h, k, fields, axes, idx, dsts))
+        return outs
 
     def set_line(self, field, axis, index, values):
         v = np.ascontiguousarray(values, FIELD_DTYPE[field])

@@ -83,6 +83,7 @@ struct pydem_tile {
     bool edge_clean = false;        // edge flags / counts are zero and the masks only differ from their defaults on etodo_prev cells
     int32_t etodo_prev = 0;         // cells whose edge_done byte the previous round cleared (tlist = flatlist)
     double *line_stage = nullptr;   // max(n, m) doubles: staging for column get/set
+    void *lines_stage = nullptr; int lines_cap = 0;   // staging for pydem_tile_get_lines
     bool graph_valid = false;   // inmask/gflags/section/prop/pit lists match the resident elev/dir/flats
     void *scratch = nullptr; size_t scratch_bytes = 0;
     int64_t device_bytes = 0;

@@ -163,7 +163,7 @@ int pydem_tile_destroy(pydem_tile *t)
                     t->counters, t->scratch, t->pits.src, t->pits.dst, t->pits.w, t->pits.in_src,
                     t->pits.in_dst, t->pits.in_w, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w,
                     t->estamp, t->edelta, t->p_delta, t->s_data, t->p_flags, t->s_flags, t->line_stage, t->contrib, t->pit_blk,
-                    t->eseed};
+                    t->eseed, t->lines_stage};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     for (int i = 0; i < 8; i++) if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
@@ -300,6 +300,44 @@ static int line_copy(pydem_tile *t, int field, int axis, int64_t index, void *ho
 }
 
 int pydem_tile_get_line(pydem_tile *t, int field, int axis, int64_t index, void *dst) { return line_copy(t, field, axis, index, dst, true); }
+
+// several lines with ONE synchronisation (an edge round of the directory flow reads ~14 strips of the
+// tile that just ran; one launch + copy + sync per strip is ~30 us each)
+int pydem_tile_get_lines(pydem_tile *t, int count, const int *fields, const int *axes, const int64_t *indices, void *const *dsts)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    const size_t L = (size_t)(t->n > t->m ? t->n : t->m);
+    if (count > 0 && t->lines_cap < count) {
+        if (t->lines_stage) { HIP_TRY(hipFree(t->lines_stage)); t->device_bytes -= (int64_t)((size_t)t->lines_cap * L * 8); }
+        const int cap = count < 16 ? 16 : count;
+        HIP_TRY(hipMalloc(&t->lines_stage, (size_t)cap * L * 8));
+        t->lines_cap = cap; t->device_bytes += (int64_t)((size_t)cap * L * 8);
+    }
+    for (int k = 0; k < count; k++) {
+        void **pp; size_t elem;
+        PYDEM_TRY(field_ptr(t, fields[k], &pp, &elem));
+        if (!*pp || !t->have[fields[k]]) { pydem_set_error("field %d has not been computed or uploaded", fields[k]); return -3; }
+        const int64_t lim = axes[k] == 0 ? t->n : t->m;
+        int64_t index = indices[k];
+        if (index < 0) index += lim;
+        if (index < 0 || index >= lim || (axes[k] != 0 && axes[k] != 1)) { pydem_set_error("line index out of range"); return -2; }
+        char *base = (char *)*pp;
+        if (axes[k] == 0) {
+            HIP_TRY(hipMemcpyAsync(dsts[k], base + (size_t)index * t->m * elem, (size_t)t->m * elem, hipMemcpyDeviceToHost, t->stream));
+        } else {
+            const int64_t cnt = t->n;
+            const int g = (int)(cdiv(cnt, 256) < 64 ? cdiv(cnt, 256) : 64);
+            char *col = base + (size_t)index * elem;
+            double *stage = (double *)t->lines_stage + (size_t)k * L;
+            if (elem == 8) hipLaunchKernelGGL(k_line_gather<double>, dim3(g), dim3(256), 0, t->stream, (const double *)col, t->m, cnt, stage);
+            else hipLaunchKernelGGL(k_line_gather<uint8_t>, dim3(g), dim3(256), 0, t->stream, (const uint8_t *)col, t->m, cnt, (uint8_t *)stage);
+            HIP_TRY(hipMemcpyAsync(dsts[k], stage, (size_t)cnt * elem, hipMemcpyDeviceToHost, t->stream));
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return 0;
+}
 int pydem_tile_set_line(pydem_tile *t, int field, int axis, int64_t index, const void *src) { return line_copy(t, field, axis, index, (void *)src, false); }
 
 int pydem_tile_synchronize(pydem_tile *t)

@@ -901,6 +901,7 @@ struct EdgeArgs {
     double *p_delta;
     int32_t *rlist, *rcount; // reached cells (seeds first): their uca is updated at the end
     int32_t *tlist, *tcount; // cells whose edge_done byte this round cleared
+    const int2 *pit_off;     // per cell {first pit in-edge, first pit out-edge} (valid where the graph word says so)
 };
 
 __device__ __forceinline__ int64_t perim_index(int i, int j, int n, int m)
@@ -1001,27 +1002,29 @@ __global__ void k_edge_init(EdgeArgs E, const double *__restrict__ sdata, const 
 // Reach (:820-825): every edge walked bumps the target's count; the first visitor lists the target and
 // expands it next level.  Todo (:848-853): edge_done = False downstream of the cells that stay 'todo'.
 template <typename Push>
-__device__ __forceinline__ void edge_flood_cell(const EdgeArgs &E, QE q, Push push)
+__device__ __forceinline__ void edge_flood_cell(const EdgeArgs &E, QE q, int32_t *rcount, int32_t *tcount, Push push)
 {
     const SweepArgs &A = E.G;
     const int32_t u = q.c;
     const uint32_t cw = q.cw;
     const bool todo = (cw >> 31) != 0;
     const int s = ci_section(cw);
+    int32_t pe = 0;
+    if (cw & CI_PIT_OUT) pe = E.pit_off[u].y;
     auto visit = [&](int32_t t) {
         const uint32_t ct = A.cinfo[t];
         if (!todo) {
             const uint32_t old = atomicOr(&E.flag[t], EF_S);
             atomicAdd(&A.cinfo[t], CI_EONE);
             if (!(old & EF_S)) {
-                E.rlist[agg_slot(E.rcount)] = t;
+                E.rlist[agg_slot(rcount)] = t;
                 push(t, ct & CI_STATIC_MASK);
             }
         } else {
             const uint32_t old = atomicOr(&E.flag[t], EF_T);
             if (!(old & EF_T)) {
                 E.edge_done[t] = 0;                                              // edge_done = ~edge_todo (:856)
-                E.tlist[agg_slot(E.tcount)] = t;
+                E.tlist[agg_slot(tcount)] = t;
                 push(t, (ct & CI_STATIC_MASK) | (1u << 31));
             }
         }
@@ -1029,7 +1032,7 @@ __device__ __forceinline__ void edge_flood_cell(const EdgeArgs &E, QE q, Push pu
     if (cw & CI_OUT1) visit(u + fe1r(s) * A.m + fe1c(s));
     if (cw & CI_OUT2) visit(u + fe2r(s) * A.m + fe2c(s));
     if (cw & CI_PIT_OUT)
-        for (int32_t e = pit_first(A.pit_src, A.pout_blk, u); e < A.n_pit && A.pit_src[e] == u; e++) visit(A.pit_dst[e]);
+        for (int32_t e = pe; e < A.n_pit && A.pit_src[e] == u; e++) visit(A.pit_dst[e]);
 }
 
 // Seeded sweep (drain_area with skip_edge=False on the flooded sub-graph, :836-842).  Seeds keep the
@@ -1044,13 +1047,19 @@ __device__ __forceinline__ void edge_sweep_cell(const EdgeArgs &E, QE q, Push pu
     const uint32_t cw = q.cw;
     const int m = A.m;
     const bool seed = (cw & CI_ESEED) != 0;
+    // (a workgroup's memory pipeline moves about one scattered access per ns: only the neighbours in the
+    // in-mask are fetched -- all in one batch, the uses come later)
     uint32_t f[8]; double dl[8], pr[8];
 #pragma unroll
     for (int d = 0; d < 8; d++) {
-        const bool has = !seed && (cw & (1u << d));
-        const int32_t u = has ? c + NB_DI[d] * m + NB_DJ[d] : c;
-        f[d] = E.flag[u]; dl[d] = E.delta[u]; pr[d] = A.prop[u];
+        f[d] = 0; dl[d] = 0.0; pr[d] = 0.0;
+        if (!seed && (cw & (1u << d))) {
+            const int32_t u = c + NB_DI[d] * m + NB_DJ[d];
+            f[d] = E.flag[u]; dl[d] = E.delta[u]; pr[d] = A.prop[u];
+        }
     }
+    int2 po = make_int2(0, 0);
+    if (cw & (CI_PIT_IN | CI_PIT_OUT)) po = E.pit_off[c];
     const int s = ci_section(cw);
     int32_t t1 = -1, t2 = -1;
     uint32_t o1 = 0, o2 = 0;
@@ -1066,7 +1075,7 @@ __device__ __forceinline__ void edge_sweep_cell(const EdgeArgs &E, QE q, Push pu
             }
         }
         if (cw & CI_PIT_IN)
-            for (int32_t e = pit_first(A.pin_dst, A.pin_blk, c); e < A.n_pit && A.pin_dst[e] == c; e++)
+            for (int32_t e = po.x; e < A.n_pit && A.pin_dst[e] == c; e++)
                 if (E.flag[A.pin_src[e]] & EF_S) acc += E.delta[A.pin_src[e]] * A.pin_w[e];
     }
     E.delta[c] = acc;
@@ -1074,7 +1083,7 @@ __device__ __forceinline__ void edge_sweep_cell(const EdgeArgs &E, QE q, Push pu
     if (t1 >= 0 && ci_ecount(o1) == 1u && !(o1 & CI_ESEED)) push(t1, o1 & CI_STATIC_MASK);
     if (t2 >= 0 && ci_ecount(o2) == 1u && !(o2 & CI_ESEED)) push(t2, o2 & CI_STATIC_MASK);
     if (cw & CI_PIT_OUT)
-        for (int32_t e = pit_first(A.pit_src, A.pout_blk, c); e < A.n_pit && A.pit_src[e] == c; e++) {
+        for (int32_t e = po.y; e < A.n_pit && A.pit_src[e] == c; e++) {
             const int32_t t = A.pit_dst[e];
             const uint32_t o = atomicSub(&A.cinfo[t], CI_EONE);
             if (ci_ecount(o) == 1u && !(o & CI_ESEED)) push(t, o & CI_STATIC_MASK);
@@ -1091,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_edge_level(EdgeArgs E, const QE *__rest
     int32_t *cn = &cnt3[(r + 1) % 3];
     for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nq; k += gridDim.x * blockDim.x) {
         auto push = [&](int32_t t, uint32_t ct) { QE e; e.c = t; e.cw = ct; qn[agg_slot(cn)] = e; };
-        if (WHICH == 0) edge_flood_cell(E, qc[k], push);
+        if (WHICH == 0) edge_flood_cell(E, qc[k], E.rcount, E.tcount, push);
         else edge_sweep_cell(E, qc[k], push);
     }
 }
@@ -1105,18 +1114,32 @@ constexpr int SMALL_CAP = 4096;
 template <int WHICH>
 __global__ __launch_bounds__(1024) void k_edge_small(EdgeArgs E, QE *q0, QE *q1, int32_t *cnt3, int r_start, int32_t *state)
 {
-    __shared__ int32_t s_next;
+    // the frontier lives in LDS (and is mirrored to the global queues, stores nobody waits for, so that a
+    // frontier that outgrows the cap can be handed back); list counters are LDS copies for the same reason
+    __shared__ QE s_q[2][SMALL_CAP];
+    __shared__ int32_t s_next, s_rcount, s_tcount;
     int r = r_start;
     int32_t nq = cnt3[r % 3];
+    if (threadIdx.x == 0) { s_rcount = *E.rcount; s_tcount = *E.tcount; }
+    if (nq > 0 && nq <= SMALL_CAP) {
+        const QE *qc = (r % 2) ? q1 : q0;
+        for (int32_t k = threadIdx.x; k < nq; k += blockDim.x) s_q[r % 2][k] = qc[k];
+    }
+    __syncthreads();
     while (nq > 0 && nq <= SMALL_CAP) {
         if (threadIdx.x == 0) s_next = 0;
         __syncthreads();
-        const QE *qc = (r % 2) ? q1 : q0;
         QE *qn = (r % 2) ? q0 : q1;
+        QE *ln = s_q[(r + 1) % 2];
         for (int32_t k = threadIdx.x; k < nq; k += blockDim.x) {
-            auto push = [&](int32_t t, uint32_t ct) { QE e; e.c = t; e.cw = ct; qn[agg_slot(&s_next)] = e; };
-            if (WHICH == 0) edge_flood_cell(E, qc[k], push);
-            else edge_sweep_cell(E, qc[k], push);
+            auto push = [&](int32_t t, uint32_t ct) {
+                QE e; e.c = t; e.cw = ct;
+                const int32_t slot = agg_slot(&s_next);
+                if (slot < SMALL_CAP) ln[slot] = e;
+                qn[slot] = e;
+            };
+            if (WHICH == 0) edge_flood_cell(E, s_q[r % 2][k], &s_rcount, &s_tcount, push);
+            else edge_sweep_cell(E, s_q[r % 2][k], push);
         }
         __syncthreads();
         nq = s_next;
@@ -1125,7 +1148,19 @@ __global__ __launch_bounds__(1024) void k_edge_small(EdgeArgs E, QE *q0, QE *q1,
     }
     if (threadIdx.x == 0) {
         cnt3[r % 3] = nq; cnt3[(r + 1) % 3] = 0; cnt3[(r + 2) % 3] = 0;
+        *E.rcount = s_rcount; *E.tcount = s_tcount;
         state[0] = r;
+    }
+}
+
+// pit edge offsets per cell for the edge rounds (the main sweep keeps them in the area slots it is
+// about to overwrite; afterwards the contribution array is free and holds them for good)
+__global__ void k_pit_offsets(const int32_t *__restrict__ pin_dst, const int32_t *__restrict__ pit_src, int64_t ne, int2 *off)
+{
+    int32_t *slots = reinterpret_cast<int32_t *>(off);
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e == 0 || pin_dst[e - 1] != pin_dst[e]) slots[2 * (int64_t)pin_dst[e]] = (int32_t)e;
+        if (e == 0 || pit_src[e - 1] != pit_src[e]) slots[2 * (int64_t)pit_src[e] + 1] = (int32_t)e;
     }
 }
 
@@ -1429,7 +1464,13 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
     E.p_done = t->p_flags; E.p_seed = t->p_flags + nper; E.p_delta = t->p_delta;
     E.rlist = t->labels; E.rcount = t->counters + 6;
     E.tlist = t->flatlist; E.tcount = t->counters + 7;
+    // int2 per cell = half of a double2 slot: the offsets use the first NN * 8 bytes of the contribution array
+    PYDEM_TRY(tile_alloc(t, &t->contrib, (size_t)t->NN * 2));
+    E.pit_off = reinterpret_cast<const int2 *>(t->contrib);
     if (!t->edge_clean) {
+        if (A.n_pit > 0)
+            hipLaunchKernelGGL(k_pit_offsets, dim3(grid_for(A.n_pit, 2048)), dim3(256), 0, t->stream, A.pin_dst, A.pit_src, A.n_pit,
+                               reinterpret_cast<int2 *>(t->contrib));
         // first round after the graph was (re)built: flags and counts to zero, masks to their defaults (:812, :817)
         HIP_TRY(hipMemsetAsync(t->estamp, 0, (size_t)t->NN * 4, t->stream));
         hipLaunchKernelGGL(k_edge_clear_levels, dim3(grid_for(t->NN, 8192)), dim3(256), 0, t->stream, A.cinfo, t->NN);
@@ -1462,7 +1503,7 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
     HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     const int32_t nflood = t->h_counters[0], nseed = t->h_counters[8];
-    int dbg_rounds[2] = {0, 0};
+    int dbg_rounds[2] = {0, 0}, dbg_wide[2] = {0, 0};
     auto run_levels = [&](int which, int32_t first) -> int {
         // which: 0 floods, 1 seeded sweep.  The frontier of level 0 is in queue[0] / cnt3[0].
         int r = 0;
@@ -1481,6 +1522,7 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
             }
             const int batch = last > 65536 ? 4 : 16;
             const int grid = grid_for(last, 1024);
+            dbg_wide[which] += batch;
             for (int b = 0; b < batch; b++, r++) {
                 if (which == 0) hipLaunchKernelGGL(k_edge_level<0>, dim3(grid), dim3(256), 0, t->stream, E, (r % 2) ? q1 : q0, (r % 2) ? q0 : q1, cnt3, r);
                 else hipLaunchKernelGGL(k_edge_level<1>, dim3(grid), dim3(256), 0, t->stream, E, (r % 2) ? q1 : q0, (r % 2) ? q0 : q1, cnt3, r);
@@ -1509,7 +1551,7 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
     HIP_TRY(hipStreamSynchronize(t->stream));
     t->etodo_prev = t->h_counters[7];
     if (getenv("PYDEM_EDGE_DEBUG"))
-        fprintf(stderr, "edge round: %d seeds, %d todo cells, %d cells reached; levels: floods %d, sweep %d; %.3f ms\n", nseed,
-                t->h_counters[7], t->h_counters[6], dbg_rounds[0], dbg_rounds[1], host_now_ms() - t_begin);
+        fprintf(stderr, "edge round: %d seeds, %d todo cells, %d cells reached; levels: floods %d (%d wide), sweep %d (%d wide); %.3f ms\n",
+                nseed, t->h_counters[7], t->h_counters[6], dbg_rounds[0], dbg_wide[0], dbg_rounds[1], dbg_wide[1], host_now_ms() - t_begin);
     return 0;
 }

@@ -231,6 +231,19 @@ class DEMProcessor(object):
         a = self._host[name]
         return np.array(a[index, :] if axis == 0 else a[:, index])
 
+    def get_lines(self, requests):
+        """[(name, axis, index)] -> list of 1-D arrays; device-resident fields are fetched with one synchronisation."""
+        dev = [k for k, (name, _, _) in enumerate(requests) if name in self._on_device and name not in self._host]
+        out = [None] * len(requests)
+        if len(dev) > 1:
+            got = self._tile.get_lines([(_FIELD_OF[requests[k][0]], requests[k][1], requests[k][2]) for k in dev])
+            for k, arr in zip(dev, got):
+                out[k] = arr.astype(bool) if requests[k][0] in _BOOL_FIELDS else arr
+        for k, (name, axis, index) in enumerate(requests):
+            if out[k] is None:
+                out[k] = self.get_line(name, axis, index)
+        return out
+
     def set_line(self, name, axis, index, values):
         if name in self._on_device:
             self._tile.set_line(_FIELD_OF[name], axis, index, values)

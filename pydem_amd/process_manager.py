@@ -91,7 +91,18 @@ class EdgeTransport(object):
 
     def gather_lines(self, requests):
         """requests: list of (tile, name, axis, index) -> list of 1-D arrays (None for missing tiles)."""
-        return [None if t < 0 else self.pm.tiles[t].get_line(name, axis, index) for t, name, axis, index in requests]
+        out = [None] * len(requests)
+        by_tile = {}
+        for k, (t, name, axis, index) in enumerate(requests):
+            if t >= 0:
+                by_tile.setdefault(t, []).append(k)
+        for t, ks in by_tile.items():
+            dp = self.pm.tiles[t]
+            reqs = [requests[k][1:] for k in ks]
+            got = dp.get_lines(reqs) if hasattr(dp, 'get_lines') else [dp.get_line(*r) for r in reqs]
+            for k, v in zip(ks, got):
+                out[k] = v
+        return out
 
     def allreduce_max(self, value):
         return value
@@ -271,6 +282,13 @@ class ProcessManager(object):
     def _edge_line(self, i, key):
         """Where tile i's `key` edge data comes from: (tile, axis, local index) for the four sides (the
         line spans the full neighbour edge) or (tile, local row, local col) for the corners."""
+        memo = self.__dict__.setdefault('_edge_line_memo', {})
+        hit = memo.get((i, key))
+        if hit is None:
+            hit = memo[(i, key)] = self._edge_line_uncached(i, key)
+        return hit
+
+    def _edge_line_uncached(self, i, key):
         ed = self.edge_data[i][key]
         slc = self.grid_slice[i]
         if key in ('left', 'right'):
@@ -580,6 +598,7 @@ class ProcessManager(object):
         self.tiles_shape = [tuple(int(v) for v in self.index[i, 6:]) for i in range(self.n_inputs)]
         self.edge_rounds = 0
         self.edge_rounds_skipped = 0
+        self._edge_line_memo = {}
         self._mets = None
         self._edge_cache = {}
         self._edge_last = {}
