@@ -20,6 +20,7 @@
 #include "internal.h"
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include <time.h>
 
 #define PI_D 3.141592653589793
@@ -555,34 +556,34 @@ __global__ __launch_bounds__(1024) void k_sweep_small(SweepArgs A, QE *q0, QE *q
 }
 
 // ------------------------------------------------------------------------------- K5b
-// Tile-local passes.  A queue round re-streams scattered 64 B lines for every cell it touches, and
-// the first dozens of rounds touch most of the grid again and again.  Here a workgroup stages one
-// 32x32 tile (plus a one-cell halo) of graph words and outgoing contributions in LDS and runs as
-// many level-synchronous rounds as it can ENTIRELY ON CHIP: a cell is final once all its upstream
-// cells are final -- those inside the tile become so during the pass, halo cells only if an earlier
-// pass finished them.  Each pass streams the unfinished tiles once; flow paths that cross tile
-// borders make progress of one tile per pass, so a few passes finish the bulk of the grid and the
-// queue rounds above only see the long river network.  Cells finished in pass p carry level p.
-// The arithmetic per cell (gather order, products) is identical to process_cell().
+// Tile passes.  A queue round moves every flow path by ONE cell per kernel boundary and re-streams
+// scattered 64 B lines for every cell it touches.  Here ONE WAVEFRONT owns a 32x32 tile for a pass and
+// runs as many level-synchronous rounds as it can without leaving the CU: a cell is final once all
+// its upstream cells are final -- those inside the tile become so during the pass, cells of the
+// one-cell halo only if an earlier pass finished them.  Only the BOOKKEEPING lives in LDS (graph
+// words, open-upstream counts, the ready list: 9 KB per tile, so 16 tiles are in flight per CU and
+// hide each other's latency); areas and contributions go straight to their global arrays, where
+// the same wavefront finds them again in its caches a round later (a workgroup-scope fence orders a
+// round's stores before the next round's loads).  A pass is either over all tiles (pass 1) or over
+// the tiles LISTED by the previous pass: whenever a finished cell drains into another tile, that
+// tile is listed for the next pass.  Flow paths advance by one tile per pass instead of one cell
+// per round.  Cells finished in pass p carry level p.  The arithmetic per cell (gather order,
+// products) is identical to process_cell().
 constexpr int TT = 32, HW = TT + 2;
+constexpr uint32_t SP_STATE_SHIFT = 30;   // sp word: state (0 open, 1 final / outside, 2 finished now) << 30 | open-upstream count
 
-struct TileLds {
-    uint32_t ci[HW * HW];
-    double cx[HW * HW], cy[HW * HW];      // outgoing contributions (tile + halo)
-    uint32_t pend[HW * HW];               // unfinished upstream cells (tile cells only)
-    uint8_t state[HW * HW];               // 0 open, 1 final before this pass / outside, 2 finished in this pass
-    double p[TT * TT], area[TT * TT];
-    uint16_t list[2][TT * TT];            // ready lists (current / next round)
-    double a0[TT];                        // cell area of the tile's rows
-    int n[2];
+struct TileW {
+    uint32_t sp[HW * HW];     // state and unfinished-upstream count
+    uint16_t ci[HW * HW];     // static graph bits
+    uint16_t list[TT * TT];   // ready cells in the order they became ready (each cell enters once)
+    double a0[TT];            // cell area of the tile's rows
+    int tail;                 // list end
     int open_cells;
 };
 
-// the on-chip part runs on ONE wavefront: a round is a handful of LDS operations on (typically) a few
-// ready cells, and a workgroup barrier per round costs more than the round itself
 __device__ __forceinline__ void tile_wave_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -592,185 +593,163 @@ struct TileNext {            // LISTED passes: tiles that must run again in the 
 };
 
 template <bool LISTED>
-__device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileLds &L, uint32_t pass, int tiles_x, int tid,
+__device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uint32_t pass, int tiles_x, int tid, int lane,
                                                uint8_t *__restrict__ tile_done, int32_t *n_final, const TileNext &N)
 {
     const int by = tid / tiles_x, bx = tid - by * tiles_x;
     const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
     const int LOFF[8] = {-HW - 1, -HW, -HW + 1, -1, 1, HW - 1, HW, HW + 1};
-    // ---- stage tile + halo
-    for (int idx = threadIdx.x; idx < HW * HW; idx += 256) {
+    // ---- stage the graph words of tile + halo
+    for (int idx = lane; idx < HW * HW; idx += 64) {
         const int li = idx / HW, lj = idx - li * HW;
         const int gi = i0 - 1 + li, gj = j0 - 1 + lj;
-        uint32_t cw = 0; uint8_t st = 1; double cx = 0.0, cy = 0.0;       // outside the grid: nothing drains from there
+        uint32_t cw = 0, st = 1;                                           // outside the grid: nothing drains from there
         if (gi >= 0 && gi < n && gj >= 0 && gj < m) {
-            const int64_t g = (int64_t)gi * m + gj;
-            cw = A.cinfo[g];
+            cw = A.cinfo[(int64_t)gi * m + gj];
             const uint32_t lv = ci_level(cw);
             st = (lv >= 1 && lv < pass);
-            if (st) { const double2 o = A.contrib[g]; cx = o.x; cy = o.y; }
         }
-        L.ci[idx] = cw; L.state[idx] = st; L.cx[idx] = cx; L.cy[idx] = cy;
+        L.ci[idx] = (uint16_t)(cw & CI_STATIC_MASK);
+        L.sp[idx] = st << SP_STATE_SHIFT;
     }
-    if (threadIdx.x == 0) { L.n[0] = 0; L.n[1] = 0; L.open_cells = 0; }
-    if (threadIdx.x < TT) L.a0[threadIdx.x] = i0 + (int)threadIdx.x < n ? A.a0[i0 + threadIdx.x] : 0.0;
-    __syncthreads();
-    // ---- per-cell setup: proportion, and how many upstream cells are still open
-    for (int cell = threadIdx.x; cell < TT * TT; cell += 256) {
+    if (lane == 0) { L.tail = 0; L.open_cells = 0; }
+    if (lane < TT) L.a0[lane] = i0 + lane < n ? A.a0[i0 + lane] : 0.0;
+    tile_wave_sync();
+    // ---- per-cell setup: how many upstream cells are still open
+    for (int cell = lane; cell < TT * TT; cell += 64) {
         const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
         const int gi = i0 + li - 1, gj = j0 + lj - 1;
-        uint32_t pend = 0;
-        double pv = 0.0;
-        if (gi < n && gj < m && !L.state[idx] && !(A.dbg & 2)) {
+        if (gi < n && gj < m && !(L.sp[idx] >> SP_STATE_SHIFT)) {
             const uint32_t cw = L.ci[idx];
             const int32_t c = gi * m + gj;
-            pv = A.prop[c];
+            uint32_t pend = 0;
 #pragma unroll
             for (int d = 0; d < 8; d++)
-                if ((cw & (1u << d)) && !L.state[idx + LOFF[d]]) pend++;
+                if ((cw & (1u << d)) && !(L.sp[idx + LOFF[d]] >> SP_STATE_SHIFT)) pend++;
             if (cw & CI_PIT_IN)                                     // pit -> drain edges are short: most sources sit in this tile
                 for (int32_t e = pit_stash(A, c).x; e < A.n_pit && A.pin_dst[e] == c; e++) {
                     const int32_t sc = A.pin_src[e];
                     const int si = sc / m - i0, sj = sc % m - j0;
                     if (si >= 0 && si < TT && sj >= 0 && sj < TT) {
-                        if (!L.state[(si + 1) * HW + sj + 1]) pend++;          // released on chip when the pit finishes
+                        if (!(L.sp[(si + 1) * HW + sj + 1] >> SP_STATE_SHIFT)) pend++;   // released on chip when the pit finishes
                     } else {
                         const uint32_t lv = ci_level(A.cinfo[sc]);
                         if (!(lv >= 1 && lv < pass)) pend += 64;               // another tile's business: blocked for this pass
                     }
                 }
-            if (pend == 0) L.list[0][atomicAdd(&L.n[0], 1)] = (uint16_t)cell;
+            // the state bits of an open cell are zero: the word is the count
+            L.sp[idx] = pend;
+            if (pend == 0) L.list[atomicAdd(&L.tail, 1)] = (uint16_t)cell;
         }
-        L.pend[idx] = pend;
-        L.p[cell] = pv;
     }
-    __syncthreads();
-    // ---- rounds on chip (wavefront 0): the ready list is processed, targets whose last upstream cell just
-    // finished form the next list.  Work per round is proportional to the cells that are ready, not to the tile.
+    tile_wave_sync();
+    // ---- rounds: the ready cells [head, tail) are processed, the targets they release are appended
     int32_t finalized = 0;
-    if (threadIdx.x < 64 && !(A.dbg & 1)) {
-        int cur = 0;
-        for (;;) {
-            const int nl = L.n[cur];
-            if (nl == 0) break;
-            const int nxt = cur ^ 1;
-            for (int k = threadIdx.x; k < nl; k += 64) {
-                const int cell = L.list[cur][k];
-                const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
-                const int gi = i0 + li - 1, gj = j0 + lj - 1;
-                const int32_t c = gi * m + gj;
-                const uint32_t cw = L.ci[idx];
-                double a = L.a0[li - 1];
-                bool td = (gi == 0 || gi == n - 1 || gj == 0 || gj == m - 1) && A.todo_work[c] != 0;
+    int head = 0;
+    for (;;) {
+        const int tail = L.tail;
+        if (head == tail) break;
+        for (int k = head + lane; k < tail; k += 64) {
+            const int cell = L.list[k];
+            const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
+            const int gi = i0 + li - 1, gj = j0 + lj - 1;
+            const int32_t c = gi * m + gj;
+            const uint32_t cw = L.ci[idx];
+            // everything that only needs (c, cw): proportion, pit slots, the in-edge contributions
+            double pv = 0.0;
+            if (cw & (CI_OUT1 | CI_OUT2)) pv = A.prop[c];
+            int2 po = make_int2(0, 0);
+            if (cw & (CI_PIT_IN | CI_PIT_OUT)) po = pit_stash(A, c);
+            double x8[8];
 #pragma unroll
-                for (int d = 0; d < 8; d++) {
-                    if (cw & (1u << d)) {
-                        const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
-                        const double x = cardinal ? L.cx[idx + LOFF[d]] : L.cy[idx + LOFF[d]];
-                        a += fabs(x);
-                        td = td || (x < 0);
-                    }
+            for (int d = 0; d < 8; d++) {
+                x8[d] = 0.0;
+                if (cw & (1u << d)) {
+                    const int32_t u = c + NB_DI[d] * m + NB_DJ[d];
+                    const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
+                    x8[d] = cardinal ? A.contrib[u].x : A.contrib[u].y;
                 }
-                if (cw & CI_PIT_IN)
-                    for (int32_t e = pit_stash(A, c).x; e < A.n_pit && A.pin_dst[e] == c; e++) {
-                        const int32_t sc = A.pin_src[e];
-                        const int si = sc / m - i0, sj = sc % m - j0;
-                        if (si >= 0 && si < TT && sj >= 0 && sj < TT && L.state[(si + 1) * HW + sj + 1] == 2) {
-                            const double sa = L.area[si * TT + sj];               // finished in this pass: still on chip
-                            a += fabs(sa) * A.pin_w[e];
-                            td = td || (sa < 0);
-                        } else {
-                            a += A.area[sc] * A.pin_w[e];
-                            td = td || (A.todo_work[sc] != 0);
-                        }
-                    }
-                double ox = 0.0, oy = 0.0;
-                if (cw & (CI_OUT1 | CI_OUT2)) {
-                    const double p = L.p[cell];
-                    if (cw & CI_OUT1) ox = a * p;
-                    if (cw & CI_OUT2) oy = a * (1 - p);
-                    if (td) { ox = -ox; oy = -oy; }
-                }
-                L.cx[idx] = ox; L.cy[idx] = oy; L.area[cell] = td ? -a : a;   // sign of the stored area carries the taint
-                L.state[idx] = 2;
-                finalized++;
-                // release the targets inside the tile
-                const int sct = ci_section(cw);
-                if (cw & CI_OUT1) {
-                    const int ti = li + fe1r(sct), tj = lj + fe1c(sct);
-                    if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && atomicSub(&L.pend[ti * HW + tj], 1u) == 1u)
-                        L.list[nxt][atomicAdd(&L.n[nxt], 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
-                }
-                if (cw & CI_OUT2) {
-                    const int ti = li + fe2r(sct), tj = lj + fe2c(sct);
-                    if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && atomicSub(&L.pend[ti * HW + tj], 1u) == 1u)
-                        L.list[nxt][atomicAdd(&L.n[nxt], 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
-                }
-                if (cw & CI_PIT_OUT)
-                    for (int32_t e = pit_stash(A, c).y; e < A.n_pit && A.pit_src[e] == c; e++) {
-                        const int32_t dc = A.pit_dst[e];
-                        const int ti = dc / m - i0 + 1, tj = dc % m - j0 + 1;
-                        if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT && !L.state[ti * HW + tj]
-                            && atomicSub(&L.pend[ti * HW + tj], 1u) == 1u)
-                            L.list[nxt][atomicAdd(&L.n[nxt], 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
-                    }
             }
-            tile_wave_sync();
-            if (threadIdx.x == 0) L.n[cur] = 0;
-            cur = nxt;
-            tile_wave_sync();
+            double a = L.a0[li - 1];
+            bool td = (gi == 0 || gi == n - 1 || gj == 0 || gj == m - 1) && A.todo_work[c] != 0;
+#pragma unroll
+            for (int d = 0; d < 8; d++)
+                if (cw & (1u << d)) { a += fabs(x8[d]); td = td || (x8[d] < 0); }
+            if (cw & CI_PIT_IN)
+                for (int32_t e = po.x; e < A.n_pit && A.pin_dst[e] == c; e++) {
+                    const int32_t sc = A.pin_src[e];
+                    a += A.area[sc] * A.pin_w[e];
+                    td = td || (A.todo_work[sc] != 0);
+                }
+            double2 o = make_double2(0.0, 0.0);
+            if (cw & CI_OUT1) o.x = a * pv;
+            if (cw & CI_OUT2) o.y = a * (1 - pv);
+            if (td) { o.x = -o.x; o.y = -o.y; }
+            A.area[c] = a;
+            A.contrib[c] = o;
+            if (td) A.todo_work[c] = 1;
+            L.sp[idx] = 2u << SP_STATE_SHIFT;
+            finalized++;
+            // release the targets inside the tile; targets in other tiles may be ready now: their tiles run in the
+            // next pass (listing a tile whose cell still waits for somebody else costs one idle staging; whoever
+            // finishes last lists it again)
+            auto release = [&](int ti, int tj) {      // tile-local coordinates 1..TT when inside
+                if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT) {
+                    const uint32_t old = atomicSub(&L.sp[ti * HW + tj], 1u);
+                    if (old == 1u) L.list[atomicAdd(&L.tail, 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
+                } else if (LISTED) {
+                    const int gti = i0 + ti - 1, gtj = j0 + tj - 1;
+                    if (gti < 0 || gti >= n || gtj < 0 || gtj >= m) return;
+                    const int tt = (gti / TT) * tiles_x + gtj / TT;
+                    if (atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tt;
+                }
+            };
+            const int sct = ci_section(cw);
+            if (cw & CI_OUT1) release(li + fe1r(sct), lj + fe1c(sct));
+            if (cw & CI_OUT2) release(li + fe2r(sct), lj + fe2c(sct));
+            if (cw & CI_PIT_OUT)
+                for (int32_t e = po.y; e < A.n_pit && A.pit_src[e] == c; e++) {
+                    const int32_t dc = A.pit_dst[e];
+                    const int ti = dc / m - i0 + 1, tj = dc % m - j0 + 1;
+                    // a drain inside the tile that an earlier pass already finished cannot exist (it waits for this pit)
+                    release(ti, tj);
+                }
         }
+        head = tail;
+        tile_wave_sync();
     }
-    __syncthreads();
-    // ---- write back what this pass finished (consecutive threads own consecutive cells)
+    // ---- stamp what this pass finished (consecutive lanes own consecutive cells)
     int open_cells = 0;
-    for (int cell = threadIdx.x; cell < TT * TT; cell += 256) {
+    for (int cell = lane; cell < TT * TT; cell += 64) {
         const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
         const int gi = i0 + li - 1, gj = j0 + lj - 1;
         if (gi >= n || gj >= m) continue;
-        const uint8_t st = L.state[idx];
+        const uint32_t st = L.sp[idx] >> SP_STATE_SHIFT;
         if (st == 0) { open_cells = 1; continue; }
         if (st != 2) continue;
-        const int32_t c = gi * m + gj;
-        const double a = L.area[cell];
-        const uint32_t cw = L.ci[idx];
-        if (LISTED) {
-            // targets outside the tile may be ready now: their tiles run in the next pass.  (Listing a tile whose
-            // cell turns out to wait for somebody else costs one idle staging; whoever finishes last lists it again.)
-            auto wake = [&](int ti, int tj) {
-                if (ti < 0 || ti >= n || tj < 0 || tj >= m) return;
-                const int tt = (ti / TT) * tiles_x + tj / TT;
-                if (tt == tid) return;
-                if (atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tt;
-            };
-            const int sct = ci_section(cw);
-            if (cw & CI_OUT1) wake(gi + fe1r(sct), gj + fe1c(sct));
-            if (cw & CI_OUT2) wake(gi + fe2r(sct), gj + fe2c(sct));
-            if (cw & CI_PIT_OUT)        // the slot still holds the edge offsets: the area is written just below
-                for (int32_t e = pit_stash(A, c).y; e < A.n_pit && A.pit_src[e] == c; e++) wake(A.pit_dst[e] / m, A.pit_dst[e] % m);
-        }
-        A.area[c] = fabs(a);
-        A.contrib[c] = make_double2(L.cx[idx], L.cy[idx]);
-        A.cinfo[c] = ci_with_level(cw, pass);
-        if (a < 0) A.todo_work[c] = 1;
+        A.cinfo[gi * m + gj] = ci_with_level(L.ci[idx], pass);
     }
-    if (open_cells) L.open_cells = 1;
-    for (int off = 32; off > 0; off >>= 1) finalized += __shfl_down(finalized, off);
-    if (threadIdx.x == 0 && finalized) atomicAdd(n_final, finalized);
-    __syncthreads();
-    if (threadIdx.x == 0 && !L.open_cells) tile_done[tid] = 1;
+    for (int off = 32; off > 0; off >>= 1) { finalized += __shfl_down(finalized, off); open_cells |= __shfl_down(open_cells, off); }
+    if (lane == 0) {
+        if (finalized) atomicAdd(n_final, finalized);
+        if (!open_cells) tile_done[tid] = 1;
+    }
+    tile_wave_sync();
 }
 
-// pass 1: every tile, XCD-contiguous bands of tiles
+// every tile that is not done yet, four tiles per workgroup, XCD-contiguous bands of tiles (LISTED: also
+// lists the tiles of the next pass)
+template <bool LISTED>
 __global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total,
-                                                     uint8_t *__restrict__ tile_done, int32_t *n_final)
+                                                     uint8_t *__restrict__ tile_done, int32_t *n_final, TileNext N)
 {
-    __shared__ TileLds L;
-    const int per = (tiles_total + 7) >> 3;
-    const int tid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    __shared__ TileW L[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // workgroup b runs on XCD b % 8: give every XCD one contiguous band of tiles (gridDim.x is a multiple of 8)
+    const int per = (gridDim.x >> 3) * 4;
+    const int tid = (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + wave;
     if (tid >= tiles_total || tile_done[tid]) return;
-    TileNext N; N.flag = nullptr; N.list = nullptr; N.count = nullptr;
-    sweep_one_tile<false>(A, L, pass, tiles_x, tid, tile_done, n_final, N);
+    sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, n_final, N);
 }
 
 // later passes: only the listed tiles (those a finished cell of the previous pass drains into); lists the next ones
@@ -778,13 +757,12 @@ __global__ __launch_bounds__(256) void k_sweep_tiles_listed(SweepArgs A, uint32_
                                                             const int32_t *n_in, uint8_t *__restrict__ tile_done, int32_t *n_final,
                                                             TileNext N, int32_t *clear_count)
 {
-    __shared__ TileLds L;
+    __shared__ TileW L[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t nt = *n_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *clear_count = 0;      // the list of the pass after the next one
-    for (int32_t k = blockIdx.x; k < nt; k += gridDim.x) {
-        sweep_one_tile<true>(A, L, pass, tiles_x, list_in[k], tile_done, n_final, N);
-        __syncthreads();
-    }
+    for (int32_t k = blockIdx.x * 4 + wave; k < nt; k += gridDim.x * 4)
+        sweep_one_tile<true>(A, L[wave], pass, tiles_x, list_in[k], lane, tile_done, n_final, N);
 }
 
 // switch from queue rounds to listed tile passes: the tiles that hold the current frontier
@@ -1297,20 +1275,65 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     int64_t launches = 0;
     uint32_t pass = 0;
     int64_t done_prev = 0;
+    // listed tile passes from pass p on (the list of pass p is in tile_list[p % 2] / cntT[p % 3]); returns the next pass number
+    auto run_listed = [&](int p, int64_t ntiles) -> int {
+        TileNext N;
+        N.flag = tile_flag;
+        while (ntiles > 0) {
+            const int batch = ntiles > 16384 ? 2 : 8;
+            const int grid = (int)(ntiles < 8192 ? (ntiles > 64 ? ntiles : 64) : 8192);
+            for (int b = 0; b < batch; b++, p++) {
+                N.list = tile_list[(p + 1) % 2]; N.count = &cntT[(p + 1) % 3];
+                hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), 0, t->stream, A, (uint32_t)p, tiles_x,
+                                   (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
+                                   &cntT[(p + 2) % 3]);
+                launches++;
+            }
+            if (hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream) != hipSuccess) return -1;
+            if (hipStreamSynchronize(t->stream) != hipSuccess) return -1;
+            ntiles = t->h_counters[56 + p % 3];
+            if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "listed tile pass %d: %lld tiles listed next, processed %d\n", p, (long long)ntiles, t->h_counters[3]);
+            if (p > (int)CI_LEVEL_INF - 256) return -2;
+        }
+        return p;
+    };
+    static int sweep_mode = -1;     // 0: tile passes only (default), 1: tile pass + queue rounds + listed tail
+    if (sweep_mode < 0) { const char *e = getenv("PYDEM_SWEEP_MODE"); sweep_mode = (e && !strcmp(e, "queue")) ? 1 : 0; }
+    const unsigned full_grid = (unsigned)(((tiles_total + 31) / 32) * 8);
+    if (sweep_mode == 0) {
+        // pass 1 over every tile, pass 2 over every tile that is not done (it also lists the tiles of pass 3),
+        // then only the listed tiles until no tile is listed any more
+        TileNext N0; N0.flag = nullptr; N0.list = nullptr; N0.count = nullptr;
+        hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), 0, t->stream, A, 1u, tiles_x, tiles_total, tile_done, total, N0);
+        TileNext N; N.flag = tile_flag; N.list = tile_list[3 % 2]; N.count = &cntT[3 % 3];
+        hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(256), 0, t->stream, A, 2u, tiles_x, tiles_total, tile_done, total, N);
+        launches += 2;
+        HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "tile passes 1-2: %d cells of %lld, %d tiles listed\n", t->h_counters[3], (long long)t->NN, t->h_counters[56]);
+        const int p_end = run_listed(3, t->h_counters[56 + 3 % 3]);
+        if (p_end == -1) { pydem_set_error("HIP error in the listed tile passes"); return -4; }
+        if (p_end == -2) { pydem_set_error("flow paths longer than %u passes are not supported", CI_LEVEL_INF); return -5; }
+        pass = (uint32_t)p_end;
+        t->tm.sweep_tile_passes = (int64_t)pass;
+        HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+    }
+    if (sweep_mode == 1) {
     // every pass re-stages all tiles that still have an open cell (rivers cross most tiles), so after the
     // first pass (which finishes ~3/4 of the grid) the queue rounds are cheaper than another pass
     static int max_passes = -1;
     if (max_passes < 0) { const char *e = getenv("PYDEM_TILE_PASSES"); max_passes = e ? atoi(e) : 1; if (max_passes < 1) max_passes = 1; }
     for (;;) {
         pass++;
-        hipLaunchKernelGGL(k_sweep_tiles, dim3((unsigned)(((tiles_total + 7) / 8) * 8)), dim3(256), 0, t->stream, A, pass, tiles_x,
-                           tiles_total, tile_done, total);
+        { TileNext N0; N0.flag = nullptr; N0.list = nullptr; N0.count = nullptr;
+          hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), 0, t->stream, A, pass, tiles_x, tiles_total, tile_done, total, N0); }
         launches++;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         const int64_t done_now = t->h_counters[3];
         const int64_t gained = done_now - done_prev;
-        if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "tile pass %u: +%lld cells (%.2f%%), total %.2f%%, iterations so far %d over %d active tiles\n", pass, (long long)gained, 100.0 * gained / t->NN, 100.0 * done_now / t->NN, t->h_counters[4], t->h_counters[10]);
+        if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "tile pass %u: +%lld cells (%.2f%%), total %.2f%%\n", pass, (long long)gained, 100.0 * gained / t->NN, 100.0 * done_now / t->NN);
         done_prev = done_now;
         // a pass costs about one streaming read of the unfinished tiles; stop when it finishes < 1.5 % of the grid
         if (done_now >= t->NN || gained * 64 < t->NN || (int)pass >= max_passes) break;
@@ -1396,6 +1419,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "round %d: frontier %lld, processed %d\n", r, (long long)last, t->h_counters[3]);
         if (r > (int)CI_LEVEL_INF - 256) { pydem_set_error("flow paths longer than %u rounds are not supported", CI_LEVEL_INF); return -5; }
     }
+    }   // sweep_mode == 1
     if (t->h_counters[15] > 0) { pydem_set_error("sweep frontier exceeded the queue capacity (%lld entries)", (long long)A.qcap); return -5; }
     const int64_t processed = (int64_t)t->h_counters[3];     // tile passes + queue rounds ([4], [10]: tile-pass statistics)
     t->tm.n_unresolved = t->NN - processed;
