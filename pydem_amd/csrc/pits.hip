@@ -450,33 +450,56 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
 
 // ---------------------------------------------------------------------------------------------
 // Wavefront version (second pass: the ~10 % of the pits the lane version hands over; they average
-// 66 rounds with borders of 50-250 cells).  The border is an incremental, unordered LIST in LDS
-// (elevation, window position, pit flag): a round is one strided scan for the minimum, a ballot
-// that takes the cells equal to it out of the list, and one 64-lane step per 8 promoted cells that
+// 66 rounds with borders of 50-250 cells).  The kernel is bound by instruction issue (a wave64
+// instruction occupies its SIMD for 4 cycles and a round used to be ~600 of them), so a round is
+// kept short: the border is an incremental, unordered LIST in LDS (elevation, window position, pit
+// flag) that is read ONCE per round into registers -- minimum (DPP reduction), then a ballot per
+// 64 slots takes the cells equal to it out of the list; their slots are recycled for the cells that
+// enter next, so the list stays as short as the border; then one 64-lane step per 8 promoted cells
 // tests their 8 neighbours against the region|border bitmap (LDS atomicOr: exactly one lane wins a
-// new cell), loads the new elevations in parallel and appends them with a ballot rank.  As in the
-// lane version the drain tests are evaluated when a cell enters the border.  Promoted slots stay
-// behind as holes and are squeezed out when the list runs short.  Window 128x128 cells; pits that
-// leave it (or exceed the list / drain capacity) go to the workgroup version.
+// new cell), loads the new elevations in parallel and files them by ballot rank.  As in the lane
+// version the drain tests are evaluated when a cell enters the border.  Window 128x128 cells; pits
+// that leave it (or exceed the list / drain capacity) go to the workgroup version.
 // ---------------------------------------------------------------------------------------------
-constexpr int W2 = 128;           // window edge (positions fit 14 bits; 0xFFFF marks a hole)
-constexpr int W2_CAP = 512;       // border list capacity
+constexpr int W2 = 128;           // window edge (positions fit 14 bits)
+constexpr int W2_CAP = 384;       // border list capacity (6 slots per lane)
+constexpr int W2_SLOTS = W2_CAP / 64;
 constexpr int WV_MAXD = 64;       // drain list capacity
+constexpr uint16_t W2_HOLE = 0xFFFF, W2_PITBIT = 1u << 14;
 
 struct WaveLds {
     uint32_t seen[W2 * W2 / 32];
     double le[W2_CAP];
-    uint16_t lpos[W2_CAP];
-    uint8_t lpm[W2_CAP];
-    uint16_t pq[64];
-    int32_t dl[WV_MAXD];
-    double dxy[WV_MAXD], sv[WV_MAXD];
+    uint16_t lpos[W2_CAP];        // window position | W2_PITBIT; W2_HOLE = free slot
+    uint16_t holes[W2_CAP];       // free slots below the list end
+    union {
+        uint16_t pq[W2_CAP];      // cells promoted in the current round
+        struct { int32_t dl[WV_MAXD]; double dxy[WV_MAXD], sv[WV_MAXD]; } fin;   // drain scratch (after the rounds)
+    } u;
 };
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_fmin(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return fmin(v, __hiloint2double(hi2, lo2));
+}
+// minimum over the wavefront: butterflies inside each row of 16 lanes on the DPP crossbar, then the four
+// row values through scalar registers
 __device__ __forceinline__ double wave_min(double v)
 {
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
-    return v;
+    v = dpp_fmin<0xB1>(v);        // quad_perm [1,0,3,2]
+    v = dpp_fmin<0x4E>(v);        // quad_perm [2,3,0,1]
+    v = dpp_fmin<0x141>(v);       // row_half_mirror
+    v = dpp_fmin<0x140>(v);       // row_mirror
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double r = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    r = fmin(r, __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16)));
+    r = fmin(r, __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)));
+    r = fmin(r, __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48)));
+    return r;
 }
 __device__ __forceinline__ void wave_sync()
 {
@@ -497,17 +520,17 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
     for (int w = lane; w < W2 * W2 / 32; w += 64) L.seen[w] = 0;
     const double epit = P.elev[pit];
     double epit_border = epit;
-    int nb = 0, n_alive = 0;        // list end / live entries (wave-uniform)
+    int nb = 0, nh = 0, n_alive = 0;        // list end / free slots below it / live entries (wave-uniform)
     bool has_np = false, has_p = false;
-    int over = 0;                   // 1: left the window, 2: list capacity, 3: drain capacity
-    // the unseen neighbours of the nq cells in L.pq join the border
+    int over = 0;                           // 1: left the window, 2: list capacity, 3: drain capacity
+    // the unseen neighbours of the nq cells in L.u.pq join the border
     auto expand = [&](int nq) {
         for (int base = 0; base < nq * 8; base += 64) {
             const int idx = base + lane;
             bool isnew = false, out = false;
-            double e = 0.0; uint8_t pm = 0; int npos = 0;
+            double e = 0.0; uint32_t pm = 0; int npos = 0;
             if (idx < nq * 8) {
-                const int pos = L.pq[idx >> 3], d = idx & 7;
+                const int pos = L.u.pq[idx >> 3], d = idx & 7;
                 const int di = d < 3 ? -1 : (d < 5 ? 0 : 1);
                 const int dj = d < 3 ? d - 1 : (d == 3 ? -1 : (d == 4 ? 1 : d - 6));
                 const int r = pos / W2, c = pos % W2;
@@ -530,18 +553,23 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
             if (__ballot(out)) over = 1;
             const unsigned long long bal = __ballot(isnew);
             const int cnt = __popcll(bal);
-            if (nb + cnt > W2_CAP) { over = 2; break; }
-            if (isnew) { const int k = nb + __popcll(bal & lt); L.le[k] = e; L.lpos[k] = (uint16_t)npos; L.lpm[k] = pm; }
+            const int fresh = cnt > nh ? cnt - nh : 0;                           // slots taken beyond the list end
+            if (nb + fresh > W2_CAP) { over = 2; break; }
+            if (isnew) {
+                const int rk = __popcll(bal & lt);
+                const int k = rk < nh ? (int)L.holes[nh - 1 - rk] : nb + (rk - nh);
+                L.le[k] = e; L.lpos[k] = (uint16_t)(npos | (pm ? W2_PITBIT : 0));
+            }
             if (__ballot(isnew && pm && e < epit)) has_p = true;
             if (__ballot(isnew && !pm && e < epit_border)) has_np = true;
-            nb += cnt; n_alive += cnt;
+            nh -= cnt - fresh; nb += fresh; n_alive += cnt;
         }
         wave_sync();
     };
     if (lane == 0) {                                                             // pit_area = [pit] (:1289-1292)
         const int pos = (ipit - r0) * W2 + (jpit - c0);
         L.seen[pos >> 5] = 1u << (pos & 31);
-        L.pq[0] = (uint16_t)pos;
+        L.u.pq[0] = (uint16_t)pos;
     }
     wave_sync();
     expand(1);
@@ -559,39 +587,38 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
         if (has_np) { mode = 1; break; }                                         // :1312-1316
         if (has_p) { mode = 2; break; }                                          // :1317-1320
         it_used = it + 1;
-        if (nb > W2_CAP - 128 && n_alive < nb) {                                 // squeeze the holes out
-            int wr = 0;
-            for (int base = 0; base < nb; base += 64) {
-                const int k = base + lane;
-                const bool alive = k < nb && L.lpos[k] != 0xFFFF;
-                const double e = alive ? L.le[k] : 0.0;
-                const uint16_t ps = alive ? L.lpos[k] : (uint16_t)0;
-                const uint8_t pm = alive ? L.lpm[k] : (uint8_t)0;
-                const unsigned long long bal = __ballot(alive);
-                wave_sync();
-                if (alive) { const int d = wr + __popcll(bal & lt); L.le[d] = e; L.lpos[d] = ps; L.lpm[d] = pm; }
-                wr += __popcll(bal);
-                wave_sync();
-            }
-            nb = wr;
-        }
+        // one read of the list: the minimum ...
+        double e[W2_SLOTS];
         double mn = INFINITY;
-        for (int k = lane; k < nb; k += 64) mn = fmin(mn, L.le[k]);
+#pragma unroll
+        for (int j = 0; j < W2_SLOTS; j++) {
+            const int k = lane + 64 * j;
+            e[j] = (j * 64 < nb && k < nb) ? L.le[k] : INFINITY;                 // free slots hold +inf
+            mn = fmin(mn, e[j]);
+        }
         mn = wave_min(mn);
-        // pit_area += border[eborder == emin] (:1322-1323); cells appended below sit beyond nb0
-        const int nb0 = nb;
-        for (int base = 0; base < nb0; base += 64) {
-            const int k = base + lane;
-            const bool match = k < nb0 && L.le[k] == mn && L.lpos[k] != 0xFFFF;
+        // ... and pit_area += border[eborder == emin] (:1322-1323): out of the list, slots recycled
+        int nq = 0;
+#pragma unroll
+        for (int j = 0; j < W2_SLOTS; j++) {
+            if (j * 64 >= nb) break;
+            const int k = lane + 64 * j;
+            bool match = k < nb && e[j] == mn;
+            uint16_t ps = 0;
+            if (match) { ps = L.lpos[k]; match = ps != W2_HOLE; }
             const unsigned long long bal = __ballot(match);
             if (!bal) continue;
-            if (match) { L.pq[__popcll(bal & lt)] = L.lpos[k]; L.le[k] = INFINITY; L.lpos[k] = 0xFFFF; }
-            const int nq = __popcll(bal);
-            n_alive -= nq;
-            wave_sync();
-            expand(nq);
-            if (over) break;
+            if (match) {
+                const int r = nq + __popcll(bal & lt);
+                L.u.pq[r] = (uint16_t)(ps & (W2_PITBIT - 1));
+                L.holes[nh + r] = (uint16_t)k;
+                L.le[k] = INFINITY; L.lpos[k] = W2_HOLE;
+            }
+            nq += __popcll(bal);
         }
+        nh += nq; n_alive -= nq;
+        wave_sync();
+        expand(nq);
     }
     if (!over && mode) {
         // drains: ballot-compacted, then rank-sorted into ascending cell order (the order of setdiff1d)
@@ -600,25 +627,27 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
             const int k = base + lane;
             bool pred = false;
             int32_t cell = 0;
-            if (k < nb && L.lpos[k] != 0xFFFF) {
-                const int pos = L.lpos[k];
-                const double e = L.le[k];
-                pred = mode == 1 ? (!L.lpm[k] && e < epit_border) : (L.lpm[k] && e < epit);
+            if (k < nb && L.lpos[k] != W2_HOLE) {
+                const int pos = L.lpos[k] & (W2_PITBIT - 1);
+                const bool pm = (L.lpos[k] & W2_PITBIT) != 0;
+                const double ev = L.le[k];
+                pred = mode == 1 ? (!pm && ev < epit_border) : (pm && ev < epit);
                 cell = (int32_t)((int64_t)(r0 + pos / W2) * m + (c0 + pos % W2));
             }
             const unsigned long long bal = __ballot(pred);
             const int rank = nd + __popcll(bal & lt);
-            if (pred && rank < WV_MAXD) L.dl[rank] = cell;
+            wave_sync();                                                         // (u.pq is dead: the drain scratch may be written)
+            if (pred && rank < WV_MAXD) L.u.fin.dl[rank] = cell;
             nd += __popcll(bal);
         }
         if (nd > WV_MAXD) over = 3;
         else {
             wave_sync();
-            const int32_t key = lane < nd ? L.dl[lane] : INT32_MAX;
+            const int32_t key = lane < nd ? L.u.fin.dl[lane] : INT32_MAX;
             int rank = 0;
-            for (int t = 0; t < nd; t++) rank += L.dl[t] < key;
+            for (int t = 0; t < nd; t++) rank += L.u.fin.dl[t] < key;
             wave_sync();
-            if (lane < nd) L.dl[rank] = key;
+            if (lane < nd) L.u.fin.dl[rank] = key;
             wave_sync();
             ndrain = nd;
         }
@@ -632,9 +661,8 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
         return;
     }
     if (ndrain < 0) { if (lane == 0) atomicAdd(&P.out_count[1], 1); return; }    // :1327-1329
-    finish_pit_wave(P, pit, ipit, jpit, epit, ndrain, L.dl, L.dxy, L.sv, chunk_base, chunk_left, lane);
+    finish_pit_wave(P, pit, ipit, jpit, epit, ndrain, L.u.fin.dl, L.u.fin.dxy, L.u.fin.sv, chunk_base, chunk_left, lane);
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Lane version (first pass over ALL pits).  The wavefront version spends ~700 VALU issues per round
