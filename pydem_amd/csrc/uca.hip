@@ -570,16 +570,28 @@ __global__ __launch_bounds__(1024) void k_sweep_small(SweepArgs A, QE *q0, QE *q
 // per round.  Cells finished in pass p carry level p.  The arithmetic per cell (gather order,
 // products) is identical to process_cell().
 constexpr int TT = 32, HW = TT + 2;
-constexpr uint32_t SP_STATE_SHIFT = 30;   // sp word: state (0 open, 1 final / outside, 2 finished now) << 30 | open-upstream count
+// sp half-word of a cell: bits 14-15 state (0 open, 1 final / outside, 2 finished in this pass), bit 13 "waits for
+// a cell another tile must finish", bits 0-12 upstream cells of this tile that are still open
+constexpr uint32_t SP_STATE_SHIFT = 14, SP_BLOCKED = 1u << 13;
+constexpr int TILE_RING = 512;  // ready-list ring (a push that does not fit is dropped: the cell stays open with a zero
+                                // count, the tile lists itself and the next pass picks the cell up in its setup)
 
 struct TileW {
-    uint32_t sp[HW * HW];     // state and unfinished-upstream count
-    uint16_t ci[HW * HW];     // static graph bits
-    uint16_t list[TT * TT];   // ready cells in the order they became ready (each cell enters once)
-    double a0[TT];            // cell area of the tile's rows
-    int tail;                 // list end
-    int open_cells;
+    uint16_t sp[HW * HW + 2];   // state and open-upstream count (16-bit halves of 32-bit words: LDS atomics work on the words)
+    uint16_t ci[HW * HW];       // static graph bits
+    uint16_t list[TILE_RING];   // ready cells in the order they became ready
+    double a0[TT];              // cell area of the tile's rows
+    int tail;                   // list end (monotonic; slot = index % TILE_RING)
+    int limit;                  // first list index whose push was dropped (INT_MAX: none): the pass stops there
 };
+
+// count-down of cell idx; returns the old half-word
+__device__ __forceinline__ uint32_t sp_dec(TileW &L, int idx)
+{
+    uint32_t *w = reinterpret_cast<uint32_t *>(L.sp) + (idx >> 1);
+    const int sh = (idx & 1) * 16;
+    return (atomicSub(w, 1u << sh) >> sh) & 0xFFFFu;
+}
 
 __device__ __forceinline__ void tile_wave_sync()
 {
@@ -599,58 +611,120 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
     const int by = tid / tiles_x, bx = tid - by * tiles_x;
     const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
     const int LOFF[8] = {-HW - 1, -HW, -HW + 1, -1, 1, HW - 1, HW, HW + 1};
-    // ---- stage the graph words of tile + halo
-    for (int idx = lane; idx < HW * HW; idx += 64) {
-        const int li = idx / HW, lj = idx - li * HW;
-        const int gi = i0 - 1 + li, gj = j0 - 1 + lj;
-        uint32_t cw = 0, st = 1;                                           // outside the grid: nothing drains from there
-        if (gi >= 0 && gi < n && gj >= 0 && gj < m) {
-            cw = A.cinfo[(int64_t)gi * m + gj];
-            const uint32_t lv = ci_level(cw);
-            st = (lv >= 1 && lv < pass);
-        }
-        L.ci[idx] = (uint16_t)(cw & CI_STATIC_MASK);
-        L.sp[idx] = st << SP_STATE_SHIFT;
-    }
-    if (lane == 0) { L.tail = 0; L.open_cells = 0; }
+    // ready-list push; `consumed` = entries already processed (ring occupancy = tail - consumed)
+    auto push_ready = [&](int cell, int consumed) {
+        const int slot = atomicAdd(&L.tail, 1);
+        if (slot - consumed < TILE_RING) L.list[slot % TILE_RING] = (uint16_t)cell;
+        else atomicMin(&L.limit, slot);
+    };
+    const bool prof = (A.dbg & 4) != 0;
+    long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+    int nrounds = 0;
+    if (prof) tk0 = clock64();
+    // ---- stage the graph words of tile + halo, five loads of a lane in flight at a time (the passes are
+    // latency-bound: a load-use-load-use loop would cost 19 memory round trips, one batch of 19 too many registers)
+    constexpr int NSTG = (HW * HW + 63) / 64, STG_B = 5;
+    if (lane == 0) { L.tail = 0; L.limit = INT32_MAX; }
     if (lane < TT) L.a0[lane] = i0 + lane < n ? A.a0[i0 + lane] : 0.0;
+#pragma unroll 1
+    for (int kb = 0; kb < NSTG; kb += STG_B) {
+        uint32_t wst[STG_B];
+#pragma unroll
+        for (int k = 0; k < STG_B; k++) {
+            const int idx = lane + 64 * (kb + k);
+            const int li = idx / HW, lj = idx - li * HW;
+            const int gi = i0 - 1 + li, gj = j0 - 1 + lj;
+            wst[k] = 0xFFFFFFFFu;                                          // marker: outside the grid
+            if (idx < HW * HW && gi >= 0 && gi < n && gj >= 0 && gj < m) wst[k] = A.cinfo[(int64_t)gi * m + gj];
+        }
+#pragma unroll
+        for (int k = 0; k < STG_B; k++) {
+            const int idx = lane + 64 * (kb + k);
+            if (idx < HW * HW) {
+                uint32_t cw = wst[k], st = 1;                              // outside the grid: nothing drains from there
+                if (cw == 0xFFFFFFFFu) cw = 0;
+                else { const uint32_t lv = ci_level(cw); st = (lv >= 1 && lv < pass); }
+                L.ci[idx] = (uint16_t)(cw & CI_STATIC_MASK);
+                L.sp[idx] = (uint16_t)(st << SP_STATE_SHIFT);
+            }
+        }
+    }
     tile_wave_sync();
-    // ---- per-cell setup: how many upstream cells are still open
-    for (int cell = lane; cell < TT * TT; cell += 64) {
+    if (prof) tk1 = clock64();
+    // ---- per-cell setup: how many upstream cells are still open.  First the neighbours (LDS only) ...
+    constexpr int NSET = TT * TT / 64;
+    uint32_t pitmask = 0;
+#pragma unroll 1
+    for (int k = 0; k < NSET; k++) {
+        const int cell = lane + 64 * k;
         const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
         const int gi = i0 + li - 1, gj = j0 + lj - 1;
         if (gi < n && gj < m && !(L.sp[idx] >> SP_STATE_SHIFT)) {
             const uint32_t cw = L.ci[idx];
-            const int32_t c = gi * m + gj;
             uint32_t pend = 0;
 #pragma unroll
             for (int d = 0; d < 8; d++)
                 if ((cw & (1u << d)) && !(L.sp[idx + LOFF[d]] >> SP_STATE_SHIFT)) pend++;
-            if (cw & CI_PIT_IN)                                     // pit -> drain edges are short: most sources sit in this tile
-                for (int32_t e = pit_stash(A, c).x; e < A.n_pit && A.pin_dst[e] == c; e++) {
-                    const int32_t sc = A.pin_src[e];
-                    const int si = sc / m - i0, sj = sc % m - j0;
-                    if (si >= 0 && si < TT && sj >= 0 && sj < TT) {
-                        if (!(L.sp[(si + 1) * HW + sj + 1] >> SP_STATE_SHIFT)) pend++;   // released on chip when the pit finishes
-                    } else {
-                        const uint32_t lv = ci_level(A.cinfo[sc]);
-                        if (!(lv >= 1 && lv < pass)) pend += 64;               // another tile's business: blocked for this pass
-                    }
+            L.sp[idx] = (uint16_t)pend;                             // the state bits of an open cell are zero: the half-word is the count
+            if (cw & CI_PIT_IN) pitmask |= 1u << k;
+            else if (pend == 0) push_ready(cell, 0);
+        }
+    }
+    // ... then the pit in-edges of the lane's drains: their list offsets in one batch, the edges two loads at a time
+    if (pitmask) {
+        constexpr int PB = 4;
+#pragma unroll 1
+        for (int kb = 0; kb < NSET; kb += PB) {
+            if (!((pitmask >> kb) & ((1u << PB) - 1u))) continue;
+            int32_t e0[PB];
+#pragma unroll
+            for (int k = 0; k < PB; k++) {
+                e0[k] = 0;
+                if (pitmask & (1u << (kb + k))) {
+                    const int cell = lane + 64 * (kb + k);
+                    e0[k] = pit_stash(A, (i0 + (cell >> 5)) * m + j0 + (cell & 31)).x;
                 }
-            // the state bits of an open cell are zero: the word is the count
-            L.sp[idx] = pend;
-            if (pend == 0) L.list[atomicAdd(&L.tail, 1)] = (uint16_t)cell;
+            }
+#pragma unroll
+            for (int k = 0; k < PB; k++) {
+                if (!(pitmask & (1u << (kb + k)))) continue;
+                const int cell = lane + 64 * (kb + k);
+                const int32_t c = (i0 + (cell >> 5)) * m + j0 + (cell & 31);
+                const int idx = ((cell >> 5) + 1) * HW + (cell & 31) + 1;
+                uint32_t pend = L.sp[idx];
+                for (int32_t e = e0[k];; e += 2) {                  // pit -> drain edges are short: most sources sit in this tile
+                    const int64_t ia = e < A.n_pit ? e : A.n_pit - 1, ib = e + 1 < A.n_pit ? e + 1 : A.n_pit - 1;
+                    const int32_t da = A.pin_dst[ia], db = A.pin_dst[ib], sa = A.pin_src[ia], sb = A.pin_src[ib];
+                    const bool va = e < A.n_pit && da == c, vb = va && e + 1 < A.n_pit && db == c;
+                    auto blocked = [&](int32_t sc) -> uint32_t {
+                        const int si = sc / m - i0, sj = sc % m - j0;
+                        if (si >= 0 && si < TT && sj >= 0 && sj < TT)
+                            return (L.sp[(si + 1) * HW + sj + 1] >> SP_STATE_SHIFT) ? 0u : 1u;   // released on chip when the pit finishes
+                        const uint32_t lv = ci_level(A.cinfo[sc]);
+                        return (lv >= 1 && lv < pass) ? 0u : SP_BLOCKED;                   // another tile's business: blocked for this pass
+                    };
+                    uint32_t ba = 0, bb = 0;
+                    if (va) ba = blocked(sa);
+                    if (vb) bb = blocked(sb);
+                    pend = (pend + (ba & 1u) + (bb & 1u)) | ((ba | bb) & SP_BLOCKED);
+                    if (!vb) break;
+                }
+                L.sp[idx] = (uint16_t)pend;
+                if (pend == 0) push_ready(cell, 0);
+            }
         }
     }
     tile_wave_sync();
     // ---- rounds: the ready cells [head, tail) are processed, the targets they release are appended
+    if (prof) tk2 = clock64();
     int32_t finalized = 0;
     int head = 0;
     for (;;) {
-        const int tail = L.tail;
-        if (head == tail) break;
+        const int tail = L.tail < L.limit ? L.tail : L.limit;
+        if (head >= tail) break;
+        nrounds++;
         for (int k = head + lane; k < tail; k += 64) {
-            const int cell = L.list[k];
+            const int cell = L.list[k % TILE_RING];
             const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
             const int gi = i0 + li - 1, gj = j0 + lj - 1;
             const int32_t c = gi * m + gj;
@@ -688,15 +762,14 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
             A.area[c] = a;
             A.contrib[c] = o;
             if (td) A.todo_work[c] = 1;
-            L.sp[idx] = 2u << SP_STATE_SHIFT;
+            L.sp[idx] = (uint16_t)(2u << SP_STATE_SHIFT);
             finalized++;
             // release the targets inside the tile; targets in other tiles may be ready now: their tiles run in the
             // next pass (listing a tile whose cell still waits for somebody else costs one idle staging; whoever
             // finishes last lists it again)
             auto release = [&](int ti, int tj) {      // tile-local coordinates 1..TT when inside
                 if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT) {
-                    const uint32_t old = atomicSub(&L.sp[ti * HW + tj], 1u);
-                    if (old == 1u) L.list[atomicAdd(&L.tail, 1)] = (uint16_t)((ti - 1) * TT + (tj - 1));
+                    if (sp_dec(L, ti * HW + tj) == 1u) push_ready((ti - 1) * TT + (tj - 1), head);
                 } else if (LISTED) {
                     const int gti = i0 + ti - 1, gtj = j0 + tj - 1;
                     if (gti < 0 || gti >= n || gtj < 0 || gtj >= m) return;
@@ -719,6 +792,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
         tile_wave_sync();
     }
     // ---- stamp what this pass finished (consecutive lanes own consecutive cells)
+    if (prof) tk3 = clock64();
     int open_cells = 0;
     for (int cell = lane; cell < TT * TT; cell += 64) {
         const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
@@ -733,6 +807,14 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
     if (lane == 0) {
         if (finalized) atomicAdd(n_final, finalized);
         if (!open_cells) tile_done[tid] = 1;
+        if (LISTED && L.limit != INT32_MAX && atomicExch(&N.flag[tid], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tid;
+        if (prof) {      // cycles per phase, summed over tiles (PYDEM_TILE_DEBUG=4)
+            const long long tk4 = clock64();
+            unsigned long long *acc = reinterpret_cast<unsigned long long *>(A.err + 1 + 16);   // counters[32..] region: see stage_sweep
+            atomicAdd(acc + 0, (unsigned long long)(tk1 - tk0)); atomicAdd(acc + 1, (unsigned long long)(tk2 - tk1));
+            atomicAdd(acc + 2, (unsigned long long)(tk3 - tk2)); atomicAdd(acc + 3, (unsigned long long)(tk4 - tk3));
+            atomicAdd(acc + 4, (unsigned long long)nrounds); atomicAdd(acc + 5, 1ull);
+        }
     }
     tile_wave_sync();
 }
@@ -740,7 +822,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
 // every tile that is not done yet, four tiles per workgroup, XCD-contiguous bands of tiles (LISTED: also
 // lists the tiles of the next pass)
 template <bool LISTED>
-__global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total,
+__global__ __launch_bounds__(256, 6) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total,
                                                      uint8_t *__restrict__ tile_done, int32_t *n_final, TileNext N)
 {
     __shared__ TileW L[4];
@@ -753,7 +835,7 @@ __global__ __launch_bounds__(256) void k_sweep_tiles(SweepArgs A, uint32_t pass,
 }
 
 // later passes: only the listed tiles (those a finished cell of the previous pass drains into); lists the next ones
-__global__ __launch_bounds__(256) void k_sweep_tiles_listed(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
+__global__ __launch_bounds__(256, 6) void k_sweep_tiles_listed(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
                                                             const int32_t *n_in, uint8_t *__restrict__ tile_done, int32_t *n_final,
                                                             TileNext N, int32_t *clear_count)
 {
@@ -1272,9 +1354,12 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     int32_t *cntT = t->counters + 56;          // rotating tile-list sizes
     HIP_TRY(hipMemsetAsync(tile_done, 0, tiles_pad * 5, t->stream));      // done bytes + stamps
     HIP_TRY(hipMemsetAsync(cntT, 0, 4 * sizeof(int32_t), t->stream));
+    if (A.dbg & 4) HIP_TRY(hipMemsetAsync(t->counters + 32, 0, 12 * sizeof(int32_t), t->stream));
     int64_t launches = 0;
     uint32_t pass = 0;
     int64_t done_prev = 0;
+    static int lds_pad = -1;        // occupancy experiments only: extra dynamic LDS per workgroup (PYDEM_TILE_LDS_PAD)
+    if (lds_pad < 0) { const char *e = getenv("PYDEM_TILE_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
     // listed tile passes from pass p on (the list of pass p is in tile_list[p % 2] / cntT[p % 3]); returns the next pass number
     auto run_listed = [&](int p, int64_t ntiles) -> int {
         TileNext N;
@@ -1284,7 +1369,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
             const int grid = (int)(ntiles < 8192 ? (ntiles > 64 ? ntiles : 64) : 8192);
             for (int b = 0; b < batch; b++, p++) {
                 N.list = tile_list[(p + 1) % 2]; N.count = &cntT[(p + 1) % 3];
-                hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), 0, t->stream, A, (uint32_t)p, tiles_x,
+                hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), (size_t)lds_pad, t->stream, A, (uint32_t)p, tiles_x,
                                    (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
                                    &cntT[(p + 2) % 3]);
                 launches++;
@@ -1304,9 +1389,9 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         // pass 1 over every tile, pass 2 over every tile that is not done (it also lists the tiles of pass 3),
         // then only the listed tiles until no tile is listed any more
         TileNext N0; N0.flag = nullptr; N0.list = nullptr; N0.count = nullptr;
-        hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), 0, t->stream, A, 1u, tiles_x, tiles_total, tile_done, total, N0);
+        hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, 1u, tiles_x, tiles_total, tile_done, total, N0);
         TileNext N; N.flag = tile_flag; N.list = tile_list[3 % 2]; N.count = &cntT[3 % 3];
-        hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(256), 0, t->stream, A, 2u, tiles_x, tiles_total, tile_done, total, N);
+        hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, 2u, tiles_x, tiles_total, tile_done, total, N);
         launches += 2;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
@@ -1318,6 +1403,11 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         t->tm.sweep_tile_passes = (int64_t)pass;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
+        if (A.dbg & 4) {
+            const unsigned long long *acc = (const unsigned long long *)(t->h_counters + 32);
+            fprintf(stderr, "tile phases (cycles summed over %llu tile runs): stage %llu, setup %llu, rounds %llu (%llu rounds), stamp %llu\n",
+                    acc[5], acc[0], acc[1], acc[2], acc[4], acc[3]);
+        }
     }
     if (sweep_mode == 1) {
     // every pass re-stages all tiles that still have an open cell (rivers cross most tiles), so after the
