@@ -37,7 +37,7 @@ struct RowTab {
     double hyp;       // sqrt(dX*dX + dY*dY)            (dem_processing.py:1962 denominator)
     double thA;       // atan2(dY, dX): facets 0,3,4,7  (dem_processing.py:1936)
     double thB;       // atan2(dX, dY): facets 1,2,5,6
-    double pad[3];
+    double rdX, rdY, rhyp;   // correctly rounded reciprocals of dX, dY, hyp (Markstein division in the marching stencil)
 };
 
 // pit -> drain edges: raw triplets as emitted (the reference's pit_i, pit_j, pit_prop) and two

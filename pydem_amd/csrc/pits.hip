@@ -98,6 +98,7 @@ struct PitParams {
     int32_t *overflow_list;     // pits to re-run with the large window
     int32_t *lane_overflow;     // pits the lane version hands to the wavefront version (count: out_count[4])
     int32_t *dbg;               // PYDEM_PITS_DEBUG=2: per-pit {rounds, last border size, hand-over reason, drains}
+    unsigned long long *prof;   // PYDEM_PITS_DEBUG=3: cycles per phase of the lane pass
 };
 
 // group = the threads that own one pit: a wavefront (NT = 64) or a whole workgroup (NT = 256)
@@ -715,6 +716,9 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
         const int32_t q = base + tid;
         int nd = 0;                 // drains of this lane's pit, sorted, in slots [0, nd)
         int status = 0;             // 1: drained, 2: no drain, 3: hand over to the wavefront version
+        const bool prof = P.prof != nullptr;
+        long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+        if (prof) tk0 = clock64();
         int32_t pit = 0;
         int r0 = 0, c0 = 0;
         double ssum = 0.0;
@@ -777,6 +781,7 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
             }
             int mode = 0;
             status = 2;
+            if (prof) tk1 = clock64();
             for (int it = 0; it < P.max_iter; it++) {                            // :1300
                 if (over) break;
                 if (nb == 0) break;                                              // :1304-1305
@@ -797,6 +802,7 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
                 // ... then the new border cells around them
                 for (int j = 0; j < nq; j++) { const int pos = lq[j * LN_T]; add_neighbours(pos >> 4, pos & 15); }
             }
+            if (prof) tk2 = clock64();
             if (over) status = 3;
             else if (mode) {
                 // drains to the front of the list in ascending cell order (window order == cell order)
@@ -850,6 +856,7 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
             }
         }
         // ---- lanes are convergent again: one slot allocation / counter update per wavefront
+        if (prof) tk3 = clock64();
         int incl = nd;
         for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
         const int tot = __shfl(incl, 63);
@@ -874,6 +881,12 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
             if (lane == 0) obase = atomicAdd(&P.out_count[4], __popcll(b_ov));
             obase = __shfl(obase, 0);
             if (status == 3) P.lane_overflow[obase + __popcll(b_ov & ((1ull << lane) - 1ull))] = pit;
+        }
+        if (prof && lane == 0) {    // wave-level phase times (lane 0's clock: the phases are lock-step per wavefront)
+            const long long tk4 = clock64();
+            atomicAdd(P.prof + 0, (unsigned long long)(tk1 - tk0)); atomicAdd(P.prof + 1, (unsigned long long)(tk2 - tk1));
+            atomicAdd(P.prof + 2, (unsigned long long)(tk3 - tk2)); atomicAdd(P.prof + 3, (unsigned long long)(tk4 - tk3));
+            atomicAdd(P.prof + 4, 1ull);
         }
     }
 }
@@ -1020,8 +1033,9 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         }
         HIP_TRY(hipMemsetAsync(cnt + 1, 0, 8 * sizeof(int32_t), t->stream));
         PitParams P;
-        P.dbg = nullptr;
+        P.dbg = nullptr; P.prof = nullptr;
         const char *dbg_env = getenv("PYDEM_PITS_DEBUG");
+        if (dbg_env && atoi(dbg_env) == 3) { HIP_TRY(hipMalloc(&P.prof, 64)); HIP_TRY(hipMemsetAsync(P.prof, 0, 64, t->stream)); }
         if (dbg_env && atoi(dbg_env) >= 2) HIP_TRY(hipMalloc(&P.dbg, (size_t)npits * 16));
         HIP_TRY(hipMemsetAsync(t->pits.raw_src, 0xFF, (size_t)t->pits.raw_cap * 4, t->stream));   // -1 = unused slot
         P.elev = t->elev; P.pitmask = t->flat0; P.dX = t->dX; P.dY = t->dY; P.mag = t->mag; P.flats = t->flats;
@@ -1037,6 +1051,13 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         const int32_t n_lane_over = t->h_counters[5];
+        if (P.prof) {
+            unsigned long long h[8];
+            HIP_TRY(hipMemcpy(h, P.prof, 64, hipMemcpyDeviceToHost));
+            fprintf(stderr, "pits/lane phases (cycles summed over %llu wavefront iterations): init+first border %llu, rounds %llu, finish %llu, output %llu\n",
+                    h[4], h[0], h[1], h[2], h[3]);
+            (void)hipFree(P.prof); P.prof = nullptr;
+        }
         if (n_lane_over > 0) {
             const int gw = (int)(cdiv(n_lane_over, 4) < 16384 ? cdiv(n_lane_over, 4) : 16384);
             hipLaunchKernelGGL(k_pits_wave, dim3(gw), dim3(256), 0, t->stream, P, t->queue[0], cnt + 5);

@@ -108,19 +108,30 @@ __device__ __forceinline__ double winner_direction(const Best &b) { return direc
 // atan2(s, s) == atan2(d, d) in the reference).
 struct Acc { double rad2; int code; };
 
-__device__ __forceinline__ void facet_lean(double s1, double s2, double sd, double d1, double d2, int k, Acc &acc)
+// squares are passed in: an edge quotient enters up to two facets of a cell, its square is computed once
+__device__ __forceinline__ void facet_lean(double s1, double s2, double sd, double s1sq, double s2sq, double sdsq,
+                                           double d1, double d2, int k, Acc &acc)
 {
-    const double s1sq = s1 * s1;
     const bool s1gt = s1 > 0, s1le = s1 <= 0, s2gt = s2 > 0, s2le = s2 <= 0;
     const bool rgt = s1gt && s2gt && (s2 * d1 > s1 * d2);
     const bool diag = (s1le && s2gt) || rgt;                    // I1 :1973-1976
     const bool card = s1gt && s2le;                             // I2 :1978-1981
-    const bool none = s1le && (s2le || (s2gt && sd <= 0));      // I3 :1983-1984
-    double rad2 = diag ? sd * sd : s1sq + s2 * s2;
-    rad2 = card ? s1sq : rad2;
-    rad2 = none ? -1.0 : rad2;
-    const int code = 4 * k + (card ? 1 : (diag ? 2 : 3));
-    if (rad2 > acc.rad2) { acc.rad2 = rad2; acc.code = code; } // I4 :1986-1989
+    const bool none = s1le && (s2le || (s2gt && sd <= 0));      // I3 :1983-1984 (rad2 = -1 never beats the running maximum)
+    const double cand = card ? s1sq : (diag ? sdsq : s1sq + s2sq);
+    const bool upd = !none && cand > acc.rad2;                  // I4 :1986-1989
+    acc.rad2 = upd ? cand : acc.rad2;
+    acc.code = upd ? 4 * k + (card ? 1 : (diag ? 2 : 3)) : acc.code;
+}
+
+// x / d for a per-row spacing d with r = RN(1/d) from the host: q = RN(x*r), one exact remainder, one
+// correction -- Markstein's sequence returns the correctly rounded quotient (checked against 4e8
+// IEEE divisions on the host, oracle/ and tests compare the results bit for bit), 3 full-rate
+// operations instead of ~11 with a quarter-rate v_rcp_f64
+__device__ __forceinline__ double div_row(double x, double d, double r)
+{
+    const double q = x * r;
+    const double rem = __builtin_fma(-q, d, x);
+    return __builtin_fma(rem, r, q);
 }
 
 // all 8 facets of an interior cell.  tn = spacing row i-1 (facets 0-3), ts = row i (facets 4-7)
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict_
                                                        uint8_t *__restrict__ flat0, int strips, int chunks)
 {
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);          // wavefront id
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wavefront id (scalar: row tables via s_load)
     if (wid >= strips * chunks) return;
     const int chunk = wid / strips, strip = wid - chunk * strips;  // consecutive waves walk along a row band
     const int j = strip * 62 + lane;                                // this lane's column (lane 0 / 63 = halo)
@@ -256,12 +267,12 @@ __global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict_
     // quantities of the rows already in the window, as if they had entered one by one
     double zE0 = lane_next(z0), zW0 = lane_prev(z0);
     const RowTab t0 = rowtab[i0 - 1];
-    double hEs_N = (zN - lane_next(zN)) / t0.dX;        // E-edge of row i-1 over its south spacing dX[i-1]
-    double hEn_0 = (z0 - zE0) / t0.dX;                  // E-edge of row i over its north spacing dX[i-1]
-    double v_N = (zN - z0) / t0.dY;                     // vertical edge (i-1) -> i
-    double dSE_N = (zN - zE0) / t0.hyp;                 // diagonal (i-1,j) -> (i,j+1)
-    double dSW_N = (zN - zW0) / t0.hyp;                 // diagonal (i-1,j) -> (i,j-1)
-    double hEs_0 = (i0 <= n - 2) ? (z0 - zE0) / rowtab[i0].dX : 0.0;   // E-edge of row i over its south spacing dX[i]
+    double hEs_N = div_row(zN - lane_next(zN), t0.dX, t0.rdX);   // E-edge of row i-1 over its south spacing dX[i-1]
+    double hEn_0 = div_row(z0 - zE0, t0.dX, t0.rdX);             // E-edge of row i over its north spacing dX[i-1]
+    double v_N = div_row(zN - z0, t0.dY, t0.rdY);                // vertical edge (i-1) -> i
+    double dSE_N = div_row(zN - zE0, t0.hyp, t0.rhyp);           // diagonal (i-1,j) -> (i,j+1)
+    double dSW_N = div_row(zN - zW0, t0.hyp, t0.rhyp);           // diagonal (i-1,j) -> (i,j-1)
+    double hEs_0 = (i0 <= n - 2) ? div_row(z0 - zE0, rowtab[i0].dX, rowtab[i0].rdX) : 0.0;   // E-edge of row i over its south spacing dX[i]
     // neighbours' copies
     double hEs_N_L = lane_prev(hEs_N), dSE_N_L = lane_prev(dSE_N), v_N_L = lane_prev(v_N), v_N_R = lane_next(v_N);
     double dSW_N_R = lane_next(dSW_N), hEn_0_L = lane_prev(hEn_0), hEs_0_L = lane_prev(hEs_0);
@@ -271,11 +282,11 @@ __global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict_
         // ---- row i+1 enters
         const double zS = col[(size_t)(i + 1) * m];
         const double zES = lane_next(zS), zWS = lane_prev(zS);
-        const double hEn_S = (zS - zES) / ts.dX;        // E-edge of row i+1 over its north spacing dX[i]
-        const double v_0 = (z0 - zS) / ts.dY;           // vertical edge i -> i+1
-        const double dSE_0 = (z0 - zES) / ts.hyp;
-        const double dSW_0 = (z0 - zWS) / ts.hyp;
-        const double hEs_S = (i + 1 <= n - 2) ? (zS - zES) / rowtab[i + 1].dX : 0.0;
+        const double hEn_S = div_row(zS - zES, ts.dX, ts.rdX);   // E-edge of row i+1 over its north spacing dX[i]
+        const double v_0 = div_row(z0 - zS, ts.dY, ts.rdY);      // vertical edge i -> i+1
+        const double dSE_0 = div_row(z0 - zES, ts.hyp, ts.rhyp);
+        const double dSW_0 = div_row(z0 - zWS, ts.hyp, ts.rhyp);
+        const double hEs_S = (i + 1 <= n - 2) ? div_row(zS - zES, rowtab[i + 1].dX, rowtab[i + 1].rdX) : 0.0;
         const double hEn_S_L = lane_prev(hEn_S), v_0_L = lane_prev(v_0), v_0_R = lane_next(v_0);
         const double dSE_0_L = lane_prev(dSE_0), dSW_0_R = lane_next(dSW_0), hEs_S_L = lane_prev(hEs_S);
         // ---- the 8 facets of cell (i, j)
@@ -289,14 +300,17 @@ __global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict_
         const double s1_5 = v_0, s2_5 = -hEn_S_L;          // s1=(z0-zS)/dYs  s2=(zS-zSW)/dXs
         const double s2_6 = hEn_S;                         //                 s2=(zS-zSE)/dXs
         const double s1_7 = hEs_0, s2_7 = v_0_R;           // s1=(z0-zE)/dXs  s2=(zE-zSE)/dYs
-        facet_lean(s1_0, s2_0, sdNE, tn.dX, tn.dY, 0, acc);
-        facet_lean(s1_1, s2_1, sdNE, tn.dY, tn.dX, 1, acc);
-        facet_lean(s1_1, s2_2, sdNW, tn.dY, tn.dX, 2, acc);
-        facet_lean(s1_3, s2_3, sdNW, tn.dX, tn.dY, 3, acc);
-        facet_lean(s1_4, s2_4, dSW_0, ts.dX, ts.dY, 4, acc);
-        facet_lean(s1_5, s2_5, dSW_0, ts.dY, ts.dX, 5, acc);
-        facet_lean(s1_5, s2_6, dSE_0, ts.dY, ts.dX, 6, acc);
-        facet_lean(s1_7, s2_7, dSE_0, ts.dX, ts.dY, 7, acc);
+        // (x*x == (-x)*(-x): the squares are taken from the un-negated quotients)
+        const double qNE = dSW_N_R * dSW_N_R, qNW = dSE_N_L * dSE_N_L, qSW = dSW_0 * dSW_0, qSE = dSE_0 * dSE_0;
+        const double q1_1 = v_N * v_N, q1_5 = v_0 * v_0;
+        facet_lean(s1_0, s2_0, sdNE, hEn_0 * hEn_0, v_N_R * v_N_R, qNE, tn.dX, tn.dY, 0, acc);
+        facet_lean(s1_1, s2_1, sdNE, q1_1, hEs_N * hEs_N, qNE, tn.dY, tn.dX, 1, acc);
+        facet_lean(s1_1, s2_2, sdNW, q1_1, hEs_N_L * hEs_N_L, qNW, tn.dY, tn.dX, 2, acc);
+        facet_lean(s1_3, s2_3, sdNW, hEn_0_L * hEn_0_L, v_N_L * v_N_L, qNW, tn.dX, tn.dY, 3, acc);
+        facet_lean(s1_4, s2_4, dSW_0, hEs_0_L * hEs_0_L, v_0_L * v_0_L, qSW, ts.dX, ts.dY, 4, acc);
+        facet_lean(s1_5, s2_5, dSW_0, q1_5, hEn_S_L * hEn_S_L, qSW, ts.dY, ts.dX, 5, acc);
+        facet_lean(s1_5, s2_6, dSE_0, q1_5, hEn_S * hEn_S, qSE, ts.dY, ts.dX, 6, acc);
+        facet_lean(s1_7, s2_7, dSE_0, hEs_0 * hEs_0, v_0_R * v_0_R, qSE, ts.dX, ts.dY, 7, acc);
         if (lane >= 1 && lane <= 62 && j >= 1 && j < m - 1) {
             const int k = acc.code >> 2, kind = acc.code & 3;
             // slopes / table angle of the winning facet

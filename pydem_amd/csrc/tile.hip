@@ -185,7 +185,7 @@ int pydem_tile_set_spacing(pydem_tile *t, const double *dX, const double *dY, co
         e.hyp = sqrt(dX[r] * dX[r] + dY[r] * dY[r]);   // np.sqrt(d1**2 + d2**2), dem_processing.py:1962
         e.thA = atan2(dY[r], dX[r]);                    // np.arctan2(d2, d1), :1936 (host libm == numpy)
         e.thB = atan2(dX[r], dY[r]);
-        e.pad[0] = e.pad[1] = e.pad[2] = 0;
+        e.rdX = 1.0 / e.dX; e.rdY = 1.0 / e.dY; e.rhyp = 1.0 / e.hyp;
     }
     // theta per row for section/proportion: facet-0 spacing of rows 1..n-2 with the first and last
     // entries duplicated (dem_processing.py:1031-1033)
