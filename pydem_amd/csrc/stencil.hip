@@ -73,11 +73,13 @@ __device__ __constant__ const double ATAN_16[17] = {
 
 __device__ __forceinline__ double atan2_pos(double y, double x)
 {
+    // atan(num/den), num <= den: c = nearest multiple of 1/16 to the quotient (a raw reciprocal is good enough to pick
+    // it), u = (num/den - c) / (1 + c num/den) = (num - c den) / (den + c num): one division
     const bool swap = y > x;
-    const double q = swap ? x / y : y / x;
-    const double kf = rint(q * 16.0);
+    const double num = swap ? x : y, den = swap ? y : x;
+    const double kf = rint(num * __builtin_amdgcn_rcp(den) * 16.0);
     const double c = kf * 0.0625;
-    const double u = (q - c) / __builtin_fma(q, c, 1.0);
+    const double u = __builtin_fma(-c, den, num) / __builtin_fma(c, num, den);
     const double w = u * u;
     double p = __builtin_fma(w, -1.0 / 11, 1.0 / 9);
     p = __builtin_fma(w, p, -1.0 / 7);
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict_
     double hEs_N_L = lane_prev(hEs_N), dSE_N_L = lane_prev(dSE_N), v_N_L = lane_prev(v_N), v_N_R = lane_next(v_N);
     double dSW_N_R = lane_next(dSW_N), hEn_0_L = lane_prev(hEn_0), hEs_0_L = lane_prev(hEs_0);
 
+#pragma unroll 2
     for (int i = i0; i < i1; i++) {
         const RowTab tn = rowtab[i - 1], ts = rowtab[i];
         // ---- row i+1 enters
