@@ -50,11 +50,22 @@ __device__ __constant__ const int NB_DJ[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
 __device__ __constant__ const int NB_S0[8] = {6, 5, 4, 0, 3, 0, 1, 2};
 __device__ __constant__ const int NB_S1[8] = {7, 6, 5, 7, 4, 1, 2, 3};
 
-// ------------------------------------------------------------------------------- K3
+// keep-filter of _mk_adjacency_matrix (:1136-1137)
+__device__ __forceinline__ bool keep_edge(double w, double z_to, double z_from)
+{
+    return !isnan(w) && (w > 1e-8) && (z_to <= z_from);
+}
+
+// ------------------------------------------------------------------------------- K3 (+ first half of K4)
+// section / proportion, and while both are in registers the cell's two regular out-edges (keep-filter of
+// :1136-1137): the graph word leaves this kernel with its out flags and facet index; the in-mask follows
+// in k_graph_inmask from the neighbours' words
 __global__ __launch_bounds__(256) void k_section_proportion(const double *__restrict__ dir,
                                                             const uint8_t *__restrict__ flats,
-                                                            const double *__restrict__ sec_theta, int64_t NN, int m,
-                                                            int8_t *__restrict__ section, double *__restrict__ prop)
+                                                            const double *__restrict__ sec_theta, int64_t NN, int n, int m,
+                                                            const double *__restrict__ elev,
+                                                            int8_t *__restrict__ section, double *__restrict__ prop,
+                                                            uint32_t *__restrict__ cinfo)
 {
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < NN; c += (int64_t)gridDim.x * blockDim.x) {
         const double theta = sec_theta[c / m];
@@ -74,56 +85,54 @@ __global__ __launch_bounds__(256) void k_section_proportion(const double *__rest
         if (flats[c]) { sec = -1; p = NAN; }                                     // :1064-1065
         if (sec == 8) sec = 0;                                                   // :1067
         const int a = (sec & 1) ? -1 : 1;                                        // adjust[section], negative wraps
-        prop[c] = (1 + a) / 2.0 - (double)a * p;                                 // :1068
+        const double pf = (1 + a) / 2.0 - (double)a * p;                         // :1068
+        prop[c] = pf;
         section[c] = (int8_t)sec;
+        uint32_t gf = 0;
+        if (sec >= 0 && sec <= 7) {
+            const int i = (int)(c / m), j = (int)(c - (int64_t)i * m);
+            const double z = elev[c];
+            const int i1 = i + fe1r(sec), j1 = j + fe1c(sec), i2 = i + fe2r(sec), j2 = j + fe2c(sec);
+            if (i1 >= 0 && i1 < n && j1 >= 0 && j1 < m && keep_edge(pf, elev[(int64_t)i1 * m + j1], z)) gf |= CI_OUT1;
+            if (i2 >= 0 && i2 < n && j2 >= 0 && j2 < m && keep_edge(1 - pf, elev[(int64_t)i2 * m + j2], z)) gf |= CI_OUT2;   // weights [prop, 1 - prop] :1082
+        }
+        cinfo[c] = gf | ((uint32_t)(sec & 7) << CI_SEC_SHIFT);
     }
 }
 
 // ------------------------------------------------------------------------------- K4
-// keep-filter of _mk_adjacency_matrix (:1136-1137)
-__device__ __forceinline__ bool keep_edge(double w, double z_to, double z_from)
-{
-    return !isnan(w) && (w > 1e-8) && (z_to <= z_from);
-}
-
-__global__ __launch_bounds__(256) void k_build_graph(const int8_t *__restrict__ section, const double *__restrict__ prop,
-                                                     const double *__restrict__ elev, int n, int m,
-                                                     uint32_t *__restrict__ cinfo, uint8_t *__restrict__ todo0,
-                                                     uint8_t *__restrict__ todo_work, double *__restrict__ corner_sums)
+// second half of K4: a neighbour drains into this cell iff its facet points here and that out-edge survived the
+// keep-filter -- both are in the neighbour's graph word (4 B, row-coalesced) instead of its section, proportion
+// and elevation
+__global__ __launch_bounds__(256) void k_graph_inmask(const double *__restrict__ prop, const double *__restrict__ elev,
+                                                      int n, int m, uint32_t *__restrict__ cinfo, uint8_t *__restrict__ todo0,
+                                                      uint8_t *__restrict__ todo_work, double *__restrict__ corner_sums)
 {
     const int64_t NN = (int64_t)n * m;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < NN; c += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(c / m), j = (int)(c - (int64_t)i * m);
-        const int s = section[c];
-        const double p = prop[c], z = elev[c];
-        uint32_t gf = 0;
-        double outsum = 0.0;
-        if (s >= 0 && s <= 7) {
-            const int i1 = i + fe1r(s), j1 = j + fe1c(s), i2 = i + fe2r(s), j2 = j + fe2c(s);
-            const double w2 = 1 - p;                                             // :1082
-            if (i1 >= 0 && i1 < n && j1 >= 0 && j1 < m && keep_edge(p, elev[(int64_t)i1 * m + j1], z)) { gf |= CI_OUT1; outsum += p; }
-            if (i2 >= 0 && i2 < n && j2 >= 0 && j2 < m && keep_edge(w2, elev[(int64_t)i2 * m + j2], z)) { gf |= CI_OUT2; outsum += w2; }
-        }
-        uint8_t im = 0;
-        double insum = 0.0;
+        const uint32_t cw = cinfo[c] & (CI_OUT1 | CI_OUT2 | (7u << CI_SEC_SHIFT));
+        uint32_t im = 0;
 #pragma unroll
         for (int d = 0; d < 8; d++) {
             const int ui = i + NB_DI[d], uj = j + NB_DJ[d];
             if (ui < 0 || ui >= n || uj < 0 || uj >= m) continue;
-            const int64_t u = (int64_t)ui * m + uj;
-            const int su = section[u];
-            if (su != NB_S0[d] && su != NB_S1[d]) continue;
+            const uint32_t wu = cinfo[(int64_t)ui * m + uj];
+            const int su = (int)((wu >> CI_SEC_SHIFT) & 7u);
             const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
-            const double pu = prop[u];
-            const double w = cardinal ? pu : 1 - pu;
-            if (keep_edge(w, z, elev[u])) { im |= (uint8_t)(1u << d); insum += w; }
+            if ((su == NB_S0[d] || su == NB_S1[d]) && (wu & (cardinal ? CI_OUT1 : CI_OUT2))) im |= 1u << d;
         }
         // sources (no in-edges) are round 0
-        cinfo[c] = (uint32_t)im | gf | ((uint32_t)(s & 7) << CI_SEC_SHIFT) | ((im ? CI_LEVEL_INF : 0u) << CI_LEVEL_SHIFT);
+        cinfo[c] = im | cw | ((im ? CI_LEVEL_INF : 0u) << CI_LEVEL_SHIFT);
         // inlet-edge detection (_calc_uca_chunk :909-930); interior cells are never 'todo'
         const bool top = i == 0, bot = i == n - 1, left = j == 0, right = j == m - 1;
         if (top || bot || left || right) {
             const double TOL = 1e-2;
+            const double p = prop[c], z = elev[c];
+            double outsum = 0.0;
+            if (cw & CI_OUT1) outsum += p;
+            if (cw & CI_OUT2) outsum += 1 - p;
+            const int s = (cw & (CI_OUT1 | CI_OUT2)) ? ci_section(cw) : -1;     // only cells with an out-edge can be inlets
             bool td = false;
             const bool has_out = outsum > TOL;
             // assignment order of the reference: left, right, top, bottom (later overwrite earlier)
@@ -132,6 +141,13 @@ __global__ __launch_bounds__(256) void k_build_graph(const int8_t *__restrict__ 
             if (top) td = has_out && (s == 4 || s == 5 || s == 6 || s == 7);
             if (bot) td = has_out && (s == 0 || s == 1 || s == 2 || s == 3);
             if ((top || bot) && (left || right)) {
+                double insum = 0.0;
+                for (int d = 0; d < 8; d++)
+                    if (im & (1u << d)) {
+                        const int64_t u = (int64_t)(i + NB_DI[d]) * m + (j + NB_DJ[d]);
+                        const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
+                        insum += cardinal ? prop[u] : 1 - prop[u];
+                    }
                 const int q = (top ? 0 : 2) + (left ? 0 : 1);
                 corner_sums[q * 3 + 0] = outsum;
                 corner_sums[q * 3 + 1] = insum;
@@ -1276,8 +1292,8 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt)
     PYDEM_TRY(tile_alloc(t, &t->pit_blk, (size_t)(nblk + 2) * 2));
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
     const int big = grid_for(t->NN, 8192);
-    hipLaunchKernelGGL(k_section_proportion, dim3(big), dim3(256), 0, t->stream, t->dir, t->flats, t->sec_theta, t->NN, m,
-                       t->section, t->prop);
+    hipLaunchKernelGGL(k_section_proportion, dim3(big), dim3(256), 0, t->stream, t->dir, t->flats, t->sec_theta, t->NN, n, m,
+                       t->elev, t->section, t->prop, (uint32_t *)t->indeg);
     HIP_TRY(hipEventRecord(t->ev[1], t->stream));
     t->tm.n_pit_edges = 0; t->tm.n_pits_undrained = 0; t->tm.pits_ms = 0;
     t->pits.n_edges = 0; t->pits.n_raw = 0;
@@ -1287,7 +1303,7 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt)
     HIP_TRY(hipMemsetAsync(t->counters, 0, 64 * sizeof(int32_t), t->stream));
     HIP_TRY(hipMemsetAsync(t->edge_todo, 0, (size_t)t->NN, t->stream));
     HIP_TRY(hipMemsetAsync(t->todo_work, 0, (size_t)t->NN, t->stream));
-    hipLaunchKernelGGL(k_build_graph, dim3(big), dim3(256), 0, t->stream, t->section, t->prop, t->elev, n, m,
+    hipLaunchKernelGGL(k_graph_inmask, dim3(big), dim3(256), 0, t->stream, t->prop, t->elev, n, m,
                        (uint32_t *)t->indeg, t->edge_todo, t->todo_work, corner_sums);
     if (t->pits.n_edges > 0) {
         hipLaunchKernelGGL(k_graph_add_pits, dim3(grid_for(t->pits.n_edges, 1024)), dim3(256), 0, t->stream, t->pits.src,
