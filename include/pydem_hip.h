@@ -169,6 +169,22 @@ int pydem_comm_pack_line(pydem_comm *c, pydem_tile *t, int field, int axis, int6
 int pydem_comm_put(pydem_comm *c, const double *host_in, int64_t n_doubles, int64_t offset);
 int pydem_comm_allreduce(pydem_comm *c, int64_t n_doubles, int op /* 0 sum, 1 max */, double *host_out);
 
+/* ---- elevation conditioning: host-side inner loops (no device work; pydem_amd/conditioning.py keeps the
+ * vectorised prologues -- 3x3 filters, scipy.ndimage.label, the numpy argsort whose tie order is part of the
+ * result -- and calls these for the per-region / per-pit loops of the reference)
+ *   pydem_cond_pit_artifacts: calc_fill_pit_artifacts (dem_processing.py:396-426); lab = labels (1..nlab) of the
+ *       candidate depressions, raise[c] = 1 where the cell is lifted by one unit
+ *   pydem_cond_fill_flats:    _fill_flat (:308-394) for every labelled flat of calc_fill_flats (:551-579);
+ *       data = unmodified surface (float64, NaN = masked), built = copy of it that receives the new flats
+ *   pydem_cond_pit_paths:     calc_pit_drain_paths (:428-548) for the pits in the given order, surface edited in place */
+int pydem_cond_pit_artifacts(const double *elev, int64_t n_rows, int64_t n_cols, const int32_t *lab, int32_t nlab,
+                             double max_area, uint8_t *raise);
+int pydem_cond_fill_flats(const double *data, double *built, int64_t n_rows, int64_t n_cols, const int32_t *lab,
+                          int32_t nlab, double source_tol, int peaks, int pits);
+int pydem_cond_pit_paths(double *elev, int64_t n_rows, int64_t n_cols, const int64_t *pits, int64_t npits,
+                         const double *dX, int64_t n_dX, const double *dY, int max_iter, int max_dist,
+                         double max_dist_XY, int64_t *n_failed, int64_t *iter_used);
+
 #ifdef __cplusplus
 }
 #endif

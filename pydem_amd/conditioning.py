@@ -4,17 +4,31 @@ These are the three steps the reference runs before the slope stencil when `fill
 `drain_pits_path` are set (creare-com/pydem v1.2.1, pydem/dem_processing.py: calc_fill_pit_artifacts
 :396-426, calc_fill_flats :551-579 with _fill_flat :308-394, calc_pit_drain_paths :428-548, helpers
 pydem/utils.py:270-468).  They are region-by-region / pit-by-pit sequential algorithms (each pit path
-edits the surface the next pit sees), so this first implementation keeps them on the host in
-numpy / scipy.ndimage -- like the reference -- and hands the conditioned surface to the device path.
-It is written against the reference's *behaviour* (every quirk that changes a value is reproduced and
-cited); results are pinned bit for bit by tests/golden/g5_* and g7_* (captured from the reference).
+edits the surface the next pit sees).  The vectorised prologues stay in numpy / scipy.ndimage (3x3
+filters, connected-component labels, and the argsort whose tie order is part of the result); the
+per-region / per-pit loops -- 20 k tiny scipy calls for a 768^2 tile -- run in the native library
+(csrc/conditioning.hip, host code behind the same C-ABI; ~60x faster than the numpy loops below).
+The numpy versions of those loops are kept as `*_numpy` functions: they are what the native code was
+written from and the tests compare the two on random tiles.  Everything is written against the
+reference's *behaviour* (every quirk that changes a value is reproduced and cited); results are pinned
+bit for bit by tests/golden/g5_* and g7_* (captured from the reference).
 
 A device version is future work.
 """
+import ctypes as C
 import warnings
 
 import numpy as np
 from scipy import ndimage
+
+
+def _native():
+    from . import _ffi
+    return _ffi.load()
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
 
 _EIGHT = np.ones((3, 3), bool)
 _CROSS = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]])
@@ -32,6 +46,22 @@ def _sea_mask(a, below_sea):
 def fill_pit_artifacts(elev, maximum_pit_area=32.0, fill_flats_below_sea=False):
     """Raise by one unit every small flat depression whose whole 8-connected rim is exactly one unit
     higher -- the signature of integer quantisation.  Keeps the input dtype."""
+    elev = np.asarray(elev)
+    if elev.dtype == np.float32 or np.ma.isMaskedArray(elev) or elev.ndim != 2:
+        return fill_pit_artifacts_numpy(elev, maximum_pit_area, fill_flats_below_sea)   # float32 rounds `rim - 1` differently
+    low = (ndimage.minimum_filter(elev, (3, 3)) >= elev) & _sea_mask(elev, fill_flats_below_sea)
+    lab, nlab = ndimage.label(low, structure=_EIGHT)
+    lab = np.ascontiguousarray(lab, np.int32)
+    z = np.ascontiguousarray(elev, np.float64)
+    up = np.empty(elev.shape, np.uint8)
+    lib = _native()
+    if lib.pydem_cond_pit_artifacts(_ptr(z), elev.shape[0], elev.shape[1], _ptr(lab), int(nlab), float(maximum_pit_area), _ptr(up)):
+        raise RuntimeError("pydem_cond_pit_artifacts failed")
+    return elev + up.astype(elev.dtype)
+
+
+def fill_pit_artifacts_numpy(elev, maximum_pit_area=32.0, fill_flats_below_sea=False):
+    """The same in numpy / scipy (what the native loop was written from; used by the tests and for float32)."""
     elev = np.asarray(elev)
     out = elev.copy()
     low = (ndimage.minimum_filter(elev, (3, 3)) >= elev) & _sea_mask(elev, fill_flats_below_sea)
@@ -147,6 +177,24 @@ def fill_flats(elev, maximum_pit_area=32.0, fill_flats_below_sea=False, fill_fla
     re-surfaced between its uphill rim and its outlet.  Returns float64."""
     if maximum_pit_area:
         elev = fill_pit_artifacts(elev, maximum_pit_area, fill_flats_below_sea)
+    data = np.ascontiguousarray(np.ma.filled(np.asarray(elev).astype('float64'), np.nan))
+    built = data.copy()
+    flat = (ndimage.minimum_filter(data, (3, 3)) >= data) & _sea_mask(data, fill_flats_below_sea)
+    flat[0, 0] = flat[-1, 0] = flat[0, -1] = flat[-1, -1] = False          # corners never (:569-572)
+    lab, nlab = ndimage.label(flat, structure=_EIGHT)
+    lab = np.ascontiguousarray(lab, np.int32)
+    lib = _native()
+    if lib.pydem_cond_fill_flats(_ptr(data), _ptr(built), data.shape[0], data.shape[1], _ptr(lab), int(nlab),
+                                 float(fill_flats_source_tol), int(bool(fill_flats_peaks)), int(bool(fill_flats_pits))):
+        raise RuntimeError("pydem_cond_fill_flats failed")
+    return built
+
+
+def fill_flats_numpy(elev, maximum_pit_area=32.0, fill_flats_below_sea=False, fill_flats_source_tol=1,
+                     fill_flats_peaks=True, fill_flats_pits=True):
+    """The same in numpy / scipy (what the native loop was written from; used by the tests)."""
+    if maximum_pit_area:
+        elev = fill_pit_artifacts_numpy(elev, maximum_pit_area, fill_flats_below_sea)
     data = np.ma.filled(np.asarray(elev).astype('float64'), np.nan)
     built = data.copy()
     edge = np.ones(data.shape, bool)
@@ -197,6 +245,31 @@ def pit_drain_paths(elev, dX, dY, drain_pits_max_iter=300, drain_pits_max_dist=3
     that fall linearly from pit to outlet.  The surface is edited IN PLACE and sequentially -- later pits
     see earlier paths -- in the array's own dtype, exactly like the reference.  Returns (elev, n_failed,
     max_iter_used)."""
+    if not (isinstance(elev, np.ndarray) and elev.dtype == np.float64 and elev.flags.c_contiguous and elev.ndim == 2
+            and not np.ma.isMaskedArray(elev)):
+        return pit_drain_paths_numpy(elev, dX, dY, drain_pits_max_iter, drain_pits_max_dist, drain_pits_max_dist_XY,
+                                     fill_flats_below_sea)       # integer surfaces truncate the path values: numpy semantics
+    e = elev.ravel()
+    lows = (ndimage.minimum_filter(elev, footprint=_RING).ravel() > e) & _sea_mask(e, fill_flats_below_sea)
+    pit_ids = np.where(lows)[0]
+    order = np.ascontiguousarray(pit_ids[np.argsort(e[pit_ids])], np.int64)   # same call as the reference (:450): same tie order
+    dXc = np.ascontiguousarray(dX, np.float64)
+    dYc = np.ascontiguousarray(dY, np.float64)
+    failed = C.c_int64(0)
+    used = C.c_int64(0)
+    lib = _native()
+    if lib.pydem_cond_pit_paths(_ptr(elev), elev.shape[0], elev.shape[1], _ptr(order), order.size, _ptr(dXc), dXc.size, _ptr(dYc),
+                                int(drain_pits_max_iter), int(drain_pits_max_dist or 0),
+                                float(drain_pits_max_dist_XY) if drain_pits_max_dist_XY else 0.0, C.byref(failed), C.byref(used)):
+        raise RuntimeError("pydem_cond_pit_paths failed")
+    if failed.value:
+        warnings.warn("Warning %d pits had no place to drain to in this chunk" % failed.value)
+    return elev, int(failed.value), int(used.value)
+
+
+def pit_drain_paths_numpy(elev, dX, dY, drain_pits_max_iter=300, drain_pits_max_dist=32, drain_pits_max_dist_XY=None,
+                          fill_flats_below_sea=False):
+    """The same in numpy (what the native loop was written from; used by the tests and for non-float64 surfaces)."""
     nr, nc = elev.shape
     e = elev.ravel()                                             # view: edits land in `elev`
     lows = (ndimage.minimum_filter(elev, footprint=_RING).ravel() > e) & _sea_mask(e, fill_flats_below_sea)

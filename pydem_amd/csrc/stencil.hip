@@ -279,7 +279,6 @@ __global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict_
     double hEs_N_L = lane_prev(hEs_N), dSE_N_L = lane_prev(dSE_N), v_N_L = lane_prev(v_N), v_N_R = lane_next(v_N);
     double dSW_N_R = lane_next(dSW_N), hEn_0_L = lane_prev(hEn_0), hEs_0_L = lane_prev(hEs_0);
 
-#pragma unroll 2
     for (int i = i0; i < i1; i++) {
         const RowTab tn = rowtab[i - 1], ts = rowtab[i];
         // ---- row i+1 enters

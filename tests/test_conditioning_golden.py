@@ -32,3 +32,40 @@ def test_conditioning_matches_reference(name):
             out, _, _ = conditioning.pit_drain_paths(np.array(elev), g['in_dX'], g['in_dY'])
         assert out.dtype == g['elev_drained'].dtype
         assert np.array_equal(out, g['elev_drained'], equal_nan=True)
+
+
+@pytest.mark.parametrize('kind,shape,seed', [('srtm', (160, 200), 5), ('srtm', (257, 129), 6), ('quant', (192, 192), 7),
+                                            ('fractal', (128, 160), 8)])
+def test_native_loops_match_numpy_loops(kind, shape, seed):
+    """csrc/conditioning.hip against the numpy versions it was written from, on tiles with thousands of flats,
+    quantisation pits, plateaus on the tile edge and summit plateaus (bit for bit, all three stages)."""
+    from pydem_amd import synth
+    n, m = shape
+    if kind == 'srtm':
+        elev = synth.srtm_int16(n, m, seed=seed)
+    elif kind == 'quant':
+        elev = np.rint(synth.fractal(n, m, seed=seed, top_shift=6, n_octaves=6, zrange=40.0)).astype('int32')
+    else:
+        elev = synth.fractal(n, m, seed=seed, top_shift=6, n_octaves=7)
+    dX = 25.0 + 0.01 * np.arange(n - 1)
+    dY = 31.0 - 0.004 * np.arange(n - 1)
+    a1 = conditioning.fill_pit_artifacts(elev)
+    a0 = conditioning.fill_pit_artifacts_numpy(elev)
+    assert a1.dtype == a0.dtype and np.array_equal(a1, a0)
+    f1 = conditioning.fill_flats(elev)
+    f0 = conditioning.fill_flats_numpy(elev)
+    assert np.array_equal(f1, f0, equal_nan=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        p1, bad1, it1 = conditioning.pit_drain_paths(f1.copy(), dX, dY)
+        p0, bad0, it0 = conditioning.pit_drain_paths_numpy(f0.copy(), dX, dY)
+    assert np.array_equal(p1, p0, equal_nan=True) and bad1 == bad0 and it1 == it0
+    # options that take other branches: no peaks / no pits, tolerance 0, distance limits
+    g1 = conditioning.fill_flats(elev, fill_flats_source_tol=0, fill_flats_peaks=False, fill_flats_pits=False)
+    g0 = conditioning.fill_flats_numpy(elev, fill_flats_source_tol=0, fill_flats_peaks=False, fill_flats_pits=False)
+    assert np.array_equal(g1, g0, equal_nan=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        q1 = conditioning.pit_drain_paths(f1.copy(), dX, dY, drain_pits_max_iter=20, drain_pits_max_dist=6, drain_pits_max_dist_XY=150.0)
+        q0 = conditioning.pit_drain_paths_numpy(f0.copy(), dX, dY, drain_pits_max_iter=20, drain_pits_max_dist=6, drain_pits_max_dist_XY=150.0)
+    assert np.array_equal(q1[0], q0[0], equal_nan=True) and q1[1:] == q0[1:]
