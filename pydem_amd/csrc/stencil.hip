@@ -246,20 +246,20 @@ __device__ __forceinline__ double lane_next(double x)    // value held by lane+1
     return __hiloint2double(hi, lo);
 }
 
-constexpr int MARCH_ROWS = 128;   // output rows per wavefront
+constexpr int MARCH_ROWS = 128;   // output rows per wavefront on large tiles (fewer on small ones: the chip wants >= ~10 k wavefronts)
 
 __global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict__ elev, int n, int m,
                                                        const RowTab *__restrict__ rowtab,
                                                        double *__restrict__ mag, double *__restrict__ dir,
-                                                       uint8_t *__restrict__ flat0, int strips, int chunks)
+                                                       uint8_t *__restrict__ flat0, int strips, int chunks, int rows_per_wave)
 {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wavefront id (scalar: row tables via s_load)
     if (wid >= strips * chunks) return;
     const int chunk = wid / strips, strip = wid - chunk * strips;  // consecutive waves walk along a row band
     const int j = strip * 62 + lane;                                // this lane's column (lane 0 / 63 = halo)
-    const int i0 = 1 + chunk * MARCH_ROWS;                          // first output row
-    const int i1 = (i0 + MARCH_ROWS < n - 1) ? i0 + MARCH_ROWS : n - 1;   // one past the last output row
+    const int i0 = 1 + chunk * rows_per_wave;                       // first output row
+    const int i1 = (i0 + rows_per_wave < n - 1) ? i0 + rows_per_wave : n - 1;   // one past the last output row
     const bool colok = j < m;
     const int jc = colok ? j : m - 1;
     const double *col = elev + jc;
@@ -458,10 +458,13 @@ static int stencil_variant()
 static void launch_stencil(pydem_tile *t)
 {
     if (stencil_variant() == 1) { launch_interior<true>(t); return; }
-    const int strips = (int)cdiv(t->m - 2, 62), chunks = (int)cdiv(t->n - 2, MARCH_ROWS);
+    const int strips = (int)cdiv(t->m - 2, 62);
+    int rows = MARCH_ROWS;            // every chunk re-reads two halo rows: long chunks on big tiles, enough wavefronts on small ones
+    while (rows > 16 && (int64_t)strips * cdiv(t->n - 2, rows) < 12288) rows >>= 1;
+    const int chunks = (int)cdiv(t->n - 2, rows);
     const int waves = strips * chunks;
     hipLaunchKernelGGL(k_stencil_march, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, t->stream, t->elev, (int)t->n, (int)t->m,
-                       t->rowtab, t->mag, t->dir, t->flat0, strips, chunks);
+                       t->rowtab, t->mag, t->dir, t->flat0, strips, chunks, rows);
 }
 
 int stage_stencil(pydem_tile *t)
