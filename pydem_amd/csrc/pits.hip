@@ -95,7 +95,8 @@ struct PitParams {
     int32_t *out_src, *out_dst; double *out_w;
     int32_t *out_count;         // [0] edges, [1] pits without drain, [2] overflow pits, [3] capacity errors
     int32_t out_cap;
-    int32_t *overflow_list;     // pits to re-run with the large window
+    int32_t *overflow_list;     // pits to re-run with the next larger window
+    int32_t *overflow_count;
     int32_t *lane_overflow;     // pits the lane version hands to the wavefront version (count: out_count[4])
     int32_t *dbg;               // PYDEM_PITS_DEBUG=2: per-pit {rounds, last border size, hand-over reason, drains}
     unsigned long long *prof;   // PYDEM_PITS_DEBUG=3: cycles per phase of the lane pass
@@ -439,7 +440,7 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
     group_sync<NT>();
     if (flag[0]) {                                                               // hand over to the large-window pass
         if (gl == 0) {
-            if (P.overflow_list) P.overflow_list[atomicAdd(&P.out_count[2], 1)] = pit;
+            if (P.overflow_list) P.overflow_list[atomicAdd(P.overflow_count, 1)] = pit;
             else atomicAdd(&P.out_count[3], 1);
         }
         return;
@@ -462,19 +463,21 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
 // version the drain tests are evaluated when a cell enters the border.  Window 128x128 cells; pits
 // that leave it (or exceed the list / drain capacity) go to the workgroup version.
 // ---------------------------------------------------------------------------------------------
-constexpr int W2 = 128;           // window edge (positions fit 14 bits)
-constexpr int W2_CAP = 384;       // border list capacity (6 slots per lane)
-constexpr int W2_SLOTS = W2_CAP / 64;
 constexpr int WV_MAXD = 64;       // drain list capacity
-constexpr uint16_t W2_HOLE = 0xFFFF, W2_PITBIT = 1u << 14;
 
+// Two instances: <128, 384, uint16_t> for the bulk (positions fit 14 bits, bit 14 = pit flag) and
+// <256, 2048, uint32_t> for the pits of plateau terrain whose border outgrows 384 cells (integer DEMs: a
+// quarter of the candidates at 4096^2) -- one wavefront per workgroup there, 44 KB of LDS each
+template <int WW, int CAP, typename PosT>
 struct WaveLds {
-    uint32_t seen[W2 * W2 / 32];
-    double le[W2_CAP];
-    uint16_t lpos[W2_CAP];        // window position | W2_PITBIT; W2_HOLE = free slot
-    uint16_t holes[W2_CAP];       // free slots below the list end
+    static constexpr PosT HOLE = (PosT)~(PosT)0;
+    static constexpr PosT PITBIT = (PosT)((PosT)1 << (sizeof(PosT) * 8 - 2));
+    uint32_t seen[WW * WW / 32];
+    double le[CAP];
+    PosT lpos[CAP];               // window position | PITBIT; HOLE = free slot
+    uint16_t holes[CAP];          // free slots below the list end
     union {
-        uint16_t pq[W2_CAP];      // cells promoted in the current round
+        PosT pq[CAP];             // cells promoted in the current round
         struct { int32_t dl[WV_MAXD]; double dxy[WV_MAXD], sv[WV_MAXD]; } fin;   // drain scratch (after the rounds)
     } u;
 };
@@ -508,8 +511,12 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLds &L, int32_t &chunk_base, int32_t &chunk_left)
+template <int W2, int W2_CAP, typename PosT>
+__device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLds<W2, W2_CAP, PosT> &L, int32_t &chunk_base,
+                               int32_t &chunk_left)
 {
+    constexpr int W2_SLOTS = W2_CAP / 64;
+    constexpr PosT W2_HOLE = WaveLds<W2, W2_CAP, PosT>::HOLE, W2_PITBIT = WaveLds<W2, W2_CAP, PosT>::PITBIT;
     const int n = P.n, m = P.m;
     const int ipit = pit / m, jpit = pit - ipit * m;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -559,7 +566,7 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
             if (isnew) {
                 const int rk = __popcll(bal & lt);
                 const int k = rk < nh ? (int)L.holes[nh - 1 - rk] : nb + (rk - nh);
-                L.le[k] = e; L.lpos[k] = (uint16_t)(npos | (pm ? W2_PITBIT : 0));
+                L.le[k] = e; L.lpos[k] = (PosT)((PosT)npos | (pm ? W2_PITBIT : (PosT)0));
             }
             if (__ballot(isnew && pm && e < epit)) has_p = true;
             if (__ballot(isnew && !pm && e < epit_border)) has_np = true;
@@ -570,7 +577,7 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
     if (lane == 0) {                                                             // pit_area = [pit] (:1289-1292)
         const int pos = (ipit - r0) * W2 + (jpit - c0);
         L.seen[pos >> 5] = 1u << (pos & 31);
-        L.u.pq[0] = (uint16_t)pos;
+        L.u.pq[0] = (PosT)pos;
     }
     wave_sync();
     expand(1);
@@ -605,13 +612,13 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
             if (j * 64 >= nb) break;
             const int k = lane + 64 * j;
             bool match = k < nb && e[j] == mn;
-            uint16_t ps = 0;
+            PosT ps = 0;
             if (match) { ps = L.lpos[k]; match = ps != W2_HOLE; }
             const unsigned long long bal = __ballot(match);
             if (!bal) continue;
             if (match) {
                 const int r = nq + __popcll(bal & lt);
-                L.u.pq[r] = (uint16_t)(ps & (W2_PITBIT - 1));
+                L.u.pq[r] = (PosT)(ps & (PosT)(W2_PITBIT - 1));
                 L.holes[nh + r] = (uint16_t)k;
                 L.le[k] = INFINITY; L.lpos[k] = W2_HOLE;
             }
@@ -629,7 +636,7 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
             bool pred = false;
             int32_t cell = 0;
             if (k < nb && L.lpos[k] != W2_HOLE) {
-                const int pos = L.lpos[k] & (W2_PITBIT - 1);
+                const int pos = (int)(L.lpos[k] & (PosT)(W2_PITBIT - 1));
                 const bool pm = (L.lpos[k] & W2_PITBIT) != 0;
                 const double ev = L.le[k];
                 pred = mode == 1 ? (!pm && ev < epit_border) : (pm && ev < epit);
@@ -657,8 +664,8 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
         const int idx = atomicAdd(&P.out_count[6], 1);
         P.dbg[4 * idx] = it_used; P.dbg[4 * idx + 1] = n_alive; P.dbg[4 * idx + 2] = over; P.dbg[4 * idx + 3] = ndrain;
     }
-    if (over) {                                                                  // hand over to the large-window pass
-        if (lane == 0) P.overflow_list[atomicAdd(&P.out_count[2], 1)] = pit;
+    if (over) {                                                                  // hand over to the next larger pass
+        if (lane == 0) P.overflow_list[atomicAdd(P.overflow_count, 1)] = pit;
         return;
     }
     if (ndrain < 0) { if (lane == 0) atomicAdd(&P.out_count[1], 1); return; }    // :1327-1329
@@ -896,12 +903,25 @@ constexpr int W_LARGE = 640, MAXD_LARGE = 2048;
 // wave-per-pit: 4 pits per 256-thread block
 __global__ __launch_bounds__(256) void k_pits_wave(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits)
 {
-    __shared__ WaveLds s_l[4];
+    __shared__ WaveLds<128, 384, uint16_t> s_l[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t np = *npits;
     int32_t chunk_base = 0, chunk_left = 0;
     for (int32_t q = blockIdx.x * 4 + wave; q < np; q += gridDim.x * 4) {
         solve_pit_wave(P, pits[q], lane, s_l[wave], chunk_base, chunk_left);
+        wave_sync();
+    }
+}
+
+// the same with a 256x256 window and room for 2048 border cells: one pit per 64-thread workgroup
+__global__ __launch_bounds__(64) void k_pits_wave_big(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits)
+{
+    __shared__ WaveLds<256, 2048, uint32_t> s_l;
+    const int lane = threadIdx.x;
+    const int32_t np = *npits;
+    int32_t chunk_base = 0, chunk_left = 0;
+    for (int32_t q = blockIdx.x; q < np; q += gridDim.x) {
+        solve_pit_wave(P, pits[q], lane, s_l, chunk_base, chunk_left);
         wave_sync();
     }
 }
@@ -1043,7 +1063,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         P.min_border = opt->drain_pits_min_border; P.max_dist_XY = opt->drain_pits_max_dist_XY;
         P.out_src = t->pits.raw_src; P.out_dst = t->pits.raw_dst; P.out_w = t->pits.raw_w;
         P.out_count = cnt + 1; P.out_cap = (int32_t)(t->pits.raw_cap < INT32_MAX ? t->pits.raw_cap : INT32_MAX);
-        P.overflow_list = t->labels;
+        P.overflow_list = t->labels; P.overflow_count = cnt + 3;
         P.lane_overflow = t->queue[0];
         // pass 1: a lane per pit (16x16 window); pass 2: a wavefront per pit it handed over (64x64)
         const int gl = (int)(cdiv(npits, LN_T) < (1 << 20) ? cdiv(npits, LN_T) : (1 << 20));
@@ -1064,8 +1084,18 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
         }
-        const int32_t n_over = t->h_counters[3];
-        if (dbg_env) fprintf(stderr, "pits: %d candidates, %d left the 16x16 lane window, %d left the 128x128 window, %d edge slots, %d undrained\n", npits, n_lane_over, n_over, t->h_counters[1], t->h_counters[2]);
+        const int32_t n_wave_over = t->h_counters[3];
+        int32_t n_over = 0;
+        if (n_wave_over > 0) {
+            // pass 3: the wavefront solver with a 256x256 window / 2048 border cells for what outgrew pass 2
+            HIP_TRY(hipMemsetAsync(cnt + 9, 0, sizeof(int32_t), t->stream));
+            P.overflow_list = t->queue[0]; P.overflow_count = cnt + 9;
+            hipLaunchKernelGGL(k_pits_wave_big, dim3(n_wave_over < 4096 ? n_wave_over : 4096), dim3(64), 0, t->stream, P, t->labels, cnt + 3);
+            HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            n_over = t->h_counters[9];
+        }
+        if (dbg_env) fprintf(stderr, "pits: %d candidates, %d left the 16x16 lane window, %d left the 128x128 / 384-cell pass, %d left the 256x256 / 2048-cell pass, %d edge slots, %d undrained\n", npits, n_lane_over, n_wave_over, n_over, t->h_counters[1], t->h_counters[2]);
         if (P.dbg) {
             const int nrec = t->h_counters[7];
             std::vector<int32_t> rec((size_t)nrec * 4);
@@ -1100,8 +1130,8 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             double *g_dxy = (double *)t->scratch;
             double *g_sv = g_dxy + (size_t)gb * MAXD_LARGE;
             int32_t *g_dl = (int32_t *)(g_sv + (size_t)gb * MAXD_LARGE);
-            P.overflow_list = nullptr;
-            hipLaunchKernelGGL(k_pits_block, dim3(gb), dim3(256), dyn, t->stream, P, t->labels, cnt + 3, g_dl, g_dxy, g_sv);
+            P.overflow_list = nullptr; P.overflow_count = nullptr;
+            hipLaunchKernelGGL(k_pits_block, dim3(gb), dim3(256), dyn, t->stream, P, t->queue[0], cnt + 9, g_dl, g_dxy, g_sv);
             HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
         }

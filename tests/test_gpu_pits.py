@@ -94,3 +94,24 @@ def test_hip_pits_vs_oracle_bench_tile_4096():
     _check_pits(dp, o.pit_i, o.pit_j, o.pit_prop)
     assert dp.timings['n_pits_undrained'] == o.n_warn
     _close(dp.uca, o.uca, 'uca')
+
+
+def test_hip_pits_vs_oracle_plateau_terrain_2048():
+    """Config-5 style surface (int16 plateaus, conditioned on the host): borders of hundreds of cells, pits that run
+    into the 300-iteration limit -- the 256x256 / 2048-cell wavefront pass and the undrained bookkeeping."""
+    from oracle import oracle as O
+    from pydem_amd import DEMProcessor, synth, conditioning
+    import warnings
+    n = 2048
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        z = conditioning.fill_flats(synth.srtm_int16(n, n, seed=3))
+        z, _, _ = conditioning.pit_drain_paths(z, 30.0 * np.ones(n - 1), 30.0 * np.ones(n - 1))
+        o = O.OracleDEM(z, dX=30.0, dY=30.0, drain_pits=True)
+        o.calc_uca()
+        dp = DEMProcessor(elev=z, dX=30.0, dY=30.0, fill_flats=False, drain_pits_path=False, drain_pits=True)
+        dp.calc_slopes_directions()
+        dp.calc_uca()
+    _check_pits(dp, o.pit_i, o.pit_j, o.pit_prop)
+    assert dp.timings['n_pits_undrained'] == o.n_warn
+    _close(dp.uca, o.uca, 'uca')

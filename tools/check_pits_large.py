@@ -14,7 +14,16 @@ from pydem_amd import DEMProcessor        # noqa: E402
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-z = O.synth_fractal(size, size, seed=seed)
+if len(sys.argv) > 3 and sys.argv[3] == 'srtm':
+    # config-5 style surface: int16 plateaus, conditioned on the host (fill_flats + pit drain paths), then the pit solver
+    # meets borders of hundreds of cells and many pits that never drain
+    from pydem_amd import synth, conditioning
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        z = conditioning.fill_flats(synth.srtm_int16(size, size, seed=seed))
+        z, _, _ = conditioning.pit_drain_paths(z, 30.0 * np.ones(size - 1), 30.0 * np.ones(size - 1))
+else:
+    z = O.synth_fractal(size, size, seed=seed)
 t0 = time.time()
 o = O.OracleDEM(z, dX=30.0, dY=30.0, drain_pits=True)
 o.calc_uca()
