@@ -1,0 +1,36 @@
+"""The alternative sweep schedule (frontier queue rounds + listed tile passes for the tail, PYDEM_SWEEP_MODE=queue) must
+give the same answers as the default tile-pass schedule.  The mode is read once per process, hence the subprocess."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCRIPT = r'''
+import sys, warnings
+import numpy as np
+sys.path.insert(0, %(root)r)
+warnings.simplefilter('ignore')
+from oracle import oracle as O
+from pydem_amd import DEMProcessor, synth
+for shape, seed in (((700, 520), 41), ((1024, 1024), 42)):
+    z = synth.fractal(shape[0], shape[1], seed=seed, top_shift=7, n_octaves=7)
+    o = O.OracleDEM(z, dX=30.0, dY=30.0, drain_pits=True); o.calc_uca()
+    dp = DEMProcessor(elev=z, dX=30.0, dY=30.0, fill_flats=False, drain_pits_path=False, drain_pits=True)
+    dp.calc_slopes_directions(); dp.calc_uca()
+    assert np.array_equal(np.isnan(dp.uca), np.isnan(o.uca))
+    assert np.allclose(dp.uca, o.uca, rtol=1e-9, atol=0, equal_nan=True)
+    assert np.array_equal(dp.edge_todo, o.edge_todo) and np.array_equal(dp.edge_done, o.edge_done)
+print("MODES-OK", dp.timings['sweep_rounds'], dp.timings['sweep_kernel_launches'])
+'''
+
+
+@pytest.mark.parametrize('env', [{'PYDEM_SWEEP_MODE': 'queue'}, {'PYDEM_SWEEP_MODE': 'queue', 'PYDEM_SWEEP_TILE_SWITCH': '0'},
+                                 {'PYDEM_SWEEP_MODE': 'queue', 'PYDEM_TILE_PASSES': '3'}])
+def test_queue_schedule_matches_oracle(env):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, '-c', SCRIPT % {'root': root}], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'MODES-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
