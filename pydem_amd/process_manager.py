@@ -603,6 +603,12 @@ class ProcessManager(object):
         self._edge_cache = {}
         self._edge_last = {}
         self.transport_is_collective = not type(self.transport) is EdgeTransport
+        # every line of a tile that some round or metric of another (or the same) tile can ask for: after a tile ran
+        # its round they are refreshed in ONE batch (one device synchronisation / one collective per round)
+        interest = {}
+        for i in range(self.n_inputs):
+            for req in self._snapshot_requests(i) | self._metric_requests(i):
+                interest.setdefault(req[0], set()).add(req)
         mets = self.update_uca_edge_metrics()
         I = self._rank_tiles(mets, mets_type)
         I_old = np.zeros_like(I)
@@ -610,6 +616,7 @@ class ProcessManager(object):
         while np.any(I_old != I) and self.edge_rounds < self.max_edge_rounds:
             f = int(I[0])
             self._edge_round(f)
+            self._edge_lines(sorted(interest.get(f, ())))
             self.edge_rounds += 1
             I_old[:] = I[:]
             r, c, _ = self.grid_id[f]
