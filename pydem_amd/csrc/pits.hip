@@ -98,6 +98,7 @@ struct PitParams {
     int32_t *overflow_list;     // pits to re-run with the next larger window
     int32_t *overflow_count;
     int32_t *lane_overflow;     // pits the lane version hands to the wavefront version (count: out_count[4])
+    int32_t *work_next;         // next unclaimed entry of the pit list (lane version)
     int32_t *dbg;               // PYDEM_PITS_DEBUG=2: per-pit {rounds, last border size, hand-over reason, drains}
     unsigned long long *prof;   // PYDEM_PITS_DEBUG=3: cycles per phase of the lane pass
 };
@@ -707,6 +708,33 @@ __device__ __forceinline__ double np_pairwise_leaf_strided(const double *a, int 
     return res;
 }
 
+// np_pairwise_leaf for slices of at most 15 elements with all loads issued up front (indices clamped to the slice):
+// the lane version sums dX / dY over the rows between a pit and its drain, a chain of dependent global loads otherwise
+__device__ __forceinline__ double np_pairwise_leaf15(const double *__restrict__ a, int n)
+{
+    double v[15];
+#pragma unroll
+    for (int k = 0; k < 15; k++) v[k] = a[k < n ? k : (n > 0 ? n - 1 : 0)];
+    if (n < 8) {
+        double res = 0.;
+#pragma unroll
+        for (int k = 0; k < 7; k++) if (k < n) res += v[k];
+        return res;
+    }
+    double res = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+#pragma unroll
+    for (int k = 8; k < 15; k++) if (k < n) res += v[k];
+    return res;
+}
+
+// Lanes are re-armed as soon as their pit is finished: a wavefront keeps a private range of the pit list
+// (LN_CHUNK pits per global atomic) and every loop trip (a) hands new pits to idle lanes, (b) runs ONE round
+// of every busy lane -- or its drain selection when the growth has ended -- and (c) writes the output of the
+// lanes that just finished with one slot allocation per wavefront.  With one pit per lane per launch a
+// wavefront would run as long as its slowest pit (~40 rounds) while the average pit needs 11.
+constexpr int LN_CHUNK = 256;
+constexpr int LN_FIN_BATCH = 32;   // lanes that wait before the drain selection runs (12: 6.6 ms, 20: 6.0, 32: 5.6, 44: 5.8 at 16384^2)
+
 __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits)
 {
     __shared__ double s_e[LN_B * LN_T];          // [slot][lane]: border elevations, later the drain slopes
@@ -714,86 +742,112 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
     __shared__ uint8_t s_q[LN_B * LN_T];         // [slot][lane]: cells promoted in the current round
     __shared__ uint32_t s_seen[8 * LN_T];        // [word][lane]: region | border bitmap of the window
     const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const int n = P.n, m = P.m;
     const int32_t np = *npits;
     double *const le = s_e + tid;
     uint8_t *const lp = s_p + tid, *const lq = s_q + tid;
     uint32_t *const seen = s_seen + tid;
-    for (int32_t base = blockIdx.x * LN_T; base < np; base += gridDim.x * LN_T) {
-        const int32_t q = base + tid;
-        int nd = 0;                 // drains of this lane's pit, sorted, in slots [0, nd)
-        int status = 0;             // 1: drained, 2: no drain, 3: hand over to the wavefront version
-        const bool prof = P.prof != nullptr;
-        long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+    // per-lane state of the pit in progress
+    bool running = false, over = false, has_np = false, has_p = false;
+    int pending = 0;            // growth has ended: 1 / 2 drain mode, 3 no drain, 4 hand over; the lane waits for the next batch
+    int32_t pit = 0;
+    int r0 = 0, c0 = 0, ipit = 0, jpit = 0, nb = 0, it = 0;
+    uint32_t pitbits = 0;
+    double epit = 0.0, epit_border = 0.0;
+    // the wavefront's range of the pit list
+    int32_t chunk_next = 0, chunk_end = 0;
+    bool more = true;
+    // add the unseen neighbours of window cell (r, c) to the border
+    auto add_neighbours = [&](int r, int c) {
+        double e8[8]; uint8_t pm8[8]; int pos8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int di = k < 3 ? -1 : (k < 5 ? 0 : 1);
+            const int dj = k < 3 ? k - 1 : (k == 3 ? -1 : (k == 4 ? 1 : k - 6));
+            const int ii = r0 + r + di, jj = c0 + c + dj;
+            const int rr = r + di, cc = c + dj;
+            pos8[k] = -1; e8[k] = 0.0; pm8[k] = 0;
+            if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+            if (rr < 0 || rr >= LN_W || cc < 0 || cc >= LN_W) { over = true; continue; }
+            const int pos = rr * LN_W + cc;
+            const uint32_t bit = 1u << (pos & 31);
+            const uint32_t wd = seen[(pos >> 5) * LN_T];
+            if (wd & bit) continue;
+            seen[(pos >> 5) * LN_T] = wd | bit;
+            const int64_t cell = (int64_t)ii * m + jj;
+            e8[k] = P.elev[cell]; pm8[k] = P.pitmask[cell];
+            pos8[k] = pos;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (pos8[k] < 0) continue;
+            if (nb == LN_B) { over = true; continue; }
+            le[nb * LN_T] = e8[k]; lp[nb * LN_T] = (uint8_t)pos8[k];
+            if (pm8[k]) { pitbits |= 1u << nb; if (e8[k] < epit) has_p = true; }
+            else { pitbits &= ~(1u << nb); if (e8[k] < epit_border) has_np = true; }
+            nb++;
+        }
+    };
+    const bool prof = P.prof != nullptr;
+    long long acc_a = 0, acc_b = 0, acc_c = 0, trips = 0, busy = 0;
+    for (;;) {
+        long long tk0 = 0, tk1 = 0, tk2 = 0;
         if (prof) tk0 = clock64();
-        int32_t pit = 0;
-        int r0 = 0, c0 = 0;
+        // ---- (a) new pits for idle lanes
+        const unsigned long long idle = __ballot(!running);
+        if (idle && more) {
+            if (chunk_next == chunk_end) {
+                int32_t b = 0;
+                if (lane == 0) b = atomicAdd(P.work_next, LN_CHUNK);
+                b = __shfl(b, 0);
+                chunk_next = b < np ? b : np;
+                chunk_end = b + LN_CHUNK < np ? b + LN_CHUNK : np;
+                if (chunk_next >= chunk_end) more = false;
+            }
+            const int avail = chunk_end - chunk_next, want = __popcll(idle);
+            const int rank = __popcll(idle & lt);
+            if (!running && rank < avail) {
+                pit = pits[chunk_next + rank];
+                ipit = pit / m; jpit = pit - ipit * m;
+                r0 = ipit - LN_W / 2; c0 = jpit - LN_W / 2;
+                if (r0 > n - LN_W) r0 = n - LN_W;
+                if (c0 > m - LN_W) c0 = m - LN_W;
+                if (r0 < 0) r0 = 0;
+                if (c0 < 0) c0 = 0;
+#pragma unroll
+                for (int w = 0; w < 8; w++) seen[w * LN_T] = 0;
+                epit = P.elev[pit];
+                epit_border = epit;
+                nb = 0; pitbits = 0; it = 0;
+                has_np = false; has_p = false; over = false;
+                {                                                                // pit_area = [pit] (:1289-1292)
+                    const int pos = (ipit - r0) * LN_W + (jpit - c0);
+                    seen[(pos >> 5) * LN_T] = 1u << (pos & 31);
+                    add_neighbours(ipit - r0, jpit - c0);
+                }
+                if (P.min_border) {                                              // :1294-1295
+                    double mn = INFINITY;
+                    for (int k = 0; k < nb; k++) mn = fmin(mn, le[k * LN_T]);
+                    if (nb) epit_border = mn;
+                    has_np = false;                                              // nothing is below the minimum
+                }
+                running = true;
+            }
+            chunk_next += want < avail ? want : avail;
+        }
+        if (!__ballot(running)) { if (more) continue; break; }
+        if (prof) { tk1 = clock64(); busy += __popcll(__ballot(running)); trips++; }
+        // ---- (b) one step of every busy lane
+        int nd = 0;                 // drains of a pit that finished in this trip, sorted, in slots [0, nd)
+        int status = 0;             // 1: drained, 2: no drain, 3: hand over to the wavefront version
         double ssum = 0.0;
-        if (q < np) {
-            pit = pits[q];
-            const int ipit = pit / m, jpit = pit - ipit * m;
-            r0 = ipit - LN_W / 2; c0 = jpit - LN_W / 2;
-            if (r0 > n - LN_W) r0 = n - LN_W;
-            if (c0 > m - LN_W) c0 = m - LN_W;
-            if (r0 < 0) r0 = 0;
-            if (c0 < 0) c0 = 0;
-#pragma unroll
-            for (int w = 0; w < 8; w++) seen[w * LN_T] = 0;
-            const double epit = P.elev[pit];
-            double epit_border = epit;
-            int nb = 0;
-            uint32_t pitbits = 0;
-            bool has_np = false, has_p = false, over = false;
-            // add the unseen neighbours of window cell (r, c) to the border
-            auto add_neighbours = [&](int r, int c) {
-                double e8[8]; uint8_t pm8[8]; int pos8[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int di = k < 3 ? -1 : (k < 5 ? 0 : 1);
-                    const int dj = k < 3 ? k - 1 : (k == 3 ? -1 : (k == 4 ? 1 : k - 6));
-                    const int ii = r0 + r + di, jj = c0 + c + dj;
-                    const int rr = r + di, cc = c + dj;
-                    pos8[k] = -1; e8[k] = 0.0; pm8[k] = 0;
-                    if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
-                    if (rr < 0 || rr >= LN_W || cc < 0 || cc >= LN_W) { over = true; continue; }
-                    const int pos = rr * LN_W + cc;
-                    const uint32_t bit = 1u << (pos & 31);
-                    const uint32_t wd = seen[(pos >> 5) * LN_T];
-                    if (wd & bit) continue;
-                    seen[(pos >> 5) * LN_T] = wd | bit;
-                    const int64_t cell = (int64_t)ii * m + jj;
-                    e8[k] = P.elev[cell]; pm8[k] = P.pitmask[cell];
-                    pos8[k] = pos;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    if (pos8[k] < 0) continue;
-                    if (nb == LN_B) { over = true; continue; }
-                    le[nb * LN_T] = e8[k]; lp[nb * LN_T] = (uint8_t)pos8[k];
-                    if (pm8[k]) { pitbits |= 1u << nb; if (e8[k] < epit) has_p = true; }
-                    else { pitbits &= ~(1u << nb); if (e8[k] < epit_border) has_np = true; }
-                    nb++;
-                }
-            };
-            {                                                                    // pit_area = [pit] (:1289-1292)
-                const int pos = (ipit - r0) * LN_W + (jpit - c0);
-                seen[(pos >> 5) * LN_T] = 1u << (pos & 31);
-                add_neighbours(ipit - r0, jpit - c0);
-            }
-            if (P.min_border) {                                                  // :1294-1295
-                double mn = INFINITY;
-                for (int k = 0; k < nb; k++) mn = fmin(mn, le[k * LN_T]);
-                if (nb) epit_border = mn;
-                has_np = false;                                                  // nothing is below the minimum
-            }
-            int mode = 0;
-            status = 2;
-            if (prof) tk1 = clock64();
-            for (int it = 0; it < P.max_iter; it++) {                            // :1300
-                if (over) break;
-                if (nb == 0) break;                                              // :1304-1305
-                if (has_np) { mode = 1; break; }                                 // :1312-1316
-                if (has_p) { mode = 2; break; }                                  // :1317-1320
+        if (running && !pending) {
+            if (over) pending = 4;
+            else if (it >= P.max_iter || nb == 0) pending = 3;                   // :1300, :1304-1305
+            else if (has_np) pending = 1;                                        // :1312-1316
+            else if (has_p) pending = 2;                                         // :1317-1320
+            else {
                 double mn = INFINITY;
                 for (int k = 0; k < nb; k++) mn = fmin(mn, le[k * LN_T]);
                 // pit_area += border[eborder == emin] (:1322-1323): take them out of the list first ...
@@ -808,10 +862,17 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
                 }
                 // ... then the new border cells around them
                 for (int j = 0; j < nq; j++) { const int pos = lq[j * LN_T]; add_neighbours(pos >> 4, pos & 15); }
+                it++;
             }
-            if (prof) tk2 = clock64();
-            if (over) status = 3;
-            else if (mode) {
+        }
+        // the drain selection / slope arithmetic is a long divergent path: it runs for a batch of waiting lanes at once
+        // (when a third of the wavefront waits, or nobody is growing any more) instead of in every trip
+        const unsigned long long waiting = __ballot(pending != 0), growing = __ballot(running && !pending);
+        if (!(__popcll(waiting) >= LN_FIN_BATCH || (waiting && !growing))) continue;
+        if (pending) {
+            const int mode = pending <= 2 ? pending : 0;
+            status = pending == 4 ? 3 : 2;
+            if (mode) {
                 // drains to the front of the list in ascending cell order (window order == cell order)
                 for (;;) {
                     int best = -1, bestpos = 256;
@@ -844,9 +905,9 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
                     const int a = ipit < idr ? ipit : idr, b = ipit < idr ? idr : ipit;
                     double dxm;
                     if (ipit == idr) dxm = P.dX[ipit < ndX - 1 ? ipit : ndX - 1];    // _get_dX_mean :1994-1995
-                    else dxm = np_pairwise_leaf(P.dX + a, b - a) / (double)(b - a);  // .mean() :1997
+                    else dxm = np_pairwise_leaf15(P.dX + a, b - a) / (double)(b - a);    // .mean() :1997 (window: b - a <= 15)
                     const double dx = dxm * (double)(jpit - jdr);
-                    const double dy = np_pairwise_leaf(P.dY + a, b - a);
+                    const double dy = np_pairwise_leaf15(P.dY + a, b - a);
                     const double d = sqrt(dx * dx + dy * dy);
                     if (xy && !(d <= P.max_dist_XY)) continue;                   // :1352-1358
                     le[keep * LN_T] = fabs(epit - le[t * LN_T]) / d;             // :1361
@@ -861,9 +922,11 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
                     status = 1;
                 }
             }
+            running = false; pending = 0;
         }
-        // ---- lanes are convergent again: one slot allocation / counter update per wavefront
-        if (prof) tk3 = clock64();
+        // ---- (c) all lanes together: one slot allocation / counter update per wavefront for the pits that just ended
+        if (prof) { tk2 = clock64(); acc_a += tk1 - tk0; acc_b += tk2 - tk1; }
+        if (!__ballot(status != 0)) continue;
         int incl = nd;
         for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
         const int tot = __shfl(incl, 63);
@@ -887,14 +950,14 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
             int32_t obase = 0;
             if (lane == 0) obase = atomicAdd(&P.out_count[4], __popcll(b_ov));
             obase = __shfl(obase, 0);
-            if (status == 3) P.lane_overflow[obase + __popcll(b_ov & ((1ull << lane) - 1ull))] = pit;
+            if (status == 3) P.lane_overflow[obase + __popcll(b_ov & lt)] = pit;
         }
-        if (prof && lane == 0) {    // wave-level phase times (lane 0's clock: the phases are lock-step per wavefront)
-            const long long tk4 = clock64();
-            atomicAdd(P.prof + 0, (unsigned long long)(tk1 - tk0)); atomicAdd(P.prof + 1, (unsigned long long)(tk2 - tk1));
-            atomicAdd(P.prof + 2, (unsigned long long)(tk3 - tk2)); atomicAdd(P.prof + 3, (unsigned long long)(tk4 - tk3));
-            atomicAdd(P.prof + 4, 1ull);
-        }
+        if (prof) acc_c += clock64() - tk2;
+    }
+    if (prof && lane == 0) {    // cycles per phase, summed over wavefronts (PYDEM_PITS_DEBUG=3)
+        atomicAdd(P.prof + 0, (unsigned long long)acc_a); atomicAdd(P.prof + 1, (unsigned long long)acc_b);
+        atomicAdd(P.prof + 2, (unsigned long long)acc_c); atomicAdd(P.prof + 3, (unsigned long long)busy);
+        atomicAdd(P.prof + 4, (unsigned long long)trips);
     }
 }
 
@@ -1066,7 +1129,9 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         P.overflow_list = t->labels; P.overflow_count = cnt + 3;
         P.lane_overflow = t->queue[0];
         // pass 1: a lane per pit (16x16 window); pass 2: a wavefront per pit it handed over (64x64)
-        const int gl = (int)(cdiv(npits, LN_T) < (1 << 20) ? cdiv(npits, LN_T) : (1 << 20));
+        HIP_TRY(hipMemsetAsync(cnt + 10, 0, sizeof(int32_t), t->stream));
+        P.work_next = cnt + 10;
+        const int gl = (int)(cdiv(npits, LN_T) < 3072 ? cdiv(npits, LN_T) : 3072);      // persistent: 3 workgroups per CU, 4 deep
         hipLaunchKernelGGL(k_pits_lane, dim3(gl), dim3(LN_T), 0, t->stream, P, t->flatlist, cnt);
         HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
@@ -1074,8 +1139,8 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         if (P.prof) {
             unsigned long long h[8];
             HIP_TRY(hipMemcpy(h, P.prof, 64, hipMemcpyDeviceToHost));
-            fprintf(stderr, "pits/lane phases (cycles summed over %llu wavefront iterations): init+first border %llu, rounds %llu, finish %llu, output %llu\n",
-                    h[4], h[0], h[1], h[2], h[3]);
+            fprintf(stderr, "pits/lane: %llu loop trips over all wavefronts, %.1f busy lanes per trip; cycles: refill %llu, step %llu, output %llu\n",
+                    h[4], h[4] ? (double)h[3] / (double)h[4] : 0.0, h[0], h[1], h[2]);
             (void)hipFree(P.prof); P.prof = nullptr;
         }
         if (n_lane_over > 0) {

@@ -1639,8 +1639,10 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
         int r = 0;
         int32_t last = first;
         int32_t *state = t->counters + 12;
+        static int small_cap = -1;
+        if (small_cap < 0) { const char *e = getenv("PYDEM_EDGE_SMALL_CAP"); small_cap = e ? atoi(e) : SMALL_CAP; if (small_cap > SMALL_CAP) small_cap = SMALL_CAP; }
         while (last > 0) {
-            if (last <= SMALL_CAP) {
+            if (last <= small_cap) {
                 if (which == 0) hipLaunchKernelGGL(k_edge_small<0>, dim3(1), dim3(1024), 0, t->stream, E, q0, q1, cnt3, r, state);
                 else hipLaunchKernelGGL(k_edge_small<1>, dim3(1), dim3(1024), 0, t->stream, E, q0, q1, cnt3, r, state);
                 HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
