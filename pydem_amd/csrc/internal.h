@@ -48,6 +48,7 @@ struct PitGraph {
     int64_t n_edges = 0, sorted_cap = 0;       // kept edges
     int32_t *src = nullptr, *dst = nullptr; double *w = nullptr;            // sorted by (src, dst)
     int32_t *in_src = nullptr, *in_dst = nullptr; double *in_w = nullptr;   // sorted by (dst, src)
+    void *sort_buf = nullptr; size_t sort_bytes = 0;                        // keys / indices / radix-sort scratch, kept across calls
 };
 
 struct pydem_tile {

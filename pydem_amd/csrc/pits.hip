@@ -1225,10 +1225,23 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             PYDEM_TRY(dev_realloc(t, &t->pits.in_dst, (size_t)ne)); PYDEM_TRY(dev_realloc(t, &t->pits.in_w, (size_t)ne));
             t->pits.sorted_cap = ne;
         }
-        uint64_t *k1 = nullptr, *k2 = nullptr, *k1s = nullptr, *k2s = nullptr; int32_t *idx = nullptr, *i1 = nullptr, *i2 = nullptr;
-        void *tmp = nullptr; size_t tmp_bytes = 0, tb2 = 0;
-        HIP_TRY(hipMalloc(&k1, ne * 8)); HIP_TRY(hipMalloc(&k2, ne * 8)); HIP_TRY(hipMalloc(&k1s, ne * 8)); HIP_TRY(hipMalloc(&k2s, ne * 8));
-        HIP_TRY(hipMalloc(&idx, ne * 4)); HIP_TRY(hipMalloc(&i1, ne * 4)); HIP_TRY(hipMalloc(&i2, ne * 4));
+        // one persistent scratch block (allocating and freeing eight buffers per call costs more than the sorts)
+        size_t tmp_bytes = 0, tb2 = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr,
+                                                   (int32_t *)nullptr, ne, 0, 64, t->stream));
+        tb2 = tmp_bytes;
+        const size_t ne8 = ((size_t)ne * 8 + 255) & ~(size_t)255, ne4 = ((size_t)ne * 4 + 255) & ~(size_t)255;
+        const size_t need_sort = 4 * ne8 + 3 * ne4 + tmp_bytes + 256;
+        if (t->pits.sort_bytes < need_sort) {
+            if (t->pits.sort_buf) { HIP_TRY(hipFree(t->pits.sort_buf)); t->device_bytes -= (int64_t)t->pits.sort_bytes; }
+            HIP_TRY(hipMalloc(&t->pits.sort_buf, need_sort + need_sort / 4));
+            t->pits.sort_bytes = need_sort + need_sort / 4; t->device_bytes += (int64_t)t->pits.sort_bytes;
+        }
+        char *sb = (char *)t->pits.sort_buf;
+        uint64_t *k1 = (uint64_t *)sb, *k2 = (uint64_t *)(sb + ne8), *k1s = (uint64_t *)(sb + 2 * ne8), *k2s = (uint64_t *)(sb + 3 * ne8);
+        int32_t *idx = (int32_t *)(sb + 4 * ne8), *i1 = (int32_t *)(sb + 4 * ne8 + ne4), *i2 = (int32_t *)(sb + 4 * ne8 + 2 * ne4);
+        void *tmp = sb + 4 * ne8 + 3 * ne4;
+        (void)tb2;
         const int g = (int)(cdiv(ne, 256) < 1024 ? cdiv(ne, 256) : 1024);
         hipLaunchKernelGGL(k_pit_keys, dim3(g), dim3(256), 0, t->stream, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w, t->elev,
                            ne, k1, k2, idx);
@@ -1248,8 +1261,6 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         HIP_TRY(hipGetLastError());
         t->pits.n_edges = t->h_counters[0];     // kept edges (a prefix of both sorted views)
         t->tm.n_pit_edges = t->pits.n_edges;
-        (void)hipFree(k1); (void)hipFree(k2); (void)hipFree(k1s); (void)hipFree(k2s); (void)hipFree(idx); (void)hipFree(i1);
-        (void)hipFree(i2); (void)hipFree(tmp);
     }
     HIP_TRY(hipEventRecord(t->ev[5], t->stream));
     HIP_TRY(hipEventSynchronize(t->ev[5]));
