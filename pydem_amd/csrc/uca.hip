@@ -67,8 +67,12 @@ __global__ __launch_bounds__(256) void k_section_proportion(const double *__rest
                                                             int8_t *__restrict__ section, double *__restrict__ prop,
                                                             uint32_t *__restrict__ cinfo)
 {
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < NN; c += (int64_t)gridDim.x * blockDim.x) {
-        const double theta = sec_theta[c / m];
+    // rows come from blockIdx.y (grid-stride), columns from blockIdx.x: no 64-bit division per cell
+    (void)NN;
+    for (int i = blockIdx.y; i < n; i += gridDim.y)
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+        const int64_t c = (int64_t)i * m + j;
+        const double theta = sec_theta[i];
         const double d = dir[c];
         int sec0 = (int)(int8_t)(int)floor(d / PI_D * 2.0);                      // :1035
         const double quadrant = d - PI_D / 2.0 * (double)sec0;                   // :1037
@@ -90,7 +94,6 @@ __global__ __launch_bounds__(256) void k_section_proportion(const double *__rest
         section[c] = (int8_t)sec;
         uint32_t gf = 0;
         if (sec >= 0 && sec <= 7) {
-            const int i = (int)(c / m), j = (int)(c - (int64_t)i * m);
             const double z = elev[c];
             const int i1 = i + fe1r(sec), j1 = j + fe1c(sec), i2 = i + fe2r(sec), j2 = j + fe2c(sec);
             if (i1 >= 0 && i1 < n && j1 >= 0 && j1 < m && keep_edge(pf, elev[(int64_t)i1 * m + j1], z)) gf |= CI_OUT1;
@@ -108,9 +111,9 @@ __global__ __launch_bounds__(256) void k_graph_inmask(const double *__restrict__
                                                       int n, int m, uint32_t *__restrict__ cinfo, uint8_t *__restrict__ todo0,
                                                       uint8_t *__restrict__ todo_work, double *__restrict__ corner_sums)
 {
-    const int64_t NN = (int64_t)n * m;
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < NN; c += (int64_t)gridDim.x * blockDim.x) {
-        const int i = (int)(c / m), j = (int)(c - (int64_t)i * m);
+    for (int i = blockIdx.y; i < n; i += gridDim.y)
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+        const int64_t c = (int64_t)i * m + j;
         const uint32_t cw = cinfo[c] & (CI_OUT1 | CI_OUT2 | (7u << CI_SEC_SHIFT));
         uint32_t im = 0;
 #pragma unroll
@@ -1291,8 +1294,8 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt)
     const int32_t nblk = (int32_t)(t->NN >> PIT_BLK_SHIFT) + 1;
     PYDEM_TRY(tile_alloc(t, &t->pit_blk, (size_t)(nblk + 2) * 2));
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
-    const int big = grid_for(t->NN, 8192);
-    hipLaunchKernelGGL(k_section_proportion, dim3(big), dim3(256), 0, t->stream, t->dir, t->flats, t->sec_theta, t->NN, n, m,
+    const dim3 grid2((unsigned)(cdiv(m, 256) < 64 ? cdiv(m, 256) : 64), (unsigned)(n < 16384 ? n : 16384));
+    hipLaunchKernelGGL(k_section_proportion, grid2, dim3(256), 0, t->stream, t->dir, t->flats, t->sec_theta, t->NN, n, m,
                        t->elev, t->section, t->prop, (uint32_t *)t->indeg);
     HIP_TRY(hipEventRecord(t->ev[1], t->stream));
     t->tm.n_pit_edges = 0; t->tm.n_pits_undrained = 0; t->tm.pits_ms = 0;
@@ -1303,7 +1306,7 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt)
     HIP_TRY(hipMemsetAsync(t->counters, 0, 64 * sizeof(int32_t), t->stream));
     HIP_TRY(hipMemsetAsync(t->edge_todo, 0, (size_t)t->NN, t->stream));
     HIP_TRY(hipMemsetAsync(t->todo_work, 0, (size_t)t->NN, t->stream));
-    hipLaunchKernelGGL(k_graph_inmask, dim3(big), dim3(256), 0, t->stream, t->prop, t->elev, n, m,
+    hipLaunchKernelGGL(k_graph_inmask, grid2, dim3(256), 0, t->stream, t->prop, t->elev, n, m,
                        (uint32_t *)t->indeg, t->edge_todo, t->todo_work, corner_sums);
     if (t->pits.n_edges > 0) {
         hipLaunchKernelGGL(k_graph_add_pits, dim3(grid_for(t->pits.n_edges, 1024)), dim3(256), 0, t->stream, t->pits.src,
