@@ -7,12 +7,19 @@ n = int(sys.argv[1]); nt = int(sys.argv[2])
 pm = process_manager.ProcessManager(elev_source_files=bench.tile_specs(nt, n, n), elev_conditioned=True,
                                     dem_proc_kwargs={'drain_pits': os.environ.get('PM_DRAIN', '1') == '1'}, devices=[0], keep_first_pass_uca=False)
 pm.compute_grid(); pm.process_elevation()
+if os.environ.get('PICKS'):
+    _orig = pm._edge_round
+    picks = []
+    def _wrap(i):
+        picks.append(i); return _orig(i)
+    pm._edge_round = _wrap
 for rep in range(2):
     t0 = time.perf_counter(); pm.process_aspect_slope(); pm.process_uca()
     for t in pm.tiles: t._tile.synchronize()
     t1 = time.perf_counter(); pm.process_uca_edges(); t2 = time.perf_counter()
     for t in pm.tiles: t.find_flats(); t.run_twi()
     t3 = time.perf_counter()
+    if os.environ.get('PICKS'): print('picks', picks); del picks[:]
     print('n=%d tiles=%d: tiles %.1f ms, edge fix-up %.1f ms (%d rounds), twi %.1f ms' % (n, nt, (t1-t0)*1e3, (t2-t1)*1e3, pm.edge_rounds, (t3-t2)*1e3))
 if len(sys.argv) > 3:
     import cProfile, pstats
