@@ -71,7 +71,6 @@ struct pydem_tile {
     // graph / sweep scratch
     uint8_t *inmask = nullptr, *gflags = nullptr, *todo_work = nullptr;   // inmask/gflags: unused since the cinfo word
     double *contrib = nullptr;     // [2*NN] outgoing contributions per cell (double2)
-    int32_t *pit_blk = nullptr;    // block start tables of the pit side lists
     int32_t *indeg = nullptr, *queue[2] = {nullptr, nullptr}, *labels = nullptr, *flatlist = nullptr;
     int32_t *counters = nullptr;       // device scalars
     int32_t *h_counters = nullptr;     // pinned host mirror

@@ -1017,19 +1017,38 @@ __global__ void k_pitmask(const uint8_t *__restrict__ flats, const double *__res
 
 // same block-aggregated compaction as the flats stage (mask -> list of cell ids)
 __global__ __launch_bounds__(256) void k_compact_mask(const uint8_t *__restrict__ mask, int64_t NN,
-                                                      int32_t *__restrict__ list, int32_t *__restrict__ count)
+                                                       int32_t *__restrict__ list, int32_t *__restrict__ count)
 {
+    // 64 cells per thread (four 16 B loads), 16 Ki cells per block trip: the trip is bound by its barrier + atomic
+    // round trip, not by the 1 B/cell it reads
     __shared__ int32_t wave_tot[4];
     __shared__ int32_t blk_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t base = (int64_t)blockIdx.x * 4096; base < NN; base += (int64_t)gridDim.x * 4096) {
-        const int64_t c0 = base + (int64_t)threadIdx.x * 16;
-        uint32_t bits = 0;
-        for (int k = 0; k < 16; k++)
-            if (c0 + k < NN && mask[c0 + k]) bits |= 1u << k;
-        const int32_t mine = __popc(bits);
+    for (int64_t base = (int64_t)blockIdx.x * 16384; base < NN; base += (int64_t)gridDim.x * 16384) {
+        const int64_t c0 = base + (int64_t)threadIdx.x * 64;
+        unsigned long long bits = 0;   // bit k set <=> cell c0+k is set
+        if (c0 + 64 <= NN) {
+            uint4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const uint4 *>(mask + c0 + 16 * q);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    bits |= (unsigned long long)(((w[k >> 2] >> (8 * (k & 3))) & 0xffu) ? 1u : 0u) << (16 * q + k);
+            }
+        } else {
+            for (int k = 0; k < 64; k++)
+                if (c0 + k < NN && mask[c0 + k]) bits |= 1ull << k;
+        }
+        const int32_t mine = __popcll(bits);
         int32_t incl = mine;
-        for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1039,7 +1058,11 @@ __global__ __launch_bounds__(256) void k_compact_mask(const uint8_t *__restrict_
         __syncthreads();
         int32_t off = blk_base + incl - mine;
         for (int k = 0; k < wave; k++) off += wave_tot[k];
-        while (bits) { const int k = __ffs((int)bits) - 1; bits &= bits - 1; list[off++] = (int32_t)(c0 + k); }
+        while (bits) {
+            const int k = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            list[off++] = (int32_t)(c0 + k);
+        }
         __syncthreads();
     }
 }

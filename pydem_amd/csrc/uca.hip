@@ -40,7 +40,6 @@ constexpr uint32_t CI_LEVEL_INF = 0x1FFFFu, CI_STATIC_MASK = 0x7FFFu;
 __device__ __forceinline__ uint32_t ci_level(uint32_t w) { return w >> CI_LEVEL_SHIFT; }
 __device__ __forceinline__ int ci_section(uint32_t w) { return (int)((w >> CI_SEC_SHIFT) & 7u); }
 __device__ __forceinline__ uint32_t ci_with_level(uint32_t w, uint32_t lv) { return (w & CI_STATIC_MASK) | (lv << CI_LEVEL_SHIFT); }
-constexpr int PIT_BLK_SHIFT = 5;     // pit side lists are indexed per block of 32 cells (<1 entry per block: the lookup is two loads)
 
 // 8-neighbour offsets in ascending cell-id order: NW N NE W E SW S SE
 __device__ __constant__ const int NB_DI[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
@@ -218,31 +217,11 @@ struct SweepArgs {
     // pit side lists: out-edges sorted by (src, dst), in-edges sorted by (dst, src), block start tables
     const int32_t *pit_src, *pit_dst;
     const int32_t *pin_dst, *pin_src; const double *pin_w;
-    const int32_t *pout_blk, *pin_blk;
     int64_t n_pit;
     int dbg;                     // timing experiments only (PYDEM_TILE_DEBUG)
     int32_t qcap;                // frontier queue capacity (entries)
     int32_t *err;                // queue overflow counter
 };
-
-// first index e >= blk[cell >> 8] with key[e] >= cell (lists are sorted; ~6 entries per block)
-__device__ __forceinline__ int32_t pit_first(const int32_t *__restrict__ key, const int32_t *__restrict__ blk, int32_t cell)
-{
-    int32_t e = blk[cell >> PIT_BLK_SHIFT];
-    const int32_t hi = blk[(cell >> PIT_BLK_SHIFT) + 1];
-    while (e < hi && key[e] < cell) e++;
-    return e;
-}
-
-__global__ void k_pit_block_starts(const int32_t *__restrict__ key, int64_t ne, int32_t nblk, int32_t *__restrict__ blk)
-{
-    for (int32_t b = blockIdx.x * blockDim.x + threadIdx.x; b <= nblk; b += gridDim.x * blockDim.x) {
-        const int64_t target = (int64_t)b << PIT_BLK_SHIFT;
-        int64_t lo = 0, hi = ne;
-        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (key[mid] < target) lo = mid + 1; else hi = mid; }
-        blk[b] = (int32_t)lo;
-    }
-}
 
 // A frontier entry carries the cell AND its graph word: the round that processes it starts its
 // gathers straight from the queue load (one dependent memory round trip less per round -- the long
@@ -1291,8 +1270,6 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt)
     t->edge_clean = false;
     PYDEM_TRY(tile_alloc(t, &t->todo_work, (size_t)t->NN));
     PYDEM_TRY(tile_alloc(t, &t->indeg, (size_t)t->NN));          // the cinfo words
-    const int32_t nblk = (int32_t)(t->NN >> PIT_BLK_SHIFT) + 1;
-    PYDEM_TRY(tile_alloc(t, &t->pit_blk, (size_t)(nblk + 2) * 2));
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
     const dim3 grid2((unsigned)(cdiv(m, 256) < 64 ? cdiv(m, 256) : 64), (unsigned)(n < 16384 ? n : 16384));
     hipLaunchKernelGGL(k_section_proportion, grid2, dim3(256), 0, t->stream, t->dir, t->flats, t->sec_theta, t->NN, n, m,
@@ -1311,10 +1288,6 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt)
     if (t->pits.n_edges > 0) {
         hipLaunchKernelGGL(k_graph_add_pits, dim3(grid_for(t->pits.n_edges, 1024)), dim3(256), 0, t->stream, t->pits.src,
                            t->pits.dst, t->pits.w, t->pits.n_edges, n, m, (uint32_t *)t->indeg, corner_sums);
-        hipLaunchKernelGGL(k_pit_block_starts, dim3(grid_for(nblk + 1, 1024)), dim3(256), 0, t->stream, t->pits.src,
-                           t->pits.n_edges, nblk, t->pit_blk);
-        hipLaunchKernelGGL(k_pit_block_starts, dim3(grid_for(nblk + 1, 1024)), dim3(256), 0, t->stream, t->pits.in_dst,
-                           t->pits.n_edges, nblk, t->pit_blk + nblk + 2);
     }
     hipLaunchKernelGGL(k_corner_todo, dim3(1), dim3(64), 0, t->stream, corner_sums, t->elev, n, m, t->edge_todo, t->todo_work);
     HIP_TRY(hipEventRecord(t->ev[3], t->stream));
@@ -1329,12 +1302,10 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt)
 
 static void fill_sweep_args(pydem_tile *t, SweepArgs &A)
 {
-    const int32_t nblk = (int32_t)(t->NN >> PIT_BLK_SHIFT) + 1;
     A.cinfo = (uint32_t *)t->indeg; A.prop = t->prop; A.a0 = t->row_area; A.area = t->uca;
     A.contrib = (double2 *)t->contrib; A.todo_work = t->todo_work; A.n = (int)t->n; A.m = (int)t->m;
     A.pit_src = t->pits.src; A.pit_dst = t->pits.dst; A.n_pit = t->pits.n_edges;
     A.pin_dst = t->pits.in_dst; A.pin_src = t->pits.in_src; A.pin_w = t->pits.in_w;
-    A.pout_blk = t->pit_blk; A.pin_blk = t->pit_blk ? t->pit_blk + nblk + 2 : nullptr;
     A.qcap = (int32_t)(t->NN / 2 < INT32_MAX ? t->NN / 2 : INT32_MAX);      // queue buffers hold NN ints = NN/2 entries
     A.err = t->counters + 15;
     { const char *e = getenv("PYDEM_TILE_DEBUG"); A.dbg = e ? atoi(e) : 0; }
