@@ -812,6 +812,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
             atomicAdd(acc + 0, (unsigned long long)(tk1 - tk0)); atomicAdd(acc + 1, (unsigned long long)(tk2 - tk1));
             atomicAdd(acc + 2, (unsigned long long)(tk3 - tk2)); atomicAdd(acc + 3, (unsigned long long)(tk4 - tk3));
             atomicAdd(acc + 4, (unsigned long long)nrounds); atomicAdd(acc + 5, 1ull);
+            if (finalized == 0) atomicAdd(acc + 6, 1ull);
         }
     }
     tile_wave_sync();
@@ -1344,7 +1345,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     int32_t *cntT = t->counters + 56;          // rotating tile-list sizes
     HIP_TRY(hipMemsetAsync(tile_done, 0, tiles_pad * 5, t->stream));      // done bytes + stamps
     HIP_TRY(hipMemsetAsync(cntT, 0, 4 * sizeof(int32_t), t->stream));
-    if (A.dbg & 4) HIP_TRY(hipMemsetAsync(t->counters + 32, 0, 12 * sizeof(int32_t), t->stream));
+    if (A.dbg & 4) HIP_TRY(hipMemsetAsync(t->counters + 32, 0, 14 * sizeof(int32_t), t->stream));
     int64_t launches = 0;
     uint32_t pass = 0;
     int64_t done_prev = 0;
@@ -1395,8 +1396,8 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         HIP_TRY(hipStreamSynchronize(t->stream));
         if (A.dbg & 4) {
             const unsigned long long *acc = (const unsigned long long *)(t->h_counters + 32);
-            fprintf(stderr, "tile phases (cycles summed over %llu tile runs): stage %llu, setup %llu, rounds %llu (%llu rounds), stamp %llu\n",
-                    acc[5], acc[0], acc[1], acc[2], acc[4], acc[3]);
+            fprintf(stderr, "tile phases (cycles summed over %llu tile runs, %llu of them finished nothing): stage %llu, setup %llu, rounds %llu (%llu rounds), stamp %llu\n",
+                    acc[5], acc[6], acc[0], acc[1], acc[2], acc[4], acc[3]);
         }
     }
     if (sweep_mode == 1) {
