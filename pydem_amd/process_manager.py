@@ -74,8 +74,16 @@ def read_tile(fn):
         out.setdefault('dlat', -(top - bottom) / elev.shape[0])
         out['shape'] = elev.shape
         return out
-    raise NotImplementedError("unsupported tile format %r (raster IO is outside the accelerated path; "
-                              "use .npz tiles with `elev` and `bounds`)" % ext)
+    if ext in ('.tif', '.tiff'):
+        # what the reference's workers get from rasterio + geopy (utils.dem_processor_from_raster_kwargs :46-51)
+        from . import raster
+        out = raster.dem_processor_from_raster_kwargs(fn)
+        elev = out['elev']
+        out['dlon'] = out['transform'][0]
+        out['dlat'] = out['transform'][4]
+        out['shape'] = elev.shape
+        return out
+    raise NotImplementedError("unsupported tile format %r (.npz tiles with `elev` and `bounds`, or GeoTIFF)" % ext)
 
 
 class EdgeTransport(object):
@@ -114,7 +122,7 @@ class ProcessManager(object):
     n_workers = 1
     in_path = '.'
     out_format = 'npy'
-    _INPUT_FILE_TYPES = ["npz"]
+    _INPUT_FILE_TYPES = ["tif", "tiff", "npz"]
 
     def __init__(self, **kwargs):
         self.dem_proc_kwargs = {}

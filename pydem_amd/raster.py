@@ -1,0 +1,372 @@
+"""Minimal GeoTIFF reader / writer and WGS-84 pixel spacing -- what the reference gets from rasterio and geopy.
+
+The reference opens every tile with rasterio (pydem/utils.py:43-51 `read_raster`, `dem_processor_from_raster_kwargs`)
+and derives the per-row spacing `dX, dY, dX2, dY2` with `geopy.distance` on the tile's geotransform
+(`mk_dx_dy_from_geotif_layer`, pydem/utils.py:127-174).  Neither package is part of the accelerated path, and
+neither is needed for it: this module reads the single-band GeoTIFFs DEM tiles come in (strips or tiles;
+uncompressed, LZW, Deflate or PackBits; horizontal predictor; 8/16/32-bit integers, float32/float64; little or
+big endian; classic and BigTIFF), extracts geotransform / model type / ellipsoid / nodata from the GeoTIFF tags, and
+reproduces the reference's spacing rules with Vincenty's inverse formula on the ellipsoid (agrees with
+geographiclib -- what geopy calls -- to ~1e-10 relative on pixel-sized lines; the results of the terrain path are
+compared at 1e-6).  If rasterio is importable it is NOT used: one code path, testable here.
+
+`write_geotiff` is the small counterpart (uncompressed or Deflate strips) used by the tests and by
+`ProcessManager.save_non_overlap_data`.
+"""
+import struct
+import zlib
+
+import numpy as np
+
+# ---------------------------------------------------------------------------------------------------------------
+# TIFF decoding
+# ---------------------------------------------------------------------------------------------------------------
+_TYPE_FMT = {1: 'B', 2: 'c', 3: 'H', 4: 'I', 5: 'II', 6: 'b', 7: 'B', 8: 'h', 9: 'i', 10: 'ii', 11: 'f', 12: 'd', 16: 'Q', 17: 'q',
+             18: 'Q'}
+_ELLIPSOIDS = {            # name -> (semi-major axis [m], flattening); keys as geopy spells them (utils.py:140-151)
+    'WGS-84': (6378137.0, 1 / 298.257223563),
+    'GRS-80': (6378137.0, 1 / 298.257222101),
+    'Airy (1830)': (6377563.396, 1 / 299.3249646),
+    'Intl 1924': (6378388.0, 1 / 297.0),
+    'Clarke (1880)': (6378249.145, 1 / 293.465),
+    'GRS-67': (6378160.0, 1 / 298.25),
+    'Clarke (1866)': (6378206.4, 1 / 294.9786982),
+}
+_GEOG_CODES = {4326: 'WGS-84', 4269: 'GRS-80', 4258: 'GRS-80', 4267: 'Clarke (1866)', 4230: 'Intl 1924'}
+_ELLIPSOID_CODES = {7030: 'WGS-84', 7019: 'GRS-80', 7022: 'Intl 1924', 7001: 'Airy (1830)', 7036: 'GRS-67'}
+
+
+def _lzw_decode(data, expected):
+    """TIFF flavour of LZW (MSB-first codes, 9..12 bits, ClearCode 256, EOI 257, 'early change')."""
+    out = bytearray()
+    table = None
+    nbits = 9
+    acc = 0
+    have = 0
+    prev = None
+    pos = 0
+    n = len(data)
+    while True:
+        while have < nbits and pos < n:
+            acc = (acc << 8) | data[pos]; pos += 1; have += 8
+        if have < nbits:
+            break
+        code = (acc >> (have - nbits)) & ((1 << nbits) - 1)
+        have -= nbits
+        if code == 256:
+            table = [bytes([i]) for i in range(256)] + [b'', b'']
+            nbits = 9
+            prev = None
+            continue
+        if code == 257:
+            break
+        if table is None:
+            raise ValueError("LZW stream does not start with a clear code")
+        if prev is None:
+            entry = table[code]
+        elif code < len(table):
+            entry = table[code]
+            table.append(prev + entry[:1])
+        else:
+            entry = prev + prev[:1]
+            table.append(entry)
+        out += entry
+        prev = entry
+        if len(table) >= (1 << nbits) - 1 and nbits < 12:
+            nbits += 1
+        if len(out) >= expected:
+            break
+    return bytes(out[:expected])
+
+
+def _packbits_decode(data, expected):
+    out = bytearray()
+    i = 0
+    while i < len(data) and len(out) < expected:
+        n = data[i]; i += 1
+        if n < 128:
+            out += data[i:i + n + 1]; i += n + 1
+        elif n > 128:
+            out += data[i:i + 1] * (257 - n); i += 1
+    return bytes(out[:expected])
+
+
+class GeoTiff(object):
+    """What the terrain path needs from a rasterio dataset: `read()`, `shape`, `transform` (a, b, c, d, e, f),
+    `bounds` (left, bottom, right, top), `is_projected`, `ellipsoid`, `nodata`."""
+
+    def __init__(self, array, transform, is_projected, ellipsoid, nodata):
+        self.array = array
+        self.shape = array.shape
+        self.transform = transform
+        self.is_projected = is_projected
+        self.ellipsoid = ellipsoid
+        self.nodata = nodata
+        a, b, c, d, e, f = transform
+        h, w = array.shape
+        xs = [c, c + a * w]
+        ys = [f, f + e * h]
+        self.bounds = (min(xs), min(ys), max(xs), max(ys))
+
+    def read(self, band=1):
+        return self.array
+
+
+def read_geotiff(path):
+    with open(path, 'rb') as fh:
+        buf = fh.read()
+    if buf[:2] == b'II':
+        bo = '<'
+    elif buf[:2] == b'MM':
+        bo = '>'
+    else:
+        raise ValueError("%s is not a TIFF file" % path)
+    magic = struct.unpack(bo + 'H', buf[2:4])[0]
+    if magic == 42:
+        big = False
+        ifd = struct.unpack(bo + 'I', buf[4:8])[0]
+    elif magic == 43:
+        big = True
+        ifd = struct.unpack(bo + 'Q', buf[8:16])[0]
+    else:
+        raise ValueError("%s: unknown TIFF version %d" % (path, magic))
+    if big:
+        n = struct.unpack(bo + 'Q', buf[ifd:ifd + 8])[0]
+        base, esz, cnt_fmt, inline = ifd + 8, 20, 'Q', 8
+    else:
+        n = struct.unpack(bo + 'H', buf[ifd:ifd + 2])[0]
+        base, esz, cnt_fmt, inline = ifd + 2, 12, 'I', 4
+    tags = {}
+    for k in range(n):
+        e = buf[base + k * esz: base + (k + 1) * esz]
+        tag, typ = struct.unpack(bo + 'HH', e[:4])
+        cnt = struct.unpack(bo + cnt_fmt, e[4:4 + inline])[0]
+        fmt = _TYPE_FMT.get(typ)
+        if fmt is None:
+            continue
+        size = struct.calcsize(bo + fmt) * cnt
+        if size <= inline:
+            raw = e[4 + inline: 4 + inline + size]
+        else:
+            off = struct.unpack(bo + cnt_fmt, e[4 + inline: 4 + 2 * inline])[0]
+            raw = buf[off:off + size]
+        if typ == 2:
+            tags[tag] = raw.split(b'\x00')[0].decode('latin-1')
+        else:
+            vals = struct.unpack(bo + fmt * cnt if len(fmt) == 1 else bo + fmt * cnt, raw)
+            if typ in (5, 10):
+                vals = tuple(vals[i] / vals[i + 1] if vals[i + 1] else 0.0 for i in range(0, len(vals), 2))
+            tags[tag] = vals
+    w, h = tags[256][0], tags[257][0]
+    spp = tags.get(277, (1,))[0]
+    if spp != 1:
+        raise NotImplementedError("%s: %d samples per pixel (single-band DEMs only)" % (path, spp))
+    bits = tags.get(258, (1,))[0]
+    fmt_code = tags.get(339, (1,))[0]
+    comp = tags.get(259, (1,))[0]
+    pred = tags.get(317, (1,))[0]
+    kind = {1: 'u', 2: 'i', 3: 'f'}.get(fmt_code)
+    if kind is None or bits not in (8, 16, 32, 64) or (kind == 'f' and bits < 32):
+        raise NotImplementedError("%s: sample format %d with %d bits" % (path, fmt_code, bits))
+    dt = np.dtype(bo + kind + str(bits // 8))
+
+    def inflate(chunk, nbytes):
+        if comp == 1:
+            return chunk[:nbytes]
+        if comp == 5:
+            return _lzw_decode(chunk, nbytes)
+        if comp in (8, 32946):
+            return zlib.decompress(chunk)[:nbytes]
+        if comp == 32773:
+            return _packbits_decode(chunk, nbytes)
+        raise NotImplementedError("%s: TIFF compression %d" % (path, comp))
+
+    def unpredict(block):
+        if pred == 1:
+            return block
+        if pred == 2 and kind in 'ui':
+            return np.cumsum(block, axis=1, dtype=block.dtype)          # wraps like the encoder's differences
+        raise NotImplementedError("%s: predictor %d for %s samples" % (path, pred, dt))
+
+    out = np.empty((h, w), dt.newbyteorder('='))
+    if 322 in tags:                                                     # tiled
+        tw, th = tags[322][0], tags[323][0]
+        offs, cnts = tags[324], tags[325]
+        per_row = (w + tw - 1) // tw
+        for t, (o, c) in enumerate(zip(offs, cnts)):
+            r0, c0 = (t // per_row) * th, (t % per_row) * tw
+            blk = np.frombuffer(inflate(buf[o:o + c], tw * th * dt.itemsize), dt).reshape(th, tw)
+            blk = unpredict(blk)
+            out[r0:r0 + th, c0:c0 + tw] = blk[:min(th, h - r0), :min(tw, w - c0)]
+    else:
+        rps = tags.get(278, (h,))[0]
+        offs, cnts = tags[273], tags.get(279)
+        for s, o in enumerate(offs):
+            r0 = s * rps
+            rows = min(rps, h - r0)
+            c = cnts[s] if cnts else rows * w * dt.itemsize
+            blk = np.frombuffer(inflate(buf[o:o + c], rows * w * dt.itemsize), dt).reshape(rows, w)
+            out[r0:r0 + rows] = unpredict(blk)
+    # ---- georeferencing
+    if 34264 in tags:                                                   # ModelTransformationTag (4x4)
+        m = tags[34264]
+        transform = (m[0], m[1], m[3], m[4], m[5], m[7])
+    elif 33550 in tags and 33922 in tags:                               # pixel scale + tie point
+        sx, sy = tags[33550][0], tags[33550][1]
+        i, j, _, x, y, _ = tags[33922][:6]
+        transform = (sx, 0.0, x - i * sx, 0.0, -sy, y + j * sy)
+    else:
+        transform = (1.0, 0.0, 0.0, 0.0, -1.0, float(h))
+    projected, ellipsoid = False, 'WGS-84'
+    if 34735 in tags:
+        keys = tags[34735]
+        for k in range(1, keys[3] + 1):
+            key, loc, cnt, val = keys[4 * k: 4 * k + 4]
+            if key == 1024 and loc == 0:
+                projected = (val == 1)
+            elif key == 2048 and loc == 0:
+                ellipsoid = _GEOG_CODES.get(val, ellipsoid)
+            elif key == 2056 and loc == 0:
+                ellipsoid = _ELLIPSOID_CODES.get(val, ellipsoid)
+    else:
+        projected = True                                                # no geo keys: plain pixel coordinates
+    nodata = None
+    if 42113 in tags:
+        try:
+            nodata = float(tags[42113])
+        except ValueError:
+            nodata = None
+    # pixel-is-point rasters (GTRasterTypeGeoKey 1025 == 2) anchor the tie point at the pixel centre
+    if 34735 in tags:
+        keys = tags[34735]
+        for k in range(1, keys[3] + 1):
+            key, loc, cnt, val = keys[4 * k: 4 * k + 4]
+            if key == 1025 and loc == 0 and val == 2:
+                a, b, c, d, e, f = transform
+                transform = (a, b, c - a / 2, d, e, f - e / 2)
+    return GeoTiff(out, transform, projected, ellipsoid, nodata)
+
+
+def write_geotiff(path, array, transform, projected=False, nodata=None, compress=False):
+    """Single-band little-endian GeoTIFF, one strip (uncompressed or Deflate).  `transform` = (a, b, c, d, e, f)."""
+    arr = np.ascontiguousarray(array)
+    if arr.dtype.byteorder == '>':
+        arr = arr.astype(arr.dtype.newbyteorder('<'))
+    kind = {'u': 1, 'i': 2, 'f': 3}[arr.dtype.kind]
+    h, w = arr.shape
+    payload = arr.tobytes()
+    if compress:
+        payload = zlib.compress(payload, 6)
+    a, b, c, d, e, f = transform
+    entries = []      # (tag, type, count, packed bytes)
+
+    def add(tag, typ, values):
+        fmt = _TYPE_FMT[typ]
+        if typ == 2:
+            raw = values.encode('latin-1') + b'\x00'
+            entries.append((tag, typ, len(raw), raw))
+        else:
+            entries.append((tag, typ, len(values), struct.pack('<' + fmt * len(values), *values)))
+
+    add(256, 4, [w]); add(257, 4, [h]); add(258, 3, [arr.dtype.itemsize * 8]); add(259, 3, [8 if compress else 1])
+    add(262, 3, [1]); add(273, 4, [0]); add(277, 3, [1]); add(278, 4, [h]); add(279, 4, [len(payload)]); add(339, 3, [kind])
+    add(33550, 12, [a, -e, 0.0]); add(33922, 12, [0.0, 0.0, 0.0, c, f, 0.0])
+    add(34735, 3, [1, 1, 0, 3, 1024, 0, 1, 1 if projected else 2, 1025, 0, 1, 1, 2048, 0, 1, 4326])
+    if nodata is not None:
+        add(42113, 2, repr(float(nodata)))
+    entries.sort(key=lambda t: t[0])
+    ifd_off = 8
+    ifd_len = 2 + 12 * len(entries) + 4
+    extra_off = ifd_off + ifd_len
+    extra = b''
+    strip_entry = None
+    body = b''
+    for k, (tag, typ, cnt, raw) in enumerate(entries):
+        if len(raw) <= 4:
+            val = raw + b'\x00' * (4 - len(raw))
+        else:
+            val = struct.pack('<I', extra_off + len(extra))
+            extra += raw + (b'\x00' if len(raw) % 2 else b'')
+        if tag == 273:
+            strip_entry = k
+        body += struct.pack('<HHI', tag, typ, cnt) + val
+    data_off = extra_off + len(extra)
+    k = strip_entry
+    body = body[:12 * k + 8] + struct.pack('<I', data_off) + body[12 * k + 12:]
+    with open(path, 'wb') as fh:
+        fh.write(b'II' + struct.pack('<HI', 42, ifd_off))
+        fh.write(struct.pack('<H', len(entries)) + body + struct.pack('<I', 0))
+        fh.write(extra)
+        fh.write(payload)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# geodesic pixel spacing
+# ---------------------------------------------------------------------------------------------------------------
+def geodesic_m(lat1, lon1, lat2, lon2, ellipsoid='WGS-84'):
+    """Geodesic distance in metres between two points (degrees) on the ellipsoid: Vincenty's inverse formula
+    (what geopy.distance returned before it switched to geographiclib; the two agree to ~1e-10 relative on
+    pixel-sized lines; the iteration converges in 2-3 steps for nearby points and degenerates gracefully on a
+    meridian)."""
+    a, f = _ELLIPSOIDS[ellipsoid]
+    b = a * (1 - f)
+    p1, p2 = np.radians(lat1), np.radians(lat2)
+    L = np.radians(lon2 - lon1)
+    if lat1 == lat2 and L == 0:
+        return 0.0
+    U1 = np.arctan((1 - f) * np.tan(p1))
+    U2 = np.arctan((1 - f) * np.tan(p2))
+    sU1, cU1, sU2, cU2 = np.sin(U1), np.cos(U1), np.sin(U2), np.cos(U2)
+    lam = L
+    for _ in range(200):
+        sl, cl = np.sin(lam), np.cos(lam)
+        ss = np.hypot(cU2 * sl, cU1 * sU2 - sU1 * cU2 * cl)
+        if ss == 0:
+            return 0.0
+        cs = sU1 * sU2 + cU1 * cU2 * cl
+        sig = np.arctan2(ss, cs)
+        sa = cU1 * cU2 * sl / ss
+        c2a = 1 - sa * sa
+        c2m = cs - 2 * sU1 * sU2 / c2a if c2a != 0 else 0.0
+        C = f / 16 * c2a * (4 + f * (4 - 3 * c2a))
+        new = L + (1 - C) * f * sa * (sig + C * ss * (c2m + C * cs * (-1 + 2 * c2m * c2m)))
+        if abs(new - lam) < 1e-15:
+            lam = new
+            break
+        lam = new
+    u2 = c2a * (a * a - b * b) / (b * b)
+    A = 1 + u2 / 16384 * (4096 + u2 * (-768 + u2 * (320 - 175 * u2)))
+    B = u2 / 1024 * (256 + u2 * (-128 + u2 * (74 - 47 * u2)))
+    ds = B * ss * (c2m + B / 4 * (cs * (-1 + 2 * c2m * c2m) - B / 6 * c2m * (-3 + 4 * ss * ss) * (-3 + 4 * c2m * c2m)))
+    return float(b * A * (sig - ds))
+
+
+def spacing_from_geotransform(n_rows, transform, projected, ellipsoid='WGS-84'):
+    """dX, dY (n_rows - 1 values) and dX2, dY2 (n_rows values) exactly as `mk_dx_dy_from_geotif_layer`
+    (pydem/utils.py:127-174) builds them: projected rasters use the pixel size; geographic ones measure, per row, the
+    geodesic between two points one pixel apart in longitude (dX) and the meridian arc to the next row (dY).  The
+    reference anchors the longitude at `transform.d` (the rotation term, 0 for north-up rasters) -- irrelevant, only
+    differences enter -- and the latitude at `transform.f`; both quirks are kept."""
+    a, b, c, d, e, f = transform
+    if projected:
+        return (np.ones(n_rows - 1) * a, np.abs(np.ones(n_rows - 1) * e), np.ones(n_rows) * a, np.abs(np.ones(n_rows) * e))
+    dx, dy = a, e
+
+    def clip(v):
+        return min(max(v, -90.0), 90.0)
+
+    lon, lat = d + dx / 2, f + dy / 2
+    dX = np.array([geodesic_m(clip(lat + dy * (j + 1)), lon + dx, clip(lat + dy * (j + 1)), lon, ellipsoid) for j in range(n_rows - 1)])
+    dY = np.array([geodesic_m(clip(lat + dy * i), lon, clip(lat + dy * (i + 1)), lon, ellipsoid) for i in range(n_rows - 1)])
+    lon, lat = d + dx, f + dy
+    dX2 = np.array([geodesic_m(clip(lat + dy * (j + 1)), lon + dx, clip(lat + dy * (j + 1)), lon, ellipsoid) for j in range(n_rows)])
+    dY2 = np.array([geodesic_m(clip(lat + dy * i), lon, clip(lat + dy * (i + 1)), lon, ellipsoid) for i in range(n_rows)])
+    return dX, dY, dX2, dY2
+
+
+def dem_processor_from_raster_kwargs(path):
+    """The reference's helper of the same name (pydem/utils.py:46-51): constructor arguments of a DEMProcessor for one
+    raster tile.  Nodata cells become a masked array like rasterio's `read(masked=...)` users expect downstream."""
+    ds = read_geotiff(path)
+    dX, dY, dX2, dY2 = spacing_from_geotransform(ds.shape[0], ds.transform, ds.is_projected, ds.ellipsoid)
+    return dict(dX=dX, dY=dY, elev=ds.read(1), bounds=ds.bounds, transform=ds.transform, dX2=dX2, dY2=dY2)

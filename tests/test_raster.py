@@ -1,0 +1,232 @@
+"""pydem_amd/raster.py: the GeoTIFF reader against the reference's own test raster and against files built here with
+every layout it claims to read; Vincenty against published lines; the spacing rules of the reference; and the
+directory flow fed with GeoTIFF tiles instead of .npz tiles (CPU only)."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from pydem_amd import raster
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_reads_the_reference_test_raster():
+    """pydem/test/test_NN032_033_elev.tif (a data file of the reference's tests): same samples as the golden captured
+    when the reference ran on it, and the georeferencing its file name spells (N46.0/W73.0 ... N45.0/W72.0, 32 px)."""
+    ds = raster.read_geotiff(os.path.join(HERE, 'golden', 'ref_test_NN032_033_elev.tif'))
+    g = load_golden('g3_tif32')
+    assert ds.array.dtype == np.float64 and np.array_equal(ds.array, g['in_elev'])
+    assert not ds.is_projected and ds.ellipsoid == 'WGS-84'
+    a, b, c, d, e, f = ds.transform
+    assert abs(a - 1 / 31.0) < 1e-12 and abs(e + 1 / 31.0) < 1e-12 and b == 0 and d == 0
+    assert np.allclose(ds.bounds, (-73 - 0.5 / 31, 45 - 0.5 / 31, -72 + 0.5 / 31, 46 + 0.5 / 31))
+
+
+def _lzw_encode(data):
+    """Textbook TIFF LZW encoder (test-side only) to exercise the decoder."""
+    codes, table, nbits = [], {bytes([i]): i for i in range(256)}, 9
+    out, acc, have = bytearray(), 0, 0
+
+    def emit(code, nb):
+        nonlocal acc, have
+        acc = (acc << nb) | code; have += nb
+        while have >= 8:
+            out.append((acc >> (have - 8)) & 0xFF); have -= 8
+
+    emit(256, 9)
+    nxt, w = 258, b''
+    for byte in data:
+        wc = w + bytes([byte])
+        if wc in table:
+            w = wc
+            continue
+        emit(table[w], nbits)
+        table[wc] = nxt; nxt += 1
+        if nxt == (1 << nbits) - 1 + 1 and nbits < 12:      # early change: widen one code early
+            nbits += 1
+        if nxt == 4094:
+            emit(256, nbits)
+            table, nbits, nxt = {bytes([i]): i for i in range(256)}, 9, 258
+        w = bytes([byte])
+    if w:
+        emit(table[w], nbits)
+    emit(257, nbits)
+    if have:
+        out.append((acc << (8 - have)) & 0xFF)
+    return bytes(out)
+
+
+def _packbits_encode(data):
+    out, i = bytearray(), 0
+    while i < len(data):
+        n = min(128, len(data) - i)
+        out.append(n - 1); out += data[i:i + n]; i += n
+    return bytes(out)
+
+
+def _build_tiff(arr, bo='<', comp=1, pred=1, tile=None, rows_per_strip=None, big=False):
+    """Single-band TIFF with the requested byte order / compression / predictor / layout (test-side writer)."""
+    a = np.ascontiguousarray(arr).astype(arr.dtype.newbyteorder(bo))
+    h, w = a.shape
+    kind = {'u': 1, 'i': 2, 'f': 3}[a.dtype.kind]
+
+    def pack_block(blk):
+        b = np.ascontiguousarray(blk)
+        if pred == 2:
+            nat = b.astype(b.dtype.newbyteorder('='))
+            d = nat.copy(); d[:, 1:] = nat[:, 1:] - nat[:, :-1]
+            b = d.astype(a.dtype)
+        raw = b.tobytes()
+        return {1: lambda r: r, 5: _lzw_encode, 8: lambda r: zlib.compress(r), 32773: _packbits_encode}[comp](raw)
+
+    chunks = []
+    if tile:
+        th, tw = tile
+        for r0 in range(0, h, th):
+            for c0 in range(0, w, tw):
+                blk = np.zeros((th, tw), a.dtype)
+                sub = a[r0:r0 + th, c0:c0 + tw]
+                blk[:sub.shape[0], :sub.shape[1]] = sub
+                chunks.append(pack_block(blk))
+    else:
+        rps = rows_per_strip or h
+        for r0 in range(0, h, rps):
+            chunks.append(pack_block(a[r0:r0 + rps]))
+    off_fmt, hdr = ('Q', 16) if big else ('I', 8)
+    entries = [(256, 4, [w]), (257, 4, [h]), (258, 3, [a.dtype.itemsize * 8]), (259, 3, [comp]), (262, 3, [1]), (277, 3, [1]),
+               (317, 3, [pred]), (339, 3, [kind]), (33550, 12, [0.5, 0.25, 0.0]), (33922, 12, [0.0, 0.0, 0.0, 100.0, 200.0, 0.0]),
+               (34735, 3, [1, 1, 0, 1, 1024, 0, 1, 1]), (42113, 2, b'-9999\x00')]
+    if tile:
+        entries += [(322, 4, [tile[1]]), (323, 4, [tile[0]]), (324, 16 if big else 4, None), (325, 16 if big else 4, [len(c) for c in chunks])]
+    else:
+        entries += [(278, 4, [rows_per_strip or h]), (273, 16 if big else 4, None), (279, 16 if big else 4, [len(c) for c in chunks])]
+    entries.sort(key=lambda t: t[0])
+    esz, inline = (20, 8) if big else (12, 4)
+    ifd_len = (8 if big else 2) + esz * len(entries) + (8 if big else 4)
+    extra_off = hdr + ifd_len
+    fmts = {2: 'c', 3: 'H', 4: 'I', 12: 'd', 16: 'Q'}
+    sizes = {2: 1, 3: 2, 4: 4, 12: 8, 16: 8}
+    # first pass: sizes of out-of-line values, then the data offsets
+    extra_len = 0
+    for tag, typ, vals in entries:
+        cnt = len(chunks) if vals is None else len(vals)
+        sz = sizes[typ] * cnt
+        if sz > inline:
+            extra_len += sz + (sz % 2)
+    data_off = extra_off + extra_len
+    offs, o = [], data_off
+    for c in chunks:
+        offs.append(o); o += len(c)
+    body, extra = b'', b''
+    for tag, typ, vals in entries:
+        if vals is None:
+            vals = offs
+        raw = vals if typ == 2 else struct.pack(bo + fmts[typ] * len(vals), *vals)
+        cnt = len(vals)
+        if len(raw) <= inline:
+            val = raw + b'\x00' * (inline - len(raw))
+        else:
+            val = struct.pack(bo + off_fmt, extra_off + len(extra))
+            extra += raw + (b'\x00' if len(raw) % 2 else b'')
+        body += struct.pack(bo + 'HH' + ('Q' if big else 'I'), tag, typ, cnt) + val
+    head = (b'II' if bo == '<' else b'MM')
+    if big:
+        head += struct.pack(bo + 'HHHQ', 43, 8, 0, 16)
+        ifd = struct.pack(bo + 'Q', len(entries)) + body + struct.pack(bo + 'Q', 0)
+    else:
+        head += struct.pack(bo + 'HI', 42, 8)
+        ifd = struct.pack(bo + 'H', len(entries)) + body + struct.pack(bo + 'I', 0)
+    return head + ifd + extra + b''.join(chunks)
+
+
+@pytest.mark.parametrize('dtype', ['int16', 'uint16', 'int32', 'float32', 'float64', 'uint8'])
+@pytest.mark.parametrize('layout', [dict(), dict(comp=8), dict(comp=5), dict(comp=32773), dict(comp=5, pred=2), dict(comp=8, pred=2, tile=(16, 32)),
+                                    dict(bo='>'), dict(bo='>', comp=5, tile=(32, 16)), dict(rows_per_strip=7, comp=8), dict(big=True, comp=8),
+                                    dict(big=True, bo='>', tile=(16, 16))])
+def test_reads_every_layout(dtype, layout, tmp_path):
+    if layout.get('pred') == 2 and dtype.startswith('float'):
+        pytest.skip("horizontal differencing is defined for integer samples")
+    rng = np.random.default_rng(7)
+    base = rng.integers(0, 200, (45, 70))
+    base = np.cumsum(base, axis=1) % 250 if dtype == 'uint8' else base * 13 - 900
+    arr = base.astype(dtype)
+    if dtype.startswith('float'):
+        arr = arr + rng.random((45, 70)).astype(dtype)
+    fn = str(tmp_path / 't.tif')
+    open(fn, 'wb').write(_build_tiff(arr, **layout))
+    ds = raster.read_geotiff(fn)
+    assert ds.array.dtype == np.dtype(dtype) and np.array_equal(ds.array, arr)
+    assert ds.is_projected and ds.nodata == -9999.0
+    assert ds.transform == (0.5, 0.0, 100.0, 0.0, -0.25, 200.0)
+    assert ds.bounds == (100.0, 200.0 - 0.25 * 45, 100.0 + 0.5 * 70, 200.0)
+
+
+@pytest.mark.parametrize('compress', [False, True])
+def test_writer_round_trip(compress, tmp_path):
+    arr = (np.arange(37 * 53).reshape(37, 53) % 311).astype('int16')
+    fn = str(tmp_path / 'w.tif')
+    raster.write_geotiff(fn, arr, (1 / 3600.0, 0.0, -72.5, 0.0, -1 / 3600.0, 45.25), projected=False, nodata=-32768, compress=compress)
+    ds = raster.read_geotiff(fn)
+    assert np.array_equal(ds.array, arr) and not ds.is_projected and ds.nodata == -32768.0
+    assert np.allclose(ds.transform, (1 / 3600.0, 0.0, -72.5, 0.0, -1 / 3600.0, 45.25), rtol=0, atol=1e-15)
+
+
+def test_vincenty_published_lines():
+    # Geoscience Australia's GDA94 test line Flinders Peak -> Buninyong (GRS80): 54 972.271 m
+    d = raster.geodesic_m(-(37 + 57 / 60 + 3.72030 / 3600), 144 + 25 / 60 + 29.52440 / 3600,
+                          -(37 + 39 / 60 + 10.15610 / 3600), 143 + 55 / 60 + 35.38390 / 3600, 'GRS-80')
+    assert abs(d - 54972.271) < 1e-3
+    assert abs(raster.geodesic_m(0, 0, 90, 0) - 10001965.7293) < 1e-3           # WGS-84 quarter meridian
+    assert abs(raster.geodesic_m(0, 10, 0, 11) - 6378137.0 * np.pi / 180) < 1e-6  # one degree of the equator
+    assert raster.geodesic_m(12.5, 7.0, 12.5, 7.0) == 0.0
+    assert abs(raster.geodesic_m(45, 0, 45, 1 / 3600) - raster.geodesic_m(45, 5, 45, 5 + 1 / 3600)) < 1e-9
+
+
+def test_spacing_rules_of_the_reference():
+    n = 6
+    t = (1 / 3600.0, 0.0, -72.0, 0.0, -1 / 3600.0, 45.0)
+    dX, dY, dX2, dY2 = raster.spacing_from_geotransform(n, t, False)
+    assert dX.shape == (n - 1,) and dY.shape == (n - 1,) and dX2.shape == (n,) and dY2.shape == (n,)
+    lat0 = 45.0 - 0.5 / 3600                                                     # transform.f + dy / 2 (utils.py:155)
+    for j in range(n - 1):
+        assert abs(dX[j] - raster.geodesic_m(lat0 - (j + 1) / 3600, 0.0, lat0 - (j + 1) / 3600, 1 / 3600)) < 1e-9   # longitude anchor irrelevant
+        assert abs(dY[j] - raster.geodesic_m(lat0 - j / 3600, 0.0, lat0 - (j + 1) / 3600, 0.0)) < 1e-9
+    assert np.all(np.diff(dX) > 0)                      # going south from 45 N the parallels get longer
+    assert 30.8 < dY.mean() < 30.9 and 21.8 < dX.mean() < 22.0
+    p = raster.spacing_from_geotransform(n, (30.0, 0, 5e5, 0, -25.0, 4e6), True)
+    assert np.array_equal(p[0], np.full(n - 1, 30.0)) and np.array_equal(p[1], np.full(n - 1, 25.0))
+    assert np.array_equal(p[2], np.full(n, 30.0)) and np.array_equal(p[3], np.full(n, 25.0))
+
+
+def test_directory_flow_from_geotiff_tiles(tmp_path):
+    """The same mosaic as .npz tiles and as (projected, Deflate) GeoTIFF tiles must give the same results."""
+    from oracle_processor import OracleProcessor
+    from pydem_amd import process_manager
+    from test_process_manager_cpu import run_pm
+    g = load_golden('pm_cone32_3x3_ov2')
+    pm0, compact0, order0 = run_pm(g, str(tmp_path / 'npz'), processor_cls=OracleProcessor)
+    tif_dir = tmp_path / 'tif'
+    os.makedirs(tif_dir)
+    for i in range(int(g['n_tiles'])):
+        elev = g['t%02d_elev' % i]
+        left, bottom, right, top = [float(v) for v in g['t%02d_bounds' % i]]
+        n, m = elev.shape
+        raster.write_geotiff(str(tif_dir / ('tile_%03d.tif' % i)), elev, ((right - left) / m, 0.0, left, 0.0, -(top - bottom) / n, top),
+                             projected=True, compress=True)
+    dkw = {k: v for k, v in g['kwargs'].items() if k not in ('ny_grid', 'nx_grid', 'overlap')}
+    process_manager.DEBUG = True
+    try:
+        pm1 = process_manager.ProcessManager(in_path=str(tif_dir), dem_proc_kwargs=dkw, elev_conditioned=True, processor_cls=OracleProcessor)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            pm1.process_twi()
+            compact1 = pm1.save_non_overlap_data()
+    finally:
+        process_manager.DEBUG = False
+    for key in ('elev', 'uca', 'aspect', 'slope', 'twi'):
+        assert np.array_equal(compact0[key], compact1[key], equal_nan=True), key
