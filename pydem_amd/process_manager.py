@@ -694,3 +694,28 @@ class ProcessManager(object):
             out[key] = full
         self.out_file_noverlap = out
         return out
+
+    def save_geotiff(self, filename, key, dtype, crs=None, max_files=2, rescale=None, overview_type=None, overview_factors=None):
+        """One stitched result as a GeoTIFF (reference :862-931): same geotransform rules (one pixel size for the whole
+        mosaic, else NotImplementedError), same optional rescaling.  Written by pydem_amd/raster.py as one Deflate strip;
+        tiling / BigTIFF / overviews of the reference's rasterio call are not reproduced (`overview_type` must be None).
+        `crs`: 'projected' or anything else = geographic WGS-84 (the default follows the first input tile)."""
+        from . import raster
+        if overview_type is not None:
+            raise NotImplementedError("overviews are not written (use rasterio / gdaladdo on the result)")
+        data = self.out_file_noverlap[key]
+        dlats = np.unique(np.round(self.index[self.grid_id2i.max(axis=1), 5], decimals=6))
+        dlons = np.unique(np.round(self.index[self.grid_id2i.max(axis=0), 4], decimals=6))
+        if dlats.size > 1 or dlons.size > 1:
+            raise NotImplementedError
+        top, bottom = self.index[:, 3].max(), self.index[:, 1].min()
+        left, right = self.index[:, 0].min(), self.index[:, 2].max()
+        dlat = (bottom - top) / self.grid_size_tot_unique[0]
+        dlon = (right - left) / self.grid_size_tot_unique[1]
+        if crs is None:
+            meta = self._tile_meta[0]
+            crs = 'projected' if meta.get('is_projected', 'dX' not in meta) else 'geographic'
+        if rescale:
+            data = (data - rescale[0]) / (rescale[1] - rescale[0]) * rescale[2]
+        raster.write_geotiff(filename, np.asarray(data).astype(dtype), (dlon, 0.0, left, 0.0, dlat, top),
+                             projected=(crs == 'projected'), compress=True)

@@ -369,4 +369,5 @@ def dem_processor_from_raster_kwargs(path):
     raster tile.  Nodata cells become a masked array like rasterio's `read(masked=...)` users expect downstream."""
     ds = read_geotiff(path)
     dX, dY, dX2, dY2 = spacing_from_geotransform(ds.shape[0], ds.transform, ds.is_projected, ds.ellipsoid)
-    return dict(dX=dX, dY=dY, elev=ds.read(1), bounds=ds.bounds, transform=ds.transform, dX2=dX2, dY2=dY2)
+    return dict(dX=dX, dY=dY, elev=ds.read(1), bounds=ds.bounds, transform=ds.transform, dX2=dX2, dY2=dY2,
+                is_projected=ds.is_projected)

@@ -230,3 +230,9 @@ def test_directory_flow_from_geotiff_tiles(tmp_path):
         process_manager.DEBUG = False
     for key in ('elev', 'uca', 'aspect', 'slope', 'twi'):
         assert np.array_equal(compact0[key], compact1[key], equal_nan=True), key
+    # export (reference save_geotiff :862-931) and read back
+    out = str(tmp_path / 'uca.tif')
+    pm1.save_geotiff(out, 'uca', 'float32')
+    ds = raster.read_geotiff(out)
+    assert ds.array.dtype == np.float32 and np.array_equal(ds.array, compact1['uca'].astype('float32'), equal_nan=True)
+    assert ds.is_projected and abs(ds.bounds[0] - pm1.index[:, 0].min()) < 1e-9 and abs(ds.bounds[3] - pm1.index[:, 3].max()) < 1e-9
