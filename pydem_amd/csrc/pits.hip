@@ -3,13 +3,15 @@
 // Replaces _mk_connectivity_pits (reference pydem/dem_processing.py:1269-1382) with its helpers
 // utils.get_border_index (pydem/utils.py:313-340) and _get_dX_mean (:1993-1997).  The reference
 // walks the pits one by one in Python (402 k border recomputations with np.setdiff1d at 1024^2);
-// each pit is independent of the others, so here one WAVEFRONT owns one pit: the growing region
-// and its border live as bitmaps over a 64x64 cell window in LDS (a region can grow by at most one
-// cell of Chebyshev radius per iteration), lanes scan their slice of the window, minima are
-// wave-reduced with shuffles, and border updates use LDS atomics.  Pits whose region leaves the
-// window (or with too many drains) are re-run by a whole WORKGROUP with a 640x640 window -- large
-// enough for drain_pits_max_iter <= 300 always.  Integer work (which cells drain where) is exact;
-// weights use numpy's pairwise summation order so they match the reference bit for bit.
+// each pit is independent of the others, so they are solved in parallel in four tiers of growing
+// window / border capacity (a region can grow by at most one cell of Chebyshev radius per iteration):
+// a LANE per pit (16x16 window, 89 % of the pits), a WAVEFRONT per pit (128x128, then 256x256 for
+// plateau terrain) and a WORKGROUP per pit with a 640x640 bitmap window -- large enough for
+// drain_pits_max_iter <= 300 always.  Region and border live in LDS (bitmap + unordered border list),
+// minima are lane-serial / DPP reductions, border updates use LDS atomics.  Integer work (which cells
+// drain where) is exact; weights use numpy's pairwise summation order so they match the reference
+// bit for bit.  The raw (pit, drain, weight) triplets are then filtered like _mk_adjacency_matrix
+// (:1136-1137) and radix-sorted into the two side lists of the implicit graph.
 #include "internal.h"
 #include <hipcub/hipcub.hpp>
 #include <math.h>

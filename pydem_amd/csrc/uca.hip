@@ -8,15 +8,19 @@
 //       :1136-1137, so a cell's regular in-edges are one bit per 8-neighbour (`inmask`); the few
 //       non-adjacent pit->drain edges live in a small side list (PitGraph).
 //   K5  _calc_uca_chunk :864-987 + the native loop cyutils._drain_area (pydem/cyfuncs/cyutils.pyx
-//       :119-187): level-synchronous topological sweep.  The reference pushes area[i]*w along
-//       out-edges and re-scans all N cells four times per round; here each frontier cell PULLS
-//       a0 + sum(area[u]*w(u->c)) over its in-edges in a fixed order (no floating-point atomics,
-//       so results are run-to-run deterministic) and then decrements its targets' in-degree;
-//       the next frontier is compacted with a wavefront ballot/popcount prefix and one atomic
-//       per wave.  On a DAG both formulations compute the same fixed point; only the order of
-//       the additions differs (<= a few ulp; tolerance 1e-6 relative per BASELINE.json).
+//       :119-187): topological sweep.  The reference pushes area[i]*w along out-edges and re-scans
+//       all N cells four times per round; here each cell PULLS a0 + sum(area[u]*w(u->c)) over its
+//       in-edges in a fixed order (no floating-point atomics, so results are run-to-run
+//       deterministic).  Default schedule: tile passes (K5b) -- one wavefront per 32x32 tile runs
+//       as many level-synchronous rounds as it can on its CU, tiles are re-listed when a finished
+//       cell drains into them.  Alternative (PYDEM_SWEEP_MODE=queue): frontier queue rounds with a
+//       level-ownership hand-off instead of in-degree atomics.  On a DAG all formulations compute
+//       the same fixed point; only the order of the additions differs from the reference's push
+//       (<= a few ulp; tolerance 1e-6 relative per BASELINE.json).
+//   K7  edge-resolution rounds: calc_uca(uca_init=, edge_init_data=) :724-771 (count-based Kahn on
+//       the cells downstream of the seeds).
 //   K6  calc_twi :1647-1677.
-// Everything here is bounded by HBM (or by launch/atomic latency in the sweep's long tail).
+// The pointwise kernels are bounded by HBM; the sweeps by dependent memory latency times the tiles / cells in flight.
 #include "internal.h"
 #include <math.h>
 #include <stdlib.h>
