@@ -427,19 +427,26 @@ int64_t oracle_pit_edges(const double *elev, uint8_t *flats, double *mag, int64_
         double epit_border = epit;
         if (min_border) {                                           /* :1294-1295 */
             epit_border = INFINITY;
-            for (int64_t t = 0; t < nb; t++) if (elev[border[t]] < epit_border) epit_border = elev[border[t]];
+            for (int64_t t = 0; t < nb; t++) {
+                if (isnan(elev[border[t]])) { epit_border = NAN; break; }        /* np.min propagates NaN */
+                if (elev[border[t]] < epit_border) epit_border = elev[border[t]];
+            }
         }
         for (int64_t it = 0; it < max_iter; it++) {                  /* :1300 */
             if (nb == 0) break;                                      /* :1304-1305 */
             qsort(border, nb, sizeof(int64_t), i64_cmp);             /* setdiff1d is sorted */
             double emin = INFINITY, emin_np = INFINITY, emin_p = INFINITY;
-            int has_np = 0, has_p = 0;
+            int has_np = 0, has_p = 0, has_nan = 0;
             for (int64_t t = 0; t < nb; t++) {
                 double e = elev[border[t]];
+                if (isnan(e)) has_nan = 1;               /* a nodata cell is never a pit (elev > 0 is False) */
                 if (e < emin) emin = e;
                 if (pits_bool[border[t]]) { has_p = 1; if (e < emin_p) emin_p = e; }
                 else { has_np = 1; if (e < emin_np) emin_np = e; }
             }
+            /* numpy's min propagates NaN: with a nodata cell on the border `eborder_nopits.min() < epit_border` and
+               `eborder == emin` are False for every cell -- no non-pit drain, no growth (the loop idles to max_iter) */
+            if (has_nan) { emin = NAN; emin_np = NAN; }
             if (has_np && emin_np < epit_border) {                   /* :1312-1316 */
                 ndrain = 0;
                 for (int64_t t = 0; t < nb; t++)

@@ -253,9 +253,25 @@ def main():
     quant = np.rint(synth.fractal(64, 64, seed=9, top_shift=5, n_octaves=5, zrange=60.0)).astype(np.float64)
     cases.append(('g5_quant_f64_pits', quant, 10.0, 10.0, dict(fill_flats=False, drain_pits_path=False)))
 
+    # G4 with nodata: NaN lake, NaN block on the tile edge, isolated NaN cells (how the reference treats missing data
+    # in the stencil, the flats, the graph, the pit search and the edge flags)
+    frn = synth.fractal(72, 96, seed=11, top_shift=5, n_octaves=5)
+    rng = np.random.default_rng(11)
+    frn[20:34, 30:52] = np.nan
+    frn[0:9, 70:] = np.nan
+    for _ in range(25):
+        frn[rng.integers(0, 72), rng.integers(0, 96)] = np.nan
+    cases.append(('g4_fractal_nan_pits', frn, 30.0, 30.0, dict(fill_flats=False, drain_pits_path=False)))
+    cases.append(('g4_fractal_nan_nopits', frn, 30.0, 30.0, dict(fill_flats=False, drain_pits=False, drain_pits_path=False)))
+    if '--only-nan' in sys.argv:
+        cases = [c for c in cases if 'nan' in c[0]]
+
     for name, elev, dX, dY, kw in cases:
         rec = run_case(elev, dX, dY, **kw)
         save(name, rec, kw)
+    if '--only-nan' in sys.argv:
+        write_manifest()
+        return
 
     edge_cases()
     conditioning_cases()

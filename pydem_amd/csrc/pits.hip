@@ -342,8 +342,7 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
         if (flag[0]) break;                                                      // left the window
         const int w_first = flag[2] * WPR, w_last = (flag[3] + 1) * WPR;         // rows that hold border / region bits
         // --- scan the border: minima of all / non-pit / pit cells
-        double mn = INFINITY, mn_np = INFINITY, mn_p = INFINITY;
-        int any = 0;
+        double mn = INFINITY, mn_np = INFINITY, mn_p = INFINITY, nan_mark = 1.0;
         for (int w = w_first + gl; w < w_last; w += NT) {
             uint32_t b = border[w];
             while (b) {
@@ -351,7 +350,7 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
                 const int r = w / WPR, c = (w % WPR) * 32 + k;
                 const int64_t cell = (int64_t)(r0 + r) * m + (c0 + c);
                 const double e = P.elev[cell];
-                any = 1;
+                if (e != e) nan_mark = -1.0;
                 mn = fmin(mn, e);
                 if (P.pitmask[cell]) mn_p = fmin(mn_p, e); else mn_np = fmin(mn_np, e);
             }
@@ -359,11 +358,13 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
         mn = group_min<NT>(mn, redd, gl);
         mn_np = group_min<NT>(mn_np, redd, gl);
         mn_p = group_min<NT>(mn_p, redd, gl);
-        (void)any;
-        if (mn == INFINITY) break;                                               // empty border (:1304-1305)
+        // numpy's min propagates NaN: with a nodata cell on the border there is no non-pit drain and no growth
+        const bool has_nan = group_min<NT>(nan_mark, redd, gl) < 0;
+        if (mn == INFINITY && !has_nan) break;                                   // empty border (:1304-1305)
         int mode = 0;                                                            // 1: non-pit drains, 2: pit drains
-        if (mn_np < epit_border) mode = 1;                                       // :1312-1316
+        if (!has_nan && mn_np < epit_border) mode = 1;                           // :1312-1316
         else if (mn_p < epit) mode = 2;                                          // :1317-1320
+        if (!mode && has_nan) break;
         if (mode) {
             // collect drains in ascending cell order (window scan order == ascending id)
             int cnt = 0;
@@ -532,7 +533,7 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
     const double epit = P.elev[pit];
     double epit_border = epit;
     int nb = 0, nh = 0, n_alive = 0;        // list end / free slots below it / live entries (wave-uniform)
-    bool has_np = false, has_p = false;
+    bool has_np = false, has_p = false, has_nan = false;
     int over = 0;                           // 1: left the window, 2: list capacity, 3: drain capacity
     // the unseen neighbours of the nq cells in L.u.pq join the border
     auto expand = [&](int nq) {
@@ -573,6 +574,7 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
             }
             if (__ballot(isnew && pm && e < epit)) has_p = true;
             if (__ballot(isnew && !pm && e < epit_border)) has_np = true;
+            if (__ballot(isnew && e != e)) has_nan = true;                       // nodata on the border (see below)
             nh -= cnt - fresh; nb += fresh; n_alive += cnt;
         }
         wave_sync();
@@ -595,6 +597,8 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
     for (int it = 0; it < P.max_iter; it++) {                                    // :1300
         if (over) break;
         if (n_alive == 0) break;                                                 // :1304-1305
+        // numpy's min propagates NaN: with a nodata cell on the border there is no non-pit drain and no growth
+        if (has_nan) { if (has_p) mode = 2; break; }
         if (has_np) { mode = 1; break; }                                         // :1312-1316
         if (has_p) { mode = 2; break; }                                          // :1317-1320
         it_used = it + 1;
@@ -751,7 +755,7 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
     uint8_t *const lp = s_p + tid, *const lq = s_q + tid;
     uint32_t *const seen = s_seen + tid;
     // per-lane state of the pit in progress
-    bool running = false, over = false, has_np = false, has_p = false;
+    bool running = false, over = false, has_np = false, has_p = false, has_nan = false;
     int pending = 0;            // growth has ended: 1 / 2 drain mode, 3 no drain, 4 hand over; the lane waits for the next batch
     int32_t pit = 0;
     int r0 = 0, c0 = 0, ipit = 0, jpit = 0, nb = 0, it = 0;
@@ -786,6 +790,7 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
             if (pos8[k] < 0) continue;
             if (nb == LN_B) { over = true; continue; }
             le[nb * LN_T] = e8[k]; lp[nb * LN_T] = (uint8_t)pos8[k];
+            if (e8[k] != e8[k]) has_nan = true;          // nodata on the border: see the drain rules below
             if (pm8[k]) { pitbits |= 1u << nb; if (e8[k] < epit) has_p = true; }
             else { pitbits &= ~(1u << nb); if (e8[k] < epit_border) has_np = true; }
             nb++;
@@ -822,7 +827,7 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
                 epit = P.elev[pit];
                 epit_border = epit;
                 nb = 0; pitbits = 0; it = 0;
-                has_np = false; has_p = false; over = false;
+                has_np = false; has_p = false; has_nan = false; over = false;
                 {                                                                // pit_area = [pit] (:1289-1292)
                     const int pos = (ipit - r0) * LN_W + (jpit - c0);
                     seen[(pos >> 5) * LN_T] = 1u << (pos & 31);
@@ -847,6 +852,9 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
         if (running && !pending) {
             if (over) pending = 4;
             else if (it >= P.max_iter || nb == 0) pending = 3;                   // :1300, :1304-1305
+            // numpy's min propagates NaN: with a nodata cell on the border neither `eborder_nopits.min() < epit_border`
+            // nor `eborder == emin` can hold -- no non-pit drain, no growth; only a lower pit cell can still drain it
+            else if (has_nan) pending = has_p ? 2 : 3;
             else if (has_np) pending = 1;                                        // :1312-1316
             else if (has_p) pending = 2;                                         // :1317-1320
             else {

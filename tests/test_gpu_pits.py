@@ -115,3 +115,31 @@ def test_hip_pits_vs_oracle_plateau_terrain_2048():
     _check_pits(dp, o.pit_i, o.pit_j, o.pit_prop)
     assert dp.timings['n_pits_undrained'] == o.n_warn
     _close(dp.uca, o.uca, 'uca')
+
+
+@pytest.mark.parametrize('seed', [52, 53])
+def test_hip_pits_with_nodata_vs_oracle(seed):
+    """NaN (nodata) cells: a lake, a block on the tile edge, isolated cells.  numpy's min propagates NaN, so a pit whose
+    border touches nodata can only drain into a lower PIT cell and its region stops growing (pinned for the oracle by
+    the g4_fractal_nan_* goldens of the reference); every tier of the device solver must follow."""
+    from oracle import oracle as O
+    from pydem_amd import DEMProcessor, synth
+    import warnings
+    n, m = 300, 420
+    z = synth.fractal(n, m, seed=seed, top_shift=6, n_octaves=6)
+    rng = np.random.default_rng(seed)
+    z[40:90, 100:180] = np.nan
+    z[0:30, 300:] = np.nan
+    for _ in range(40):
+        z[rng.integers(0, n), rng.integers(0, m)] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        o = O.OracleDEM(z, dX=30.0, dY=30.0, drain_pits=True)
+        o.calc_twi()
+        dp = DEMProcessor(elev=z, dX=30.0, dY=30.0, fill_flats=False, drain_pits_path=False, drain_pits=True)
+        twi = dp.calc_twi()
+    _check_pits(dp, o.pit_i, o.pit_j, o.pit_prop)
+    assert dp.timings['n_pits_undrained'] == o.n_warn
+    assert np.array_equal(dp.section, o.section) and np.array_equal(dp.flats, o.flats.astype(bool))
+    _close(dp.mag, o.mag, 'mag'); _close(dp.uca, o.uca, 'uca'); _close(twi, o.twi / 10, 'twi')
+    assert np.array_equal(dp.edge_todo, o.edge_todo) and np.array_equal(dp.edge_done, o.edge_done)
