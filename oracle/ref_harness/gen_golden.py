@@ -263,8 +263,16 @@ def main():
         frn[rng.integers(0, 72), rng.integers(0, 96)] = np.nan
     cases.append(('g4_fractal_nan_pits', frn, 30.0, 30.0, dict(fill_flats=False, drain_pits_path=False)))
     cases.append(('g4_fractal_nan_nopits', frn, 30.0, 30.0, dict(fill_flats=False, drain_pits=False, drain_pits_path=False)))
+    # sea: large areas at exactly 0 (SRTM oceans), a trench below 0 -- `elev > 0` gates the pit search (:1284) and the
+    # flat filling (:565), so these cells stay flats
+    sea = synth.fractal(80, 96, seed=13, top_shift=5, n_octaves=5, zrange=400.0) - 150.0
+    sea[sea < 0] = 0.0
+    sea[50:56, 10:40] = -12.5
+    cases.append(('g4_fractal_sea_pits', sea, 30.0, 30.0, dict(fill_flats=False, drain_pits_path=False)))
+    sea16 = np.rint(sea).astype(np.int16)
+    cases.append(('g5_int16_sea_defaults', sea16, 30.0, 30.0, dict()))
     if '--only-nan' in sys.argv:
-        cases = [c for c in cases if 'nan' in c[0]]
+        cases = [c for c in cases if 'nan' in c[0] or 'sea' in c[0]]
 
     for name, elev, dX, dY, kw in cases:
         rec = run_case(elev, dX, dY, **kw)
