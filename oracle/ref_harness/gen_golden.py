@@ -271,8 +271,22 @@ def main():
     cases.append(('g4_fractal_sea_pits', sea, 30.0, 30.0, dict(fill_flats=False, drain_pits_path=False)))
     sea16 = np.rint(sea).astype(np.int16)
     cases.append(('g5_int16_sea_defaults', sea16, 30.0, 30.0, dict()))
+    # non-default options (every trait of DEMProcessor that changes a number on this path, :105-154)
+    qz = np.rint(synth.fractal(72, 88, seed=17, top_shift=5, n_octaves=5, zrange=90.0)).astype(np.float64)
+    base = dict(fill_flats=False, drain_pits_path=False)
+    for nm, kw in (('minborder', dict(drain_pits_min_border=True)),
+                   ('shortreach', dict(drain_pits_max_iter=5, drain_pits_max_dist=3)),
+                   ('xyreach', dict(drain_pits_max_dist_XY=70.0)),
+                   ('ucalimit', dict(apply_uca_limit_edges=True, uca_saturation_limit=2.0)),
+                   ('twilimits', dict(apply_twi_limits=True, apply_twi_limits_on_uca=True, twi_min_slope=0.01, uca_saturation_limit=4.0))):
+        k2 = dict(base); k2.update(kw)
+        cases.append(('g5_opt_' + nm, qz, 10.0, 12.0, k2))
+    qi = np.rint(synth.fractal(64, 72, seed=19, top_shift=5, n_octaves=5, zrange=50.0) - 8.0).astype(np.int16)
+    cases.append(('g5_opt_cond_a', qi, 30.0, 30.0, dict(maximum_pit_area=4, fill_flats_source_tol=0, fill_flats_peaks=False)))
+    cases.append(('g5_opt_cond_b', qi, 30.0, 30.0, dict(fill_flats_pits=False, fill_flats_below_sea=True, drain_pits_max_iter=8,
+                                                        drain_pits_max_dist=4)))
     if '--only-nan' in sys.argv:
-        cases = [c for c in cases if 'nan' in c[0] or 'sea' in c[0]]
+        cases = [c for c in cases if 'nan' in c[0] or 'sea' in c[0] or '_opt_' in c[0]]
 
     for name, elev, dX, dY, kw in cases:
         rec = run_case(elev, dX, dY, **kw)

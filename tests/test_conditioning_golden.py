@@ -19,17 +19,21 @@ def test_conditioning_matches_reference(name):
     g = load_golden(name)
     kw = g['kwargs']
     elev = g['in_elev'].copy()
+    sea = kw.get('fill_flats_below_sea', False)
     if kw.get('fill_flats', True):
-        art = conditioning.fill_pit_artifacts(elev, kw.get('maximum_pit_area', 32.0))
-        assert art.dtype == g['elev_artifacts'].dtype
-        assert np.array_equal(art, g['elev_artifacts'])
-        filled = conditioning.fill_flats(elev, kw.get('maximum_pit_area', 32.0))
+        if kw.get('maximum_pit_area', 32.0):
+            art = conditioning.fill_pit_artifacts(elev, kw.get('maximum_pit_area', 32.0), sea)
+            assert art.dtype == g['elev_artifacts'].dtype
+            assert np.array_equal(art, g['elev_artifacts'])
+        filled = conditioning.fill_flats(elev, kw.get('maximum_pit_area', 32.0), sea, kw.get('fill_flats_source_tol', 1),
+                                         kw.get('fill_flats_peaks', True), kw.get('fill_flats_pits', True))
         assert np.array_equal(filled, g['elev_filled'], equal_nan=True)
         elev = filled
     if kw.get('drain_pits_path', True):
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            out, _, _ = conditioning.pit_drain_paths(np.array(elev), g['in_dX'], g['in_dY'])
+            out, _, _ = conditioning.pit_drain_paths(np.array(elev), g['in_dX'], g['in_dY'], kw.get('drain_pits_max_iter', 300),
+                                                     kw.get('drain_pits_max_dist', 32), kw.get('drain_pits_max_dist_XY', None), sea)
         assert out.dtype == g['elev_drained'].dtype
         assert np.array_equal(out, g['elev_drained'], equal_nan=True)
 

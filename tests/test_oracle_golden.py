@@ -15,8 +15,10 @@ from oracle import oracle as O
 
 def _run(g):
     kw = g['kwargs']
+    import inspect
+    known = set(inspect.signature(O.OracleDEM.__init__).parameters)
     o = O.OracleDEM(g['elev_final'], dX=g['in_dX'], dY=g['in_dY'], dX2=g['in_dX2'], dY2=g['in_dY2'],
-                    drain_pits=kw.get('drain_pits', True))
+                    **{k: v for k, v in kw.items() if k in known})
     o.calc_slopes_directions()
     return o
 
@@ -36,7 +38,9 @@ def test_oracle_matches_reference(name):
     if 'pit_i' in g:
         ref = sorted(zip(g['pit_i'].tolist(), g['pit_j'].tolist(), g['pit_prop'].tolist()))
         mine = sorted(zip(o.pit_i.tolist(), o.pit_j.tolist(), o.pit_prop.tolist()))
-        assert ref == mine
+        assert [r[:2] for r in ref] == [x[:2] for x in mine]
+        # (weights can be NaN: with drain_pits_min_border a pit may drain to a cell of its own height, s = 0 / 0)
+        assert np.array_equal([r[2] for r in ref], [x[2] for x in mine], equal_nan=True)
     for a, b in zip(o.A, (g['A_indptr'], g['A_indices'], g['A_data'])):
         assert np.array_equal(a, b)
     assert np.array_equal(o.mag, g['mag_final'])
