@@ -49,7 +49,8 @@ enum pydem_field {
     PYDEM_FIELD_COUNT = 10
 };
 
-/* element types accepted by pydem_tile_upload for PYDEM_ELEV (converted to float64 on device) */
+/* element types accepted by pydem_tile_upload for PYDEM_ELEV (held as float64 on the device; a PYDEM_F32 elevation
+ * keeps the reference's float32 subtraction of elevations, dem_processing.py:1958-1962 / :1361) */
 enum pydem_dtype { PYDEM_F64 = 0, PYDEM_F32 = 1, PYDEM_I16 = 2, PYDEM_I32 = 3, PYDEM_U8 = 4, PYDEM_I8 = 5 };
 
 /* options of the hot path; names and defaults follow the DEMProcessor traits

@@ -35,6 +35,7 @@ def lib():
     if _LIB is None:
         L = C.CDLL(build())
         L.oracle_free.argtypes = [C.c_void_p]
+        L.oracle_set_elev_f32.argtypes = [C.c_int]
         L.oracle_slopes_directions.argtypes = [_f64p, C.c_int64, C.c_int64, _f64p, _f64p, _f64p, _f64p]
         L.oracle_flats_edges.argtypes = [_f64p, _f64p, _f64p, C.c_int64, C.c_int64, _u8p]
         L.oracle_section_proportion.argtypes = [_f64p, _u8p, C.c_int64, C.c_int64, _f64p, _f64p, _i8p, _f64p]
@@ -98,7 +99,9 @@ def slopes_directions(elev, dX, dY):
     n, m = elev.shape
     e = np.ascontiguousarray(elev, np.float64)
     mag = np.empty((n, m)); direction = np.empty((n, m))
+    lib().oracle_set_elev_f32(int(np.asarray(elev).dtype == np.float32))     # float32 DEMs subtract in float32
     rc = lib().oracle_slopes_directions(e, n, m, dX, dY, mag, direction)
+    lib().oracle_set_elev_f32(0)
     assert rc == 0
     return mag, direction
 
@@ -123,10 +126,12 @@ def pit_edges(elev, flats, mag, dX, dY, max_iter=300, max_dist=32, max_dist_XY=N
     n, m = elev.shape
     pi, pj, pp = C.c_void_p(), C.c_void_p(), C.c_void_p()
     nwarn = C.c_int64(0)
+    lib().oracle_set_elev_f32(int(np.asarray(elev).dtype == np.float32))
     cnt = lib().oracle_pit_edges(np.ascontiguousarray(elev, np.float64), flats, mag, n, m, dX, dY,
                                  max_iter, max_dist or 0,
                                  float('nan') if not max_dist_XY else float(max_dist_XY), int(min_border),
                                  C.byref(pi), C.byref(pj), C.byref(pp), C.byref(nwarn))
+    lib().oracle_set_elev_f32(0)
     assert cnt >= 0
     return _take(pi, cnt, np.int64), _take(pj, cnt, np.int64), _take(pp, cnt, np.float64), nwarn.value
 
@@ -210,6 +215,7 @@ class OracleDEM(object):
                  drain_pits_min_border=False, circular_ref_maxcount=50, apply_uca_limit_edges=False,
                  uca_saturation_limit=32.0, twi_min_slope=1e-3, apply_twi_limits=False,
                  apply_twi_limits_on_uca=False):
+        self.elev_in = np.asarray(elev)               # keeps the dtype: float32 DEMs subtract in float32
         self.elev = np.ascontiguousarray(elev, np.float64)
         self.dX, self.dY, self.dX2, self.dY2 = spacing_arrays(elev.shape[0], dX, dY, dX2, dY2)
         self.opt = dict(drain_pits=drain_pits, max_iter=drain_pits_max_iter, max_dist=drain_pits_max_dist,
@@ -221,7 +227,7 @@ class OracleDEM(object):
         self.mag = self.direction = self.flats = self.uca = None
 
     def calc_slopes_directions(self):
-        self.mag, self.direction = slopes_directions(self.elev, self.dX, self.dY)
+        self.mag, self.direction = slopes_directions(self.elev_in, self.dX, self.dY)
         self.mag_raw, self.direction_raw = self.mag.copy(), self.direction.copy()
         self.flats = flats_edges(self.elev, self.mag, self.direction)
         return self.mag, self.direction
@@ -231,7 +237,7 @@ class OracleDEM(object):
         self.section, self.proportion = section_proportion(self.direction, self.flats, self.dX, self.dY)
         if o['drain_pits']:
             self.pit_i, self.pit_j, self.pit_prop, self.n_warn = pit_edges(
-                self.elev, self.flats, self.mag, self.dX, self.dY, o['max_iter'], o['max_dist'],
+                self.elev_in, self.flats, self.mag, self.dX, self.dY, o['max_iter'], o['max_dist'],
                 o['max_dist_XY'], o['min_border'])
         else:
             self.pit_i = self.pit_j = self.pit_prop = None

@@ -115,14 +115,26 @@ static double *row_theta_table(const double *dX, const double *dY, int64_t n)
 }
 #define spacing_row(dX, dY, k, i, d1, d2, th) do { spacing_row_raw(dX, dY, k, i, d1, d2); *(th) = TH[(k) * n + (i)]; } while (0)
 
+/* Elevation dtype of the tile being restated.  numpy subtracts a float32 DEM in float32 (`data[slc0] - data[slc1]`,
+ * :1958-1962; `e[pit] - e[drain]`, :1361) and only the division by the float64 spacing promotes; the oracle holds the
+ * values as doubles (exact), so the float32 case rounds each difference to float32.  Integer DEMs subtract exactly
+ * unless the difference leaves the integer type's range (numpy wraps; not restated -- see DESIGN.md). */
+static int g_elev_f32 = 0;
+void oracle_set_elev_f32(int on) { g_elev_f32 = on != 0; }
+static double zsub(double a, double b)
+{
+    if (g_elev_f32) return (double)((float)a - (float)b);
+    return a - b;
+}
+
 /* _calc_direction for one cell and one facet (:1954-1989). */
 static void facet_update(double z0, double z1, double z2, double d1, double d2, double theta, int k,
                          double *mag, double *dir)
 {
-    double s1 = (z0 - z1) / d1;                  /* :1958 */
-    double s2 = (z1 - z2) / d2;                  /* :1959 */
+    double s1 = zsub(z0, z1) / d1;                  /* :1958 */
+    double s2 = zsub(z1, z2) / d2;                  /* :1959 */
     double s1_2 = s1 * s1;                       /* :1960 */
-    double sd = (z0 - z2) / sqrt(d1 * d1 + d2 * d2); /* :1962 */
+    double sd = zsub(z0, z2) / sqrt(d1 * d1 + d2 * d2); /* :1962 */
     double r = atan2(s2, s1);                    /* :1963 */
     double rad2 = s1_2 + s2 * s2;                /* :1964 */
     int b_s1_lte0 = s1 <= 0, b_s2_lte0 = s2 <= 0, b_s1_gt0 = s1 > 0, b_s2_gt0 = s2 > 0;
@@ -511,7 +523,7 @@ int64_t oracle_pit_edges(const double *elev, uint8_t *flats, double *mag, int64_
             if (!keep) { warn++; continue; }
             ndrain = keep;
         }
-        for (int64_t t = 0; t < ndrain; t++) s[t] = fabs(elev[pit] - elev[drain[t]]) / dxy[t];  /* :1361 */
+        for (int64_t t = 0; t < ndrain; t++) s[t] = fabs(zsub(elev[pit], elev[drain[t]])) / dxy[t];  /* :1361 */
         double ssum = np_pairwise_sum(s, ndrain);
         if (nout + ndrain >= cap_o) {
             while (nout + ndrain >= cap_o) cap_o *= 2;

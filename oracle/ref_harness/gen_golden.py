@@ -285,13 +285,26 @@ def main():
     cases.append(('g5_opt_cond_a', qi, 30.0, 30.0, dict(maximum_pit_area=4, fill_flats_source_tol=0, fill_flats_peaks=False)))
     cases.append(('g5_opt_cond_b', qi, 30.0, 30.0, dict(fill_flats_pits=False, fill_flats_below_sea=True, drain_pits_max_iter=8,
                                                         drain_pits_max_dist=4)))
+    # float32 DEMs (what most GeoTIFF DEMs are): with the conditioning off numpy subtracts elevations in float32 and only
+    # the division by the float64 spacing promotes (:1958-1962, :1361); drain_pits_path edits the float32 surface in place
+    # (:543-544); fill_flats converts to float64 first (:561)
+    # (low, rough relief around zero: neighbours differ by more than a factor two, where a float32 difference is inexact)
+    f32 = (synth.fractal(80, 104, seed=23, top_shift=3, n_octaves=4, zmin=-1.5, zrange=37.7) + 0.123456789).astype(np.float32)
+    cases.append(('g5_f32_pits', f32, 29.7, 31.3, dict(fill_flats=False, drain_pits_path=False)))
+    cases.append(('g5_f32_nopits', f32, 29.7, 31.3, dict(fill_flats=False, drain_pits=False, drain_pits_path=False)))
+    cases.append(('g5_f32_pathonly', f32, 29.7, 31.3, dict(fill_flats=False)))
+    cases.append(('g5_f32_defaults', f32, 29.7, 31.3, dict()))
+    i32 = np.rint(synth.fractal(64, 80, seed=29, top_shift=5, n_octaves=5, zrange=70000.0)).astype(np.int32)
+    cases.append(('g5_int32_pits', i32, 30.0, 30.0, dict(fill_flats=False, drain_pits_path=False)))
     if '--only-nan' in sys.argv:
         cases = [c for c in cases if 'nan' in c[0] or 'sea' in c[0] or '_opt_' in c[0]]
+    if '--only-f32' in sys.argv:
+        cases = [c for c in cases if '_f32_' in c[0] or '_int32_' in c[0]]
 
     for name, elev, dX, dY, kw in cases:
         rec = run_case(elev, dX, dY, **kw)
         save(name, rec, kw)
-    if '--only-nan' in sys.argv:
+    if '--only-nan' in sys.argv or '--only-f32' in sys.argv:
         write_manifest()
         return
 

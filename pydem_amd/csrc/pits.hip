@@ -92,6 +92,7 @@ struct PitParams {
     uint8_t *flats;             // patched: flats[pit] = False   (:1371)
     int n, m;
     int max_iter, max_dist, min_border;
+    int elev_f32;               // float32 DEM: |e[pit]-e[drain]| is a float32 subtraction in the reference (:1361)
     double max_dist_XY;         // NaN = None
     // raw output triplets (pit, drain, weight), appended per pit in ascending drain order
     int32_t *out_src, *out_dst; double *out_w;
@@ -104,6 +105,12 @@ struct PitParams {
     int32_t *dbg;               // PYDEM_PITS_DEBUG=2: per-pit {rounds, last border size, hand-over reason, drains}
     unsigned long long *prof;   // PYDEM_PITS_DEBUG=3: cycles per phase of the lane pass
 };
+
+__device__ __forceinline__ double pit_drop(const PitParams &P, double epit, double edrain)
+{
+    if (P.elev_f32) return (double)fabsf((float)epit - (float)edrain);
+    return fabs(epit - edrain);
+}
 
 // group = the threads that own one pit: a wavefront (NT = 64) or a whole workgroup (NT = 256)
 template <int NT>
@@ -188,7 +195,7 @@ __device__ void finish_pit(const PitParams &P, int32_t pit, int ipit, int jpit, 
     }
     if (nd == 0) { atomicAdd(&P.out_count[1], 1); }
     else {
-        for (int t = 0; t < nd; t++) sv[t] = fabs(epit - P.elev[dlist[t]]) / dxy[t];   // :1361
+        for (int t = 0; t < nd; t++) sv[t] = pit_drop(P, epit, P.elev[dlist[t]]) / dxy[t];   // :1361
         const double ssum = np_pairwise_sum(sv, nd, stk);
         // output slots come in chunks (one global atomic per ~30 pits instead of one per pit: 3.5 M
         // atomics on a single address cost ~40 ms); unused slots keep src = -1 and are dropped later
@@ -261,7 +268,7 @@ __device__ __forceinline__ void finish_pit_wave(const PitParams &P, int32_t pit,
     }
     if (nd == 0) { if (lane == 0) atomicAdd(&P.out_count[1], 1); return; }
     double s = 0.0;
-    if (live) { s = fabs(epit - P.elev[cell]) / d; sv[lane] = s; }           // :1361
+    if (live) { s = pit_drop(P, epit, P.elev[cell]) / d; sv[lane] = s; }           // :1361
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     double ssum = 0.0;
@@ -920,7 +927,7 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
                     const double dy = np_pairwise_leaf15(P.dY + a, b - a);
                     const double d = sqrt(dx * dx + dy * dy);
                     if (xy && !(d <= P.max_dist_XY)) continue;                   // :1352-1358
-                    le[keep * LN_T] = fabs(epit - le[t * LN_T]) / d;             // :1361
+                    le[keep * LN_T] = pit_drop(P, epit, le[t * LN_T]) / d;             // :1361
                     lp[keep * LN_T] = (uint8_t)pos;
                     keep++;
                 }
@@ -1157,6 +1164,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         P.elev = t->elev; P.pitmask = t->flat0; P.dX = t->dX; P.dY = t->dY; P.mag = t->mag; P.flats = t->flats;
         P.n = n; P.m = m; P.max_iter = opt->drain_pits_max_iter; P.max_dist = opt->drain_pits_max_dist;
         P.min_border = opt->drain_pits_min_border; P.max_dist_XY = opt->drain_pits_max_dist_XY;
+        P.elev_f32 = t->elev_f32 ? 1 : 0;
         P.out_src = t->pits.raw_src; P.out_dst = t->pits.raw_dst; P.out_w = t->pits.raw_w;
         P.out_count = cnt + 1; P.out_cap = (int32_t)(t->pits.raw_cap < INT32_MAX ? t->pits.raw_cap : INT32_MAX);
         P.overflow_list = t->labels; P.overflow_count = cnt + 3;

@@ -136,23 +136,35 @@ __device__ __forceinline__ double div_row(double x, double d, double r)
     return __builtin_fma(rem, r, q);
 }
 
+// elevation difference in the dtype the reference subtracts in: numpy keeps a float32 DEM float32 through
+// `data[slc0] - data[slc1]` and only the division by the float64 spacing promotes (_calc_direction :1958-1962), so a
+// float32 tile (uploaded PYDEM_F32, conditioning off) rounds every difference to 24 bits first.  The casts are exact
+// (the device copy holds the float32 values), RN subtraction is sign-symmetric in either width.
+template <bool F32>
+__device__ __forceinline__ double zsub(double a, double b)
+{
+    if (F32) return (double)((float)a - (float)b);
+    return a - b;
+}
+
 // all 8 facets of an interior cell.  tn = spacing row i-1 (facets 0-3), ts = row i (facets 4-7)
 // (_get_d1_d2 :1912-1924: facets 0,3,4,7 use d1 = dX, d2 = dY; facets 1,2,5,6 d1 = dY, d2 = dX)
+template <bool F32>
 __device__ __forceinline__ void eight_facets(double z0, double zN, double zS, double zE, double zW,
                                              double zNE, double zNW, double zSW, double zSE,
                                              const RowTab &tn, const RowTab &ts, Best &b)
 {
-    const double sdNE = (z0 - zNE) / tn.hyp, sdNW = (z0 - zNW) / tn.hyp;
-    const double sdSW = (z0 - zSW) / ts.hyp, sdSE = (z0 - zSE) / ts.hyp;
-    const double s1N = (z0 - zN) / tn.dY, s1S = (z0 - zS) / ts.dY;
-    facet((z0 - zE) / tn.dX, (zE - zNE) / tn.dY, sdNE, tn.dX, tn.dY, tn.thA, 0, b);
-    facet(s1N, (zN - zNE) / tn.dX, sdNE, tn.dY, tn.dX, tn.thB, 1, b);
-    facet(s1N, (zN - zNW) / tn.dX, sdNW, tn.dY, tn.dX, tn.thB, 2, b);
-    facet((z0 - zW) / tn.dX, (zW - zNW) / tn.dY, sdNW, tn.dX, tn.dY, tn.thA, 3, b);
-    facet((z0 - zW) / ts.dX, (zW - zSW) / ts.dY, sdSW, ts.dX, ts.dY, ts.thA, 4, b);
-    facet(s1S, (zS - zSW) / ts.dX, sdSW, ts.dY, ts.dX, ts.thB, 5, b);
-    facet(s1S, (zS - zSE) / ts.dX, sdSE, ts.dY, ts.dX, ts.thB, 6, b);
-    facet((z0 - zE) / ts.dX, (zE - zSE) / ts.dY, sdSE, ts.dX, ts.dY, ts.thA, 7, b);
+    const double sdNE = zsub<F32>(z0, zNE) / tn.hyp, sdNW = zsub<F32>(z0, zNW) / tn.hyp;
+    const double sdSW = zsub<F32>(z0, zSW) / ts.hyp, sdSE = zsub<F32>(z0, zSE) / ts.hyp;
+    const double s1N = zsub<F32>(z0, zN) / tn.dY, s1S = zsub<F32>(z0, zS) / ts.dY;
+    facet(zsub<F32>(z0, zE) / tn.dX, zsub<F32>(zE, zNE) / tn.dY, sdNE, tn.dX, tn.dY, tn.thA, 0, b);
+    facet(s1N, zsub<F32>(zN, zNE) / tn.dX, sdNE, tn.dY, tn.dX, tn.thB, 1, b);
+    facet(s1N, zsub<F32>(zN, zNW) / tn.dX, sdNW, tn.dY, tn.dX, tn.thB, 2, b);
+    facet(zsub<F32>(z0, zW) / tn.dX, zsub<F32>(zW, zNW) / tn.dY, sdNW, tn.dX, tn.dY, tn.thA, 3, b);
+    facet(zsub<F32>(z0, zW) / ts.dX, zsub<F32>(zW, zSW) / ts.dY, sdSW, ts.dX, ts.dY, ts.thA, 4, b);
+    facet(s1S, zsub<F32>(zS, zSW) / ts.dX, sdSW, ts.dY, ts.dX, ts.thB, 5, b);
+    facet(s1S, zsub<F32>(zS, zSE) / ts.dX, sdSE, ts.dY, ts.dX, ts.thB, 6, b);
+    facet(zsub<F32>(z0, zE) / ts.dX, zsub<F32>(zE, zSE) / ts.dY, sdSE, ts.dX, ts.dY, ts.thA, 7, b);
 }
 
 __device__ __forceinline__ Best best_init()
@@ -168,7 +180,7 @@ __device__ __forceinline__ Best best_init()
 // remapped to tile (b % 8) * tiles_per_xcd + b / 8: each XCD walks a contiguous band of tiles
 // and neighbouring tiles share halo lines in the same L2.
 // ---------------------------------------------------------------------------------------------
-template <bool XCD_SWIZZLE>
+template <bool XCD_SWIZZLE, bool F32>
 __global__ __launch_bounds__(256) void k_stencil_interior(const double *__restrict__ elev, int n, int m,
                                                           const RowTab *__restrict__ rowtab,
                                                           double *__restrict__ mag, double *__restrict__ dir,
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(256) void k_stencil_interior(const double *__restri
         if (i >= 1 && i < n - 1 && j >= 1 && j < m - 1) {
             const RowTab tn = rowtab[i - 1], ts = rowtab[i];
             Best b = best_init();
-            eight_facets(c0, a0, b0, cE, cW, aE, aW, bW, bE, tn, ts, b);
+            eight_facets<F32>(c0, a0, b0, cE, cW, aE, aW, bW, bE, tn, ts, b);
             const size_t c = (size_t)i * m + j;
             mag[c] = b.rad2 > 0 ? sqrt(b.rad2) : b.rad2;           // :1901
             dir[c] = winner_direction(b);
@@ -248,6 +260,7 @@ __device__ __forceinline__ double lane_next(double x)    // value held by lane+1
 
 constexpr int MARCH_ROWS = 128;   // output rows per wavefront on large tiles (fewer on small ones: the chip wants >= ~10 k wavefronts)
 
+template <bool F32>
 __global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict__ elev, int n, int m,
                                                        const RowTab *__restrict__ rowtab,
                                                        double *__restrict__ mag, double *__restrict__ dir,
@@ -269,12 +282,12 @@ __global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict_
     // quantities of the rows already in the window, as if they had entered one by one
     double zE0 = lane_next(z0), zW0 = lane_prev(z0);
     const RowTab t0 = rowtab[i0 - 1];
-    double hEs_N = div_row(zN - lane_next(zN), t0.dX, t0.rdX);   // E-edge of row i-1 over its south spacing dX[i-1]
-    double hEn_0 = div_row(z0 - zE0, t0.dX, t0.rdX);             // E-edge of row i over its north spacing dX[i-1]
-    double v_N = div_row(zN - z0, t0.dY, t0.rdY);                // vertical edge (i-1) -> i
-    double dSE_N = div_row(zN - zE0, t0.hyp, t0.rhyp);           // diagonal (i-1,j) -> (i,j+1)
-    double dSW_N = div_row(zN - zW0, t0.hyp, t0.rhyp);           // diagonal (i-1,j) -> (i,j-1)
-    double hEs_0 = (i0 <= n - 2) ? div_row(z0 - zE0, rowtab[i0].dX, rowtab[i0].rdX) : 0.0;   // E-edge of row i over its south spacing dX[i]
+    double hEs_N = div_row(zsub<F32>(zN, lane_next(zN)), t0.dX, t0.rdX);   // E-edge of row i-1 over its south spacing dX[i-1]
+    double hEn_0 = div_row(zsub<F32>(z0, zE0), t0.dX, t0.rdX);             // E-edge of row i over its north spacing dX[i-1]
+    double v_N = div_row(zsub<F32>(zN, z0), t0.dY, t0.rdY);                // vertical edge (i-1) -> i
+    double dSE_N = div_row(zsub<F32>(zN, zE0), t0.hyp, t0.rhyp);           // diagonal (i-1,j) -> (i,j+1)
+    double dSW_N = div_row(zsub<F32>(zN, zW0), t0.hyp, t0.rhyp);           // diagonal (i-1,j) -> (i,j-1)
+    double hEs_0 = (i0 <= n - 2) ? div_row(zsub<F32>(z0, zE0), rowtab[i0].dX, rowtab[i0].rdX) : 0.0;   // E-edge of row i over its south spacing dX[i]
     // neighbours' copies
     double hEs_N_L = lane_prev(hEs_N), dSE_N_L = lane_prev(dSE_N), v_N_L = lane_prev(v_N), v_N_R = lane_next(v_N);
     double dSW_N_R = lane_next(dSW_N), hEn_0_L = lane_prev(hEn_0), hEs_0_L = lane_prev(hEs_0);
@@ -284,11 +297,11 @@ __global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict_
         // ---- row i+1 enters
         const double zS = col[(size_t)(i + 1) * m];
         const double zES = lane_next(zS), zWS = lane_prev(zS);
-        const double hEn_S = div_row(zS - zES, ts.dX, ts.rdX);   // E-edge of row i+1 over its north spacing dX[i]
-        const double v_0 = div_row(z0 - zS, ts.dY, ts.rdY);      // vertical edge i -> i+1
-        const double dSE_0 = div_row(z0 - zES, ts.hyp, ts.rhyp);
-        const double dSW_0 = div_row(z0 - zWS, ts.hyp, ts.rhyp);
-        const double hEs_S = (i + 1 <= n - 2) ? div_row(zS - zES, rowtab[i + 1].dX, rowtab[i + 1].rdX) : 0.0;
+        const double hEn_S = div_row(zsub<F32>(zS, zES), ts.dX, ts.rdX);   // E-edge of row i+1 over its north spacing dX[i]
+        const double v_0 = div_row(zsub<F32>(z0, zS), ts.dY, ts.rdY);      // vertical edge i -> i+1
+        const double dSE_0 = div_row(zsub<F32>(z0, zES), ts.hyp, ts.rhyp);
+        const double dSW_0 = div_row(zsub<F32>(z0, zWS), ts.hyp, ts.rhyp);
+        const double hEs_S = (i + 1 <= n - 2) ? div_row(zsub<F32>(zS, zES), rowtab[i + 1].dX, rowtab[i + 1].rdX) : 0.0;
         const double hEn_S_L = lane_prev(hEn_S), v_0_L = lane_prev(v_0), v_0_R = lane_next(v_0);
         const double dSE_0_L = lane_prev(dSE_0), dSW_0_R = lane_next(dSW_0), hEs_S_L = lane_prev(hEs_S);
         // ---- the 8 facets of cell (i, j)
@@ -344,6 +357,7 @@ __global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict_
 // ---------------------------------------------------------------------------------------------
 // perimeter kernel: one thread per edge/corner cell (dem_processing.py:1779-1899).
 // ---------------------------------------------------------------------------------------------
+template <bool F32>
 __device__ void interior_cell(const double *elev, int n, int m, const RowTab *rowtab, int i, int j,
                               double &rad2, double &d)
 {
@@ -353,12 +367,13 @@ __device__ void interior_cell(const double *elev, int n, int m, const RowTab *ro
     if (i < 1 || i > n - 2 || j < 1 || j > m - 2) return;
     const double *r0 = elev + (size_t)(i - 1) * m + j, *r1 = r0 + m, *r2 = r1 + m;
     Best b = best_init();
-    eight_facets(r1[0], r0[0], r2[0], r1[1], r1[-1], r0[1], r0[-1], r2[-1], r2[1], rowtab[i - 1], rowtab[i], b);
+    eight_facets<F32>(r1[0], r0[0], r2[0], r1[1], r1[-1], r0[1], r0[-1], r2[-1], r2[1], rowtab[i - 1], rowtab[i], b);
     rad2 = b.rad2; d = winner_direction(b);
 }
 
 // one facet of an edge cell; mode 0: per-row spacing (left/right edges, topbot == None),
 // mode 1: fixed spacing row `sr` ('top' -> 0, 'bot' -> n-2) (:1925-1934)
+template <bool F32>
 __device__ void edge_facet(const double *elev, int n, int m, const RowTab *rowtab, int i, int j, int k,
                            int mode, int sr, Best &b)
 {
@@ -371,9 +386,10 @@ __device__ void edge_facet(const double *elev, int n, int m, const RowTab *rowta
     const double z0 = elev[(size_t)i * m + j];
     const double z1 = elev[(size_t)(i + fe1r(k)) * m + (j + fe1c(k))];
     const double z2 = elev[(size_t)(i + fe2r(k)) * m + (j + fe2c(k))];
-    facet((z0 - z1) / d1, (z1 - z2) / d2, (z0 - z2) / t.hyp, d1, d2, th, k, b);
+    facet(zsub<F32>(z0, z1) / d1, zsub<F32>(z1, z2) / d2, zsub<F32>(z0, z2) / t.hyp, d1, d2, th, k, b);
 }
 
+template <bool F32>
 __global__ void k_stencil_perimeter(const double *__restrict__ elev, int n, int m,
                                     const RowTab *__restrict__ rowtab,
                                     double *__restrict__ mag, double *__restrict__ dir, uint8_t *__restrict__ flat0)
@@ -395,7 +411,7 @@ __global__ void k_stencil_perimeter(const double *__restrict__ elev, int n, int 
     const bool top = (i == 0), bot = (i == n - 1), left = (j == 0), right = (j == m - 1);
     if ((left || right) && !top && !bot) {
         double r2, dd;
-        interior_cell(elev, n, m, rowtab, i, left ? 1 : m - 2, r2, dd);
+        interior_cell<F32>(elev, n, m, rowtab, i, left ? 1 : m - 2, r2, dd);
         const bool take = left ? (dd > HP && dd < P32) : (dd < HP || dd > P32);
         if (take) { rad2 = r2; d = dd; }
     } else {
@@ -405,11 +421,11 @@ __global__ void k_stencil_perimeter(const double *__restrict__ elev, int n, int 
         double r2 = -1.0, dd = -1.0;
         if (left || right) {
             double r3, d3;
-            interior_cell(elev, n, m, rowtab, ii, left ? 1 : m - 2, r3, d3);
+            interior_cell<F32>(elev, n, m, rowtab, ii, left ? 1 : m - 2, r3, d3);
             const bool take1 = left ? (d3 > HP && d3 < P32) : (d3 < HP || d3 > P32);
             if (take1) { r2 = r3; dd = d3; }
         } else {
-            interior_cell(elev, n, m, rowtab, ii, j, r2, dd);
+            interior_cell<F32>(elev, n, m, rowtab, ii, j, r2, dd);
         }
         const bool take = top ? (dd > 0 && dd < PI_D) : (dd > PI_D && dd < TWOPI);
         if (take) { rad2 = r2; d = dd; }
@@ -420,14 +436,14 @@ __global__ void k_stencil_perimeter(const double *__restrict__ elev, int n, int 
     int copied = (rad2 > -1.0) || (d != -1.0);
     (void)copied;
     const int sr = top ? 0 : n - 2;
-    if (top && left) { edge_facet(elev, n, m, rowtab, i, j, 6, 1, sr, b); edge_facet(elev, n, m, rowtab, i, j, 7, 1, sr, b); }
-    else if (top && right) { edge_facet(elev, n, m, rowtab, i, j, 4, 1, sr, b); edge_facet(elev, n, m, rowtab, i, j, 5, 1, sr, b); }
-    else if (bot && left) { edge_facet(elev, n, m, rowtab, i, j, 0, 1, sr, b); edge_facet(elev, n, m, rowtab, i, j, 1, 1, sr, b); }
-    else if (bot && right) { edge_facet(elev, n, m, rowtab, i, j, 2, 1, sr, b); edge_facet(elev, n, m, rowtab, i, j, 3, 1, sr, b); }
-    else if (left) { const int ks[4] = {0, 1, 6, 7}; for (int q = 0; q < 4; q++) edge_facet(elev, n, m, rowtab, i, j, ks[q], 0, 0, b); }
-    else if (right) { const int ks[4] = {2, 3, 4, 5}; for (int q = 0; q < 4; q++) edge_facet(elev, n, m, rowtab, i, j, ks[q], 0, 0, b); }
-    else if (top) { const int ks[4] = {4, 5, 6, 7}; for (int q = 0; q < 4; q++) edge_facet(elev, n, m, rowtab, i, j, ks[q], 1, sr, b); }
-    else { const int ks[4] = {0, 1, 2, 3}; for (int q = 0; q < 4; q++) edge_facet(elev, n, m, rowtab, i, j, ks[q], 1, sr, b); }
+    if (top && left) { edge_facet<F32>(elev, n, m, rowtab, i, j, 6, 1, sr, b); edge_facet<F32>(elev, n, m, rowtab, i, j, 7, 1, sr, b); }
+    else if (top && right) { edge_facet<F32>(elev, n, m, rowtab, i, j, 4, 1, sr, b); edge_facet<F32>(elev, n, m, rowtab, i, j, 5, 1, sr, b); }
+    else if (bot && left) { edge_facet<F32>(elev, n, m, rowtab, i, j, 0, 1, sr, b); edge_facet<F32>(elev, n, m, rowtab, i, j, 1, 1, sr, b); }
+    else if (bot && right) { edge_facet<F32>(elev, n, m, rowtab, i, j, 2, 1, sr, b); edge_facet<F32>(elev, n, m, rowtab, i, j, 3, 1, sr, b); }
+    else if (left) { const int ks[4] = {0, 1, 6, 7}; for (int q = 0; q < 4; q++) edge_facet<F32>(elev, n, m, rowtab, i, j, ks[q], 0, 0, b); }
+    else if (right) { const int ks[4] = {2, 3, 4, 5}; for (int q = 0; q < 4; q++) edge_facet<F32>(elev, n, m, rowtab, i, j, ks[q], 0, 0, b); }
+    else if (top) { const int ks[4] = {4, 5, 6, 7}; for (int q = 0; q < 4; q++) edge_facet<F32>(elev, n, m, rowtab, i, j, ks[q], 1, sr, b); }
+    else { const int ks[4] = {0, 1, 2, 3}; for (int q = 0; q < 4; q++) edge_facet<F32>(elev, n, m, rowtab, i, j, ks[q], 1, sr, b); }
     const double dout = (b.k >= 0) ? winner_direction(b) : d;   // no facet beat the copied value
     const size_t c = (size_t)i * m + j;
     mag[c] = b.rad2 > 0 ? sqrt(b.rad2) : b.rad2;
@@ -441,8 +457,12 @@ int launch_interior(pydem_tile *t)
     const int tiles_x = (int)cdiv(t->m, TX), tiles_y = (int)cdiv(t->n, TY);
     const int total = tiles_x * tiles_y;
     const int grid = SW ? ((total + 7) / 8) * 8 : total;
-    hipLaunchKernelGGL(k_stencil_interior<SW>, dim3(grid), dim3(256), 0, t->stream, t->elev, (int)t->n, (int)t->m,
-                       t->rowtab, t->mag, t->dir, t->flat0, tiles_x, total);
+    if (t->elev_f32)
+        hipLaunchKernelGGL((k_stencil_interior<SW, true>), dim3(grid), dim3(256), 0, t->stream, t->elev, (int)t->n, (int)t->m,
+                           t->rowtab, t->mag, t->dir, t->flat0, tiles_x, total);
+    else
+        hipLaunchKernelGGL((k_stencil_interior<SW, false>), dim3(grid), dim3(256), 0, t->stream, t->elev, (int)t->n, (int)t->m,
+                           t->rowtab, t->mag, t->dir, t->flat0, tiles_x, total);
     return 0;
 }
 
@@ -463,8 +483,12 @@ static void launch_stencil(pydem_tile *t)
     while (rows > 16 && (int64_t)strips * cdiv(t->n - 2, rows) < 12288) rows >>= 1;
     const int chunks = (int)cdiv(t->n - 2, rows);
     const int waves = strips * chunks;
-    hipLaunchKernelGGL(k_stencil_march, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, t->stream, t->elev, (int)t->n, (int)t->m,
-                       t->rowtab, t->mag, t->dir, t->flat0, strips, chunks, rows);
+    if (t->elev_f32)
+        hipLaunchKernelGGL(k_stencil_march<true>, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, t->stream, t->elev, (int)t->n, (int)t->m,
+                           t->rowtab, t->mag, t->dir, t->flat0, strips, chunks, rows);
+    else
+        hipLaunchKernelGGL(k_stencil_march<false>, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, t->stream, t->elev, (int)t->n, (int)t->m,
+                           t->rowtab, t->mag, t->dir, t->flat0, strips, chunks, rows);
 }
 
 int stage_stencil(pydem_tile *t)
@@ -473,8 +497,12 @@ int stage_stencil(pydem_tile *t)
     launch_stencil(t);
     HIP_TRY(hipEventRecord(t->ev[1], t->stream));
     const int64_t nper = 2 * t->m + 2 * (t->n - 2);
-    hipLaunchKernelGGL(k_stencil_perimeter, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, t->elev,
-                       (int)t->n, (int)t->m, t->rowtab, t->mag, t->dir, t->flat0);
+    if (t->elev_f32)
+        hipLaunchKernelGGL(k_stencil_perimeter<true>, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, t->elev,
+                           (int)t->n, (int)t->m, t->rowtab, t->mag, t->dir, t->flat0);
+    else
+        hipLaunchKernelGGL(k_stencil_perimeter<false>, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, t->elev,
+                           (int)t->n, (int)t->m, t->rowtab, t->mag, t->dir, t->flat0);
     HIP_TRY(hipEventRecord(t->ev[2], t->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventSynchronize(t->ev[2]));

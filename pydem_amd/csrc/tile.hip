@@ -245,6 +245,7 @@ int pydem_tile_upload(pydem_tile *t, int field, const void *src, int dtype)
         HIP_TRY(hipStreamSynchronize(t->stream));
     }
     t->have[field] = true;
+    if (field == PYDEM_ELEV) t->elev_f32 = (dtype == PYDEM_F32);
     if (field == PYDEM_ELEV || field == PYDEM_MAG || field == PYDEM_DIRECTION || field == PYDEM_FLATS) t->graph_valid = false;
     return 0;
 }
@@ -358,6 +359,7 @@ int pydem_tile_synth_fractal(pydem_tile *t, uint32_t seed, int64_t row0, int64_t
     PYDEM_TRY(ensure_field(t, PYDEM_ELEV));
     PYDEM_TRY(stage_synth(t, seed, row0, col0, n_octaves, top_shift, zmin, zrange));
     t->have[PYDEM_ELEV] = true;
+    t->elev_f32 = false;
     for (int f = PYDEM_MAG; f < PYDEM_FIELD_COUNT; f++) t->have[f] = false;
     return 0;
 }
