@@ -575,25 +575,28 @@ constexpr int TT = 32, HW = TT + 2;
 // sp half-word of a cell: bits 14-15 state (0 open, 1 final / outside, 2 finished in this pass), bit 13 "waits for
 // a cell another tile must finish", bits 0-12 upstream cells of this tile that are still open
 constexpr uint32_t SP_STATE_SHIFT = 14, SP_BLOCKED = 1u << 13;
-constexpr int TILE_RING = 512;  // ready-list ring (a push that does not fit is dropped: the cell stays open with a zero
+constexpr int TILE_RING = 256;  // ready-list ring (a push that does not fit is dropped: the cell stays open with a zero
                                 // count, the tile lists itself and the next pass picks the cell up in its setup)
 
 struct TileW {
-    uint16_t sp[HW * HW + 2];   // state and open-upstream count (16-bit halves of 32-bit words: LDS atomics work on the words)
-    uint16_t ci[HW * HW];       // static graph bits
-    uint16_t list[TILE_RING];   // ready cells in the order they became ready
-    double a0[TT];              // cell area of the tile's rows
-    int tail;                   // list end (monotonic; slot = index % TILE_RING)
-    int limit;                  // first list index whose push was dropped (INT_MAX: none): the pass stops there
-};
+    uint32_t cs[TT * TT];           // per cell of the tile: high half = static graph bits, low half = sp (state / blocked / open-upstream
+                                    // count); one LDS word per cell: a count-down is a plain 32-bit atomic, setup and rounds read both
+                                    // halves at once.  The halo ring only exists as bits of `fin`.
+    union {
+        unsigned long long fin[HW]; // staging and setup: bit lj of row li (halo coordinates) = the cell was final before this pass
+                                    // (or lies outside the grid)
+        double a0[TT];              // rounds: cell area of the tile's rows
+    };
+    uint16_t list[TILE_RING];       // ready cells in the order they became ready
+    int tail;                       // list end (monotonic; slot = index % TILE_RING)
+    int limit;                      // first list index whose push was dropped (INT_MAX: none): the pass stops there
+};                                  // 4888 bytes: eight 4-tile workgroups per CU
 
-// count-down of cell idx; returns the old half-word
-__device__ __forceinline__ uint32_t sp_dec(TileW &L, int idx)
-{
-    uint32_t *w = reinterpret_cast<uint32_t *>(L.sp) + (idx >> 1);
-    const int sh = (idx & 1) * 16;
-    return (atomicSub(w, 1u << sh) >> sh) & 0xFFFFu;
-}
+__device__ __forceinline__ uint16_t &sp_of(TileW &L, int idx) { return reinterpret_cast<uint16_t *>(L.cs)[2 * idx]; }
+__device__ __forceinline__ uint32_t sp_state(const TileW &L, int idx) { return (L.cs[idx] >> SP_STATE_SHIFT) & 3u; }
+
+// count-down of cell idx; returns the old half-word (a count that is decremented is >= 1: no borrow into the graph bits)
+__device__ __forceinline__ uint32_t sp_dec(TileW &L, int idx) { return atomicSub(&L.cs[idx], 1u) & 0xFFFFu; }
 
 __device__ __forceinline__ void tile_wave_sync()
 {
@@ -606,70 +609,102 @@ struct TileNext {            // LISTED passes: tiles that must run again in the 
     int32_t *list, *count;
 };
 
+// contribution of in-edge d (0..7 = NW N NE W E SW S SE, the order of the in-mask bits) into cell c: one 8-byte load,
+// the cardinal neighbours hand over their first share, the diagonal ones their second
+__device__ __forceinline__ const double *in_edge_ptr(const SweepArgs &A, int32_t c, int m, int d)
+{
+    const int q = d + (d >> 2);                   // 0..8 with the centre (4) skipped
+    const int di = (q * 11) >> 5;                 // q / 3
+    const int32_t u = c + (di - 1) * m + (q - 3 * di - 1);
+    return reinterpret_cast<const double *>(A.contrib + u) + (((0x5A >> d) & 1) ? 0 : 1);
+}
+__device__ __forceinline__ double in_edge(const SweepArgs &A, int32_t c, int m, int d) { return *in_edge_ptr(A, c, m, d); }
+
 template <bool LISTED>
 __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uint32_t pass, int tiles_x, int tid, int lane,
                                                uint8_t *__restrict__ tile_done, int32_t *n_final, const TileNext &N)
 {
     const int by = tid / tiles_x, bx = tid - by * tiles_x;
     const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
-    const int LOFF[8] = {-HW - 1, -HW, -HW + 1, -1, 1, HW - 1, HW, HW + 1};
+    const int half = lane >> 5, l32 = lane & 31;         // interior cell k of a lane: row 2k + half, column l32 of the tile
     // ready-list push; `consumed` = entries already processed (ring occupancy = tail - consumed)
     auto push_ready = [&](int cell, int consumed) {
         const int slot = atomicAdd(&L.tail, 1);
         if (slot - consumed < TILE_RING) L.list[slot % TILE_RING] = (uint16_t)cell;
         else atomicMin(&L.limit, slot);
     };
-    const bool prof = (A.dbg & 4) != 0;
+#ifdef PYDEM_TILE_PROF
+    const bool prof = (A.dbg & 4) != 0 && (int)pass >= (A.dbg >> 8);      // PYDEM_TILE_DEBUG = 4 + 256 * first pass to account
+#else
+    constexpr bool prof = false;       // (the phase timers cost registers: build with -DPYDEM_TILE_PROF to use PYDEM_TILE_DEBUG=4)
+#endif
     long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
     int nrounds = 0;
-    if (prof) tk0 = clock64();
-    // ---- stage the graph words of tile + halo, five loads of a lane in flight at a time (the passes are
-    // latency-bound: a load-use-load-use loop would cost 19 memory round trips, one batch of 19 too many registers)
-    constexpr int NSTG = (HW * HW + 63) / 64, STG_B = 5;
+    if (prof) tk0 = wall_clock64();
+    // ---- stage the graph words of tile + halo by rows (two 32-cell rows per wavefront load, the halo ring in three
+    // loads), a few loads of a lane in flight at a time: the passes are latency-bound.  The "final before this pass"
+    // bits come out of wave ballots, one 64-bit word per row.
     if (lane == 0) { L.tail = 0; L.limit = INT32_MAX; }
-    if (lane < TT) L.a0[lane] = i0 + lane < n ? A.a0[i0 + lane] : 0.0;
+    const double a0_row = (lane < TT && i0 + lane < n) ? A.a0[i0 + lane] : 0.0;       // lands in LDS once the final bitmap is no longer needed
+    auto stage_word = [&](int gi, int gj) -> uint32_t {                  // 0xFFFFFFFF: outside the grid
+        return (gi >= 0 && gi < n && gj >= 0 && gj < m) ? A.cinfo[(int64_t)gi * m + gj] : 0xFFFFFFFFu;
+    };
+    auto final_before = [&](uint32_t w) -> bool {                        // outside the grid: nothing drains from there
+        if (w == 0xFFFFFFFFu) return true;
+        const uint32_t lv = ci_level(w);
+        return lv >= 1 && lv < pass;
+    };
+    uint32_t colL, colR;
+    {
+        const uint32_t wc = stage_word(i0 + l32, half ? j0 + TT : j0 - 1);          // left / right halo column
+        const uint32_t wr = stage_word(half ? i0 + TT : i0 - 1, j0 + l32);          // top / bottom halo row
+        uint32_t wk = 0xFFFFFFFFu;
+        if (lane < 4) wk = stage_word((lane & 2) ? i0 + TT : i0 - 1, (lane & 1) ? j0 + TT : j0 - 1);   // corners
+        const bool fc = final_before(wc), fr = final_before(wr), fk = lane < 4 && final_before(wk);
+        const unsigned long long bc = __ballot(fc), br = __ballot(fr), bk = __ballot(fk);
+        colL = (uint32_t)bc; colR = (uint32_t)(bc >> 32);
+        if (lane == 0) {
+            L.fin[0] = ((br & 0xFFFFFFFFull) << 1) | (bk & 1ull) | (((bk >> 1) & 1ull) << 33);
+            L.fin[HW - 1] = ((br >> 32) << 1) | ((bk >> 2) & 1ull) | (((bk >> 3) & 1ull) << 33);
+        }
+    }
+    constexpr int NSET = TT * TT / 64, STG_B = 4;
 #pragma unroll 1
-    for (int kb = 0; kb < NSTG; kb += STG_B) {
+    for (int kb = 0; kb < NSET; kb += STG_B) {
         uint32_t wst[STG_B];
 #pragma unroll
-        for (int k = 0; k < STG_B; k++) {
-            const int idx = lane + 64 * (kb + k);
-            const int li = idx / HW, lj = idx - li * HW;
-            const int gi = i0 - 1 + li, gj = j0 - 1 + lj;
-            wst[k] = 0xFFFFFFFFu;                                          // marker: outside the grid
-            if (idx < HW * HW && gi >= 0 && gi < n && gj >= 0 && gj < m) wst[k] = A.cinfo[(int64_t)gi * m + gj];
-        }
+        for (int k = 0; k < STG_B; k++) wst[k] = stage_word(i0 + 2 * (kb + k) + half, j0 + l32);
 #pragma unroll
         for (int k = 0; k < STG_B; k++) {
-            const int idx = lane + 64 * (kb + k);
-            if (idx < HW * HW) {
-                uint32_t cw = wst[k], st = 1;                              // outside the grid: nothing drains from there
-                if (cw == 0xFFFFFFFFu) cw = 0;
-                else { const uint32_t lv = ci_level(cw); st = (lv >= 1 && lv < pass); }
-                L.ci[idx] = (uint16_t)(cw & CI_STATIC_MASK);
-                L.sp[idx] = (uint16_t)(st << SP_STATE_SHIFT);
+            const int r = 2 * (kb + k);                                  // this load: local rows r + 1 (lanes 0-31), r + 2
+            const bool f = final_before(wst[k]);
+            L.cs[lane + 64 * (kb + k)] = ((wst[k] == 0xFFFFFFFFu ? 0u : (wst[k] & CI_STATIC_MASK)) << 16) | ((f ? 1u : 0u) << SP_STATE_SHIFT);
+            const unsigned long long b = __ballot(f);
+            if (lane == 0) {
+                L.fin[r + 1] = ((b & 0xFFFFFFFFull) << 1) | ((colL >> r) & 1u) | ((unsigned long long)((colR >> r) & 1u) << 33);
+                L.fin[r + 2] = ((b >> 32) << 1) | ((colL >> (r + 1)) & 1u) | ((unsigned long long)((colR >> (r + 1)) & 1u) << 33);
             }
         }
     }
     tile_wave_sync();
-    if (prof) tk1 = clock64();
-    // ---- per-cell setup: how many upstream cells are still open.  First the neighbours (LDS only) ...
-    constexpr int NSET = TT * TT / 64;
+    if (prof) tk1 = wall_clock64();
+    // ---- per-cell setup: how many upstream cells are still open = in-mask bits whose neighbour is not final (three row
+    // words of the final bitmap, LDS broadcasts) ...
     uint32_t pitmask = 0;
-#pragma unroll 1
+    int32_t n_open = 0;
+#pragma unroll 2
     for (int k = 0; k < NSET; k++) {
-        const int cell = lane + 64 * k;
-        const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
-        const int gi = i0 + li - 1, gj = j0 + lj - 1;
-        if (gi < n && gj < m && !(L.sp[idx] >> SP_STATE_SHIFT)) {
-            const uint32_t cw = L.ci[idx];
-            uint32_t pend = 0;
-#pragma unroll
-            for (int d = 0; d < 8; d++)
-                if ((cw & (1u << d)) && !(L.sp[idx + LOFF[d]] >> SP_STATE_SHIFT)) pend++;
-            L.sp[idx] = (uint16_t)pend;                             // the state bits of an open cell are zero: the half-word is the count
-            if (cw & CI_PIT_IN) pitmask |= 1u << k;
-            else if (pend == 0) push_ready(cell, 0);
+        const int li = 2 * k + half + 1, idx = lane + 64 * k;
+        const uint32_t w = L.cs[idx];
+        if (!((w >> SP_STATE_SHIFT) & 3u)) {                        // open (cells outside the grid were staged as final)
+            const unsigned long long f0 = L.fin[li - 1], f1 = L.fin[li], f2 = L.fin[li + 1];
+            const uint32_t nf = ((uint32_t)(f0 >> l32) & 7u) | (((uint32_t)(f1 >> l32) & 1u) << 3) |
+                                (((uint32_t)(f1 >> (l32 + 2)) & 1u) << 4) | (((uint32_t)(f2 >> l32) & 7u) << 5);
+            const uint32_t pend = __popc((w >> 16) & 0xFFu & ~nf);
+            sp_of(L, idx) = (uint16_t)pend;                         // the state bits of an open cell are zero: the half-word is the count
+            n_open++;
+            if (w & (CI_PIT_IN << 16)) pitmask |= 1u << k;
+            else if (pend == 0) push_ready(lane + 64 * k, 0);
         }
     }
     // ... then the pit in-edges of the lane's drains: their list offsets in one batch, the edges two loads at a time
@@ -692,8 +727,8 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
                 if (!(pitmask & (1u << (kb + k)))) continue;
                 const int cell = lane + 64 * (kb + k);
                 const int32_t c = (i0 + (cell >> 5)) * m + j0 + (cell & 31);
-                const int idx = ((cell >> 5) + 1) * HW + (cell & 31) + 1;
-                uint32_t pend = L.sp[idx];
+                const int idx = cell;
+                uint32_t pend = sp_of(L, idx);
                 for (int32_t e = e0[k];; e += 2) {                  // pit -> drain edges are short: most sources sit in this tile
                     const int64_t ia = e < A.n_pit ? e : A.n_pit - 1, ib = e + 1 < A.n_pit ? e + 1 : A.n_pit - 1;
                     const int32_t da = A.pin_dst[ia], db = A.pin_dst[ib], sa = A.pin_src[ia], sb = A.pin_src[ib];
@@ -701,7 +736,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
                     auto blocked = [&](int32_t sc) -> uint32_t {
                         const int si = sc / m - i0, sj = sc % m - j0;
                         if (si >= 0 && si < TT && sj >= 0 && sj < TT)
-                            return (L.sp[(si + 1) * HW + sj + 1] >> SP_STATE_SHIFT) ? 0u : 1u;   // released on chip when the pit finishes
+                            return sp_state(L, si * TT + sj) ? 0u : 1u;          // released on chip when the pit finishes
                         const uint32_t lv = ci_level(A.cinfo[sc]);
                         return (lv >= 1 && lv < pass) ? 0u : SP_BLOCKED;                   // another tile's business: blocked for this pass
                     };
@@ -711,46 +746,69 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
                     pend = (pend + (ba & 1u) + (bb & 1u)) | ((ba | bb) & SP_BLOCKED);
                     if (!vb) break;
                 }
-                L.sp[idx] = (uint16_t)pend;
+                sp_of(L, idx) = (uint16_t)pend;
                 if (pend == 0) push_ready(cell, 0);
             }
         }
     }
     tile_wave_sync();
+    if (lane < TT) L.a0[lane] = a0_row;                  // (the final bitmap is dead now)
+    tile_wave_sync();
     // ---- rounds: the ready cells [head, tail) are processed, the targets they release are appended
-    if (prof) tk2 = clock64();
+    if (prof) tk2 = wall_clock64();
     int32_t finalized = 0;
+    uint32_t wake = 0;                 // bit (dti + 1) * 3 + dtj + 1: a finished cell drains into that neighbour tile
     int head = 0;
+    // A lane that finishes a cell and thereby makes one of its targets ready keeps that target for itself ("chain"):
+    // the next iteration needs neither the ready list (three dependent LDS operations) nor a load of the contribution it
+    // has just stored (a load behind a pending write-through store waits for the store's round trip) -- the share travels
+    // in a register.  Along a river this is the whole critical path of a tile visit.  Lanes without a chained cell take
+    // the next entries of the ready list.
+    int mycell = -1, cd = -1;          // the lane's cell (tile-local id), the in-edge (bit of the in-mask) the chained share arrives by
+    double cv = 0.0;                   // the chained share
     for (;;) {
         const int tail = L.tail < L.limit ? L.tail : L.limit;
-        if (head >= tail) break;
+        const bool need = mycell < 0;
+        const unsigned long long nb = __ballot(need);
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nb, 0u));
+        const int avail = tail - head, wanted = __popcll(nb);
+        if (need && rank < avail) { mycell = L.list[(head + rank) % TILE_RING]; cd = -1; }
+        head += wanted < avail ? wanted : avail;
+        if (!__ballot(mycell >= 0)) break;
         nrounds++;
-        for (int k = head + lane; k < tail; k += 64) {
-            const int cell = L.list[k % TILE_RING];
-            const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
+        int next = -1, nd = -1;
+        double nv = 0.0;
+        if (mycell >= 0) {
+            const int cell = mycell;
+            const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = cell;
             const int gi = i0 + li - 1, gj = j0 + lj - 1;
             const int32_t c = gi * m + gj;
-            const uint32_t cw = L.ci[idx];
-            // everything that only needs (c, cw): proportion, pit slots, the in-edge contributions
+            const uint32_t cw = L.cs[idx] >> 16;
+            // everything that only needs (c, cw): proportion, pit slots, the in-edge contributions (most cells have one
+            // or two in-edges: walk the set bits, in ascending order like the reference's pull, four loads in flight)
             double pv = 0.0;
             if (cw & (CI_OUT1 | CI_OUT2)) pv = A.prop[c];
             int2 po = make_int2(0, 0);
             if (cw & (CI_PIT_IN | CI_PIT_OUT)) po = pit_stash(A, c);
-            double x8[8];
+            uint32_t mm = cw & 0xFFu;
+            double xs[4];
 #pragma unroll
-            for (int d = 0; d < 8; d++) {
-                x8[d] = 0.0;
-                if (cw & (1u << d)) {
-                    const int32_t u = c + NB_DI[d] * m + NB_DJ[d];
-                    const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
-                    x8[d] = cardinal ? A.contrib[u].x : A.contrib[u].y;
+            for (int q = 0; q < 4; q++) {
+                xs[q] = 0.0;
+                if (mm) {
+                    const int d = __ffs(mm) - 1; mm &= mm - 1u;
+                    if (d == cd) xs[q] = cv; else xs[q] = in_edge(A, c, m, d);
                 }
             }
             double a = L.a0[li - 1];
             bool td = (gi == 0 || gi == n - 1 || gj == 0 || gj == m - 1) && A.todo_work[c] != 0;
 #pragma unroll
-            for (int d = 0; d < 8; d++)
-                if (cw & (1u << d)) { a += fabs(x8[d]); td = td || (x8[d] < 0); }
+            for (int q = 0; q < 4; q++) { a += fabs(xs[q]); td = td || (xs[q] < 0); }       // (+0.0 leaves the positive sum as it is)
+            while (mm) {                                                                    // five and more in-edges: rare
+                const int d = __ffs(mm) - 1; mm &= mm - 1u;
+                const double x = (d == cd) ? cv : in_edge(A, c, m, d);
+                a += fabs(x); td = td || (x < 0);
+            }
             if (cw & CI_PIT_IN)
                 for (int32_t e = po.x; e < A.n_pit && A.pin_dst[e] == c; e++) {
                     const int32_t sc = A.pin_src[e];
@@ -763,55 +821,70 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
             if (td) { o.x = -o.x; o.y = -o.y; }
             A.area[c] = a;
             A.contrib[c] = o;
+            if (LISTED) A.cinfo[c] = ci_with_level(cw, pass);        // finished in this pass (other tiles treat levels < their pass as final)
             if (td) A.todo_work[c] = 1;
-            L.sp[idx] = (uint16_t)(2u << SP_STATE_SHIFT);
+            sp_of(L, idx) = (uint16_t)(2u << SP_STATE_SHIFT);
             finalized++;
             // release the targets inside the tile; targets in other tiles may be ready now: their tiles run in the
             // next pass (listing a tile whose cell still waits for somebody else costs one idle staging; whoever
             // finishes last lists it again)
-            auto release = [&](int ti, int tj) {      // tile-local coordinates 1..TT when inside
+            auto release = [&](int ti, int tj, double share, bool chainable) {      // tile-local coordinates 1..TT when inside
                 if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT) {
-                    if (sp_dec(L, ti * HW + tj) == 1u) push_ready((ti - 1) * TT + (tj - 1), head);
+                    const int tcell = (ti - 1) * TT + (tj - 1);
+                    if (sp_dec(L, tcell) == 1u) {
+                        if (chainable && next < 0) {
+                            const int q = (li - ti + 1) * 3 + (lj - tj + 1);          // where this cell sits in the target's 3x3 window
+                            next = tcell; nd = q - (q > 4 ? 1 : 0); nv = share;
+                        } else push_ready(tcell, head);
+                    }
                 } else if (LISTED) {
-                    const int gti = i0 + ti - 1, gtj = j0 + tj - 1;
-                    if (gti < 0 || gti >= n || gtj < 0 || gtj >= m) return;
-                    const int tt = (gti / TT) * tiles_x + gtj / TT;
-                    if (atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tt;
+                    // (out-edges only exist towards cells of the grid.)  The eight neighbour tiles are woken once, after
+                    // the rounds: two dependent returning atomics per cell would sit on every round's critical path
+                    const int dti = ti < 1 ? -1 : (ti > TT ? 1 : 0), dtj = tj < 1 ? -1 : (tj > TT ? 1 : 0);
+                    if (ti >= 1 - TT && ti <= 2 * TT && tj >= 1 - TT && tj <= 2 * TT) wake |= 1u << ((dti + 1) * 3 + dtj + 1);
+                    else {                                            // a pit draining further away than the next tile
+                        const int tt = ((i0 + ti - 1) / TT) * tiles_x + (j0 + tj - 1) / TT;
+                        if (atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tt;
+                    }
                 }
             };
             const int sct = ci_section(cw);
-            if (cw & CI_OUT1) release(li + fe1r(sct), lj + fe1c(sct));
-            if (cw & CI_OUT2) release(li + fe2r(sct), lj + fe2c(sct));
+            if (cw & CI_OUT1) release(li + fe1r(sct), lj + fe1c(sct), o.x, true);
+            if (cw & CI_OUT2) release(li + fe2r(sct), lj + fe2c(sct), o.y, true);
             if (cw & CI_PIT_OUT)
                 for (int32_t e = po.y; e < A.n_pit && A.pit_src[e] == c; e++) {
                     const int32_t dc = A.pit_dst[e];
                     const int ti = dc / m - i0 + 1, tj = dc % m - j0 + 1;
                     // a drain inside the tile that an earlier pass already finished cannot exist (it waits for this pit)
-                    release(ti, tj);
+                    release(ti, tj, 0.0, false);
                 }
         }
-        head = tail;
+        mycell = next; cd = nd; cv = nv;
         tile_wave_sync();
     }
-    // ---- stamp what this pass finished (consecutive lanes own consecutive cells)
-    if (prof) tk3 = clock64();
-    int open_cells = 0;
-    for (int cell = lane; cell < TT * TT; cell += 64) {
-        const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = li * HW + lj;
-        const int gi = i0 + li - 1, gj = j0 + lj - 1;
-        if (gi >= n || gj >= m) continue;
-        const uint32_t st = L.sp[idx] >> SP_STATE_SHIFT;
-        if (st == 0) { open_cells = 1; continue; }
-        if (st != 2) continue;
-        A.cinfo[gi * m + gj] = ci_with_level(L.ci[idx], pass);
+    // ---- the tile is done when every cell that was open at setup has been finished.  A pass that revisits a tile
+    // finishes few cells and stamps their level as it goes; the first pass finishes most of the tile and stamps in rows
+    if (prof) tk3 = wall_clock64();
+    if (!LISTED)
+        for (int k = 0; k < NSET; k++) {
+            const int li = 2 * k + half + 1, idx = lane + 64 * k;
+            const uint32_t w = L.cs[idx];
+            if (((w >> SP_STATE_SHIFT) & 3u) == 2u) A.cinfo[(int64_t)(i0 + li - 1) * m + j0 + l32] = ci_with_level(w >> 16, pass);
+        }
+    for (int off = 32; off > 0; off >>= 1) { finalized += __shfl_down(finalized, off); n_open += __shfl_down(n_open, off); }
+    if (LISTED) {
+        for (int off = 32; off > 0; off >>= 1) wake |= __shfl_xor(wake, off);
+        if (lane < 9 && ((wake >> lane) & 1u)) {
+            const int tt = tid + (lane / 3 - 1) * tiles_x + (lane % 3 - 1);
+            if (atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tt;
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) { finalized += __shfl_down(finalized, off); open_cells |= __shfl_down(open_cells, off); }
     if (lane == 0) {
         if (finalized) atomicAdd(n_final, finalized);
-        if (!open_cells) tile_done[tid] = 1;
+        if (finalized == n_open) tile_done[tid] = 1;
         if (LISTED && L.limit != INT32_MAX && atomicExch(&N.flag[tid], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tid;
         if (prof) {      // cycles per phase, summed over tiles (PYDEM_TILE_DEBUG=4)
-            const long long tk4 = clock64();
+            const long long tk4 = wall_clock64();
             unsigned long long *acc = reinterpret_cast<unsigned long long *>(A.err + 1 + 16);   // counters[32..] region: see stage_sweep
             atomicAdd(acc + 0, (unsigned long long)(tk1 - tk0)); atomicAdd(acc + 1, (unsigned long long)(tk2 - tk1));
             atomicAdd(acc + 2, (unsigned long long)(tk3 - tk2)); atomicAdd(acc + 3, (unsigned long long)(tk4 - tk3));
@@ -825,11 +898,11 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
 // every tile that is not done yet, four tiles per workgroup, XCD-contiguous bands of tiles (LISTED: also
 // lists the tiles of the next pass)
 template <bool LISTED>
-__global__ __launch_bounds__(256, 6) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total,
+__global__ __launch_bounds__(256, 8) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total,
                                                      uint8_t *__restrict__ tile_done, int32_t *n_final, TileNext N)
 {
     __shared__ TileW L[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // workgroup b runs on XCD b % 8: give every XCD one contiguous band of tiles (gridDim.x is a multiple of 8)
     const int per = (gridDim.x >> 3) * 4;
     const int tid = (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + wave;
@@ -846,8 +919,10 @@ __global__ __launch_bounds__(256, 6) void k_sweep_tiles_listed(SweepArgs A, uint
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t nt = *n_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *clear_count = 0;      // the list of the pass after the next one
-    for (int32_t k = blockIdx.x * 4 + wave; k < nt; k += gridDim.x * 4)
-        sweep_one_tile<true>(A, L[wave], pass, tiles_x, list_in[k], lane, tile_done, n_final, N);
+    // (the tile id is the same for the whole wavefront: as a scalar it keeps the tile's coordinates and every address
+    // derived from them out of the vector registers)
+    for (int32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); k < nt; k += gridDim.x * 4)
+        sweep_one_tile<true>(A, L[wave], pass, tiles_x, __builtin_amdgcn_readfirstlane(list_in[k]), lane, tile_done, n_final, N);
 }
 
 // switch from queue rounds to listed tile passes: the tiles that hold the current frontier
@@ -1349,7 +1424,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     int32_t *cntT = t->counters + 56;          // rotating tile-list sizes
     HIP_TRY(hipMemsetAsync(tile_done, 0, tiles_pad * 5, t->stream));      // done bytes + stamps
     HIP_TRY(hipMemsetAsync(cntT, 0, 4 * sizeof(int32_t), t->stream));
-    if (A.dbg & 4) HIP_TRY(hipMemsetAsync(t->counters + 32, 0, 14 * sizeof(int32_t), t->stream));
+    if (A.dbg & 4) HIP_TRY(hipMemsetAsync(t->counters + 32, 0, 24 * sizeof(int32_t), t->stream));
     int64_t launches = 0;
     uint32_t pass = 0;
     int64_t done_prev = 0;
@@ -1400,7 +1475,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         HIP_TRY(hipStreamSynchronize(t->stream));
         if (A.dbg & 4) {
             const unsigned long long *acc = (const unsigned long long *)(t->h_counters + 32);
-            fprintf(stderr, "tile phases (cycles summed over %llu tile runs, %llu of them finished nothing): stage %llu, setup %llu, rounds %llu (%llu rounds), stamp %llu\n",
+            fprintf(stderr, "tile phases (10 ns ticks summed over %llu tile runs, %llu of them finished nothing): stage %llu, setup %llu, rounds %llu (%llu rounds), stamp %llu\n",
                     acc[5], acc[6], acc[0], acc[1], acc[2], acc[4], acc[3]);
         }
     }
