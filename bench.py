@@ -29,6 +29,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # the host driver only supports dmabuf IPC (RCCL across processes)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 STENCIL_BYTES_PER_CELL = 24.0
@@ -133,11 +134,18 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend='gloo', rank=rank, world_size=world)
         from pydem_amd import parallel
+        rccl = None
         try:
-            pm.transport = parallel.make_rccl_transport(pm, device, dist)
-            exchange = "rccl"
+            rccl = parallel.make_rccl_transport(pm, device, dist)
         except Exception as e:      # keep the scaling run alive and say so in the JSON line
-            sys.stderr.write("bench: RCCL transport unavailable (%s); falling back to gloo host strips\n" % e)
+            sys.stderr.write("bench: rank %d: RCCL transport unavailable (%s)\n" % (rank, e))
+        # every rank must take the same path: one failed communicator sends all of them to the host fallback
+        ok = [None] * world
+        dist.all_gather_object(ok, rccl is not None)
+        if all(ok):
+            pm.transport = rccl
+            exchange = "rccl"
+        else:
             pm.transport = parallel.DistTransport(pm, rank, world)
             exchange = "gloo-host-fallback"
     pm.compute_grid()

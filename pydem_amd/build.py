@@ -18,6 +18,7 @@ SOURCES = ['tile.hip', 'stencil.hip', 'flats.hip', 'uca.hip', 'pits.hip', 'synth
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-fno-fast-math',
          '-Wall', '-Wno-unused-function', '-Wno-unused-result']
+FLAGS += os.environ.get('PYDEM_HIPCC_FLAGS', '').split()     # kernel-tuning experiments (-D...), not part of the product build
 
 
 def _deps_mtime():

@@ -575,6 +575,9 @@ constexpr int TT = 32, HW = TT + 2;
 // sp half-word of a cell: bits 14-15 state (0 open, 1 final / outside, 2 finished in this pass), bit 13 "waits for
 // a cell another tile must finish", bits 0-12 upstream cells of this tile that are still open
 constexpr uint32_t SP_STATE_SHIFT = 14, SP_BLOCKED = 1u << 13;
+#ifndef PYDEM_STG_B
+#define PYDEM_STG_B 4
+#endif
 constexpr int TILE_RING = 256;  // ready-list ring (a push that does not fit is dropped: the cell stays open with a zero
                                 // count, the tile lists itself and the next pass picks the cell up in its setup)
 
@@ -668,7 +671,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
             L.fin[HW - 1] = ((br >> 32) << 1) | ((bk >> 2) & 1ull) | (((bk >> 3) & 1ull) << 33);
         }
     }
-    constexpr int NSET = TT * TT / 64, STG_B = 4;
+    constexpr int NSET = TT * TT / 64, STG_B = PYDEM_STG_B;
 #pragma unroll 1
     for (int kb = 0; kb < NSET; kb += STG_B) {
         uint32_t wst[STG_B];

@@ -1,2 +1,1 @@
-timeout 300 python -m pytest tests -m gpu -x -q -W ignore -k "sweep or parity or pits" 2>&1 | tail -2
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --kernel-trace -d gpurun_out/sw -o t --output-format csv -- python bench.py --steps 2 --warmup 0 --cpu-sample 0 > gpurun_out/sw.log 2>&1; python tools/sweep_passes.py gpurun_out/sw 2 > gpurun_out/sw_passes.txt; head -12 gpurun_out/sw_passes.txt; sed -n 30,32p gpurun_out/sw_passes.txt; tail -1 gpurun_out/sw_passes.txt
+PYDEM_PITS_DEBUG=2 python bench.py --steps 1 --warmup 0 --cpu-sample 0 2>&1 | grep "^pits"
