@@ -1,1 +1,2 @@
-PYDEM_PITS_DEBUG=2 python bench.py --steps 1 --warmup 0 --cpu-sample 0 2>&1 | grep "^pits"
+for th in 1024 256 64; do echo "threads $th"; PYDEM_EDGE_SMALL_THREADS=$th python tools/pm_multitile_timing.py 8192 4 2>&1 | grep "edge fix-up" | tail -1; done
+PYDEM_EDGE_DEBUG=1 python tools/pm_multitile_timing.py 8192 4 2>&1 | grep -i "edge" | head -30
