@@ -94,6 +94,21 @@ def main():
     run_pm_case('pm_fractal_2x2_ov2', fr, 2, 2, 2, nopath)
     run_pm_case('pm_fractal_2x3_ov1', fr, 2, 3, 1, nopath)
     run_pm_case('pm_fractal_2x2_ov1_nopits', fr, 2, 2, 1, dict(drain_pits_path=False, drain_pits=False))
+    if '--base-only' in sys.argv:
+        write_manifest()
+        return
+    # nodata and sea level across tile edges (NaN strips in the edge exchange, `elev > 0` gates)
+    frn = synth.fractal(64, 80, seed=31, top_shift=5, n_octaves=5, zrange=300.0) - 60.0
+    frn[frn < 0] = 0.0
+    frn[24:40, 30:46] = np.nan          # a nodata block that straddles the 2x2 tile cross
+    frn[0:6, 60:] = np.nan
+    run_pm_case('pm_nansea_2x2_ov2', frn, 2, 2, 2, nopath)
+    # float32 tiles, conditioning off: the tiles subtract elevations in float32 (dem_processing.py:1958-1962)
+    f32 = (synth.fractal(56, 64, seed=37, top_shift=3, n_octaves=4, zmin=-1.0, zrange=33.3) + 0.123456789).astype(np.float32)
+    run_pm_case('pm_f32_2x2_ov1', f32, 2, 2, 1, dict(fill_flats=False, drain_pits_path=False))
+    # quantised int16 tiles with the reference's default options (conditioning inside every tile)
+    q16 = np.rint(synth.fractal(48, 60, seed=41, top_shift=5, n_octaves=5, zrange=80.0)).astype(np.int16)
+    run_pm_case('pm_int16_defaults_2x2_ov2', q16, 2, 2, 2, {})
     write_manifest()
 
 
