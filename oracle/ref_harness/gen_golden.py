@@ -296,15 +296,35 @@ def main():
     cases.append(('g5_f32_defaults', f32, 29.7, 31.3, dict()))
     i32 = np.rint(synth.fractal(64, 80, seed=29, top_shift=5, n_octaves=5, zrange=70000.0)).astype(np.int32)
     cases.append(('g5_int32_pits', i32, 30.0, 30.0, dict(fill_flats=False, drain_pits_path=False)))
+    # degenerate tiles: the smallest legal tile, one-cell-wide interiors, constant / all-sea / all-nodata tiles, a
+    # checkerboard (every other cell a pit), one pit in a bowl, negative and very large elevations
+    rng = np.random.default_rng(3)
+    deg = {
+        'ramp3x3': np.arange(9, dtype=float).reshape(3, 3) + 1,
+        'ramp3x7': (np.arange(21, dtype=float).reshape(3, 7) % 5) + 1,
+        'ramp7x3': (np.arange(21, dtype=float).reshape(7, 3) % 4) + 1,
+        'const8': np.full((8, 8), 5.0),
+        'zeros6': np.zeros((6, 6)),
+        'allnan6': np.full((6, 6), np.nan),
+        'checker10': (np.indices((10, 10)).sum(0) % 2).astype(float) * 3 + 2,
+        'onepit9': np.maximum(np.abs(np.arange(9) - 4)[:, None], np.abs(np.arange(9) - 4)[None, :]).astype(float) + 1,
+        'neg8': -(rng.random((8, 8)) * 10 + 1),
+        'huge8': rng.random((8, 8)) * 1e12 + 1e13,
+    }
+    for nm, z in deg.items():
+        cases.append(('g5_deg_%s_pits' % nm, z, 2.0, 3.0, dict(fill_flats=False, drain_pits_path=False)))
+        cases.append(('g5_deg_%s_nopits' % nm, z, 2.0, 3.0, dict(fill_flats=False, drain_pits=False, drain_pits_path=False)))
     if '--only-nan' in sys.argv:
         cases = [c for c in cases if 'nan' in c[0] or 'sea' in c[0] or '_opt_' in c[0]]
+    if '--only-deg' in sys.argv:
+        cases = [c for c in cases if '_deg_' in c[0]]
     if '--only-f32' in sys.argv:
         cases = [c for c in cases if '_f32_' in c[0] or '_int32_' in c[0]]
 
     for name, elev, dX, dY, kw in cases:
         rec = run_case(elev, dX, dY, **kw)
         save(name, rec, kw)
-    if '--only-nan' in sys.argv or '--only-f32' in sys.argv:
+    if '--only-nan' in sys.argv or '--only-f32' in sys.argv or '--only-deg' in sys.argv:
         write_manifest()
         return
 
