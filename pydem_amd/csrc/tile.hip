@@ -145,6 +145,9 @@ int pydem_tile_create(int64_t n_rows, int64_t n_cols, int device, pydem_tile **o
     pydem_tile *t = new pydem_tile();
     t->n = n_rows; t->m = n_cols; t->NN = n_rows * n_cols; t->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
     for (int i = 0; i < 8; i++) HIP_TRY(hipEventCreate(&t->ev[i]));
     PYDEM_TRY(tile_alloc(t, &t->counters, 64));
     HIP_TRY(hipHostMalloc((void **)&t->h_counters, 64 * sizeof(int32_t), hipHostMallocDefault));
@@ -167,6 +170,9 @@ int pydem_tile_destroy(pydem_tile *t)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     for (int i = 0; i < 8; i++) if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
+    if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
+    if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+    if (t->stream2) { (void)hipStreamSynchronize(t->stream2); (void)hipStreamDestroy(t->stream2); }
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
     return 0;

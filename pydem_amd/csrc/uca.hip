@@ -1360,14 +1360,21 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt)
     HIP_TRY(hipEventRecord(t->ev[1], t->stream));
     t->tm.n_pit_edges = 0; t->tm.n_pits_undrained = 0; t->tm.pits_ms = 0;
     t->pits.n_edges = 0; t->pits.n_raw = 0;
+    // The in-mask kernel only needs the graph words the section kernel has just written (plus prop / elev, read-only):
+    // it streams through HBM on a side stream while the pit search -- bound by instruction issue, little memory
+    // traffic, touching none of these arrays (flats, mag, its own lists and counters[40..55]) -- runs on the main one.
+    double *corner_sums = (double *)(t->counters + 16);                          // 12 doubles inside the counter block
+    HIP_TRY(hipEventRecord(t->ev_fork, t->stream));
+    HIP_TRY(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
+    HIP_TRY(hipMemsetAsync(t->counters + 16, 0, 24 * sizeof(int32_t), t->stream2));
+    HIP_TRY(hipMemsetAsync(t->edge_todo, 0, (size_t)t->NN, t->stream2));
+    HIP_TRY(hipMemsetAsync(t->todo_work, 0, (size_t)t->NN, t->stream2));
+    hipLaunchKernelGGL(k_graph_inmask, grid2, dim3(256), 0, t->stream2, t->prop, t->elev, n, m,
+                       (uint32_t *)t->indeg, t->edge_todo, t->todo_work, corner_sums);
+    HIP_TRY(hipEventRecord(t->ev_join, t->stream2));
     if (opt->drain_pits) PYDEM_TRY(stage_pits(t, opt));
     HIP_TRY(hipEventRecord(t->ev[2], t->stream));
-    double *corner_sums = (double *)(t->counters + 16);                          // 12 doubles inside the counter block
-    HIP_TRY(hipMemsetAsync(t->counters, 0, 64 * sizeof(int32_t), t->stream));
-    HIP_TRY(hipMemsetAsync(t->edge_todo, 0, (size_t)t->NN, t->stream));
-    HIP_TRY(hipMemsetAsync(t->todo_work, 0, (size_t)t->NN, t->stream));
-    hipLaunchKernelGGL(k_graph_inmask, grid2, dim3(256), 0, t->stream, t->prop, t->elev, n, m,
-                       (uint32_t *)t->indeg, t->edge_todo, t->todo_work, corner_sums);
+    HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0));
     if (t->pits.n_edges > 0) {
         hipLaunchKernelGGL(k_graph_add_pits, dim3(grid_for(t->pits.n_edges, 1024)), dim3(256), 0, t->stream, t->pits.src,
                            t->pits.dst, t->pits.w, t->pits.n_edges, n, m, (uint32_t *)t->indeg, corner_sums);
