@@ -474,9 +474,17 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
 // version the drain tests are evaluated when a cell enters the border.  Window 128x128 cells; pits
 // that leave it (or exceed the list / drain capacity) go to the workgroup version.
 // ---------------------------------------------------------------------------------------------
+#ifndef PYDEM_WV_OCC
+#define PYDEM_WV_OCC 6
+#endif
+#ifndef PYDEM_WV_CAP
+#define PYDEM_WV_CAP 256
+#endif
 constexpr int WV_MAXD = 64;       // drain list capacity
 
-// Two instances: <128, 384, uint16_t> for the bulk (positions fit 14 bits, bit 14 = pit flag) and
+// Two instances: <128, 256, uint16_t> for the bulk (positions fit 14 bits, bit 14 = pit flag; 6.4 KB of LDS and 80 VGPRs:
+// six wavefronts per SIMD instead of five with a 384-cell list -- 18 of 397 678 pits of the 16384^2 bench tile then need the
+// large instance) and
 // <256, 2048, uint32_t> for the pits of plateau terrain whose border outgrows 384 cells (integer DEMs: a
 // quarter of the candidates at 4096^2) -- one wavefront per workgroup there, 44 KB of LDS each
 template <int WW, int CAP, typename PosT>
@@ -981,9 +989,9 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
 constexpr int W_LARGE = 640, MAXD_LARGE = 2048;
 
 // wave-per-pit: 4 pits per 256-thread block
-__global__ __launch_bounds__(256) void k_pits_wave(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits)
+__global__ __launch_bounds__(256, PYDEM_WV_OCC) void k_pits_wave(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits)
 {
-    __shared__ WaveLds<128, 384, uint16_t> s_l[4];
+    __shared__ WaveLds<128, PYDEM_WV_CAP, uint16_t> s_l[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t np = *npits;
     int32_t chunk_base = 0, chunk_left = 0;
@@ -1201,7 +1209,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             HIP_TRY(hipStreamSynchronize(t->stream));
             n_over = t->h_counters[9];
         }
-        if (dbg_env) fprintf(stderr, "pits: %d candidates, %d left the 16x16 lane window, %d left the 128x128 / 384-cell pass, %d left the 256x256 / 2048-cell pass, %d edge slots, %d undrained\n", npits, n_lane_over, n_wave_over, n_over, t->h_counters[1], t->h_counters[2]);
+        if (dbg_env) fprintf(stderr, "pits: %d candidates, %d left the 16x16 lane window, %d left the 128x128 / 256-cell pass, %d left the 256x256 / 2048-cell pass, %d edge slots, %d undrained\n", npits, n_lane_over, n_wave_over, n_over, t->h_counters[1], t->h_counters[2]);
         if (P.dbg) {
             const int nrec = t->h_counters[7];
             std::vector<int32_t> rec((size_t)nrec * 4);
