@@ -708,7 +708,10 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
 // ---------------------------------------------------------------------------------------------
 constexpr int LN_W = 16;          // window edge
 constexpr int LN_B = 32;          // border list capacity (one bit per slot in a 32-bit register)
-constexpr int LN_T = 128;         // threads (= pits) per workgroup
+#ifndef PYDEM_LN_T
+#define PYDEM_LN_T 64
+#endif
+constexpr int LN_T = PYDEM_LN_T;  // threads (= pits) per workgroup: one wavefront, 22.5 KB of LDS -> 7 workgroups per CU (128 threads: 6 wavefronts per CU)
 
 __device__ __forceinline__ double np_pairwise_leaf_strided(const double *a, int stride, int n)
 {
@@ -1180,7 +1183,8 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         // pass 1: a lane per pit (16x16 window); pass 2: a wavefront per pit it handed over (64x64)
         HIP_TRY(hipMemsetAsync(cnt + 10, 0, sizeof(int32_t), t->stream));
         P.work_next = cnt + 10;
-        const int gl = (int)(cdiv(npits, LN_T) < 3072 ? cdiv(npits, LN_T) : 3072);      // persistent: 3 workgroups per CU, 4 deep
+        const int gl_cap = 3072 * 128 / LN_T;
+        const int gl = (int)(cdiv(npits, LN_T) < gl_cap ? cdiv(npits, LN_T) : gl_cap);      // persistent: 3 workgroups per CU, 4 deep
         hipLaunchKernelGGL(k_pits_lane, dim3(gl), dim3(LN_T), 0, t->stream, P, t->flatlist, cnt);
         HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
