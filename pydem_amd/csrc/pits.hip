@@ -501,13 +501,23 @@ struct WaveLds {
     } u;
 };
 
+// fmin without the canonicalising v_max_f64 the compiler puts in front of every llvm.minnum operand (one extra fp64
+// instruction per minimum in kernels that are bound by instruction issue): v_min_f64 already returns the other operand
+// when one is a (quiet) NaN, which is what the border scans rely on
+__device__ __forceinline__ double min_f64(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_fmin(double v)
 {
     const int lo = __double2loint(v), hi = __double2hiint(v);
     const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
     const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
-    return fmin(v, __hiloint2double(hi2, lo2));
+    return min_f64(v, __hiloint2double(hi2, lo2));
 }
 // minimum over the wavefront: butterflies inside each row of 16 lanes on the DPP crossbar, then the four
 // row values through scalar registers
@@ -519,9 +529,9 @@ __device__ __forceinline__ double wave_min(double v)
     v = dpp_fmin<0x140>(v);       // row_mirror
     const int lo = __double2loint(v), hi = __double2hiint(v);
     double r = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
-    r = fmin(r, __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16)));
-    r = fmin(r, __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)));
-    r = fmin(r, __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48)));
+    r = min_f64(r, __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16)));
+    r = min_f64(r, __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)));
+    r = min_f64(r, __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48)));
     return r;
 }
 __device__ __forceinline__ void wave_sync()
@@ -603,7 +613,7 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
     expand(1);
     if (P.min_border) {                                                          // :1294-1295
         double mn = INFINITY;
-        for (int k = lane; k < nb; k += 64) mn = fmin(mn, L.le[k]);
+        for (int k = lane; k < nb; k += 64) mn = min_f64(mn, L.le[k]);
         mn = wave_min(mn);
         if (nb) epit_border = mn;
         has_np = false;                                                          // nothing is below the minimum
@@ -624,7 +634,7 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
         for (int j = 0; j < W2_SLOTS; j++) {
             const int k = lane + 64 * j;
             e[j] = (j * 64 < nb && k < nb) ? L.le[k] : INFINITY;                 // free slots hold +inf
-            mn = fmin(mn, e[j]);
+            mn = min_f64(mn, e[j]);
         }
         mn = wave_min(mn);
         // ... and pit_area += border[eborder == emin] (:1322-1323): out of the list, slots recycled
@@ -853,7 +863,7 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
                 }
                 if (P.min_border) {                                              // :1294-1295
                     double mn = INFINITY;
-                    for (int k = 0; k < nb; k++) mn = fmin(mn, le[k * LN_T]);
+                    for (int k = 0; k < nb; k++) mn = min_f64(mn, le[k * LN_T]);
                     if (nb) epit_border = mn;
                     has_np = false;                                              // nothing is below the minimum
                 }
@@ -877,7 +887,7 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
             else if (has_p) pending = 2;                                         // :1317-1320
             else {
                 double mn = INFINITY;
-                for (int k = 0; k < nb; k++) mn = fmin(mn, le[k * LN_T]);
+                for (int k = 0; k < nb; k++) mn = min_f64(mn, le[k * LN_T]);
                 // pit_area += border[eborder == emin] (:1322-1323): take them out of the list first ...
                 int nq = 0;
                 for (int k = 0; k < nb;) {
