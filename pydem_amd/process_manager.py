@@ -132,6 +132,8 @@ class ProcessManager(object):
         self.transport = None
         self.max_edge_rounds = 10000
         self.keep_first_pass_uca = True    # keep 'uca' (first pass) and 'uca_edges' separately like the reference's store
+        self.tiles_in_flight = 1           # tiles of this process worked on at once in the per-tile phases (threads; the
+                                           # library is re-entrant per tile handle, every tile has its own HIP stream)
         for k, v in kwargs.items():
             if k == 'dem_proc_kwargs':
                 bad = [kk for kk in v if kk not in DEM_PROC_KWARGS]
@@ -361,13 +363,30 @@ class ProcessManager(object):
             kw['device'] = self._device_of(i)
         return self.processor_cls(**kw)
 
+    def _per_tile(self, fn):
+        """Run fn(i) for every owned tile: one after the other, or `tiles_in_flight` at a time from worker threads
+        (the reference's n_workers pool, :1214-1288, with threads instead of processes: ctypes releases the GIL for
+        the duration of a library call, and the latency-bound tail of one tile's sweep overlaps the next tile's
+        streaming kernels on the same GPU)."""
+        owned = list(self._owned())
+        k = max(1, int(self.tiles_in_flight))
+        if k == 1 or len(owned) < 2:
+            for i in owned:
+                fn(i)
+            return
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=k) as ex:
+            list(ex.map(fn, owned))                    # (re-raises a worker's exception)
+
     def process_aspect_slope(self):
         """Reference :1010-1030 + worker calc_aspect_slope :73-92."""
         self.compute_grid_overlaps()
-        for i in self._owned():
+
+        def one(i):
             dp = self.tiles[i]
             dp.fill_flats = False                      # "assuming we already did this" (:78)
             getattr(dp, 'run_slopes_directions', dp.calc_slopes_directions)()
+        self._per_tile(one)
         return [1] * self.n_inputs
 
     def _patch_overlap1_edges(self):
@@ -456,12 +475,14 @@ class ProcessManager(object):
     def process_uca(self):
         """Reference :1032-1059 + worker calc_uca :94-197 (overlap-1 patch, find_flats, calc_uca)."""
         self._patch_overlap1_edges()
-        for i in self._owned():
+
+        def one(i):
             dp = self.tiles[i]
             dp.find_flats()
             getattr(dp, 'run_uca', dp.calc_uca)()
             dp.restore_pit_slopes()        # the worker does not write its patched slope back (:192-194)
             self.uca0[i] = None
+        self._per_tile(one)
         return [1] * self.n_inputs
 
     # ---- edge fix-up ------------------------------------------------------------------------

@@ -28,6 +28,15 @@ def test_directory_flow_matches_reference(name, tmp_path):
     assert pm.edge_rounds >= 1
 
 
+@pytest.mark.parametrize('name', ['pm_fractal_2x3_ov1', 'pm_cone32_4x5_ov3'])
+def test_directory_flow_with_tiles_in_flight(name, tmp_path):
+    """Several tiles of one GPU worked on at once (worker threads, one HIP stream per tile): same results."""
+    from test_process_manager_cpu import compare_with_golden, run_pm
+    g = load_golden(name)
+    pm, compact, order = run_pm(g, str(tmp_path), tiles_in_flight=3)
+    compare_with_golden(pm, compact, order, g, _close)
+
+
 def test_multi_tile_equals_single_tile_on_cone(tmp_path):
     """The reference's own acceptance test (pydem/test/test_end_to_end.py:86-149): on the pit-free cone
     the stitched multi-tile UCA equals the single-tile UCA on [1:-1, 1:-1] to 6 decimals."""
