@@ -334,6 +334,11 @@ class DEMProcessor(object):
             self.run_slopes_directions()
         if uca_init is not None or uca_resident:
             return self._calc_uca_edge_round(uca_init, edge_init_data, uca_resident)
+        if not self.drain_pits and (self.drain_flats or self.drain_pits_spill):
+            # (_mk_connectivity_flats / _mk_connectivity_pits_spill, dem_processing.py:1108-1123: alternatives the
+            # reference itself labels "not a great option"; only reachable with drain_pits=False)
+            raise NotImplementedError("drain_flats / drain_pits_spill (without drain_pits) are not implemented on the "
+                                      "device path; use drain_pits=True (the reference default) or leave both off")
         self._ensure_tile()
         self._push('elev', 'mag', 'direction', 'flats')
         opt = self._options()

@@ -53,3 +53,15 @@ def test_public_methods_of_the_path_exist():
     assert not missing, "DEMProcessor lacks %r" % missing
     missing = [m for m in REF['processmanager_methods'] if m not in NOT_PROVIDED_PM and not callable(getattr(ProcessManager, m, None))]
     assert not missing, "ProcessManager lacks %r" % missing
+
+
+@pytest.mark.parametrize('kw', [dict(drain_flats=True), dict(drain_pits_spill=True)])
+def test_unimplemented_drainage_alternatives_fail_loudly(kw):
+    """drain_flats / drain_pits_spill only act when drain_pits is off (dem_processing.py:1094-1123); the device path
+    does not implement them and must say so instead of returning the plain result."""
+    from pydem_amd import DEMProcessor
+    dp = DEMProcessor(elev=np.arange(25, dtype=float).reshape(5, 5) + 1.0, dX=2.0, dY=3.0, fill_flats=False,
+                      drain_pits_path=False, drain_pits=False, **kw)
+    dp.mag = np.ones((5, 5)); dp.direction = np.ones((5, 5)); dp.flats = np.zeros((5, 5), bool)   # skip the device stencil
+    with pytest.raises(NotImplementedError):
+        dp.run_uca()
