@@ -56,7 +56,7 @@ struct pydem_tile {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // side stream: memory-bound graph kernels that run beside the issue-bound pit search
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_snap = nullptr;
     hipEvent_t ev[8] = {};
     // fields
     double *elev = nullptr, *mag = nullptr, *dir = nullptr, *prop = nullptr, *uca = nullptr, *twi = nullptr;

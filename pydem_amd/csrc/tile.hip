@@ -148,6 +148,7 @@ int pydem_tile_create(int64_t n_rows, int64_t n_cols, int device, pydem_tile **o
     HIP_TRY(hipStreamCreateWithFlags(&t->stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_snap, hipEventDisableTiming));
     for (int i = 0; i < 8; i++) HIP_TRY(hipEventCreate(&t->ev[i]));
     PYDEM_TRY(tile_alloc(t, &t->counters, 64));
     HIP_TRY(hipHostMalloc((void **)&t->h_counters, 64 * sizeof(int32_t), hipHostMallocDefault));
@@ -172,6 +173,7 @@ int pydem_tile_destroy(pydem_tile *t)
     for (int i = 0; i < 8; i++) if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+    if (t->ev_snap) (void)hipEventDestroy(t->ev_snap);
     if (t->stream2) { (void)hipStreamSynchronize(t->stream2); (void)hipStreamDestroy(t->stream2); }
     if (t->stream) (void)hipStreamDestroy(t->stream);
     delete t;
