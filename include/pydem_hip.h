@@ -167,6 +167,9 @@ int pydem_comm_create(int world, int rank, const char *uid128, int device, pydem
 int pydem_comm_destroy(pydem_comm *c);
 int pydem_comm_begin(pydem_comm *c, int64_t n_doubles);
 int pydem_comm_pack_line(pydem_comm *c, pydem_tile *t, int field, int axis, int64_t index, int64_t offset);
+/* several lines of one tile without a host synchronisation (stream events order clear -> packs -> collective) */
+int pydem_comm_pack_lines(pydem_comm *c, pydem_tile *t, int count, const int *fields, const int *axes, const int64_t *indices,
+                          const int64_t *offsets);
 int pydem_comm_put(pydem_comm *c, const double *host_in, int64_t n_doubles, int64_t offset);
 int pydem_comm_allreduce(pydem_comm *c, int64_t n_doubles, int op /* 0 sum, 1 max */, double *host_out);
 

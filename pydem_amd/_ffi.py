@@ -82,6 +82,7 @@ SYMBOLS = {
     'pydem_comm_destroy': (C.c_int, [_P]),
     'pydem_comm_begin': (C.c_int, [_P, C.c_int64]),
     'pydem_comm_pack_line': (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64]),
+    'pydem_comm_pack_lines': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
     'pydem_comm_put': (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     'pydem_comm_allreduce': (C.c_int, [_P, C.c_int64, C.c_int, _P]),
 }
@@ -266,6 +267,13 @@ class Comm(object):
 
     def pack_line(self, tile, field, axis, index, offset):
         check(self.lib.pydem_comm_pack_line(self._h, tile._h, field, axis, index, offset))
+
+    def pack_lines(self, tile, lines):
+        """lines: [(field, axis, index, offset)] of ONE tile; no host synchronisation (see comm.hip)."""
+        k = len(lines)
+        fields = (C.c_int * k)(*[l[0] for l in lines]); axes = (C.c_int * k)(*[l[1] for l in lines])
+        idx = (C.c_int64 * k)(*[l[2] for l in lines]); offs = (C.c_int64 * k)(*[l[3] for l in lines])
+        check(self.lib.pydem_comm_pack_lines(self._h, tile._h, k, fields, axes, idx, offs))
 
     def put(self, values, offset=0):
         v = np.ascontiguousarray(values, np.float64)

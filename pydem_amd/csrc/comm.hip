@@ -16,6 +16,7 @@ struct pydem_comm {
     int world = 1, rank = 0, device = 0;
     double *buf = nullptr;      // device staging buffer
     size_t cap = 0;             // in doubles
+    hipEvent_t ev_clear = nullptr, ev_packed = nullptr;   // staging buffer cleared (comm stream) / lines packed (tile stream)
 };
 
 #define NCCL_TRY(expr)                                                                             \
@@ -56,6 +57,8 @@ int pydem_comm_create(int world, int rank, const char *uid128, int device, pydem
     pydem_comm *c = new pydem_comm();
     c->world = world; c->rank = rank; c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_clear, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
     ncclUniqueId id;
     memcpy(&id, uid128, sizeof(id));
     NCCL_TRY(ncclCommInitRank(&c->comm, world, id, rank));
@@ -69,6 +72,8 @@ int pydem_comm_destroy(pydem_comm *c)
     (void)hipSetDevice(c->device);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->buf) (void)hipFree(c->buf);
+    if (c->ev_clear) (void)hipEventDestroy(c->ev_clear);
+    if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -84,12 +89,11 @@ int pydem_comm_begin(pydem_comm *c, int64_t n_doubles)
         c->cap = (size_t)n_doubles;
     }
     HIP_TRY(hipMemsetAsync(c->buf, 0, (size_t)n_doubles * 8, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipEventRecord(c->ev_clear, c->stream));      // the packs wait for this on their own streams
     return 0;
 }
 
-// one row / column of a resident field -> doubles at buf[offset ...] (device to device)
-int pydem_comm_pack_line(pydem_comm *c, pydem_tile *t, int field, int axis, int64_t index, int64_t offset)
+static int pack_one(pydem_comm *c, pydem_tile *t, int field, int axis, int64_t index, int64_t offset)
 {
     HIP_TRY(hipSetDevice(t->device));
     if (t->device != c->device) { pydem_set_error("pydem_comm_pack_line: tile and communicator live on different devices"); return -2; }
@@ -119,7 +123,29 @@ int pydem_comm_pack_line(pydem_comm *c, pydem_tile *t, int field, int axis, int6
         default: pydem_set_error("pydem_comm_pack_line: unsupported field %d", field); return -2;
     }
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// one row / column of a resident field -> doubles at buf[offset ...] (device to device)
+int pydem_comm_pack_line(pydem_comm *c, pydem_tile *t, int field, int axis, int64_t index, int64_t offset)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipStreamWaitEvent(t->stream, c->ev_clear, 0));
+    PYDEM_TRY(pack_one(c, t, field, axis, index, offset));
     HIP_TRY(hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+// several lines of one tile, no host synchronisation: the pack kernels wait (event) for the clear of the staging
+// buffer on the communicator's stream, and the next collective on that stream waits (event) for the packs
+int pydem_comm_pack_lines(pydem_comm *c, pydem_tile *t, int count, const int *fields, const int *axes, const int64_t *indices,
+                          const int64_t *offsets)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    HIP_TRY(hipStreamWaitEvent(t->stream, c->ev_clear, 0));
+    for (int k = 0; k < count; k++) PYDEM_TRY(pack_one(c, t, fields[k], axes[k], indices[k], offsets[k]));
+    HIP_TRY(hipEventRecord(c->ev_packed, t->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_packed, 0));
     return 0;
 }
 

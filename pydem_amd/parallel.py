@@ -79,12 +79,15 @@ class RcclTransport(EdgeTransport):
         if total == 0:
             return [None] * len(requests)
         self.comm.begin(total)
+        mine = {}
         for (t, name, axis, index), off in zip(requests, offs):
             if t >= 0 and self.owns(t):
-                dp = self.pm.tiles[t]
-                dp._ensure_tile()
-                dp._push(name)
-                self.comm.pack_line(dp._tile, _FIELD_OF[name], axis, index, off)
+                mine.setdefault(t, []).append((name, axis, index, off))
+        for t, lines in mine.items():          # one launch sequence per tile, ordered against the collective by stream events
+            dp = self.pm.tiles[t]
+            dp._ensure_tile()
+            dp._push(*sorted(set(l[0] for l in lines)))
+            self.comm.pack_lines(dp._tile, [(_FIELD_OF[name], axis, index, off) for name, axis, index, off in lines])
         flat = self.comm.allreduce(total, op=0)
         out = []
         for (t, name, axis, index), off, n in zip(requests, offs, lens):

@@ -7,6 +7,10 @@ n = int(sys.argv[1]); nt = int(sys.argv[2])
 pm = process_manager.ProcessManager(elev_source_files=bench.tile_specs(nt, n, n), elev_conditioned=True,
                                     dem_proc_kwargs={'drain_pits': os.environ.get('PM_DRAIN', '1') == '1'}, devices=[0], keep_first_pass_uca=False,
                                     tiles_in_flight=int(os.environ.get('PM_IN_FLIGHT', '1')))
+if os.environ.get('PM_RCCL'):      # the RCCL strip transport with a single rank: its per-round overhead against the in-process one
+    from pydem_amd import _ffi
+    from pydem_amd.parallel import RcclTransport
+    pm.transport = RcclTransport(pm, _ffi.Comm(1, 0, _ffi.Comm.unique_id(), 0))
 pm.compute_grid(); pm.process_elevation()
 if os.environ.get('PICKS'):
     _orig = pm._edge_round
