@@ -792,16 +792,17 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
     // the wavefront's range of the pit list
     int32_t chunk_next = 0, chunk_end = 0;
     bool more = true;
-    // add the unseen neighbours of window cell (r, c) to the border
-    auto add_neighbours = [&](int r, int c) {
-        double e8[8]; uint8_t pm8[8]; int pos8[8];
+    // The unseen neighbours of the cells promoted in a round join the border in two steps: first every promoted cell
+    // files the window positions of its new neighbours (LDS only), then the elevations / pit flags of ALL new cells are
+    // fetched in one batch -- one memory round trip per round instead of one per promoted cell (the 64 pits of a
+    // wavefront advance in lock-step, so a round used to last as long as the lane with the most promoted cells).
+    auto discover = [&](int r, int c) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int di = k < 3 ? -1 : (k < 5 ? 0 : 1);
             const int dj = k < 3 ? k - 1 : (k == 3 ? -1 : (k == 4 ? 1 : k - 6));
             const int ii = r0 + r + di, jj = c0 + c + dj;
             const int rr = r + di, cc = c + dj;
-            pos8[k] = -1; e8[k] = 0.0; pm8[k] = 0;
             if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
             if (rr < 0 || rr >= LN_W || cc < 0 || cc >= LN_W) { over = true; continue; }
             const int pos = rr * LN_W + cc;
@@ -809,25 +810,39 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
             const uint32_t wd = seen[(pos >> 5) * LN_T];
             if (wd & bit) continue;
             seen[(pos >> 5) * LN_T] = wd | bit;
-            const int64_t cell = (int64_t)ii * m + jj;
-            e8[k] = P.elev[cell]; pm8[k] = P.pitmask[cell];
-            pos8[k] = pos;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (pos8[k] < 0) continue;
             if (nb == LN_B) { over = true; continue; }
-            le[nb * LN_T] = e8[k]; lp[nb * LN_T] = (uint8_t)pos8[k];
-            if (e8[k] != e8[k]) has_nan = true;          // nodata on the border: see the drain rules below
-            if (pm8[k]) { pitbits |= 1u << nb; if (e8[k] < epit) has_p = true; }
-            else { pitbits &= ~(1u << nb); if (e8[k] < epit_border) has_np = true; }
+            lp[nb * LN_T] = (uint8_t)pos;
             nb++;
         }
     };
+    auto fetch_new = [&](int nb0) {
+        constexpr int FB = 8;
+        for (int base = nb0; base < nb; base += FB) {
+            double e8[FB]; uint8_t pm8[FB];
+#pragma unroll
+            for (int k = 0; k < FB; k++) {
+                e8[k] = 0.0; pm8[k] = 0;
+                if (base + k < nb) {
+                    const int pos = lp[(base + k) * LN_T];
+                    const int64_t cell = (int64_t)(r0 + (pos >> 4)) * m + (c0 + (pos & 15));
+                    e8[k] = P.elev[cell]; pm8[k] = P.pitmask[cell];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < FB; k++) {
+                const int idx = base + k;
+                if (idx >= nb) continue;
+                le[idx * LN_T] = e8[k];
+                if (e8[k] != e8[k]) has_nan = true;          // nodata on the border: see the drain rules below
+                if (pm8[k]) { pitbits |= 1u << idx; if (e8[k] < epit) has_p = true; }
+                else { pitbits &= ~(1u << idx); if (e8[k] < epit_border) has_np = true; }
+            }
+        }
+    };
     const bool prof = P.prof != nullptr;
-    long long acc_a = 0, acc_b = 0, acc_c = 0, trips = 0, busy = 0;
+    long long acc_a = 0, acc_b = 0, acc_c = 0, acc_g = 0, trips = 0, busy = 0;
     for (;;) {
-        long long tk0 = 0, tk1 = 0, tk2 = 0;
+        long long tk0 = 0, tk1 = 0, tk2 = 0, tkg = 0;
         if (prof) tk0 = clock64();
         // ---- (a) new pits for idle lanes
         const unsigned long long idle = __ballot(!running);
@@ -859,7 +874,8 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
                 {                                                                // pit_area = [pit] (:1289-1292)
                     const int pos = (ipit - r0) * LN_W + (jpit - c0);
                     seen[(pos >> 5) * LN_T] = 1u << (pos & 31);
-                    add_neighbours(ipit - r0, jpit - c0);
+                    discover(ipit - r0, jpit - c0);
+                    fetch_new(0);
                 }
                 if (P.min_border) {                                              // :1294-1295
                     double mn = INFINITY;
@@ -886,48 +902,89 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
             else if (has_np) pending = 1;                                        // :1312-1316
             else if (has_p) pending = 2;                                         // :1317-1320
             else {
+                // the minimum, then the entries equal to it: two passes over the list with eight independent LDS reads in
+                // flight (a one-entry-at-a-time loop waits out the LDS latency 2 x nb times per round)
                 double mn = INFINITY;
-                for (int k = 0; k < nb; k++) mn = min_f64(mn, le[k * LN_T]);
-                // pit_area += border[eborder == emin] (:1322-1323): take them out of the list first ...
+                for (int k0 = 0; k0 < nb; k0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = k0 + i < nb ? le[(k0 + i) * LN_T] : INFINITY;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) mn = min_f64(mn, v[i]);
+                }
+                uint32_t eq = 0;
+                for (int k0 = 0; k0 < nb; k0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = k0 + i < nb ? le[(k0 + i) * LN_T] : INFINITY;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) if (k0 + i < nb && v[i] == mn) eq |= 1u << (k0 + i);
+                }
+                // pit_area += border[eborder == emin] (:1322-1323): take them out of the list first (highest slot first: the
+                // entry that fills a hole then always comes from the kept tail) ...
                 int nq = 0;
-                for (int k = 0; k < nb;) {
-                    if (le[k * LN_T] == mn) {
-                        lq[nq * LN_T] = lp[k * LN_T]; nq++;
-                        nb--;
+                while (eq) {
+                    const int k = 31 - __clz((int)eq);
+                    eq &= ~(1u << k);
+                    lq[nq * LN_T] = lp[k * LN_T]; nq++;
+                    nb--;
+                    if (k != nb) {
                         le[k * LN_T] = le[nb * LN_T]; lp[k * LN_T] = lp[nb * LN_T];
                         pitbits = (pitbits & ~(1u << k)) | (((pitbits >> nb) & 1u) << k);
-                    } else k++;
+                    }
                 }
                 // ... then the new border cells around them
-                for (int j = 0; j < nq; j++) { const int pos = lq[j * LN_T]; add_neighbours(pos >> 4, pos & 15); }
+                const int nb0 = nb;
+                for (int j = 0; j < nq; j++) { const int pos = lq[j * LN_T]; discover(pos >> 4, pos & 15); }
+                fetch_new(nb0);
                 it++;
             }
         }
         // the drain selection / slope arithmetic is a long divergent path: it runs for a batch of waiting lanes at once
         // (when a third of the wavefront waits, or nobody is growing any more) instead of in every trip
         const unsigned long long waiting = __ballot(pending != 0), growing = __ballot(running && !pending);
+        if (prof) { tkg = clock64(); acc_g += tkg - tk1; }
         if (!(__popcll(waiting) >= LN_FIN_BATCH || (waiting && !growing))) continue;
         if (pending) {
             const int mode = pending <= 2 ? pending : 0;
             status = pending == 4 ? 3 : 2;
             if (mode) {
-                // drains to the front of the list in ascending cell order (window order == cell order)
-                for (;;) {
-                    int best = -1, bestpos = 256;
-                    for (int k = nd; k < nb; k++) {
-                        const bool isp = (pitbits >> k) & 1u;
-                        const double e = le[k * LN_T];
-                        const bool match = mode == 1 ? (!isp && e < epit_border) : (isp && e < epit);
-                        const int pos = lp[k * LN_T];
-                        if (match && pos < bestpos) { best = k; bestpos = pos; }
+                // drains to the front of the list in ascending cell order (window order == cell order): one pass marks
+                // them (eight LDS reads in flight), the marked entries are swapped to the front in slot order and the
+                // handful of drains is then insertion-sorted by position
+                uint32_t mt = 0;
+                for (int k0 = 0; k0 < nb; k0 += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] = k0 + i < nb ? le[(k0 + i) * LN_T] : INFINITY;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const bool isp = (pitbits >> (k0 + i)) & 1u;
+                        if (k0 + i < nb && (mode == 1 ? (!isp && v[i] < epit_border) : (isp && v[i] < epit))) mt |= 1u << (k0 + i);
                     }
-                    if (best < 0) break;
-                    const double eb = le[best * LN_T];
-                    const uint32_t bb = (pitbits >> best) & 1u, bn = (pitbits >> nd) & 1u;
-                    le[best * LN_T] = le[nd * LN_T]; lp[best * LN_T] = lp[nd * LN_T];
-                    le[nd * LN_T] = eb; lp[nd * LN_T] = (uint8_t)bestpos;
-                    pitbits = (pitbits & ~((1u << best) | (1u << nd))) | (bn << best) | (bb << nd);
+                }
+                while (mt) {
+                    const int k = __ffs((int)mt) - 1;
+                    mt &= mt - 1u;
+                    if (k != nd) {                                               // slot nd holds an entry that is not a drain
+                        const double ek = le[k * LN_T], en = le[nd * LN_T];
+                        const uint8_t pk = lp[k * LN_T], pn = lp[nd * LN_T];
+                        const uint32_t bk = (pitbits >> k) & 1u, bn = (pitbits >> nd) & 1u;
+                        le[k * LN_T] = en; lp[k * LN_T] = pn; le[nd * LN_T] = ek; lp[nd * LN_T] = pk;
+                        pitbits = (pitbits & ~((1u << k) | (1u << nd))) | (bn << k) | (bk << nd);
+                    }
                     nd++;
+                }
+                for (int a = 1; a < nd; a++) {                                   // insertion sort by window position
+                    const double ea = le[a * LN_T]; const uint8_t pa = lp[a * LN_T]; const uint32_t ba = (pitbits >> a) & 1u;
+                    int b = a - 1;
+                    while (b >= 0 && lp[b * LN_T] > pa) {
+                        le[(b + 1) * LN_T] = le[b * LN_T]; lp[(b + 1) * LN_T] = lp[b * LN_T];
+                        pitbits = (pitbits & ~(1u << (b + 1))) | (((pitbits >> b) & 1u) << (b + 1));
+                        b--;
+                    }
+                    le[(b + 1) * LN_T] = ea; lp[(b + 1) * LN_T] = pa;
+                    pitbits = (pitbits & ~(1u << (b + 1))) | (ba << (b + 1));
                 }
                 // filters and slopes (see finish_pit; every slice is shorter than 16 rows)
                 const int ndX = n - 1;
@@ -963,7 +1020,7 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
             running = false; pending = 0;
         }
         // ---- (c) all lanes together: one slot allocation / counter update per wavefront for the pits that just ended
-        if (prof) { tk2 = clock64(); acc_a += tk1 - tk0; acc_b += tk2 - tk1; }
+        if (prof) { tk2 = clock64(); acc_a += tk1 - tk0; acc_b += tk2 - tkg; }
         if (!__ballot(status != 0)) continue;
         int incl = nd;
         for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off); if (lane >= off) incl += o; }
@@ -995,7 +1052,7 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
     if (prof && lane == 0) {    // cycles per phase, summed over wavefronts (PYDEM_PITS_DEBUG=3)
         atomicAdd(P.prof + 0, (unsigned long long)acc_a); atomicAdd(P.prof + 1, (unsigned long long)acc_b);
         atomicAdd(P.prof + 2, (unsigned long long)acc_c); atomicAdd(P.prof + 3, (unsigned long long)busy);
-        atomicAdd(P.prof + 4, (unsigned long long)trips);
+        atomicAdd(P.prof + 4, (unsigned long long)trips); atomicAdd(P.prof + 5, (unsigned long long)acc_g);
     }
 }
 
@@ -1202,8 +1259,8 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         if (P.prof) {
             unsigned long long h[8];
             HIP_TRY(hipMemcpy(h, P.prof, 64, hipMemcpyDeviceToHost));
-            fprintf(stderr, "pits/lane: %llu loop trips over all wavefronts, %.1f busy lanes per trip; cycles: refill %llu, step %llu, output %llu\n",
-                    h[4], h[4] ? (double)h[3] / (double)h[4] : 0.0, h[0], h[1], h[2]);
+            fprintf(stderr, "pits/lane: %llu loop trips over all wavefronts, %.1f busy lanes per trip; cycles: refill %llu, growth %llu, drain selection %llu, output %llu\n",
+                    h[4], h[4] ? (double)h[3] / (double)h[4] : 0.0, h[0], h[5], h[1], h[2]);
             (void)hipFree(P.prof); P.prof = nullptr;
         }
         if (n_lane_over > 0) {
