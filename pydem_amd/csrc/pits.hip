@@ -797,6 +797,12 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
     // fetched in one batch -- one memory round trip per round instead of one per promoted cell (the 64 pits of a
     // wavefront advance in lock-step, so a round used to last as long as the lane with the most promoted cells).
     auto discover = [&](int r, int c) {
+        // the 3x3 neighbourhood of (r, c) lives in two words of the window bitmap (a word holds two 16-cell rows; rows
+        // r - 1 and r + 1 are in consecutive words, row r in one of them): two independent reads, the eight bit tests in
+        // registers, two writes -- instead of eight dependent read-modify-write round trips to LDS
+        const int wa = (r > 0 ? r - 1 : 0) >> 1, wb = (r < LN_W - 1 ? r + 1 : LN_W - 1) >> 1;
+        uint32_t va = seen[wa * LN_T], vb = seen[wb * LN_T];
+        if (wb == wa) vb = va;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int di = k < 3 ? -1 : (k < 5 ? 0 : 1);
@@ -807,13 +813,17 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
             if (rr < 0 || rr >= LN_W || cc < 0 || cc >= LN_W) { over = true; continue; }
             const int pos = rr * LN_W + cc;
             const uint32_t bit = 1u << (pos & 31);
-            const uint32_t wd = seen[(pos >> 5) * LN_T];
+            const bool in_a = (pos >> 5) == wa;
+            const uint32_t wd = in_a ? va : vb;
             if (wd & bit) continue;
-            seen[(pos >> 5) * LN_T] = wd | bit;
+            if (in_a) va |= bit; else vb |= bit;
+            if (wb == wa) vb = va;
             if (nb == LN_B) { over = true; continue; }
             lp[nb * LN_T] = (uint8_t)pos;
             nb++;
         }
+        seen[wa * LN_T] = va;
+        if (wb != wa) seen[wb * LN_T] = vb;
     };
     auto fetch_new = [&](int nb0) {
         constexpr int FB = 8;
