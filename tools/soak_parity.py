@@ -14,6 +14,7 @@ from oracle import oracle as O            # noqa: E402  (checker only)
 from pydem_amd import DEMProcessor, synth  # noqa: E402
 
 RTOL, ATOL = 1e-9, 1e-12
+BIG = os.environ.get('SOAK_BIG') == '1'
 
 
 def close(a, b, what):
@@ -31,6 +32,8 @@ def make_case(k):
     n, m = int(rng.integers(3, 700)), int(rng.integers(3, 700))
     if rng.random() < 0.15:
         n, m = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+    if BIG:                                                # large tiles: plateau pits that need the big pit tiers, deep sweeps
+        n, m = int(rng.integers(900, 2600)), int(rng.integers(900, 2600))
     rec = dict(case=k, shape=(n, m))
     ts = int(rng.integers(2, 8))
     z = synth.fractal(n, m, seed=int(rng.integers(0, 1 << 30)), top_shift=ts, n_octaves=int(rng.integers(2, ts + 1)),
@@ -59,7 +62,8 @@ def make_case(k):
         kw = dict(dX=float(rng.choice([30.0, 1.0, 12.5])), dY=float(rng.choice([30.0, 1.0, 17.0])))
     else:
         a, b = float(rng.uniform(5, 40)), float(rng.uniform(5, 40))
-        kw = dict(dX=a + 0.01 * np.arange(n - 1), dY=b - 0.003 * np.arange(n - 1), dX2=a + 0.01 * np.arange(n), dY2=b - 0.003 * np.arange(n))
+        gx, gy = 0.3 * a / n, 0.2 * b / n                   # spacings stay positive on tiles of any height
+        kw = dict(dX=a + gx * np.arange(n - 1), dY=b - gy * np.arange(n - 1), dX2=a + gx * np.arange(n), dY2=b - gy * np.arange(n))
         rec['spacing'] = 'varying'
     opt = {}
     if rng.random() < 0.2: opt['drain_pits'] = False
