@@ -16,7 +16,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from oracle_processor import OracleProcessor   # noqa: E402  (checker only)
-from pydem_amd import process_manager, synth    # noqa: E402
+from pydem_amd import _ffi, process_manager, synth    # noqa: E402
+from pydem_amd.parallel import RcclTransport   # noqa: E402
+
+
+_COMM = []
+
+
+def comm():
+    if not _COMM:
+        _COMM.append(_ffi.Comm(1, 0, _ffi.Comm.unique_id(), 0))
+    return _COMM[0]
 
 
 def make_case(k):
@@ -48,6 +58,8 @@ def run(z, ny, nx, ov, dkw, cls):
         process_manager.DEBUG = True
         kw = {} if cls is None else dict(processor_cls=cls)
         pm = process_manager.ProcessManager(in_path=d, elev_conditioned=True, dem_proc_kwargs=dict(dkw), **kw)
+        if cls is None and os.environ.get('SOAK_RCCL') == '1':      # strips through the RCCL transport (one rank)
+            pm.transport = RcclTransport(pm, comm())
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             pm.process_twi()
