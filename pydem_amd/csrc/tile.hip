@@ -1,5 +1,6 @@
 // tile.hip -- handle management, spacing tables, upload/download and the extern "C" surface.
 #include "internal.h"
+#include <cmath>
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
@@ -184,6 +185,14 @@ int pydem_tile_set_spacing(pydem_tile *t, const double *dX, const double *dY, co
 {
     HIP_TRY(hipSetDevice(t->device));
     const int64_t n = t->n;
+    // the facet tests compare slopes by cross-multiplication with the spacings and divide with host reciprocals: both
+    // assume finite, strictly positive cell sizes (the reference would run on with negative or zero ones and return
+    // mirrored / infinite slopes -- not reproduced, so refuse)
+    for (int64_t r = 0; r < n - 1; r++)
+        if (!(dX[r] > 0 && dY[r] > 0 && std::isfinite(dX[r]) && std::isfinite(dY[r]))) {
+            pydem_set_error("pydem_tile_set_spacing: dX / dY must be finite and > 0 (row %lld: %g, %g)", (long long)r, dX[r], dY[r]);
+            return -2;
+        }
     t->h_dX.assign(dX, dX + n - 1); t->h_dY.assign(dY, dY + n - 1);
     t->h_dX2.assign(dX2, dX2 + n); t->h_dY2.assign(dY2, dY2 + n);
     std::vector<RowTab> tab((size_t)(n - 1));

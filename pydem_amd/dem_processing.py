@@ -164,6 +164,12 @@ class DEMProcessor(object):
         self.dY = np.array(kwargs.pop('dY'), dtype='float64')
         self.dX2 = np.array(kwargs.pop('dX2', np.ones(n_rows)), dtype='float64')
         self.dY2 = np.array(kwargs.pop('dY2', np.ones(n_rows)), dtype='float64')
+        for nm in ('dX', 'dY'):
+            d = getattr(self, nm)
+            if not (np.isfinite(d).all() and (d > 0).all()):
+                # (the reference runs on with negative / zero cell sizes and returns mirrored / infinite slopes; the device
+                # kernels compare slopes by cross-multiplication with the spacings and refuse such input instead)
+                raise ValueError("%s must be finite and > 0 (pass cell sizes, not signed geotransform steps)" % nm)
         for k, v in kwargs.items():
             if k in _FIELD_OF:
                 setattr(self, k, v)

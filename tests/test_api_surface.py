@@ -65,3 +65,12 @@ def test_unimplemented_drainage_alternatives_fail_loudly(kw):
     dp.mag = np.ones((5, 5)); dp.direction = np.ones((5, 5)); dp.flats = np.zeros((5, 5), bool)   # skip the device stencil
     with pytest.raises(NotImplementedError):
         dp.run_uca()
+
+
+@pytest.mark.parametrize('kw', [dict(dX=30.0, dY=-30.0), dict(dX=0.0, dY=30.0), dict(dX=float('nan'), dY=1.0)])
+def test_non_positive_spacing_is_refused(kw):
+    """Cell sizes must be finite and > 0: the device facet tests cross-multiply with them (the reference would
+    silently return mirrored / infinite slopes)."""
+    from pydem_amd import DEMProcessor
+    with pytest.raises(ValueError):
+        DEMProcessor(elev=np.arange(25, dtype=float).reshape(5, 5) + 1.0, fill_flats=False, **kw)
