@@ -193,6 +193,11 @@ int pydem_tile_set_spacing(pydem_tile *t, const double *dX, const double *dY, co
             pydem_set_error("pydem_tile_set_spacing: dX / dY must be finite and > 0 (row %lld: %g, %g)", (long long)r, dX[r], dY[r]);
             return -2;
         }
+    for (int64_t r = 0; r < n; r++)      // the sweep carries the edge_todo taint in the sign of a cell's shares: areas must be positive
+        if (!(dX2[r] * dY2[r] > 0 && std::isfinite(dX2[r] * dY2[r]))) {
+            pydem_set_error("pydem_tile_set_spacing: dX2 * dY2 (cell area) must be finite and > 0 (row %lld: %g, %g)", (long long)r, dX2[r], dY2[r]);
+            return -2;
+        }
     t->h_dX.assign(dX, dX + n - 1); t->h_dY.assign(dY, dY + n - 1);
     t->h_dX2.assign(dX2, dX2 + n); t->h_dY2.assign(dY2, dY2 + n);
     std::vector<RowTab> tab((size_t)(n - 1));

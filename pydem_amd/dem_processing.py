@@ -170,6 +170,9 @@ class DEMProcessor(object):
                 # (the reference runs on with negative / zero cell sizes and returns mirrored / infinite slopes; the device
                 # kernels compare slopes by cross-multiplication with the spacings and refuse such input instead)
                 raise ValueError("%s must be finite and > 0 (pass cell sizes, not signed geotransform steps)" % nm)
+        area = self.dX2 * self.dY2
+        if not (np.isfinite(area).all() and (area > 0).all()):
+            raise ValueError("dX2 * dY2 (the cell areas) must be finite and > 0")   # the sweep keeps a flag in the sign of a share
         for k, v in kwargs.items():
             if k in _FIELD_OF:
                 setattr(self, k, v)
