@@ -32,6 +32,9 @@ def make_case(k):
     n, m = int(rng.integers(3, 700)), int(rng.integers(3, 700))
     if rng.random() < 0.15:
         n, m = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+    if rng.random() < 0.06:                                # slivers: one dimension minimal, the other long
+        a, b = int(rng.integers(3, 8)), int(rng.integers(500, 20000))
+        n, m = (a, b) if rng.random() < 0.5 else (b, a)
     if BIG:                                                # large tiles: plateau pits that need the big pit tiers, deep sweeps
         n, m = int(rng.integers(900, 2600)), int(rng.integers(900, 2600))
     rec = dict(case=k, shape=(n, m))
