@@ -56,7 +56,7 @@ def run(z, ny, nx, ov, dkw, cls):
         for t, (elev, bounds) in enumerate(synth.split_mosaic(z, ny, nx, ov)):
             np.savez(os.path.join(d, 'tile_%03d.npz' % t), elev=elev, bounds=bounds)
         process_manager.DEBUG = True
-        kw = {} if cls is None else dict(processor_cls=cls)
+        kw = dict(tiles_in_flight=int(os.environ.get('SOAK_IN_FLIGHT', '1'))) if cls is None else dict(processor_cls=cls)
         pm = process_manager.ProcessManager(in_path=d, elev_conditioned=True, dem_proc_kwargs=dict(dkw), **kw)
         if cls is None and os.environ.get('SOAK_RCCL') == '1':      # strips through the RCCL transport (one rank)
             pm.transport = RcclTransport(pm, comm())
