@@ -1,0 +1,42 @@
+"""A short slice of the randomised soaks (tools/soak_parity.py, tools/soak_pm.py): random tiles and random mosaics,
+device path against the CPU oracle.  The full soaks run for minutes on the GPU box; these
+fixed case ranges keep the generators and the comparison alive in the regular GPU tier."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOOLS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools')
+if TOOLS not in sys.path:
+    sys.path.insert(0, TOOLS)
+
+
+@pytest.mark.parametrize('first', [0, 300000])
+def test_random_tiles_match_the_oracle(first):
+    import soak_parity
+    for k in range(first, first + 25):
+        rec, errs = soak_parity.run_case(k)
+        assert not errs, (rec, errs)
+
+
+def test_random_mosaics_match_the_oracle_backed_directory_flow():
+    import numpy as np
+    import soak_pm
+    from oracle_processor import OracleProcessor
+    for k in range(30):
+        rec, z, ny, nx, ov, dkw = soak_pm.make_case(k)
+        ref = soak_pm.run(z, ny, nx, ov, dkw, OracleProcessor)
+        dev = soak_pm.run(z, ny, nx, ov, dkw, None)
+        assert dev.edge_rounds == ref.edge_rounds, rec
+        for i in range(ref.n_inputs):
+            zero_area = np.abs(np.asarray(ref.tile_result(i, 'uca_total'), float)) < 1e-9
+            for key in ('aspect', 'slope', 'uca_total', 'twi'):
+                a, b = np.asarray(dev.tile_result(i, key), float), np.asarray(ref.tile_result(i, key), float)
+                if key == 'twi':
+                    a = np.where(zero_area, 0.0, a); b = np.where(zero_area, 0.0, b)
+                assert np.array_equal(np.isnan(a), np.isnan(b)), (rec, i, key)
+                assert np.allclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True), (rec, i, key)
+            for key in ('edge_todo', 'edge_done'):
+                assert np.array_equal(dev.tile_result(i, key), ref.tile_result(i, key)), (rec, i, key)
