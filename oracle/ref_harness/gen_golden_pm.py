@@ -77,6 +77,9 @@ def run_pm_case(name, raster, ny_grid, nx_grid, overlap, dp_kwargs):
     for key in ('elev', 'uca', 'aspect', 'slope', 'twi'):
         rec['compact_' + key] = np.array(pm.out_file_noverlap[key][:])
     rec['kwargs_repr'] = np.array(repr(sorted(dict(dp_kwargs, ny_grid=ny_grid, nx_grid=nx_grid, overlap=overlap).items())))
+    if name is None:                       # in-memory use (soak_pm_reference.py)
+        shutil.rmtree(tmp)
+        return rec
     os.makedirs(OUT, exist_ok=True)
     fn = os.path.join(OUT, name + '.npz')
     np.savez_compressed(fn, **rec)

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""Differential soak of the ProcessManager drop-in's HOST LOGIC against the unmodified reference ProcessManager on
+random mosaics (raster, tile grid, overlap, options): our ProcessManager runs with the oracle-backed processor
+(tests/oracle_processor.py), so every difference is grid bookkeeping / overlap patching / edge-round order.  Build
+container only.   bash run.sh soak_pm_reference.py [seconds] [first_case]"""
+import os
+import sys
+import tempfile
+import shutil
+import time
+import warnings
+
+import gen_golden_pm as GP    # noqa: F401  (imports the reference)
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+from pydem_amd import synth                               # noqa: E402
+from oracle_processor import OracleProcessor              # noqa: E402
+from test_process_manager_cpu import compare_with_golden, run_pm   # noqa: E402
+
+
+def close(a, b, what):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    assert np.array_equal(np.isnan(a), np.isnan(b)), what
+    assert np.allclose(a, b, rtol=1e-12, atol=1e-13, equal_nan=True), what
+
+
+def make_case(k):
+    rng = np.random.default_rng(88000 + k)
+    ny, nx = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    ov = int(rng.integers(1, 4))
+    n, m = int(rng.integers(10 * ny, 28 * ny + 1)), int(rng.integers(10 * nx, 28 * nx + 1))
+    ts = int(rng.integers(2, 6))
+    z = synth.fractal(n, m, seed=int(rng.integers(0, 1 << 30)), top_shift=ts, n_octaves=int(rng.integers(2, ts + 1)),
+                      zmin=float(rng.choice([1.0, -15.0])), zrange=float(rng.choice([300.0, 40.0])))
+    if rng.random() < 0.3:
+        z[z < 0] = 0.0
+    if rng.random() < 0.3:
+        z = np.rint(z)
+    if rng.random() < 0.25:
+        i0, j0 = int(rng.integers(0, n)), int(rng.integers(0, m))
+        z[i0:i0 + int(rng.integers(1, 8)), j0:j0 + int(rng.integers(1, 8))] = np.nan
+    dkw = dict(drain_pits_path=False)
+    if rng.random() < 0.4:
+        dkw['fill_flats'] = False
+    if rng.random() < 0.25:
+        dkw['drain_pits'] = False
+    return dict(case=k, shape=(n, m), grid=(ny, nx), overlap=ov, options=dkw), z, ny, nx, ov, dkw
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    t0 = time.time(); done = 0; skipped = 0
+    warnings.simplefilter('ignore')
+    devnull = open(os.devnull, 'w')
+    while time.time() - t0 < budget:
+        rec, z, ny, nx, ov, dkw = make_case(k)
+        k += 1
+        out, sys.stdout = sys.stdout, devnull
+        try:
+            try:
+                g = GP.run_pm_case(None, z, ny, nx, ov, dkw)
+            except Exception:
+                skipped += 1               # mosaics the reference itself cannot process (degenerate chunk edges)
+                continue
+        finally:
+            sys.stdout = out
+        g['kwargs'] = dict(eval(str(g.pop('kwargs_repr'))))
+        d = tempfile.mkdtemp()
+        try:
+            pm, compact, order = run_pm(g, d, processor_cls=OracleProcessor)
+            compare_with_golden(pm, compact, order, g, close)
+        except AssertionError as e:
+            print('MISMATCH', rec, str(e)[:200])
+            sys.exit(1)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        done += 1
+    print('pm reference soak ok: %d random mosaics (%d skipped) up to case %d in %.0f s' % (done, skipped, k, time.time() - t0))
+
+
+if __name__ == '__main__':
+    main()
