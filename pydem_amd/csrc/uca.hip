@@ -562,9 +562,9 @@ __global__ __launch_bounds__(1024) void k_sweep_small(SweepArgs A, QE *q0, QE *q
 // scattered 64 B lines for every cell it touches.  Here ONE WAVEFRONT owns a 32x32 tile for a pass and
 // runs as many level-synchronous rounds as it can without leaving the CU: a cell is final once all
 // its upstream cells are final -- those inside the tile become so during the pass, cells of the
-// one-cell halo only if an earlier pass finished them.  Only the BOOKKEEPING lives in LDS (graph
-// words, open-upstream counts, the ready list: 9 KB per tile, so 16 tiles are in flight per CU and
-// hide each other's latency); areas and contributions go straight to their global arrays, where
+// one-cell halo only if an earlier pass finished them.  Only the BOOKKEEPING lives in LDS (one word
+// per cell -- graph bits + open-upstream count --, a final-cell bitmap for the setup, the ready ring: 4.9 KB per tile, so 32
+// tiles are in flight per CU in the full passes and hide each other's latency); areas and contributions go straight to their global arrays, where
 // the same wavefront finds them again in its caches a round later (a workgroup-scope fence orders a
 // round's stores before the next round's loads).  A pass is either over all tiles (pass 1) or over
 // the tiles LISTED by the previous pass: whenever a finished cell drains into another tile, that
