@@ -50,10 +50,28 @@ def make_case(k):
     return dict(case=k, shape=(n, m), grid=(ny, nx), overlap=ov, options=dkw), z, ny, nx, ov, dkw
 
 
+# The reference's workers swallow their exceptions (process_manager.py:69-71, 312-315: they return (0, traceback) and the
+# loop only logs it).  On some mosaics its Cython drain_connections raises IndexError (out-of-bounds buffer access,
+# cyutils.pyx:45) inside the edge round; the directory flow then stops with unresolved edges.  Such cases are not a
+# behaviour to reproduce: they are counted and skipped.
+_WORKER_ERRORS = []
+from pydem import process_manager as _RPM   # noqa: E402
+for _name in ('calc_uca_ec', 'calc_uca', 'calc_aspect_slope', 'calc_elev_cond', 'calc_twi'):
+    if hasattr(_RPM, _name):
+        def _wrap(orig):
+            def f(*a, **kw):
+                r = orig(*a, **kw)
+                if isinstance(r, tuple) and len(r) >= 2 and r[0] == 0 and isinstance(r[1], str):
+                    _WORKER_ERRORS.append(r[1])
+                return r
+            return f
+        setattr(_RPM, _name, _wrap(getattr(_RPM, _name)))
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    t0 = time.time(); done = 0; skipped = 0
+    t0 = time.time(); done = 0; skipped = 0; ref_failed = 0
     warnings.simplefilter('ignore')
     devnull = open(os.devnull, 'w')
     while time.time() - t0 < budget:
@@ -61,6 +79,7 @@ def main():
         k += 1
         out, sys.stdout = sys.stdout, devnull
         try:
+            del _WORKER_ERRORS[:]
             try:
                 g = GP.run_pm_case(None, z, ny, nx, ov, dkw)
             except Exception:
@@ -68,6 +87,9 @@ def main():
                 continue
         finally:
             sys.stdout = out
+        if _WORKER_ERRORS:
+            ref_failed += 1                # a reference worker raised (see above)
+            continue
         g['kwargs'] = dict(eval(str(g.pop('kwargs_repr'))))
         d = tempfile.mkdtemp()
         try:
@@ -79,7 +101,8 @@ def main():
         finally:
             shutil.rmtree(d, ignore_errors=True)
         done += 1
-    print('pm reference soak ok: %d random mosaics (%d skipped) up to case %d in %.0f s' % (done, skipped, k, time.time() - t0))
+    print('pm reference soak ok: %d random mosaics (%d skipped, %d where a reference worker raised) up to case %d in %.0f s'
+          % (done, skipped, ref_failed, k, time.time() - t0))
 
 
 if __name__ == '__main__':
