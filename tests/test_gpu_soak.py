@@ -40,3 +40,17 @@ def test_random_mosaics_match_the_oracle_backed_directory_flow():
                 assert np.allclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True), (rec, i, key)
             for key in ('edge_todo', 'edge_done'):
                 assert np.array_equal(dev.tile_result(i, key), ref.tile_result(i, key)), (rec, i, key)
+
+
+def test_circular_drainage_is_refused_loudly():
+    """Known gap: mosaic 122733 of the soak -- the overlap-1 patch closes a two-cell loop
+    in one tile.  The reference / oracle re-seed the stalled sweep (dem_processing.py:951-964); the device path does not
+    emulate that yet and must say so instead of returning numbers.  (When the emulation lands, this test turns into a
+    parity check against the oracle-backed run, which completes.)"""
+    import soak_pm
+    from oracle_processor import OracleProcessor
+    rec, z, ny, nx, ov, dkw = soak_pm.make_case(122733)
+    ref = soak_pm.run(z, ny, nx, ov, dkw, OracleProcessor)          # the oracle-backed flow handles it
+    assert ref.n_inputs == 9
+    with pytest.raises(RuntimeError, match='circular drainage'):
+        soak_pm.run(z, ny, nx, ov, dkw, None)
