@@ -22,6 +22,8 @@
 //   K6  calc_twi :1647-1677.
 // The pointwise kernels are bounded by HBM; the sweeps by dependent memory latency times the tiles / cells in flight.
 #include "internal.h"
+#include <algorithm>
+#include <vector>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -982,6 +984,150 @@ __global__ void k_row_area(const double *__restrict__ dX2, const double *__restr
     if (i < n) a0[i] = dX2[i] * dY2[i];                                          // :885
 }
 
+// ------------------------------------------------------------------------------- K5c
+// Circular drainage (rare: e.g. the overlap-1 patch of a tile's edge aspects can close a two-cell loop).  When the tile
+// passes stall, the cells on and below the loop are unfinished; the reference then re-seeds its push sweep from the
+// unfinished cells within 1 % of the highest unfinished elevation (dem_processing.py:951-964) and its Cython loop
+// (cyutils.pyx:119-187) keeps going round by round -- pushing IN PLACE in ascending cell order, queueing a cell again
+// whenever all its sources are done, skipping pushes into finished cells on the tile edge.  Those rules are order
+// dependent, so the handful of unfinished cells is replayed here exactly like that by ONE thread (the oracle's
+// oracle_uca_chunk / oracle_drain_area are the line-by-line model); everything else of the tile is already final.
+struct ReseedCell { int32_t c; int32_t pin_first; int32_t pout_first; int32_t pad; };
+
+// not finished by any pass: sources start with level 0, every other cell with "not yet known"
+__device__ __forceinline__ bool ci_unfinished(uint32_t w) { const uint32_t lv = ci_level(w); return lv == 0 || lv == CI_LEVEL_INF; }
+
+// area / taint an unfinished cell has received so far: the shares of its FINISHED upstream cells (graph word level >= 1)
+__device__ void gather_finished(const SweepArgs &A, int32_t c, uint32_t cw, int32_t pin_first, double &a, bool &td)
+{
+    const int m = A.m, gi = c / m, gj = c - gi * m;
+    a = A.a0[gi];
+    td = (gi == 0 || gi == A.n - 1 || gj == 0 || gj == m - 1) && A.todo_work[c] != 0;
+    for (int d = 0; d < 8; d++)
+        if (cw & (1u << d)) {
+            const int32_t u = c + NB_DI[d] * m + NB_DJ[d];
+            if (ci_unfinished(A.cinfo[u])) continue;
+            const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
+            const double x = cardinal ? A.contrib[u].x : A.contrib[u].y;
+            a += fabs(x); td = td || (x < 0);
+        }
+    if (cw & CI_PIT_IN)
+        for (int32_t e = pin_first; e < A.n_pit && A.pin_dst[e] == c; e++) {
+            const int32_t sc = A.pin_src[e];
+            if (ci_unfinished(A.cinfo[sc])) continue;
+            a += A.area[sc] * A.pin_w[e];
+            td = td || (A.todo_work[sc] != 0);
+        }
+}
+
+// the unfinished cells, in any order (the host sorts the few of them); their pit-list offsets are saved because the area
+// slot that holds them is about to carry the area
+__global__ __launch_bounds__(256) void k_reseed_collect(SweepArgs A, ReseedCell *__restrict__ list, int32_t *count, int32_t cap,
+                                                        const double *__restrict__ elev, int32_t *nan_flag)
+{
+    const int64_t NN = (int64_t)A.n * A.m;
+    for (int64_t c64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c64 < NN; c64 += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t c = (int32_t)c64;
+        if (elev[c] != elev[c]) *nan_flag = 1;              // numpy's max over the tile propagates NaN (:963): then nothing is re-seeded
+        const uint32_t w = A.cinfo[c];
+        if (!ci_unfinished(w)) continue;
+        int2 po = make_int2(0, 0);
+        if (w & (CI_PIT_IN | CI_PIT_OUT)) po = pit_stash(A, c);
+        const int32_t slot = atomicAdd(count, 1);
+        if (slot < cap) { list[slot].c = c; list[slot].pin_first = po.x; list[slot].pout_first = po.y; list[slot].pad = 0; }
+    }
+}
+
+__device__ __forceinline__ int reseed_find(const ReseedCell *U, int32_t nU, int32_t c)
+{
+    int lo = 0, hi = nU - 1;
+    while (lo <= hi) { const int mid = (lo + hi) >> 1; if (U[mid].c == c) return mid; if (U[mid].c < c) lo = mid + 1; else hi = mid - 1; }
+    return -1;
+}
+
+// ONE thread.  st[k]: bit 0 done, bit 1 in the current frontier, bit 2 in the previous frontier; tdf[k]: taint
+__global__ void k_reseed_replay(SweepArgs A, const ReseedCell *__restrict__ U, int32_t nU, const double *__restrict__ elev,
+                                const double *__restrict__ pit_w, uint8_t *__restrict__ st, uint8_t *__restrict__ tdf,
+                                int tile_has_nan, int maxcount, uint32_t pass, int32_t *n_final, int32_t *n_done_out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int n = A.n, m = A.m;
+    auto on_edge = [&](int32_t c) { const int i = c / m, j = c - i * m; return i == 0 || i == n - 1 || j == 0 || j == m - 1; };
+    auto is_done = [&](int32_t c) -> bool {            // finished before the stall, or in the replay
+        if (!ci_unfinished(A.cinfo[c])) return true;
+        const int k = reseed_find(U, nU, c);
+        return k >= 0 && (st[k] & 1u);
+    };
+    // what the unfinished cells have received so far
+    for (int k = 0; k < nU; k++) {
+        double a; bool td;
+        gather_finished(A, U[k].c, A.cinfo[U[k].c] & CI_STATIC_MASK, U[k].pin_first, a, td);
+        A.area[U[k].c] = a; tdf[k] = td; st[k] = 0;
+    }
+    int32_t n_done = 0, done_prev = -1;
+    for (int count = 2; n_done < nU && count < maxcount && n_done != done_prev; count++) {     // :951-952 (the first drain was the tile passes)
+        done_prev = n_done;
+        // ---- the new frontier: ids[((data * ~done - max_elev) / max_elev > -0.01)] (:962-964); finished cells count as 0
+        double mx = 0.0;
+        for (int k = 0; k < nU; k++) if (!(st[k] & 1u) && elev[U[k].c] > mx) mx = elev[U[k].c];
+        if (tile_has_nan) mx = NAN;
+        for (int k = 0; k < nU; k++) {
+            const double v = (st[k] & 1u) ? 0.0 : elev[U[k].c];
+            st[k] = (uint8_t)((st[k] & 1u) | (((v - mx) / mx > -0.01) ? 2u : 0u));
+        }
+        // ---- cyutils._drain_area (:119-187)
+        for (int64_t guard = 0; guard < 8 * (int64_t)nU + 64; guard++) {
+            for (int k = 0; k < nU; k++) if (st[k] & 2u) { if (!(st[k] & 1u)) n_done++; st[k] |= 1u; }     // :138-140
+            for (int k = 0; k < nU; k++) st[k] = (uint8_t)((st[k] & 1u) | ((st[k] & 2u) ? 4u : 0u));         // swap, zero the new frontier
+            for (int k = 0; k < nU; k++) {
+                if (!(st[k] & 4u)) continue;
+                const int32_t i = U[k].c;
+                const uint32_t cw = A.cinfo[i] & CI_STATIC_MASK;
+                // the column of i: targets in ascending cell order (scipy sorts the indices of a CSC column)
+                int32_t tg[2]; double fc[2]; int nt = 0;
+                if (cw & (CI_OUT1 | CI_OUT2)) {
+                    const int sct = ci_section(cw);
+                    const double pv = A.prop[i];
+                    if (cw & CI_OUT1) { tg[nt] = i + fe1r(sct) * m + fe1c(sct); fc[nt] = pv; nt++; }
+                    if (cw & CI_OUT2) { tg[nt] = i + fe2r(sct) * m + fe2c(sct); fc[nt] = 1 - pv; nt++; }
+                    if (nt == 2 && tg[1] < tg[0]) { const int32_t tt = tg[0]; tg[0] = tg[1]; tg[1] = tt; const double ff = fc[0]; fc[0] = fc[1]; fc[1] = ff; }
+                }
+                int32_t e = (cw & CI_PIT_OUT) ? U[k].pout_first : 0;
+                for (int q = 0;; q++) {
+                    int32_t row; double factor;
+                    if (cw & CI_PIT_OUT) { if (!(e < A.n_pit && A.pit_src[e] == i)) break; row = A.pit_dst[e]; factor = pit_w[e]; e++; }
+                    else { if (q >= nt) break; row = tg[q]; factor = fc[q]; }
+                    const int kr = reseed_find(U, nU, row);
+                    if (kr < 0) continue;                                   // (cannot happen: everything below an unfinished cell is unfinished)
+                    if ((st[kr] & 1u) && on_edge(row)) continue;            // :159-161
+                    A.area[row] += A.area[i] * factor;                      // :163
+                    if (tdf[k]) tdf[kr] = 1;                                // edge_todo[row] += edge_todo[i] * factor (positive factors)
+                    bool wait = false;                                      // :173-179
+                    const uint32_t cwr = A.cinfo[row] & CI_STATIC_MASK;
+                    for (int d = 0; d < 8 && !wait; d++)
+                        if ((cwr & (1u << d)) && !is_done(row + NB_DI[d] * m + NB_DJ[d])) wait = true;
+                    if (!wait && (cwr & CI_PIT_IN))
+                        for (int32_t e2 = U[kr].pin_first; e2 < A.n_pit && A.pin_dst[e2] == row; e2++)
+                            if (!is_done(A.pin_src[e2])) { wait = true; break; }
+                    if (!wait) st[kr] |= 2u;
+                }
+            }
+            bool changed = false;                                           // :187
+            for (int k = 0; k < nU; k++) if (((st[k] >> 1) & 1u) != ((st[k] >> 2) & 1u)) changed = true;
+            if (!changed) break;
+        }
+        for (int k = 0; k < nU; k++) st[k] &= 1u;                           // ids[:] = False (:962)
+    }
+    // finished cells join the others (level stamp, taint); the rest keep what they have received, like the reference
+    for (int k = 0; k < nU; k++) {
+        const int32_t c = U[k].c;
+        if (tdf[k]) A.todo_work[c] = 1;
+        if (st[k] & 1u) A.cinfo[c] = ci_with_level(A.cinfo[c], pass);
+    }
+    atomicAdd(n_final, n_done);
+    *n_done_out = n_done;
+}
+
 // finalisation of _calc_uca_chunk (:966-980): NaN on flats, edge_done = ~edge_todo etc.
 __global__ __launch_bounds__(256) void k_uca_finalize(double *__restrict__ uca, const uint8_t *__restrict__ flats,
                                                       const uint8_t *__restrict__ todo_work, const double *__restrict__ elev,
@@ -1488,6 +1634,35 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         t->tm.sweep_tile_passes = (int64_t)pass;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
+        // ---- circular drainage: replay of the reference's re-seed loop over the unfinished cells (K5c)
+        if ((int64_t)t->h_counters[3] < t->NN) {
+            const int64_t unfinished = t->NN - (int64_t)t->h_counters[3];
+            ReseedCell *U = (ReseedCell *)t->queue[0];                       // scratch: the queue buffers are idle in this schedule
+            const int64_t cap64 = t->NN * 4 / (int64_t)sizeof(ReseedCell);
+            if (unfinished > cap64 || unfinished > (1 << 22)) {
+                pydem_set_error("circular drainage: %lld unfinished cells are more than the sequential replay of the re-seed loop is meant for", (long long)unfinished);
+                return -5;
+            }
+            uint8_t *stf = (uint8_t *)t->queue[1];                           // state bytes, then taint bytes
+            int32_t *rc = t->counters + 60;                                  // [60] collected, [61] NaN flag, [62] finished by the replay
+            HIP_TRY(hipMemsetAsync(rc, 0, 3 * sizeof(int32_t), t->stream));
+            hipLaunchKernelGGL(k_reseed_collect, dim3(grid_for(t->NN, 4096)), dim3(256), 0, t->stream, A, U, rc, (int32_t)cap64,
+                               (const double *)t->elev, rc + 1);
+            std::vector<ReseedCell> hu((size_t)unfinished);
+            HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipMemcpyAsync(hu.data(), U, hu.size() * sizeof(ReseedCell), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            if ((int64_t)t->h_counters[60] != unfinished) { pydem_set_error("circular drainage: unfinished-cell count mismatch (%d collected, %lld expected)", t->h_counters[60], (long long)unfinished); return -5; }
+            std::sort(hu.begin(), hu.end(), [](const ReseedCell &a, const ReseedCell &b) { return a.c < b.c; });
+            HIP_TRY(hipMemcpyAsync(U, hu.data(), hu.size() * sizeof(ReseedCell), hipMemcpyHostToDevice, t->stream));
+            hipLaunchKernelGGL(k_reseed_replay, dim3(1), dim3(64), 0, t->stream, A, (const ReseedCell *)U, (int32_t)unfinished,
+                               (const double *)t->elev, (const double *)t->pits.w, stf, stf + unfinished, t->h_counters[61],
+                               (int)opt->circular_ref_maxcount, pass, total, rc + 2);
+            launches += 2;
+            HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "circular drainage: %lld unfinished cells, %d finished by the re-seed replay\n", (long long)unfinished, t->h_counters[62]);
+        }
         if (A.dbg & 4) {
             const unsigned long long *acc = (const unsigned long long *)(t->h_counters + 32);
             fprintf(stderr, "tile phases (10 ns ticks summed over %llu tile runs, %llu of them finished nothing): stage %llu, setup %llu, rounds %llu (%llu rounds), stamp %llu\n",

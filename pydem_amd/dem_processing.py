@@ -355,9 +355,10 @@ class DEMProcessor(object):
         self._tile.uca(opt)
         tm = self._tile.timings()
         if tm['n_unresolved']:
-            raise RuntimeError("%d cells lie on or below a circular drainage pattern; the reference's re-seeding "
-                               "loop (dem_processing.py:951-964) is not reproduced on the device yet"
-                               % tm['n_unresolved'])
+            # circular drainage that the re-seed loop (dem_processing.py:951-964, replayed on the device) did not resolve
+            # within circular_ref_maxcount rounds: like the reference, those cells keep the area they have received
+            warnings.warn("%d cells lie on or below a circular drainage pattern that the re-seed loop did not resolve"
+                          % tm['n_unresolved'])
         if tm['n_pits_undrained']:
             warnings.warn("Warning %d pits had no place to drain to in this chunk" % tm['n_pits_undrained'])
         self.twi_min_area = min(self.twi_min_area, opt.twi_min_area)

@@ -42,15 +42,21 @@ def test_random_mosaics_match_the_oracle_backed_directory_flow():
                 assert np.array_equal(dev.tile_result(i, key), ref.tile_result(i, key)), (rec, i, key)
 
 
-def test_circular_drainage_is_refused_loudly():
-    """Known gap: mosaic 122733 of the soak -- the overlap-1 patch closes a two-cell loop
-    in one tile.  The reference / oracle re-seed the stalled sweep (dem_processing.py:951-964); the device path does not
-    emulate that yet and must say so instead of returning numbers.  (When the emulation lands, this test turns into a
-    parity check against the oracle-backed run, which completes.)"""
+def test_circular_drainage_is_replayed_like_the_reference():
+    """Mosaic 122733 of the soak: the overlap-1 patch closes a two-cell loop in one tile; the reference / oracle re-seed
+    the stalled sweep (dem_processing.py:951-964, cyutils.pyx:119-187), the device replays that loop over the unfinished
+    cells.  Device flow against the oracle-backed flow, like every other mosaic of the soak."""
+    import numpy as np
     import soak_pm
     from oracle_processor import OracleProcessor
     rec, z, ny, nx, ov, dkw = soak_pm.make_case(122733)
-    ref = soak_pm.run(z, ny, nx, ov, dkw, OracleProcessor)          # the oracle-backed flow handles it
-    assert ref.n_inputs == 9
-    with pytest.raises(RuntimeError, match='circular drainage'):
-        soak_pm.run(z, ny, nx, ov, dkw, None)
+    ref = soak_pm.run(z, ny, nx, ov, dkw, OracleProcessor)
+    dev = soak_pm.run(z, ny, nx, ov, dkw, None)
+    assert dev.edge_rounds == ref.edge_rounds
+    for i in range(ref.n_inputs):
+        for key in ('uca_total', 'twi'):
+            a, b = np.asarray(dev.tile_result(i, key), float), np.asarray(ref.tile_result(i, key), float)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (i, key)
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True), (i, key)
+        for key in ('edge_todo', 'edge_done'):
+            assert np.array_equal(dev.tile_result(i, key), ref.tile_result(i, key)), (i, key)
