@@ -84,7 +84,7 @@ typedef struct pydem_timings {
     int64_t n_flats;              /* cells in the flats mask after slopes_directions */
     int64_t n_pit_edges;          /* pit -> drain edges built                  */
     int64_t n_pits_undrained;     /* the reference's "pits had no place to drain" count */
-    int64_t n_unresolved;         /* cells the sweep could not reach (cyclic drainage) */
+    int64_t n_unresolved;         /* cells still unfinished after the re-seed loop (circular drainage, dem_processing.py:951-964) */
     int64_t sweep_tile_passes;    /* LDS tile-local passes run before the queue rounds */
 } pydem_timings;
 

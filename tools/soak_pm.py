@@ -84,8 +84,8 @@ def main():
         try:
             dev = run(z, ny, nx, ov, dkw, None)
         except RuntimeError as e:
-            if 'circular drainage' in str(e):       # known gap: the re-seed loop of :951-964 is not on the device;
-                cyclic.append(rec['case'])          # the path refuses loudly.  First seen on case 122733 (overlap-1 patching closes a 2-cell loop)
+            if 'circular drainage' in str(e):       # more unfinished cells than the sequential re-seed replay accepts
+                cyclic.append(rec['case'])
                 continue
             print('DEVICE RUN FAILED', rec, repr(e)[:300])
             sys.exit(1)
