@@ -163,3 +163,38 @@ def test_hip_results_are_run_to_run_identical():
         assert np.array_equal(a, b, equal_nan=True)
     uca = outs[0][4]
     assert np.nanmin(uca) >= 900.0 - 1e-9          # every cell carries at least its own area
+
+
+@pytest.mark.parametrize('loop', ['two_cells', 'three_cells', 'two_loops'])
+def test_circular_drainage_replay_vs_oracle(loop):
+    """Hand-made flow fields on a level surface with cells that drain into each other: the tile passes stall, the
+    reference re-seeds (dem_processing.py:951-964); the device replays that loop (K5c) -- UCA and edge flags against the
+    oracle, which restates the reference's push sweep line by line."""
+    import warnings
+    from oracle import oracle as O
+    from pydem_amd import DEMProcessor
+    n, m = 9, 10
+    elev = np.full((n, m), 10.0)
+    direction = np.full((n, m), 1.5 * np.pi)          # everything drains south ...
+    E, N, W, S = 0.0, 0.5 * np.pi, np.pi, 1.5 * np.pi
+    if loop == 'two_cells':
+        direction[3, 3] = E; direction[3, 4] = W
+    elif loop == 'three_cells':                        # (3,3) -> (3,4) -> (4,4) ... back through a diagonal
+        direction[3, 3] = E; direction[3, 4] = S; direction[4, 4] = 0.75 * np.pi      # NW: back to (3,3)
+    else:
+        direction[2, 2] = E; direction[2, 3] = W
+        direction[5, 6] = S; direction[6, 6] = N
+    mag = np.ones((n, m))
+    flats = np.zeros((n, m), bool)
+    o = O.OracleDEM(elev, dX=2.0, dY=3.0)
+    o.mag, o.direction, o.flats = mag.copy(), direction.copy(), flats.astype(np.uint8)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        o.calc_uca()
+        dp = DEMProcessor(elev=elev, dX=2.0, dY=3.0, mag=mag.copy(), direction=direction.copy(), flats=flats.copy(),
+                          fill_flats=False, drain_pits_path=False)
+        uca = dp.calc_uca()
+    assert o.stats[0] > 1, "the case is meant to need the re-seed loop"
+    _close(uca, o.uca, 'uca')
+    assert np.array_equal(dp.edge_todo, o.edge_todo)
+    assert np.array_equal(dp.edge_done, o.edge_done)
