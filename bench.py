@@ -126,7 +126,8 @@ def main():
     device = local_rank % ndev
     pm = process_manager.ProcessManager(elev_source_files=tile_specs(world, n, m), elev_conditioned=True,
                                         dem_proc_kwargs={'drain_pits': bool(args.drain_pits)}, devices=[device],
-                                        keep_first_pass_uca=False)
+                                        keep_first_pass_uca=False, n_workers=world,
+                                        edge_mode=('pool' if world > 1 else 'reference'))
     exchange = "in-process"
     if world > 1:
         # process-group plumbing only (hands the RCCL id around); the strips themselves travel over RCCL
@@ -219,7 +220,8 @@ def main():
             "stages_ms": dict({k: tm[k] for k in ('slopes_directions_ms', 'stencil_kernel_ms', 'flats_ms', 'graph_ms',
                                                    'pits_ms', 'sweep_ms', 'twi_ms')}, **phase),
             "sweep": {"rounds": tm['sweep_rounds'], "kernel_launches": tm['sweep_kernel_launches'],
-                      "n_flats": tm['n_flats'], "n_pit_edges": tm['n_pit_edges'], "edge_rounds": pm.edge_rounds},
+                      "n_flats": tm['n_flats'], "n_pit_edges": tm['n_pit_edges'], "edge_rounds": pm.edge_rounds,
+                      "edge_waves": pm.edge_waves, "edge_mode": 'pool' if world > 1 else 'reference'},
             "device_bytes": tile.device_bytes(),
         }
         if args.cpu_sample:

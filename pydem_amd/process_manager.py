@@ -14,10 +14,12 @@ What is different by design:
   * tiles shard round-robin over the visible GPUs (or over the ranks of a multi-process job),
     replacing multiprocessing.Pool; the only cross-tile coupling, the UCA edge fix-up, moves
     KiB-sized edge strips between neighbours (`EdgeTransport`);
-  * the edge fix-up runs in lock-step Jacobi rounds (every tile with a finished neighbour edge
-    updates in the same round from the previous round's strips) instead of the reference's
-    one-tile-at-a-time, metric-ordered loop (:1109-1211).  Corrections are additive deltas, so
-    both reach the same fixed point up to float64 rounding (pinned by tests/golden/pm_*).
+  * the edge fix-up has the reference's two schedules: `edge_mode='reference'` is its serial loop
+    (n_workers == 1, :1140-1211: one tile at a time in metric order -- the order the pm_* goldens were
+    captured in), `edge_mode='pool'` is its multi-worker schedule (:1214-1246) as deterministic waves:
+    the best-ranked tiles with finished neighbour edges run their edge rounds concurrently (one per
+    GPU) from ONE snapshot of the strips, then the metrics of those tiles and their neighbours are
+    refreshed.  See `process_uca_edges`.
 """
 import logging
 import os
@@ -486,9 +488,9 @@ class ProcessManager(object):
         return [1] * self.n_inputs
 
     # ---- edge fix-up ------------------------------------------------------------------------
-    def _edge_inputs(self, i, snap):
+    def _edge_inputs(self, i, snap, drop_mutual_todo=True):
         """Strips for one tile from the snapshot of the previous round, with the corner rules of the
-        reference's calc_uca_ec (:250-274)."""
+        reference's calc_uca_ec (:250-274).  drop_mutual_todo=False leaves out the last rule (:274)."""
         data, done, todo, todo_nb = {}, {}, {}, {}
         own = {'left': (1, 0), 'right': (1, -1), 'top': (0, 0), 'bottom': (0, -1)}
         for key in SIDES:
@@ -514,7 +516,11 @@ class ProcessManager(object):
                         v = snap[(src, 'uca', 0, lr)][lc]
                         data[keylr][inds[0]] = v                                         # :269
                         data[keytb][inds[1]] = v                                         # :270
-        todo = {k: v & (todo_nb[k] == False) for k, v in todo.items()}                   # noqa: E712  (:274)
+        if drop_mutual_todo == 'self':
+            # only where the "neighbour" line is the tile's own edge (the mosaic border, :695-705 with no overlap found)
+            todo = {k: (v & (todo_nb[k] == False)) if self._edge_line(i, k)[0] == i else v for k, v in todo.items()}   # noqa: E712
+        elif drop_mutual_todo:
+            todo = {k: v & (todo_nb[k] == False) for k, v in todo.items()}               # noqa: E712  (:274)
         return data, done, todo
 
     def _snapshot_requests(self, i):
@@ -527,6 +533,7 @@ class ProcessManager(object):
                     req.add((src, nm, axis, idx))
             a, ix = own[key]
             req.add((i, 'edge_todo', a, ix))
+            req.add((i, 'edge_done', a, ix))                                             # pool mode: `_adopt_finished`
         for key in CORNERS:
             if self.check_1overlap(self.grid_slice[i], self.edge_data[i][key]):
                 src, lr, lc = self._edge_line(i, key)
@@ -599,6 +606,10 @@ class ProcessManager(object):
             return
         self._edge_last[i] = sig
         self._edge_cache_drop(i)
+        self._run_edge_round(i, data, done, todo)
+
+    def _run_edge_round(self, i, data, done, todo):
+        """dp.calc_uca(uca_init=uca + uca_edges, edge_init_data=...) of the worker (:276-279) on the resident tile."""
         if not self.transport.owns(i):
             return
         dp = self.tiles[i]
@@ -614,49 +625,180 @@ class ProcessManager(object):
             return np.zeros(1, int)
         return np.argpartition(-mets[:, mets_type], min(self.n_workers * 2, mets.shape[0] - 1))   # :1111-1113
 
-    def process_uca_edges(self, mets_type=0):
-        """Cross-tile UCA correction, following the reference's serial loop exactly (:1109-1211,
-        n_workers == 1): rank the tiles by the fraction of their 'todo' edge cells that face a finished
-        neighbour, run one edge round on the first (even when its count is zero), refresh the metrics of
-        that tile and its four neighbours, stop when the ranking no longer changes.  The result depends on
-        the visiting order (finished edge cells are re-synchronised with the neighbour's value at every
-        round, :806-809), so parity needs the same order: updating all tiles with a non-zero count
-        concurrently was tried and does NOT reach the single-tile answer on the reference's own cone
-        test.  The loop is latency-bound (KiB strips, long thin floods) and serial across tiles: it is
-        the Amdahl term of the multi-GPU numbers."""
+    def _neighbours(self, f):
+        """Tile f and its four side neighbours (the metrics the reference refreshes after a round, check_mets :1116-1136)."""
+        nr, nc = self.grid_id2i.shape
+        r, c, _ = self.grid_id[f]
+        out = [int(f)]
+        if c > 0: out.append(int(self.grid_id2i[r, c - 1]))
+        if c < nc - 1: out.append(int(self.grid_id2i[r, c + 1]))
+        if r > 0: out.append(int(self.grid_id2i[r - 1, c]))
+        if r < nr - 1: out.append(int(self.grid_id2i[r + 1, c]))
+        return [t for t in out if t != -1]
+
+    def _edge_setup(self):
         self.tiles_shape = [tuple(int(v) for v in self.index[i, 6:]) for i in range(self.n_inputs)]
         self.edge_rounds = 0
         self.edge_rounds_skipped = 0
+        self.edge_waves = 0
         self._edge_line_memo = {}
         self._mets = None
         self._edge_cache = {}
         self._edge_last = {}
         self.transport_is_collective = not type(self.transport) is EdgeTransport
         # every line of a tile that some round or metric of another (or the same) tile can ask for: after a tile ran
-        # its round they are refreshed in ONE batch (one device synchronisation / one collective per round)
+        # its round they are refreshed in ONE batch (one device synchronisation / one collective per round or wave)
         interest = {}
         for i in range(self.n_inputs):
             for req in self._snapshot_requests(i) | self._metric_requests(i):
                 interest.setdefault(req[0], set()).add(req)
+        return interest
+
+    def process_uca_edges(self, mets_type=0):
+        """Cross-tile UCA correction (reference :1090-1246).  Two schedules, like the reference:
+
+        edge_mode='reference' (default when n_workers == 1) follows the reference's serial loop exactly
+        (:1140-1211): rank the tiles by the fraction of their 'todo' edge cells that face a finished
+        neighbour, run one edge round on the first (even when its count is zero), refresh the metrics of
+        that tile and its four neighbours, stop when the ranking no longer changes.  The result depends on
+        the visiting order (finished edge cells are re-synchronised with the neighbour's value at every
+        round, :806-809, and :274 drops a tile's 'todo' where the neighbour is 'todo' too), so the pm_*
+        goldens of the reference are reproduced in this mode only.
+
+        edge_mode='pool' (default when n_workers > 1): `_process_uca_edges_pool`."""
+        mode = getattr(self, 'edge_mode', None) or ('reference' if self.n_workers == 1 else 'pool')
+        if mode == 'pool':
+            return self._process_uca_edges_pool(mets_type)
+        if mode != 'reference':
+            raise ValueError("edge_mode must be 'reference' or 'pool', not %r" % (mode,))
+        interest = self._edge_setup()
         mets = self.update_uca_edge_metrics()
         I = self._rank_tiles(mets, mets_type)
         I_old = np.zeros_like(I)
-        nr, nc = self.grid_id2i.shape
         while np.any(I_old != I) and self.edge_rounds < self.max_edge_rounds:
             f = int(I[0])
             self._edge_round(f)
             self._edge_lines(sorted(interest.get(f, ())))
             self.edge_rounds += 1
+            self.edge_waves += 1
             I_old[:] = I[:]
-            r, c, _ = self.grid_id[f]
-            check = [f]
-            if c > 0: check.append(self.grid_id2i[r, c - 1])
-            if c < nc - 1: check.append(self.grid_id2i[r, c + 1])
-            if r > 0: check.append(self.grid_id2i[r - 1, c])
-            if r < nr - 1: check.append(self.grid_id2i[r + 1, c])
-            check = np.unique(check)
-            mets = self.update_uca_edge_metrics(check[check != -1].tolist())
+            mets = self.update_uca_edge_metrics(sorted(set(self._neighbours(f))))
             I = self._rank_tiles(mets, mets_type)
+        return mets
+
+    def _todo_dropped(self, i, snap, todo):
+        """Number of tile i's 'todo' edge PIXELS that a round with the per-side flags `todo` (after rule :274, from
+        `_edge_inputs`) would drop: a pixel survives when any side it belongs to keeps it (corner pixels sit on two
+        strips, :726-739 ORs them)."""
+        own = {'left': (1, 0), 'right': (1, -1), 'top': (0, 0), 'bottom': (0, -1)}
+        kept = {k: todo[k].copy() for k in SIDES}
+        for keytb, keylr in (('top', 'left'), ('top', 'right'), ('bottom', 'left'), ('bottom', 'right')):
+            a = 0 if keytb == 'top' else -1          # position of the corner on the left/right strips
+            b = 0 if keylr == 'left' else -1         # ... and on the top/bottom strips
+            kept[keylr][a] = kept[keytb][b] = kept[keylr][a] | kept[keytb][b]
+        lost = {k: snap[(i, 'edge_todo',) + own[k]] & ~kept[k] for k in SIDES}
+        n = sum(int(np.count_nonzero(v)) for v in lost.values())
+        for keytb, keylr in (('top', 'left'), ('top', 'right'), ('bottom', 'left'), ('bottom', 'right')):
+            a = 0 if keytb == 'top' else -1
+            b = 0 if keylr == 'left' else -1
+            n -= int(lost[keylr][a] and lost[keytb][b])                             # a lost corner was counted twice
+        return n
+
+    def _adopt_finished(self, i, snap, done, todo):
+        """Pool mode: an edge cell whose neighbour cell is finished while the tile's own value is not (edge_done False:
+        it lies downstream of one of the tile's unresolved inlets without being an inlet itself) becomes a seed --
+        it adopts the neighbour's final value and hands the difference downstream like any other seed.  The worker of
+        the reference only re-synchronises such a cell with the neighbour's value (:806-809) AND lets it receive from
+        the seeds upstream of it in the same round (it is not 'done on the tile edge', cyutils.pyx:159-161): the
+        upstream area is then counted twice.  Whether the serial loop runs into this depends on its visiting order
+        (a corner pixel shared by four one-pixel-overlap tiles of the reference's cone test does, for some orders)."""
+        own = {'left': (1, 0), 'right': (1, -1), 'top': (0, 0), 'bottom': (0, -1)}
+        return {k: todo[k] | (done[k] & ~snap[(i, 'edge_done',) + own[k]]) for k in SIDES}
+
+    def _process_uca_edges_pool(self, mets_type=0):
+        """The reference's multi-worker schedule (:1214-1246) as deterministic waves.  The reference keeps up to
+        2 * n_workers edge rounds in flight: the best-ranked tiles (np.argpartition of the metric, :1111-1113) whose
+        count of 'todo' cells facing a finished neighbour is positive; every finished worker refreshes the metrics of
+        its tile and its neighbours (check_mets) and the free slots are refilled from the new ranking; the loop ends
+        when nothing is in flight and no candidate is left.  Which strips a worker reads depends on when the OS
+        starts it, so the reference's results are not reproducible run to run.  Here a WAVE takes the same candidates,
+        builds all their strip inputs from ONE snapshot, runs the rounds concurrently (tiles of different GPUs / ranks
+        at the same time), then refreshes the lines and metrics of everything that ran -- one strip exchange per wave.
+        Finished cells are final, so tiles that update side by side from one snapshot only see each other's values one
+        wave late.  What is NOT safe to do early is rule :274 of the worker: it drops a tile's 'todo' flag where the
+        neighbour's line is 'todo' too ("that should never happen except for floating point rounding errors") -- but
+        it also happens, legitimately, wherever the neighbour's cell sits on that neighbour's own unresolved inlet
+        edge (line ends, one-pixel overlaps) until the neighbour has run, and a dropped flag turns the cell and
+        everything downstream of it into 'done' with the upstream area missing.  The serial loop gets away with it by
+        visiting the tiles with the highest fraction first (when it does; on terrain with pits it loses cells, and
+        which ones depends on the visiting order).  The waves therefore apply :274 only as the tie-break it was
+        written for: 'todo' cells on the mosaic border (where the edge table points a tile at its own line) are dropped
+        at once -- a tile that has such cells is a candidate even with a zero count, the serial loop only cleans the
+        tiles it happens to visit -- while any tile has a seed, other mutual 'todo' cells stay 'todo'; when no tile can make progress
+        and :274 would still drop cells somewhere, ONE tile (the one that would drop most, lowest index first) runs a round with
+        :274 and gives its cells up, which seeds its neighbours.  A tile whose inputs are bit-identical to those of
+        its last round is not a candidate (the round would reproduce its state; the reference would re-run it for ever
+        when only a corner pixel keeps its count > 0)."""
+        interest = self._edge_setup()
+        mets = self.update_uca_edge_metrics()
+        width = max(1, 2 * int(self.n_workers))
+        self.edge_tiebreaks = 0
+        while self.edge_waves < self.max_edge_rounds:
+            inputs, snaps = {}, {}
+            eff = np.zeros_like(mets)
+            for a in range(self.n_inputs):
+                reqs = sorted(self._snapshot_requests(a))
+                snaps[a] = dict(zip(reqs, self._edge_lines(reqs)))
+                data, done, todo = self._edge_inputs(a, snaps[a], drop_mutual_todo='self')
+                if mets[a, 0] <= 0 and self._todo_dropped(a, snaps[a], todo) == 0:
+                    continue
+                todo = self._adopt_finished(a, snaps[a], done, todo)
+                sig = tuple(np.asarray(v[k]).tobytes() for v in (data, done, todo) for k in SIDES)
+                if self._edge_last.get(a) == sig:
+                    continue
+                inputs[a] = (data, done, todo, sig)
+                eff[a] = mets[a] if mets[a, 0] > 0 else (1e-9, 0)       # border clean-up rounds rank last
+            if inputs:
+                I = self._rank_tiles(eff, mets_type)
+                wave = [int(a) for a in I[:width] if a in inputs]
+                wave.sort()
+            else:
+                # nobody can make progress: the tie-break of :274, one tile at a time
+                best = None
+                for a in range(self.n_inputs):
+                    data, done, todo = self._edge_inputs(a, snaps[a], drop_mutual_todo=True)
+                    n = self._todo_dropped(a, snaps[a], todo)
+                    if n > 0 and (best is None or n > best[0]):
+                        best = (n, a, data, done, self._adopt_finished(a, snaps[a], done, todo))
+                if best is None:
+                    break
+                a = best[1]
+                inputs[a] = best[2:] + (None,)
+                wave = [a]
+                self.edge_tiebreaks += 1
+            for a in wave:
+                self._edge_last[a] = inputs[a][3]
+            mine = [a for a in wave if self.transport.owns(a)]
+            k = max(1, int(self.tiles_in_flight))
+            if k > 1 and len(mine) > 1:
+                # one process driving several GPUs (or several tiles of one GPU): the rounds of a wave from worker threads
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=k) as ex:
+                    list(ex.map(lambda a: self._run_edge_round(a, *inputs[a][:3]), mine))
+            else:
+                for a in mine:
+                    self._run_edge_round(a, *inputs[a][:3])
+            fetch = set()
+            for a in wave:
+                self._edge_cache_drop(a)
+                fetch |= interest.get(a, set())
+            self._edge_lines(sorted(fetch))
+            self.edge_rounds += len(wave)
+            self.edge_waves += 1
+            check = set()
+            for a in wave:
+                check.update(self._neighbours(a))
+            mets = self.update_uca_edge_metrics(sorted(check))
         return mets
 
     def process_twi(self):

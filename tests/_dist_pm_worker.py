@@ -20,11 +20,13 @@ def main():
     from pydem_amd import process_manager
     from pydem_amd.parallel import DistTransport
     name, path = sys.argv[1], sys.argv[2]
+    mode = sys.argv[3] if len(sys.argv) > 3 else 'reference'
     g = load_golden(name)
     dkw = {k: v for k, v in g['kwargs'].items() if k not in ('ny_grid', 'nx_grid', 'overlap')}
     process_manager.DEBUG = True
     pm = process_manager.ProcessManager(in_path=path, dem_proc_kwargs=dkw, elev_conditioned=True,
-                                        processor_cls=OracleProcessor, transport=False)
+                                        processor_cls=OracleProcessor, transport=False,
+                                        n_workers=(1 if mode == 'reference' else world), edge_mode=mode)
     pm.transport = DistTransport(pm, rank, world)
     import warnings
     with warnings.catch_warnings():
@@ -33,21 +35,39 @@ def main():
     order = [int(np.argmin([np.abs(g['t%02d_bounds' % j] - pm.index[i, :4]).sum() for j in range(pm.n_inputs)]))
              for i in range(pm.n_inputs)]
     checked = 0
-    for i, j in enumerate(order):
-        if not pm.transport.owns(i):
-            assert pm.tiles[i] is None
-            continue
-        T = lambda key: g['t%02d_%s' % (j, key)]
-        assert np.allclose(pm.tile_result(i, 'uca_total'), T('uca') + T('uca_edges'), rtol=1e-12, atol=1e-13, equal_nan=True), (rank, i)
-        assert np.array_equal(pm.tile_result(i, 'edge_todo'), T('edge_todo')), (rank, i)
-        assert np.array_equal(pm.tile_result(i, 'edge_done'), T('edge_done')), (rank, i)
-        assert np.allclose(pm.tile_result(i, 'twi'), T('twi'), rtol=1e-12, atol=1e-13, equal_nan=True), (rank, i)
-        checked += 1
+    if mode == 'pool':
+        # pool mode is checked against the single-process pool run of the same mosaic: same waves, identical results
+        # (what the waves converge to is tested in tests/test_process_manager_pool.py)
+        pm1 = process_manager.ProcessManager(in_path=path, dem_proc_kwargs=dkw, elev_conditioned=True,
+                                             processor_cls=OracleProcessor, n_workers=world, edge_mode='pool')
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            pm1.process_twi()
+        assert (pm.edge_waves, pm.edge_rounds) == (pm1.edge_waves, pm1.edge_rounds), (pm.edge_waves, pm1.edge_waves)
+        assert pm.edge_waves < pm.edge_rounds
+        for i in range(pm.n_inputs):
+            if not pm.transport.owns(i):
+                assert pm.tiles[i] is None
+                continue
+            for key in ('uca_total', 'edge_todo', 'edge_done', 'twi'):
+                assert np.array_equal(pm.tile_result(i, key), pm1.tile_result(i, key), equal_nan=True), (rank, i, key)
+            checked += 1
+    else:
+        for i, j in enumerate(order):
+            if not pm.transport.owns(i):
+                assert pm.tiles[i] is None
+                continue
+            T = lambda key: g['t%02d_%s' % (j, key)]
+            assert np.allclose(pm.tile_result(i, 'uca_total'), T('uca') + T('uca_edges'), rtol=1e-12, atol=1e-13, equal_nan=True), (rank, i)
+            assert np.array_equal(pm.tile_result(i, 'edge_todo'), T('edge_todo')), (rank, i)
+            assert np.array_equal(pm.tile_result(i, 'edge_done'), T('edge_done')), (rank, i)
+            assert np.allclose(pm.tile_result(i, 'twi'), T('twi'), rtol=1e-12, atol=1e-13, equal_nan=True), (rank, i)
+            checked += 1
     tot = pm.transport.allreduce_max(checked)
     assert tot >= 1
     dist.barrier()
     dist.destroy_process_group()
-    print('rank %d ok: %d tiles checked, %d edge rounds' % (rank, checked, pm.edge_rounds))
+    print('rank %d ok: %d tiles checked, %d edge rounds in %d waves (%s)' % (rank, checked, pm.edge_rounds, pm.edge_waves, mode))
 
 
 if __name__ == '__main__':

@@ -1,8 +1,9 @@
 """GPU: the ProcessManager drop-in on multi-tile mosaics against per-tile results of the unmodified
 reference ProcessManager (tests/golden/pm_*.npz; n_workers=1, DEBUG spacing like the reference's own
 tests).  Tiles start from the reference's conditioned elevation (conditioning is not on the device
-yet).  The edge fix-up runs as lock-step rounds here and one tile at a time in the reference, so
-float fields are compared at 1e-9 relative; masks, NaN patterns and facet-derived fields exactly."""
+yet).  The edge fix-up follows the reference's serial visiting order; the sums inside a round differ in order, so
+float fields are compared at 1e-9 relative; masks, NaN patterns and facet-derived fields exactly.
+Pool mode (the multi-worker schedule): the reference's acceptance cases and the oracle-backed flow."""
 import numpy as np
 import pytest
 
@@ -85,3 +86,50 @@ def test_rccl_transport_single_rank(tmp_path):
     compare_with_golden(pm, compact, order, g, _close)
     assert pm.transport.allreduce_max(3.5) == 3.5
     comm.close()
+
+
+REF_CASES = [((3, 3), 2), ((4, 5), 2), ((4, 5), 3), ((3, 3), 1), ((4, 3), 1)]    # test_end_to_end.py:86-149, (ny, nx), overlap
+
+
+@pytest.mark.parametrize('tiles,ov', REF_CASES)
+def test_pool_mode_reference_acceptance_cases(tiles, ov, tmp_path):
+    """edge_mode='pool' on the device: the reference's own acceptance test (stitched multi-tile UCA == single-tile UCA
+    on [1:-1, 1:-1], 6 decimals; NN = 32 like its class) with the rounds of a wave running side by side."""
+    import os
+    from pydem_amd import DEMProcessor, process_manager, synth
+    cone = synth.cone_scaled(32)
+    single = DEMProcessor(elev=cone, fill_flats=False, drain_pits_path=False)
+    single.dX[:] = 1; single.dY[:] = 1; single.dX2[:] = 1; single.dY2[:] = 1
+    single.calc_twi()
+    d = str(tmp_path)
+    for t, (elev, bounds) in enumerate(synth.split_mosaic(cone, tiles[0], tiles[1], ov)):
+        np.savez(os.path.join(d, 'tile_%03d.npz' % t), elev=elev, bounds=bounds)
+    process_manager.DEBUG = True
+    try:
+        pm = process_manager.ProcessManager(in_path=d, elev_conditioned=True, n_workers=8, tiles_in_flight=4)
+        pm.process_twi()
+        compact = pm.save_non_overlap_data()
+    finally:
+        process_manager.DEBUG = False
+    assert pm.edge_waves < pm.edge_rounds
+    np.testing.assert_array_almost_equal(compact['uca'][1:-1, 1:-1], single.uca[1:-1, 1:-1], decimal=6)
+
+
+@pytest.mark.parametrize('name', ['pm_fractal_2x3_ov1', 'pm_fractal_2x2_ov2', 'pm_nansea_2x2_ov2', 'pm_cone32_4x5_ov3'])
+def test_pool_mode_device_matches_oracle_backed_flow(name, tmp_path):
+    """Same waves, same masks, UCA / TWI within 1e-9 of the same host logic run with the oracle-backed processor."""
+    from oracle_processor import OracleProcessor
+    from test_process_manager_cpu import run_pm
+    g = load_golden(name)
+    pm, compact, _ = run_pm(g, str(tmp_path / 'dev'), n_workers=8, tiles_in_flight=2)
+    po, compact_o, _ = run_pm(g, str(tmp_path / 'ora'), n_workers=8, processor_cls=OracleProcessor)
+    assert (pm.edge_waves, pm.edge_rounds, pm.edge_tiebreaks) == (po.edge_waves, po.edge_rounds, po.edge_tiebreaks)
+    for i in range(pm.n_inputs):
+        assert np.array_equal(pm.tile_result(i, 'edge_todo'), po.tile_result(i, 'edge_todo')), i
+        assert np.array_equal(pm.tile_result(i, 'edge_done'), po.tile_result(i, 'edge_done')), i
+        _close(pm.tile_result(i, 'uca_total'), po.tile_result(i, 'uca_total'), 'tile %d uca' % i)
+    for key in ('uca', 'twi'):
+        a, b = compact[key], compact_o[key]
+        finite = np.isfinite(a) & np.isfinite(b)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), key
+        assert np.allclose(a[finite], b[finite], rtol=1e-9, atol=1e-12), key

@@ -6,7 +6,8 @@ from pydem_amd import process_manager
 n = int(sys.argv[1]); nt = int(sys.argv[2])
 pm = process_manager.ProcessManager(elev_source_files=bench.tile_specs(nt, n, n), elev_conditioned=True,
                                     dem_proc_kwargs={'drain_pits': os.environ.get('PM_DRAIN', '1') == '1'}, devices=[0], keep_first_pass_uca=False,
-                                    tiles_in_flight=int(os.environ.get('PM_IN_FLIGHT', '1')))
+                                    tiles_in_flight=int(os.environ.get('PM_IN_FLIGHT', '1')),
+                                    n_workers=int(os.environ.get('PM_WORKERS', '1')), edge_mode=os.environ.get('PM_EDGE_MODE') or None)
 if os.environ.get('PM_RCCL'):      # the RCCL strip transport with a single rank: its per-round overhead against the in-process one
     from pydem_amd import _ffi
     from pydem_amd.parallel import RcclTransport
@@ -25,7 +26,7 @@ for rep in range(2):
     for t in pm.tiles: t.find_flats(); t.run_twi()
     t3 = time.perf_counter()
     if os.environ.get('PICKS'): print('picks', picks); del picks[:]
-    print('n=%d tiles=%d: tiles %.1f ms, edge fix-up %.1f ms (%d rounds), twi %.1f ms' % (n, nt, (t1-t0)*1e3, (t2-t1)*1e3, pm.edge_rounds, (t3-t2)*1e3))
+    print('n=%d tiles=%d: tiles %.1f ms, edge fix-up %.1f ms (%d rounds in %d waves), twi %.1f ms' % (n, nt, (t1-t0)*1e3, (t2-t1)*1e3, pm.edge_rounds, pm.edge_waves, (t3-t2)*1e3))
 if len(sys.argv) > 3:
     import cProfile, pstats
     pr = cProfile.Profile(); pr.enable(); pm.process_aspect_slope(); pm.process_uca(); pm.process_uca_edges(); pr.disable()
