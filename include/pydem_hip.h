@@ -125,6 +125,18 @@ int pydem_uca(pydem_tile *t, pydem_options *opt);
 int pydem_uca_edge_update(pydem_tile *t, pydem_options *opt,
                           const double *const data[4], const uint8_t *const done[4],
                           const uint8_t *const todo[4]);
+/* The same edge-resolution step for the multi-worker schedule of ProcessManager.process_uca_edges
+ * (pydem/process_manager.py:1214-1246, here deterministic waves): the state of the fix-up stays on the device
+ * between rounds -- a cell is processed once, when the last unresolved inlet upstream of it resolves, instead of
+ * once per round -- so a round costs the cells it finishes, not everything downstream of its seeds.  Masks after
+ * a round (edge_todo / edge_done, :848-856) and the areas of finished cells are those of pydem_uca_edge_update;
+ * areas of cells that are still downstream of an unresolved inlet lag behind until pydem_uca_edge_flush, which
+ * hands them what their finished upstream cells hold (call it when the fix-up ends; pydem_uca_edge_update,
+ * pydem_twi and downloads of PYDEM_UCA do it implicitly).  Not available with opt->apply_uca_limit_edges (-6). */
+int pydem_uca_edge_round_inc(pydem_tile *t, pydem_options *opt,
+                             const double *const data[4], const uint8_t *const done[4],
+                             const uint8_t *const todo[4]);
+int pydem_uca_edge_flush(pydem_tile *t);
 int pydem_twi(pydem_tile *t, pydem_options *opt);
 
 /* The pit -> drain triplets built by the last pydem_uca (the reference's local pit_i, pit_j,

@@ -71,6 +71,8 @@ SYMBOLS = {
     'pydem_find_flats': (C.c_int, [_P]),
     'pydem_uca': (C.c_int, [_P, C.POINTER(Options)]),
     'pydem_uca_edge_update': (C.c_int, [_P, C.POINTER(Options), _PP, _PP, _PP]),
+    'pydem_uca_edge_round_inc': (C.c_int, [_P, C.POINTER(Options), _PP, _PP, _PP]),
+    'pydem_uca_edge_flush': (C.c_int, [_P]),
     'pydem_twi': (C.c_int, [_P, C.POINTER(Options)]),
     'pydem_tile_pit_edges': (C.c_int, [_P, C.POINTER(C.c_int64), _P, _P, _P]),
     'pydem_tile_restore_pit_slopes': (C.c_int, [_P]),
@@ -197,8 +199,8 @@ class Tile(object):
     def uca(self, opt):
         check(self.lib.pydem_uca(self._h, C.byref(opt)))
 
-    def uca_edge_update(self, opt, data, done, todo):
-        """data/done/todo: sequences (left, right, top, bottom) of 1-D arrays."""
+    def uca_edge_update(self, opt, data, done, todo, incremental=False):
+        """data/done/todo: sequences (left, right, top, bottom) of 1-D arrays.  incremental: pydem_uca_edge_round_inc."""
         n, m = self.shape
         lens = (n, n, m, m)
         d = [np.ascontiguousarray(np.asarray(a, np.float64).ravel()) for a in data]
@@ -207,7 +209,11 @@ class Tile(object):
         for arrs in (d, dn, td):
             assert [a.size for a in arrs] == list(lens), "edge strips must have n_rows / n_cols entries"
         pack = lambda xs: (C.c_void_p * 4)(*[x.ctypes.data_as(C.c_void_p) for x in xs])
-        check(self.lib.pydem_uca_edge_update(self._h, C.byref(opt), pack(d), pack(dn), pack(td)))
+        fn = self.lib.pydem_uca_edge_round_inc if incremental else self.lib.pydem_uca_edge_update
+        check(fn(self._h, C.byref(opt), pack(d), pack(dn), pack(td)))
+
+    def uca_edge_flush(self):
+        check(self.lib.pydem_uca_edge_flush(self._h))
 
     def twi(self, opt):
         check(self.lib.pydem_twi(self._h, C.byref(opt)))

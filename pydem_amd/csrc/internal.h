@@ -84,6 +84,8 @@ struct pydem_tile {
     int32_t eepoch = 0;
     int32_t *eseed = nullptr;       // seed frontier of the current edge round (cell, graph word) pairs
     bool edge_clean = false;        // edge flags / counts are zero and the masks only differ from their defaults on etodo_prev cells
+    bool einc_ready = false;        // incremental edge rounds: counts / deltas / FINAL flags are live (uca.hip K7i)
+    double *h_strip_d = nullptr; uint8_t *h_strip_f = nullptr; size_t h_strip_cap = 0;   // pinned strip staging
     int32_t etodo_prev = 0;         // cells whose edge_done byte the previous round cleared (tlist = flatlist)
     double *line_stage = nullptr;   // max(n, m) doubles: staging for column get/set
     void *lines_stage = nullptr; int lines_cap = 0;   // staging for pydem_tile_get_lines
@@ -107,6 +109,9 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt);
 int stage_twi(pydem_tile *t, const pydem_options *opt);
 int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *const data[4], const uint8_t *const done[4],
                       const uint8_t *const todo[4]);
+int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *const data[4], const uint8_t *const done[4],
+                         const uint8_t *const todo[4]);
+int stage_edge_flush(pydem_tile *t);
 int stage_synth(pydem_tile *t, uint32_t seed, int64_t row0, int64_t col0, int n_oct, int top_shift,
                 double zmin, double zrange);
 int bench_stencil(pydem_tile *t, int iters, double *avg_ms);

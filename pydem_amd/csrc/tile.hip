@@ -171,6 +171,8 @@ int pydem_tile_destroy(pydem_tile *t)
                     t->eseed, t->lines_stage, t->pits.sort_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (t->h_counters) (void)hipHostFree(t->h_counters);
+    if (t->h_strip_d) (void)hipHostFree(t->h_strip_d);
+    if (t->h_strip_f) (void)hipHostFree(t->h_strip_f);
     for (int i = 0; i < 8; i++) if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
@@ -235,6 +237,7 @@ int pydem_tile_set_spacing(pydem_tile *t, const double *dX, const double *dY, co
 int pydem_tile_upload(pydem_tile *t, int field, const void *src, int dtype)
 {
     t->edge_clean = false;
+    t->einc_ready = false;
     HIP_TRY(hipSetDevice(t->device));
     void **pp; size_t elem;
     PYDEM_TRY(field_ptr(t, field, &pp, &elem));
@@ -278,6 +281,7 @@ int pydem_tile_download(pydem_tile *t, int field, void *dst)
     void **pp; size_t elem;
     PYDEM_TRY(field_ptr(t, field, &pp, &elem));
     if (!*pp || !t->have[field]) { pydem_set_error("field %d has not been computed or uploaded", field); return -3; }
+    if (field == PYDEM_UCA) PYDEM_TRY(stage_edge_flush(t));     // incremental edge rounds: settle what is still waiting upstream
     HIP_TRY(hipMemcpyAsync(dst, *pp, (size_t)t->NN * elem, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     return 0;
@@ -395,6 +399,7 @@ static int need(pydem_tile *t, int field, const char *what)
 int pydem_slopes_directions(pydem_tile *t)
 {
     t->edge_clean = false;      // these stages reuse the edge-round work lists
+    t->einc_ready = false;
     HIP_TRY(hipSetDevice(t->device));
     PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_slopes_directions"));
     if (!t->spacing_set) { pydem_set_error("pydem_slopes_directions: call pydem_tile_set_spacing first"); return -3; }
@@ -424,6 +429,7 @@ int pydem_find_flats(pydem_tile *t)
 int pydem_uca(pydem_tile *t, pydem_options *opt)
 {
     t->edge_clean = false;      // these stages reuse the edge-round work lists
+    t->einc_ready = false;
     HIP_TRY(hipSetDevice(t->device));
     PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_uca"));
     PYDEM_TRY(need(t, PYDEM_MAG, "pydem_uca"));
@@ -469,9 +475,29 @@ int pydem_uca_edge_update(pydem_tile *t, pydem_options *opt, const double *const
     return 0;
 }
 
+int pydem_uca_edge_round_inc(pydem_tile *t, pydem_options *opt, const double *const data[4],
+                             const uint8_t *const done[4], const uint8_t *const todo[4])
+{
+    HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(need(t, PYDEM_UCA, "pydem_uca_edge_round_inc"));
+    PYDEM_TRY(need(t, PYDEM_FLATS, "pydem_uca_edge_round_inc"));
+    PYDEM_TRY(need(t, PYDEM_EDGE_TODO, "pydem_uca_edge_round_inc"));
+    PYDEM_TRY(need(t, PYDEM_EDGE_DONE, "pydem_uca_edge_round_inc"));
+    if (!t->graph_valid) { pydem_set_error("pydem_uca_edge_round_inc: the flow graph of pydem_uca is not resident"); return -3; }
+    PYDEM_TRY(stage_edge_round_inc(t, opt, data, done, todo));
+    return 0;
+}
+
+int pydem_uca_edge_flush(pydem_tile *t)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    return stage_edge_flush(t);
+}
+
 int pydem_twi(pydem_tile *t, pydem_options *opt)
 {
     HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(stage_edge_flush(t));
     PYDEM_TRY(need(t, PYDEM_UCA, "pydem_twi"));
     PYDEM_TRY(need(t, PYDEM_MAG, "pydem_twi"));
     PYDEM_TRY(ensure_field(t, PYDEM_TWI));
@@ -518,6 +544,7 @@ int pydem_tile_restore_pit_slopes(pydem_tile *t)
 int pydem_bench_stencil(pydem_tile *t, int iters, double *avg_ms)
 {
     t->edge_clean = false;      // these stages reuse the edge-round work lists
+    t->einc_ready = false;
     HIP_TRY(hipSetDevice(t->device));
     PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_bench_stencil"));
     if (!t->spacing_set) { pydem_set_error("pydem_bench_stencil: call pydem_tile_set_spacing first"); return -3; }

@@ -1489,6 +1489,226 @@ __global__ void k_edge_cleanup(EdgeArgs E, const int32_t *nr, const int32_t *nt)
     }
 }
 
+
+// ------------------------------------------------------------------------------- K7i
+// Incremental edge rounds (the pool schedule of the ProcessManager).  A round of the kind above walks
+// everything downstream of its seeds -- whole rivers -- although most of those cells stay downstream of
+// another unresolved inlet and are of no use to anybody until that one resolves too; a river that runs along a
+// tile border hands a seed across it dozens of times and each hand-over re-walks the rest of the river
+// (measured: 247 rounds, 3-7 ms each, for an 8-tile mosaic).  Here the state of the fix-up persists between
+// rounds instead:
+//   * ND, the cells that are not 'done' (edge_done == 0: downstream of an unresolved inlet), is closed under
+//     "downstream of"; the count field of the graph word holds, for every cell, the number of its in-edges
+//     that come from ND cells, plus ONE for the outside of the tile while the cell is an unresolved inlet
+//     (edge_todo == 1);
+//   * a cell is 'done' when its count reaches zero (nothing unresolved is left upstream of it): it then PULLS
+//     the deltas of its upstream cells in the fixed neighbour order (deterministic, no floating-point
+//     atomics), adds the sum to its area and counts its targets down.  A seed adopts the neighbour's finished
+//     value when the strip arrives (it never receives, cyutils.pyx:159-161) and loses its outside edge; it is
+//     'done' like any other cell, when its count reaches zero, and only then lets go of its targets;
+//   * deltas wait in the FINAL upstream cells (delta[]) until the cell below them becomes final: every cell is
+//     processed exactly once in the whole fix-up, and a round only costs the chain of cells it finishes.
+// When the fix-up ends, the cells that are still not done (their inlet never resolved) pull what their FINAL
+// upstream cells hold (pydem_uca_edge_flush): the reference propagates those partial sums round by round
+// (:836-842), the areas agree up to the order of the additions.  'done' / 'todo' masks after every round are
+// the reference's: edge_done = not downstream of a remaining 'todo' inlet (:848-856), edge_todo = the inlets
+// that stay 'todo' (:817).
+constexpr uint32_t EF_FINAL = 16u;
+
+struct IncArgs {
+    SweepArgs G;
+    uint32_t *flag;          // [NN] EF_FINAL
+    double *delta;           // [NN] valid where EF_FINAL
+    const uint8_t *flats;
+    uint8_t *edge_done, *edge_todo;
+    double *uca;
+    const int2 *pit_off;
+    int set_done;            // 0 in the final flush: the cells stay 'not done'
+};
+
+// once per fix-up: counts of the ND sub-graph
+__global__ __launch_bounds__(256) void k_einc_prepare(IncArgs E, int64_t NN)
+{
+    const SweepArgs &A = E.G;
+    for (int64_t c64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c64 < NN; c64 += (int64_t)gridDim.x * blockDim.x) {
+        if (E.edge_done[c64]) continue;
+        const int32_t u = (int32_t)c64;
+        E.delta[u] = 0.0;
+        const uint32_t cw = A.cinfo[u];
+        const int s = ci_section(cw);
+        if (cw & CI_OUT1) atomicAdd(&A.cinfo[u + fe1r(s) * A.m + fe1c(s)], CI_EONE);
+        if (cw & CI_OUT2) atomicAdd(&A.cinfo[u + fe2r(s) * A.m + fe2c(s)], CI_EONE);
+        if (cw & CI_PIT_OUT)
+            for (int32_t e = E.pit_off[u].y; e < A.n_pit && A.pit_src[e] == u; e++) atomicAdd(&A.cinfo[A.pit_dst[e]], CI_EONE);
+        if (E.edge_todo[u]) atomicAdd(&A.cinfo[u], CI_EONE);                     // the outside of the tile
+    }
+}
+
+__device__ __forceinline__ void perim_cell(int64_t p, int n, int m, int &i, int &j)
+{
+    if (p < m) { i = 0; j = (int)p; }
+    else if (p < 2 * (int64_t)m) { i = n - 1; j = (int)(p - m); }
+    else if (p < 2 * (int64_t)m + (n - 2)) { i = (int)(p - 2 * (int64_t)m) + 1; j = 0; }
+    else { i = (int)(p - 2 * (int64_t)m - (n - 2)) + 1; j = m - 1; }
+}
+
+// strips -> events on the perimeter (:726-739, :798-809).  Queue entries are cells whose count reached zero.
+__global__ void k_einc_seed(IncArgs E, const double *__restrict__ sdata, const uint8_t *__restrict__ sdone,
+                            const uint8_t *__restrict__ stodo, int L, QE *q, int32_t *nq)
+{
+    const int n = E.G.n, m = E.G.m;
+    const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nper) return;
+    int i, j;
+    perim_cell(p, n, m, i, j);
+    const int32_t c = i * m + j;
+    bool dn = false, td = false;
+    double init = 0.0;
+    // dict order of the reference: left, right, top, bottom
+    if (j == 0) { dn |= sdone[0 * L + i] != 0; init += sdata[0 * L + i] * (double)(sdone[0 * L + i] != 0); td |= stodo[0 * L + i] != 0; }
+    if (j == m - 1) { dn |= sdone[1 * L + i] != 0; init += sdata[1 * L + i] * (double)(sdone[1 * L + i] != 0); td |= stodo[1 * L + i] != 0; }
+    if (i == 0) { dn |= sdone[2 * L + j] != 0; init += sdata[2 * L + j] * (double)(sdone[2 * L + j] != 0); td |= stodo[2 * L + j] != 0; }
+    if (i == n - 1) { dn |= sdone[3 * L + j] != 0; init += sdata[3 * L + j] * (double)(sdone[3 * L + j] != 0); td |= stodo[3 * L + j] != 0; }
+    const bool own_todo = E.edge_todo[c] != 0;
+    const bool own_done = E.edge_done[c] != 0;
+    const uint32_t cw = E.G.cinfo[c] & CI_STATIC_MASK;
+    if (dn) {
+        const double d = E.flats[c] ? NAN : init - E.uca[c];                     // :806-809, :815
+        if (!(E.flag[c] & EF_FINAL) && !own_done) {
+            // a seed (:798), or a cell below one of the tile's own unresolved inlets whose neighbour copy is finished:
+            // it adopts the finished value (it will not pull) and holds the difference for the cells below it.  It is
+            // 'done' -- and lets go of its targets -- once nothing unresolved is left upstream of it inside the tile
+            E.uca[c] += d;
+            E.delta[c] = d;
+            E.flag[c] = EF_FINAL;
+            E.edge_todo[c] = 0;
+            if (own_todo) {
+                const uint32_t old = atomicSub(&E.G.cinfo[c], CI_EONE);          // the outside of the tile
+                if (ci_ecount(old) == 1u) { QE e; e.c = c; e.cw = cw; q[agg_slot(nq)] = e; }
+            }
+        } else {
+            E.uca[c] += d;                                                      // finished on both sides: re-synchronised
+            E.edge_todo[c] = 0;
+        }
+    } else if (own_todo && !td) {
+        // the 'todo' flag was dropped without a value (rule :274 / the mosaic border): the outside edge goes away
+        E.edge_todo[c] = 0;
+        const uint32_t old = atomicSub(&E.G.cinfo[c], CI_EONE);
+        if (ci_ecount(old) == 1u) { QE e; e.c = c; e.cw = cw; q[agg_slot(nq)] = e; }
+    }
+}
+
+// the final flush: the remaining inlets let go of the outside (their flags stay)
+__global__ void k_einc_release_todo(IncArgs E, QE *q, int32_t *nq)
+{
+    const int n = E.G.n, m = E.G.m;
+    const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nper) return;
+    int i, j;
+    perim_cell(p, n, m, i, j);
+    const int32_t c = i * m + j;
+    if (!E.edge_todo[c] || (E.flag[c] & EF_FINAL)) return;
+    const uint32_t old = atomicSub(&E.G.cinfo[c], CI_EONE);
+    if (ci_ecount(old) == 1u) { QE e; e.c = c; e.cw = E.G.cinfo[c] & CI_STATIC_MASK; q[agg_slot(nq)] = e; }
+}
+
+template <typename Push>
+__device__ __forceinline__ void einc_cell(const IncArgs &E, QE q, Push push)
+{
+    const SweepArgs &A = E.G;
+    const int32_t c = q.c;
+    const uint32_t cw = q.cw;
+    const int m = A.m;
+    int2 po = make_int2(0, 0);
+    if (cw & (CI_PIT_IN | CI_PIT_OUT)) po = E.pit_off[c];
+    if (!(E.flag[c] & EF_FINAL)) {                                               // (seeds keep the value they adopted)
+        uint32_t f[8]; double dl[8], pr[8];
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            f[d] = 0; dl[d] = 0.0; pr[d] = 0.0;
+            if (cw & (1u << d)) {
+                const int32_t u = c + NB_DI[d] * m + NB_DJ[d];
+                f[d] = E.flag[u]; dl[d] = E.delta[u]; pr[d] = A.prop[u];
+            }
+        }
+        double acc = E.flats[c] ? NAN : 0.0;                                     // :815
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            if ((cw & (1u << d)) && (f[d] & EF_FINAL)) {
+                const bool cardinal = (NB_DI[d] == 0) || (NB_DJ[d] == 0);
+                acc += dl[d] * (cardinal ? pr[d] : 1 - pr[d]);
+            }
+        }
+        if (cw & CI_PIT_IN)
+            for (int32_t e = po.x; e < A.n_pit && A.pin_dst[e] == c; e++)
+                if (E.flag[A.pin_src[e]] & EF_FINAL) acc += E.delta[A.pin_src[e]] * A.pin_w[e];
+        E.delta[c] = acc;
+        E.uca[c] += acc;
+        E.flag[c] = EF_FINAL;
+    }
+    if (E.set_done) E.edge_done[c] = 1;
+    const int s = ci_section(cw);
+    auto release = [&](int32_t t) {
+        const uint32_t old = atomicSub(&A.cinfo[t], CI_EONE);
+        if (ci_ecount(old) == 1u) push(t, old & CI_STATIC_MASK);
+    };
+    if (cw & CI_OUT1) release(c + fe1r(s) * m + fe1c(s));
+    if (cw & CI_OUT2) release(c + fe2r(s) * m + fe2c(s));
+    if (cw & CI_PIT_OUT)
+        for (int32_t e = po.y; e < A.n_pit && A.pit_src[e] == c; e++) release(A.pit_dst[e]);
+}
+
+__global__ __launch_bounds__(256) void k_einc_level(IncArgs E, const QE *__restrict__ qc, QE *__restrict__ qn, int32_t *cnt3, int r)
+{
+    const int32_t nq = cnt3[r % 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt3[(r + 2) % 3] = 0;
+    if (nq == 0) return;
+    int32_t *cn = &cnt3[(r + 1) % 3];
+    for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nq; k += gridDim.x * blockDim.x) {
+        auto push = [&](int32_t t, uint32_t ct) { QE e; e.c = t; e.cw = ct; qn[agg_slot(cn)] = e; };
+        einc_cell(E, qc[k], push);
+    }
+}
+
+// small frontiers: one workgroup, level after level (see k_edge_small)
+__global__ __launch_bounds__(1024) void k_einc_small(IncArgs E, QE *q0, QE *q1, int32_t *cnt3, int r_start, int32_t *state)
+{
+    __shared__ QE s_q[2][SMALL_CAP];
+    __shared__ int32_t s_next;
+    int r = r_start;
+    int32_t nq = cnt3[r % 3];
+    if (nq > 0 && nq <= SMALL_CAP) {
+        const QE *qc = (r % 2) ? q1 : q0;
+        for (int32_t k = threadIdx.x; k < nq; k += blockDim.x) s_q[r % 2][k] = qc[k];
+    }
+    __syncthreads();
+    while (nq > 0 && nq <= SMALL_CAP) {
+        if (threadIdx.x == 0) s_next = 0;
+        __syncthreads();
+        QE *qn = (r % 2) ? q0 : q1;
+        QE *ln = s_q[(r + 1) % 2];
+        for (int32_t k = threadIdx.x; k < nq; k += blockDim.x) {
+            auto push = [&](int32_t t, uint32_t ct) {
+                QE e; e.c = t; e.cw = ct;
+                const int32_t slot = agg_slot(&s_next);
+                if (slot < SMALL_CAP) ln[slot] = e;
+                qn[slot] = e;
+            };
+            einc_cell(E, s_q[r % 2][k], push);
+        }
+        __syncthreads();
+        nq = s_next;
+        r++;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        cnt3[r % 3] = nq; cnt3[(r + 1) % 3] = 0; cnt3[(r + 2) % 3] = 0;
+        state[0] = r;
+    }
+}
+
 int grid_for(int64_t work, int cap) { const int64_t g = cdiv(work, 256); return (int)(g < cap ? (g > 0 ? g : 1) : cap); }
 
 }  // namespace
@@ -1497,6 +1717,7 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt)
 {
     const int n = (int)t->n, m = (int)t->m;
     t->edge_clean = false;
+    t->einc_ready = false;
     PYDEM_TRY(tile_alloc(t, &t->todo_work, (size_t)t->NN));
     PYDEM_TRY(tile_alloc(t, &t->indeg, (size_t)t->NN));          // the cinfo words
     const dim3 grid2((unsigned)(cdiv(m, 256) < 64 ? cdiv(m, 256) : 64), (unsigned)(n < 16384 ? n : 16384));
@@ -1815,6 +2036,7 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
                       const uint8_t *const todo[4])
 {
     (void)opt;
+    if (t->einc_ready) PYDEM_TRY(stage_edge_flush(t));      // incremental rounds left deltas waiting: settle them first
     const double t_begin = host_now_ms();
     const int n = (int)t->n, m = (int)t->m;
     PYDEM_TRY(tile_alloc(t, &t->row_area, (size_t)t->n));
@@ -1929,5 +2151,122 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
     if (getenv("PYDEM_EDGE_DEBUG"))
         fprintf(stderr, "edge round: %d seeds, %d todo cells, %d cells reached; levels: floods %d (%d wide), sweep %d (%d wide); %.3f ms\n",
                 nseed, t->h_counters[7], t->h_counters[6], dbg_rounds[0], dbg_wide[0], dbg_rounds[1], dbg_wide[1], host_now_ms() - t_begin);
+    return 0;
+}
+
+// ---- incremental edge rounds: host side ----------------------------------------------------------------
+static int einc_args(pydem_tile *t, IncArgs &E)
+{
+    PYDEM_TRY(tile_alloc(t, &t->row_area, (size_t)t->n));
+    PYDEM_TRY(tile_alloc(t, &t->estamp, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->edelta, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->queue[0], (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->queue[1], (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->contrib, (size_t)t->NN * 2));
+    fill_sweep_args(t, E.G);
+    E.flag = (uint32_t *)t->estamp; E.delta = t->edelta; E.flats = t->flats; E.edge_done = t->edge_done; E.edge_todo = t->edge_todo;
+    E.uca = t->uca; E.pit_off = reinterpret_cast<const int2 *>(t->contrib); E.set_done = 1;
+    return 0;
+}
+
+// run the cascade whose first frontier is in queue[0] / counters[0]; ONE host synchronisation when the frontier stays small
+static int einc_cascade(pydem_tile *t, const IncArgs &E, int *levels)
+{
+    int32_t *cnt3 = t->counters;
+    int32_t *state = t->counters + 12;
+    QE *q0 = (QE *)t->queue[0], *q1 = (QE *)t->queue[1];
+    int r = 0;
+    for (;;) {
+        hipLaunchKernelGGL(k_einc_small, dim3(1), dim3(1024), 0, t->stream, E, q0, q1, cnt3, r, state);
+        HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        r = t->h_counters[12];
+        int32_t last = t->h_counters[r % 3];
+        if (last == 0) break;
+        // the frontier outgrew one workgroup: level kernels until it is small again
+        while (last > SMALL_CAP) {
+            const int batch = last > 65536 ? 4 : 16;
+            const int grid = grid_for(last, 1024);
+            for (int b = 0; b < batch; b++, r++)
+                hipLaunchKernelGGL(k_einc_level, dim3(grid), dim3(256), 0, t->stream, E, (r % 2) ? q1 : q0, (r % 2) ? q0 : q1, cnt3, r);
+            HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            last = t->h_counters[r % 3];
+            if (r > (1 << 24)) { pydem_set_error("edge update: flow paths too long"); return -5; }
+        }
+        if (last == 0) break;
+    }
+    if (levels) *levels = r;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *const data[4], const uint8_t *const done[4],
+                         const uint8_t *const todo[4])
+{
+    if (opt->apply_uca_limit_edges) {
+        // edge_done is then more than "not downstream of a 'todo' inlet" (:977-980): the counts below would be wrong
+        pydem_set_error("incremental edge rounds do not support apply_uca_limit_edges; use pydem_uca_edge_update");
+        return -6;
+    }
+    const double t_begin = host_now_ms();
+    const int n = (int)t->n, m = (int)t->m;
+    const int L = n > m ? n : m;
+    const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
+    IncArgs E;
+    PYDEM_TRY(einc_args(t, E));
+    PYDEM_TRY(tile_alloc(t, &t->s_data, (size_t)L * 4));
+    PYDEM_TRY(tile_alloc(t, &t->s_flags, (size_t)L * 8));
+    if (!t->einc_ready) {
+        if (E.G.n_pit > 0)
+            hipLaunchKernelGGL(k_pit_offsets, dim3(grid_for(E.G.n_pit, 2048)), dim3(256), 0, t->stream, E.G.pin_dst, E.G.pit_src, E.G.n_pit,
+                               reinterpret_cast<int2 *>(t->contrib));
+        HIP_TRY(hipMemsetAsync(t->estamp, 0, (size_t)t->NN * 4, t->stream));
+        hipLaunchKernelGGL(k_edge_clear_levels, dim3(grid_for(t->NN, 8192)), dim3(256), 0, t->stream, E.G.cinfo, t->NN);
+        hipLaunchKernelGGL(k_einc_prepare, dim3(grid_for(t->NN, 8192)), dim3(256), 0, t->stream, E, t->NN);
+        t->einc_ready = true;
+        t->edge_clean = false;          // the classic rounds find their zeroed state gone
+    }
+    // strips -> device (left, right, top, bottom), padded to L entries each (pinned staging: the copies are asynchronous)
+    if (t->h_strip_cap < (size_t)L) {
+        if (t->h_strip_d) { (void)hipHostFree(t->h_strip_d); (void)hipHostFree(t->h_strip_f); }
+        HIP_TRY(hipHostMalloc((void **)&t->h_strip_d, (size_t)L * 4 * sizeof(double)));
+        HIP_TRY(hipHostMalloc((void **)&t->h_strip_f, (size_t)L * 8));
+        t->h_strip_cap = (size_t)L;
+    }
+    double *hd = t->h_strip_d;
+    uint8_t *hf = t->h_strip_f;
+    for (int s = 0; s < 4; s++) {
+        const int len = s < 2 ? n : m;
+        for (int k = 0; k < len; k++) {
+            hd[(size_t)s * L + k] = data[s][k];
+            hf[(size_t)s * L + k] = done[s][k] != 0;
+            hf[(size_t)(4 + s) * L + k] = todo[s][k] != 0;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(t->s_data, hd, (size_t)L * 4 * 8, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->s_flags, hf, (size_t)L * 8, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
+    hipLaunchKernelGGL(k_einc_seed, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, E, t->s_data, t->s_flags,
+                       t->s_flags + (size_t)4 * L, L, (QE *)t->queue[0], &t->counters[0]);
+    int levels = 0;
+    PYDEM_TRY(einc_cascade(t, E, &levels));
+    if (getenv("PYDEM_EDGE_DEBUG"))
+        fprintf(stderr, "incremental edge round: %d levels; %.3f ms\n", levels, host_now_ms() - t_begin);
+    return 0;
+}
+
+int stage_edge_flush(pydem_tile *t)
+{
+    if (!t->einc_ready) return 0;
+    const int n = (int)t->n, m = (int)t->m;
+    const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
+    IncArgs E;
+    PYDEM_TRY(einc_args(t, E));
+    E.set_done = 0;
+    HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
+    hipLaunchKernelGGL(k_einc_release_todo, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, E, (QE *)t->queue[0], &t->counters[0]);
+    PYDEM_TRY(einc_cascade(t, E, nullptr));
+    t->einc_ready = false;              // counts and deltas are spent: the next incremental round starts from the masks again
     return 0;
 }

@@ -336,13 +336,16 @@ class DEMProcessor(object):
         self.run_uca(edge_init_data=edge_init_data, uca_init=uca_init)
         return self.uca
 
-    def run_uca(self, edge_init_data=None, uca_init=None, uca_resident=False):
+    def run_uca(self, edge_init_data=None, uca_init=None, uca_resident=False, incremental=False):
         """calc_uca without bringing the result back to the host.  `uca_resident=True` (edge rounds only)
-        says uca_init is the tile's own device-resident UCA, so nothing is uploaded."""
+        says uca_init is the tile's own device-resident UCA, so nothing is uploaded; `incremental=True` (with
+        uca_resident) runs the round on the persistent fix-up state (pydem_uca_edge_round_inc): finished cells and
+        masks are those of the plain round, cells below an unresolved inlet are settled by `flush_edge_rounds()`."""
         if not self._has('direction'):
             self.run_slopes_directions()
         if uca_init is not None or uca_resident:
-            return self._calc_uca_edge_round(uca_init, edge_init_data, uca_resident)
+            return self._calc_uca_edge_round(uca_init, edge_init_data, uca_resident,
+                                             incremental and uca_resident and not self.apply_uca_limit_edges)
         if not self.drain_pits and (self.drain_flats or self.drain_pits_spill):
             # (_mk_connectivity_flats / _mk_connectivity_pits_spill, dem_processing.py:1108-1123: alternatives the
             # reference itself labels "not a great option"; only reachable with drain_pits=False)
@@ -372,7 +375,13 @@ class DEMProcessor(object):
             self._tile.restore_pit_slopes()
             self._host.pop('mag', None)
 
-    def _calc_uca_edge_round(self, uca_init, edge_init_data, uca_resident=False):
+    def flush_edge_rounds(self):
+        """End of a series of incremental edge rounds (no-op otherwise)."""
+        if self._tile is not None:
+            self._tile.uca_edge_flush()
+            self._host.pop('uca', None)
+
+    def _calc_uca_edge_round(self, uca_init, edge_init_data, uca_resident=False, incremental=False):
         """calc_uca(uca_init=..., edge_init_data=[data, done, todo]) of the reference (:724-771):
         only the contributions entering through finished neighbour edges are propagated."""
         keys = ('left', 'right', 'top', 'bottom')
@@ -392,7 +401,8 @@ class DEMProcessor(object):
         self._push('elev', 'mag', 'direction', 'flats', 'uca')
         opt = self._options()
         logger.info("Starting edge resolution round")
-        self._tile.uca_edge_update(opt, [data[k] for k in keys], [done[k] for k in keys], [todo[k] for k in keys])
+        self._tile.uca_edge_update(opt, [data[k] for k in keys], [done[k] for k in keys], [todo[k] for k in keys],
+                                   incremental=incremental and 'edge_done' in self._on_device)
         self._produced('uca', 'edge_todo', 'edge_done', 'mag', 'flats', 'section', 'proportion')
 
     def calc_twi(self):

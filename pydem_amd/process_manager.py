@@ -23,6 +23,7 @@ What is different by design:
 """
 import logging
 import os
+import time
 
 import numpy as np
 
@@ -608,15 +609,23 @@ class ProcessManager(object):
         self._edge_cache_drop(i)
         self._run_edge_round(i, data, done, todo)
 
-    def _run_edge_round(self, i, data, done, todo):
-        """dp.calc_uca(uca_init=uca + uca_edges, edge_init_data=...) of the worker (:276-279) on the resident tile."""
+    def _run_edge_round(self, i, data, done, todo, incremental=False):
+        """dp.calc_uca(uca_init=uca + uca_edges, edge_init_data=...) of the worker (:276-279) on the resident tile.
+        incremental (pool waves, device processor): the round runs on the fix-up state the tile keeps between rounds."""
         if not self.transport.owns(i):
             return
         dp = self.tiles[i]
+        t0 = time.perf_counter()
+        try:
+            self._run_edge_round_inner(i, dp, data, done, todo, incremental)
+        finally:
+            self.edge_round_log.append((self.edge_waves, i, (time.perf_counter() - t0) * 1e3))
+
+    def _run_edge_round_inner(self, i, dp, data, done, todo, incremental=False):
         if self.keep_first_pass_uca and self.uca0[i] is None:
             self.uca0[i] = np.array(dp.uca)              # the reference keeps the first pass as 'uca'
         if hasattr(dp, 'run_uca'):
-            dp.run_uca(edge_init_data=[data, done, todo], uca_resident=True)
+            dp.run_uca(edge_init_data=[data, done, todo], uca_resident=True, incremental=incremental)
         else:
             dp.calc_uca(uca_init=dp.uca, edge_init_data=[data, done, todo])
 
@@ -641,6 +650,7 @@ class ProcessManager(object):
         self.edge_rounds = 0
         self.edge_rounds_skipped = 0
         self.edge_waves = 0
+        self.edge_round_log = []           # (wave, tile, host ms) of every round this process ran
         self._edge_line_memo = {}
         self._mets = None
         self._edge_cache = {}
@@ -743,6 +753,7 @@ class ProcessManager(object):
         mets = self.update_uca_edge_metrics()
         width = max(1, 2 * int(self.n_workers))
         self.edge_tiebreaks = 0
+        inc = bool(getattr(self, 'edge_incremental', True))
         while self.edge_waves < self.max_edge_rounds:
             inputs, snaps = {}, {}
             eff = np.zeros_like(mets)
@@ -784,10 +795,10 @@ class ProcessManager(object):
                 # one process driving several GPUs (or several tiles of one GPU): the rounds of a wave from worker threads
                 from concurrent.futures import ThreadPoolExecutor
                 with ThreadPoolExecutor(max_workers=k) as ex:
-                    list(ex.map(lambda a: self._run_edge_round(a, *inputs[a][:3]), mine))
+                    list(ex.map(lambda a: self._run_edge_round(a, *inputs[a][:3], incremental=inc), mine))
             else:
                 for a in mine:
-                    self._run_edge_round(a, *inputs[a][:3])
+                    self._run_edge_round(a, *inputs[a][:3], incremental=inc)
             fetch = set()
             for a in wave:
                 self._edge_cache_drop(a)
@@ -799,6 +810,9 @@ class ProcessManager(object):
             for a in wave:
                 check.update(self._neighbours(a))
             mets = self.update_uca_edge_metrics(sorted(check))
+        for a in self._owned():                   # incremental rounds: cells still below an unresolved inlet catch up
+            if hasattr(self.tiles[a], 'flush_edge_rounds'):
+                self.tiles[a].flush_edge_rounds()
         return mets
 
     def process_twi(self):

@@ -1,0 +1,5 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r2b
+timeout 900 python -m pytest tests/test_gpu_edge_update.py tests/test_gpu_process_manager.py tests/test_gpu_soak.py -m gpu -q > gpurun_out/r2b/gpu_tests.log 2>&1; echo "pytest rc $?" >> gpurun_out/r2b/gpu_tests.log
+PM_WORKERS=8 PM_EDGE_MODE=pool PYDEM_EDGE_DEBUG=1 timeout 600 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/r2b/pm_pool_16384.log 2>&1
