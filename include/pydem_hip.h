@@ -136,6 +136,8 @@ int pydem_uca_edge_update(pydem_tile *t, pydem_options *opt,
 int pydem_uca_edge_round_inc(pydem_tile *t, pydem_options *opt,
                              const double *const data[4], const uint8_t *const done[4],
                              const uint8_t *const todo[4]);
+/* the same round with the strips already in the tile's device buffers (written by pydem_board_eval) */
+int pydem_uca_edge_round_inc_dev(pydem_tile *t, pydem_options *opt);
 int pydem_uca_edge_flush(pydem_tile *t);
 int pydem_twi(pydem_tile *t, pydem_options *opt);
 
@@ -184,6 +186,35 @@ int pydem_comm_pack_lines(pydem_comm *c, pydem_tile *t, int count, const int *fi
                           const int64_t *offsets);
 int pydem_comm_put(pydem_comm *c, const double *host_in, int64_t n_doubles, int64_t offset);
 int pydem_comm_allreduce(pydem_comm *c, int64_t n_doubles, int op /* 0 sum, 1 max */, double *host_out);
+
+/* ---- edge board: the strips of ProcessManager.process_uca_edges stay on the device (comm.hip).
+ * Replaces what the reference's edge worker and manager do on the host for every round: reading the neighbour
+ * lines from the store, the corner rules and rule :274 (pydem/process_manager.py:243-274), the metrics
+ * (calc_uca_ec_metrics :199-221).  The board holds every line some tile reads (doubles; masks as 0 / 1) at fixed
+ * offsets, identically on every rank.
+ *   pydem_board_set_desc  where tile `index` finds its lines: offsets28 = own_todo[4], own_done[4], nb_uca[4],
+ *                         nb_done[4], nb_todo[4] (sides left, right, top, bottom), cnr_done[4], cnr_uca[4] (diagonal
+ *                         pixel of the corners tl, tr, bl, br); -1 = missing; flags8 = nb_self[4] (the edge table
+ *                         points the tile at its own line), cnr_1ov[4] (check_1overlap :286-293); `tile` = the
+ *                         resident tile whose strip buffers the evaluation fills (NULL: a tile of another rank)
+ *   pydem_board_refresh   after a wave: this rank packs the listed lines of its tiles into the wave staging buffer,
+ *                         one ncclAllReduce(sum) over disjoint fills when `c` spans several ranks, then the nseg
+ *                         segments (staging offset, board offset, length) are copied into the board
+ *   pydem_board_eval      strips (data, done, todo after the corner rules, rule :274 -- everywhere if full[k], else
+ *                         only on the mosaic border -- and the adoption of finished neighbour values) into the
+ *                         tiles' buffers, and 8 words per tile to `out` (all tiles of the board): cells 'todo' and
+ *                         facing a finished neighbour, cells 'todo', 'todo' pixels the border rule / full rule :274
+ *                         would drop, seeds, a hash of the strips */
+typedef struct pydem_board pydem_board;
+int pydem_board_create(int device, int n_tiles, int64_t n_doubles, pydem_board **out);
+int pydem_board_destroy(pydem_board *b);
+int pydem_board_set_desc(pydem_board *b, int index, int32_t n, int32_t m, const int64_t *offsets28, const int32_t *flags8,
+                         pydem_tile *tile);
+int pydem_board_refresh(pydem_board *b, pydem_comm *c, int64_t wave_doubles, int nseg, const int64_t *seg3,
+                        int count, pydem_tile *const *tiles, const int *fields, const int *axes, const int64_t *indices,
+                        const int64_t *wb_offsets);
+int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *full, unsigned long long *out);
+int pydem_board_download(pydem_board *b, double *out);
 
 /* ---- elevation conditioning: host-side inner loops (no device work; pydem_amd/conditioning.py keeps the
  * vectorised prologues -- 3x3 filters, scipy.ndimage.label, the numpy argsort whose tie order is part of the

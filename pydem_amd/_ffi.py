@@ -72,6 +72,7 @@ SYMBOLS = {
     'pydem_uca': (C.c_int, [_P, C.POINTER(Options)]),
     'pydem_uca_edge_update': (C.c_int, [_P, C.POINTER(Options), _PP, _PP, _PP]),
     'pydem_uca_edge_round_inc': (C.c_int, [_P, C.POINTER(Options), _PP, _PP, _PP]),
+    'pydem_uca_edge_round_inc_dev': (C.c_int, [_P, C.POINTER(Options)]),
     'pydem_uca_edge_flush': (C.c_int, [_P]),
     'pydem_twi': (C.c_int, [_P, C.POINTER(Options)]),
     'pydem_tile_pit_edges': (C.c_int, [_P, C.POINTER(C.c_int64), _P, _P, _P]),
@@ -87,6 +88,12 @@ SYMBOLS = {
     'pydem_comm_pack_lines': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
     'pydem_comm_put': (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     'pydem_comm_allreduce': (C.c_int, [_P, C.c_int64, C.c_int, _P]),
+    'pydem_board_create': (C.c_int, [C.c_int, C.c_int, C.c_int64, _PP]),
+    'pydem_board_destroy': (C.c_int, [_P]),
+    'pydem_board_set_desc': (C.c_int, [_P, C.c_int, C.c_int32, C.c_int32, _P, _P, _P]),
+    'pydem_board_refresh': (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P]),
+    'pydem_board_eval': (C.c_int, [_P, C.c_int, _P, _P, _P]),
+    'pydem_board_download': (C.c_int, [_P, _P]),
 }
 
 _lib = None
@@ -215,6 +222,10 @@ class Tile(object):
     def uca_edge_flush(self):
         check(self.lib.pydem_uca_edge_flush(self._h))
 
+    def uca_edge_round_dev(self, opt):
+        """Incremental edge round with the strips the edge board wrote into the tile's buffers."""
+        check(self.lib.pydem_uca_edge_round_inc_dev(self._h, C.byref(opt)))
+
     def twi(self, opt):
         check(self.lib.pydem_twi(self._h, C.byref(opt)))
 
@@ -246,6 +257,56 @@ class Tile(object):
 
     def device_bytes(self):
         return self.lib.pydem_tile_device_bytes(self._h)
+
+
+class Board(object):
+    """Device-resident edge board (include/pydem_hip.h, pydem_board_*)."""
+
+    def __init__(self, device, n_tiles, n_doubles):
+        self.lib = load()
+        self.n_tiles, self.n_doubles = n_tiles, n_doubles
+        self._h = C.c_void_p()
+        check(self.lib.pydem_board_create(device, n_tiles, n_doubles, C.byref(self._h)))
+        self._out = np.zeros((n_tiles, 8), np.uint64)
+
+    def close(self):
+        if self._h:
+            self.lib.pydem_board_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_desc(self, index, n, m, offsets28, flags8, tile=None):
+        o = np.ascontiguousarray(offsets28, np.int64); f = np.ascontiguousarray(flags8, np.int32)
+        assert o.size == 28 and f.size == 8
+        check(self.lib.pydem_board_set_desc(self._h, index, n, m, o.ctypes.data_as(_P), f.ctypes.data_as(_P),
+                                            tile._h if tile is not None else None))
+
+    def refresh(self, comm, wave_doubles, segments, lines):
+        """segments: int64 array [nseg, 3] (staging offset, board offset, length); lines: [(tile, field, axis, index,
+        staging offset)] of this process's tiles."""
+        seg = np.ascontiguousarray(segments, np.int64).reshape(-1, 3)
+        k = len(lines)
+        tiles = (C.c_void_p * max(k, 1))(*[l[0]._h for l in lines])
+        fields = (C.c_int * max(k, 1))(*[l[1] for l in lines]); axes = (C.c_int * max(k, 1))(*[l[2] for l in lines])
+        idx = (C.c_int64 * max(k, 1))(*[l[3] for l in lines]); offs = (C.c_int64 * max(k, 1))(*[l[4] for l in lines])
+        check(self.lib.pydem_board_refresh(self._h, comm._h if comm is not None else None, int(wave_doubles), seg.shape[0],
+                                           seg.ctypes.data_as(_P), k, tiles, fields, axes, idx, offs))
+
+    def eval(self, tiles, full):
+        k = len(tiles)
+        t = (C.c_int * max(k, 1))(*tiles); f = (C.c_int * max(k, 1))(*[int(v) for v in full])
+        check(self.lib.pydem_board_eval(self._h, k, t, f, self._out.ctypes.data_as(_P)))
+        return self._out
+
+    def download(self):
+        out = np.empty(self.n_doubles, np.float64)
+        check(self.lib.pydem_board_download(self._h, out.ctypes.data_as(_P)))
+        return out
 
 
 class Comm(object):

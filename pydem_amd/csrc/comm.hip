@@ -9,6 +9,7 @@
 #include "internal.h"
 #include <rccl/rccl.h>
 #include <string.h>
+#include <vector>
 
 struct pydem_comm {
     ncclComm_t comm = nullptr;
@@ -167,6 +168,291 @@ int pydem_comm_put(pydem_comm *c, const double *host_in, int64_t n_doubles, int6
     if ((size_t)(offset + n_doubles) > c->cap) { pydem_set_error("pydem_comm_put: staging buffer too small"); return -2; }
     HIP_TRY(hipMemcpyAsync(c->buf + offset, host_in, (size_t)n_doubles * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// Edge board: the strips of the cross-tile fix-up stay on the device.
+//
+// The reference's edge workers read their neighbours' lines from the shared zarr store, apply the corner rules
+// and hand the strips to calc_uca (pydem/process_manager.py:243-279); its manager recomputes the metrics of the
+// tiles around every finished worker (calc_uca_ec_metrics :199-221, update_uca_edge_metrics :1061-1088).  With
+// one tile per GPU and KiB-sized strips that bookkeeping -- not the flow routing -- sets the pace, so here it
+// never leaves the device: every rank keeps a replicated BOARD of all the lines any tile reads from any other
+// (or from itself), refreshed after each wave by ONE collective (pack -> ncclAllReduce -> scatter), and one
+// kernel evaluates a tile from the board: it writes the strips (data, done, todo) straight into the buffers the
+// tile's round reads and reduces the numbers the schedule needs (metric counts, dropped 'todo' pixels, a hash
+// of the strips) into a few words per tile, the only thing the host reads per wave.
+// The rules are those of pydem_amd/process_manager.py (_edge_inputs, _todo_dropped, _adopt_finished,
+// _tile_metric), which stays the specification: the CPU test tier runs it with the oracle-backed processor
+// and tests/test_gpu_process_manager.py checks that both produce the same waves, rounds and masks.
+struct pydem_board_desc {           // one per tile; offsets in doubles into the board, -1 = no such line
+    int32_t n, m;
+    int64_t own_todo[4], own_done[4];             // sides: left, right, top, bottom
+    int64_t nb_uca[4], nb_done[4], nb_todo[4];
+    int32_t nb_self[4];                           // the edge table points the tile at its own line (mosaic border)
+    int64_t cnr_done[4], cnr_uca[4];              // diagonal neighbour's pixel for the corners tl, tr, bl, br
+    int32_t cnr_1ov[4];                           // check_1overlap (:286-293) of that corner
+    double *s_data; uint8_t *s_flags; int32_t L;  // strips of the tile's next round (tiles resident on this device)
+};
+
+struct pydem_board {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    double *mb = nullptr; int64_t cap = 0;        // the board
+    double *wb = nullptr; int64_t wcap = 0;       // wave staging (what the collective carries)
+    pydem_board_desc *desc = nullptr; int n_tiles = 0;
+    std::vector<pydem_board_desc> h_desc;
+    unsigned long long *scal = nullptr, *h_scal = nullptr;   // [n_tiles][8]
+    int64_t *seg = nullptr; int seg_cap = 0;      // scatter table of the current wave
+};
+
+namespace {
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x)
+{
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+
+// one thread per (side, position) of one tile
+__global__ __launch_bounds__(256) void k_board_eval(const double *__restrict__ mb, const pydem_board_desc *__restrict__ descs,
+                                                    int tile, int full, unsigned long long *__restrict__ scal)
+{
+    const pydem_board_desc D = descs[tile];
+    const int n = D.n, m = D.m;
+    const int64_t total = 2 * (int64_t)n + 2 * (int64_t)m;
+    unsigned long long a_ndone = 0, a_pdone = 0, a_dself = 0, a_dfull = 0, a_seeds = 0, a_hash = 0;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+        int k; int64_t p;
+        if (q < n) { k = 0; p = q; } else if (q < 2 * (int64_t)n) { k = 1; p = q - n; }
+        else if (q < 2 * (int64_t)n + m) { k = 2; p = q - 2 * (int64_t)n; } else { k = 3; p = q - 2 * (int64_t)n - m; }
+        const int64_t len = k < 2 ? n : m;
+        auto rd = [&](int64_t off, int64_t pos) -> double { return off < 0 ? 0.0 : mb[off + pos]; };
+        const bool own_td = rd(D.own_todo[k], p) != 0.0;
+        const bool own_dn = rd(D.own_done[k], p) != 0.0;
+        double data = rd(D.nb_uca[k], p);
+        const bool nb_dn = rd(D.nb_done[k], p) != 0.0;
+        const bool nb_td = rd(D.nb_todo[k], p) != 0.0;
+        bool done = nb_dn;
+        // ---- corner rules (:258-270): the top / bottom strip gives its corner up when both strips are finished
+        // there; with a one-pixel overlap both take the diagonal neighbour's value when that one is finished
+        const bool at_lo = p == 0, at_hi = p == len - 1;
+        int ctb = -1, clr = -1;
+        if (at_lo || at_hi) {
+            if (k >= 2) { ctb = k; clr = at_lo ? 0 : 1; }
+            else { clr = k; ctb = at_lo ? 2 : 3; }
+        }
+        // (a 1-wide or 1-high tile has both ends in one position: the lower end's rule wins like the dict order)
+        if (ctb >= 0) {
+            const int64_t pos_tb = clr == 0 ? 0 : m - 1;      // corner on the top / bottom strip
+            const int64_t pos_lr = ctb == 2 ? 0 : n - 1;      // corner on the left / right strip
+            const bool d_tb = rd(D.nb_done[ctb], pos_tb) != 0.0;
+            const bool d_lr = rd(D.nb_done[clr], pos_lr) != 0.0;
+            if (d_tb && d_lr) {
+                if (k >= 2) done = false;                                                           // :266
+                const int key = (ctb == 2 ? 0 : 2) + (clr == 0 ? 0 : 1);                            // tl, tr, bl, br
+                if (D.cnr_1ov[key] && D.cnr_done[key] >= 0 && mb[D.cnr_done[key]] != 0.0) data = mb[D.cnr_uca[key]];   // :268-270
+            }
+        }
+        // ---- rule :274 (full), or only where the neighbour line is the tile's own (mosaic border)
+        const bool drop_self = own_td && nb_td && D.nb_self[k];
+        const bool drop_full = own_td && nb_td;
+        const bool td = own_td && !(full ? drop_full : drop_self);
+        const bool td_adopt = td || (done && !own_dn);                                             // _adopt_finished
+        if (D.s_data) {
+            D.s_data[(size_t)k * D.L + p] = data;
+            D.s_flags[(size_t)k * D.L + p] = done;
+            D.s_flags[(size_t)(4 + k) * D.L + p] = td_adopt;
+        }
+        a_seeds += done && td_adopt;
+        // ---- metric (:199-221): 'todo' cells facing a finished neighbour cell, all eight keys
+        a_ndone += own_td && nb_dn;
+        a_pdone += own_td;
+        if (k >= 2 && (at_lo || at_hi)) {
+            const int key = (k == 2 ? 0 : 2) + (at_lo ? 0 : 1);
+            const bool edn = D.cnr_done[key] >= 0 && mb[D.cnr_done[key]] != 0.0;
+            a_ndone += own_td && edn;
+            a_pdone += own_td;
+            if (at_lo && at_hi) {   // m == 1: the same pixel is the other corner too
+                const int key2 = (k == 2 ? 0 : 2) + 1;
+                const bool edn2 = D.cnr_done[key2] >= 0 && mb[D.cnr_done[key2]] != 0.0;
+                a_ndone += own_td && edn2; a_pdone += own_td;
+            }
+        }
+        // ---- dropped 'todo' pixels (_todo_dropped): a corner pixel survives if either of its strips keeps it
+        if (k < 2 || !(at_lo || at_hi)) {
+            bool keep_s = own_td && !drop_self, keep_f = own_td && !drop_full;
+            if (k < 2 && (at_lo || at_hi)) {
+                const int64_t pos_tb = k == 0 ? 0 : m - 1;
+                const bool tb_own = rd(D.own_todo[ctb], pos_tb) != 0.0, tb_nb = rd(D.nb_todo[ctb], pos_tb) != 0.0;
+                keep_s = keep_s || (tb_own && !(tb_nb && D.nb_self[ctb]));
+                keep_f = keep_f || (tb_own && !tb_nb);
+            }
+            a_dself += own_td && !keep_s;
+            a_dfull += own_td && !keep_f;
+        }
+        unsigned long long h = (unsigned long long)__double_as_longlong(done ? data : 0.0);
+        h = mix64(h ^ ((unsigned long long)q * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)done << 1) ^ (unsigned long long)td_adopt);
+        a_hash += h;
+    }
+    // block reduction, one atomic per block and value
+    __shared__ unsigned long long red[6][256];
+    const unsigned long long v[6] = {a_ndone, a_pdone, a_dself, a_dfull, a_seeds, a_hash};
+    for (int j = 0; j < 6; j++) red[j][threadIdx.x] = v[j];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) for (int j = 0; j < 6; j++) red[j][threadIdx.x] += red[j][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) for (int j = 0; j < 6; j++) atomicAdd(&scal[(size_t)tile * 8 + j], red[j][0]);
+}
+
+// wave staging -> board: segment s copies seg[3s+2] doubles from wb + seg[3s] to mb + seg[3s+1]
+__global__ void k_board_scatter(const double *__restrict__ wb, double *__restrict__ mb, const int64_t *__restrict__ seg, int nseg)
+{
+    for (int s = blockIdx.y; s < nseg; s += gridDim.y) {
+        const int64_t src = seg[3 * s], dst = seg[3 * s + 1], cnt = seg[3 * s + 2];
+        for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * blockDim.x) mb[dst + k] = wb[src + k];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pydem_board_create(int device, int n_tiles, int64_t n_doubles, pydem_board **out)
+{
+    HIP_TRY(hipSetDevice(device));
+    pydem_board *b = new pydem_board();
+    b->device = device; b->n_tiles = n_tiles; b->cap = n_doubles;
+    HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&b->ev, hipEventDisableTiming));
+    HIP_TRY(hipMalloc((void **)&b->mb, (size_t)(n_doubles > 0 ? n_doubles : 1) * 8));
+    HIP_TRY(hipMemsetAsync(b->mb, 0, (size_t)(n_doubles > 0 ? n_doubles : 1) * 8, b->stream));
+    HIP_TRY(hipMalloc((void **)&b->desc, (size_t)n_tiles * sizeof(pydem_board_desc)));
+    HIP_TRY(hipMalloc((void **)&b->scal, (size_t)n_tiles * 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc((void **)&b->h_scal, (size_t)n_tiles * 8 * sizeof(unsigned long long)));
+    b->h_desc.resize((size_t)n_tiles);
+    *out = b;
+    return 0;
+}
+
+int pydem_board_destroy(pydem_board *b)
+{
+    if (!b) return 0;
+    (void)hipSetDevice(b->device);
+    (void)hipStreamSynchronize(b->stream);
+    for (void *p : {(void *)b->mb, (void *)b->wb, (void *)b->desc, (void *)b->scal, (void *)b->seg}) if (p) (void)hipFree(p);
+    if (b->h_scal) (void)hipHostFree(b->h_scal);
+    if (b->ev) (void)hipEventDestroy(b->ev);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+    return 0;
+}
+
+// descriptor of one tile: 4+4+12+8 offsets and the flags, in the order of pydem_board_desc (see _ffi.Board.set_desc);
+// `tile` = the resident tile whose strip buffers the evaluation fills, or NULL for a tile of another rank / device
+int pydem_board_set_desc(pydem_board *b, int index, int32_t n, int32_t m, const int64_t *offsets28, const int32_t *flags8, pydem_tile *tile)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    if (index < 0 || index >= b->n_tiles) { pydem_set_error("pydem_board_set_desc: tile index out of range"); return -2; }
+    pydem_board_desc &D = b->h_desc[(size_t)index];
+    D.n = n; D.m = m;
+    const int64_t *o = offsets28;
+    for (int k = 0; k < 4; k++) { D.own_todo[k] = o[k]; D.own_done[k] = o[4 + k]; D.nb_uca[k] = o[8 + k]; D.nb_done[k] = o[12 + k]; D.nb_todo[k] = o[16 + k];
+                                  D.cnr_done[k] = o[20 + k]; D.cnr_uca[k] = o[24 + k]; D.nb_self[k] = flags8[k]; D.cnr_1ov[k] = flags8[4 + k]; }
+    for (int k = 0; k < 28; k++) if (o[k] >= b->cap) { pydem_set_error("pydem_board_set_desc: offset beyond the board"); return -2; }
+    D.s_data = nullptr; D.s_flags = nullptr; D.L = n > m ? n : m;
+    if (tile) {
+        if (tile->device != b->device) { pydem_set_error("pydem_board_set_desc: tile lives on another device"); return -2; }
+        if (tile->n != n || tile->m != m) { pydem_set_error("pydem_board_set_desc: tile shape mismatch"); return -2; }
+        PYDEM_TRY(tile_alloc(tile, &tile->s_data, (size_t)D.L * 4));
+        PYDEM_TRY(tile_alloc(tile, &tile->s_flags, (size_t)D.L * 8));
+        D.s_data = tile->s_data; D.s_flags = tile->s_flags;
+    }
+    HIP_TRY(hipMemcpyAsync(b->desc + index, &D, sizeof(D), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+// Refresh the board with the lines of the tiles that ran in a wave.  `nseg` segments (staging offset, board
+// offset, length) describe the whole wave identically on every rank; this rank packs the `count` lines of ITS
+// tiles (tiles[k], fields[k], axes[k], indices[k]) to staging offset wb_offsets[k].  With a communicator the
+// staging buffer is summed over the ranks (disjoint fills) before it is scattered into the board.
+int pydem_board_refresh(pydem_board *b, pydem_comm *c, int64_t wave_doubles, int nseg, const int64_t *seg3,
+                        int count, pydem_tile *const *tiles, const int *fields, const int *axes, const int64_t *indices,
+                        const int64_t *wb_offsets)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    if (wave_doubles <= 0 || nseg <= 0) return 0;
+    if (wave_doubles > b->wcap) {
+        if (b->wb) HIP_TRY(hipFree(b->wb));
+        HIP_TRY(hipMalloc((void **)&b->wb, (size_t)wave_doubles * 8));
+        b->wcap = wave_doubles;
+    }
+    if (nseg > b->seg_cap) {
+        if (b->seg) HIP_TRY(hipFree(b->seg));
+        HIP_TRY(hipMalloc((void **)&b->seg, (size_t)nseg * 3 * sizeof(int64_t)));
+        b->seg_cap = nseg;
+    }
+    HIP_TRY(hipMemcpyAsync(b->seg, seg3, (size_t)nseg * 3 * sizeof(int64_t), hipMemcpyHostToDevice, b->stream));
+    if (c && c->world > 1) HIP_TRY(hipMemsetAsync(b->wb, 0, (size_t)wave_doubles * 8, b->stream));
+    HIP_TRY(hipEventRecord(b->ev, b->stream));
+    // packs run on the tiles' own streams (behind the rounds they just ran), the board stream waits for them
+    pydem_comm tmp;                       // pack_one only looks at buf / cap / device
+    tmp.buf = b->wb; tmp.cap = (size_t)b->wcap; tmp.device = b->device;
+    pydem_tile *last = nullptr;
+    for (int k = 0; k < count; k++) {
+        pydem_tile *t = tiles[k];
+        if (t != last) {
+            if (last) { HIP_TRY(hipEventRecord(last->ev_snap, last->stream)); HIP_TRY(hipStreamWaitEvent(b->stream, last->ev_snap, 0)); }
+            HIP_TRY(hipStreamWaitEvent(t->stream, b->ev, 0));
+            last = t;
+        }
+        const int r = pack_one(&tmp, t, fields[k], axes[k], indices[k], wb_offsets[k]);
+        if (r) { tmp.buf = nullptr; return r; }
+    }
+    if (last) { HIP_TRY(hipEventRecord(last->ev_snap, last->stream)); HIP_TRY(hipStreamWaitEvent(b->stream, last->ev_snap, 0)); }
+    tmp.buf = nullptr;
+    if (c && c->world > 1)
+        NCCL_TRY(ncclAllReduce(b->wb, b->wb, (size_t)wave_doubles, ncclDouble, ncclSum, c->comm, b->stream));
+    hipLaunchKernelGGL(k_board_scatter, dim3(16, nseg < 64 ? nseg : 64), dim3(256), 0, b->stream, b->wb, b->mb, b->seg, nseg);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// evaluate `count` tiles (tiles[k], full[k]: rule :274 everywhere instead of on the mosaic border only); the scalars
+// of ALL tiles of the board are returned (8 words per tile: n_done, p_done, dropped_self, dropped_full, seeds, hash, -, -;
+// tiles that were not evaluated keep their previous values)
+int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *full, unsigned long long *out)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    for (int k = 0; k < count; k++) {
+        const int i = tiles[k];
+        if (i < 0 || i >= b->n_tiles) { pydem_set_error("pydem_board_eval: tile index out of range"); return -2; }
+        HIP_TRY(hipMemsetAsync(b->scal + (size_t)i * 8, 0, 8 * sizeof(unsigned long long), b->stream));
+        const pydem_board_desc &D = b->h_desc[(size_t)i];
+        const int64_t total = 2 * (int64_t)D.n + 2 * (int64_t)D.m;
+        const int g = (int)(cdiv(total, 256) < 128 ? cdiv(total, 256) : 128);
+        hipLaunchKernelGGL(k_board_eval, dim3(g), dim3(256), 0, b->stream, b->mb, b->desc, i, full[k], b->scal);
+    }
+    HIP_TRY(hipMemcpyAsync(b->h_scal, b->scal, (size_t)b->n_tiles * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    memcpy(out, b->h_scal, (size_t)b->n_tiles * 8 * sizeof(unsigned long long));
+    return 0;
+}
+
+// debugging / tests: a copy of the board
+int pydem_board_download(pydem_board *b, double *out)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipMemcpyAsync(out, b->mb, (size_t)b->cap * 8, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
     return 0;
 }
 

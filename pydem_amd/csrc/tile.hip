@@ -488,6 +488,19 @@ int pydem_uca_edge_round_inc(pydem_tile *t, pydem_options *opt, const double *co
     return 0;
 }
 
+int pydem_uca_edge_round_inc_dev(pydem_tile *t, pydem_options *opt)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(need(t, PYDEM_UCA, "pydem_uca_edge_round_inc_dev"));
+    PYDEM_TRY(need(t, PYDEM_FLATS, "pydem_uca_edge_round_inc_dev"));
+    PYDEM_TRY(need(t, PYDEM_EDGE_TODO, "pydem_uca_edge_round_inc_dev"));
+    PYDEM_TRY(need(t, PYDEM_EDGE_DONE, "pydem_uca_edge_round_inc_dev"));
+    if (!t->graph_valid) { pydem_set_error("pydem_uca_edge_round_inc_dev: the flow graph of pydem_uca is not resident"); return -3; }
+    if (!t->s_data || !t->s_flags) { pydem_set_error("pydem_uca_edge_round_inc_dev: no strips (pydem_board_set_desc + pydem_board_eval first)"); return -3; }
+    PYDEM_TRY(stage_edge_round_inc(t, opt, nullptr, nullptr, nullptr));
+    return 0;
+}
+
 int pydem_uca_edge_flush(pydem_tile *t)
 {
     HIP_TRY(hipSetDevice(t->device));

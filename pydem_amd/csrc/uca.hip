@@ -1524,6 +1524,7 @@ struct IncArgs {
     double *uca;
     const int2 *pit_off;
     int set_done;            // 0 in the final flush: the cells stay 'not done'
+    int32_t *prof;           // -DPYDEM_EINC_PROF: levels / 10 ns ticks by frontier width (<=8, <=64, <=512, more)
 };
 
 // once per fix-up: counts of the ND sub-graph
@@ -1621,19 +1622,24 @@ __device__ __forceinline__ void einc_cell(const IncArgs &E, QE q, Push push)
     const int32_t c = q.c;
     const uint32_t cw = q.cw;
     const int m = A.m;
+    // every load of the cell in ONE batch (own flag / area, the in-neighbours' flag / delta / proportion): the cascade
+    // is a chain of dependent memory round trips and nothing else
     int2 po = make_int2(0, 0);
     if (cw & (CI_PIT_IN | CI_PIT_OUT)) po = E.pit_off[c];
-    if (!(E.flag[c] & EF_FINAL)) {                                               // (seeds keep the value they adopted)
-        uint32_t f[8]; double dl[8], pr[8];
+    const uint32_t own_flag = E.flag[c];
+    const double own_uca = E.uca[c];
+    const bool flat = E.flats[c] != 0;
+    uint32_t f[8]; double dl[8], pr[8];
 #pragma unroll
-        for (int d = 0; d < 8; d++) {
-            f[d] = 0; dl[d] = 0.0; pr[d] = 0.0;
-            if (cw & (1u << d)) {
-                const int32_t u = c + NB_DI[d] * m + NB_DJ[d];
-                f[d] = E.flag[u]; dl[d] = E.delta[u]; pr[d] = A.prop[u];
-            }
+    for (int d = 0; d < 8; d++) {
+        f[d] = 0; dl[d] = 0.0; pr[d] = 0.0;
+        if (cw & (1u << d)) {
+            const int32_t u = c + NB_DI[d] * m + NB_DJ[d];
+            f[d] = E.flag[u]; dl[d] = E.delta[u]; pr[d] = A.prop[u];
         }
-        double acc = E.flats[c] ? NAN : 0.0;                                     // :815
+    }
+    if (!(own_flag & EF_FINAL)) {                                                // (seeds keep the value they adopted)
+        double acc = flat ? NAN : 0.0;                                           // :815
 #pragma unroll
         for (int d = 0; d < 8; d++) {
             if ((cw & (1u << d)) && (f[d] & EF_FINAL)) {
@@ -1645,7 +1651,7 @@ __device__ __forceinline__ void einc_cell(const IncArgs &E, QE q, Push push)
             for (int32_t e = po.x; e < A.n_pit && A.pin_dst[e] == c; e++)
                 if (E.flag[A.pin_src[e]] & EF_FINAL) acc += E.delta[A.pin_src[e]] * A.pin_w[e];
         E.delta[c] = acc;
-        E.uca[c] += acc;
+        E.uca[c] = own_uca + acc;
         E.flag[c] = EF_FINAL;
     }
     if (E.set_done) E.edge_done[c] = 1;
@@ -1673,7 +1679,7 @@ __global__ __launch_bounds__(256) void k_einc_level(IncArgs E, const QE *__restr
 }
 
 // small frontiers: one workgroup, level after level (see k_edge_small)
-__global__ __launch_bounds__(1024) void k_einc_small(IncArgs E, QE *q0, QE *q1, int32_t *cnt3, int r_start, int32_t *state)
+__global__ __launch_bounds__(1024) void k_einc_small(IncArgs E, QE *q0, QE *q1, int32_t *cnt3, int r_start, int32_t *state)   // (launched with 64..1024 threads)
 {
     __shared__ QE s_q[2][SMALL_CAP];
     __shared__ int32_t s_next;
@@ -1683,8 +1689,15 @@ __global__ __launch_bounds__(1024) void k_einc_small(IncArgs E, QE *q0, QE *q1, 
         const QE *qc = (r % 2) ? q1 : q0;
         for (int32_t k = threadIdx.x; k < nq; k += blockDim.x) s_q[r % 2][k] = qc[k];
     }
+#ifdef PYDEM_EINC_PROF
+    long long prof_t[4] = {0, 0, 0, 0}; int prof_n[4] = {0, 0, 0, 0};
+#endif
     __syncthreads();
     while (nq > 0 && nq <= SMALL_CAP) {
+#ifdef PYDEM_EINC_PROF
+        const long long t0 = wall_clock64();
+        const int cls = nq <= 8 ? 0 : (nq <= 64 ? 1 : (nq <= 512 ? 2 : 3));
+#endif
         if (threadIdx.x == 0) s_next = 0;
         __syncthreads();
         QE *qn = (r % 2) ? q0 : q1;
@@ -1702,10 +1715,16 @@ __global__ __launch_bounds__(1024) void k_einc_small(IncArgs E, QE *q0, QE *q1, 
         nq = s_next;
         r++;
         __syncthreads();
+#ifdef PYDEM_EINC_PROF
+        prof_t[cls] += wall_clock64() - t0; prof_n[cls]++;
+#endif
     }
     if (threadIdx.x == 0) {
         cnt3[r % 3] = nq; cnt3[(r + 1) % 3] = 0; cnt3[(r + 2) % 3] = 0;
         state[0] = r;
+#ifdef PYDEM_EINC_PROF
+        for (int k = 0; k < 4; k++) { atomicAdd(&E.prof[k], prof_n[k]); atomicAdd(&E.prof[4 + k], (int)prof_t[k]); }
+#endif
     }
 }
 
@@ -2166,6 +2185,7 @@ static int einc_args(pydem_tile *t, IncArgs &E)
     fill_sweep_args(t, E.G);
     E.flag = (uint32_t *)t->estamp; E.delta = t->edelta; E.flats = t->flats; E.edge_done = t->edge_done; E.edge_todo = t->edge_todo;
     E.uca = t->uca; E.pit_off = reinterpret_cast<const int2 *>(t->contrib); E.set_done = 1;
+    E.prof = t->counters + 40;
     return 0;
 }
 
@@ -2177,7 +2197,9 @@ static int einc_cascade(pydem_tile *t, const IncArgs &E, int *levels)
     QE *q0 = (QE *)t->queue[0], *q1 = (QE *)t->queue[1];
     int r = 0;
     for (;;) {
-        hipLaunchKernelGGL(k_einc_small, dim3(1), dim3(1024), 0, t->stream, E, q0, q1, cnt3, r, state);
+        static int einc_block = -1;
+        if (einc_block < 0) { const char *e = getenv("PYDEM_EINC_BLOCK"); einc_block = e ? atoi(e) : 1024; }
+        hipLaunchKernelGGL(k_einc_small, dim3(1), dim3(einc_block), 0, t->stream, E, q0, q1, cnt3, r, state);
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         r = t->h_counters[12];
@@ -2227,32 +2249,44 @@ int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *
         t->einc_ready = true;
         t->edge_clean = false;          // the classic rounds find their zeroed state gone
     }
-    // strips -> device (left, right, top, bottom), padded to L entries each (pinned staging: the copies are asynchronous)
-    if (t->h_strip_cap < (size_t)L) {
-        if (t->h_strip_d) { (void)hipHostFree(t->h_strip_d); (void)hipHostFree(t->h_strip_f); }
-        HIP_TRY(hipHostMalloc((void **)&t->h_strip_d, (size_t)L * 4 * sizeof(double)));
-        HIP_TRY(hipHostMalloc((void **)&t->h_strip_f, (size_t)L * 8));
-        t->h_strip_cap = (size_t)L;
-    }
-    double *hd = t->h_strip_d;
-    uint8_t *hf = t->h_strip_f;
-    for (int s = 0; s < 4; s++) {
-        const int len = s < 2 ? n : m;
-        for (int k = 0; k < len; k++) {
-            hd[(size_t)s * L + k] = data[s][k];
-            hf[(size_t)s * L + k] = done[s][k] != 0;
-            hf[(size_t)(4 + s) * L + k] = todo[s][k] != 0;
+    // strips -> device (left, right, top, bottom), padded to L entries each (pinned staging: the copies are asynchronous);
+    // data == NULL: the edge board's evaluation kernel has already written them (comm.hip)
+    if (data) {
+        if (t->h_strip_cap < (size_t)L) {
+            if (t->h_strip_d) { (void)hipHostFree(t->h_strip_d); (void)hipHostFree(t->h_strip_f); }
+            HIP_TRY(hipHostMalloc((void **)&t->h_strip_d, (size_t)L * 4 * sizeof(double)));
+            HIP_TRY(hipHostMalloc((void **)&t->h_strip_f, (size_t)L * 8));
+            t->h_strip_cap = (size_t)L;
         }
+        double *hd = t->h_strip_d;
+        uint8_t *hf = t->h_strip_f;
+        for (int s = 0; s < 4; s++) {
+            const int len = s < 2 ? n : m;
+            for (int k = 0; k < len; k++) {
+                hd[(size_t)s * L + k] = data[s][k];
+                hf[(size_t)s * L + k] = done[s][k] != 0;
+                hf[(size_t)(4 + s) * L + k] = todo[s][k] != 0;
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(t->s_data, hd, (size_t)L * 4 * 8, hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->s_flags, hf, (size_t)L * 8, hipMemcpyHostToDevice, t->stream));
     }
-    HIP_TRY(hipMemcpyAsync(t->s_data, hd, (size_t)L * 4 * 8, hipMemcpyHostToDevice, t->stream));
-    HIP_TRY(hipMemcpyAsync(t->s_flags, hf, (size_t)L * 8, hipMemcpyHostToDevice, t->stream));
     HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
+    HIP_TRY(hipMemsetAsync(t->counters + 40, 0, 8 * sizeof(int32_t), t->stream));
     hipLaunchKernelGGL(k_einc_seed, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, E, t->s_data, t->s_flags,
                        t->s_flags + (size_t)4 * L, L, (QE *)t->queue[0], &t->counters[0]);
     int levels = 0;
     PYDEM_TRY(einc_cascade(t, E, &levels));
     if (getenv("PYDEM_EDGE_DEBUG"))
         fprintf(stderr, "incremental edge round: %d levels; %.3f ms\n", levels, host_now_ms() - t_begin);
+#ifdef PYDEM_EINC_PROF
+    if (getenv("PYDEM_EDGE_DEBUG")) {
+        int32_t pr[8];
+        HIP_TRY(hipMemcpy(pr, t->counters + 40, sizeof(pr), hipMemcpyDeviceToHost));
+        fprintf(stderr, "   levels by frontier width <=8 / <=64 / <=512 / more: %d %d %d %d; us: %.0f %.0f %.0f %.0f\n", pr[0], pr[1], pr[2], pr[3],
+                pr[4] * 0.01, pr[5] * 0.01, pr[6] * 0.01, pr[7] * 0.01);
+    }
+#endif
     return 0;
 }
 

@@ -375,6 +375,12 @@ class DEMProcessor(object):
             self._tile.restore_pit_slopes()
             self._host.pop('mag', None)
 
+    def run_edge_round_dev(self):
+        """One incremental edge round whose strips the edge board (pydem_board_eval) has put into the tile's buffers."""
+        self._ensure_tile()
+        self._tile.uca_edge_round_dev(self._options())
+        self._produced('uca', 'edge_todo', 'edge_done')
+
     def flush_edge_rounds(self):
         """End of a series of incremental edge rounds (no-op otherwise)."""
         if self._tile is not None:

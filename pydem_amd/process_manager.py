@@ -749,6 +749,8 @@ class ProcessManager(object):
         :274 and gives its cells up, which seeds its neighbours.  A tile whose inputs are bit-identical to those of
         its last round is not a candidate (the round would reproduce its state; the reference would re-run it for ever
         when only a corner pixel keeps its count > 0)."""
+        if self._device_board_usable():
+            return self._process_uca_edges_pool_device(mets_type)
         interest = self._edge_setup()
         mets = self.update_uca_edge_metrics()
         width = max(1, 2 * int(self.n_workers))
@@ -764,7 +766,9 @@ class ProcessManager(object):
                 if mets[a, 0] <= 0 and self._todo_dropped(a, snaps[a], todo) == 0:
                     continue
                 todo = self._adopt_finished(a, snaps[a], done, todo)
-                sig = tuple(np.asarray(v[k]).tobytes() for v in (data, done, todo) for k in SIDES)
+                # (values of unfinished neighbour cells never enter a round: they are not part of the signature)
+                sig = tuple(np.where(done[k], data[k], 0.0).tobytes() for k in SIDES) + \
+                    tuple(np.asarray(v[k]).tobytes() for v in (done, todo) for k in SIDES)
                 if self._edge_last.get(a) == sig:
                     continue
                 inputs[a] = (data, done, todo, sig)
@@ -813,6 +817,179 @@ class ProcessManager(object):
         for a in self._owned():                   # incremental rounds: cells still below an unresolved inlet catch up
             if hasattr(self.tiles[a], 'flush_edge_rounds'):
                 self.tiles[a].flush_edge_rounds()
+        return mets
+
+    # ---- the same schedule with the strips resident on the device ------------------------------------------
+    def _device_board_usable(self):
+        """Device processors, all of this process's tiles on one GPU, strips carried in-process or by RCCL."""
+        if not getattr(self, 'edge_device_board', True) or not getattr(self, 'edge_incremental', True):
+            return False
+        owned = self._owned()
+        if not owned or any(not hasattr(self.tiles[i], 'run_edge_round_dev') for i in owned):
+            return False
+        if self.dem_proc_kwargs.get('apply_uca_limit_edges'):
+            return False
+        if len(set(self.tiles[i]._device for i in owned)) != 1:
+            return False
+        if type(self.transport) is EdgeTransport:
+            return len(owned) == self.n_inputs
+        return hasattr(self.transport, 'comm') and hasattr(self.transport.comm, '_h')
+
+    def _process_uca_edges_pool_device(self, mets_type=0):
+        """`_process_uca_edges_pool` with the edge board of csrc/comm.hip: the lines every tile reads live in one
+        replicated device buffer, a kernel applies the strip rules above (they stay the specification; the CPU tier
+        and tests/test_gpu_process_manager.py hold the two against each other) and the host only sees a few numbers
+        per tile and wave.  Same candidates, same tie-break, same waves."""
+        from . import _ffi
+        from .dem_processing import _FIELD_OF
+        interest = self._edge_setup()
+        n_t = self.n_inputs
+        own = {'left': (1, 0), 'right': (1, -1), 'top': (0, 0), 'bottom': (0, -1)}
+        length = lambda req: int(self.index[req[0], 7] if req[2] == 0 else self.index[req[0], 6])
+        layout, start, size, off = {}, {}, {}, 0
+        for t in range(n_t):
+            start[t] = off
+            for req in sorted(interest.get(t, ())):
+                layout[req] = off
+                off += length(req)
+            size[t] = off - start[t]
+        owned = self._owned()
+        comm = getattr(self.transport, 'comm', None)
+        board = _ffi.Board(self.tiles[owned[0]]._device, n_t, off)
+        readers = {t: set([t]) for t in range(n_t)}
+        for i in range(n_t):
+            o28, f8 = [], []
+            srcs = [self._edge_line(i, key) for key in SIDES]
+            o28 += [layout[(i, 'edge_todo',) + own[key]] for key in SIDES]
+            o28 += [layout[(i, 'edge_done',) + own[key]] for key in SIDES]
+            for name in ('uca', 'edge_done', 'edge_todo'):
+                o28 += [layout[(src, name, axis, idx)] if src >= 0 else -1 for src, axis, idx in srcs]
+            f8 += [int(src == i) for src, _, _ in srcs]
+            cd, cu, c1 = [], [], []
+            for key in ('top-left', 'top-right', 'bottom-left', 'bottom-right'):
+                src, lr, lc = self._edge_line(i, key)
+                ov1 = bool(self.check_1overlap(self.grid_slice[i], self.edge_data[i][key]))
+                cd.append(layout[(src, 'edge_done', 0, lr)] + lc if src >= 0 else -1)
+                cu.append(layout[(src, 'uca', 0, lr)] + lc if (src >= 0 and ov1) else -1)
+                c1.append(int(ov1))
+                if src >= 0:
+                    readers[src].add(i)
+            for src, _, _ in srcs:
+                if src >= 0:
+                    readers[src].add(i)
+            n, m = self.tiles_shape[i]
+            dp = self.tiles[i] if self.transport.owns(i) else None
+            if dp is not None:
+                dp._ensure_tile()
+                dp._push('uca', 'edge_todo', 'edge_done', 'flats')
+            board.set_desc(i, n, m, o28 + cd + cu, f8 + c1, dp._tile if dp is not None else None)
+
+        def refresh(tiles):
+            segs, lines, woff = [], [], 0
+            for t in sorted(tiles):
+                segs.append((woff, start[t], size[t]))
+                if self.transport.owns(t):
+                    tl = self.tiles[t]._tile
+                    for req in sorted(interest.get(t, ())):
+                        lines.append((tl, _FIELD_OF[req[1]], req[2], req[3], woff + layout[req] - start[t]))
+                woff += size[t]
+            board.refresh(comm, woff, segs, lines)
+
+        def check_against_host_rules(tiles, scal):
+            # PYDEM_BOARD_CHECK=1 (tests): the numbers of the evaluation kernel against the host rules on the same lines
+            self._edge_cache = {}
+            for a in tiles:
+                reqs = sorted(self._snapshot_requests(a) | self._metric_requests(a))
+                snap = dict(zip(reqs, self._edge_lines(reqs)))
+                met = self._tile_metric(a, snap)
+                got = [int(v) for v in scal[a, :5]]
+                want = [met[1], None]
+                d0, dn0, td0 = self._edge_inputs(a, snap, drop_mutual_todo='self')
+                d1, dn1, td1 = self._edge_inputs(a, snap, drop_mutual_todo=True)
+                want += [self._todo_dropped(a, snap, td0), self._todo_dropped(a, snap, td1)]
+                tda = self._adopt_finished(a, snap, dn0, td0)
+                want.append(sum(int(np.count_nonzero(dn0[k] & tda[k])) for k in SIDES))
+                for j in (0, 2, 3, 4):
+                    assert got[j] == want[j], "edge board: tile %d value %d: kernel %r, host rules %r" % (a, j, got, want)
+                assert abs(got[0] / (1e-16 + got[1]) - met[0]) < 1e-12, (a, got, met)
+            self._edge_cache = {}
+
+        checking = bool(os.environ.get('PYDEM_BOARD_CHECK'))
+        refresh(range(n_t))
+        scal = board.eval(list(range(n_t)), [0] * n_t)
+        if checking:
+            check_against_host_rules(range(n_t), scal)
+        width = max(1, 2 * int(self.n_workers))
+        self.edge_tiebreaks = 0
+        last_hash = {}
+        mets = np.zeros((n_t, 2))
+        def refresh_mets(tiles):
+            for a in tiles:
+                nd = float(scal[a, 0])
+                mets[a] = (nd / (1e-16 + float(scal[a, 1])), nd)
+
+        refresh_mets(range(n_t))
+        while self.edge_waves < self.max_edge_rounds:
+            eff = np.zeros_like(mets)
+            cand = []
+            for a in range(n_t):
+                if mets[a, 0] <= 0 and scal[a, 2] == 0:
+                    continue
+                if last_hash.get(a) == int(scal[a, 5]):
+                    continue
+                cand.append(a)
+                eff[a] = mets[a] if mets[a, 0] > 0 else (1e-9, 0)
+            if cand:
+                I = self._rank_tiles(eff, mets_type)
+                cs = set(cand)
+                wave = sorted(int(a) for a in I[:width] if a in cs)
+                for a in wave:
+                    last_hash[a] = int(scal[a, 5])
+            else:
+                drops = scal[:, 3].astype(np.int64)
+                if not (drops > 0).any():
+                    break
+                a = int(np.argmax(drops))                   # the most dropped pixels, lowest index first
+                board.eval([a], [1])                        # its strips again, with rule :274 everywhere
+                last_hash.pop(a, None)
+                wave = [a]
+                self.edge_tiebreaks += 1
+            mine = [a for a in wave if self.transport.owns(a)]
+            for a in mine:
+                dp = self.tiles[a]
+                if self.keep_first_pass_uca and self.uca0[a] is None:
+                    self.uca0[a] = np.array(dp.uca)
+            k = max(1, int(self.tiles_in_flight))
+
+            def one(a):
+                t0 = time.perf_counter()
+                self.tiles[a].run_edge_round_dev()
+                self.edge_round_log.append((self.edge_waves, a, (time.perf_counter() - t0) * 1e3))
+            if k > 1 and len(mine) > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=k) as ex:
+                    list(ex.map(one, mine))
+            else:
+                for a in mine:
+                    one(a)
+            refresh(wave)
+            affected = set()
+            for a in wave:
+                affected |= readers[a]
+            affected = sorted(affected)
+            scal = board.eval(affected, [0] * len(affected))
+            if checking:
+                check_against_host_rules(range(n_t), scal)
+            self.edge_rounds += len(wave)
+            self.edge_waves += 1
+            check = set()
+            for a in wave:                      # like check_mets (:1116-1136): the tiles that ran and their four side
+                check.update(self._neighbours(a))   # neighbours; a diagonal neighbour keeps its old metric until then
+            refresh_mets(sorted(check))
+        for a in owned:
+            self.tiles[a].flush_edge_rounds()
+        self._mets = mets.copy()
+        board.close()
         return mets
 
     def process_twi(self):

@@ -62,9 +62,12 @@ def test_multi_tile_equals_single_tile_on_cone(tmp_path):
         np.testing.assert_array_almost_equal(compact['uca'][1:-1, 1:-1], single.uca[1:-1, 1:-1], decimal=6)
 
 
-def test_rccl_transport_single_rank(tmp_path):
+@pytest.mark.parametrize('n_workers', [1, 8])
+def test_rccl_transport_single_rank(n_workers, tmp_path):
     """The RCCL strip transport end to end on one GPU (world size 1: the collective still runs):
-    device pack -> ncclAllReduce -> host views must reproduce the in-process transport's result."""
+    device pack -> ncclAllReduce -> host views must reproduce the in-process transport's result (n_workers=1: the
+    serial loop against the reference golden; n_workers=8: pool waves on the device edge board against the same
+    waves with in-process strips)."""
     from test_process_manager_cpu import compare_with_golden, run_pm
     from pydem_amd import _ffi
     from pydem_amd.parallel import RcclTransport
@@ -79,11 +82,17 @@ def test_rccl_transport_single_rank(tmp_path):
     orig = process_manager.EdgeTransport
     process_manager.EdgeTransport = T          # ProcessManager builds its default transport from this name
     try:
-        pm, compact, order = run_pm(g, str(tmp_path))
+        pm, compact, order = run_pm(g, str(tmp_path), n_workers=n_workers)
     finally:
         process_manager.EdgeTransport = orig
     assert isinstance(pm.transport, RcclTransport)
-    compare_with_golden(pm, compact, order, g, _close)
+    if n_workers == 1:
+        compare_with_golden(pm, compact, order, g, _close)
+    else:
+        pm2, compact2, _ = run_pm(g, str(tmp_path / 'inproc'), n_workers=n_workers)
+        assert (pm.edge_waves, pm.edge_rounds) == (pm2.edge_waves, pm2.edge_rounds)
+        for key in compact:
+            assert np.array_equal(compact[key], compact2[key], equal_nan=True), key
     assert pm.transport.allreduce_max(3.5) == 3.5
     comm.close()
 
