@@ -197,9 +197,11 @@ int pydem_comm_allreduce(pydem_comm *c, int64_t n_doubles, int op /* 0 sum, 1 ma
  *                         pixel of the corners tl, tr, bl, br); -1 = missing; flags8 = nb_self[4] (the edge table
  *                         points the tile at its own line), cnr_1ov[4] (check_1overlap :286-293); `tile` = the
  *                         resident tile whose strip buffers the evaluation fills (NULL: a tile of another rank)
- *   pydem_board_refresh   after a wave: this rank packs the listed lines of its tiles into the wave staging buffer,
- *                         one ncclAllReduce(sum) over disjoint fills when `c` spans several ranks, then the nseg
- *                         segments (staging offset, board offset, length) are copied into the board
+ *   pydem_board_set_lines which part of the board holds the lines of tile `index` (mb_start, size) and, for a tile of
+ *                         this rank, the lines to gather from it (field / axis / index -> rel_offset inside that part)
+ *   pydem_board_refresh   after a wave (the same tile list on every rank): the tiles of this rank gather their lines
+ *                         into the wave staging buffer, one ncclAllReduce(sum) over disjoint fills when `c` is given,
+ *                         then the staging buffer is copied into the board
  *   pydem_board_eval      strips (data, done, todo after the corner rules, rule :274 -- everywhere if full[k], else
  *                         only on the mosaic border -- and the adoption of finished neighbour values) into the
  *                         tiles' buffers, and 8 words per tile to `out` (all tiles of the board): cells 'todo' and
@@ -210,9 +212,9 @@ int pydem_board_create(int device, int n_tiles, int64_t n_doubles, pydem_board *
 int pydem_board_destroy(pydem_board *b);
 int pydem_board_set_desc(pydem_board *b, int index, int32_t n, int32_t m, const int64_t *offsets28, const int32_t *flags8,
                          pydem_tile *tile);
-int pydem_board_refresh(pydem_board *b, pydem_comm *c, int64_t wave_doubles, int nseg, const int64_t *seg3,
-                        int count, pydem_tile *const *tiles, const int *fields, const int *axes, const int64_t *indices,
-                        const int64_t *wb_offsets);
+int pydem_board_set_lines(pydem_board *b, int index, int64_t mb_start, int64_t size, pydem_tile *tile, int count,
+                          const int *fields, const int *axes, const int64_t *indices, const int64_t *rel_offsets);
+int pydem_board_refresh(pydem_board *b, pydem_comm *c, int n_wave, const int *wave_tiles);
 int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *full, unsigned long long *out);
 int pydem_board_download(pydem_board *b, double *out);
 

@@ -91,7 +91,8 @@ SYMBOLS = {
     'pydem_board_create': (C.c_int, [C.c_int, C.c_int, C.c_int64, _PP]),
     'pydem_board_destroy': (C.c_int, [_P]),
     'pydem_board_set_desc': (C.c_int, [_P, C.c_int, C.c_int32, C.c_int32, _P, _P, _P]),
-    'pydem_board_refresh': (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P]),
+    'pydem_board_set_lines': (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int, _P, _P, _P, _P]),
+    'pydem_board_refresh': (C.c_int, [_P, _P, C.c_int, _P]),
     'pydem_board_eval': (C.c_int, [_P, C.c_int, _P, _P, _P]),
     'pydem_board_download': (C.c_int, [_P, _P]),
 }
@@ -286,16 +287,20 @@ class Board(object):
         check(self.lib.pydem_board_set_desc(self._h, index, n, m, o.ctypes.data_as(_P), f.ctypes.data_as(_P),
                                             tile._h if tile is not None else None))
 
-    def refresh(self, comm, wave_doubles, segments, lines):
-        """segments: int64 array [nseg, 3] (staging offset, board offset, length); lines: [(tile, field, axis, index,
-        staging offset)] of this process's tiles."""
-        seg = np.ascontiguousarray(segments, np.int64).reshape(-1, 3)
+    def set_lines(self, index, mb_start, size, tile=None, lines=()):
+        """lines: [(field, axis, index, rel_offset)] of `tile` (a tile of this process), or nothing for a remote tile."""
         k = len(lines)
-        tiles = (C.c_void_p * max(k, 1))(*[l[0]._h for l in lines])
-        fields = (C.c_int * max(k, 1))(*[l[1] for l in lines]); axes = (C.c_int * max(k, 1))(*[l[2] for l in lines])
-        idx = (C.c_int64 * max(k, 1))(*[l[3] for l in lines]); offs = (C.c_int64 * max(k, 1))(*[l[4] for l in lines])
-        check(self.lib.pydem_board_refresh(self._h, comm._h if comm is not None else None, int(wave_doubles), seg.shape[0],
-                                           seg.ctypes.data_as(_P), k, tiles, fields, axes, idx, offs))
+        fields = (C.c_int * max(k, 1))(*[l[0] for l in lines]); axes = (C.c_int * max(k, 1))(*[l[1] for l in lines])
+        idx = (C.c_int64 * max(k, 1))(*[l[2] for l in lines]); offs = (C.c_int64 * max(k, 1))(*[l[3] for l in lines])
+        check(self.lib.pydem_board_set_lines(self._h, index, int(mb_start), int(size), tile._h if tile is not None else None,
+                                             k, fields, axes, idx, offs))
+
+    def refresh(self, comm, tiles):
+        tiles = list(tiles)
+        for k0 in range(0, len(tiles), 64):
+            part = tiles[k0:k0 + 64]
+            arr = (C.c_int * len(part))(*part)
+            check(self.lib.pydem_board_refresh(self._h, comm._h if comm is not None else None, len(part), arr))
 
     def eval(self, tiles, full):
         k = len(tiles)

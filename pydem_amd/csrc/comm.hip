@@ -198,6 +198,11 @@ struct pydem_board_desc {           // one per tile; offsets in doubles into the
     double *s_data; uint8_t *s_flags; int32_t L;  // strips of the tile's next round (tiles resident on this device)
 };
 
+struct pydem_pack_line { const void *src; int64_t stride, count, rel; int32_t bytes; };   // bytes: 8 = double, 1 = mask
+
+struct pydem_board_list { int n; int tile[64]; int full[64]; };
+struct pydem_board_segs { int n; int64_t src[64], dst[64], cnt[64]; };
+
 struct pydem_board {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -207,7 +212,9 @@ struct pydem_board {
     pydem_board_desc *desc = nullptr; int n_tiles = 0;
     std::vector<pydem_board_desc> h_desc;
     unsigned long long *scal = nullptr, *h_scal = nullptr;   // [n_tiles][8]
-    int64_t *seg = nullptr; int seg_cap = 0;      // scatter table of the current wave
+    // per tile: where its lines live in the board, and (tiles of this rank) how to gather them from the tile
+    struct TileLines { int64_t mb_start = 0, size = 0; pydem_tile *tile = nullptr; int count = 0; pydem_pack_line *lines = nullptr; };
+    std::vector<TileLines> tl;
 };
 
 namespace {
@@ -220,8 +227,9 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
 
 // one thread per (side, position) of one tile
 __global__ __launch_bounds__(256) void k_board_eval(const double *__restrict__ mb, const pydem_board_desc *__restrict__ descs,
-                                                    int tile, int full, unsigned long long *__restrict__ scal)
+                                                    pydem_board_list Lst, unsigned long long *__restrict__ scal)
 {
+    const int tile = Lst.tile[blockIdx.y], full = Lst.full[blockIdx.y];
     const pydem_board_desc D = descs[tile];
     const int n = D.n, m = D.m;
     const int64_t total = 2 * (int64_t)n + 2 * (int64_t)m;
@@ -311,13 +319,35 @@ __global__ __launch_bounds__(256) void k_board_eval(const double *__restrict__ m
     if (threadIdx.x == 0) for (int j = 0; j < 6; j++) atomicAdd(&scal[(size_t)tile * 8 + j], red[j][0]);
 }
 
-// wave staging -> board: segment s copies seg[3s+2] doubles from wb + seg[3s] to mb + seg[3s+1]
-__global__ void k_board_scatter(const double *__restrict__ wb, double *__restrict__ mb, const int64_t *__restrict__ seg, int nseg)
+// all lines of one tile -> wave staging (blockIdx.y = line)
+__global__ void k_board_pack(const pydem_pack_line *__restrict__ lines, int nlines, double *__restrict__ wb)
 {
-    for (int s = blockIdx.y; s < nseg; s += gridDim.y) {
-        const int64_t src = seg[3 * s], dst = seg[3 * s + 1], cnt = seg[3 * s + 2];
+    for (int l = blockIdx.y; l < nlines; l += gridDim.y) {
+        const pydem_pack_line P = lines[l];
+        double *dst = wb + P.rel;
+        if (P.bytes == 8) {
+            const double *src = (const double *)P.src;
+            for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < P.count; k += (int64_t)gridDim.x * blockDim.x) dst[k] = src[k * P.stride];
+        } else {
+            const uint8_t *src = (const uint8_t *)P.src;
+            for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < P.count; k += (int64_t)gridDim.x * blockDim.x) dst[k] = (double)src[k * P.stride];
+        }
+    }
+}
+
+// wave staging -> board (blockIdx.y = tile of the wave)
+__global__ void k_board_scatter(const double *__restrict__ wb, double *__restrict__ mb, pydem_board_segs S)
+{
+    for (int s = blockIdx.y; s < S.n; s += gridDim.y) {
+        const int64_t src = S.src[s], dst = S.dst[s], cnt = S.cnt[s];
         for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * blockDim.x) mb[dst + k] = wb[src + k];
     }
+}
+
+__global__ void k_board_zero(unsigned long long *scal, pydem_board_list Lst)
+{
+    const int k = threadIdx.x >> 3, j = threadIdx.x & 7;
+    if (k < Lst.n) scal[(size_t)Lst.tile[k] * 8 + j] = 0ull;
 }
 
 }  // namespace
@@ -346,7 +376,8 @@ int pydem_board_destroy(pydem_board *b)
     if (!b) return 0;
     (void)hipSetDevice(b->device);
     (void)hipStreamSynchronize(b->stream);
-    for (void *p : {(void *)b->mb, (void *)b->wb, (void *)b->desc, (void *)b->scal, (void *)b->seg}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)b->mb, (void *)b->wb, (void *)b->desc, (void *)b->scal}) if (p) (void)hipFree(p);
+    for (auto &T : b->tl) if (T.lines) (void)hipFree(T.lines);
     if (b->h_scal) (void)hipHostFree(b->h_scal);
     if (b->ev) (void)hipEventDestroy(b->ev);
     if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -379,48 +410,86 @@ int pydem_board_set_desc(pydem_board *b, int index, int32_t n, int32_t m, const 
     return 0;
 }
 
-// Refresh the board with the lines of the tiles that ran in a wave.  `nseg` segments (staging offset, board
-// offset, length) describe the whole wave identically on every rank; this rank packs the `count` lines of ITS
-// tiles (tiles[k], fields[k], axes[k], indices[k]) to staging offset wb_offsets[k].  With a communicator the
-// staging buffer is summed over the ranks (disjoint fills) before it is scattered into the board.
-int pydem_board_refresh(pydem_board *b, pydem_comm *c, int64_t wave_doubles, int nseg, const int64_t *seg3,
-                        int count, pydem_tile *const *tiles, const int *fields, const int *axes, const int64_t *indices,
-                        const int64_t *wb_offsets)
+// which lines of the board belong to tile `index` (contiguous: mb_start .. mb_start + size) and, for a tile of this rank,
+// how to gather them: line k = fields[k] / axes[k] / indices[k] of `tile`, rel_offsets[k] doubles after mb_start
+int pydem_board_set_lines(pydem_board *b, int index, int64_t mb_start, int64_t size, pydem_tile *tile, int count,
+                          const int *fields, const int *axes, const int64_t *indices, const int64_t *rel_offsets)
 {
     HIP_TRY(hipSetDevice(b->device));
-    if (wave_doubles <= 0 || nseg <= 0) return 0;
-    if (wave_doubles > b->wcap) {
-        if (b->wb) HIP_TRY(hipFree(b->wb));
-        HIP_TRY(hipMalloc((void **)&b->wb, (size_t)wave_doubles * 8));
-        b->wcap = wave_doubles;
-    }
-    if (nseg > b->seg_cap) {
-        if (b->seg) HIP_TRY(hipFree(b->seg));
-        HIP_TRY(hipMalloc((void **)&b->seg, (size_t)nseg * 3 * sizeof(int64_t)));
-        b->seg_cap = nseg;
-    }
-    HIP_TRY(hipMemcpyAsync(b->seg, seg3, (size_t)nseg * 3 * sizeof(int64_t), hipMemcpyHostToDevice, b->stream));
-    if (c && c->world > 1) HIP_TRY(hipMemsetAsync(b->wb, 0, (size_t)wave_doubles * 8, b->stream));
-    HIP_TRY(hipEventRecord(b->ev, b->stream));
-    // packs run on the tiles' own streams (behind the rounds they just ran), the board stream waits for them
-    pydem_comm tmp;                       // pack_one only looks at buf / cap / device
-    tmp.buf = b->wb; tmp.cap = (size_t)b->wcap; tmp.device = b->device;
-    pydem_tile *last = nullptr;
+    if (index < 0 || index >= b->n_tiles) { pydem_set_error("pydem_board_set_lines: tile index out of range"); return -2; }
+    if (mb_start < 0 || mb_start + size > b->cap) { pydem_set_error("pydem_board_set_lines: lines beyond the board"); return -2; }
+    if ((int)b->tl.size() != b->n_tiles) b->tl.resize((size_t)b->n_tiles);
+    pydem_board::TileLines &T = b->tl[(size_t)index];
+    T.mb_start = mb_start; T.size = size; T.tile = tile; T.count = 0;
+    if (!tile) return 0;
+    if (tile->device != b->device) { pydem_set_error("pydem_board_set_lines: tile lives on another device"); return -2; }
+    std::vector<pydem_pack_line> h((size_t)count);
     for (int k = 0; k < count; k++) {
-        pydem_tile *t = tiles[k];
-        if (t != last) {
-            if (last) { HIP_TRY(hipEventRecord(last->ev_snap, last->stream)); HIP_TRY(hipStreamWaitEvent(b->stream, last->ev_snap, 0)); }
-            HIP_TRY(hipStreamWaitEvent(t->stream, b->ev, 0));
-            last = t;
-        }
-        const int r = pack_one(&tmp, t, fields[k], axes[k], indices[k], wb_offsets[k]);
-        if (r) { tmp.buf = nullptr; return r; }
+        void **pp; size_t elem;
+        const int axis = axes[k];
+        int64_t idx = indices[k];
+        const int64_t lim = axis == 0 ? tile->n : tile->m;
+        if (idx < 0) idx += lim;
+        if (idx < 0 || idx >= lim || (axis != 0 && axis != 1)) { pydem_set_error("pydem_board_set_lines: line index out of range"); return -2; }
+        const int f = fields[k];
+        const void *base = nullptr;
+        if (f == PYDEM_UCA) { base = tile->uca; elem = 8; }
+        else if (f == PYDEM_EDGE_TODO) { base = tile->edge_todo; elem = 1; }
+        else if (f == PYDEM_EDGE_DONE) { base = tile->edge_done; elem = 1; }
+        else { pydem_set_error("pydem_board_set_lines: field %d is not an edge field", f); return -2; }
+        (void)pp;
+        if (!base || !tile->have[f]) { pydem_set_error("pydem_board_set_lines: field %d is not resident", f); return -3; }
+        pydem_pack_line &P = h[(size_t)k];
+        P.count = axis == 0 ? tile->m : tile->n;
+        P.stride = axis == 0 ? 1 : tile->m;
+        P.src = (const char *)base + (size_t)(axis == 0 ? idx * tile->m : idx) * elem;
+        P.rel = rel_offsets[k]; P.bytes = (int32_t)elem;
+        if (P.rel < 0 || P.rel + P.count > size) { pydem_set_error("pydem_board_set_lines: line beyond the tile's board segment"); return -2; }
     }
-    if (last) { HIP_TRY(hipEventRecord(last->ev_snap, last->stream)); HIP_TRY(hipStreamWaitEvent(b->stream, last->ev_snap, 0)); }
-    tmp.buf = nullptr;
-    if (c && c->world > 1)
-        NCCL_TRY(ncclAllReduce(b->wb, b->wb, (size_t)wave_doubles, ncclDouble, ncclSum, c->comm, b->stream));
-    hipLaunchKernelGGL(k_board_scatter, dim3(16, nseg < 64 ? nseg : 64), dim3(256), 0, b->stream, b->wb, b->mb, b->seg, nseg);
+    if (T.lines) HIP_TRY(hipFree(T.lines));
+    HIP_TRY(hipMalloc((void **)&T.lines, (size_t)(count > 0 ? count : 1) * sizeof(pydem_pack_line)));
+    HIP_TRY(hipMemcpyAsync(T.lines, h.data(), (size_t)count * sizeof(pydem_pack_line), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    T.count = count;
+    return 0;
+}
+
+// Refresh the board with the lines of the tiles that ran in a wave (the same list on every rank, at most 64 tiles per
+// call): the tiles of this rank gather their lines into the wave staging buffer (one kernel each, on the tile's own
+// stream behind the round it just ran), with a communicator the staging buffer is summed over the ranks (disjoint
+// fills), then one kernel copies it into the board.
+int pydem_board_refresh(pydem_board *b, pydem_comm *c, int n_wave, const int *wave_tiles)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    if (n_wave <= 0) return 0;
+    if (n_wave > 64) { pydem_set_error("pydem_board_refresh: at most 64 tiles per call"); return -2; }
+    pydem_board_segs S;
+    S.n = n_wave;
+    int64_t total = 0;
+    for (int k = 0; k < n_wave; k++) {
+        const int i = wave_tiles[k];
+        if (i < 0 || i >= (int)b->tl.size()) { pydem_set_error("pydem_board_refresh: tile without lines (pydem_board_set_lines)"); return -2; }
+        S.src[k] = total; S.dst[k] = b->tl[(size_t)i].mb_start; S.cnt[k] = b->tl[(size_t)i].size;
+        total += b->tl[(size_t)i].size;
+    }
+    if (total > b->wcap) {
+        if (b->wb) HIP_TRY(hipFree(b->wb));
+        HIP_TRY(hipMalloc((void **)&b->wb, (size_t)total * 8));
+        b->wcap = total;
+    }
+    if (c) HIP_TRY(hipMemsetAsync(b->wb, 0, (size_t)total * 8, b->stream));
+    HIP_TRY(hipEventRecord(b->ev, b->stream));
+    for (int k = 0; k < n_wave; k++) {
+        pydem_board::TileLines &T = b->tl[(size_t)wave_tiles[k]];
+        if (!T.tile || T.count == 0) continue;
+        pydem_tile *t = T.tile;
+        HIP_TRY(hipStreamWaitEvent(t->stream, b->ev, 0));
+        hipLaunchKernelGGL(k_board_pack, dim3(8, T.count), dim3(256), 0, t->stream, T.lines, T.count, b->wb + S.src[k]);
+        HIP_TRY(hipEventRecord(t->ev_snap, t->stream));
+        HIP_TRY(hipStreamWaitEvent(b->stream, t->ev_snap, 0));
+    }
+    if (c) NCCL_TRY(ncclAllReduce(b->wb, b->wb, (size_t)total, ncclDouble, ncclSum, c->comm, b->stream));   // also for world == 1
+    hipLaunchKernelGGL(k_board_scatter, dim3(16, n_wave), dim3(256), 0, b->stream, b->wb, b->mb, S);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -431,14 +500,21 @@ int pydem_board_refresh(pydem_board *b, pydem_comm *c, int64_t wave_doubles, int
 int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *full, unsigned long long *out)
 {
     HIP_TRY(hipSetDevice(b->device));
-    for (int k = 0; k < count; k++) {
-        const int i = tiles[k];
-        if (i < 0 || i >= b->n_tiles) { pydem_set_error("pydem_board_eval: tile index out of range"); return -2; }
-        HIP_TRY(hipMemsetAsync(b->scal + (size_t)i * 8, 0, 8 * sizeof(unsigned long long), b->stream));
-        const pydem_board_desc &D = b->h_desc[(size_t)i];
-        const int64_t total = 2 * (int64_t)D.n + 2 * (int64_t)D.m;
-        const int g = (int)(cdiv(total, 256) < 128 ? cdiv(total, 256) : 128);
-        hipLaunchKernelGGL(k_board_eval, dim3(g), dim3(256), 0, b->stream, b->mb, b->desc, i, full[k], b->scal);
+    for (int k0 = 0; k0 < count; k0 += 64) {
+        pydem_board_list Lst;
+        Lst.n = count - k0 < 64 ? count - k0 : 64;
+        int64_t most = 1;
+        for (int k = 0; k < Lst.n; k++) {
+            const int i = tiles[k0 + k];
+            if (i < 0 || i >= b->n_tiles) { pydem_set_error("pydem_board_eval: tile index out of range"); return -2; }
+            Lst.tile[k] = i; Lst.full[k] = full[k0 + k];
+            const pydem_board_desc &D = b->h_desc[(size_t)i];
+            const int64_t total = 2 * (int64_t)D.n + 2 * (int64_t)D.m;
+            if (total > most) most = total;
+        }
+        const int g = (int)(cdiv(most, 256) < 64 ? cdiv(most, 256) : 64);
+        hipLaunchKernelGGL(k_board_zero, dim3(1), dim3(512), 0, b->stream, b->scal, Lst);
+        hipLaunchKernelGGL(k_board_eval, dim3(g, Lst.n), dim3(256), 0, b->stream, b->mb, b->desc, Lst, b->scal);
     }
     HIP_TRY(hipMemcpyAsync(b->h_scal, b->scal, (size_t)b->n_tiles * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipGetLastError());

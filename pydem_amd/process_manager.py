@@ -884,16 +884,15 @@ class ProcessManager(object):
                 dp._push('uca', 'edge_todo', 'edge_done', 'flats')
             board.set_desc(i, n, m, o28 + cd + cu, f8 + c1, dp._tile if dp is not None else None)
 
+        for t in range(n_t):
+            if self.transport.owns(t):
+                board.set_lines(t, start[t], size[t], self.tiles[t]._tile,
+                                [(_FIELD_OF[req[1]], req[2], req[3], layout[req] - start[t]) for req in sorted(interest.get(t, ()))])
+            else:
+                board.set_lines(t, start[t], size[t])
+
         def refresh(tiles):
-            segs, lines, woff = [], [], 0
-            for t in sorted(tiles):
-                segs.append((woff, start[t], size[t]))
-                if self.transport.owns(t):
-                    tl = self.tiles[t]._tile
-                    for req in sorted(interest.get(t, ())):
-                        lines.append((tl, _FIELD_OF[req[1]], req[2], req[3], woff + layout[req] - start[t]))
-                woff += size[t]
-            board.refresh(comm, woff, segs, lines)
+            board.refresh(comm, sorted(tiles))
 
         def check_against_host_rules(tiles, scal):
             # PYDEM_BOARD_CHECK=1 (tests): the numbers of the evaluation kernel against the host rules on the same lines
