@@ -1728,6 +1728,291 @@ __global__ __launch_bounds__(1024) void k_einc_small(IncArgs E, QE *q0, QE *q1, 
     }
 }
 
+
+// ---- compact form of the incremental rounds ----------------------------------------------------------------
+// The cascade above is a chain of dependent accesses into seven tile-sized arrays: a level costs 5-7 us, most of
+// it address translation and HBM misses (measured: 35 k levels = 230 ms for an 8-tile fix-up at 16384^2) although
+// the cells it will ever touch -- ND, 50-70 k per tile -- would fit the L2.  So the fix-up state moves into ONE
+// 128-byte record per ND cell (compact id k: the cell, its graph word, the compact ids and weights of its
+// in-edges, the ids of its two targets, count, flags, delta); a finished cell writes its contribution into its
+// targets' in-slots (plain stores, one slot per edge: the sum stays in the fixed neighbour order) and counts them
+// down, so a cell that becomes ready needs nothing but its own record -- ONE dependent access per level plus the
+// count-down atomics.  The cascade runs on records only, and the
+// areas / masks of the tile are updated from the records by a streaming kernel after the cascade (nothing in the
+// chain waits for the big arrays).  Tiles whose ND set is too large for that (a tile that is one single
+// catchment below its inlet edge) keep the cell-indexed form.
+struct __attribute__((aligned(128))) NDRec {
+    int32_t cell;
+    uint32_t cw;
+    int32_t out_id[2];       // compact ids of the two targets (-1: no such edge)
+    uint8_t out_slot[2];     // which in-slot of the target this cell feeds (the target's neighbour index NW..SE)
+    uint16_t pad_;
+    int32_t cnt;             // unresolved in-edges (+1 for the outside of the tile while the cell is a 'todo' inlet)
+    uint32_t flag;
+    double delta;
+    double out_w[2];         // proportion, 1 - proportion (:1082)
+    double in_delta[8];      // what the finished in-neighbour NW..SE has handed over (0 until then)
+};
+static_assert(sizeof(NDRec) == 128, "one cache line per ND cell");
+constexpr uint32_t NF_FINAL = 1u, NF_DONE = 2u, NF_APPLIED = 4u, NF_SEED = 8u;
+constexpr uint32_t ND_FLAT = 1u << 16;            // in the record's graph word: the cell is a flat (its delta is NaN, :815)
+constexpr int64_t ND_COMPACT_MAX = 6 << 20;      // records (768 MiB)
+
+struct CIncArgs {
+    SweepArgs G;
+    NDRec *rec; int32_t nd;
+    int32_t *cid;            // [NN] compact id + 1 (0: not an ND cell)
+    const int2 *pit_off;
+    const uint8_t *flats;
+    uint8_t *edge_done, *edge_todo;
+    double *uca;
+    int set_done;
+    int32_t *prof;
+};
+
+__global__ __launch_bounds__(256) void k_nd_count(const uint8_t *__restrict__ edge_done, int64_t NN, unsigned long long *count)
+{
+    unsigned long long c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < NN; i += (int64_t)gridDim.x * blockDim.x) c += edge_done[i] == 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+__global__ __launch_bounds__(256) void k_nd_assign(CIncArgs E, int64_t NN, int32_t *counter)
+{
+    for (int64_t c64 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c64 < NN; c64 += (int64_t)gridDim.x * blockDim.x) {
+        if (E.edge_done[c64]) continue;
+        const int32_t k = agg_slot(counter);
+        E.cid[c64] = k + 1;
+        NDRec &R = E.rec[k];
+        R.cell = (int32_t)c64;
+        R.cw = (E.G.cinfo[c64] & CI_STATIC_MASK) | (E.flats[c64] ? ND_FLAT : 0u);
+        R.flag = 0; R.delta = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_nd_link(CIncArgs E)
+{
+    const SweepArgs &A = E.G;
+    const int m = A.m;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                   // the sink of the missing edges
+        NDRec &S = E.rec[E.nd];
+        S.cell = -1; S.cw = 0; S.out_id[0] = S.out_id[1] = -1; S.out_slot[0] = S.out_slot[1] = 0; S.cnt = 1 << 30; S.flag = 0; S.delta = 0.0;
+    }
+    for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < E.nd; k += gridDim.x * blockDim.x) {
+        NDRec &R = E.rec[k];
+        const int32_t c = R.cell;
+        const uint32_t cw = R.cw;
+        int32_t cnt = 0;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            if (cw & (1u << d)) cnt += E.cid[c + NB_DI[d] * m + NB_DJ[d]] != 0;
+            R.in_delta[d] = 0.0;
+        }
+        if (cw & CI_PIT_IN)
+            for (int32_t e = E.pit_off[c].x; e < A.n_pit && A.pin_dst[e] == c; e++) cnt += E.cid[A.pin_src[e]] != 0;
+        const int s = ci_section(cw);
+        const double p = A.prop[c];
+        const int dr[2] = {fe1r(s), fe2r(s)}, dc[2] = {fe1c(s), fe2c(s)};
+        const uint32_t has[2] = {cw & CI_OUT1, cw & CI_OUT2};
+        for (int j = 0; j < 2; j++) {
+            int32_t id = -1; int slot = 0;
+            if (has[j]) {
+                id = E.cid[c + dr[j] * m + dc[j]] - 1;
+                // seen from the target, this cell sits at (-dr, -dc): its index in the neighbour order NW..SE
+                for (int d = 0; d < 8; d++) if (NB_DI[d] == -dr[j] && NB_DJ[d] == -dc[j]) slot = d;
+            }
+            R.out_id[j] = id; R.out_slot[j] = (uint8_t)slot;
+        }
+        R.out_w[0] = p; R.out_w[1] = 1 - p;
+        if (E.edge_todo[c]) cnt += 1;                                            // the outside of the tile
+        R.cnt = cnt;
+    }
+}
+
+__global__ void k_cinc_seed(CIncArgs E, const double *__restrict__ sdata, const uint8_t *__restrict__ sdone,
+                            const uint8_t *__restrict__ stodo, int L, QE *q, int32_t *nq)
+{
+    const int n = E.G.n, m = E.G.m;
+    const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nper) return;
+    int i, j;
+    perim_cell(p, n, m, i, j);
+    const int32_t c = i * m + j;
+    bool dn = false, td = false;
+    double init = 0.0;
+    if (j == 0) { dn |= sdone[0 * L + i] != 0; init += sdata[0 * L + i] * (double)(sdone[0 * L + i] != 0); td |= stodo[0 * L + i] != 0; }
+    if (j == m - 1) { dn |= sdone[1 * L + i] != 0; init += sdata[1 * L + i] * (double)(sdone[1 * L + i] != 0); td |= stodo[1 * L + i] != 0; }
+    if (i == 0) { dn |= sdone[2 * L + j] != 0; init += sdata[2 * L + j] * (double)(sdone[2 * L + j] != 0); td |= stodo[2 * L + j] != 0; }
+    if (i == n - 1) { dn |= sdone[3 * L + j] != 0; init += sdata[3 * L + j] * (double)(sdone[3 * L + j] != 0); td |= stodo[3 * L + j] != 0; }
+    const bool own_todo = E.edge_todo[c] != 0;
+    const bool own_done = E.edge_done[c] != 0;
+    const int32_t k = E.cid[c] - 1;
+    if (dn) {
+        const double d = E.flats[c] ? NAN : init - E.uca[c];
+        E.uca[c] += d;
+        E.edge_todo[c] = 0;
+        if (k >= 0 && !own_done && !(E.rec[k].flag & NF_FINAL)) {
+            NDRec &R = E.rec[k];
+            R.delta = d;
+            R.flag = NF_FINAL | NF_SEED;
+            if (own_todo) {
+                const int32_t old = atomicSub(&R.cnt, 1);
+                if (old == 1) { QE e; e.c = k; e.cw = 0; q[agg_slot(nq)] = e; }
+            }
+        }
+    } else if (own_todo && !td) {
+        E.edge_todo[c] = 0;
+        if (k >= 0) {
+            const int32_t old = atomicSub(&E.rec[k].cnt, 1);
+            if (old == 1) { QE e; e.c = k; e.cw = 0; q[agg_slot(nq)] = e; }
+        }
+    }
+}
+
+__global__ void k_cinc_release_todo(CIncArgs E, QE *q, int32_t *nq)
+{
+    const int n = E.G.n, m = E.G.m;
+    const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nper) return;
+    int i, j;
+    perim_cell(p, n, m, i, j);
+    const int32_t c = i * m + j;
+    const int32_t k = E.cid[c] - 1;
+    if (k < 0 || !E.edge_todo[c] || (E.rec[k].flag & NF_FINAL)) return;
+    const int32_t old = atomicSub(&E.rec[k].cnt, 1);
+    if (old == 1) { QE e; e.c = k; e.cw = 0; q[agg_slot(nq)] = e; }
+}
+
+template <typename Push>
+__device__ __forceinline__ void cinc_cell(const CIncArgs &E, QE q, Push push)
+{
+    // (letting the lane walk on along the chain it releases -- one count-down atomic plus one record load per step, no
+    // queue, no barrier -- was measured and is slower: 323 instead of 209 ms of rounds for the 8-tile fix-up at
+    // 16384^2; the side branches a walking lane pushes wait for the whole walk)
+    const int32_t k = q.c;
+    NDRec &R = E.rec[k];
+    // the only dependent access of a level: the cell's own record, one cache line, loaded whole
+    const uint4 *line = reinterpret_cast<const uint4 *>(&R);
+    uint4 L[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) L[i] = line[i];
+    NDRec V;
+    __builtin_memcpy(&V, L, sizeof(V));
+    const uint32_t cw = V.cw;
+    double delta = V.delta;
+    if (!(V.flag & NF_FINAL)) {
+        double acc = (cw & ND_FLAT) ? NAN : 0.0;                                 // :815
+#pragma unroll
+        for (int d = 0; d < 8; d++) acc += V.in_delta[d];                        // fixed order NW..SE; untouched slots are 0
+        if (cw & CI_PIT_IN) {
+            const SweepArgs &A = E.G;
+            for (int32_t e = E.pit_off[V.cell].x; e < A.n_pit && A.pin_dst[e] == V.cell; e++) {
+                const int32_t ks = E.cid[A.pin_src[e]] - 1;
+                if (ks >= 0 && (E.rec[ks].flag & NF_FINAL)) acc += E.rec[ks].delta * A.pin_w[e];
+            }
+        }
+        delta = acc;
+        R.delta = acc;
+        R.flag = NF_FINAL | NF_DONE;
+    } else {
+        R.flag = V.flag | NF_DONE;                                               // a seed keeps the value it adopted
+    }
+    // hand the contribution over, then count the targets down.  A missing edge points at the sink record rec[nd]
+    // (its count never reaches zero), so both stores and both atomics are issued unconditionally, back to back
+    const int32_t o0 = V.out_id[0] >= 0 ? V.out_id[0] : E.nd, o1 = V.out_id[1] >= 0 ? V.out_id[1] : E.nd;
+    E.rec[o0].in_delta[V.out_slot[0]] = delta * V.out_w[0];
+    E.rec[o1].in_delta[V.out_slot[1]] = delta * V.out_w[1];
+    const int32_t old0 = atomicSub(&E.rec[o0].cnt, 1);
+    const int32_t old1 = atomicSub(&E.rec[o1].cnt, 1);
+    if (old0 == 1) push(o0, 0u);
+    if (old1 == 1) push(o1, 0u);
+    if (cw & CI_PIT_OUT) {
+        const SweepArgs &A = E.G;
+        for (int32_t e = E.pit_off[V.cell].y; e < A.n_pit && A.pit_src[e] == V.cell; e++) {
+            const int32_t kt = E.cid[A.pit_dst[e]] - 1;
+            if (kt >= 0 && atomicSub(&E.rec[kt].cnt, 1) == 1) push(kt, 0u);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cinc_level(CIncArgs E, const QE *__restrict__ qc, QE *__restrict__ qn, int32_t *cnt3, int r)
+{
+    const int32_t nq = cnt3[r % 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt3[(r + 2) % 3] = 0;
+    if (nq == 0) return;
+    int32_t *cn = &cnt3[(r + 1) % 3];
+    for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nq; k += gridDim.x * blockDim.x) {
+        auto push = [&](int32_t t, uint32_t ct) { QE e; e.c = t; e.cw = ct; qn[agg_slot(cn)] = e; };
+        cinc_cell(E, qc[k], push);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_cinc_small(CIncArgs E, QE *q0, QE *q1, int32_t *cnt3, int r_start, int32_t *state)
+{
+    __shared__ QE s_q[2][SMALL_CAP];
+    __shared__ int32_t s_cnt[3];     // pushes of level r go to s_cnt[(r + 1) % 3]; s_cnt[(r + 2) % 3] is zeroed meanwhile: ONE barrier per level
+    int r = r_start;
+    int32_t nq = cnt3[r % 3];
+    if (nq > 0 && nq <= SMALL_CAP) {
+        const QE *qc = (r % 2) ? q1 : q0;
+        for (int32_t k = threadIdx.x; k < nq; k += blockDim.x) s_q[r % 2][k] = qc[k];
+    }
+    if (threadIdx.x == 0) { s_cnt[0] = s_cnt[1] = s_cnt[2] = 0; }
+#ifdef PYDEM_EINC_PROF
+    long long prof_t[4] = {0, 0, 0, 0}; int prof_n[4] = {0, 0, 0, 0};
+#endif
+    __syncthreads();
+    while (nq > 0 && nq <= SMALL_CAP) {
+#ifdef PYDEM_EINC_PROF
+        const long long t0 = wall_clock64();
+        const int cls = nq <= 8 ? 0 : (nq <= 64 ? 1 : (nq <= 512 ? 2 : 3));
+#endif
+        int32_t *cn = &s_cnt[(r + 1) % 3];
+        if (threadIdx.x == 0) s_cnt[(r + 2) % 3] = 0;
+        QE *qn = (r % 2) ? q0 : q1;
+        QE *ln = s_q[(r + 1) % 2];
+        for (int32_t k = threadIdx.x; k < nq; k += blockDim.x) {
+            auto push = [&](int32_t t, uint32_t ct) {
+                QE e; e.c = t; e.cw = ct;
+                const int32_t slot = agg_slot(cn);
+                if (slot < SMALL_CAP) ln[slot] = e;
+                qn[slot] = e;
+            };
+            cinc_cell(E, s_q[r % 2][k], push);
+        }
+        __syncthreads();
+        nq = *cn;
+        r++;
+#ifdef PYDEM_EINC_PROF
+        prof_t[cls] += wall_clock64() - t0; prof_n[cls]++;
+#endif
+    }
+    if (threadIdx.x == 0) {
+        cnt3[r % 3] = nq; cnt3[(r + 1) % 3] = 0; cnt3[(r + 2) % 3] = 0;
+        state[0] = r;
+#ifdef PYDEM_EINC_PROF
+        for (int k = 0; k < 4; k++) { atomicAdd(&E.prof[k], prof_n[k]); atomicAdd(&E.prof[4 + k], (int)prof_t[k]); }
+#endif
+    }
+}
+
+// records -> tile: areas and masks of the cells the last cascade finished
+__global__ __launch_bounds__(256) void k_cinc_apply(CIncArgs E)
+{
+    for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < E.nd; k += gridDim.x * blockDim.x) {
+        NDRec &R = E.rec[k];
+        const uint32_t f = R.flag;
+        if ((f & NF_DONE) && !(f & NF_APPLIED)) {
+            if (!(f & NF_SEED)) E.uca[R.cell] += R.delta;                       // (a seed took its value when the strip arrived)
+            if (E.set_done) E.edge_done[R.cell] = 1;
+            R.flag = f | NF_APPLIED;
+        }
+    }
+}
+
 int grid_for(int64_t work, int cap) { const int64_t g = cdiv(work, 256); return (int)(g < cap ? (g > 0 ? g : 1) : cap); }
 
 }  // namespace
@@ -2223,6 +2508,90 @@ static int einc_cascade(pydem_tile *t, const IncArgs &E, int *levels)
     return 0;
 }
 
+
+static int cinc_args(pydem_tile *t, CIncArgs &E)
+{
+    fill_sweep_args(t, E.G);
+    E.rec = (NDRec *)t->nd_rec; E.nd = t->nd; E.cid = t->estamp;
+    E.pit_off = reinterpret_cast<const int2 *>(t->contrib);
+    E.flats = t->flats; E.edge_done = t->edge_done; E.edge_todo = t->edge_todo; E.uca = t->uca; E.set_done = 1;
+    E.prof = t->counters + 40;
+    return 0;
+}
+
+static int cinc_cascade(pydem_tile *t, const CIncArgs &E, int *levels)
+{
+    int32_t *cnt3 = t->counters;
+    int32_t *state = t->counters + 12;
+    QE *q0 = (QE *)t->queue[0], *q1 = (QE *)t->queue[1];
+    int r = 0;
+    for (;;) {
+        hipLaunchKernelGGL(k_cinc_small, dim3(1), dim3(1024), 0, t->stream, E, q0, q1, cnt3, r, state);
+        HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        r = t->h_counters[12];
+        int32_t last = t->h_counters[r % 3];
+        if (last == 0) break;
+        while (last > SMALL_CAP) {
+            const int batch = last > 65536 ? 4 : 16;
+            const int grid = grid_for(last, 1024);
+            for (int b = 0; b < batch; b++, r++)
+                hipLaunchKernelGGL(k_cinc_level, dim3(grid), dim3(256), 0, t->stream, E, (r % 2) ? q1 : q0, (r % 2) ? q0 : q1, cnt3, r);
+            HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            last = t->h_counters[r % 3];
+            if (r > (1 << 24)) { pydem_set_error("edge update: flow paths too long"); return -5; }
+        }
+        if (last == 0) break;
+    }
+    if (levels) *levels = r;
+    hipLaunchKernelGGL(k_cinc_apply, dim3(grid_for(E.nd, 1024)), dim3(256), 0, t->stream, E);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+// first incremental round after the graph was (re)built: count the cells that are not done and choose the form
+static int einc_prepare(pydem_tile *t, IncArgs &E)
+{
+    if (E.G.n_pit > 0)
+        hipLaunchKernelGGL(k_pit_offsets, dim3(grid_for(E.G.n_pit, 2048)), dim3(256), 0, t->stream, E.G.pin_dst, E.G.pit_src, E.G.n_pit,
+                           reinterpret_cast<int2 *>(t->contrib));
+    HIP_TRY(hipMemsetAsync(t->estamp, 0, (size_t)t->NN * 4, t->stream));
+    unsigned long long *cnt64 = reinterpret_cast<unsigned long long *>(t->counters + 48);
+    HIP_TRY(hipMemsetAsync(t->counters + 48, 0, 4 * sizeof(int32_t), t->stream));
+    hipLaunchKernelGGL(k_nd_count, dim3(grid_for(t->NN, 4096)), dim3(256), 0, t->stream, t->edge_done, t->NN, cnt64);
+    HIP_TRY(hipMemcpyAsync(t->h_counters + 48, t->counters + 48, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    const int64_t nd = (int64_t)*reinterpret_cast<unsigned long long *>(t->h_counters + 48);
+    static int64_t compact_max = -1;
+    if (compact_max < 0) { const char *e = getenv("PYDEM_EINC_COMPACT_MAX"); compact_max = e ? atoll(e) : ND_COMPACT_MAX; }
+    t->einc_compact = nd <= compact_max;
+    if (t->einc_compact) {
+        if (nd > t->nd_cap) {
+            if (t->nd_rec) { HIP_TRY(hipFree(t->nd_rec)); t->device_bytes -= t->nd_cap * (int64_t)sizeof(NDRec); }
+            const int64_t cap = nd + nd / 8 + 1024;
+            HIP_TRY(hipMalloc(&t->nd_rec, (size_t)cap * sizeof(NDRec)));
+            t->nd_cap = cap; t->device_bytes += cap * (int64_t)sizeof(NDRec);
+        }
+        t->nd = (int32_t)nd;
+        CIncArgs C;
+        PYDEM_TRY(cinc_args(t, C));
+        HIP_TRY(hipMemsetAsync(t->counters + 50, 0, sizeof(int32_t), t->stream));
+        if (nd > 0) {
+            hipLaunchKernelGGL(k_nd_assign, dim3(grid_for(t->NN, 4096)), dim3(256), 0, t->stream, C, t->NN, t->counters + 50);
+            hipLaunchKernelGGL(k_nd_link, dim3(grid_for(nd, 1024)), dim3(256), 0, t->stream, C);
+        }
+    } else {
+        hipLaunchKernelGGL(k_edge_clear_levels, dim3(grid_for(t->NN, 8192)), dim3(256), 0, t->stream, E.G.cinfo, t->NN);
+        hipLaunchKernelGGL(k_einc_prepare, dim3(grid_for(t->NN, 8192)), dim3(256), 0, t->stream, E, t->NN);
+    }
+    HIP_TRY(hipGetLastError());
+    t->einc_ready = true;
+    t->edge_clean = false;          // the classic rounds find their zeroed state gone
+    return 0;
+}
+
 int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *const data[4], const uint8_t *const done[4],
                          const uint8_t *const todo[4])
 {
@@ -2239,16 +2608,7 @@ int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *
     PYDEM_TRY(einc_args(t, E));
     PYDEM_TRY(tile_alloc(t, &t->s_data, (size_t)L * 4));
     PYDEM_TRY(tile_alloc(t, &t->s_flags, (size_t)L * 8));
-    if (!t->einc_ready) {
-        if (E.G.n_pit > 0)
-            hipLaunchKernelGGL(k_pit_offsets, dim3(grid_for(E.G.n_pit, 2048)), dim3(256), 0, t->stream, E.G.pin_dst, E.G.pit_src, E.G.n_pit,
-                               reinterpret_cast<int2 *>(t->contrib));
-        HIP_TRY(hipMemsetAsync(t->estamp, 0, (size_t)t->NN * 4, t->stream));
-        hipLaunchKernelGGL(k_edge_clear_levels, dim3(grid_for(t->NN, 8192)), dim3(256), 0, t->stream, E.G.cinfo, t->NN);
-        hipLaunchKernelGGL(k_einc_prepare, dim3(grid_for(t->NN, 8192)), dim3(256), 0, t->stream, E, t->NN);
-        t->einc_ready = true;
-        t->edge_clean = false;          // the classic rounds find their zeroed state gone
-    }
+    if (!t->einc_ready) PYDEM_TRY(einc_prepare(t, E));
     // strips -> device (left, right, top, bottom), padded to L entries each (pinned staging: the copies are asynchronous);
     // data == NULL: the edge board's evaluation kernel has already written them (comm.hip)
     if (data) {
@@ -2273,10 +2633,18 @@ int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *
     }
     HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
     HIP_TRY(hipMemsetAsync(t->counters + 40, 0, 8 * sizeof(int32_t), t->stream));
-    hipLaunchKernelGGL(k_einc_seed, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, E, t->s_data, t->s_flags,
-                       t->s_flags + (size_t)4 * L, L, (QE *)t->queue[0], &t->counters[0]);
     int levels = 0;
-    PYDEM_TRY(einc_cascade(t, E, &levels));
+    if (t->einc_compact) {
+        CIncArgs C;
+        PYDEM_TRY(cinc_args(t, C));
+        hipLaunchKernelGGL(k_cinc_seed, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, C, t->s_data, t->s_flags,
+                           t->s_flags + (size_t)4 * L, L, (QE *)t->queue[0], &t->counters[0]);
+        PYDEM_TRY(cinc_cascade(t, C, &levels));
+    } else {
+        hipLaunchKernelGGL(k_einc_seed, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, E, t->s_data, t->s_flags,
+                           t->s_flags + (size_t)4 * L, L, (QE *)t->queue[0], &t->counters[0]);
+        PYDEM_TRY(einc_cascade(t, E, &levels));
+    }
     if (getenv("PYDEM_EDGE_DEBUG"))
         fprintf(stderr, "incremental edge round: %d levels; %.3f ms\n", levels, host_now_ms() - t_begin);
 #ifdef PYDEM_EINC_PROF
@@ -2295,12 +2663,20 @@ int stage_edge_flush(pydem_tile *t)
     if (!t->einc_ready) return 0;
     const int n = (int)t->n, m = (int)t->m;
     const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
-    IncArgs E;
-    PYDEM_TRY(einc_args(t, E));
-    E.set_done = 0;
     HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
-    hipLaunchKernelGGL(k_einc_release_todo, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, E, (QE *)t->queue[0], &t->counters[0]);
-    PYDEM_TRY(einc_cascade(t, E, nullptr));
+    if (t->einc_compact) {
+        CIncArgs C;
+        PYDEM_TRY(cinc_args(t, C));
+        C.set_done = 0;
+        hipLaunchKernelGGL(k_cinc_release_todo, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, C, (QE *)t->queue[0], &t->counters[0]);
+        PYDEM_TRY(cinc_cascade(t, C, nullptr));
+    } else {
+        IncArgs E;
+        PYDEM_TRY(einc_args(t, E));
+        E.set_done = 0;
+        hipLaunchKernelGGL(k_einc_release_todo, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, E, (QE *)t->queue[0], &t->counters[0]);
+        PYDEM_TRY(einc_cascade(t, E, nullptr));
+    }
     t->einc_ready = false;              // counts and deltas are spent: the next incremental round starts from the masks again
     return 0;
 }
