@@ -9,8 +9,10 @@
 // round's pushes, a target that is already done and lies on the tile edge is skipped, a target becomes
 // part of the next frontier when all its CSR upstream cells are done, and the loop ends when the
 // frontier repeats itself (normally: is empty).  Differences: frontiers are lists (the Cython code
-// rescans all N cells four times per round), additions into one target within a round are fp64
-// atomics (the Cython order is ascending source id), so sums can differ in the last bits.
+// rescans all N cells four times per round).  The additions into one target within a round keep the
+// Cython order -- ascending source id -- without floating-point atomics: a round first collects its
+// targets, then every target PULLS over its CSR row (scipy's tocsr keeps the column indices sorted)
+// from the sources that are in the round's frontier; results are bit-identical run to run.
 #include "internal.h"
 #include <string.h>
 
@@ -29,33 +31,55 @@ __global__ void k_cy_mark_done(const int32_t *__restrict__ front, int32_t nf, ui
     }
 }
 
-__global__ void k_cy_push(const int32_t *__restrict__ front, int32_t nf, double *area, const uint8_t *__restrict__ done,
-                          const int32_t *__restrict__ col_indptr, const int32_t *__restrict__ col_indices,
-                          const double *__restrict__ col_data, const int32_t *__restrict__ row_indptr,
-                          const int32_t *__restrict__ row_indices, int64_t n_rows, int64_t n_cols, double *edge_todo,
-                          double *edge_todo_nm, int skip_edge, int32_t *mark, int32_t tag, int32_t *next, int32_t *n_next,
-                          int32_t *n_repeat)
+// phase 1 of a round: the distinct targets of the frontier (cyutils.pyx:155-161)
+__global__ void k_cy_targets(const int32_t *__restrict__ front, int32_t nf, const uint8_t *__restrict__ done,
+                             const int32_t *__restrict__ col_indptr, const int32_t *__restrict__ col_indices, int64_t n_rows,
+                             int64_t n_cols, int skip_edge, int32_t *tmark, int32_t tag, int32_t *targets, int32_t *n_targets)
 {
     for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
         const int32_t i = front[q];
-        const double ai = area[i];
-        const double ti = edge_todo ? edge_todo[i] : 0.0, tni = edge_todo_nm ? edge_todo_nm[i] : 0.0;
         for (int32_t j = col_indptr[i]; j < col_indptr[i + 1]; j++) {
             const int32_t row = col_indices[j];
-            const double w = col_data[j];
             if ((skip_edge || done[row]) && cy_on_edge(row, n_rows, n_cols)) continue;          // :159-161
-            atomicAdd(&area[row], ai * w);                                                       // :163
-            if (edge_todo) atomicAdd(&edge_todo[row], ti * w);                                   // :165-168
-            if (edge_todo_nm) atomicAdd(&edge_todo_nm[row], tni * w);
-            bool wait = false;
-            for (int32_t k = row_indptr[row]; k < row_indptr[row + 1]; k++)
-                if (!done[row_indices[k]]) { wait = true; break; }                               // :173-179
-            if (!wait) {
-                const int32_t old = atomicExch(&mark[row], tag);
-                if (old != tag) {                                                                // first time this round
-                    next[atomicAdd(n_next, 1)] = row;
-                    if (old == tag - 1) atomicAdd(n_repeat, 1);                                  // was in the previous frontier too
+            if (atomicExch(&tmark[row], tag) != tag) targets[atomicAdd(n_targets, 1)] = row;
+        }
+    }
+}
+
+// phase 2: every target adds what the frontier sends it, in ascending source order (:163-168), then checks
+// whether all of its upstream cells are done (:173-179)
+__global__ void k_cy_pull(const int32_t *__restrict__ targets, int32_t nt, double *area, const uint8_t *__restrict__ done,
+                          const int32_t *__restrict__ col_indptr, const int32_t *__restrict__ col_indices,
+                          const double *__restrict__ col_data, const int32_t *__restrict__ row_indptr,
+                          const int32_t *__restrict__ row_indices, double *edge_todo, double *edge_todo_nm,
+                          int32_t *mark, int32_t tag, int32_t *next, int32_t *n_next, int32_t *n_repeat)
+{
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nt; q += gridDim.x * blockDim.x) {
+        const int32_t row = targets[q];
+        double a = area[row];
+        double t = edge_todo ? edge_todo[row] : 0.0, tn = edge_todo_nm ? edge_todo_nm[row] : 0.0;
+        bool wait = false;
+        for (int32_t k = row_indptr[row]; k < row_indptr[row + 1]; k++) {
+            const int32_t src = row_indices[k];
+            if (mark[src] == tag - 1) {                      // a member of this round's frontier: its push, :163
+                for (int32_t j = col_indptr[src]; j < col_indptr[src + 1]; j++) {
+                    if (col_indices[j] != row) continue;
+                    const double w = col_data[j];
+                    a += area[src] * w;
+                    if (edge_todo) t += edge_todo[src] * w;
+                    if (edge_todo_nm) tn += edge_todo_nm[src] * w;
                 }
+            }
+            if (!done[src]) wait = true;
+        }
+        area[row] = a;
+        if (edge_todo) edge_todo[row] = t;
+        if (edge_todo_nm) edge_todo_nm[row] = tn;
+        if (!wait) {
+            const int32_t old = atomicExch(&mark[row], tag);
+            if (old != tag) {
+                next[atomicAdd(n_next, 1)] = row;
+                if (old == tag - 1) atomicAdd(n_repeat, 1);                                      // was in the previous frontier too
             }
         }
     }
@@ -103,10 +127,11 @@ int pydem_drain_area(double *area, uint8_t *done, uint8_t *ids, const int32_t *c
     const int64_t N = n_rows * n_cols;
     if (N >= INT32_MAX) { pydem_set_error("graph too large for int32 ids"); return -2; }
     const int64_t nnz = col_indptr[N];
-    DevBuf d_area, d_done, d_cp, d_ci, d_cd, d_rp, d_ri, d_et, d_etn, d_mark, d_q0, d_q1, d_cnt;
+    DevBuf d_area, d_done, d_cp, d_ci, d_cd, d_rp, d_ri, d_et, d_etn, d_mark, d_q0, d_q1, d_cnt, d_tmark, d_targets;
     PYDEM_TRY(d_area.alloc(N * 8)); PYDEM_TRY(d_done.alloc(N)); PYDEM_TRY(d_cp.alloc((N + 1) * 4)); PYDEM_TRY(d_ci.alloc(nnz * 4));
     PYDEM_TRY(d_cd.alloc(nnz * 8)); PYDEM_TRY(d_rp.alloc((N + 1) * 4)); PYDEM_TRY(d_ri.alloc(nnz * 4));
     PYDEM_TRY(d_mark.alloc(N * 4)); PYDEM_TRY(d_q0.alloc(N * 4)); PYDEM_TRY(d_q1.alloc(N * 4)); PYDEM_TRY(d_cnt.alloc(16));
+    PYDEM_TRY(d_tmark.alloc(N * 4)); PYDEM_TRY(d_targets.alloc(N * 4));
     if (edge_todo) PYDEM_TRY(d_et.alloc(N * 8));
     if (edge_todo_no_mask) PYDEM_TRY(d_etn.alloc(N * 8));
     HIP_TRY(hipMemcpy(d_area.p, area, N * 8, hipMemcpyHostToDevice));
@@ -119,6 +144,7 @@ int pydem_drain_area(double *area, uint8_t *done, uint8_t *ids, const int32_t *c
     if (edge_todo) HIP_TRY(hipMemcpy(d_et.p, edge_todo, N * 8, hipMemcpyHostToDevice));
     if (edge_todo_no_mask) HIP_TRY(hipMemcpy(d_etn.p, edge_todo_no_mask, N * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemset(d_mark.p, 0, N * 4));
+    HIP_TRY(hipMemset(d_tmark.p, 0, N * 4));
     std::vector<int32_t> front;
     front_from_mask(ids, N, front);
     int32_t nf = (int32_t)front.size();
@@ -132,10 +158,17 @@ int pydem_drain_area(double *area, uint8_t *done, uint8_t *ids, const int32_t *c
             const int g = (int)(cdiv(nf, 256) < 2048 ? cdiv(nf, 256) : 2048);
             hipLaunchKernelGGL(k_cy_mark_done, dim3(g), dim3(256), 0, 0, q[cur], nf, d_done.as<uint8_t>(), d_mark.as<int32_t>(), tag);
             HIP_TRY(hipMemset(d_cnt.p, 0, 16));
-            hipLaunchKernelGGL(k_cy_push, dim3(g), dim3(256), 0, 0, q[cur], nf, d_area.as<double>(), d_done.as<uint8_t>(),
-                               d_cp.as<int32_t>(), d_ci.as<int32_t>(), d_cd.as<double>(), d_rp.as<int32_t>(), d_ri.as<int32_t>(),
-                               n_rows, n_cols, edge_todo ? d_et.as<double>() : nullptr, edge_todo_no_mask ? d_etn.as<double>() : nullptr,
-                               skip_edge, d_mark.as<int32_t>(), tag, q[1 - cur], d_cnt.as<int32_t>(), d_cnt.as<int32_t>() + 1);
+            hipLaunchKernelGGL(k_cy_targets, dim3(g), dim3(256), 0, 0, q[cur], nf, d_done.as<uint8_t>(), d_cp.as<int32_t>(), d_ci.as<int32_t>(),
+                               n_rows, n_cols, skip_edge, d_tmark.as<int32_t>(), tag, d_targets.as<int32_t>(), d_cnt.as<int32_t>() + 2);
+            int32_t nt = 0;
+            HIP_TRY(hipMemcpy(&nt, d_cnt.as<int32_t>() + 2, 4, hipMemcpyDeviceToHost));
+            if (nt > 0) {
+                const int gt = (int)(cdiv(nt, 256) < 2048 ? cdiv(nt, 256) : 2048);
+                hipLaunchKernelGGL(k_cy_pull, dim3(gt), dim3(256), 0, 0, d_targets.as<int32_t>(), nt, d_area.as<double>(), d_done.as<uint8_t>(),
+                                   d_cp.as<int32_t>(), d_ci.as<int32_t>(), d_cd.as<double>(), d_rp.as<int32_t>(), d_ri.as<int32_t>(),
+                                   edge_todo ? d_et.as<double>() : nullptr, edge_todo_no_mask ? d_etn.as<double>() : nullptr,
+                                   d_mark.as<int32_t>(), tag, q[1 - cur], d_cnt.as<int32_t>(), d_cnt.as<int32_t>() + 1);
+            }
             HIP_TRY(hipGetLastError());
         } else {
             HIP_TRY(hipMemset(d_cnt.p, 0, 16));

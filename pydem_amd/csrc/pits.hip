@@ -1311,11 +1311,9 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             // second pass: workgroup per pit, 640x640 window in LDS
             const int gb = n_over < 1024 ? n_over : 1024;
             const size_t dyn = (size_t)3 * W_LARGE * W_LARGE / 8;
-            static bool attr_set = false;
-            if (!attr_set) {
-                HIP_TRY(hipFuncSetAttribute((const void *)k_pits_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-                attr_set = true;
-            }
+            // (function attributes are per device, and tiles of several devices / threads come through here: set it
+            // every time -- the call is cheap next to a 640 x 640 window search)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_pits_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
             const size_t need = (size_t)gb * MAXD_LARGE * (4 + 8 + 8);
             if (t->scratch_bytes < need) {
                 if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->device_bytes -= (int64_t)t->scratch_bytes; }

@@ -2527,12 +2527,17 @@ static int cinc_cascade(pydem_tile *t, const CIncArgs &E, int *levels)
     int r = 0;
     for (;;) {
         hipLaunchKernelGGL(k_cinc_small, dim3(1), dim3(1024), 0, t->stream, E, q0, q1, cnt3, r, state);
+        // (the usual case: the frontier stayed small and the cascade is over -- the records go to the tile right away,
+        // ONE host synchronisation per round; cells finished so far are applied either way)
+        hipLaunchKernelGGL(k_cinc_apply, dim3(grid_for(E.nd, 1024)), dim3(256), 0, t->stream, E);
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         r = t->h_counters[12];
         int32_t last = t->h_counters[r % 3];
         if (last == 0) break;
+        bool wide = false;
         while (last > SMALL_CAP) {
+            wide = true;
             const int batch = last > 65536 ? 4 : 16;
             const int grid = grid_for(last, 1024);
             for (int b = 0; b < batch; b++, r++)
@@ -2542,12 +2547,13 @@ static int cinc_cascade(pydem_tile *t, const CIncArgs &E, int *levels)
             last = t->h_counters[r % 3];
             if (r > (1 << 24)) { pydem_set_error("edge update: flow paths too long"); return -5; }
         }
-        if (last == 0) break;
+        if (last == 0) {
+            if (wide) { hipLaunchKernelGGL(k_cinc_apply, dim3(grid_for(E.nd, 1024)), dim3(256), 0, t->stream, E); HIP_TRY(hipStreamSynchronize(t->stream)); }
+            break;
+        }
     }
     if (levels) *levels = r;
-    hipLaunchKernelGGL(k_cinc_apply, dim3(grid_for(E.nd, 1024)), dim3(256), 0, t->stream, E);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(t->stream));
     return 0;
 }
 
@@ -2632,7 +2638,9 @@ int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *
         HIP_TRY(hipMemcpyAsync(t->s_flags, hf, (size_t)L * 8, hipMemcpyHostToDevice, t->stream));
     }
     HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
+#ifdef PYDEM_EINC_PROF
     HIP_TRY(hipMemsetAsync(t->counters + 40, 0, 8 * sizeof(int32_t), t->stream));
+#endif
     int levels = 0;
     if (t->einc_compact) {
         CIncArgs C;

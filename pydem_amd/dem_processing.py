@@ -50,6 +50,9 @@ class _Resident(object):
         if value is None:
             obj._host.pop(self.name, None)
         else:
+            if np.ma.isMaskedArray(value):
+                # masked cells are no-data: NaN, like the reference's np.ma.filled(elev.astype(float64), nan) (:213-214)
+                value = np.ma.filled(value.astype(np.float64), np.nan)
             obj._host[self.name] = np.asarray(value)
 
 
