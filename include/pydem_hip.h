@@ -117,6 +117,14 @@ int64_t pydem_tile_device_bytes(pydem_tile *t);
 int pydem_tile_synth_fractal(pydem_tile *t, uint32_t seed, int64_t row0, int64_t col0,
                              int n_octaves, int top_shift, double zmin, double zrange);
 
+/* Elevation conditioning on the resident elevation (csrc/cond_device.hip): DEMProcessor.calc_fill_flats
+ * (pydem/dem_processing.py:551-579: quantisation artefacts :396-426 when max_pit_area > 0, then _fill_flat :308-394 for
+ * every labelled flat), or only DEMProcessor.calc_fill_pit_artifacts with artefacts_only.  The elevation stays on the
+ * device (float64 after the flats step, the values of the input dtype after the artefact step alone).  *needs_host = 1
+ * and an untouched tile when the tile has no-data cells: the caller uses the host implementation
+ * (pydem_cond_pit_artifacts / pydem_cond_fill_flats below) for those. */
+int pydem_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double source_tol, int peaks, int pits, int artefacts_only,
+                     int *needs_host);
 int pydem_slopes_directions(pydem_tile *t);
 int pydem_find_flats(pydem_tile *t);
 int pydem_uca(pydem_tile *t, pydem_options *opt);

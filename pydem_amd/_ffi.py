@@ -67,6 +67,7 @@ SYMBOLS = {
     'pydem_tile_device_bytes': (C.c_int64, [_P]),
     'pydem_tile_synth_fractal': (C.c_int, [_P, C.c_uint32, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                            C.c_double, C.c_double]),
+    'pydem_fill_flats': (C.c_int, [_P, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, _P]),
     'pydem_slopes_directions': (C.c_int, [_P]),
     'pydem_find_flats': (C.c_int, [_P]),
     'pydem_uca': (C.c_int, [_P, C.POINTER(Options)]),
@@ -203,6 +204,13 @@ class Tile(object):
 
     def find_flats(self):
         check(self.lib.pydem_find_flats(self._h))
+
+    def fill_flats(self, max_pit_area, below_sea, source_tol, peaks, pits, artefacts_only=False):
+        """Conditioning on the resident elevation; returns False when the tile must go through the host path (NaN cells)."""
+        flag = C.c_int(0)
+        check(self.lib.pydem_fill_flats(self._h, float(max_pit_area or 0.0), int(bool(below_sea)), float(source_tol), int(bool(peaks)),
+                                        int(bool(pits)), int(bool(artefacts_only)), C.byref(flag)))
+        return flag.value == 0
 
     def uca(self, opt):
         check(self.lib.pydem_uca(self._h, C.byref(opt)))

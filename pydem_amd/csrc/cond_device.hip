@@ -1,0 +1,552 @@
+// cond_device.hip -- elevation conditioning on the device, part 1: quantisation artefacts and flats.
+//
+// Replaces, for a tile whose elevation is resident in HBM (reference creare-com/pydem v1.2.1):
+//   pydem/dem_processing.py:396-426   calc_fill_pit_artifacts
+//   pydem/dem_processing.py:551-579   calc_fill_flats, with _fill_flat :308-394 and the helpers
+//   pydem/utils.py:342-370 get_border_mask, :374-402 get_distance, :450-468 find_centroid
+// The reference labels the candidate cells with scipy.ndimage.label and then runs a Python loop over the
+// labelled regions, each inside its bounding box grown by one pixel: 155 k regions on a 2048^2 SRTM-like tile,
+// a handful of scipy.ndimage calls each.  No region reads what another region writes (`roi` is the unmodified
+// surface, `out` only receives the region's own cells, :308-394), so all regions are processed at once:
+//   * candidate masks by a 3x3 minimum (scipy.ndimage.minimum_filter with its 'reflect' border = minimum over the
+//     neighbours that exist);
+//   * regions by the union-find labelling of ccl.h (a component of cells that are <= all their neighbours has ONE
+//     elevation, so "the region's level" is the elevation of any of its cells);
+//   * per-region facts (size, bounding box, rim tests, lowest uphill rim value, coordinate sums) by atomics on a
+//     record per region;
+//   * the two (1, sqrt 2) chamfer distances of _fill_flat as Jacobi sweeps over ALL flat cells of all regions,
+//     every region frozen at the sweep at which utils.get_distance would have stopped for it -- as soon as all of
+//     its cells have SOME finite value, not at convergence (:392-401): the sweep number is part of the result.
+// Every floating-point expression keeps numpy's operation order (-ffp-contract=off); the host implementation
+// (conditioning.hip behind pydem_amd/conditioning.py, pinned bit for bit by tests/golden/g5_* and g7_*) is the
+// twin the tests compare with.  Tiles with no-data (NaN) cells are left to the host path: the order in which
+// scipy's filters meet a NaN is an implementation detail this file does not reproduce.
+#include "internal.h"
+#include <math.h>
+
+namespace {
+
+#include "ccl.h"
+
+constexpr double SQRT2 = 1.4142135623730951;      // np.sqrt(2.0)
+
+// one list slot per calling lane, one atomic per wavefront
+__device__ __forceinline__ int32_t agg_slot_c(int32_t *count)
+{
+    const unsigned long long bal = __ballot(true);
+    const int lane = (int)__lane_id();
+    const int leader = __ffsll((long long)bal) - 1;
+    int32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (int32_t)__popcll(bal));
+    base = __shfl(base, leader);
+    return base + __popcll(bal & ((1ull << lane) - 1ull));
+}
+
+struct CondArgs {
+    int n, m;
+    int64_t NN;
+    double *elev;            // the surface being conditioned (input of the step)
+    double *built;           // output surface of fill_flats
+    uint8_t *mask;           // candidate mask of the step
+    const int32_t *list;     // compacted mask cells
+    const int32_t *count;
+    int32_t *labels;         // root cell per mask cell
+    int32_t *rid;            // [NN] region index of a ROOT cell
+    int f32;                 // the elevations are float32 values: `rim - 1` rounds in float32 (:424)
+    int below_sea;
+};
+
+// one record per region (struct of arrays, sized by the number of mask cells)
+struct Regions {
+    int32_t *size, *n_edge, *i0, *i1, *j0, *j1, *flags, *centre, *done_hi, *done_lo, *rem_hi, *rem_lo;
+    unsigned long long *sum_i, *sum_j, *lowest_bits, *cdist_bits;
+    double *top;
+};
+constexpr int32_t RF_BAD = 1, RF_SOURCE = 2, RF_DRAIN = 4, RF_GENERAL = 8, RF_SRC_CENTRE = 16, RF_DRN_CENTRE = 32, RF_DRN_EDGE = 64,
+                  RF_INTERP = 128, RF_NEED_CENTRE = 256;
+
+__device__ __forceinline__ bool sea_ok(double v, int below_sea) { return below_sea ? (v != 0.0) : (v > 0.0); }
+
+// order-preserving map double -> uint64 (for atomicMin on values of either sign)
+__device__ __forceinline__ unsigned long long dkey(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dunkey(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+// candidate mask: minimum_filter(elev, 3x3) >= elev, and above (or not at) sea level (:410-412, :565-568)
+__global__ __launch_bounds__(256) void k_cond_mask(CondArgs A, int corners_off, int32_t *nan_count)
+{
+    const int n = A.n, m = A.m;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < A.NN; c += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(c / m), j = (int)(c - (int64_t)i * m);
+        const double z = A.elev[c];
+        if (isnan(z)) { atomicAdd(nan_count, 1); A.mask[c] = 0; continue; }
+        bool low = true;
+        for (int di = -1; di <= 1 && low; di++) {
+            const int ii = i + di;
+            if (ii < 0 || ii >= n) continue;
+            for (int dj = -1; dj <= 1; dj++) {
+                const int jj = j + dj;
+                if (jj < 0 || jj >= m) continue;
+                if (A.elev[(int64_t)ii * m + jj] < z) { low = false; break; }
+            }
+        }
+        bool v = low && sea_ok(z, A.below_sea);
+        if (corners_off && (i == 0 || i == n - 1) && (j == 0 || j == m - 1)) v = false;          // :569-572
+        A.mask[c] = v;
+    }
+}
+
+__global__ void k_region_index(CondArgs A, int32_t *nreg)
+{
+    const int32_t nf = *A.count;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
+        const int32_t c = A.list[q];
+        if (A.labels[c] == c) A.rid[c] = atomicAdd(nreg, 1);
+    }
+}
+
+__global__ void k_region_init(Regions R, int32_t nreg, int n, int m)
+{
+    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nreg; r += gridDim.x * blockDim.x) {
+        R.size[r] = 0; R.n_edge[r] = 0; R.i0[r] = n; R.i1[r] = -1; R.j0[r] = m; R.j1[r] = -1; R.flags[r] = 0; R.centre[r] = 0x7FFFFFFF;
+        R.done_hi[r] = 0x7FFFFFFF; R.done_lo[r] = 0x7FFFFFFF; R.rem_hi[r] = 0; R.rem_lo[r] = 0;
+        R.sum_i[r] = 0; R.sum_j[r] = 0; R.lowest_bits[r] = ~0ull; R.cdist_bits[r] = ~0ull; R.top[r] = 0.0;
+    }
+}
+
+// ---- quantisation artefacts (:396-426) ---------------------------------------------------------------------
+// a region is raised by one unit when it is small, lies strictly inside the array and its whole rim is exactly
+// one unit higher
+__global__ void k_art_scan(CondArgs A, Regions R, double max_area)
+{
+    const int32_t nf = *A.count;
+    const int n = A.n, m = A.m;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
+        const int32_t c = A.list[q];
+        const int32_t r = A.rid[A.labels[c]];
+        const int i = c / m, j = c - i * m;
+        atomicAdd(&R.size[r], 1);
+        bool bad = (i == 0 || j == 0 || i == n - 1 || j == m - 1);               // the one-pixel rim must lie inside (:414-415)
+        const double level = A.elev[c];
+        if (!bad) {
+            for (int d = 0; d < 9; d++) {
+                if (d == 4) continue;
+                const int32_t nb = c + (d / 3 - 1) * m + (d % 3 - 1);
+                if (A.mask[nb]) continue;                                         // same region
+                const double v = A.elev[nb];
+                const bool ok = A.f32 ? ((float)v - 1.0f == (float)level) : (v - 1 == level);    // :424
+                if (!ok) { bad = true; break; }
+            }
+        }
+        if (bad) atomicOr(&R.flags[r], RF_BAD);
+    }
+}
+
+__global__ void k_art_apply(CondArgs A, Regions R, double max_area)
+{
+    const int32_t nf = *A.count;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
+        const int32_t c = A.list[q];
+        const int32_t r = A.rid[A.labels[c]];
+        if ((R.flags[r] & RF_BAD) || (double)R.size[r] > max_area) continue;     // :419-420
+        const double v = A.elev[c];
+        A.elev[c] = A.f32 ? (double)((float)v + 1.0f) : v + 1;                   // :425 (in the array's dtype)
+    }
+}
+
+// ---- flats (:551-579, _fill_flat :308-394) -------------------------------------------------------------------
+// facts about every region: size, bounding box, cells on the tile edge, coordinate sums, and what its rim offers
+// (a cell of the rim is 8-adjacent to the region and not part of it: get_border_mask, utils.py:342-370)
+__global__ void k_flat_scan(CondArgs A, Regions R)
+{
+    const int32_t nf = *A.count;
+    const int n = A.n, m = A.m;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
+        const int32_t c = A.list[q];
+        const int32_t r = A.rid[A.labels[c]];
+        const int i = c / m, j = c - i * m;
+        atomicAdd(&R.size[r], 1);
+        atomicMin(&R.i0[r], i); atomicMax(&R.i1[r], i); atomicMin(&R.j0[r], j); atomicMax(&R.j1[r], j);
+        if (i == 0 || j == 0 || i == n - 1 || j == m - 1) atomicAdd(&R.n_edge[r], 1);
+        atomicAdd(&R.sum_i[r], (unsigned long long)i);
+        atomicAdd(&R.sum_j[r], (unsigned long long)j);
+        const double level = A.elev[c];
+        int32_t fl = 0;
+        for (int d = 0; d < 9; d++) {
+            if (d == 4) continue;
+            const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
+            if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+            const int32_t nb = ii * m + jj;
+            if (A.mask[nb]) continue;
+            const double v = A.elev[nb];
+            if (v == level) fl |= RF_DRAIN;                                      // :337
+            else if (v > level) { fl |= RF_SOURCE; atomicMin(&R.lowest_bits[r], dkey(v)); }   // :338, :344
+        }
+        if (fl) atomicOr(&R.flags[r], fl);
+    }
+}
+
+// window of a region: its bounding box grown by one pixel inside the array (:575-577)
+__device__ __forceinline__ void region_window(const Regions &R, int32_t r, int n, int m, int &wi0, int &wi1, int &wj0, int &wj1)
+{
+    wi0 = R.i0[r] > 0 ? R.i0[r] - 1 : 0; wi1 = R.i1[r] + 2 < n ? R.i1[r] + 2 : n;
+    wj0 = R.j0[r] > 0 ? R.j0[r] - 1 : 0; wj1 = R.j1[r] + 2 < m ? R.j1[r] + 2 : m;
+}
+
+// the decisions of _fill_flat that need the whole region (:340-371); single pixels are done on the spot (:312-325)
+__global__ void k_flat_plan(CondArgs A, Regions R, int32_t nreg, const int32_t *root_of, double source_tol, int peaks, int pits)
+{
+    const int n = A.n, m = A.m;
+    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nreg; r += gridDim.x * blockDim.x) {
+        const int32_t root = root_of[r];
+        const double level = A.elev[root];
+        int wi0, wi1, wj0, wj1;
+        region_window(R, r, n, m, wi0, wi1, wj0, wj1);
+        const int64_t wsize = (int64_t)(wi1 - wi0) * (wj1 - wj0);
+        int32_t fl = R.flags[r];
+        if (wsize <= 9 && R.size[r] == 1) {
+            // "a single pixel": raise it towards its lowest higher neighbour, unless every neighbour is higher (:312-325)
+            int n_high = 0; double low_high = INFINITY;
+            for (int ii = wi0; ii < wi1; ii++)
+                for (int jj = wj0; jj < wj1; jj++) {
+                    const double v = A.elev[(int64_t)ii * m + jj];
+                    if (v > level) { n_high++; low_high = v < low_high ? v : low_high; }
+                }
+            if (n_high == wsize - 1) { }
+            else if (n_high > 0) { const double d = low_high - level; A.built[root] = A.built[root] + ((d < 1.0 ? d : 1.0) - 0.01); }
+            else if (peaks) A.built[root] = A.built[root] + 0.5;
+            continue;
+        }
+        bool go = true;
+        if (fl & RF_SOURCE) {
+            const double lowest = dunkey(R.lowest_bits[r]);
+            R.top[r] = (level + 1.0 < lowest) ? level + 1.0 : lowest;            // min(level + 1.0, lowest) :346
+        } else if (peaks) {
+            R.top[r] = level + 0.5;                                               // :349
+            fl |= RF_SRC_CENTRE | RF_NEED_CENTRE;
+        } else go = false;
+        if (go) {
+            if (fl & RF_DRAIN) { }
+            else if (R.n_edge[r] > 0) {                                           // :362-366
+                fl |= RF_DRN_EDGE;
+                if (R.n_edge[r] == R.size[r]) go = false;
+            } else if (pits) fl |= RF_DRN_CENTRE | RF_NEED_CENTRE;                // :367-371
+            else go = false;
+        }
+        if (go) fl |= RF_GENERAL | RF_INTERP;
+        R.flags[r] = fl;
+    }
+}
+
+// centre cell of the regions that need one (find_centroid, utils.py:450-468): the region cell closest to the
+// centre of mass, first in raster order among equals.  Coordinates are window coordinates like the reference's.
+__device__ __forceinline__ double centre_dist(const Regions &R, int32_t r, int i, int j, int n, int m)
+{
+    int wi0, wi1, wj0, wj1;
+    region_window(R, r, n, m, wi0, wi1, wj0, wj1);
+    const double cnt = (double)R.size[r];
+    const double cy = (double)(long long)(R.sum_i[r] - (unsigned long long)R.size[r] * (unsigned long long)wi0) / cnt;
+    const double cx = (double)(long long)(R.sum_j[r] - (unsigned long long)R.size[r] * (unsigned long long)wj0) / cnt;
+    const double dy = (double)(i - wi0) - cy, dx = (double)(j - wj0) - cx;
+    return sqrt(dy * dy + dx * dx);
+}
+
+__global__ void k_centre_pass(CondArgs A, Regions R, int pass)
+{
+    const int32_t nf = *A.count;
+    const int n = A.n, m = A.m;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
+        const int32_t c = A.list[q];
+        const int32_t r = A.rid[A.labels[c]];
+        if (!(R.flags[r] & RF_NEED_CENTRE)) continue;
+        const int i = c / m, j = c - i * m;
+        const unsigned long long k = dkey(centre_dist(R, r, i, j, n, m));
+        if (pass == 0) atomicMin(&R.cdist_bits[r], k);
+        else if (k == R.cdist_bits[r]) atomicMin(&R.centre[r], c);
+    }
+}
+
+// seeds inside the regions and the number of cells that still wait for a distance
+__global__ void k_flat_seed(CondArgs A, Regions R, double *dh, double *dl)
+{
+    const int32_t nf = *A.count;
+    const int n = A.n, m = A.m;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
+        const int32_t c = A.list[q];
+        const int32_t r = A.rid[A.labels[c]];
+        const int32_t fl = R.flags[r];
+        const int i = c / m, j = c - i * m;
+        const bool on_edge = (i == 0 || j == 0 || i == n - 1 || j == m - 1);
+        const bool is_centre = R.centre[r] == c;
+        if ((fl & RF_SRC_CENTRE) && is_centre) A.built[c] = R.top[r];            // out[ci] = top, whatever follows (:351)
+        if (!(fl & RF_GENERAL)) continue;
+        const bool seed_hi = (fl & RF_SRC_CENTRE) && is_centre;
+        const bool seed_lo = ((fl & RF_DRN_EDGE) && on_edge) || ((fl & RF_DRN_CENTRE) && is_centre);
+        dh[c] = seed_hi ? 0.0 : INFINITY;
+        dl[c] = seed_lo ? 0.0 : INFINITY;
+        if (!seed_hi) atomicAdd(&R.rem_hi[r], 1);
+        if (!seed_lo) atomicAdd(&R.rem_lo[r], 1);
+    }
+}
+
+__global__ void k_flat_seed_done(Regions R, int32_t nreg)
+{
+    for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nreg; r += gridDim.x * blockDim.x) {
+        if (!(R.flags[r] & RF_GENERAL)) continue;
+        if (R.rem_hi[r] == 0) R.done_hi[r] = 0;
+        if (R.rem_lo[r] == 0) R.done_lo[r] = 0;
+    }
+}
+
+// One Jacobi sweep of utils.get_distance (:392-401) for both distances of every region that has not stopped yet:
+//   d = min(d, min(d over the cell and its 4 cardinal neighbours) + 1, min(d over the 3x3) + sqrt 2)
+// with d = 0 on the seeds of the rim and "no value yet" everywhere else outside the region.  A region stops
+// after the sweep in which its last cell got a value (done_* = number of that sweep).
+__global__ __launch_bounds__(256) void k_flat_sweep(CondArgs A, Regions R, const int32_t *__restrict__ alist, int32_t na,
+                                                    const double *__restrict__ dh0, double *__restrict__ dh1,
+                                                    const double *__restrict__ dl0, double *__restrict__ dl1, int sweep, double source_tol)
+{
+    const int n = A.n, m = A.m;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < na; q += gridDim.x * blockDim.x) {
+        const int32_t c = alist[q];
+        const int32_t r = A.rid[A.labels[c]];
+        const int32_t fl = R.flags[r];
+        const bool act_hi = R.done_hi[r] >= sweep, act_lo = R.done_lo[r] >= sweep;
+        const double oh = dh0[c], ol = dl0[c];
+        double nh = oh, nl = ol;
+        if (act_hi || act_lo) {
+            const int i = c / m, j = c - i * m;
+            const double level = A.elev[c];
+            const double src_max = (fl & RF_SOURCE) ? dunkey(R.lowest_bits[r]) + source_tol : 0.0;   // lowest + tol (:347)
+            double card_h = oh, all_h = oh, card_l = ol, all_l = ol;
+            for (int d = 0; d < 9; d++) {
+                if (d == 4) continue;
+                const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
+                if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+                const int32_t nb = ii * m + jj;
+                double vh, vl;
+                if (A.mask[nb]) { vh = dh0[nb]; vl = dl0[nb]; }
+                else {
+                    const double z = A.elev[nb];
+                    vh = ((fl & RF_SOURCE) && z > level && z <= src_max) ? 0.0 : INFINITY;
+                    vl = ((fl & RF_DRAIN) && z == level) ? 0.0 : INFINITY;
+                }
+                const bool cardinal = (d == 1 || d == 3 || d == 5 || d == 7);
+                if (cardinal) { card_h = vh < card_h ? vh : card_h; card_l = vl < card_l ? vl : card_l; }
+                all_h = vh < all_h ? vh : all_h; all_l = vl < all_l ? vl : all_l;
+            }
+            if (act_hi) {
+                const double s = card_h + 1, g = all_h + SQRT2;
+                const double best = s < g ? s : g;
+                nh = best < oh ? best : oh;
+                if (isinf(oh) && !isinf(nh) && atomicSub(&R.rem_hi[r], 1) == 1) R.done_hi[r] = sweep;
+            }
+            if (act_lo) {
+                const double s = card_l + 1, g = all_l + SQRT2;
+                const double best = s < g ? s : g;
+                nl = best < ol ? best : ol;
+                if (isinf(ol) && !isinf(nl) && atomicSub(&R.rem_lo[r], 1) == 1) R.done_lo[r] = sweep;
+            }
+        }
+        dh1[c] = nh; dl1[c] = nl;
+    }
+}
+
+// cells of regions that are still sweeping -> next active list
+__global__ void k_flat_active(CondArgs A, Regions R, const int32_t *__restrict__ alist, int32_t na, int sweep, int32_t *out, int32_t *nout)
+{
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < na; q += gridDim.x * blockDim.x) {
+        const int32_t c = alist[q];
+        const int32_t r = A.rid[A.labels[c]];
+        // (a region that stopped in the last sweep stays for one more batch: those sweeps copy its final values
+        // into the other buffer of the ping-pong pair, so that both agree when the region leaves the list)
+        if ((R.flags[r] & RF_GENERAL) && (R.done_hi[r] >= sweep - 1 || R.done_lo[r] >= sweep - 1)) out[agg_slot_c(nout)] = c;
+    }
+}
+
+// the new surface between the uphill rim and the outlet (:376-380)
+__global__ void k_flat_interp(CondArgs A, Regions R, const double *__restrict__ dh, const double *__restrict__ dl)
+{
+    const int32_t nf = *A.count;
+    const int n = A.n, m = A.m;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
+        const int32_t c = A.list[q];
+        const int32_t r = A.rid[A.labels[c]];
+        const int32_t fl = R.flags[r];
+        if (!(fl & RF_INTERP)) continue;
+        const int i = c / m, j = c - i * m;
+        // cells whose value is set, not interpolated: the LAST `pinned` assignment of _fill_flat wins (:353, :364, :370)
+        bool pinned = false;
+        if (fl & RF_DRN_EDGE) pinned = (i == 0 || j == 0 || i == n - 1 || j == m - 1);
+        else if (fl & RF_DRN_CENTRE) pinned = R.centre[r] == c;
+        else if (fl & RF_SRC_CENTRE) pinned = R.centre[r] == c;
+        if (pinned) continue;
+        const double level = A.elev[c], top = R.top[r];
+        const double h = dh[c], l = dl[c];
+        A.built[c] = (top * (l * l) + level * (h * h)) / ((l * l) + (h * h));
+    }
+}
+
+__global__ void k_roots(CondArgs A, int32_t *root_of)
+{
+    const int32_t nf = *A.count;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
+        const int32_t c = A.list[q];
+        if (A.labels[c] == c) root_of[A.rid[c]] = c;
+    }
+}
+
+int grid_of(int64_t work, int cap) { const int64_t g = cdiv(work, 256); return (int)(g < cap ? (g > 0 ? g : 1) : cap); }
+
+struct Scratch {
+    void *p = nullptr;
+    ~Scratch() { if (p) (void)hipFree(p); }
+};
+
+// carve the region records out of one allocation
+int alloc_regions(Scratch &S, Regions &R, int32_t **root_of, int32_t **alist0, int32_t **alist1, int64_t nf)
+{
+    const size_t n4 = (size_t)nf * 4, n8 = (size_t)nf * 8;
+    const size_t total = 15 * n4 + 5 * n8 + 256;
+    HIP_TRY(hipMalloc(&S.p, total));
+    char *p = (char *)S.p;
+    auto take4 = [&]() { int32_t *q = (int32_t *)p; p += n4; return q; };
+    auto take8 = [&]() { unsigned long long *q = (unsigned long long *)p; p += n8; return q; };
+    R.sum_i = take8(); R.sum_j = take8(); R.lowest_bits = take8(); R.cdist_bits = take8(); R.top = (double *)take8();
+    R.size = take4(); R.n_edge = take4(); R.i0 = take4(); R.i1 = take4(); R.j0 = take4(); R.j1 = take4(); R.flags = take4();
+    R.centre = take4(); R.done_hi = take4(); R.done_lo = take4(); R.rem_hi = take4(); R.rem_lo = take4();
+    *root_of = take4(); *alist0 = take4(); *alist1 = take4();
+    return 0;
+}
+
+// mask -> list -> labels -> region index; returns the number of mask cells and regions
+int label_regions(pydem_tile *t, CondArgs &A, int32_t *nf_out, int32_t *nreg_out)
+{
+    int32_t *cnt = t->counters;
+    HIP_TRY(hipMemsetAsync(cnt, 0, 16 * sizeof(int32_t), t->stream));
+    const int big = grid_of(t->NN, 4096);
+    hipLaunchKernelGGL(k_compact_flats, dim3(big), dim3(256), 0, t->stream, A.mask, t->NN, t->flatlist, cnt);
+    HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    const int32_t nf = t->h_counters[0];
+    *nf_out = nf; *nreg_out = 0;
+    if (nf == 0) return 0;
+    const int g1 = grid_of(nf, 2048);
+    hipLaunchKernelGGL(k_label_init, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, t->labels);
+    hipLaunchKernelGGL(k_label_union, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, A.mask, t->labels, A.n, A.m);
+    hipLaunchKernelGGL(k_label_flatten, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, t->labels);
+    hipLaunchKernelGGL(k_region_index, dim3(g1), dim3(256), 0, t->stream, A, cnt + 1);
+    HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    *nreg_out = t->h_counters[1];
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// calc_fill_flats (:551-579) on the tile's resident elevation: artefact pits first when max_pit_area > 0 (:560-561),
+// then every flat is re-surfaced.  Returns 1 (and leaves the tile untouched) when the tile has NaN cells.
+int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double source_tol, int peaks, int pits, int artefacts_only)
+{
+    const int n = (int)t->n, m = (int)t->m;
+    PYDEM_TRY(tile_alloc(t, &t->flat0, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->labels, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->flatlist, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->queue[0], (size_t)t->NN));
+    CondArgs A;
+    A.n = n; A.m = m; A.NN = t->NN; A.elev = t->elev; A.built = nullptr; A.mask = t->flat0; A.list = t->flatlist; A.count = t->counters;
+    A.labels = t->labels; A.rid = t->queue[0]; A.f32 = t->elev_f32 ? 1 : 0; A.below_sea = below_sea;
+    const int big = grid_of(t->NN, 8192);
+    int32_t nf = 0, nreg = 0;
+    // ---- quantisation artefacts
+    if (max_pit_area > 0) {
+        HIP_TRY(hipMemsetAsync(t->counters + 8, 0, sizeof(int32_t), t->stream));
+        hipLaunchKernelGGL(k_cond_mask, dim3(big), dim3(256), 0, t->stream, A, 0, t->counters + 8);
+        HIP_TRY(hipMemcpyAsync(t->h_counters + 8, t->counters + 8, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (t->h_counters[8] > 0) return 1;
+        PYDEM_TRY(label_regions(t, A, &nf, &nreg));
+        if (nf > 0) {
+            Scratch S; Regions R; int32_t *root_of, *al0, *al1;
+            PYDEM_TRY(alloc_regions(S, R, &root_of, &al0, &al1, nf));
+            const int g1 = grid_of(nf, 2048), gr = grid_of(nreg, 2048);
+            hipLaunchKernelGGL(k_region_init, dim3(gr), dim3(256), 0, t->stream, R, nreg, n, m);
+            hipLaunchKernelGGL(k_art_scan, dim3(g1), dim3(256), 0, t->stream, A, R, max_pit_area);
+            hipLaunchKernelGGL(k_art_apply, dim3(g1), dim3(256), 0, t->stream, A, R, max_pit_area);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(t->stream));
+        }
+    }
+    if (artefacts_only) return 0;
+    // ---- flats: the surface becomes float64 (:562), `built` starts as a copy of it
+    PYDEM_TRY(tile_alloc(t, &t->mag, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->dir, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->uca, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->twi, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->prop, (size_t)t->NN));
+    A.f32 = 0;
+    A.built = t->prop;
+    HIP_TRY(hipMemsetAsync(t->counters + 8, 0, sizeof(int32_t), t->stream));
+    hipLaunchKernelGGL(k_cond_mask, dim3(big), dim3(256), 0, t->stream, A, 1, t->counters + 8);
+    HIP_TRY(hipMemcpyAsync(t->h_counters + 8, t->counters + 8, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(A.built, t->elev, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    if (t->h_counters[8] > 0) return 1;
+    PYDEM_TRY(label_regions(t, A, &nf, &nreg));
+    if (nf > 0) {
+        Scratch S; Regions R; int32_t *root_of, *al0, *al1;
+        PYDEM_TRY(alloc_regions(S, R, &root_of, &al0, &al1, nf));
+        const int g1 = grid_of(nf, 2048), gr = grid_of(nreg, 2048);
+        double *dh[2] = {t->mag, t->dir}, *dl[2] = {t->uca, t->twi};
+        hipLaunchKernelGGL(k_region_init, dim3(gr), dim3(256), 0, t->stream, R, nreg, n, m);
+        hipLaunchKernelGGL(k_roots, dim3(g1), dim3(256), 0, t->stream, A, root_of);
+        hipLaunchKernelGGL(k_flat_scan, dim3(g1), dim3(256), 0, t->stream, A, R);
+        hipLaunchKernelGGL(k_flat_plan, dim3(gr), dim3(256), 0, t->stream, A, R, nreg, root_of, source_tol, peaks, pits);
+        hipLaunchKernelGGL(k_centre_pass, dim3(g1), dim3(256), 0, t->stream, A, R, 0);
+        hipLaunchKernelGGL(k_centre_pass, dim3(g1), dim3(256), 0, t->stream, A, R, 1);
+        hipLaunchKernelGGL(k_flat_seed, dim3(g1), dim3(256), 0, t->stream, A, R, dh[0], dl[0]);
+        hipLaunchKernelGGL(k_flat_seed_done, dim3(gr), dim3(256), 0, t->stream, R, nreg);
+        // active cells: every cell of a region in the general case; the list shrinks as regions stop (checked after
+        // 1, 2, 4, 8, ... sweeps: most regions are a few cells wide, a lake keeps sweeping alone)
+        int32_t *cnt = t->counters;
+        HIP_TRY(hipMemsetAsync(cnt + 2, 0, sizeof(int32_t), t->stream));
+        hipLaunchKernelGGL(k_flat_active, dim3(g1), dim3(256), 0, t->stream, A, R, t->flatlist, nf, 1, al0, cnt + 2);
+        HIP_TRY(hipMemcpyAsync(t->h_counters + 2, cnt + 2, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        int32_t na = t->h_counters[2];
+        int32_t *al[2] = {al0, al1};
+        int cur = 0, sweep = 1, batch = 1, pp = 0;
+        const int64_t sweep_cap = (int64_t)n * m + 2;
+        while (na > 0) {
+            const int ga = grid_of(na, 4096);
+            for (int b = 0; b < batch; b++, sweep++, pp ^= 1)
+                hipLaunchKernelGGL(k_flat_sweep, dim3(ga), dim3(256), 0, t->stream, A, R, al[cur], na, dh[pp], dh[pp ^ 1], dl[pp], dl[pp ^ 1],
+                                   sweep, source_tol);
+            HIP_TRY(hipMemsetAsync(cnt + 2, 0, sizeof(int32_t), t->stream));
+            hipLaunchKernelGGL(k_flat_active, dim3(ga), dim3(256), 0, t->stream, A, R, al[cur], na, sweep, al[cur ^ 1], cnt + 2);
+            HIP_TRY(hipMemcpyAsync(t->h_counters + 2, cnt + 2, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            na = t->h_counters[2];
+            cur ^= 1;
+            if (batch < 64) batch *= 2;
+            if (sweep > sweep_cap) { pydem_set_error("fill_flats: distance sweeps did not terminate"); return -5; }
+        }
+        // (every region took part in at least one sweep after the one that stopped it: both buffers hold its final values)
+        hipLaunchKernelGGL(k_flat_interp, dim3(g1), dim3(256), 0, t->stream, A, R, dh[pp], dl[pp]);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(t->stream));
+    }
+    // built -> elev
+    HIP_TRY(hipMemcpyAsync(t->elev, A.built, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    t->elev_f32 = false;                 // float64 from here on, like the reference's data.astype('float64') (:562)
+    return 0;
+}

@@ -14,116 +14,7 @@
 
 namespace {
 
-#define RLX_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-
-// stream compaction of flat0 != 0 into a list of cell ids.  Each thread reads 16 mask bytes with
-// one 16 B load; ranks come from a wavefront prefix (shuffles) plus a per-block LDS prefix over
-// the 4 waves, and the block reserves its output range with ONE global atomic per 4096 cells
-// (a first version issued one atomic per wavefront on a single address: 22 ms at 16384^2).
-__global__ __launch_bounds__(256) void k_compact_flats(const uint8_t *__restrict__ flat0, int64_t NN,
-                                                       int32_t *__restrict__ list, int32_t *__restrict__ count)
-{
-    // 64 cells per thread (four 16 B loads), 16 Ki cells per block trip: the trip is bound by its barrier + atomic
-    // round trip, not by the 1 B/cell it reads
-    __shared__ int32_t wave_tot[4];
-    __shared__ int32_t blk_base;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t base = (int64_t)blockIdx.x * 16384; base < NN; base += (int64_t)gridDim.x * 16384) {
-        const int64_t c0 = base + (int64_t)threadIdx.x * 64;
-        unsigned long long bits = 0;   // bit k set <=> cell c0+k is set
-        if (c0 + 64 <= NN) {
-            uint4 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const uint4 *>(flat0 + c0 + 16 * q);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-                for (int k = 0; k < 16; k++)
-                    bits |= (unsigned long long)(((w[k >> 2] >> (8 * (k & 3))) & 0xffu) ? 1u : 0u) << (16 * q + k);
-            }
-        } else {
-            for (int k = 0; k < 64; k++)
-                if (c0 + k < NN && flat0[c0 + k]) bits |= 1ull << k;
-        }
-        const int32_t mine = __popcll(bits);
-        int32_t incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int32_t o = __shfl_up(incl, off);
-            if (lane >= off) incl += o;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-            blk_base = tot ? atomicAdd(count, tot) : 0;
-        }
-        __syncthreads();
-        int32_t off = blk_base + incl - mine;
-        for (int k = 0; k < wave; k++) off += wave_tot[k];
-        while (bits) {
-            const int k = __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-            list[off++] = (int32_t)(c0 + k);
-        }
-        __syncthreads();
-    }
-}
-
-__global__ void k_label_init(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *labels)
-{
-    const int32_t nf = *count;
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) labels[list[q]] = list[q];
-}
-
-__device__ __forceinline__ int32_t uf_find(int32_t *L, int32_t x)
-{
-    int32_t p = RLX_LOAD(&L[x]);
-    while (p != x) { x = p; p = RLX_LOAD(&L[x]); }
-    return x;
-}
-
-// lock-free union with min-index roots (labels only ever decrease)
-__device__ __forceinline__ void uf_union(int32_t *L, int32_t a, int32_t b)
-{
-    for (;;) {
-        a = uf_find(L, a);
-        b = uf_find(L, b);
-        if (a == b) return;
-        if (a > b) { const int32_t t = a; a = b; b = t; }
-        const int32_t old = atomicMin(&L[b], a);     // link the larger root under the smaller
-        if (old == b) return;
-        b = old;                                      // someone else moved b meanwhile: retry
-    }
-}
-
-__global__ void k_label_union(const int32_t *__restrict__ list, const int32_t *__restrict__ count,
-                              const uint8_t *__restrict__ flat0, int32_t *labels, int n, int m)
-{
-    const int32_t nf = *count;
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
-        const int32_t c = list[q];
-        const int i = c / m, j = c - i * m;
-        // forward half of the 8-neighbourhood: E, SW, S, SE (each pair is visited once)
-        if (j + 1 < m && flat0[c + 1]) uf_union(labels, c, c + 1);
-        if (i + 1 < n) {
-            if (j > 0 && flat0[c + m - 1]) uf_union(labels, c, c + m - 1);
-            if (flat0[c + m]) uf_union(labels, c, c + m);
-            if (j + 1 < m && flat0[c + m + 1]) uf_union(labels, c, c + m + 1);
-        }
-    }
-}
-
-__global__ void k_label_flatten(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *labels)
-{
-    const int32_t nf = *count;
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
-        const int32_t c = list[q];
-        const int32_t r = uf_find(labels, c);
-        if (r != c) __hip_atomic_store(&labels[c], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
+#include "ccl.h"
 
 // For every neighbour J of every flat cell: flats[J] = (elev[J] == elev[root of the max-root flat
 // region adjacent to J]).  Several threads may compute the same J; they all write the same value.

@@ -114,6 +114,7 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
 int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *const data[4], const uint8_t *const done[4],
                          const uint8_t *const todo[4]);
 int stage_edge_flush(pydem_tile *t);
+int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double source_tol, int peaks, int pits, int artefacts_only);
 int stage_synth(pydem_tile *t, uint32_t seed, int64_t row0, int64_t col0, int n_oct, int top_shift,
                 double zmin, double zrange);
 int bench_stencil(pydem_tile *t, int iters, double *avg_ms);

@@ -412,6 +412,21 @@ int pydem_slopes_directions(pydem_tile *t)
     return 0;
 }
 
+int pydem_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double source_tol, int peaks, int pits, int artefacts_only,
+                     int *needs_host)
+{
+    t->edge_clean = false;
+    t->einc_ready = false;
+    HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_fill_flats"));
+    t->graph_valid = false;
+    const int r = stage_fill_flats(t, max_pit_area, below_sea, source_tol, peaks, pits, artefacts_only);
+    if (r < 0) return r;
+    if (needs_host) *needs_host = r;
+    for (int f = PYDEM_MAG; f < PYDEM_FIELD_COUNT; f++) t->have[f] = false;     // the work planes of the conditioning
+    return 0;
+}
+
 int pydem_find_flats(pydem_tile *t)
 {
     t->edge_clean = false;      // these stages reuse the edge-round work lists

@@ -81,6 +81,7 @@ class DEMProcessor(object):
     apply_twi_limits_on_uca = False
 
     plotflag = False
+    _elev_dtype_after = None
     uca_saturation_limit = 32.0
     twi_min_slope = 1e-3
     twi_min_area = np.inf
@@ -293,14 +294,41 @@ class DEMProcessor(object):
         self._tile.find_flats()
         self._produced('flats')
 
-    # ---- elevation conditioning: host side for now (pydem_amd/conditioning.py), see DESIGN.md
+    # ---- elevation conditioning: artefacts and flats on the device (csrc/cond_device.hip); tiles with no-data cells and
+    # the pit drain paths go through the host implementation (pydem_amd/conditioning.py)
+    def _condition_on_device(self, artefacts_only):
+        """True when the resident elevation was conditioned by the library (False: the caller falls back to the host)."""
+        elev = self._host.get('elev')
+        if elev is not None and (np.ma.isMaskedArray(elev) or np.asarray(elev).dtype.kind not in 'iuf' or np.asarray(elev).ndim != 2):
+            return False
+        if min(self.shape) < 3:
+            return False
+        self._ensure_tile()
+        self._push('elev')
+        ok = self._tile.fill_flats(self.maximum_pit_area if (self.maximum_pit_area or artefacts_only) else 0.0, self.fill_flats_below_sea,
+                                   self.fill_flats_source_tol, self.fill_flats_peaks, self.fill_flats_pits, artefacts_only)
+        if not ok:
+            return False
+        dtype = None if elev is None else np.asarray(elev).dtype
+        self._produced('elev')
+        for nm in ('mag', 'direction', 'flats', 'uca', 'section', 'proportion', 'edge_todo', 'edge_done'):
+            self._on_device.discard(nm)             # the conditioning used those planes as scratch
+        self._elev_dtype_after = dtype if artefacts_only else None
+        return True
+
     def calc_fill_pit_artifacts(self):
         """Fill quantisation pits (reference :396-426)."""
+        if self._condition_on_device(artefacts_only=True):
+            if self._elev_dtype_after is not None and self._elev_dtype_after != np.float64:
+                self.elev = self.elev.astype(self._elev_dtype_after)          # the step keeps the array's dtype
+            return
         from . import conditioning
         self.elev = conditioning.fill_pit_artifacts(self.elev, self.maximum_pit_area, self.fill_flats_below_sea)
 
     def calc_fill_flats(self):
         """Fill / interpolate flats before the slope stencil (reference :551-579)."""
+        if self._condition_on_device(artefacts_only=False):
+            return
         from . import conditioning
         self.elev = conditioning.fill_flats(self.elev, self.maximum_pit_area, self.fill_flats_below_sea,
                                             self.fill_flats_source_tol, self.fill_flats_peaks, self.fill_flats_pits)
