@@ -125,6 +125,16 @@ int pydem_tile_synth_fractal(pydem_tile *t, uint32_t seed, int64_t row0, int64_t
  * (pydem_cond_pit_artifacts / pydem_cond_fill_flats below) for those. */
 int pydem_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double source_tol, int peaks, int pits, int artefacts_only,
                      int *needs_host);
+/* DEMProcessor.calc_pit_drain_paths (pydem/dem_processing.py:428-548) on the resident float64 elevation
+ * (csrc/cond_paths.hip).  Three calls because the processing order is numpy's: pydem_pit_candidates finds the strict local
+ * minima (:444-449; *npits = -1 when the tile has no-data cells), pydem_pit_candidates_read returns their cells
+ * (ascending) and elevations, the caller sorts them with np.argsort like the reference (:450-452 -- the tie order of
+ * that call is part of the result) and pydem_pit_paths carves the paths in that order.  *needs_host = 1 (surface
+ * restored) when the order-preserving parallel schedule had to give up; the host loop pydem_cond_pit_paths takes over. */
+int pydem_pit_candidates(pydem_tile *t, int below_sea, int64_t *npits);
+int pydem_pit_candidates_read(pydem_tile *t, int64_t npits, int32_t *cells, double *elev);
+int pydem_pit_paths(pydem_tile *t, const int32_t *order, int64_t npits, int max_iter, int max_dist, double max_dist_XY,
+                    int64_t *n_failed, int64_t *iter_used, int64_t *rounds, int *needs_host);
 int pydem_slopes_directions(pydem_tile *t);
 int pydem_find_flats(pydem_tile *t);
 int pydem_uca(pydem_tile *t, pydem_options *opt);

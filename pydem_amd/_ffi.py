@@ -68,6 +68,9 @@ SYMBOLS = {
     'pydem_tile_synth_fractal': (C.c_int, [_P, C.c_uint32, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                            C.c_double, C.c_double]),
     'pydem_fill_flats': (C.c_int, [_P, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, _P]),
+    'pydem_pit_candidates': (C.c_int, [_P, C.c_int, C.POINTER(C.c_int64)]),
+    'pydem_pit_candidates_read': (C.c_int, [_P, C.c_int64, _P, _P]),
+    'pydem_pit_paths': (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P]),
     'pydem_slopes_directions': (C.c_int, [_P]),
     'pydem_find_flats': (C.c_int, [_P]),
     'pydem_uca': (C.c_int, [_P, C.POINTER(Options)]),
@@ -211,6 +214,25 @@ class Tile(object):
         check(self.lib.pydem_fill_flats(self._h, float(max_pit_area or 0.0), int(bool(below_sea)), float(source_tol), int(bool(peaks)),
                                         int(bool(pits)), int(bool(artefacts_only)), C.byref(flag)))
         return flag.value == 0
+
+    def pit_drain_paths(self, below_sea, max_iter, max_dist, max_dist_XY):
+        """calc_pit_drain_paths on the resident elevation.  Returns (n_failed, iterations used, rounds), or None when the tile
+        must go through the host loop (no-data cells, float32 surface, or the parallel schedule gave up: surface restored)."""
+        n = C.c_int64(0)
+        check(self.lib.pydem_pit_candidates(self._h, int(bool(below_sea)), C.byref(n)))
+        if n.value < 0:
+            return None
+        cells = np.empty(max(n.value, 1), np.int32); elev = np.empty(max(n.value, 1), np.float64)
+        check(self.lib.pydem_pit_candidates_read(self._h, n.value, cells.ctypes.data_as(_P), elev.ctypes.data_as(_P)))
+        cells, elev = cells[:n.value], elev[:n.value]
+        order = np.ascontiguousarray(cells[np.argsort(elev)], np.int32)       # the reference's call (:450): same tie order
+        failed, used, rounds, flag = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
+        check(self.lib.pydem_pit_paths(self._h, order.ctypes.data_as(_P), n.value, int(max_iter), int(max_dist or 0),
+                                       float(max_dist_XY) if max_dist_XY else 0.0, C.byref(failed), C.byref(used), C.byref(rounds),
+                                       C.byref(flag)))
+        if flag.value:
+            return None
+        return int(failed.value), int(used.value), int(rounds.value)
 
     def uca(self, opt):
         check(self.lib.pydem_uca(self._h, C.byref(opt)))

@@ -1,0 +1,628 @@
+// cond_paths.hip -- elevation conditioning on the device, part 2: pit drain paths.
+//
+// Replaces DEMProcessor.calc_pit_drain_paths (reference pydem/dem_processing.py:428-548; helpers
+// utils.get_border_index pydem/utils.py:313-340, _get_dX_mean :1993-1997) for a float64 surface resident in HBM.
+// The reference visits the strict local minima in ascending elevation (np.argsort, :450-452), grows a region from
+// each through its lowest rim cells until a rim cell lies below the pit, prunes the visiting order to an
+// 8-connected chain and rewrites the elevations along it IN PLACE (:535-539): pit k sees the paths of pits 0..k-1.
+//
+// That order is kept exactly, but not by running the pits one after the other.  A round takes the first pending
+// pits of the order (one wavefront each) and lets all of them SIMULATE on the current surface; every simulation
+// reserves the cells it read (rown = smallest order among the readers) and the cells it would write (wown).  Pit k
+// then commits iff no earlier pending pit writes a cell k read and no earlier pending pit read a cell k writes -- its
+// simulation saw exactly the surface the sequential loop would have shown it.  Everybody else simulates again next
+// round.  The earliest pending pit always commits, so the loop terminates; on fractal terrain most of a window
+// commits in its first round (pits interact only through shared channels).
+// One thing the reservations cannot see: a pit that has to wait may, after an earlier path lowered its rim, grow in a
+// new direction and meet a cell that a LATER pit has already rewritten.  Committed cells carry the order of their
+// writer; a simulation that reads a cell written by a later pit raises a flag and the caller falls back to the host
+// loop (conditioning.hip: pydem_cond_pit_paths) on the untouched surface.  The soak tools count how often
+// that happens.
+//
+// A simulation is a wavefront: membership of region + rim in a window bitmap in LDS (64 x 64 cells; pits that leave
+// it are re-run in a 640 x 640 window -- 300 iterations cannot leave that one), the rim as a list, the minimum by a
+// wave reduction, the cells at the minimum in ascending cell order by setting their bits in a second bitmap and
+// scanning it (the reference sorts them, :470), the trail in visiting order.  The arithmetic of the path (index and
+// metric reach, np.sum's pairwise order for the dY sums, np.linspace) follows the host implementation line by line.
+#include "internal.h"
+#include <math.h>
+#include <algorithm>
+
+namespace {
+
+constexpr int ST_PENDING = 0, ST_FAILED = 1, ST_PATH = 2, ST_OVERFLOW = 3, ST_TOOBIG = 4;
+
+struct PathArgs {
+    double *e;               // the surface (read by the simulations, written by the commits)
+    int n, m;
+    const int32_t *order;    // pit cells in processing order
+    const int32_t *window;   // [nw] indices into `order` of the pits of this round (ascending)
+    int nw;
+    const double *dX, *dY; int ndX;
+    int max_iter, max_dist; double max_dist_XY;
+    int32_t *rown, *wown;    // [NN] smallest order among the pending readers / writers of a cell (INT_MAX: none)
+    int32_t *bown;           // [NN] smallest order among the pits that read the cell and stay pending after this round
+    int32_t *wstamp, *rstamp;   // [NN] largest order among the committed writers / readers of a cell (-1: none)
+    int32_t *tent;           // per slot: passed the first two commit rules
+    // per window slot
+    int32_t *status, *nF, *nC, *iters;
+    int32_t **Fp, **Cp; double **CVp;      // where the slot's footprint / chain / chain values live
+    int32_t *fcap, *ccap;
+    int32_t *flags;          // [0] a simulation met a cell written by a later pit, [1] capacity exceeded
+};
+
+__device__ __forceinline__ double wave_min(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o); v = w < v ? w : v; }
+    return v;
+}
+
+// numpy's pairwise sum of a contiguous vector (np.add.reduce), n <= a few hundred here
+__device__ double np_sum_dev(const double *a, int64_t n)
+{
+    if (n < 8) { double r = 0.; for (int64_t i = 0; i < n; i++) r += a[i]; return r; }
+    if (n <= 128) {
+        double r[8];
+        for (int k = 0; k < 8; k++) r[k] = a[k];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; k++) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_sum_dev(a, n2) + np_sum_dev(a + n2, n - n2);
+}
+
+__device__ double pit_reach(const PathArgs &A, int pi, int pj, int32_t t)
+{
+    const int m = A.m;
+    const int64_t ti = t / m, tj = t % m;
+    const int64_t lo = pi < ti ? pi : ti, hi = pi < ti ? ti : pi;
+    double dxm;
+    if (pi == ti) dxm = A.dX[pi < A.ndX - 1 ? pi : A.ndX - 1];                 // _get_dX_mean :1993-1997
+    else dxm = np_sum_dev(A.dX + lo, hi - lo) / (double)(hi - lo);
+    const double run = dxm * (double)(pj - tj);
+    const double rise = np_sum_dev(A.dY + lo, hi - lo);
+    return sqrt(run * run + rise * rise);
+}
+
+// One pit, one wavefront.  WIN: window edge, RCAP: rim capacity; the trail lives in LDS for the small window and in
+// global scratch for the large one.
+template <int WIN, int RCAP>
+__device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32_t *freshmap, int32_t *rim, int32_t *trail, int tcap)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const int k = A.window[slot];
+    const int32_t pit = A.order[k];
+    const int n = A.n, m = A.m;
+    const int pi = pit / m, pj = pit - pi * m;
+    const int oi = pi - WIN / 2, oj = pj - WIN / 2;          // window origin (may be negative)
+    constexpr int WORDS = WIN * WIN / 32;
+    for (int w = lane; w < WORDS; w += 64) { seen[w] = 0; freshmap[w] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    int nrim = 0, ntrail = 0;
+    bool overflow = false, later = false;
+    auto bit_of = [&](int32_t c, int &word, uint32_t &mask) -> bool {
+        const int i = c / m - oi, j = c % m - oj;
+        if (i < 0 || i >= WIN || j < 0 || j >= WIN) return false;
+        const int b = i * WIN + j;
+        word = b >> 5; mask = 1u << (b & 31);
+        return true;
+    };
+    // the 8 neighbours of the cells src[0..cnt) that have not been seen yet join the rim
+    auto add_ring = [&](const int32_t *src, int cnt) {
+        for (int base = 0; base < cnt * 8; base += 64) {
+            const int q = base + lane;
+            bool add = false; int32_t t = -1;
+            if (q < cnt * 8) {
+                const int32_t c = src[q >> 3];
+                int d = q & 7; d += (d >= 4);
+                const int ii = c / m + d / 3 - 1, jj = c % m + d % 3 - 1;
+                if (ii >= 0 && ii < n && jj >= 0 && jj < m) {
+                    t = ii * m + jj;
+                    int word; uint32_t mask;
+                    if (!bit_of(t, word, mask)) overflow = true;
+                    else add = !(atomicOr(&seen[word], mask) & mask);
+                }
+            }
+            const unsigned long long bal = __ballot(add);
+            const int pos = nrim + __popcll(bal & ((1ull << lane) - 1ull));
+            if (add) { if (pos < RCAP) rim[pos] = t; else overflow = true; }
+            nrim += __popcll(bal);
+        }
+        overflow = __any(overflow);
+        if (nrim > RCAP) nrim = RCAP;
+        __builtin_amdgcn_wave_barrier();
+    };
+    // bits of a window bitmap (optionally AND NOT a second one) -> cells in raster = ascending cell order
+    auto emit_bits = [&](const uint32_t *map, const uint32_t *minus, bool clear, int32_t *dst, int start, int cap, int stop_at) -> int {
+        int emitted = start;
+        bool spill = false;
+        for (int base = 0; base < WORDS; base += 64) {
+            const int w = base + lane;
+            uint32_t bits = (w < WORDS) ? (minus ? (map[w] & ~minus[w]) : map[w]) : 0u;
+            const int cntw = __popc(bits);
+            int incl = cntw;
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            int pos = emitted + incl - cntw;
+            while (bits) {
+                const int b = __ffs((int)bits) - 1; bits &= bits - 1;
+                const int idx = w * 32 + b;
+                if (pos < cap) dst[pos] = (oi + idx / WIN) * m + (oj + idx % WIN); else spill = true;
+                pos++;
+            }
+            if (clear && w < WORDS) const_cast<uint32_t *>(map)[w] = 0;
+            emitted += __shfl(incl, 63);
+            if (stop_at >= 0 && emitted - start >= stop_at) break;           // (the rest of the map is empty)
+        }
+        __builtin_amdgcn_wave_barrier();
+        return __any(spill) ? -1 : emitted;
+    };
+    { int word = 0; uint32_t mask = 0; bit_of(pit, word, mask); if (lane == 0) { seen[word] |= mask; trail[0] = pit; } }
+    ntrail = 1;
+    __builtin_amdgcn_wave_barrier();
+    add_ring(trail, 1);
+    const double floor_ = A.e[pit];
+    if (A.wstamp[pit] > k) later = true;
+    bool found = false;
+    int it = 0, n_out = 0;
+    int32_t *outlet = rim;       // the outlet candidates overwrite the rim list once the growth is over
+    if (!overflow) {
+        for (it = 0; it < A.max_iter; it++) {
+            if (nrim == 0) break;
+            double lowest = INFINITY; bool has_nan = false;
+            for (int q = lane; q < nrim; q += 64) {
+                const double z = A.e[rim[q]];
+                if (A.wstamp[rim[q]] > k) later = true;
+                if (z < lowest) lowest = z;
+                if (isnan(z)) has_nan = true;
+            }
+            lowest = wave_min(lowest);
+            if (__any(has_nan)) break;                       // np.min propagates NaN: the pit fails (:468)
+            // cells at the lowest height: bits in `freshmap`; the others stay in the rim (compacted in place)
+            int keep = 0, nfresh = 0;
+            for (int base = 0; base < nrim; base += 64) {
+                const int q = base + lane;
+                bool is_fresh = false, is_rest = false; int32_t t = -1;
+                if (q < nrim) { t = rim[q]; is_fresh = A.e[t] == lowest; is_rest = !is_fresh; }
+                if (is_fresh) { int word = 0; uint32_t mask = 0; bit_of(t, word, mask); atomicOr(&freshmap[word], mask); }
+                const unsigned long long br = __ballot(is_rest);
+                const int pos = keep + __popcll(br & ((1ull << lane) - 1ull));
+                __builtin_amdgcn_wave_barrier();
+                if (is_rest) rim[pos] = t;                   // pos <= q: never overtakes a cell that is still to be read
+                keep += __popcll(br);
+                nfresh += __popcll(__ballot(is_fresh));
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (lowest < floor_) {                           // the first lower rim cells: outlet candidates (:471-473)
+                const int got = emit_bits(freshmap, nullptr, true, outlet, 0, RCAP, nfresh);
+                if (got < 0) overflow = true;
+                n_out = nfresh; found = true;
+                break;
+            }
+            if (nfresh > tcap - ntrail) { overflow = true; break; }
+            emit_bits(freshmap, nullptr, true, trail, ntrail, tcap, nfresh);      // ascending cell order (:470)
+            nrim = keep;
+            const int first = ntrail;
+            ntrail += nfresh;
+            add_ring(trail + first, nfresh);
+            if (overflow) break;
+        }
+    }
+    if (later && lane == 0) atomicOr(&A.flags[0], 1);
+    if (overflow) { if (lane == 0) { A.status[slot] = ST_OVERFLOW; A.nF[slot] = 0; A.nC[slot] = 0; A.iters[slot] = 0; } return; }
+    if (lane == 0) A.iters[slot] = found ? it + 1 : 0;
+    // ---- what the simulation read: region + everything that was ever on the rim = the `seen` map
+    int32_t *F = A.Fp[slot];
+    const int fcap = A.fcap[slot];
+    int nF = emit_bits(seen, nullptr, false, F, 0, fcap, -1);
+    if (nF < 0) { if (lane == 0) { A.status[slot] = ST_OVERFLOW; A.nF[slot] = 0; A.nC[slot] = 0; } return; }
+    // ---- the path: one lane does what the host loop does (:485-539)
+    int32_t *C = A.Cp[slot];
+    double *CV = A.CVp[slot];
+    const int ccap = A.ccap[slot];
+    int nC = 0, st = found ? ST_PATH : ST_FAILED;
+    if (lane == 0 && found) {
+        int no = n_out;
+        if (A.max_dist) {                                    // index-space reach (:485-493)
+            int w = 0;
+            for (int q = 0; q < no; q++) {
+                const int32_t t = outlet[q];
+                const double di = (double)(pi - t / m), dj = (double)(pj - t % m);
+                if (sqrt(di * di + dj * dj) <= (double)A.max_dist) outlet[w++] = t;
+            }
+            no = w;
+        }
+        const bool use_xy = A.max_dist_XY != 0 && !isnan(A.max_dist_XY);
+        int valid = 0; double best = INFINITY; int32_t end = -1;
+        for (int q = 0; q < no; q++) {                       // metric reach (:494-512)
+            const double r = pit_reach(A, pi, pj, outlet[q]);
+            if (use_xy && !(r <= A.max_dist_XY)) continue;
+            if (valid == 0) end = outlet[q];
+            valid++;
+            if (r < best) best = r;
+        }
+        if (valid == 0) st = ST_FAILED;
+        else if (valid > 1) {
+            for (int q = 0; q < no; q++) {
+                const double r = pit_reach(A, pi, pj, outlet[q]);
+                if (use_xy && !(r <= A.max_dist_XY)) continue;
+                if (r == best) { end = outlet[q]; break; }
+            }
+        }
+        if (st == ST_PATH) {
+            // prune the trail, walking back from the outlet, to an 8-connected chain (:516-532): an entry stays when it
+            // touches the entry kept after it.  Built backwards, then reversed.
+            if (ntrail + 1 > ccap) st = ST_TOOBIG;
+            else {
+                int w = 0;
+                C[w++] = end;
+                int32_t last = end;
+                for (int q = ntrail - 1; q >= 1; q--) {
+                    const int32_t a = trail[q];
+                    const int ai = a / m, aj = a % m, bi = last / m, bj = last % m;
+                    const int dii = ai > bi ? ai - bi : bi - ai, djj = aj > bj ? aj - bj : bj - aj;
+                    if (dii <= 1 && djj <= 1) { C[w++] = a; last = a; }
+                }
+                C[w++] = pit;
+                for (int a = 0, b = w - 1; a < b; a++, b--) { const int32_t tt = C[a]; C[a] = C[b]; C[b] = tt; }
+                nC = w;
+                // elevations fall linearly along the chain (:535-539)
+                double base = A.e[pit];
+                const double e_end = A.e[end];
+                if (base < e_end) {
+                    double mn = INFINITY;
+                    for (int q = 0; q < nC; q++) { const double z = A.e[C[q]]; if (z > e_end && z < mn) mn = z; }
+                    base = mn;
+                }
+                const double drop = e_end - base;
+                const double step = 1.0 / (double)(nC - 1);  // np.linspace(0, 1, L): arange * step, last = 1
+                for (int q = 0; q < nC; q++) {
+                    const double f = (q == nC - 1) ? 1.0 : (double)q * step;
+                    CV[q] = base + f * drop;
+                }
+            }
+        }
+    }
+    nC = __shfl(nC, 0); st = __shfl(st, 0);
+    if (lane == 0) {
+        if (st == ST_TOOBIG) { st = ST_OVERFLOW; }
+        A.status[slot] = st; A.nF[slot] = st == ST_OVERFLOW ? 0 : nF; A.nC[slot] = st == ST_PATH ? nC : 0;
+    }
+    st = __shfl(st, 0);
+    __builtin_amdgcn_wave_barrier();
+    if (st == ST_OVERFLOW) return;
+    for (int q = lane; q < nF; q += 64) atomicMin(&A.rown[F[q]], k);
+    if (st == ST_PATH) for (int q = lane; q < nC; q += 64) atomicMin(&A.wown[C[q]], k);
+}
+
+constexpr int SWIN = 64, SRCAP = 512, STCAP = 1024;
+constexpr int BWIN = 640, BRCAP = 8192;
+
+__global__ __launch_bounds__(256) void k_paths_small(PathArgs A, int nslots)
+{
+    __shared__ uint32_t s_seen[4][SWIN * SWIN / 32], s_fresh[4][SWIN * SWIN / 32];
+    __shared__ int32_t s_rim[4][SRCAP], s_trail[4][STCAP];
+    const int wv = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wv;
+    if (q >= nslots) return;
+    simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_trail[wv], STCAP);
+}
+
+// pits that left the small window: one wavefront per workgroup, the window in dynamic LDS, the trail in global scratch
+__global__ __launch_bounds__(64) void k_paths_big(PathArgs A, const int32_t *__restrict__ slots, int nslots, int32_t *bigtrail, int64_t trail_cap)
+{
+    extern __shared__ uint32_t dyn[];
+    uint32_t *seen = dyn, *fresh = dyn + BWIN * BWIN / 32;
+    int32_t *rim = (int32_t *)(fresh + BWIN * BWIN / 32);
+    const int q = blockIdx.x;
+    if (q >= nslots) return;
+    simulate_pit<BWIN, BRCAP>(A, slots[q], seen, fresh, rim, bigtrail + (int64_t)q * trail_cap, (int)trail_cap);
+}
+
+// Which pits commit.  Pit k saw what the sequential loop would have shown it when
+//   (1) no earlier pending pit writes a cell k read, and (2) no earlier pending pit read a cell k writes (k_paths_tentative);
+//   (3) no earlier pit that stays pending after this round has a footprint that overlaps k's (k_paths_blocked marks them,
+//       k_paths_commit checks): such a pit simulates again on a changed surface and may then write where it only read before.
+// k_limit: the first pit of the order that could not be simulated in this round -- nobody after it may commit.
+// What the rules cannot exclude is caught when it happens: a simulation that reads a cell written by a later pit
+// (simulate_pit), or a commit that writes a cell a later pit has already read (here), raises flags[0].
+__global__ __launch_bounds__(256) void k_paths_tentative(PathArgs A, int k_limit)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= A.nw) return;
+    const int k = A.window[slot];
+    const int st = A.status[slot];
+    bool ok = (st == ST_FAILED || st == ST_PATH) && k < k_limit;
+    if (ok) {
+        const int32_t *F = A.Fp[slot];
+        const int32_t *C = A.Cp[slot];
+        const int nF = A.nF[slot], nC = A.nC[slot];
+        for (int q = lane; q < nF; q += 64) if (A.wown[F[q]] < k) ok = false;
+        for (int q = lane; q < nC; q += 64) if (A.rown[C[q]] != k) ok = false;
+        ok = !__any(!ok);
+    }
+    if (lane == 0) A.tent[slot] = ok;
+}
+
+__global__ __launch_bounds__(256) void k_paths_blocked(PathArgs A)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= A.nw) return;
+    const int st = A.status[slot];
+    if ((st != ST_FAILED && st != ST_PATH) || A.tent[slot]) return;
+    const int k = A.window[slot];
+    const int32_t *F = A.Fp[slot];
+    for (int q = lane; q < A.nF[slot]; q += 64) atomicMin(&A.bown[F[q]], k);
+}
+
+__global__ __launch_bounds__(256) void k_paths_commit(PathArgs A, int32_t *done, int32_t *counts)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= A.nw) return;
+    if (!A.tent[slot]) return;
+    const int k = A.window[slot];
+    const int st = A.status[slot];
+    const int32_t *F = A.Fp[slot];
+    const int32_t *C = A.Cp[slot];
+    const int nF = A.nF[slot], nC = A.nC[slot];
+    bool ok = true, clash = false;
+    for (int q = lane; q < nF; q += 64) if (A.bown[F[q]] < k) ok = false;
+    ok = !__any(!ok);
+    if (!ok) return;
+    for (int q = lane; q < nC; q += 64) if (A.rstamp[C[q]] > k) clash = true;     // a later pit has read what this one rewrites
+    if (__any(clash)) { if (lane == 0) atomicOr(&A.flags[0], 1); return; }
+    if (st == ST_PATH) {
+        const double *CV = A.CVp[slot];
+        for (int q = lane; q < nC; q += 64) { A.e[C[q]] = CV[q]; atomicMax(&A.wstamp[C[q]], k); }
+    }
+    for (int q = lane; q < nF; q += 64) atomicMax(&A.rstamp[F[q]], k);
+    if (lane == 0) {
+        done[slot] = 1;
+        atomicAdd(&counts[0], 1);
+        if (st == ST_FAILED) atomicAdd(&counts[1], 1);
+        atomicMax(&counts[2], A.iters[slot]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_paths_release(PathArgs A)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= A.nw) return;
+    const int st = A.status[slot];
+    if (st != ST_FAILED && st != ST_PATH) return;
+    const int32_t *F = A.Fp[slot];
+    const int32_t *C = A.Cp[slot];
+    for (int q = lane; q < A.nF[slot]; q += 64) { A.rown[F[q]] = 0x7FFFFFFF; A.bown[F[q]] = 0x7FFFFFFF; }
+    for (int q = lane; q < A.nC[slot]; q += 64) A.wown[C[q]] = 0x7FFFFFFF;
+}
+
+// slot tables of a round: small slots point into the per-slot arrays
+__global__ void k_paths_slots(PathArgs A, int32_t *F, int32_t *C, double *CV, int fcap, int ccap)
+{
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < A.nw; s += gridDim.x * blockDim.x) {
+        A.Fp[s] = F + (int64_t)s * fcap; A.Cp[s] = C + (int64_t)s * ccap; A.CVp[s] = CV + (int64_t)s * ccap;
+        A.fcap[s] = fcap; A.ccap[s] = ccap;
+    }
+}
+
+__global__ void k_paths_bigslots(PathArgs A, const int32_t *slots, int nb, int32_t *F, int32_t *C, double *CV, int64_t fcap, int64_t ccap)
+{
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nb; q += gridDim.x * blockDim.x) {
+        const int s = slots[q];
+        A.Fp[s] = F + q * fcap; A.Cp[s] = C + q * ccap; A.CVp[s] = CV + q * ccap;
+        A.fcap[s] = (int32_t)fcap; A.ccap[s] = (int32_t)ccap;
+        A.status[s] = ST_PENDING;
+    }
+}
+
+// strict local minima above (or not at) sea level (:444-449): minimum_filter over the 8 neighbours > e
+__global__ __launch_bounds__(256) void k_paths_pits(const double *__restrict__ e, int n, int m, int below_sea, uint8_t *mask, int32_t *nan_count)
+{
+    const int64_t NN = (int64_t)n * m;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < NN; c += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(c / m), j = (int)(c - (int64_t)i * m);
+        const double z = e[c];
+        if (isnan(z)) { atomicAdd(nan_count, 1); mask[c] = 0; continue; }
+        // scipy's 'reflect' border mirrors the cell itself into the footprint on the array edge: e > e is false there
+        bool low = !(i == 0 || j == 0 || i == n - 1 || j == m - 1);
+        for (int d = 0; d < 9 && low; d++) {
+            if (d == 4) continue;
+            if (!(e[c + (d / 3 - 1) * m + (d % 3 - 1)] > z)) low = false;
+        }
+        mask[c] = low && (below_sea ? (z != 0.0) : (z > 0.0));
+    }
+}
+
+__global__ void k_fill_i32(int32_t *p, int64_t n, int32_t v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__global__ void k_gather_f64(const double *__restrict__ e, const int32_t *__restrict__ ids, int32_t n, double *out)
+{
+    for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = e[ids[i]];
+}
+
+#include "ccl.h"
+
+struct Buf {
+    void *p = nullptr;
+    ~Buf() { if (p) (void)hipFree(p); }
+    int get(size_t bytes) { if (p) { (void)hipFree(p); p = nullptr; } HIP_TRY(hipMalloc(&p, bytes ? bytes : 8)); return 0; }
+};
+
+int gridp(int64_t work, int cap) { const int64_t g = cdiv(work, 256); return (int)(g < cap ? (g > 0 ? g : 1) : cap); }
+
+}  // namespace
+
+// step 1: the pits of the resident surface.  *npits = number of strict minima, or -1 when the tile has NaN cells.
+// The caller reads their cells and elevations (stage_pit_paths_candidates), sorts them like the reference
+// (np.argsort) and passes the order to stage_pit_paths.
+int stage_pit_candidates(pydem_tile *t, int below_sea, int64_t *npits)
+{
+    const int n = (int)t->n, m = (int)t->m;
+    PYDEM_TRY(tile_alloc(t, &t->flat0, (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->flatlist, (size_t)t->NN));
+    HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
+    hipLaunchKernelGGL(k_paths_pits, dim3(gridp(t->NN, 8192)), dim3(256), 0, t->stream, t->elev, n, m, below_sea, t->flat0, t->counters + 8);
+    hipLaunchKernelGGL(k_compact_flats, dim3(gridp(t->NN, 4096)), dim3(256), 0, t->stream, t->flat0, t->NN, t->flatlist, t->counters);
+    HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    *npits = t->h_counters[8] > 0 ? -1 : t->h_counters[0];
+    return 0;
+}
+
+// cells (ascending) and elevations of the candidates found by stage_pit_candidates
+int stage_pit_candidates_read(pydem_tile *t, int64_t npits, int32_t *cells, double *elev)
+{
+    if (npits <= 0) return 0;
+    Buf tmp;
+    PYDEM_TRY(tmp.get((size_t)npits * 8));
+    // (the compaction emits blocks out of order: sort the ids on the host side of this call)
+    HIP_TRY(hipMemcpyAsync(cells, t->flatlist, (size_t)npits * 4, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    std::sort(cells, cells + npits);
+    HIP_TRY(hipMemcpyAsync(t->flatlist, cells, (size_t)npits * 4, hipMemcpyHostToDevice, t->stream));
+    hipLaunchKernelGGL(k_gather_f64, dim3(gridp(npits, 2048)), dim3(256), 0, t->stream, t->elev, t->flatlist, (int32_t)npits, (double *)tmp.p);
+    HIP_TRY(hipMemcpyAsync(elev, tmp.p, (size_t)npits * 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return 0;
+}
+
+// step 2: the paths, in the given order.  Returns 0 (done), 1 (the caller must use the host loop on the ORIGINAL surface,
+// which this call has restored) or a negative error.
+int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int max_iter, int max_dist, double max_dist_XY,
+                    int64_t *n_failed, int64_t *iter_used, int64_t *rounds_out)
+{
+    const int n = (int)t->n, m = (int)t->m;
+    *n_failed = 0; *iter_used = 0; if (rounds_out) *rounds_out = 0;
+    if (npits == 0) return 0;
+    if (npits >= (1ll << 30)) { pydem_set_error("too many pits"); return -2; }
+    if (!t->spacing_set) { pydem_set_error("pit drain paths: call pydem_tile_set_spacing first"); return -3; }
+    if (max_iter > 300) return 1;                             // the large window is sized for the reference's 300 iterations
+    static int win_cap = -1, big_max = -1;
+    if (win_cap < 0) { const char *e = getenv("PYDEM_PATHS_WINDOW"); win_cap = e ? atoi(e) : 32768; if (win_cap < 64) win_cap = 64; }
+    if (big_max < 0) { const char *e = getenv("PYDEM_PATHS_BIG"); big_max = e ? atoi(e) : 192; if (big_max < 1) big_max = 1; }
+    const int W = (int)(npits < win_cap ? npits : win_cap);
+    const int FCAP = STCAP + SRCAP, CCAP = STCAP + 1;
+    const int64_t BIGF = (int64_t)BWIN * BWIN;                // footprint / trail capacity of a large-window simulation
+    Buf b_bown, b_rstamp, b_tent;
+    Buf b_order, b_window, b_rown, b_wown, b_stamp, b_status, b_nF, b_nC, b_iters, b_F, b_C, b_CV, b_flags, b_done, b_counts, b_slots,
+        b_backup, b_bigtrail, b_bigF, b_bigC, b_bigCV, b_Fp, b_Cp, b_CVp, b_fcap, b_ccap;
+    PYDEM_TRY(b_order.get((size_t)npits * 4)); PYDEM_TRY(b_window.get((size_t)W * 4));
+    PYDEM_TRY(b_rown.get((size_t)t->NN * 4)); PYDEM_TRY(b_wown.get((size_t)t->NN * 4)); PYDEM_TRY(b_stamp.get((size_t)t->NN * 4));
+    PYDEM_TRY(b_bown.get((size_t)t->NN * 4)); PYDEM_TRY(b_rstamp.get((size_t)t->NN * 4)); PYDEM_TRY(b_tent.get((size_t)W * 4));
+    PYDEM_TRY(b_status.get((size_t)W * 4)); PYDEM_TRY(b_nF.get((size_t)W * 4)); PYDEM_TRY(b_nC.get((size_t)W * 4)); PYDEM_TRY(b_iters.get((size_t)W * 4));
+    PYDEM_TRY(b_F.get((size_t)W * FCAP * 4)); PYDEM_TRY(b_C.get((size_t)W * CCAP * 4)); PYDEM_TRY(b_CV.get((size_t)W * CCAP * 8));
+    PYDEM_TRY(b_Fp.get((size_t)W * 8)); PYDEM_TRY(b_Cp.get((size_t)W * 8)); PYDEM_TRY(b_CVp.get((size_t)W * 8));
+    PYDEM_TRY(b_fcap.get((size_t)W * 4)); PYDEM_TRY(b_ccap.get((size_t)W * 4));
+    PYDEM_TRY(b_flags.get(16)); PYDEM_TRY(b_done.get((size_t)W * 4)); PYDEM_TRY(b_counts.get(16)); PYDEM_TRY(b_slots.get((size_t)W * 4));
+    PYDEM_TRY(b_backup.get((size_t)t->NN * 8));
+    HIP_TRY(hipMemcpyAsync(b_backup.p, t->elev, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(b_order.p, order_host, (size_t)npits * 4, hipMemcpyHostToDevice, t->stream));
+    const int gN = gridp(t->NN, 8192);
+    hipLaunchKernelGGL(k_fill_i32, dim3(gN), dim3(256), 0, t->stream, (int32_t *)b_rown.p, t->NN, 0x7FFFFFFF);
+    hipLaunchKernelGGL(k_fill_i32, dim3(gN), dim3(256), 0, t->stream, (int32_t *)b_wown.p, t->NN, 0x7FFFFFFF);
+    hipLaunchKernelGGL(k_fill_i32, dim3(gN), dim3(256), 0, t->stream, (int32_t *)b_stamp.p, t->NN, -1);
+    hipLaunchKernelGGL(k_fill_i32, dim3(gN), dim3(256), 0, t->stream, (int32_t *)b_rstamp.p, t->NN, -1);
+    hipLaunchKernelGGL(k_fill_i32, dim3(gN), dim3(256), 0, t->stream, (int32_t *)b_bown.p, t->NN, 0x7FFFFFFF);
+    HIP_TRY(hipMemsetAsync(b_flags.p, 0, 16, t->stream));
+    HIP_TRY(hipMemsetAsync(b_counts.p, 0, 16, t->stream));
+    PathArgs A;
+    A.e = t->elev; A.n = n; A.m = m; A.order = (const int32_t *)b_order.p; A.window = (const int32_t *)b_window.p; A.nw = 0;
+    A.dX = t->dX; A.dY = t->dY; A.ndX = n - 1; A.max_iter = max_iter; A.max_dist = max_dist; A.max_dist_XY = max_dist_XY;
+    A.rown = (int32_t *)b_rown.p; A.wown = (int32_t *)b_wown.p; A.wstamp = (int32_t *)b_stamp.p;
+    A.bown = (int32_t *)b_bown.p; A.rstamp = (int32_t *)b_rstamp.p; A.tent = (int32_t *)b_tent.p;
+    A.status = (int32_t *)b_status.p; A.nF = (int32_t *)b_nF.p; A.nC = (int32_t *)b_nC.p; A.iters = (int32_t *)b_iters.p;
+    A.Fp = (int32_t **)b_Fp.p; A.Cp = (int32_t **)b_Cp.p; A.CVp = (double **)b_CVp.p; A.fcap = (int32_t *)b_fcap.p; A.ccap = (int32_t *)b_ccap.p;
+    A.flags = (int32_t *)b_flags.p;
+    std::vector<int32_t> pending, win, h_status((size_t)W), h_done((size_t)W), big;
+    int64_t next = 0;                 // first pit of the order that has not entered a window yet
+    int64_t rounds = 0, big_runs = 0;
+    bool fallback = false;
+    const size_t big_lds = (size_t)2 * (BWIN * BWIN / 8) + (size_t)BRCAP * 4;
+    bool big_ready = false;
+    while (!pending.empty() || next < npits) {
+        while ((int)pending.size() < W && next < npits) pending.push_back((int32_t)next++);
+        const int nw = (int)pending.size();
+        A.nw = nw;
+        HIP_TRY(hipMemcpyAsync(b_window.p, pending.data(), (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemsetAsync(b_done.p, 0, (size_t)nw * 4, t->stream));
+        hipLaunchKernelGGL(k_paths_slots, dim3(gridp(nw, 256)), dim3(256), 0, t->stream, A, (int32_t *)b_F.p, (int32_t *)b_C.p, (double *)b_CV.p, FCAP, CCAP);
+        hipLaunchKernelGGL(k_paths_small, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A, nw);
+        HIP_TRY(hipMemcpyAsync(h_status.data(), b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        big.clear();
+        for (int s = 0; s < nw; s++) if (h_status[(size_t)s] == ST_OVERFLOW) big.push_back(s);
+        int k_limit = 0x7FFFFFFF;
+        if (!big.empty()) {
+            // as many large-window simulations as one launch holds take part in this round; the first one left out
+            // closes the round for everybody after it: a pit commits only when every earlier pending pit was simulated
+            if (!big_ready) {
+                PYDEM_TRY(b_bigtrail.get((size_t)big_max * BIGF * 4));
+                PYDEM_TRY(b_bigF.get((size_t)big_max * BIGF * 4));
+                PYDEM_TRY(b_bigC.get((size_t)big_max * (BIGF + 1) * 4));
+                PYDEM_TRY(b_bigCV.get((size_t)big_max * (BIGF + 1) * 8));
+                HIP_TRY(hipFuncSetAttribute((const void *)k_paths_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+                big_ready = true;
+            }
+            if ((int)big.size() > big_max) { k_limit = pending[(size_t)big[(size_t)big_max]]; big.resize((size_t)big_max); }
+            const int nb = (int)big.size();
+            HIP_TRY(hipMemcpyAsync(b_slots.p, big.data(), (size_t)nb * 4, hipMemcpyHostToDevice, t->stream));
+            hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nb, 64)), dim3(256), 0, t->stream, A, (const int32_t *)b_slots.p, nb, (int32_t *)b_bigF.p,
+                               (int32_t *)b_bigC.p, (double *)b_bigCV.p, BIGF, BIGF + 1);
+            hipLaunchKernelGGL(k_paths_big, dim3(nb), dim3(64), big_lds, t->stream, A, (const int32_t *)b_slots.p, nb, (int32_t *)b_bigtrail.p, BIGF);
+            big_runs += nb;
+        }
+        hipLaunchKernelGGL(k_paths_tentative, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A, k_limit);
+        hipLaunchKernelGGL(k_paths_blocked, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A);
+        hipLaunchKernelGGL(k_paths_commit, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A, (int32_t *)b_done.p, (int32_t *)b_counts.p);
+        hipLaunchKernelGGL(k_paths_release, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A);
+        HIP_TRY(hipMemcpyAsync(h_done.data(), b_done.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(h_status.data(), b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->h_counters, b_flags.p, 16, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        rounds++;
+        if (getenv("PYDEM_PATHS_DEBUG") && atoi(getenv("PYDEM_PATHS_DEBUG")) >= 2) {
+            std::vector<int32_t> h_it((size_t)nw);
+            HIP_TRY(hipMemcpy(h_it.data(), b_iters.p, (size_t)nw * 4, hipMemcpyDeviceToHost));
+            for (int s2 = 0; s2 < nw; s2++)
+                if (h_done[(size_t)s2]) fprintf(stderr, "  commit k=%d cell=%d status=%d iters=%d\n", pending[(size_t)s2], order_host[pending[(size_t)s2]],
+                                                 h_status[(size_t)s2], h_it[(size_t)s2]);
+        }
+        if (t->h_counters[0] || t->h_counters[1]) { fallback = true; break; }
+        bool stuck = false;
+        for (int s : big) if (h_status[(size_t)s] == ST_OVERFLOW) stuck = true;      // does not even fit the large window
+        if (stuck) { fallback = true; break; }
+        win.clear();
+        for (int s = 0; s < nw; s++) if (!h_done[(size_t)s]) win.push_back(pending[(size_t)s]);
+        if ((int)win.size() == nw) { fallback = true; break; }                        // (cannot happen: the first pit always commits)
+        pending.swap(win);
+    }
+    if (rounds_out) *rounds_out = rounds;
+    if (getenv("PYDEM_PATHS_DEBUG"))
+        fprintf(stderr, "pit drain paths: %lld pits, %lld rounds, %lld large-window simulations%s\n", (long long)npits, (long long)rounds,
+                (long long)big_runs, fallback ? " -> host loop" : "");
+    if (fallback) {
+        HIP_TRY(hipMemcpyAsync(t->elev, b_backup.p, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        return 1;
+    }
+    HIP_TRY(hipMemcpyAsync(t->h_counters, b_counts.p, 16, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    *n_failed = t->h_counters[1];
+    *iter_used = t->h_counters[2];
+    return 0;
+}

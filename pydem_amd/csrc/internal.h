@@ -115,6 +115,10 @@ int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *
                          const uint8_t *const todo[4]);
 int stage_edge_flush(pydem_tile *t);
 int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double source_tol, int peaks, int pits, int artefacts_only);
+int stage_pit_candidates(pydem_tile *t, int below_sea, int64_t *npits);
+int stage_pit_candidates_read(pydem_tile *t, int64_t npits, int32_t *cells, double *elev);
+int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int max_iter, int max_dist, double max_dist_XY,
+                    int64_t *n_failed, int64_t *iter_used, int64_t *rounds_out);
 int stage_synth(pydem_tile *t, uint32_t seed, int64_t row0, int64_t col0, int n_oct, int top_shift,
                 double zmin, double zrange);
 int bench_stencil(pydem_tile *t, int iters, double *avg_ms);

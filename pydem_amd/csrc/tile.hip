@@ -427,6 +427,35 @@ int pydem_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
     return 0;
 }
 
+int pydem_pit_candidates(pydem_tile *t, int below_sea, int64_t *npits)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_pit_candidates"));
+    return stage_pit_candidates(t, below_sea, npits);
+}
+
+int pydem_pit_candidates_read(pydem_tile *t, int64_t npits, int32_t *cells, double *elev)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    return stage_pit_candidates_read(t, npits, cells, elev);
+}
+
+int pydem_pit_paths(pydem_tile *t, const int32_t *order, int64_t npits, int max_iter, int max_dist, double max_dist_XY,
+                    int64_t *n_failed, int64_t *iter_used, int64_t *rounds, int *needs_host)
+{
+    t->edge_clean = false;
+    t->einc_ready = false;
+    HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_pit_paths"));
+    if (t->elev_f32) { if (needs_host) *needs_host = 1; return 0; }            // the path values round in the array's own dtype (:539)
+    t->graph_valid = false;
+    const int r = stage_pit_paths(t, order, npits, max_iter, max_dist, max_dist_XY, n_failed, iter_used, rounds);
+    if (r < 0) return r;
+    if (needs_host) *needs_host = r;
+    for (int f = PYDEM_MAG; f < PYDEM_FIELD_COUNT; f++) t->have[f] = false;
+    return 0;
+}
+
 int pydem_find_flats(pydem_tile *t)
 {
     t->edge_clean = false;      // these stages reuse the edge-round work lists

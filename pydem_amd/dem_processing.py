@@ -336,6 +336,13 @@ class DEMProcessor(object):
     def calc_pit_drain_paths(self):
         """Carve monotone paths from pits to their outlets (reference :428-548).  Works on a copy of the
         array (the reference edits the caller's array in place)."""
+        res = self._pit_paths_on_device()
+        if res is not None:
+            n_failed, used, self._pit_path_rounds = res
+            if n_failed:
+                warnings.warn("Warning %d pits had no place to drain to in this chunk" % n_failed)
+            logger.info("... done draining pits with maxiter = %d", used)
+            return self.elev
         from . import conditioning
         elev = np.array(self.elev)
         elev, n_failed, used = conditioning.pit_drain_paths(elev, self.dX, self.dY, self.drain_pits_max_iter,
@@ -344,6 +351,25 @@ class DEMProcessor(object):
         logger.info("... done draining pits with maxiter = %d", used)
         self.elev = elev
         return elev
+
+    def _pit_paths_on_device(self):
+        """(n_failed, iterations, rounds) when the library carved the paths on the resident float64 surface, else None:
+        integer / float32 surfaces keep numpy's in-dtype arithmetic (:539) and tiles with no-data go through the host."""
+        elev = self._host.get('elev')
+        if elev is not None and (np.ma.isMaskedArray(elev) or np.asarray(elev).dtype != np.float64 or np.asarray(elev).ndim != 2):
+            return None
+        if min(self.shape) < 3:
+            return None
+        self._ensure_tile()
+        self._push('elev')
+        res = self._tile.pit_drain_paths(self.fill_flats_below_sea, self.drain_pits_max_iter, self.drain_pits_max_dist,
+                                         self.drain_pits_max_dist_XY)
+        if res is None:
+            return None
+        self._produced('elev')
+        for nm in ('mag', 'direction', 'flats', 'uca', 'section', 'proportion', 'edge_todo', 'edge_done'):
+            self._on_device.discard(nm)
+        return res
 
     def calc_slopes_directions(self, plotflag=False):
         """Slope magnitude and D-infinity direction (reference :587-619)."""

@@ -99,3 +99,78 @@ def test_large_plateau_tile_matches_host_twin():
     dp.calc_fill_flats()
     assert 'elev' in dp._on_device
     assert np.array_equal(dp.elev, want)
+
+
+# ---- pit drain paths (csrc/cond_paths.hip) ------------------------------------------------------------------
+def _drained_cases():
+    return [n for n in golden_names() + golden_names('g7_') if 'elev_drained' in load_golden(n)]
+
+
+@pytest.mark.parametrize('name', _drained_cases())
+def test_device_pit_paths_match_reference(name):
+    from pydem_amd import DEMProcessor
+    g = load_golden(name)
+    kw = g['kwargs']
+    opts = {k: kw[k] for k in ('maximum_pit_area', 'fill_flats_below_sea', 'fill_flats_source_tol', 'fill_flats_peaks', 'fill_flats_pits',
+                               'drain_pits_max_iter', 'drain_pits_max_dist', 'drain_pits_max_dist_XY') if k in kw}
+    dp = DEMProcessor(elev=g['in_elev'].copy(), dX=g['in_dX'], dY=g['in_dY'], **opts)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        if kw.get('fill_flats', True):
+            dp.calc_fill_flats()
+        dp.calc_pit_drain_paths()
+    got = np.asarray(dp.elev)
+    assert got.dtype == g['elev_drained'].dtype
+    assert np.array_equal(got, g['elev_drained'], equal_nan=True)
+
+
+@pytest.mark.parametrize('block', range(4))
+def test_device_pit_paths_match_host_twin(block):
+    """Random tiles (after the flats step, like the reference's pipeline, and raw float64 surfaces with plateaus left in):
+    the order-preserving parallel schedule against the sequential host loop, bit for bit; the fallback to the host loop
+    (a later pit's path met by an earlier pit's regrowth) must stay rare."""
+    from pydem_amd import DEMProcessor, conditioning as C
+    fell_back = 0
+    for k in range(block * 30, block * 30 + 30):
+        z, opt = _random_tile(k)
+        rng = np.random.default_rng(k)
+        n = z.shape[0]
+        dX = 25.0 + 0.01 * np.arange(n - 1); dY = 31.0 - 0.004 * np.arange(n - 1)
+        popt = dict(drain_pits_max_iter=int(rng.choice([300, 300, 6])), drain_pits_max_dist=int(rng.choice([32, 32, 3])),
+                    drain_pits_max_dist_XY=(float(rng.uniform(30, 200)) if rng.random() < 0.2 else None))
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            if rng.random() < 0.7:
+                base = C.fill_flats(z.copy(), **opt)
+            else:
+                base = np.ascontiguousarray(z, np.float64)
+            if np.isnan(base).any():
+                continue
+            want, bad, used = C.pit_drain_paths(base.copy(), dX, dY, fill_flats_below_sea=opt['fill_flats_below_sea'], **popt)
+            dp = DEMProcessor(elev=base.copy(), dX=dX, dY=dY, fill_flats_below_sea=opt['fill_flats_below_sea'], **popt)
+            res = dp._pit_paths_on_device()
+            if res is None:
+                fell_back += 1
+                dp.calc_pit_drain_paths()
+            got = np.asarray(dp.elev)
+        assert np.array_equal(got, want), "case %d (%s): paths differ on %d cells" % (k, z.shape, int((got != want).sum()))
+        if res is not None:
+            assert res[0] == bad and res[1] == used, (k, res, bad, used)
+    assert fell_back <= 3, "%d of 30 tiles fell back to the host loop" % fell_back
+
+
+def test_device_pit_paths_plateau_tile():
+    """SRTM-like int16 tile with lakes: after the flats step the lake centres are pits whose region grows for all 300
+    iterations (large-window simulations)."""
+    from pydem_amd import DEMProcessor, conditioning as C, synth
+    z = synth.srtm_int16(900, 1100, seed=3)
+    dX = np.full(899, 30.0); dY = np.full(899, 30.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        base = C.fill_flats(z.copy())
+        want, bad, used = C.pit_drain_paths(base.copy(), dX, dY)
+        dp = DEMProcessor(elev=base.copy(), dX=dX, dY=dY)
+        res = dp._pit_paths_on_device()
+    assert res is not None, "fell back to the host loop"
+    assert np.array_equal(np.asarray(dp.elev), want)
+    assert (res[0], res[1]) == (bad, used)
