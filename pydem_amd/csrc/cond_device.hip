@@ -359,6 +359,72 @@ __global__ __launch_bounds__(256) void k_flat_sweep(CondArgs A, Regions R, const
     }
 }
 
+// The same sweep over a WORK LIST: behind the front of first arrivals a region's distances settle after a few
+// sweeps, and a lake that takes 1500 sweeps to cross has millions of settled cells.  A cell is looked at in sweep s + 1
+// only if it or one of its region neighbours changed in sweep s (a cell that changed is listed itself, so that its new
+// value reaches the other buffer of the ping-pong pair); cells that are not listed have the same value in both buffers.
+__global__ __launch_bounds__(256) void k_flat_sweep_wl(CondArgs A, Regions R, const int32_t *__restrict__ wl_in, int32_t *__restrict__ wl_out,
+                                                       int32_t *cnt3, int32_t *stamp, const double *__restrict__ dh0, double *__restrict__ dh1,
+                                                       const double *__restrict__ dl0, double *__restrict__ dl1, int sweep, double source_tol)
+{
+    const int n = A.n, m = A.m;
+    const int32_t na = cnt3[sweep % 3];
+    int32_t *n_out = &cnt3[(sweep + 1) % 3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt3[(sweep + 2) % 3] = 0;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < na; q += gridDim.x * blockDim.x) {
+        const int32_t c = wl_in[q];
+        const int32_t r = A.rid[A.labels[c]];
+        const int32_t fl = R.flags[r];
+        const bool act_hi = R.done_hi[r] >= sweep, act_lo = R.done_lo[r] >= sweep;
+        const double oh = dh0[c], ol = dl0[c];
+        double nh = oh, nl = ol;
+        const int i = c / m, j = c - i * m;
+        if (act_hi || act_lo) {
+            const double level = A.elev[c];
+            const double src_max = (fl & RF_SOURCE) ? dunkey(R.lowest_bits[r]) + source_tol : 0.0;   // lowest + tol (:347)
+            double card_h = oh, all_h = oh, card_l = ol, all_l = ol;
+            for (int d = 0; d < 9; d++) {
+                if (d == 4) continue;
+                const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
+                if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+                const int32_t nb = ii * m + jj;
+                double vh, vl;
+                if (A.mask[nb]) { vh = dh0[nb]; vl = dl0[nb]; }
+                else {
+                    const double z = A.elev[nb];
+                    vh = ((fl & RF_SOURCE) && z > level && z <= src_max) ? 0.0 : INFINITY;
+                    vl = ((fl & RF_DRAIN) && z == level) ? 0.0 : INFINITY;
+                }
+                const bool cardinal = (d == 1 || d == 3 || d == 5 || d == 7);
+                if (cardinal) { card_h = vh < card_h ? vh : card_h; card_l = vl < card_l ? vl : card_l; }
+                all_h = vh < all_h ? vh : all_h; all_l = vl < all_l ? vl : all_l;
+            }
+            if (act_hi) {
+                const double sv = card_h + 1, g = all_h + SQRT2;
+                const double best = sv < g ? sv : g;
+                nh = best < oh ? best : oh;
+                if (isinf(oh) && !isinf(nh) && atomicSub(&R.rem_hi[r], 1) == 1) R.done_hi[r] = sweep;
+            }
+            if (act_lo) {
+                const double sv = card_l + 1, g = all_l + SQRT2;
+                const double best = sv < g ? sv : g;
+                nl = best < ol ? best : ol;
+                if (isinf(ol) && !isinf(nl) && atomicSub(&R.rem_lo[r], 1) == 1) R.done_lo[r] = sweep;
+            }
+        }
+        dh1[c] = nh; dl1[c] = nl;
+        if (nh != oh || nl != ol) {
+            for (int d = 0; d < 9; d++) {
+                const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
+                if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+                const int32_t nb = ii * m + jj;
+                if (!A.mask[nb]) continue;
+                if (atomicExch(&stamp[nb], sweep + 1) != sweep + 1) wl_out[atomicAdd(n_out, 1)] = nb;
+            }
+        }
+    }
+}
+
 // cells of regions that are still sweeping -> next active list
 __global__ void k_flat_active(CondArgs A, Regions R, const int32_t *__restrict__ alist, int32_t na, int sweep, int32_t *out, int32_t *nout)
 {
@@ -514,31 +580,37 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
         hipLaunchKernelGGL(k_centre_pass, dim3(g1), dim3(256), 0, t->stream, A, R, 1);
         hipLaunchKernelGGL(k_flat_seed, dim3(g1), dim3(256), 0, t->stream, A, R, dh[0], dl[0]);
         hipLaunchKernelGGL(k_flat_seed_done, dim3(gr), dim3(256), 0, t->stream, R, nreg);
-        // active cells: every cell of a region in the general case; the list shrinks as regions stop (checked after
-        // 1, 2, 4, 8, ... sweeps: most regions are a few cells wide, a lake keeps sweeping alone)
+        // sweep 1 looks at every cell of a region in the general case (it also fills the second buffer of the pair); from
+        // then on the work lists carry the cells whose neighbourhood changed.  The host looks at the list length every 32
+        // sweeps; sweeps over an empty list are no-ops.
         int32_t *cnt = t->counters;
-        HIP_TRY(hipMemsetAsync(cnt + 2, 0, sizeof(int32_t), t->stream));
+        PYDEM_TRY(tile_alloc(t, &t->indeg, (size_t)t->NN));
+        int32_t *stamp = t->indeg;
+        HIP_TRY(hipMemsetAsync(stamp, 0, (size_t)t->NN * 4, t->stream));
+        HIP_TRY(hipMemsetAsync(cnt + 2, 0, 6 * sizeof(int32_t), t->stream));
         hipLaunchKernelGGL(k_flat_active, dim3(g1), dim3(256), 0, t->stream, A, R, t->flatlist, nf, 1, al0, cnt + 2);
+        // (k_flat_active counted into cnt[2]; the sweep kernels rotate over cnt3 = cnt + 4 .. cnt + 6: sweep s reads cnt3[s % 3])
+        HIP_TRY(hipMemcpyAsync(cnt + 4 + 1, cnt + 2, sizeof(int32_t), hipMemcpyDeviceToDevice, t->stream));
         HIP_TRY(hipMemcpyAsync(t->h_counters + 2, cnt + 2, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         int32_t na = t->h_counters[2];
         int32_t *al[2] = {al0, al1};
-        int cur = 0, sweep = 1, batch = 1, pp = 0;
+        int cur = 0, sweep = 1, pp = 0;
         const int64_t sweep_cap = (int64_t)n * m + 2;
+        int64_t cell_sweeps = 0;
+        const int gw = grid_of(nf, 2048);
         while (na > 0) {
-            const int ga = grid_of(na, 4096);
-            for (int b = 0; b < batch; b++, sweep++, pp ^= 1)
-                hipLaunchKernelGGL(k_flat_sweep, dim3(ga), dim3(256), 0, t->stream, A, R, al[cur], na, dh[pp], dh[pp ^ 1], dl[pp], dl[pp ^ 1],
-                                   sweep, source_tol);
-            HIP_TRY(hipMemsetAsync(cnt + 2, 0, sizeof(int32_t), t->stream));
-            hipLaunchKernelGGL(k_flat_active, dim3(ga), dim3(256), 0, t->stream, A, R, al[cur], na, sweep, al[cur ^ 1], cnt + 2);
-            HIP_TRY(hipMemcpyAsync(t->h_counters + 2, cnt + 2, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            for (int b = 0; b < 32; b++, sweep++, pp ^= 1, cur ^= 1)
+                hipLaunchKernelGGL(k_flat_sweep_wl, dim3(gw), dim3(256), 0, t->stream, A, R, al[cur], al[cur ^ 1], cnt + 4, stamp, dh[pp], dh[pp ^ 1],
+                                   dl[pp], dl[pp ^ 1], sweep, source_tol);
+            HIP_TRY(hipMemcpyAsync(t->h_counters + 4, cnt + 4, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
-            na = t->h_counters[2];
-            cur ^= 1;
-            if (batch < 64) batch *= 2;
+            na = t->h_counters[4 + sweep % 3];
+            cell_sweeps += na;
             if (sweep > sweep_cap) { pydem_set_error("fill_flats: distance sweeps did not terminate"); return -5; }
         }
+        if (getenv("PYDEM_COND_DEBUG"))
+            fprintf(stderr, "fill_flats: %d flat cells in %d regions, %d sweeps, %lld cell-sweeps\n", nf, nreg, sweep - 1, (long long)cell_sweeps);
         // (every region took part in at least one sweep after the one that stopped it: both buffers hold its final values)
         hipLaunchKernelGGL(k_flat_interp, dim3(g1), dim3(256), 0, t->stream, A, R, dh[pp], dl[pp]);
         HIP_TRY(hipGetLastError());

@@ -27,6 +27,7 @@
 #include "internal.h"
 #include <math.h>
 #include <algorithm>
+#include <time.h>
 
 namespace {
 
@@ -92,7 +93,7 @@ __device__ double pit_reach(const PathArgs &A, int pi, int pj, int32_t t)
 // One pit, one wavefront.  WIN: window edge, RCAP: rim capacity; the trail lives in LDS for the small window and in
 // global scratch for the large one.
 template <int WIN, int RCAP>
-__device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32_t *freshmap, int32_t *rim, int32_t *trail, int tcap)
+__device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32_t *freshmap, int32_t *rim, double *rimz, int32_t *flist, int32_t *trail, int tcap)
 {
     const int lane = (int)(threadIdx.x & 63);
     const int k = A.window[slot];
@@ -130,7 +131,11 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
             }
             const unsigned long long bal = __ballot(add);
             const int pos = nrim + __popcll(bal & ((1ull << lane) - 1ull));
-            if (add) { if (pos < RCAP) rim[pos] = t; else overflow = true; }
+            if (add) {
+                // the cell's elevation is read ONCE, when it joins the rim (nothing changes the surface while the round simulates)
+                if (pos < RCAP) { rim[pos] = t; rimz[pos] = A.e[t]; if (A.wstamp[t] > k) later = true; }
+                else overflow = true;
+            }
             nrim += __popcll(bal);
         }
         overflow = __any(overflow);
@@ -167,6 +172,7 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
     add_ring(trail, 1);
     const double floor_ = A.e[pit];
     if (A.wstamp[pit] > k) later = true;
+    later = __any(later);
     bool found = false;
     int it = 0, n_out = 0;
     int32_t *outlet = rim;       // the outlet candidates overwrite the rim list once the growth is over
@@ -175,8 +181,7 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
             if (nrim == 0) break;
             double lowest = INFINITY; bool has_nan = false;
             for (int q = lane; q < nrim; q += 64) {
-                const double z = A.e[rim[q]];
-                if (A.wstamp[rim[q]] > k) later = true;
+                const double z = rimz[q];
                 if (z < lowest) lowest = z;
                 if (isnan(z)) has_nan = true;
             }
@@ -186,25 +191,47 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
             int keep = 0, nfresh = 0;
             for (int base = 0; base < nrim; base += 64) {
                 const int q = base + lane;
-                bool is_fresh = false, is_rest = false; int32_t t = -1;
-                if (q < nrim) { t = rim[q]; is_fresh = A.e[t] == lowest; is_rest = !is_fresh; }
-                if (is_fresh) { int word = 0; uint32_t mask = 0; bit_of(t, word, mask); atomicOr(&freshmap[word], mask); }
+                bool is_fresh = false, is_rest = false; int32_t t = -1; double z = 0.0;
+                if (q < nrim) { t = rim[q]; z = rimz[q]; is_fresh = z == lowest; is_rest = !is_fresh; }
+                // the first 64 fresh cells go to a list (sorted in registers below), any further ones into the bitmap
+                const unsigned long long bf = __ballot(is_fresh);
+                const int pf = nfresh + __popcll(bf & ((1ull << lane) - 1ull));
+                if (is_fresh) {
+                    if (pf < 64) flist[pf] = t;
+                    else { int word = 0; uint32_t mask = 0; bit_of(t, word, mask); atomicOr(&freshmap[word], mask); }
+                }
                 const unsigned long long br = __ballot(is_rest);
                 const int pos = keep + __popcll(br & ((1ull << lane) - 1ull));
                 __builtin_amdgcn_wave_barrier();
-                if (is_rest) rim[pos] = t;                   // pos <= q: never overtakes a cell that is still to be read
+                if (is_rest) { rim[pos] = t; rimz[pos] = z; }   // pos <= q: never overtakes a cell that is still to be read
                 keep += __popcll(br);
-                nfresh += __popcll(__ballot(is_fresh));
+                nfresh += __popcll(bf);
                 __builtin_amdgcn_wave_barrier();
             }
+            // ascending cell order (:470): up to 64 cells by rank (one cell per lane), more through the window bitmap
+            auto emit_fresh = [&](int32_t *dst, int start, int cap) -> int {
+                if (nfresh <= 64) {
+                    if (start + nfresh > cap) return -1;
+                    const int32_t mine = lane < nfresh ? flist[lane] : 0x7FFFFFFF;
+                    int rank = 0;
+                    for (int o = 0; o < nfresh; o++) rank += __shfl(mine, o) < mine;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < nfresh) dst[start + rank] = mine;
+                    __builtin_amdgcn_wave_barrier();
+                    return start + nfresh;
+                }
+                for (int q = lane; q < 64; q += 64) { int word = 0; uint32_t mask = 0; bit_of(flist[q], word, mask); atomicOr(&freshmap[word], mask); }
+                __builtin_amdgcn_wave_barrier();
+                return emit_bits(freshmap, nullptr, true, dst, start, cap, nfresh);
+            };
             if (lowest < floor_) {                           // the first lower rim cells: outlet candidates (:471-473)
-                const int got = emit_bits(freshmap, nullptr, true, outlet, 0, RCAP, nfresh);
+                const int got = emit_fresh(outlet, 0, RCAP);
                 if (got < 0) overflow = true;
                 n_out = nfresh; found = true;
                 break;
             }
             if (nfresh > tcap - ntrail) { overflow = true; break; }
-            emit_bits(freshmap, nullptr, true, trail, ntrail, tcap, nfresh);      // ascending cell order (:470)
+            emit_fresh(trail, ntrail, tcap);
             nrim = keep;
             const int first = ntrail;
             ntrail += nfresh;
@@ -212,7 +239,7 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
             if (overflow) break;
         }
     }
-    if (later && lane == 0) atomicOr(&A.flags[0], 1);
+    if (__any(later) && lane == 0) atomicOr(&A.flags[0], 1);
     if (overflow) { if (lane == 0) { A.status[slot] = ST_OVERFLOW; A.nF[slot] = 0; A.nC[slot] = 0; A.iters[slot] = 0; } return; }
     if (lane == 0) A.iters[slot] = found ? it + 1 : 0;
     // ---- what the simulation read: region + everything that was ever on the rim = the `seen` map
@@ -300,16 +327,18 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
 }
 
 constexpr int SWIN = 64, SRCAP = 512, STCAP = 1024;
-constexpr int BWIN = 640, BRCAP = 8192;
+constexpr int BWIN = 640, BRCAP = 4096;
 
 __global__ __launch_bounds__(256) void k_paths_small(PathArgs A, int nslots)
 {
     __shared__ uint32_t s_seen[4][SWIN * SWIN / 32], s_fresh[4][SWIN * SWIN / 32];
     __shared__ int32_t s_rim[4][SRCAP], s_trail[4][STCAP];
+    __shared__ double s_rimz[4][SRCAP];
+    __shared__ int32_t s_flist[4][64];
     const int wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
     if (q >= nslots) return;
-    simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_trail[wv], STCAP);
+    simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_flist[wv], s_trail[wv], STCAP);
 }
 
 // pits that left the small window: one wavefront per workgroup, the window in dynamic LDS, the trail in global scratch
@@ -317,10 +346,12 @@ __global__ __launch_bounds__(64) void k_paths_big(PathArgs A, const int32_t *__r
 {
     extern __shared__ uint32_t dyn[];
     uint32_t *seen = dyn, *fresh = dyn + BWIN * BWIN / 32;
-    int32_t *rim = (int32_t *)(fresh + BWIN * BWIN / 32);
+    double *rimz = (double *)(fresh + BWIN * BWIN / 32);
+    int32_t *rim = (int32_t *)(rimz + BRCAP);
+    int32_t *flist = rim + BRCAP;
     const int q = blockIdx.x;
     if (q >= nslots) return;
-    simulate_pit<BWIN, BRCAP>(A, slots[q], seen, fresh, rim, bigtrail + (int64_t)q * trail_cap, (int)trail_cap);
+    simulate_pit<BWIN, BRCAP>(A, slots[q], seen, fresh, rim, rimz, flist, bigtrail + (int64_t)q * trail_cap, (int)trail_cap);
 }
 
 // Which pits commit.  Pit k saw what the sequential loop would have shown it when
@@ -512,7 +543,7 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     if (max_iter > 300) return 1;                             // the large window is sized for the reference's 300 iterations
     static int win_cap = -1, big_max = -1;
     if (win_cap < 0) { const char *e = getenv("PYDEM_PATHS_WINDOW"); win_cap = e ? atoi(e) : 32768; if (win_cap < 64) win_cap = 64; }
-    if (big_max < 0) { const char *e = getenv("PYDEM_PATHS_BIG"); big_max = e ? atoi(e) : 192; if (big_max < 1) big_max = 1; }
+    if (big_max < 0) { const char *e = getenv("PYDEM_PATHS_BIG"); big_max = e ? atoi(e) : 256; if (big_max < 1) big_max = 1; }
     const int W = (int)(npits < win_cap ? npits : win_cap);
     const int FCAP = STCAP + SRCAP, CCAP = STCAP + 1;
     const int64_t BIGF = (int64_t)BWIN * BWIN;                // footprint / trail capacity of a large-window simulation
@@ -547,24 +578,39 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     A.Fp = (int32_t **)b_Fp.p; A.Cp = (int32_t **)b_Cp.p; A.CVp = (double **)b_CVp.p; A.fcap = (int32_t *)b_fcap.p; A.ccap = (int32_t *)b_ccap.p;
     A.flags = (int32_t *)b_flags.p;
     std::vector<int32_t> pending, win, h_status((size_t)W), h_done((size_t)W), big;
+    std::vector<uint8_t> known_big((size_t)npits, 0);       // pits that left the small window in an earlier round
     int64_t next = 0;                 // first pit of the order that has not entered a window yet
-    int64_t rounds = 0, big_runs = 0;
+    int64_t rounds = 0, big_runs = 0, small_runs = 0;
+    double ms_small = 0, ms_big = 0, ms_commit = 0;
+    const bool prof = getenv("PYDEM_PATHS_DEBUG") != nullptr;
+    auto now_ms = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     bool fallback = false;
-    const size_t big_lds = (size_t)2 * (BWIN * BWIN / 8) + (size_t)BRCAP * 4;
+    const size_t big_lds = (size_t)2 * (BWIN * BWIN / 8) + (size_t)BRCAP * 12 + 64 * 4;
     bool big_ready = false;
     while (!pending.empty() || next < npits) {
         while ((int)pending.size() < W && next < npits) pending.push_back((int32_t)next++);
-        const int nw = (int)pending.size();
+        // only as many large-window pits as one launch holds can take part in a round, and nobody after the first one
+        // left out may commit (k_limit below): the pits behind it are not worth simulating this round
+        int nw = (int)pending.size();
+        {
+            int seen_big = 0;
+            for (int s2 = 0; s2 < nw; s2++)
+                if (known_big[(size_t)pending[(size_t)s2]] && ++seen_big > big_max) { nw = s2; break; }
+        }
         A.nw = nw;
         HIP_TRY(hipMemcpyAsync(b_window.p, pending.data(), (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemsetAsync(b_done.p, 0, (size_t)nw * 4, t->stream));
+        const double t_a = now_ms();
+        small_runs += nw;
         hipLaunchKernelGGL(k_paths_slots, dim3(gridp(nw, 256)), dim3(256), 0, t->stream, A, (int32_t *)b_F.p, (int32_t *)b_C.p, (double *)b_CV.p, FCAP, CCAP);
         hipLaunchKernelGGL(k_paths_small, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A, nw);
         HIP_TRY(hipMemcpyAsync(h_status.data(), b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(t->stream));
+        const double t_b = now_ms();
+        ms_small += t_b - t_a;
         big.clear();
-        for (int s = 0; s < nw; s++) if (h_status[(size_t)s] == ST_OVERFLOW) big.push_back(s);
+        for (int s = 0; s < nw; s++) if (h_status[(size_t)s] == ST_OVERFLOW) { big.push_back(s); known_big[(size_t)pending[(size_t)s]] = 1; }
         int k_limit = 0x7FFFFFFF;
         if (!big.empty()) {
             // as many large-window simulations as one launch holds take part in this round; the first one left out
@@ -585,6 +631,9 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
             hipLaunchKernelGGL(k_paths_big, dim3(nb), dim3(64), big_lds, t->stream, A, (const int32_t *)b_slots.p, nb, (int32_t *)b_bigtrail.p, BIGF);
             big_runs += nb;
         }
+        if (prof) { HIP_TRY(hipStreamSynchronize(t->stream)); }
+        const double t_c = now_ms();
+        ms_big += t_c - t_b;
         hipLaunchKernelGGL(k_paths_tentative, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A, k_limit);
         hipLaunchKernelGGL(k_paths_blocked, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A);
         hipLaunchKernelGGL(k_paths_commit, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A, (int32_t *)b_done.p, (int32_t *)b_counts.p);
@@ -595,6 +644,7 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(t->stream));
         rounds++;
+        ms_commit += now_ms() - t_c;
         if (getenv("PYDEM_PATHS_DEBUG") && atoi(getenv("PYDEM_PATHS_DEBUG")) >= 2) {
             std::vector<int32_t> h_it((size_t)nw);
             HIP_TRY(hipMemcpy(h_it.data(), b_iters.p, (size_t)nw * 4, hipMemcpyDeviceToHost));
@@ -609,12 +659,14 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         win.clear();
         for (int s = 0; s < nw; s++) if (!h_done[(size_t)s]) win.push_back(pending[(size_t)s]);
         if ((int)win.size() == nw) { fallback = true; break; }                        // (cannot happen: the first pit always commits)
+        for (size_t s = (size_t)nw; s < pending.size(); s++) win.push_back(pending[s]);   // the part of the window that sat this round out
         pending.swap(win);
     }
     if (rounds_out) *rounds_out = rounds;
     if (getenv("PYDEM_PATHS_DEBUG"))
-        fprintf(stderr, "pit drain paths: %lld pits, %lld rounds, %lld large-window simulations%s\n", (long long)npits, (long long)rounds,
-                (long long)big_runs, fallback ? " -> host loop" : "");
+        fprintf(stderr, "pit drain paths: %lld pits, %lld rounds, %lld small-window and %lld large-window simulations; ms: small %.1f, large %.1f, "
+                        "commit %.1f%s\n", (long long)npits, (long long)rounds, (long long)small_runs, (long long)big_runs, ms_small, ms_big, ms_commit,
+                fallback ? " -> host loop" : "");
     if (fallback) {
         HIP_TRY(hipMemcpyAsync(t->elev, b_backup.p, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
