@@ -138,6 +138,11 @@ int pydem_pit_paths(pydem_tile *t, const int32_t *order, int64_t npits, int max_
 int pydem_slopes_directions(pydem_tile *t);
 int pydem_find_flats(pydem_tile *t);
 int pydem_uca(pydem_tile *t, pydem_options *opt);
+/* the flow graph of pydem_uca (section / proportion / adjacency / pit edges, dem_processing.py:1021-1382) for a tile whose
+ * elevation, slope, aspect and flats were uploaded instead of computed -- what the reference's edge worker rebuilds from
+ * its stores before every round (process_manager.py:227-240) and a resumed directory job needs once; it resets the tile's
+ * edge masks, so upload stored masks afterwards */
+int pydem_build_graph(pydem_tile *t, pydem_options *opt);
 /* strips in the order left, right, top, bottom; left/right have n_rows entries, top/bottom
  * n_cols; data = neighbour uca (+uca_edges), done/todo = uint8 (process_manager.py:252-255) */
 int pydem_uca_edge_update(pydem_tile *t, pydem_options *opt,

@@ -74,6 +74,7 @@ SYMBOLS = {
     'pydem_slopes_directions': (C.c_int, [_P]),
     'pydem_find_flats': (C.c_int, [_P]),
     'pydem_uca': (C.c_int, [_P, C.POINTER(Options)]),
+    'pydem_build_graph': (C.c_int, [_P, C.POINTER(Options)]),
     'pydem_uca_edge_update': (C.c_int, [_P, C.POINTER(Options), _PP, _PP, _PP]),
     'pydem_uca_edge_round_inc': (C.c_int, [_P, C.POINTER(Options), _PP, _PP, _PP]),
     'pydem_uca_edge_round_inc_dev': (C.c_int, [_P, C.POINTER(Options)]),
@@ -163,7 +164,8 @@ class Tile(object):
 
     def upload(self, field, arr):
         arr = np.ascontiguousarray(arr)
-        assert arr.shape == self.shape, (arr.shape, self.shape)
+        if arr.shape != self.shape:
+            raise ValueError("field %d: array of shape %r uploaded to a tile of shape %r" % (field, arr.shape, self.shape))
         if FIELD_DTYPE[field] != np.float64:
             arr = np.ascontiguousarray(arr.astype(FIELD_DTYPE[field], copy=False))
             dt = _DTYPES[arr.dtype]
@@ -236,6 +238,9 @@ class Tile(object):
 
     def uca(self, opt):
         check(self.lib.pydem_uca(self._h, C.byref(opt)))
+
+    def build_graph(self, opt):
+        check(self.lib.pydem_build_graph(self._h, C.byref(opt)))
 
     def uca_edge_update(self, opt, data, done, todo, incremental=False):
         """data/done/todo: sequences (left, right, top, bottom) of 1-D arrays.  incremental: pydem_uca_edge_round_inc."""

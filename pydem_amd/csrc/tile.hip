@@ -496,6 +496,30 @@ int pydem_uca(pydem_tile *t, pydem_options *opt)
     return 0;
 }
 
+// a tile rebuilt from stored elev / aspect / slope (process_manager.calc_uca_ec :227-240, or a resumed directory job):
+// the flow graph is built once, the first time an edge round needs it
+static int ensure_graph(pydem_tile *t, pydem_options *opt, const char *who)
+{
+    if (t->graph_valid) return 0;
+    PYDEM_TRY(need(t, PYDEM_ELEV, who));
+    PYDEM_TRY(need(t, PYDEM_MAG, who));
+    PYDEM_TRY(need(t, PYDEM_DIRECTION, who));
+    if (!t->spacing_set) { pydem_set_error("%s: call pydem_tile_set_spacing first", who); return -3; }
+    PYDEM_TRY(ensure_fields(t, {PYDEM_SECTION, PYDEM_PROPORTION}));
+    PYDEM_TRY(stage_section_graph(t, opt));
+    t->graph_valid = true;
+    t->have[PYDEM_SECTION] = t->have[PYDEM_PROPORTION] = true;
+    return 0;
+}
+
+int pydem_build_graph(pydem_tile *t, pydem_options *opt)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    PYDEM_TRY(need(t, PYDEM_FLATS, "pydem_build_graph"));
+    PYDEM_TRY(ensure_fields(t, {PYDEM_EDGE_TODO, PYDEM_EDGE_DONE}));
+    return ensure_graph(t, opt, "pydem_build_graph");
+}
+
 int pydem_uca_edge_update(pydem_tile *t, pydem_options *opt, const double *const data[4],
                           const uint8_t *const done[4], const uint8_t *const todo[4])
 {
@@ -503,17 +527,7 @@ int pydem_uca_edge_update(pydem_tile *t, pydem_options *opt, const double *const
     PYDEM_TRY(need(t, PYDEM_UCA, "pydem_uca_edge_update"));
     PYDEM_TRY(need(t, PYDEM_FLATS, "pydem_uca_edge_update"));
     PYDEM_TRY(ensure_fields(t, {PYDEM_EDGE_TODO, PYDEM_EDGE_DONE}));
-    if (!t->graph_valid) {
-        // a tile rebuilt from stored elev/aspect/slope (process_manager.calc_uca_ec :227-240): build the graph once
-        PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_uca_edge_update"));
-        PYDEM_TRY(need(t, PYDEM_MAG, "pydem_uca_edge_update"));
-        PYDEM_TRY(need(t, PYDEM_DIRECTION, "pydem_uca_edge_update"));
-        if (!t->spacing_set) { pydem_set_error("pydem_uca_edge_update: call pydem_tile_set_spacing first"); return -3; }
-        PYDEM_TRY(ensure_fields(t, {PYDEM_SECTION, PYDEM_PROPORTION}));
-        PYDEM_TRY(stage_section_graph(t, opt));
-        t->graph_valid = true;
-        t->have[PYDEM_SECTION] = t->have[PYDEM_PROPORTION] = true;
-    }
+    PYDEM_TRY(ensure_graph(t, opt, "pydem_uca_edge_update"));
     PYDEM_TRY(stage_edge_update(t, opt, data, done, todo));
     t->have[PYDEM_EDGE_TODO] = t->have[PYDEM_EDGE_DONE] = true;
     return 0;
@@ -527,7 +541,7 @@ int pydem_uca_edge_round_inc(pydem_tile *t, pydem_options *opt, const double *co
     PYDEM_TRY(need(t, PYDEM_FLATS, "pydem_uca_edge_round_inc"));
     PYDEM_TRY(need(t, PYDEM_EDGE_TODO, "pydem_uca_edge_round_inc"));
     PYDEM_TRY(need(t, PYDEM_EDGE_DONE, "pydem_uca_edge_round_inc"));
-    if (!t->graph_valid) { pydem_set_error("pydem_uca_edge_round_inc: the flow graph of pydem_uca is not resident"); return -3; }
+    PYDEM_TRY(ensure_graph(t, opt, "pydem_uca_edge_round_inc"));
     PYDEM_TRY(stage_edge_round_inc(t, opt, data, done, todo));
     return 0;
 }
@@ -539,7 +553,7 @@ int pydem_uca_edge_round_inc_dev(pydem_tile *t, pydem_options *opt)
     PYDEM_TRY(need(t, PYDEM_FLATS, "pydem_uca_edge_round_inc_dev"));
     PYDEM_TRY(need(t, PYDEM_EDGE_TODO, "pydem_uca_edge_round_inc_dev"));
     PYDEM_TRY(need(t, PYDEM_EDGE_DONE, "pydem_uca_edge_round_inc_dev"));
-    if (!t->graph_valid) { pydem_set_error("pydem_uca_edge_round_inc_dev: the flow graph of pydem_uca is not resident"); return -3; }
+    PYDEM_TRY(ensure_graph(t, opt, "pydem_uca_edge_round_inc_dev"));
     if (!t->s_data || !t->s_flags) { pydem_set_error("pydem_uca_edge_round_inc_dev: no strips (pydem_board_set_desc + pydem_board_eval first)"); return -3; }
     PYDEM_TRY(stage_edge_round_inc(t, opt, nullptr, nullptr, nullptr));
     return 0;

@@ -425,6 +425,16 @@ class DEMProcessor(object):
         # pits that found a drain are patched into mag/flats by the graph stage (reference :1369-1371)
         self._produced('section', 'proportion', 'uca', 'edge_todo', 'edge_done', 'mag', 'flats')
 
+    def build_graph(self):
+        """The flow graph for a tile whose slope / aspect were set instead of computed (a resumed directory job): built now,
+        before stored edge masks are uploaded (the graph stage resets them)."""
+        self._ensure_tile()
+        if not self._has('flats'):
+            self.find_flats()
+        self._push('elev', 'mag', 'direction', 'flats')
+        self._tile.build_graph(self._options())
+        self._produced('mag', 'flats', 'section', 'proportion')
+
     def restore_pit_slopes(self):
         """mag = -1 again at the pits drained by calc_uca (what the reference's slope *store* holds in
         the directory flow, process_manager.py:192-194)."""
@@ -459,7 +469,7 @@ class DEMProcessor(object):
         self._ensure_tile()
         if not self._has('flats'):
             self.find_flats()
-        if not (uca_resident and 'uca' in self._on_device):
+        if not (uca_resident and self._has('uca')):                           # (a resumed tile holds its own uca on the host)
             self.uca = np.asarray(uca_init).astype('float64')                 # :744
         self._push('elev', 'mag', 'direction', 'flats', 'uca')
         opt = self._options()

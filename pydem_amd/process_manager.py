@@ -135,8 +135,10 @@ class ProcessManager(object):
         self.transport = None
         self.max_edge_rounds = 10000
         self.keep_first_pass_uca = True    # keep 'uca' (first pass) and 'uca_edges' separately like the reference's store
-        self.tiles_in_flight = 1           # tiles of this process worked on at once in the per-tile phases (threads; the
-                                           # library is re-entrant per tile handle, every tile has its own HIP stream)
+        self.checkpoint = False            # write every phase's per-tile results to `out_path` (out_format 'npy') and resume from them
+        self.tiles_in_flight = None        # tiles of this process worked on at once in the per-tile phases (threads; the
+                                           # library is re-entrant per tile handle, every tile has its own HIP stream).
+                                           # None: one per GPU this process drives (1 for CPU-side processors)
         for k, v in kwargs.items():
             if k == 'dem_proc_kwargs':
                 bad = [kk for kk in v if kk not in DEM_PROC_KWARGS]
@@ -177,109 +179,98 @@ class ProcessManager(object):
         return index
 
     def compute_grid(self):
-        """Place every tile on a (row, col) grid keyed by its rounded top latitude / left longitude and
-        lay the tiles side by side in one big index space (reference :517-565)."""
-        lats = np.round(self.index[:, self._i('top')], self.grid_round_decimals)
-        lons = np.round(self.index[:, self._i('left')], self.grid_round_decimals)
-        ulats = np.sort(np.unique(lats))[::-1].tolist()
-        ulons = np.sort(np.unique(lons)).tolist()
-        grid_shape = (len(ulats), len(ulons))
-        grid_id = np.zeros((self.n_inputs, 3), dtype=int)
-        grid_id2i = -np.ones(grid_shape, dtype=int)
-        lat_size = -np.ones(len(ulats), dtype=int)
-        lon_size = -np.ones(len(ulons), dtype=int)
-        for i in range(self.n_inputs):
-            r, c = ulats.index(lats[i]), ulons.index(lons[i])
-            grid_id[i] = [r, c, c + r * grid_shape[1]]
-            grid_id2i[r, c] = i
-            nrows, ncols = int(self.index[i, self._i('nrows')]), int(self.index[i, self._i('ncols')])
-            if lat_size[r] < 0:
-                lat_size[r] = nrows
-            elif lat_size[r] != nrows:
-                raise AssertionError("tiles of grid row %d differ in height" % r)
-            if lon_size[c] < 0:
-                lon_size[c] = ncols
-            elif lon_size[c] != ncols:
-                raise AssertionError("tiles of grid column %d differ in width" % c)
-        lat_cum = np.concatenate([[0], lat_size.cumsum().astype(int)])
-        lon_cum = np.concatenate([[0], lon_size.cumsum().astype(int)])
-        self.grid_slice = [(slice(int(lat_cum[r]), int(lat_cum[r + 1])), slice(int(lon_cum[c]), int(lon_cum[c + 1])))
-                           for r, c, _ in grid_id]
-        self.grid_id, self.grid_id2i, self.grid_shape = grid_id, grid_id2i, grid_shape
-        self.grid_lat_size, self.grid_lon_size = lat_size, lon_size
-        self._lat_cum, self._lon_cum = lat_cum, lon_cum
-        self.grid_size_tot = [int(lat_size.sum()), int(lon_size.sum())]
-        self.grid_chunk = [int(lat_size.min()), int(lon_size.min())]
+        """Tile -> (row, col) of a grid keyed by rounded top latitude / left longitude, and the side-by-side index space in
+        which every grid row / column is as high / wide as its tiles (reference :517-565).  Whole-mosaic array
+        expressions; the results are pinned against the reference's own bookkeeping (tests/test_process_manager_grid.py)."""
+        I = self._i
+        tops = np.round(self.index[:, I('top')], self.grid_round_decimals)
+        lefts = np.round(self.index[:, I('left')], self.grid_round_decimals)
+        ulat, row = np.unique(-tops, return_inverse=True)          # north first
+        ulon, col = np.unique(lefts, return_inverse=True)
+        n_rows, n_cols = ulat.size, ulon.size
+        ids = np.arange(self.n_inputs)
+        self.grid_shape = (n_rows, n_cols)
+        self.grid_id = np.stack([row, col, col + row * n_cols], axis=1).astype(int)
+        self.grid_id2i = -np.ones(self.grid_shape, dtype=int)
+        self.grid_id2i[row, col] = ids
+        heights = self.index[:, I('nrows')].astype(int)
+        widths = self.index[:, I('ncols')].astype(int)
+
+        def per_line(line, extent, count, what):
+            lo = np.full(count, np.iinfo(int).max); hi = np.zeros(count, int)
+            np.minimum.at(lo, line, extent); np.maximum.at(hi, line, extent)
+            if np.any(lo != hi):
+                raise AssertionError("tiles of grid %s %d differ in %s" % (what, int(np.nonzero(lo != hi)[0][0]), 'height' if what == 'row' else 'width'))
+            return hi
+        self.grid_lat_size = per_line(row, heights, n_rows, 'row')
+        self.grid_lon_size = per_line(col, widths, n_cols, 'column')
+        self._lat_cum = np.concatenate([[0], np.cumsum(self.grid_lat_size)]).astype(int)
+        self._lon_cum = np.concatenate([[0], np.cumsum(self.grid_lon_size)]).astype(int)
+        self.grid_slice = [(slice(int(self._lat_cum[r]), int(self._lat_cum[r + 1])), slice(int(self._lon_cum[c]), int(self._lon_cum[c + 1])))
+                           for r, c in zip(row, col)]
+        self.grid_size_tot = [int(self.grid_lat_size.sum()), int(self.grid_lon_size.sum())]
+        self.grid_chunk = [int(self.grid_lat_size.min()), int(self.grid_lon_size.min())]
 
     @staticmethod
     def _calc_overlap(a, da, b, db, s, tie):
-        """Pixels of overlap with a neighbour, for the non-overlap slices (first value) and for locating
-        the neighbour's coincident edge line (second value; at least 1) -- reference :567-599."""
-        n_overlap_a = int(np.round(((b - a) / da + tie - 0.01) / 2))
-        n_overlap_b = max(int(np.round((b - a) / db)), 1)
-        return n_overlap_a, n_overlap_b
+        """Pixels of overlap with a neighbour: for the non-overlap slices (first value) and for locating the neighbour's
+        coincident edge line (second value, at least 1) -- reference :567-599.  Works on arrays."""
+        gap = np.asarray(b, float) - np.asarray(a, float)
+        mine = np.round((gap / da + tie - 0.01) / 2).astype(int)
+        theirs = np.maximum(np.round(gap / db).astype(int), 1)
+        return mine, theirs
 
     def compute_grid_overlaps(self):
-        """Per tile: the slice that is uniquely its own, and where (in the side-by-side index space) the
-        neighbouring edge lines and corner pixels live (reference :601-740)."""
+        """Per tile: the part that is uniquely its own, and where (in the side-by-side index space) the neighbouring edge
+        lines and corner pixels live (reference :601-740).  One array expression per side for the whole mosaic."""
         I = self._i
+        idx = self.index
+        row, col = self.grid_id[:, 0], self.grid_id[:, 1]
+        n_rows, n_cols = self.grid_id2i.shape
+        padded = -np.ones((n_rows + 2, n_cols + 2), int)
+        padded[1:-1, 1:-1] = self.grid_id2i
+        west, east = padded[row + 1, col], padded[row + 1, col + 2]
+        north, south = padded[row, col + 1], padded[row + 2, col + 1]
+
+        def side(nb, a_col, a_from_nb, d_col, b_col, b_from_nb, tie):
+            """overlap with the neighbours `nb` (-1: none) along one axis; a / b pick the two coordinates to compare"""
+            has = nb >= 0
+            j = np.where(has, nb, 0)
+            a = np.where(a_from_nb, idx[j, I(a_col)], idx[:, I(a_col)])
+            b = np.where(b_from_nb, idx[j, I(b_col)], idx[:, I(b_col)])
+            mine, theirs = self._calc_overlap(a, idx[:, I(d_col)], b, idx[j, I(d_col)], 0, tie)
+            return np.where(has, mine, 0), np.where(has, theirs, 0)
+        yes, no = np.ones(self.n_inputs, bool), np.zeros(self.n_inputs, bool)
+        w_own, w_nb = side(west, 'left', no, 'dlon', 'right', yes, 0)
+        e_own, e_nb = side(east, 'left', yes, 'dlon', 'right', no, 1)
+        n_own, n_nb = side(north, 'top', no, 'dlat', 'bottom', yes, 0)
+        s_own, s_nb = side(south, 'top', yes, 'dlat', 'bottom', no, 1)
+        r0 = self._lat_cum[row]; r1 = self._lat_cum[row + 1]
+        c0 = self._lon_cum[col]; c1 = self._lon_cum[col + 1]
+        # corners exist wherever the grid continues in both directions, whether or not the diagonal tile does (:640-643)
+        has_w, has_e, has_n, has_s = col > 0, col < n_cols - 1, row > 0, row < n_rows - 1
         self.grid_slice_unique, self.edge_data = [], []
-        nr, nc = self.grid_id2i.shape
         for i in range(self.n_inputs):
-            r, c = self.grid_id[i, 0], self.grid_id[i, 1]
-            slc = self.grid_slice[i]
-            lon_start = lon_start_e = lon_end = lon_end_e = 0
-            lat_start = lat_start_e = lat_end = lat_end_e = 0
-            if c > 0 and self.grid_id2i[r, c - 1] >= 0:
-                nb = self.grid_id2i[r, c - 1]
-                lon_start, lon_start_e = self._calc_overlap(self.index[i, I('left')], self.index[i, I('dlon')],
-                                                            self.index[nb, I('right')], self.index[nb, I('dlon')], slc[1].start, 0)
-            if c < nc - 1 and self.grid_id2i[r, c + 1] >= 0:
-                nb = self.grid_id2i[r, c + 1]
-                lon_end, lon_end_e = self._calc_overlap(self.index[nb, I('left')], self.index[i, I('dlon')],
-                                                        self.index[i, I('right')], self.index[nb, I('dlon')], slc[1].start, 1)
-            if r > 0 and self.grid_id2i[r - 1, c] >= 0:
-                nb = self.grid_id2i[r - 1, c]
-                lat_start, lat_start_e = self._calc_overlap(self.index[i, I('top')], self.index[i, I('dlat')],
-                                                            self.index[nb, I('bottom')], self.index[nb, I('dlat')], slc[0].start, 0)
-            if r < nr - 1 and self.grid_id2i[r + 1, c] >= 0:
-                nb = self.grid_id2i[r + 1, c]
-                lat_end, lat_end_e = self._calc_overlap(self.index[nb, I('top')], self.index[i, I('dlat')],
-                                                        self.index[i, I('bottom')], self.index[nb, I('dlat')], slc[0].start, 1)
-            corner_tl = int(c > 0 and r > 0)
-            corner_bl = int(c > 0 and r < nr - 1)
-            corner_tr = int(c < nc - 1 and r > 0)
-            corner_br = int(c < nc - 1 and r < nr - 1)
-            self.grid_slice_unique.append((slice(slc[0].start + lat_start, slc[0].stop - lat_end),
-                                           slice(slc[1].start + lon_start, slc[1].stop - lon_end)))
-            self.edge_data.append({
-                'left': (slc[0], slc[1].start - lon_start_e),
-                'right': (slc[0], slc[1].stop + lon_end_e - 1),
-                'top': (slc[0].start - lat_start_e, slc[1]),
-                'top-left': (slc[0].start - lat_start_e * corner_tl, slc[1].start - lon_start_e * corner_tl),
-                'top-right': (slc[0].start - lat_start_e * corner_tr, slc[1].stop + lon_end_e * corner_tr - 1),
-                'bottom': (slc[0].stop + lat_end_e - 1, slc[1]),
-                'bottom-left': (slc[0].stop + lat_end_e * corner_bl - 1, slc[1].start - lon_start_e * corner_bl),
-                'bottom-right': (slc[0].stop + lat_end_e * corner_br - 1, slc[1].stop + lon_end_e * corner_br - 1),
-            })
-        # non-overlapping mosaic (reference :707-740)
-        def _min_unique(axis):
-            vals = []
-            for k in range(self.grid_id2i.shape[axis]):
-                col = self.grid_id2i[k, :] if axis == 0 else self.grid_id2i[:, k]
-                sizes = [self.grid_slice_unique[t][axis].stop - self.grid_slice_unique[t][axis].start for t in col if t >= 0]
-                vals.append(min(sizes))
-            return np.array(vals)
-        self.grid_lat_size_unique = _min_unique(0)
-        self.grid_lon_size_unique = _min_unique(1)
-        lat_cum = np.concatenate([[0], self.grid_lat_size_unique.cumsum().astype(int)])
-        lon_cum = np.concatenate([[0], self.grid_lon_size_unique.cumsum().astype(int)])
-        self.grid_slice_noverlap = []
-        for i in range(self.n_inputs):
-            r, c = self.grid_id[i, 0], self.grid_id[i, 1]
-            su = self.grid_slice_unique[i]
-            self.grid_slice_noverlap.append((slice(int(lat_cum[r]), int(lat_cum[r]) + su[0].stop - su[0].start),
-                                             slice(int(lon_cum[c]), int(lon_cum[c]) + su[1].stop - su[1].start)))
+            rows, cols = self.grid_slice[i]
+            self.grid_slice_unique.append((slice(int(r0[i] + n_own[i]), int(r1[i] - s_own[i])), slice(int(c0[i] + w_own[i]), int(c1[i] - e_own[i]))))
+            top_line, bottom_line = int(r0[i] - n_nb[i]), int(r1[i] + s_nb[i] - 1)
+            left_line, right_line = int(c0[i] - w_nb[i]), int(c1[i] + e_nb[i] - 1)
+            corner = lambda tb, lr: (int((r0[i] - n_nb[i] * (has_n[i] and (has_w[i] if lr == 'l' else has_e[i]))) if tb == 't'
+                                        else (r1[i] + s_nb[i] * (has_s[i] and (has_w[i] if lr == 'l' else has_e[i])) - 1)),
+                                     int((c0[i] - w_nb[i] * (has_w[i] and (has_n[i] if tb == 't' else has_s[i]))) if lr == 'l'
+                                        else (c1[i] + e_nb[i] * (has_e[i] and (has_n[i] if tb == 't' else has_s[i])) - 1)))
+            self.edge_data.append({'left': (rows, left_line), 'right': (rows, right_line), 'top': (top_line, cols), 'bottom': (bottom_line, cols),
+                                   'top-left': corner('t', 'l'), 'top-right': corner('t', 'r'),
+                                   'bottom-left': corner('b', 'l'), 'bottom-right': corner('b', 'r')})
+        # the mosaic without overlaps: every grid row / column as high / wide as the smallest unique part in it (:707-740)
+        uh = np.array([s[0].stop - s[0].start for s in self.grid_slice_unique])
+        uw = np.array([s[1].stop - s[1].start for s in self.grid_slice_unique])
+        self.grid_lat_size_unique = np.full(n_rows, np.iinfo(int).max); np.minimum.at(self.grid_lat_size_unique, row, uh)
+        self.grid_lon_size_unique = np.full(n_cols, np.iinfo(int).max); np.minimum.at(self.grid_lon_size_unique, col, uw)
+        lat_cum = np.concatenate([[0], np.cumsum(self.grid_lat_size_unique)]).astype(int)
+        lon_cum = np.concatenate([[0], np.cumsum(self.grid_lon_size_unique)]).astype(int)
+        self.grid_slice_noverlap = [(slice(int(lat_cum[r]), int(lat_cum[r] + h)), slice(int(lon_cum[c]), int(lon_cum[c] + w)))
+                                    for r, c, h, w in zip(row, col, uh, uw)]
         self.grid_size_tot_unique = [int(self.grid_lat_size_unique.sum()), int(self.grid_lon_size_unique.sum())]
 
     # ------------------------------------------------------------------ locating neighbour lines
@@ -320,6 +311,54 @@ class ProcessManager(object):
                min(max(e[1], out_slice[1].start), out_slice[1].stop - 1)]
         return any(abs(a - b) == 1 for a, b in zip(e_c, e))
 
+    # ------------------------------------------------------------------ on-disk tile store and resume
+    # The reference keeps every intermediate array in a zarr store under `out_path` together with a boolean table
+    # success[n_tiles, 4] (elevation, aspect / slope, uca, twi; :998-1007, :1027-1029, :1057-1058, :1316-1317); a phase skips
+    # the tiles whose flag is set, so a directory job that died continues where it stopped.  Tiles are resident here, so the
+    # store is optional (`checkpoint=True`): one `.npy` file per tile and field (the reference's field names) plus
+    # success.npy.  A resumed tile gets its stored fields back; the flow graph is rebuilt by the library the first time an
+    # edge round needs it (process_manager.calc_uca_ec does the same from the stored elev / aspect / slope, :227-240).
+    _SUCCESS_COLS = {'elev': 0, 'aspect_slope': 1, 'uca': 2, 'twi': 3}
+
+    def _store_fn(self, i, key):
+        return os.path.join(self.out_path, 'tile_%04d_%s.npy' % (i, key))
+
+    def _success(self):
+        if getattr(self, '_success_table', None) is None:
+            fn = os.path.join(self.out_path, 'success.npy')
+            if self.checkpoint and os.path.exists(fn):
+                tab = np.load(fn)
+                if tab.shape != (self.n_inputs, 4):
+                    raise ValueError("%s belongs to another mosaic" % fn)
+                self._success_table = tab.astype(bool)
+            else:
+                self._success_table = np.zeros((self.n_inputs, 4), bool)
+        return self._success_table
+
+    def _store(self, i, phase, fields):
+        """Write the fields of one finished tile, then its success flag."""
+        if not self.checkpoint:
+            return
+        if self.out_format != 'npy':
+            raise NotImplementedError("out_format %r (only 'npy' tile stores are written)" % (self.out_format,))
+        os.makedirs(self.out_path, exist_ok=True)
+        for key, arr in fields.items():
+            tmp = self._store_fn(i, key) + '.tmp.npy'
+            np.save(tmp, np.asarray(arr))
+            os.replace(tmp, self._store_fn(i, key))
+        if phase is not None:
+            tab = self._success()
+            tab[i, self._SUCCESS_COLS[phase]] = True
+            tmp = os.path.join(self.out_path, 'success.tmp.npy')
+            np.save(tmp, tab)
+            os.replace(tmp, os.path.join(self.out_path, 'success.npy'))
+
+    def _stored(self, i, phase):
+        return bool(self.checkpoint and self._success()[i, self._SUCCESS_COLS[phase]])
+
+    def _load(self, i, key):
+        return np.load(self._store_fn(i, key))
+
     # ------------------------------------------------------------------ phases
     def _device_of(self, i):
         if self.devices is None:
@@ -351,14 +390,18 @@ class ProcessManager(object):
                 kw['fill_flats'] = False
                 kw['drain_pits_path'] = False
             meta = self._tile_meta[i]
-            if meta.get('synth') is not None:
+            if self._stored(i, 'elev'):
+                dp = self._make_processor(i, elev=self._load(i, 'elev'), **kw)        # the conditioned surface of an earlier run
+            elif meta.get('synth') is not None:
                 dp = self.processor_cls.from_synthetic(meta['shape'], meta['synth'], device=self._device_of(i), **kw)
             else:
                 dp = self._make_processor(i, elev=meta['elev'], **kw)
-            if not self.elev_conditioned:
+            if not self.elev_conditioned and not self._stored(i, 'elev'):
                 dp.calc_fill_flats()
                 dp.calc_pit_drain_paths()
             self.tiles[i] = dp
+            if not self._stored(i, 'elev') and self.checkpoint:
+                self._store(i, 'elev', {'elev': np.asarray(dp.elev, float)})
         return [1] * self.n_inputs
 
     def _make_processor(self, i, **kw):
@@ -366,13 +409,21 @@ class ProcessManager(object):
             kw['device'] = self._device_of(i)
         return self.processor_cls(**kw)
 
+    def _in_flight(self):
+        """Worker threads for the per-tile phases: the configured number, or one per GPU that holds tiles of this process."""
+        if self.tiles_in_flight is not None:
+            return max(1, int(self.tiles_in_flight))
+        devs = set(getattr(self.tiles[i], '_device', None) for i in self._owned() if self.tiles[i] is not None)
+        devs.discard(None)
+        return max(1, len(devs))
+
     def _per_tile(self, fn):
         """Run fn(i) for every owned tile: one after the other, or `tiles_in_flight` at a time from worker threads
         (the reference's n_workers pool, :1214-1288, with threads instead of processes: ctypes releases the GIL for
         the duration of a library call, and the latency-bound tail of one tile's sweep overlaps the next tile's
         streaming kernels on the same GPU)."""
         owned = list(self._owned())
-        k = max(1, int(self.tiles_in_flight))
+        k = self._in_flight()
         if k == 1 or len(owned) < 2:
             for i in owned:
                 fn(i)
@@ -387,8 +438,16 @@ class ProcessManager(object):
 
         def one(i):
             dp = self.tiles[i]
-            dp.fill_flats = False                      # "assuming we already did this" (:78)
+            # "assuming we already did this" (:78) -- but the worker applies the caller's dem_proc_kwargs AFTER that line
+            # (kwargs.update(dp_kwargs), :79), so an explicit fill_flats=True conditions the stored surface once more
+            dp.fill_flats = bool(self.dem_proc_kwargs.get('fill_flats', False))
+            if self._stored(i, 'aspect_slope'):
+                dp.direction = self._load(i, 'aspect')
+                dp.mag = self._load(i, 'slope')
+                return
             getattr(dp, 'run_slopes_directions', dp.calc_slopes_directions)()
+            if self.checkpoint:
+                self._store(i, 'aspect_slope', {'aspect': dp.direction, 'slope': dp.mag})
         self._per_tile(one)
         return [1] * self.n_inputs
 
@@ -482,9 +541,23 @@ class ProcessManager(object):
         def one(i):
             dp = self.tiles[i]
             dp.find_flats()
+            self.uca0[i] = None
+            if self._stored(i, 'uca'):
+                # first-pass area and edge masks of an earlier run, plus whatever edge corrections it had reached
+                if hasattr(dp, 'build_graph'):
+                    dp.build_graph()
+                    dp.restore_pit_slopes()
+                first = self._load(i, 'uca')
+                dp.uca = first + self._load(i, 'uca_edges') if os.path.exists(self._store_fn(i, 'uca_edges')) else first
+                dp.edge_todo = self._load(i, 'edge_todo')
+                dp.edge_done = self._load(i, 'edge_done')
+                if self.keep_first_pass_uca:
+                    self.uca0[i] = first
+                return
             getattr(dp, 'run_uca', dp.calc_uca)()
             dp.restore_pit_slopes()        # the worker does not write its patched slope back (:192-194)
-            self.uca0[i] = None
+            if self.checkpoint:
+                self._store(i, 'uca', {'uca': dp.uca, 'edge_todo': dp.edge_todo, 'edge_done': dp.edge_done})
         self._per_tile(one)
         return [1] * self.n_inputs
 
@@ -794,7 +867,7 @@ class ProcessManager(object):
             for a in wave:
                 self._edge_last[a] = inputs[a][3]
             mine = [a for a in wave if self.transport.owns(a)]
-            k = max(1, int(self.tiles_in_flight))
+            k = self._in_flight()
             if k > 1 and len(mine) > 1:
                 # one process driving several GPUs (or several tiles of one GPU): the rounds of a wave from worker threads
                 from concurrent.futures import ThreadPoolExecutor
@@ -881,7 +954,7 @@ class ProcessManager(object):
             dp = self.tiles[i] if self.transport.owns(i) else None
             if dp is not None:
                 dp._ensure_tile()
-                dp._push('uca', 'edge_todo', 'edge_done', 'flats')
+                dp._push('elev', 'mag', 'direction', 'uca', 'edge_todo', 'edge_done', 'flats')
             board.set_desc(i, n, m, o28 + cd + cu, f8 + c1, dp._tile if dp is not None else None)
 
         for t in range(n_t):
@@ -958,7 +1031,7 @@ class ProcessManager(object):
                 dp = self.tiles[a]
                 if self.keep_first_pass_uca and self.uca0[a] is None:
                     self.uca0[a] = np.array(dp.uca)
-            k = max(1, int(self.tiles_in_flight))
+            k = self._in_flight()
 
             def one(a):
                 t0 = time.perf_counter()
@@ -1003,10 +1076,24 @@ class ProcessManager(object):
         self.process_uca()
         logger.info("Compute UCA Corrections")
         self.process_uca_edges()
+        if self.checkpoint:
+            for i in self._owned():              # the state of the fix-up (the reference's uca_edges / edge_* stores, :279-281)
+                if not self._stored(i, 'twi'):
+                    first = self._load(i, 'uca')
+                    self._store(i, None, {'uca_edges': self.tiles[i].uca - first, 'edge_todo': self.tiles[i].edge_todo,
+                                          'edge_done': self.tiles[i].edge_done})
         for i in self._owned():
             dp = self.tiles[i]
+            if self._stored(i, 'twi'):
+                dp.twi = self._load(i, 'twi')
+                continue
             dp.find_flats()               # the reference's calc_twi worker rebuilds flats from slope == -1 (:310)
+            # ... on a fresh DEMProcessor (:296-307): twi_min_area is the caller's value (default inf), not the smallest
+            # cell area calc_uca found on this tile -- it matters for apply_twi_limits / apply_twi_limits_on_uca
+            dp.twi_min_area = self.dem_proc_kwargs.get('twi_min_area', np.inf)
             getattr(dp, 'run_twi', dp.calc_twi)()
+            if self.checkpoint:
+                self._store(i, 'twi', {'twi': dp.twi})
         return [1] * self.n_inputs
 
     # ------------------------------------------------------------------ results

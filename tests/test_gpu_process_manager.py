@@ -142,3 +142,34 @@ def test_pool_mode_device_matches_oracle_backed_flow(name, tmp_path):
         finite = np.isfinite(a) & np.isfinite(b)
         assert np.array_equal(np.isnan(a), np.isnan(b)), key
         assert np.allclose(a[finite], b[finite], rtol=1e-9, atol=1e-12), key
+
+
+@pytest.mark.parametrize('stop_after,n_workers', [(1, 1), (2, 1), (2, 8), (3, 8)])
+def test_resume_from_tile_store_on_device(stop_after, n_workers, tmp_path):
+    """`checkpoint=True`: a directory job that stopped after a phase continues from the `.npy` tile store (the reference's
+    `success` table, process_manager.py:998-1007 ...) -- resumed tiles get their fields uploaded, the flow graph is rebuilt on
+    the device before the first edge round -- and ends with the results of an uninterrupted run."""
+    from test_process_manager_grid import write_tiles
+    from pydem_amd import process_manager
+    g = load_golden('pm_fractal_2x3_ov1')
+    src = str(tmp_path / 'tiles')
+    write_tiles(g, src, key='elev')
+    phases = ['process_elevation', 'process_aspect_slope', 'process_uca', 'process_uca_edges']
+    process_manager.DEBUG = True
+    try:
+        mk = lambda out, **kw: process_manager.ProcessManager(in_path=src, out_path=out, elev_conditioned=True,
+                                                              dem_proc_kwargs={'drain_pits': True}, n_workers=n_workers, **kw)
+        ref = mk(str(tmp_path / 'plain'))
+        ref.process_twi()
+        want = ref.save_non_overlap_data()
+        first = mk(str(tmp_path / 'store'), checkpoint=True)
+        first.compute_grid()
+        for name in phases[:stop_after + 1]:
+            getattr(first, name)()
+        again = mk(str(tmp_path / 'store'), checkpoint=True)
+        again.process_twi()
+        got = again.save_non_overlap_data()
+    finally:
+        process_manager.DEBUG = False
+    for key in want:
+        _close(got[key], want[key], key)
