@@ -250,12 +250,13 @@ int pydem_board_download(pydem_board *b, double *out);
  *       data = unmodified surface (float64, NaN = masked), built = copy of it that receives the new flats
  *   pydem_cond_pit_paths:     calc_pit_drain_paths (:428-548) for the pits in the given order, surface edited in place */
 int pydem_cond_pit_artifacts(const double *elev, int64_t n_rows, int64_t n_cols, const int32_t *lab, int32_t nlab,
-                             double max_area, uint8_t *raise);
+                             double max_area, int f32 /* the surface holds float32 values */, uint8_t *raise);
 int pydem_cond_fill_flats(const double *data, double *built, int64_t n_rows, int64_t n_cols, const int32_t *lab,
                           int32_t nlab, double source_tol, int peaks, int pits);
 int pydem_cond_pit_paths(double *elev, int64_t n_rows, int64_t n_cols, const int64_t *pits, int64_t npits,
                          const double *dX, int64_t n_dX, const double *dY, int max_iter, int max_dist,
-                         double max_dist_XY, int64_t *n_failed, int64_t *iter_used);
+                         double max_dist_XY, int dtype_mode /* 0 float64, 1 integer, 2 float32 surface (values as float64) */,
+                         int64_t *n_failed, int64_t *iter_used);
 
 #ifdef __cplusplus
 }

@@ -156,9 +156,9 @@ size_t centre_cell(const std::vector<uint8_t> &region, int64_t h, int64_t w)
 extern "C" {
 
 // calc_fill_pit_artifacts (:396-426) for the labelled candidate regions: raise[c] = 1 where the cell must be
-// lifted by one unit.  `elev` is the surface as float64 (exact for the integer inputs this step exists for).
+// lifted by one unit.  `elev` is the surface as float64 (exact for integer and float32 inputs; f32: it holds float32 values).
 int pydem_cond_pit_artifacts(const double *elev, int64_t n, int64_t m, const int32_t *lab, int32_t nlab, double max_area,
-                             uint8_t *raise)
+                             int f32, uint8_t *raise)
 {
     std::vector<Box> box;
     find_boxes(lab, n, m, nlab, box);
@@ -185,7 +185,10 @@ int pydem_cond_pit_artifacts(const double *elev, int64_t n, int64_t m, const int
         for (int64_t i = 0; i < h && ok; i++)
             for (int64_t j = 0; j < w; j++) {
                 const size_t c = (size_t)(i * w + j);
-                if (grown[c] && !body[c] && !(elev[(R0 + i) * m + C0 + j] - 1 == level)) { ok = false; break; }
+                if (!grown[c] || body[c]) continue;
+                const double v = elev[(R0 + i) * m + C0 + j];
+                // (`rim - 1` is computed in the array's dtype: a float32 surface rounds it to float32, :424)
+                if (!(f32 ? ((float)v - 1.0f == (float)level) : (v - 1 == level))) { ok = false; break; }
             }
         if (!ok) continue;
         for (int64_t i = 0; i < h; i++)
@@ -290,8 +293,12 @@ int pydem_cond_fill_flats(const double *data, double *built, int64_t n, int64_t 
 // calc_pit_drain_paths (:428-548): pits in the given order (the caller's numpy argsort), the surface `e` is
 // edited in place and sequentially, later pits see earlier paths.
 int pydem_cond_pit_paths(double *e, int64_t n, int64_t m, const int64_t *pits, int64_t npits, const double *dX, int64_t ndX,
-                         const double *dY, int max_iter, int max_dist, double max_dist_XY, int64_t *n_failed, int64_t *iter_used)
+                         const double *dY, int max_iter, int max_dist, double max_dist_XY, int dtype_mode, int64_t *n_failed,
+                         int64_t *iter_used)
 {
+    // dtype_mode: the reference edits the array in ITS dtype (:535-539).  0: float64.  1: an integer surface -- the path
+    // values are truncated towards zero when they are stored.  2: a float32 surface -- the drop is a float32 difference and
+    // the stored values round to float32.  `e` holds the values as float64 in every mode.
     const int64_t NN = n * m;
     std::vector<int32_t> stamp((size_t)NN, -1);      // 2*p: in area of pit p, 2*p+1: on its rim
     std::vector<int64_t> rim, trail, fresh, chain, outlet, keep;
@@ -392,12 +399,16 @@ int pydem_cond_pit_paths(double *e, int64_t n, int64_t m, const int64_t *pits, i
             for (int64_t t : chain) if (e[t] > e[end] && e[t] < mn) mn = e[t];
             e[pit] = mn;
         }
-        const double drop = e[end] - e[pit], base = e[pit];
+        const double base = e[pit];
+        const double drop = dtype_mode == 2 ? (double)((float)e[end] - (float)base) : e[end] - base;
         const int64_t L = (int64_t)chain.size();
         const double step = 1.0 / (double)(L - 1);                             // np.linspace(0, 1, L): arange * step, last = 1
         for (int64_t t = 0; t < L; t++) {
             const double f = (t == L - 1) ? 1.0 : (double)t * step;
-            e[chain[(size_t)t]] = base + f * drop;
+            double v = base + f * drop;
+            if (dtype_mode == 1) v = trunc(v);
+            else if (dtype_mode == 2) v = (double)(float)v;
+            e[chain[(size_t)t]] = v;
         }
     }
     *n_failed = failed;

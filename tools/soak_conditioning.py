@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised CPU soak of the conditioning step: the native per-region / per-pit loops (libpydem_hip.so, host code)
-against the numpy restatements they were written from (pydem_amd/conditioning.py:*_numpy, themselves pinned by the
+against the numpy restatements they were written from (tests/conditioning_numpy.py, themselves pinned by the
 reference goldens g7_*): random int16 / float tiles with plateaus, sea, nodata and random options; exact equality.
 soak_conditioning.py [seconds] [first_case]"""
 import os
@@ -11,7 +11,9 @@ import warnings
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 from pydem_amd import conditioning as C, synth   # noqa: E402
+import conditioning_numpy as CN                  # noqa: E402
 
 
 def make_case(k):
@@ -52,15 +54,15 @@ def main():
         rec, z, opt, popt = make_case(k)
         k += 1
         a = C.fill_pit_artifacts(z.copy(), opt['maximum_pit_area'], opt['fill_flats_below_sea'])
-        b = C.fill_pit_artifacts_numpy(z.copy(), opt['maximum_pit_area'], opt['fill_flats_below_sea'])
+        b = CN.fill_pit_artifacts(z.copy(), opt['maximum_pit_area'], opt['fill_flats_below_sea'])
         if not same(np.asarray(a), np.asarray(b)):
             print('MISMATCH fill_pit_artifacts', rec); sys.exit(1)
-        a = C.fill_flats(z.copy(), **opt); b = C.fill_flats_numpy(z.copy(), **opt)
+        a = C.fill_flats(z.copy(), **opt); b = CN.fill_flats(z.copy(), **opt)
         if not same(a, b):
             print('MISMATCH fill_flats', rec, int((a != b).sum())); sys.exit(1)
         n = z.shape[0]
         dX, dY = 30.0 * np.ones(n - 1), 25.0 + 0.01 * np.arange(n - 1)
-        pa = C.pit_drain_paths(a.copy(), dX, dY, **popt); pb = C.pit_drain_paths_numpy(b.copy(), dX, dY, **popt)
+        pa = C.pit_drain_paths(a.copy(), dX, dY, **popt); pb = CN.pit_drain_paths(b.copy(), dX, dY, **popt)
         if not same(pa[0], pb[0]) or pa[1:] != tuple(pb[1:]):
             print('MISMATCH pit_drain_paths', rec, pa[1:], pb[1:]); sys.exit(1)
         done += 1
