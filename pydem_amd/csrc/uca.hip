@@ -1979,7 +1979,7 @@ __global__ __launch_bounds__(1024) void k_cinc_small(CIncArgs E, QE *q0, QE *q1,
                 QE e; e.c = t; e.cw = ct;
                 const int32_t slot = agg_slot(cn);
                 if (slot < SMALL_CAP) ln[slot] = e;
-                qn[slot] = e;
+                else qn[slot] = e;                           // beyond the LDS queue: straight to the global one
             };
             cinc_cell(E, s_q[r % 2][k], push);
         }
@@ -1989,6 +1989,11 @@ __global__ __launch_bounds__(1024) void k_cinc_small(CIncArgs E, QE *q0, QE *q1,
 #ifdef PYDEM_EINC_PROF
         prof_t[cls] += wall_clock64() - t0; prof_n[cls]++;
 #endif
+    }
+    if (nq > SMALL_CAP && r > r_start) {
+        // the frontier outgrew the workgroup: the level kernels take over from the global queue, whose head is still in LDS
+        QE *qg = (r % 2) ? q1 : q0;
+        for (int32_t k = threadIdx.x; k < SMALL_CAP; k += blockDim.x) qg[k] = s_q[r % 2][k];
     }
     if (threadIdx.x == 0) {
         cnt3[r % 3] = nq; cnt3[(r + 1) % 3] = 0; cnt3[(r + 2) % 3] = 0;
@@ -2526,7 +2531,9 @@ static int cinc_cascade(pydem_tile *t, const CIncArgs &E, int *levels)
     QE *q0 = (QE *)t->queue[0], *q1 = (QE *)t->queue[1];
     int r = 0;
     for (;;) {
-        hipLaunchKernelGGL(k_cinc_small, dim3(1), dim3(1024), 0, t->stream, E, q0, q1, cnt3, r, state);
+        static int cinc_block = -1;
+        if (cinc_block < 0) { const char *e = getenv("PYDEM_EINC_BLOCK"); cinc_block = e ? atoi(e) : 1024; }
+        hipLaunchKernelGGL(k_cinc_small, dim3(1), dim3(cinc_block), 0, t->stream, E, q0, q1, cnt3, r, state);
         // (the usual case: the frontier stayed small and the cascade is over -- the records go to the tile right away,
         // ONE host synchronisation per round; cells finished so far are applied either way)
         hipLaunchKernelGGL(k_cinc_apply, dim3(grid_for(E.nd, 1024)), dim3(256), 0, t->stream, E);
