@@ -70,6 +70,7 @@ struct pydem_tile {
     double *row_area = nullptr;                                            // [n] dX2*dY2
     std::vector<double> h_dX, h_dY, h_dX2, h_dY2;
     bool spacing_set = false;
+    int stencil_exact_only = 0;    // a spacing outside [2^-500, 2^500] (or PYDEM_STENCIL_EXACT=1): the marching stencil keeps to its exact path
     bool elev_f32 = false;          // the resident elevation was uploaded as float32: differences are float32 subtractions (stencil, pit drops)
     // graph / sweep scratch
     uint8_t *inmask = nullptr, *gflags = nullptr, *todo_work = nullptr;   // inmask/gflags: unused since the cinfo word

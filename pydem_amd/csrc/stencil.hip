@@ -260,12 +260,261 @@ __device__ __forceinline__ double lane_next(double x)    // value held by lane+1
 
 constexpr int MARCH_ROWS = 128;   // output rows per wavefront on large tiles (fewer on small ones: the chip wants >= ~10 k wavefronts)
 
+// ---- lane masks.  A comparison lands in an SGPR pair; everything that is only boolean algebra on comparison results
+// (the I1..I4 logic of _calc_direction, :1973-1989, and the "same test seen from the neighbouring column" shifts) is
+// done on those pairs by the scalar unit, which runs beside the vector pipeline this kernel is bound by.
+typedef uint64_t lmask;
+#define LM(cond) __builtin_amdgcn_ballot_w64(cond)
+#define ON(mask) __builtin_amdgcn_inverse_ballot_w64(mask)
+__device__ __forceinline__ lmask from_left(lmask x) { return x << 1; }    // the test lane-1 (column j-1) made
+__device__ __forceinline__ lmask from_right(lmask x) { return x >> 1; }   // the test lane+1 (column j+1) made
+
+// v_max_f64 without the canonicalising self-maximum the compiler puts in front of fmax() operands it cannot prove quiet
+// (no NaN reaches this: the window test below sends rows with NaN / huge elevations down the exact path)
+__device__ __forceinline__ double vmax(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a candidate that is not in play: high dword replaced by that of -1.0, so it is <= -1.0 and loses every maximum against
+// the -1.0 start value (one v_cndmask instead of a 64-bit select)
+__device__ __forceinline__ double only_if(lmask keep, double x, int dead_hi)
+{
+    const int hi = ON(keep) ? __double2hiint(x) : dead_hi;
+    return __hiloint2double(hi, __double2loint(x));
+}
+__device__ __forceinline__ double pick(lmask m, double a, double b) { return ON(m) ? a : b; }
+
+// IEEE division u = a / b for the arctangent's reduced argument, 0 <= a, 0 < b with b within a factor 2 of the larger
+// slope: reciprocal seed + two Newton steps + Markstein's residual correction (correctly rounded like `/`; without the
+// exponent rescue of the generic expansion, which slopes cannot need: |slope| in [2^-500, 2^500] by the window test)
+__device__ __forceinline__ double div_pos(double a, double b)
+{
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    const double q = a * y;
+    const double rem = __builtin_fma(-q, b, a);
+    return __builtin_fma(rem, y, q);
+}
+
+__device__ __forceinline__ double atan2_pos_fast(double y, double x, const double *atan_16)
+{
+    const bool swap = y > x;
+    const double num = swap ? x : y, den = swap ? y : x;
+    const double kf = rint(num * __builtin_amdgcn_rcp(den) * 16.0);
+    const double c = kf * 0.0625;
+    const double u = div_pos(__builtin_fma(-c, den, num), __builtin_fma(c, num, den));
+    const double w = u * u;
+    double p = __builtin_fma(w, -1.0 / 11, 1.0 / 9);
+    p = __builtin_fma(w, p, -1.0 / 7);
+    p = __builtin_fma(w, p, 1.0 / 5);
+    p = __builtin_fma(w, p, -1.0 / 3);
+    p = __builtin_fma(w * u, p, u);
+    const double a = atan_16[(int)kf] + p;
+    return swap ? PI_D / 2 - a : a;
+}
+
+// The marching kernel works band by band: the band between rows b and b+1 (spacing row b) holds every quotient that
+// the four south facets (4-7) of the cells of row b and the four north facets (0-3) of the cells of row b+1 need --
+// the E-edges of both rows over dX[b], the vertical edges, the two diagonals (_get_d1_d2 :1912-1924 gives facets 0-3 the
+// spacing row above the cell and 4-7 the one below).  Per band and lane (= column j): 5 quotients of its own (the fifth
+// is the E-edge of row b+1 over dX[b+1], kept for the next band), 8 lane shifts, 10 sign tests, 11 squares, 7 cross
+// products.  After that no facet needs arithmetic on slopes: each is in one of four states (none / cardinal / diagonal
+// / interior, :1973-1984) decided by mask algebra; the squared magnitude of a half (north or south) is a maximum over 9
+// ready-made numbers (4 interior sums, 3 distinct cardinal squares, 2 distinct diagonal squares) and "the first facet
+// that reaches the maximum" (:1986-1989, strict >) is 9 equality tests plus mask algebra.  A cell's north half (computed
+// in the band above it) is carried to the next iteration as (maximum, slopes of an interior winner, four masks); the
+// north half wins ties against the south half (facets 0-3 come first).
+// Names: hs1 / hn = E-edge quotient of row b / b+1 over dX[b]; v = vertical edge b -> b+1; se / sw = diagonals from
+// (b, j) to (b+1, j+-1); suffix L / R = the copy of the lane to the left / right.
+
+// what a band hands to the next one: its bottom row (the next top row) with the E-edge over the next spacing, and the
+// north half of the cells of that row
+struct BandCarry {
+    double z0;                 // elevations of the top row
+    double hs1, hsL1;          // E-edge of the top row over the band's dX, own and left neighbour's
+    lmask Phs1, Nhs1;          // hs1 > 0, hs1 < 0
+    double Mn, wn1, wn2;       // north half: squared magnitude, slopes of an interior winner ((1, 0) otherwise)
+    lmask Nk0, Nk1, NdA, NdB;  // north winner: bits of its facet number; diagonal with table angle thA / thB
+    double thAn, thBn;         // those angles (spacing row above)
+    bool ex_top;               // NaN / huge elevations in the top row
+};
+struct MarchCtx {
+    const double *col; const RowTab *rowtab; const double *rtv; const double *atan_16;
+    double *mag, *dir; uint8_t *flat0;
+    int n, m, j, i0, exact_only; bool writes;
+};
+
+template <bool F32>
+__device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, RowTab &ts, const int b, const double zS, double &z_ahead)
+{
+    const int n = cx.n, m = cx.m;
+    const int dead_hi = __double2hiint(-1.0);
+    const double BIG = 0x1p500;
+    // software pipeline: the elevations of row b+2 and the spacing row b+1 are requested now and first touched in the
+    // next band / at the very end of this one, so neither wait is exposed (the caller alternates two registers for the
+    // row in flight: it is never copied before it has been used)
+    const RowTab tnx = cx.rowtab[(b + 1 <= n - 2) ? b + 1 : n - 2];
+    z_ahead = cx.col[(size_t)((b + 2 <= n - 1) ? b + 2 : n - 1) * m];
+    const double thAs = cx.rtv[(size_t)b * 8 + 3], thBs = cx.rtv[(size_t)b * 8 + 4];
+    const double z0 = c.z0, hs1 = c.hs1, hsL1 = c.hsL1;
+    const lmask Phs1 = c.Phs1, Nhs1 = c.Nhs1;
+    // ---- row b+1 enters
+    const bool ex_bot = LM(!(fabs(zS) < BIG)) != 0;
+    const bool exact = c.ex_top || ex_bot;
+    const double zES = lane_next(zS), zWS = lane_prev(zS);
+    const double dE = zsub<F32>(zS, zES);
+    const double hn = div_row(dE, ts.dX, ts.rdX);
+    const double v = div_row(zsub<F32>(z0, zS), ts.dY, ts.rdY);
+    const double se = div_row(zsub<F32>(z0, zES), ts.hyp, ts.rhyp);
+    const double sw = div_row(zsub<F32>(z0, zWS), ts.hyp, ts.rhyp);
+    const double hnL = lane_prev(hn), vL = lane_prev(v), vR = lane_next(v);
+    const double seL = lane_prev(se), swR = lane_next(sw);
+    const double q_v = v * v, q_vL = vL * vL, q_vR = vR * vR, q_hn = hn * hn, q_hnL = hnL * hnL, q_hs1 = hs1 * hs1, q_hsL1 = hsL1 * hsL1;
+    const double q_se = se * se, q_sw = sw * sw, q_seL = seL * seL, q_swR = swR * swR;
+    const double n0 = q_hn + q_vR, n1 = q_v + q_hs1, n2 = q_v + q_hsL1, n3 = q_hnL + q_vL;     // s1^2 + s2^2 of the facets below
+    const double n4 = q_hsL1 + q_vL, n5 = q_v + q_hnL, n6 = q_v + q_hn, n7 = q_hs1 + q_vR;
+    // facets: s1, s2, sd                                     4: s1 = -hsL1  s2 = vL    sd = sw
+    //   0: s1 = hn    s2 = -vR    sd = -swR                  5: s1 = v      s2 = -hnL  sd = sw
+    //   1: s1 = -v    s2 = hs1    sd = -swR                  6: s1 = v      s2 = hn    sd = se
+    //   2: s1 = -v    s2 = -hsL1  sd = -seL                  7: s1 = hs1    s2 = vR    sd = se
+    //   3: s1 = -hnL  s2 = -vL    sd = -seL      (0-3: cell (b+1, j), 4-7: cell (b, j))
+    // sign tests and cross products (r > theta as s2*d1 > s1*d2; d1, d2 = dX, dY for facets 0,3,4,7, dY, dX for the others);
+    // a test on a neighbour's quotient is that lane's own test, shifted
+    const lmask Pv = LM(v > 0), Nv = LM(v < 0), Phn = LM(hn > 0), Nhn = LM(hn < 0);
+    const double p_v = v * ts.dX, p_vL = vL * ts.dX, p_vR = vR * ts.dX, p_hn = hn * ts.dY, p_hnL = hnL * ts.dY;
+    const double p_hs = hs1 * ts.dY, p_hsL = hsL1 * ts.dY;
+#define STATES(k, ak, bk, gk, dk)                                                                         \
+    const lmask both##k = (ak) & (bk), g##k = gk;                                                          \
+    const lmask in##k = both##k & ~g##k;                               /* interior: r = atan2(s2, s1) */    \
+    const lmask dg##k = (both##k & g##k) | (~(ak) & (bk) & (dk));      /* I1: r = theta, mag = sd; I3: only when sd > 0 */ \
+    const lmask cd##k = (ak) & ~(bk);                                  /* I2: r = 0, mag = s1 */
+
+    // ================= south half of row b, then the whole cell =================
+    double M, w1, w2;
+    lmask tAn, tBn, tAs, tBs, k0, k1, k2, flat;
+    if (__builtin_expect(!exact, 1)) {
+        const lmask dSW = LM(sw > 0), dSE = LM(se > 0);
+        STATES(4, from_left(Nhs1), from_left(Pv), LM(p_vL > -p_hsL), dSW)
+        STATES(5, Pv, from_left(Nhn), LM(-p_hnL > p_v), dSW)
+        STATES(6, Pv, Phn, LM(p_hn > p_v), dSE)
+        STATES(7, Phs1, from_right(Pv), LM(p_vR > p_hs), dSE)
+        // candidates that are not in play are made negative in place; after that an equality with the maximum needs no
+        // second look at the state (a lane where nothing is in play may see a false match: it is `flat` and stores -1)
+        const double kn4 = only_if(in4, n4, dead_hi), kn5 = only_if(in5, n5, dead_hi), kn6 = only_if(in6, n6, dead_hi), kn7 = only_if(in7, n7, dead_hi);
+        const double kc4 = only_if(cd4, q_hsL1, dead_hi), kcS = only_if(cd5 | cd6, q_v, dead_hi), kc7 = only_if(cd7, q_hs1, dead_hi);
+        const double kdSW = only_if(dg4 | dg5, q_sw, dead_hi), kdSE = only_if(dg6 | dg7, q_se, dead_hi);
+        const double Ms = vmax(vmax(vmax(vmax(-1.0, kn4), vmax(kn5, kn6)), vmax(vmax(kn7, kc4), vmax(kcS, kc7))), vmax(kdSW, kdSE));
+        const lmask eSW = LM(kdSW == Ms), eSE = LM(kdSE == Ms), ecS = LM(kcS == Ms);
+        const lmask h4 = LM(kn4 == Ms) | LM(kc4 == Ms) | (dg4 & eSW);
+        const lmask h5 = LM(kn5 == Ms) | (cd5 & ecS) | (dg5 & eSW);
+        const lmask h6 = LM(kn6 == Ms) | (cd6 & ecS) | (dg6 & eSE);
+        const lmask h7 = LM(kn7 == Ms) | LM(kc7 == Ms) | (dg7 & eSE);
+        M = vmax(c.Mn, Ms);
+        const lmask north = LM(c.Mn >= Ms);                   // facets 0-3 come first: they keep a tie
+        flat = LM(M < 0);                                     // no facet descends: mag = -1 (:1983-1984)
+        const lmask s4 = h4 & ~north, s5 = h5 & ~(north | h4), s6 = h6 & ~(north | h4 | h5), s7 = h7 & ~(north | h4 | h5 | h6);
+        w1 = pick(north, c.wn1, 1.0);
+        w1 = pick(s4 & in4, hsL1, w1); w1 = pick((s5 & in5) | (s6 & in6), v, w1); w1 = pick(s7 & in7, hs1, w1);
+        w2 = pick(north, c.wn2, 0.0);
+        w2 = pick(s4 & in4, vL, w2); w2 = pick(s5 & in5, hnL, w2); w2 = pick(s6 & in6, hn, w2); w2 = pick(s7 & in7, vR, w2);
+        tAn = north & c.NdA; tBn = north & c.NdB; tAs = (s4 & dg4) | (s7 & dg7); tBs = (s5 & dg5) | (s6 & dg6);
+        k0 = (north & c.Nk0) | s5 | s7; k1 = (north & c.Nk1) | s6 | s7; k2 = s4 | s5 | s6 | s7;
+    } else {
+        // exact path (NaN or huge elevations in the band): every comparison is made on the slopes themselves, facet after
+        // facet in the reference's order, starting from the carried north half
+        const double s1_4 = -hsL1, s2_4 = vL, s1_5 = v, s2_5 = -hnL, s2_6 = hn, s1_7 = hs1, s2_7 = vR;
+        Acc acc; acc.rad2 = c.Mn; acc.code = -8;
+        facet_lean(s1_4, s2_4, sw, q_hsL1, q_vL, q_sw, ts.dX, ts.dY, 4, acc);
+        facet_lean(s1_5, s2_5, sw, q_v, q_hnL, q_sw, ts.dY, ts.dX, 5, acc);
+        facet_lean(s1_5, s2_6, se, q_v, q_hn, q_se, ts.dY, ts.dX, 6, acc);
+        facet_lean(s1_7, s2_7, se, q_hs1, q_vR, q_se, ts.dX, ts.dY, 7, acc);
+        M = acc.rad2;
+        flat = LM(acc.rad2 == -1.0);
+        const int k = acc.code >> 2, kind = acc.code & 3;
+        const bool south = acc.code >= 0, sin = south && kind == 3, sdg = south && kind == 2;
+        w1 = sin ? (k == 4 ? s1_4 : (k == 7 ? s1_7 : s1_5)) : (south ? 1.0 : c.wn1);
+        w2 = sin ? (k == 4 ? s2_4 : (k == 5 ? s2_5 : (k == 6 ? s2_6 : s2_7))) : (south ? 0.0 : c.wn2);
+        const lmask sm = LM(south);
+        tAn = ~sm & c.NdA; tBn = ~sm & c.NdB; tAs = LM(sdg && (k == 4 || k == 7)); tBs = LM(sdg && (k == 5 || k == 6));
+        k0 = (~sm & c.Nk0) | LM(south && (k & 1)); k1 = (~sm & c.Nk1) | LM(south && (k & 2)); k2 = sm;
+    }
+    if (cx.writes && b >= cx.i0) {
+        // direction of the winner: r * ang[1] + ang[0] * pi / 2 (:1989).  r = atan2(s2, s1) for an interior winner (both
+        // slopes positive there, so the un-negated quotients serve: |x|); every other lane runs the arctangent on (0, 1),
+        // which is exactly 0 -- the r of a cardinal winner -- and a diagonal winner takes its table angle
+        double r = atan2_pos_fast(fabs(w2), fabs(w1), cx.atan_16);
+        r = pick(tAn, c.thAn, r); r = pick(tBn, c.thBn, r); r = pick(tAs, thAs, r); r = pick(tBs, thBs, r);
+        const int k = (ON(k0) ? 1 : 0) | (ON(k1) ? 2 : 0) | (ON(k2) ? 4 : 0);
+        const double rs = __hiloint2double(__double2hiint(r) ^ (int)((unsigned)k << 31), __double2loint(r));   // ang[1] = -1 for odd facets
+        const double direction = rs + (double)((k + 1) >> 1) * (PI_D / 2);
+        const size_t cc = (size_t)b * m + cx.j;
+        cx.mag[cc] = M > 0 ? sqrt(M) : M;                              // :1901
+        cx.dir[cc] = pick(flat, -1.0, direction);
+        cx.flat0[cc] = ON(flat) ? 1 : 0;
+    }
+    // ================= north half of row b+1 =================
+    if (__builtin_expect(!exact, 1)) {
+        const lmask dNE = from_right(LM(sw < 0)), dNW = from_left(LM(se < 0));
+        STATES(0, Phn, from_right(Nv), LM(-p_vR > p_hn), dNE)
+        STATES(1, Nv, Phs1, LM(p_hs > -p_v), dNE)
+        STATES(2, Nv, from_left(Nhs1), LM(-p_hsL > -p_v), dNW)
+        STATES(3, from_left(Nhn), from_left(Nv), LM(-p_vL > -p_hnL), dNW)
+        const double kn0 = only_if(in0, n0, dead_hi), kn1 = only_if(in1, n1, dead_hi), kn2 = only_if(in2, n2, dead_hi), kn3 = only_if(in3, n3, dead_hi);
+        const double kc0 = only_if(cd0, q_hn, dead_hi), kcN = only_if(cd1 | cd2, q_v, dead_hi), kc3 = only_if(cd3, q_hnL, dead_hi);
+        const double kdNE = only_if(dg0 | dg1, q_swR, dead_hi), kdNW = only_if(dg2 | dg3, q_seL, dead_hi);
+        const double Mq = vmax(vmax(vmax(vmax(-1.0, kn0), vmax(kn1, kn2)), vmax(vmax(kn3, kc0), vmax(kcN, kc3))), vmax(kdNE, kdNW));
+        const lmask eNE = LM(kdNE == Mq), eNW = LM(kdNW == Mq), ecN = LM(kcN == Mq);
+        const lmask h0 = LM(kn0 == Mq) | LM(kc0 == Mq) | (dg0 & eNE);
+        const lmask h1 = LM(kn1 == Mq) | (cd1 & ecN) | (dg1 & eNE);
+        const lmask h2 = LM(kn2 == Mq) | (cd2 & ecN) | (dg2 & eNW);
+        const lmask h3 = LM(kn3 == Mq) | LM(kc3 == Mq) | (dg3 & eNW);
+        const lmask f0 = h0, f1 = h1 & ~h0, f2 = h2 & ~(h0 | h1), f3 = h3 & ~(h0 | h1 | h2);
+        c.Mn = Mq;
+        double t1 = pick(f0 & in0, hn, 1.0); t1 = pick((f1 & in1) | (f2 & in2), v, t1); t1 = pick(f3 & in3, hnL, t1);
+        double t2 = pick(f0 & in0, vR, 0.0); t2 = pick(f1 & in1, hs1, t2); t2 = pick(f2 & in2, hsL1, t2); t2 = pick(f3 & in3, vL, t2);
+        c.wn1 = t1; c.wn2 = t2;
+        c.Nk0 = f1 | f3; c.Nk1 = f2 | f3; c.NdA = (f0 & dg0) | (f3 & dg3); c.NdB = (f1 & dg1) | (f2 & dg2);
+    } else {
+        const double s1_0 = hn, s2_0 = -vR, s1_1 = -v, s2_1 = hs1, s2_2 = -hsL1, s1_3 = -hnL, s2_3 = -vL;
+        Acc an; an.rad2 = -1.0; an.code = -4;
+        facet_lean(s1_0, s2_0, -swR, q_hn, q_vR, q_swR, ts.dX, ts.dY, 0, an);
+        facet_lean(s1_1, s2_1, -swR, q_v, q_hs1, q_swR, ts.dY, ts.dX, 1, an);
+        facet_lean(s1_1, s2_2, -seL, q_v, q_hsL1, q_seL, ts.dY, ts.dX, 2, an);
+        facet_lean(s1_3, s2_3, -seL, q_hnL, q_vL, q_seL, ts.dX, ts.dY, 3, an);
+        const int k = an.code >> 2, kind = an.code & 3;       // k = -1, kind = 0: no north facet descends
+        const bool nin = kind == 3, ndg = kind == 2;
+        c.Mn = an.rad2;
+        c.wn1 = nin ? (k == 0 ? s1_0 : (k == 3 ? s1_3 : s1_1)) : 1.0;
+        c.wn2 = nin ? (k == 0 ? s2_0 : (k == 1 ? s2_1 : (k == 2 ? s2_2 : s2_3))) : 0.0;
+        c.Nk0 = LM(k >= 0 && (k & 1)); c.Nk1 = LM(k >= 0 && (k & 2));
+        c.NdA = LM(ndg && (k == 0 || k == 3)); c.NdB = LM(ndg && (k == 1 || k == 2));
+    }
+#undef STATES
+    // ---- the E-edge of row b+1 over its own south spacing opens the next band
+    const double hs = (b + 1 <= n - 2) ? div_row(dE, tnx.dX, tnx.rdX) : 0.0;
+    c.z0 = zS; c.ex_top = cx.exact_only || ex_bot;
+    c.hs1 = hs; c.hsL1 = lane_prev(hs); c.Phs1 = LM(hs > 0); c.Nhs1 = LM(hs < 0);
+    c.thAn = thAs; c.thBn = thBs;
+    ts = tnx;
+}
+
 template <bool F32>
 __global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict__ elev, int n, int m,
                                                        const RowTab *__restrict__ rowtab,
                                                        double *__restrict__ mag, double *__restrict__ dir,
-                                                       uint8_t *__restrict__ flat0, int strips, int chunks, int rows_per_wave)
+                                                       uint8_t *__restrict__ flat0, int strips, int chunks, int rows_per_wave,
+                                                       int exact_only)
 {
+    // the arctangent table sits in LDS: a global (vmcnt) load in the loop body would make every row wait for the
+    // stores of the row before it as well
+    __shared__ double s_atan[17];
+    if (threadIdx.x < 17) s_atan[threadIdx.x] = ATAN_16[threadIdx.x];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wavefront id (scalar: row tables via s_load)
     if (wid >= strips * chunks) return;
@@ -273,85 +522,31 @@ __global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict_
     const int j = strip * 62 + lane;                                // this lane's column (lane 0 / 63 = halo)
     const int i0 = 1 + chunk * rows_per_wave;                       // first output row
     const int i1 = (i0 + rows_per_wave < n - 1) ? i0 + rows_per_wave : n - 1;   // one past the last output row
-    const bool colok = j < m;
-    const int jc = colok ? j : m - 1;
-    const double *col = elev + jc;
+    int vzero;                                                      // a zero the compiler cannot see through: the per-row angles
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));                  // are fetched by a (broadcast) vector load straight into VGPRs
+    MarchCtx cx;
+    cx.col = elev + ((j < m) ? j : m - 1); cx.rowtab = rowtab; cx.rtv = reinterpret_cast<const double *>(rowtab) + vzero;
+    cx.atan_16 = s_atan; cx.mag = mag; cx.dir = dir; cx.flat0 = flat0;
+    cx.n = n; cx.m = m; cx.j = j; cx.i0 = i0; cx.exact_only = exact_only;
+    cx.writes = lane >= 1 && lane <= 62 && j >= 1 && j < m - 1;
 
-    // window rows i-1, i (already "entered"), then row i+1 enters at every step
-    double zN = col[(size_t)(i0 - 1) * m], z0 = col[(size_t)i0 * m];
-    // quantities of the rows already in the window, as if they had entered one by one
-    double zE0 = lane_next(z0), zW0 = lane_prev(z0);
-    const RowTab t0 = rowtab[i0 - 1];
-    double hEs_N = div_row(zsub<F32>(zN, lane_next(zN)), t0.dX, t0.rdX);   // E-edge of row i-1 over its south spacing dX[i-1]
-    double hEn_0 = div_row(zsub<F32>(z0, zE0), t0.dX, t0.rdX);             // E-edge of row i over its north spacing dX[i-1]
-    double v_N = div_row(zsub<F32>(zN, z0), t0.dY, t0.rdY);                // vertical edge (i-1) -> i
-    double dSE_N = div_row(zsub<F32>(zN, zE0), t0.hyp, t0.rhyp);           // diagonal (i-1,j) -> (i,j+1)
-    double dSW_N = div_row(zsub<F32>(zN, zW0), t0.hyp, t0.rhyp);           // diagonal (i-1,j) -> (i,j-1)
-    double hEs_0 = (i0 <= n - 2) ? div_row(zsub<F32>(z0, zE0), rowtab[i0].dX, rowtab[i0].rdX) : 0.0;   // E-edge of row i over its south spacing dX[i]
-    // neighbours' copies
-    double hEs_N_L = lane_prev(hEs_N), dSE_N_L = lane_prev(dSE_N), v_N_L = lane_prev(v_N), v_N_R = lane_next(v_N);
-    double dSW_N_R = lane_next(dSW_N), hEn_0_L = lane_prev(hEn_0), hEs_0_L = lane_prev(hEs_0);
-
-    for (int i = i0; i < i1; i++) {
-        const RowTab tn = rowtab[i - 1], ts = rowtab[i];
-        // ---- row i+1 enters
-        const double zS = col[(size_t)(i + 1) * m];
-        const double zES = lane_next(zS), zWS = lane_prev(zS);
-        const double hEn_S = div_row(zsub<F32>(zS, zES), ts.dX, ts.rdX);   // E-edge of row i+1 over its north spacing dX[i]
-        const double v_0 = div_row(zsub<F32>(z0, zS), ts.dY, ts.rdY);      // vertical edge i -> i+1
-        const double dSE_0 = div_row(zsub<F32>(z0, zES), ts.hyp, ts.rhyp);
-        const double dSW_0 = div_row(zsub<F32>(z0, zWS), ts.hyp, ts.rhyp);
-        const double hEs_S = (i + 1 <= n - 2) ? div_row(zsub<F32>(zS, zES), rowtab[i + 1].dX, rowtab[i + 1].rdX) : 0.0;
-        const double hEn_S_L = lane_prev(hEn_S), v_0_L = lane_prev(v_0), v_0_R = lane_next(v_0);
-        const double dSE_0_L = lane_prev(dSE_0), dSW_0_R = lane_next(dSW_0), hEs_S_L = lane_prev(hEs_S);
-        // ---- the 8 facets of cell (i, j)
-        Acc acc; acc.rad2 = -1.0; acc.code = -4;
-        const double sdNE = -dSW_N_R, sdNW = -dSE_N_L;
-        const double s1_0 = hEn_0, s2_0 = -v_N_R;          // s1=(z0-zE)/dXn  s2=(zE-zNE)/dYn
-        const double s1_1 = -v_N, s2_1 = hEs_N;            // s1=(z0-zN)/dYn  s2=(zN-zNE)/dXn
-        const double s2_2 = -hEs_N_L;                      //                 s2=(zN-zNW)/dXn
-        const double s1_3 = -hEn_0_L, s2_3 = -v_N_L;       // s1=(z0-zW)/dXn  s2=(zW-zNW)/dYn
-        const double s1_4 = -hEs_0_L, s2_4 = v_0_L;        // s1=(z0-zW)/dXs  s2=(zW-zSW)/dYs
-        const double s1_5 = v_0, s2_5 = -hEn_S_L;          // s1=(z0-zS)/dYs  s2=(zS-zSW)/dXs
-        const double s2_6 = hEn_S;                         //                 s2=(zS-zSE)/dXs
-        const double s1_7 = hEs_0, s2_7 = v_0_R;           // s1=(z0-zE)/dXs  s2=(zE-zSE)/dYs
-        // (x*x == (-x)*(-x): the squares are taken from the un-negated quotients)
-        const double qNE = dSW_N_R * dSW_N_R, qNW = dSE_N_L * dSE_N_L, qSW = dSW_0 * dSW_0, qSE = dSE_0 * dSE_0;
-        const double q1_1 = v_N * v_N, q1_5 = v_0 * v_0;
-        facet_lean(s1_0, s2_0, sdNE, hEn_0 * hEn_0, v_N_R * v_N_R, qNE, tn.dX, tn.dY, 0, acc);
-        facet_lean(s1_1, s2_1, sdNE, q1_1, hEs_N * hEs_N, qNE, tn.dY, tn.dX, 1, acc);
-        facet_lean(s1_1, s2_2, sdNW, q1_1, hEs_N_L * hEs_N_L, qNW, tn.dY, tn.dX, 2, acc);
-        facet_lean(s1_3, s2_3, sdNW, hEn_0_L * hEn_0_L, v_N_L * v_N_L, qNW, tn.dX, tn.dY, 3, acc);
-        facet_lean(s1_4, s2_4, dSW_0, hEs_0_L * hEs_0_L, v_0_L * v_0_L, qSW, ts.dX, ts.dY, 4, acc);
-        facet_lean(s1_5, s2_5, dSW_0, q1_5, hEn_S_L * hEn_S_L, qSW, ts.dY, ts.dX, 5, acc);
-        facet_lean(s1_5, s2_6, dSE_0, q1_5, hEn_S * hEn_S, qSE, ts.dY, ts.dX, 6, acc);
-        facet_lean(s1_7, s2_7, dSE_0, hEs_0 * hEs_0, v_0_R * v_0_R, qSE, ts.dX, ts.dY, 7, acc);
-        if (lane >= 1 && lane <= 62 && j >= 1 && j < m - 1) {
-            const int k = acc.code >> 2, kind = acc.code & 3;
-            // slopes / table angle of the winning facet
-            double w1 = s1_0, w2 = s2_0;
-            w1 = k == 1 ? s1_1 : w1; w2 = k == 1 ? s2_1 : w2;
-            w1 = k == 2 ? s1_1 : w1; w2 = k == 2 ? s2_2 : w2;
-            w1 = k == 3 ? s1_3 : w1; w2 = k == 3 ? s2_3 : w2;
-            w1 = k == 4 ? s1_4 : w1; w2 = k == 4 ? s2_4 : w2;
-            w1 = k == 5 ? s1_5 : w1; w2 = k == 5 ? s2_5 : w2;
-            w1 = k == 6 ? s1_5 : w1; w2 = k == 6 ? s2_6 : w2;
-            w1 = k == 7 ? s1_7 : w1; w2 = k == 7 ? s2_7 : w2;
-            const bool kindA = (k == 0) || (k == 3) || (k == 4) || (k == 7);
-            const double th = (k < 4) ? (kindA ? tn.thA : tn.thB) : (kindA ? ts.thA : ts.thB);
-            const size_t c = (size_t)i * m + j;
-            mag[c] = acc.rad2 > 0 ? sqrt(acc.rad2) : acc.rad2;         // :1901
-            dir[c] = direction_of(k, kind, w1, w2, th);
-            flat0[c] = (acc.rad2 == -1.0);
-        }
-        // ---- roll the window
-        zN = z0; z0 = zS;
-        hEs_N = hEs_0; hEs_N_L = hEs_0_L;
-        hEn_0 = hEn_S; hEn_0_L = hEn_S_L;
-        hEs_0 = hEs_S; hEs_0_L = hEs_S_L;
-        v_N = v_0; v_N_L = v_0_L; v_N_R = v_0_R;
-        dSE_N_L = dSE_0_L; dSW_N_R = dSW_0_R;
+    // ---- the top row of the first band (row i0-1: not an output row of this wavefront, its north half is never used)
+    BandCarry c;
+    RowTab ts = rowtab[i0 - 1];
+    c.z0 = cx.col[(size_t)(i0 - 1) * m];
+    c.ex_top = exact_only || LM(!(fabs(c.z0) < 0x1p500)) != 0;
+    c.hs1 = div_row(zsub<F32>(c.z0, lane_next(c.z0)), ts.dX, ts.rdX);
+    c.hsL1 = lane_prev(c.hs1);
+    c.Phs1 = LM(c.hs1 > 0); c.Nhs1 = LM(c.hs1 < 0);
+    c.Mn = -1.0; c.wn1 = 1.0; c.wn2 = 0.0; c.thAn = 0.0; c.thBn = 0.0;
+    c.Nk0 = 0; c.Nk1 = 0; c.NdA = 0; c.NdB = 0;
+    double zP = cx.col[(size_t)i0 * m], zQ = 0.0;                  // the bottom row of a band alternates between zP and zQ
+    int b = i0 - 1;
+    for (; b + 1 < i1; b += 2) {
+        march_band<F32>(cx, c, ts, b, zP, zQ);
+        march_band<F32>(cx, c, ts, b + 1, zQ, zP);
     }
+    if (b < i1) march_band<F32>(cx, c, ts, b, zP, zQ);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -483,12 +678,13 @@ static void launch_stencil(pydem_tile *t)
     while (rows > 16 && (int64_t)strips * cdiv(t->n - 2, rows) < 12288) rows >>= 1;
     const int chunks = (int)cdiv(t->n - 2, rows);
     const int waves = strips * chunks;
+    const int exact_only = t->stencil_exact_only;   // set with the row tables: a spacing outside [2^-500, 2^500] (or PYDEM_STENCIL_EXACT=1)
     if (t->elev_f32)
         hipLaunchKernelGGL(k_stencil_march<true>, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, t->stream, t->elev, (int)t->n, (int)t->m,
-                           t->rowtab, t->mag, t->dir, t->flat0, strips, chunks, rows);
+                           t->rowtab, t->mag, t->dir, t->flat0, strips, chunks, rows, exact_only);
     else
         hipLaunchKernelGGL(k_stencil_march<false>, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, t->stream, t->elev, (int)t->n, (int)t->m,
-                           t->rowtab, t->mag, t->dir, t->flat0, strips, chunks, rows);
+                           t->rowtab, t->mag, t->dir, t->flat0, strips, chunks, rows, exact_only);
 }
 
 int stage_stencil(pydem_tile *t)

@@ -203,6 +203,7 @@ int pydem_tile_set_spacing(pydem_tile *t, const double *dX, const double *dY, co
     t->h_dX.assign(dX, dX + n - 1); t->h_dY.assign(dY, dY + n - 1);
     t->h_dX2.assign(dX2, dX2 + n); t->h_dY2.assign(dY2, dY2 + n);
     std::vector<RowTab> tab((size_t)(n - 1));
+    int exotic = 0;
     for (int64_t r = 0; r < n - 1; r++) {
         RowTab &e = tab[(size_t)r];
         e.dX = dX[r]; e.dY = dY[r];
@@ -210,7 +211,12 @@ int pydem_tile_set_spacing(pydem_tile *t, const double *dX, const double *dY, co
         e.thA = atan2(dY[r], dX[r]);                    // np.arctan2(d2, d1), :1936 (host libm == numpy)
         e.thB = atan2(dX[r], dY[r]);
         e.rdX = 1.0 / e.dX; e.rdY = 1.0 / e.dY; e.rhyp = 1.0 / e.hyp;
+        // the stencil's mask path assumes that no slope quotient can overflow into a NaN: elevations are tested per row,
+        // the spacings here
+        if (!(e.dX > 0x1p-500 && e.dX < 0x1p500 && e.dY > 0x1p-500 && e.dY < 0x1p500 && e.hyp < 0x1p500)) exotic = 1;
     }
+    { const char *ev = getenv("PYDEM_STENCIL_EXACT"); if (ev && *ev == '1') exotic = 1; }
+    t->stencil_exact_only = exotic;
     // theta per row for section/proportion: facet-0 spacing of rows 1..n-2 with the first and last
     // entries duplicated (dem_processing.py:1031-1033)
     std::vector<double> st((size_t)n);
