@@ -930,6 +930,162 @@ __global__ __launch_bounds__(256, 6) void k_sweep_tiles_listed(SweepArgs A, uint
         sweep_one_tile<true>(A, L[wave], pass, tiles_x, __builtin_amdgcn_readfirstlane(list_in[k]), lane, tile_done, n_final, N);
 }
 
+// ------------------------------------------------------------------------------- K5a
+// The first pass over a tile is special: nothing is final yet, so a cell can only be finished if its whole upstream
+// closure lies inside the tile (and involves no pit edge).  Most cells are like that (~2/3 of a fractal tile), and for
+// them nothing but the area has to leave the CU before the visit ends: one WORKGROUP of four wavefronts owns the tile,
+// every thread OWNS 4 cells (row 8k + t / 32, column t % 32), and per cell LDS holds one word (graph bits + count-down of the open upstream
+// cells) and one 16-byte slot that carries the cell's proportion until the cell is finished and its two contributions
+// afterwards (20 KB per tile: eight tiles per CU).  A round: every thread reads the words of its own open cells,
+// finishes those whose count reached zero -- in-edge gather from LDS in the same ascending order
+// as process_cell(), arithmetic identical -- and counts its in-tile targets down with non-returning LDS atomics (the
+// owner sees the zero in the next round).  At the end the rows of the tile are written once, coalesced: contribution
+// 16 B + graph word 4 B per finished cell; the generic pass stored them in dependency order and paid ~47 B of write
+// traffic per finished cell for 28 (profiles/README.md).  Cells with pit edges, cells fed from another tile and
+// everything downstream of them are left to pass 2.
+constexpr uint32_t FC_COUNT = 0xFu, FC_BLOCKED = 1u << 8, FC_DONE = 1u << 9, FC_TODO = 1u << 10;   // low half of the cell word
+
+struct TileFirst {
+    double2 slot[TT * TT];      // .x = proportion while the cell is open; (share 1, share 2) once it is finished
+    uint32_t cs[TT * TT];       // high half: static graph bits, low half: FC_*
+    double a0[TT];
+};
+
+// workgroup barrier that orders LDS traffic only: the global stores of a round (areas, fire-and-forget) are not waited for
+__device__ __forceinline__ void lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__global__ __launch_bounds__(256) void k_sweep_first(SweepArgs A, int tiles_x, int tiles_total, uint8_t *__restrict__ tile_done,
+                                                     int32_t *n_final)
+{
+    __shared__ TileFirst L;
+    __shared__ int32_t s_fin[2], s_any[2];
+    const int t = threadIdx.x;
+    const int per = gridDim.x >> 3;                 // workgroup b runs on XCD b % 8: one contiguous band of tiles per XCD
+    const int tid = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tid >= tiles_total) return;
+    const int by = tid / tiles_x, bx = tid - by * tiles_x;
+    const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
+    const int r0 = t >> 5, l32 = t & 31;            // the thread's cell k: row 8k + r0, column l32 (idx = t + 256 k)
+    const int gj = j0 + l32;
+    constexpr int NSET = TT * TT / 256;
+    uint32_t ingrid = 0;                             // bit k: the thread's cell k exists
+    if (t < 2) { s_fin[t] = 0; s_any[t] = 0; }
+    {
+        // ---- stage: graph words and proportions of the thread's cells, all loads in flight at once
+        uint32_t cw[NSET];
+        double pv[NSET];
+#pragma unroll
+        for (int k = 0; k < NSET; k++) {
+            const int gi = i0 + 8 * k + r0;
+            const bool ok = gi < n && gj < m;
+            const int64_t c = (int64_t)gi * m + gj;
+            cw[k] = ok ? A.cinfo[c] : 0xFFFFFFFFu;
+            pv[k] = ok ? A.prop[c] : 0.0;
+        }
+        if (t < TT) L.a0[t] = (i0 + t < n) ? A.a0[i0 + t] : 0.0;
+        const uint32_t out_col = (l32 == 0 ? 0x29u : 0u) | (l32 == TT - 1 ? 0x94u : 0u);      // in-edges that would come from another tile
+        const bool edge_col = gj == 0 || gj == m - 1;
+#pragma unroll
+        for (int k = 0; k < NSET; k++) {
+            const int r = 8 * k + r0, gi = i0 + r;
+            const uint32_t w = cw[k];
+            uint32_t word = FC_BLOCKED;
+            if (w != 0xFFFFFFFFu) {
+                ingrid |= 1u << k;
+                const uint32_t outside = out_col | (r == 0 ? 0x07u : 0u) | (r == TT - 1 ? 0xE0u : 0u);
+                const bool blocked = ((w & 0xFFu & outside) != 0u) || (w & (CI_PIT_IN | CI_PIT_OUT));
+                word = ((w & CI_STATIC_MASK) << 16) | __popc(w & 0xFFu) | (blocked ? FC_BLOCKED : 0u);
+                if (!blocked && (edge_col || gi == 0 || gi == n - 1) && A.todo_work[(int64_t)gi * m + gj] != 0) word |= FC_TODO;   // inlet cells of the tile's edge
+            }
+            L.cs[t + 256 * k] = word;
+            L.slot[t + 256 * k].x = pv[k];
+        }
+    }
+    lds_sync();
+    int ph = 0;
+    // ---- rounds.  A thread that counts a target down to zero goes on with that target itself ("chain": a river is
+    // walked by one thread within one round instead of one cell per round); whatever else becomes ready waits for
+    // its owner's next look
+    for (;;) {
+        uint32_t ready = 0;
+#pragma unroll
+        for (int k = 0; k < NSET; k++)
+            if ((L.cs[t + 256 * k] & (FC_COUNT | FC_BLOCKED | FC_DONE)) == 0u) ready |= 1u << k;
+        if (ready) s_any[ph] = 1;
+        lds_sync();                                    // (also: every thread has read its words before anybody counts down)
+        const bool go = s_any[ph] != 0;
+        if (t == 0) s_any[ph ^ 1] = 0;
+        ph ^= 1;
+        if (!go) break;
+        while (ready) {
+            const int k = __ffs(ready) - 1; ready &= ready - 1u;
+            int cur = t + 256 * k;
+            do {
+                const int r = cur >> 5, cl = cur & 31;
+                const uint32_t word = L.cs[cur], w = word >> 16;
+                const double pv = L.slot[cur].x;
+                double a = L.a0[r];
+                bool td = (word & FC_TODO) != 0u;
+                uint32_t mm = w & 0xFFu;
+                while (mm) {                                        // ascending neighbour order, like the reference's pull
+                    const int d = __ffs(mm) - 1; mm &= mm - 1u;
+                    const int q = d + (d >> 2), di = (q * 11) >> 5;            // q = 0..8 with the centre skipped, di = q / 3
+                    const double2 u = L.slot[cur + (di - 1) * TT + (q - 3 * di - 1)];
+                    const double x = ((0x5A >> d) & 1) ? u.x : u.y;             // cardinal neighbours hand over their first share
+                    a += fabs(x); td = td || (x < 0);
+                }
+                double2 o = make_double2(0.0, 0.0);
+                if (w & CI_OUT1) o.x = a * pv;
+                if (w & CI_OUT2) o.y = a * (1 - pv);
+                if (td) { o.x = -o.x; o.y = -o.y; }
+                L.slot[cur] = o;
+                L.cs[cur] = word | FC_DONE | (td ? FC_TODO : 0u);
+                A.area[(int64_t)(i0 + r) * m + j0 + cl] = a;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");      // the shares are in place before a count can reach zero
+                const int sct = ci_section(w);
+                int next = -1;
+                if (w & CI_OUT1) {
+                    const int tr = r + fe1r(sct), tc = cl + fe1c(sct);
+                    if (tr >= 0 && tr < TT && tc >= 0 && tc < TT &&
+                        (atomicSub(&L.cs[tr * TT + tc], 1u) & (FC_COUNT | FC_BLOCKED)) == 1u) next = tr * TT + tc;
+                }
+                if (w & CI_OUT2) {
+                    const int tr = r + fe2r(sct), tc = cl + fe2c(sct);
+                    if (tr >= 0 && tr < TT && tc >= 0 && tc < TT &&
+                        (atomicSub(&L.cs[tr * TT + tc], 1u) & (FC_COUNT | FC_BLOCKED)) == 1u && next < 0) next = tr * TT + tc;
+                }
+                cur = next;
+            } while (cur >= 0);
+        }
+        lds_sync();
+    }
+    // ---- write the finished cells, row by row
+    uint32_t done = 0;
+#pragma unroll
+    for (int k = 0; k < NSET; k++) {
+        const uint32_t word = L.cs[t + 256 * k];
+        if (!(word & FC_DONE)) continue;
+        done |= 1u << k;
+        const int64_t c = (int64_t)(i0 + 8 * k + r0) * m + gj;
+        A.contrib[c] = L.slot[t + 256 * k];
+        A.cinfo[c] = ci_with_level(word >> 16, 1u);
+        if (word & FC_TODO) A.todo_work[c] = 1;
+    }
+    const int32_t finalized = __popc(done), n_cells = __popc(ingrid);
+    if (finalized) atomicAdd(&s_fin[0], finalized);
+    if (n_cells) atomicAdd(&s_fin[1], n_cells);
+    __syncthreads();
+    if (t == 0) {
+        if (s_fin[0]) atomicAdd(n_final, s_fin[0]);
+        if (s_fin[0] == s_fin[1]) tile_done[tid] = 1;
+    }
+}
+
 // switch from queue rounds to listed tile passes: the tiles that hold the current frontier
 __global__ void k_tiles_of_frontier(const QE *__restrict__ q, const int32_t *nq, int m, int tiles_x, int32_t stamp, TileNext N)
 {
@@ -2149,8 +2305,17 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     if (sweep_mode == 0) {
         // pass 1 over every tile, pass 2 over every tile that is not done (it also lists the tiles of pass 3),
         // then only the listed tiles until no tile is listed any more
-        TileNext N0; N0.flag = nullptr; N0.list = nullptr; N0.count = nullptr;
-        hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, 1u, tiles_x, tiles_total, tile_done, total, N0);
+        // PYDEM_SWEEP_FIRST=lds: pass 1 by the LDS-resident kernel (K5a).  Measured at 16384^2: 9.9 ms against 7.8 ms of the
+        // generic kernel (eight 20-KB tiles per CU instead of 32 bookkeeping-only ones: the dependency depth of a tile times
+        // the LDS latency per cell is not hidden any more), and pass 2 inherits the cells with pit edges -- not the default
+        static int first_kind = -1;
+        if (first_kind < 0) { const char *e = getenv("PYDEM_SWEEP_FIRST"); first_kind = (e && !strcmp(e, "lds")) ? 1 : 0; }
+        if (first_kind == 1)
+            hipLaunchKernelGGL(k_sweep_first, dim3((unsigned)(((tiles_total + 7) / 8) * 8)), dim3(256), 0, t->stream, A, tiles_x, tiles_total, tile_done, total);
+        else {
+            TileNext N0; N0.flag = nullptr; N0.list = nullptr; N0.count = nullptr;
+            hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, 1u, tiles_x, tiles_total, tile_done, total, N0);
+        }
         TileNext N; N.flag = tile_flag; N.list = tile_list[3 % 2]; N.count = &cntT[3 % 3];
         hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, 2u, tiles_x, tiles_total, tile_done, total, N);
         launches += 2;

@@ -198,3 +198,28 @@ def test_circular_drainage_replay_vs_oracle(loop):
     _close(uca, o.uca, 'uca')
     assert np.array_equal(dp.edge_todo, o.edge_todo)
     assert np.array_equal(dp.edge_done, o.edge_done)
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_stencil_mask_path_equals_exact_path(dtype, monkeypatch):
+    """The marching stencil decides the facet states by mask algebra when the band holds no NaN / huge elevation and
+    facet by facet on the slopes themselves otherwise (csrc/stencil.hip); PYDEM_STENCIL_EXACT=1 forces the latter for a
+    whole tile.  Both must give the same bits -- on terrain with plateaus, exact ties (integer heights) and a spacing
+    that changes from row to row."""
+    from pydem_amd import DEMProcessor
+    rng = np.random.default_rng(11)
+    n, m = 333, 517
+    z = np.cumsum(np.cumsum(rng.normal(size=(n, m)), 0), 1) * 0.05
+    z[40:90, 100:200] = np.round(z[40:90, 100:200])            # integer terraces: ties and flats
+    z[200:230, 300:360] = z[200, 300]                            # a plateau
+    z = z.astype(dtype)
+    dX = np.linspace(25.0, 35.0, n - 1); dY = np.full(n - 1, 30.0)
+    outs = []
+    for exact in ('0', '1'):
+        monkeypatch.setenv('PYDEM_STENCIL_EXACT', exact)
+        dp = DEMProcessor(elev=z.copy(), dX=dX, dY=dY, fill_flats=False, drain_pits_path=False)
+        mag, direction = dp.calc_slopes_directions()
+        outs.append((np.array(mag), np.array(direction)))
+    assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True), 'mag'
+    assert np.array_equal(outs[0][1], outs[1][1], equal_nan=True), 'direction'
+    assert (outs[0][0] == -1).any() and (outs[0][0] > 0).any()

@@ -1,5 +1,5 @@
-"""The alternative sweep schedule (frontier queue rounds + listed tile passes for the tail, PYDEM_SWEEP_MODE=queue) must
-give the same answers as the default tile-pass schedule.  The mode is read once per process, hence the subprocess."""
+"""The alternative sweep schedules (frontier queue rounds + listed tile passes for the tail, PYDEM_SWEEP_MODE=queue; the
+LDS-resident first pass, PYDEM_SWEEP_FIRST=lds) must give the same answers as the default tile-pass schedule.  The mode is read once per process, hence the subprocess."""
 import os
 import subprocess
 import sys
@@ -28,7 +28,8 @@ print("MODES-OK", dp.timings['sweep_rounds'], dp.timings['sweep_kernel_launches'
 
 
 @pytest.mark.parametrize('env', [{'PYDEM_SWEEP_MODE': 'queue'}, {'PYDEM_SWEEP_MODE': 'queue', 'PYDEM_SWEEP_TILE_SWITCH': '0'},
-                                 {'PYDEM_SWEEP_MODE': 'queue', 'PYDEM_TILE_PASSES': '3'}])
+                                 {'PYDEM_SWEEP_MODE': 'queue', 'PYDEM_TILE_PASSES': '3'},
+                                 {'PYDEM_SWEEP_FIRST': 'lds'}])          # pass 1 by the LDS-resident kernel (csrc/uca.hip K5a)
 def test_queue_schedule_matches_oracle(env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ); e.update(env)
