@@ -121,6 +121,27 @@ __global__ void k_region_init(Regions R, int32_t nreg, int n, int m)
     }
 }
 
+
+// ---- per-region accumulation.  A lake puts millions of consecutive list entries on one region record; 64 atomics of a
+// wavefront on the same address are 64 serial round trips.  When every entry of a wavefront belongs to the same region
+// (the loops below keep all 64 lanes in step, `valid` marks the entries past the end) the lanes combine first and lane 0
+// speaks for all; mixed wavefronts (the small regions) keep their per-lane atomics.
+__device__ __forceinline__ int wave_min(int v) { for (int o = 32; o; o >>= 1) { const int w = __shfl_xor(v, o); v = w < v ? w : v; } return v; }
+__device__ __forceinline__ int wave_max(int v) { for (int o = 32; o; o >>= 1) { const int w = __shfl_xor(v, o); v = w > v ? w : v; } return v; }
+__device__ __forceinline__ int wave_or(int v) { for (int o = 32; o; o >>= 1) v |= __shfl_xor(v, o); return v; }
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) { for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ __forceinline__ unsigned long long wave_min(unsigned long long v)
+{
+    for (int o = 32; o; o >>= 1) { const unsigned long long w = __shfl_xor(v, o); v = w < v ? w : v; }
+    return v;
+}
+// all valid entries of the wavefront carry region r0 (lane 0 is valid whenever any lane is: the entries are consecutive)
+__device__ __forceinline__ bool one_region(bool valid, int32_t r, int32_t &r0)
+{
+    r0 = __shfl(r, 0);
+    return __ballot(valid && r != r0) == 0ull;
+}
+
 // ---- quantisation artefacts (:396-426) ---------------------------------------------------------------------
 // a region is raised by one unit when it is small, lies strictly inside the array and its whole rim is exactly
 // one unit higher
@@ -128,24 +149,39 @@ __global__ void k_art_scan(CondArgs A, Regions R, double max_area)
 {
     const int32_t nf = *A.count;
     const int n = A.n, m = A.m;
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
-        const int32_t c = A.list[q];
-        const int32_t r = A.rid[A.labels[c]];
-        const int i = c / m, j = c - i * m;
-        atomicAdd(&R.size[r], 1);
-        bool bad = (i == 0 || j == 0 || i == n - 1 || j == m - 1);               // the one-pixel rim must lie inside (:414-415)
-        const double level = A.elev[c];
-        if (!bad) {
-            for (int d = 0; d < 9; d++) {
-                if (d == 4) continue;
-                const int32_t nb = c + (d / 3 - 1) * m + (d % 3 - 1);
-                if (A.mask[nb]) continue;                                         // same region
-                const double v = A.elev[nb];
-                const bool ok = A.f32 ? ((float)v - 1.0f == (float)level) : (v - 1 == level);    // :424
-                if (!ok) { bad = true; break; }
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x;; q += gridDim.x * blockDim.x) {
+        const bool valid = q < nf;
+        if (!__ballot(valid)) break;
+        int32_t r = -1;
+        bool bad = false;
+        if (valid) {
+            const int32_t c = A.list[q];
+            r = A.rid[A.labels[c]];
+            const int i = c / m, j = c - i * m;
+            bad = (i == 0 || j == 0 || i == n - 1 || j == m - 1);                 // the one-pixel rim must lie inside (:414-415)
+            const double level = A.elev[c];
+            if (!bad) {
+                for (int d = 0; d < 9; d++) {
+                    if (d == 4) continue;
+                    const int32_t nb = c + (d / 3 - 1) * m + (d % 3 - 1);
+                    if (A.mask[nb]) continue;                                     // same region
+                    const double v = A.elev[nb];
+                    const bool ok = A.f32 ? ((float)v - 1.0f == (float)level) : (v - 1 == level);    // :424
+                    if (!ok) { bad = true; break; }
+                }
             }
         }
-        if (bad) atomicOr(&R.flags[r], RF_BAD);
+        int32_t r0;
+        if (one_region(valid, r, r0)) {
+            const unsigned long long nv = __ballot(valid), nb = __ballot(valid && bad);
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&R.size[r0], (int32_t)__popcll(nv));
+                if (nb) atomicOr(&R.flags[r0], RF_BAD);
+            }
+        } else if (valid) {
+            atomicAdd(&R.size[r], 1);
+            if (bad) atomicOr(&R.flags[r], RF_BAD);
+        }
     }
 }
 
@@ -168,28 +204,55 @@ __global__ void k_flat_scan(CondArgs A, Regions R)
 {
     const int32_t nf = *A.count;
     const int n = A.n, m = A.m;
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
-        const int32_t c = A.list[q];
-        const int32_t r = A.rid[A.labels[c]];
-        const int i = c / m, j = c - i * m;
-        atomicAdd(&R.size[r], 1);
-        atomicMin(&R.i0[r], i); atomicMax(&R.i1[r], i); atomicMin(&R.j0[r], j); atomicMax(&R.j1[r], j);
-        if (i == 0 || j == 0 || i == n - 1 || j == m - 1) atomicAdd(&R.n_edge[r], 1);
-        atomicAdd(&R.sum_i[r], (unsigned long long)i);
-        atomicAdd(&R.sum_j[r], (unsigned long long)j);
-        const double level = A.elev[c];
-        int32_t fl = 0;
-        for (int d = 0; d < 9; d++) {
-            if (d == 4) continue;
-            const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
-            if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
-            const int32_t nb = ii * m + jj;
-            if (A.mask[nb]) continue;
-            const double v = A.elev[nb];
-            if (v == level) fl |= RF_DRAIN;                                      // :337
-            else if (v > level) { fl |= RF_SOURCE; atomicMin(&R.lowest_bits[r], dkey(v)); }   // :338, :344
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x;; q += gridDim.x * blockDim.x) {
+        const bool valid = q < nf;
+        if (!__ballot(valid)) break;
+        int32_t r = -1, fl = 0;
+        int i = 0, j = 0;
+        bool edge = false;
+        unsigned long long low = ~0ull;
+        if (valid) {
+            const int32_t c = A.list[q];
+            r = A.rid[A.labels[c]];
+            i = c / m; j = c - i * m;
+            edge = (i == 0 || j == 0 || i == n - 1 || j == m - 1);
+            const double level = A.elev[c];
+            for (int d = 0; d < 9; d++) {
+                if (d == 4) continue;
+                const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
+                if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+                const int32_t nb = ii * m + jj;
+                if (A.mask[nb]) continue;
+                const double v = A.elev[nb];
+                if (v == level) fl |= RF_DRAIN;                                  // :337
+                else if (v > level) { fl |= RF_SOURCE; const unsigned long long k = dkey(v); low = k < low ? k : low; }   // :338, :344
+            }
         }
-        if (fl) atomicOr(&R.flags[r], fl);
+        int32_t r0;
+        if (one_region(valid, r, r0)) {
+            const int cnt = (int)__popcll(__ballot(valid)), n_edge = (int)__popcll(__ballot(valid && edge));
+            const int i0 = wave_min(valid ? i : 0x7FFFFFFF), i1 = wave_max(valid ? i : -1);
+            const int j0 = wave_min(valid ? j : 0x7FFFFFFF), j1 = wave_max(valid ? j : -1);
+            const unsigned long long si = wave_sum(valid ? (unsigned long long)i : 0ull), sj = wave_sum(valid ? (unsigned long long)j : 0ull);
+            const unsigned long long lw = wave_min(low);
+            const int flw = wave_or(fl);
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&R.size[r0], cnt);
+                atomicMin(&R.i0[r0], i0); atomicMax(&R.i1[r0], i1); atomicMin(&R.j0[r0], j0); atomicMax(&R.j1[r0], j1);
+                if (n_edge) atomicAdd(&R.n_edge[r0], n_edge);
+                atomicAdd(&R.sum_i[r0], si); atomicAdd(&R.sum_j[r0], sj);
+                if (lw != ~0ull) atomicMin(&R.lowest_bits[r0], lw);
+                if (flw) atomicOr(&R.flags[r0], flw);
+            }
+        } else if (valid) {
+            atomicAdd(&R.size[r], 1);
+            atomicMin(&R.i0[r], i); atomicMax(&R.i1[r], i); atomicMin(&R.j0[r], j); atomicMax(&R.j1[r], j);
+            if (edge) atomicAdd(&R.n_edge[r], 1);
+            atomicAdd(&R.sum_i[r], (unsigned long long)i);
+            atomicAdd(&R.sum_j[r], (unsigned long long)j);
+            if (low != ~0ull) atomicMin(&R.lowest_bits[r], low);
+            if (fl) atomicOr(&R.flags[r], fl);
+        }
     }
 }
 
@@ -262,14 +325,33 @@ __global__ void k_centre_pass(CondArgs A, Regions R, int pass)
 {
     const int32_t nf = *A.count;
     const int n = A.n, m = A.m;
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
-        const int32_t c = A.list[q];
-        const int32_t r = A.rid[A.labels[c]];
-        if (!(R.flags[r] & RF_NEED_CENTRE)) continue;
-        const int i = c / m, j = c - i * m;
-        const unsigned long long k = dkey(centre_dist(R, r, i, j, n, m));
-        if (pass == 0) atomicMin(&R.cdist_bits[r], k);
-        else if (k == R.cdist_bits[r]) atomicMin(&R.centre[r], c);
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x;; q += gridDim.x * blockDim.x) {
+        const bool valid = q < nf;
+        if (!__ballot(valid)) break;
+        int32_t r = -1, c = 0x7FFFFFFF;
+        unsigned long long k = ~0ull;
+        bool want = false;
+        if (valid) {
+            c = A.list[q];
+            r = A.rid[A.labels[c]];
+            want = (R.flags[r] & RF_NEED_CENTRE) != 0;
+            if (want) { const int i = c / m, j = c - i * m; k = dkey(centre_dist(R, r, i, j, n, m)); }
+        }
+        if (!__ballot(want)) continue;
+        int32_t r0;
+        if (one_region(valid, r, r0)) {
+            if (pass == 0) {
+                const unsigned long long kw = wave_min(want ? k : ~0ull);
+                if ((threadIdx.x & 63) == 0) atomicMin(&R.cdist_bits[r0], kw);
+            } else {
+                const unsigned long long best = R.cdist_bits[r0];
+                const int cw = wave_min((want && k == best) ? c : 0x7FFFFFFF);
+                if ((threadIdx.x & 63) == 0 && cw != 0x7FFFFFFF) atomicMin(&R.centre[r0], cw);
+            }
+        } else if (want) {
+            if (pass == 0) atomicMin(&R.cdist_bits[r], k);
+            else if (k == R.cdist_bits[r]) atomicMin(&R.centre[r], c);
+        }
     }
 }
 
@@ -278,21 +360,39 @@ __global__ void k_flat_seed(CondArgs A, Regions R, double *dh, double *dl)
 {
     const int32_t nf = *A.count;
     const int n = A.n, m = A.m;
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
-        const int32_t c = A.list[q];
-        const int32_t r = A.rid[A.labels[c]];
-        const int32_t fl = R.flags[r];
-        const int i = c / m, j = c - i * m;
-        const bool on_edge = (i == 0 || j == 0 || i == n - 1 || j == m - 1);
-        const bool is_centre = R.centre[r] == c;
-        if ((fl & RF_SRC_CENTRE) && is_centre) A.built[c] = R.top[r];            // out[ci] = top, whatever follows (:351)
-        if (!(fl & RF_GENERAL)) continue;
-        const bool seed_hi = (fl & RF_SRC_CENTRE) && is_centre;
-        const bool seed_lo = ((fl & RF_DRN_EDGE) && on_edge) || ((fl & RF_DRN_CENTRE) && is_centre);
-        dh[c] = seed_hi ? 0.0 : INFINITY;
-        dl[c] = seed_lo ? 0.0 : INFINITY;
-        if (!seed_hi) atomicAdd(&R.rem_hi[r], 1);
-        if (!seed_lo) atomicAdd(&R.rem_lo[r], 1);
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x;; q += gridDim.x * blockDim.x) {
+        const bool valid = q < nf;
+        if (!__ballot(valid)) break;
+        int32_t r = -1;
+        bool wait_hi = false, wait_lo = false;
+        if (valid) {
+            const int32_t c = A.list[q];
+            r = A.rid[A.labels[c]];
+            const int32_t fl = R.flags[r];
+            const int i = c / m, j = c - i * m;
+            const bool on_edge = (i == 0 || j == 0 || i == n - 1 || j == m - 1);
+            const bool is_centre = R.centre[r] == c;
+            if ((fl & RF_SRC_CENTRE) && is_centre) A.built[c] = R.top[r];        // out[ci] = top, whatever follows (:351)
+            if (fl & RF_GENERAL) {
+                const bool seed_hi = (fl & RF_SRC_CENTRE) && is_centre;
+                const bool seed_lo = ((fl & RF_DRN_EDGE) && on_edge) || ((fl & RF_DRN_CENTRE) && is_centre);
+                dh[c] = seed_hi ? 0.0 : INFINITY;
+                dl[c] = seed_lo ? 0.0 : INFINITY;
+                wait_hi = !seed_hi; wait_lo = !seed_lo;
+            }
+        }
+        const unsigned long long bh = __ballot(wait_hi), bl = __ballot(wait_lo);
+        if (!(bh | bl)) continue;
+        int32_t r0;
+        if (one_region(valid, r, r0)) {
+            if ((threadIdx.x & 63) == 0) {
+                if (bh) atomicAdd(&R.rem_hi[r0], (int32_t)__popcll(bh));
+                if (bl) atomicAdd(&R.rem_lo[r0], (int32_t)__popcll(bl));
+            }
+        } else {
+            if (wait_hi) atomicAdd(&R.rem_hi[r], 1);
+            if (wait_lo) atomicAdd(&R.rem_lo[r], 1);
+        }
     }
 }
 
@@ -363,65 +463,104 @@ __global__ __launch_bounds__(256) void k_flat_sweep(CondArgs A, Regions R, const
 // sweeps, and a lake that takes 1500 sweeps to cross has millions of settled cells.  A cell is looked at in sweep s + 1
 // only if it or one of its region neighbours changed in sweep s (a cell that changed is listed itself, so that its new
 // value reaches the other buffer of the ping-pong pair); cells that are not listed have the same value in both buffers.
+__device__ __forceinline__ void flat_sweep_entry(const CondArgs &A, const Regions &R, int32_t c, int32_t *__restrict__ wl_out, int32_t *n_out,
+                                                 int32_t *stamp, const double *__restrict__ dh0, double *__restrict__ dh1,
+                                                 const double *__restrict__ dl0, double *__restrict__ dl1, int sweep, double source_tol)
+{
+    const int n = A.n, m = A.m;
+    const int32_t r = A.rid[A.labels[c]];
+    const int32_t fl = R.flags[r];
+    const bool act_hi = R.done_hi[r] >= sweep, act_lo = R.done_lo[r] >= sweep;
+    const double oh = dh0[c], ol = dl0[c];
+    double nh = oh, nl = ol;
+    const int i = c / m, j = c - i * m;
+    if (act_hi || act_lo) {
+        const double level = A.elev[c];
+        const double src_max = (fl & RF_SOURCE) ? dunkey(R.lowest_bits[r]) + source_tol : 0.0;   // lowest + tol (:347)
+        double card_h = oh, all_h = oh, card_l = ol, all_l = ol;
+        for (int d = 0; d < 9; d++) {
+            if (d == 4) continue;
+            const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
+            if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
+            const int32_t nb = ii * m + jj;
+            double vh, vl;
+            if (A.mask[nb]) { vh = dh0[nb]; vl = dl0[nb]; }
+            else {
+                const double z = A.elev[nb];
+                vh = ((fl & RF_SOURCE) && z > level && z <= src_max) ? 0.0 : INFINITY;
+                vl = ((fl & RF_DRAIN) && z == level) ? 0.0 : INFINITY;
+            }
+            const bool cardinal = (d == 1 || d == 3 || d == 5 || d == 7);
+            if (cardinal) { card_h = vh < card_h ? vh : card_h; card_l = vl < card_l ? vl : card_l; }
+            all_h = vh < all_h ? vh : all_h; all_l = vl < all_l ? vl : all_l;
+        }
+        if (act_hi) {
+            const double sv = card_h + 1, g = all_h + SQRT2;
+            const double best = sv < g ? sv : g;
+            nh = best < oh ? best : oh;
+            if (isinf(oh) && !isinf(nh) && atomicSub(&R.rem_hi[r], 1) == 1) R.done_hi[r] = sweep;
+        }
+        if (act_lo) {
+            const double sv = card_l + 1, g = all_l + SQRT2;
+            const double best = sv < g ? sv : g;
+            nl = best < ol ? best : ol;
+            if (isinf(ol) && !isinf(nl) && atomicSub(&R.rem_lo[r], 1) == 1) R.done_lo[r] = sweep;
+        }
+    }
+    dh1[c] = nh; dl1[c] = nl;
+    if (nh != oh || nl != ol) {
+        // the cell and its region neighbours are looked at in the next sweep: all nine stamps travel together
+        int32_t nbs[9];
+        bool take[9];
+#pragma unroll
+        for (int d = 0; d < 9; d++) {
+            const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
+            nbs[d] = ii * m + jj;
+            take[d] = ii >= 0 && ii < n && jj >= 0 && jj < m && A.mask[nbs[d]];
+        }
+#pragma unroll
+        for (int d = 0; d < 9; d++) take[d] = take[d] && atomicExch(&stamp[nbs[d]], sweep + 1) != sweep + 1;
+        int cnt = 0;
+#pragma unroll
+        for (int d = 0; d < 9; d++) cnt += take[d] ? 1 : 0;
+        if (cnt) {
+            int32_t at = atomicAdd(n_out, cnt);
+#pragma unroll
+            for (int d = 0; d < 9; d++) if (take[d]) wl_out[at++] = nbs[d];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_flat_sweep_wl(CondArgs A, Regions R, const int32_t *__restrict__ wl_in, int32_t *__restrict__ wl_out,
                                                        int32_t *cnt3, int32_t *stamp, const double *__restrict__ dh0, double *__restrict__ dh1,
                                                        const double *__restrict__ dl0, double *__restrict__ dl1, int sweep, double source_tol)
 {
-    const int n = A.n, m = A.m;
     const int32_t na = cnt3[sweep % 3];
     int32_t *n_out = &cnt3[(sweep + 1) % 3];
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt3[(sweep + 2) % 3] = 0;
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < na; q += gridDim.x * blockDim.x) {
-        const int32_t c = wl_in[q];
-        const int32_t r = A.rid[A.labels[c]];
-        const int32_t fl = R.flags[r];
-        const bool act_hi = R.done_hi[r] >= sweep, act_lo = R.done_lo[r] >= sweep;
-        const double oh = dh0[c], ol = dl0[c];
-        double nh = oh, nl = ol;
-        const int i = c / m, j = c - i * m;
-        if (act_hi || act_lo) {
-            const double level = A.elev[c];
-            const double src_max = (fl & RF_SOURCE) ? dunkey(R.lowest_bits[r]) + source_tol : 0.0;   // lowest + tol (:347)
-            double card_h = oh, all_h = oh, card_l = ol, all_l = ol;
-            for (int d = 0; d < 9; d++) {
-                if (d == 4) continue;
-                const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
-                if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
-                const int32_t nb = ii * m + jj;
-                double vh, vl;
-                if (A.mask[nb]) { vh = dh0[nb]; vl = dl0[nb]; }
-                else {
-                    const double z = A.elev[nb];
-                    vh = ((fl & RF_SOURCE) && z > level && z <= src_max) ? 0.0 : INFINITY;
-                    vl = ((fl & RF_DRAIN) && z == level) ? 0.0 : INFINITY;
-                }
-                const bool cardinal = (d == 1 || d == 3 || d == 5 || d == 7);
-                if (cardinal) { card_h = vh < card_h ? vh : card_h; card_l = vl < card_l ? vl : card_l; }
-                all_h = vh < all_h ? vh : all_h; all_l = vl < all_l ? vl : all_l;
-            }
-            if (act_hi) {
-                const double sv = card_h + 1, g = all_h + SQRT2;
-                const double best = sv < g ? sv : g;
-                nh = best < oh ? best : oh;
-                if (isinf(oh) && !isinf(nh) && atomicSub(&R.rem_hi[r], 1) == 1) R.done_hi[r] = sweep;
-            }
-            if (act_lo) {
-                const double sv = card_l + 1, g = all_l + SQRT2;
-                const double best = sv < g ? sv : g;
-                nl = best < ol ? best : ol;
-                if (isinf(ol) && !isinf(nl) && atomicSub(&R.rem_lo[r], 1) == 1) R.done_lo[r] = sweep;
-            }
-        }
-        dh1[c] = nh; dl1[c] = nl;
-        if (nh != oh || nl != ol) {
-            for (int d = 0; d < 9; d++) {
-                const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
-                if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
-                const int32_t nb = ii * m + jj;
-                if (!A.mask[nb]) continue;
-                if (atomicExch(&stamp[nb], sweep + 1) != sweep + 1) wl_out[atomicAdd(n_out, 1)] = nb;
-            }
-        }
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < na; q += gridDim.x * blockDim.x)
+        flat_sweep_entry(A, R, wl_in[q], wl_out, n_out, stamp, dh0, dh1, dl0, dl1, sweep, source_tol);
+}
+
+// The tail of the sweeps -- the front of first arrivals crossing a large lake, a few hundred cells per sweep for a
+// thousand sweeps and more -- is nothing but kernel boundaries when every sweep is a launch.  One workgroup runs
+// `nsweeps` sweeps in a row: the lists, distances and region records it touches were written by itself (visible
+// through the CU's L1 after a workgroup barrier); the list counters and stamps are only ever touched by atomics.
+__global__ __launch_bounds__(1024) void k_flat_sweep_small(CondArgs A, Regions R, int32_t *al0, int32_t *al1, int32_t *cnt3, int32_t *stamp,
+                                                           double *dhA, double *dhB, double *dlA, double *dlB, int sweep0, int nsweeps,
+                                                           double source_tol)
+{
+    for (int s = sweep0; s < sweep0 + nsweeps; s++) {
+        const int cur = (s - 1) & 1;
+        const int32_t *wl_in = cur ? al1 : al0;
+        int32_t *wl_out = cur ? al0 : al1;
+        const double *dh0 = cur ? dhB : dhA, *dl0 = cur ? dlB : dlA;
+        double *dh1 = cur ? dhA : dhB, *dl1 = cur ? dlA : dlB;
+        const int32_t na = __hip_atomic_load(&cnt3[s % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(&cnt3[(s + 2) % 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int32_t q = threadIdx.x; q < na; q += blockDim.x)
+            flat_sweep_entry(A, R, wl_in[q], wl_out, &cnt3[(s + 1) % 3], stamp, dh0, dh1, dl0, dl1, s, source_tol);
+        __syncthreads();
     }
 }
 
@@ -599,10 +738,22 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
         const int64_t sweep_cap = (int64_t)n * m + 2;
         int64_t cell_sweeps = 0;
         const int gw = grid_of(nf, 2048);
+        static int small_cap = -1;          // lists up to this length are swept by one workgroup, many sweeps per launch
+        if (small_cap < 0) { const char *e = getenv("PYDEM_FLAT_SMALL"); small_cap = e ? atoi(e) : 4096; }
         while (na > 0) {
-            for (int b = 0; b < 32; b++, sweep++, pp ^= 1, cur ^= 1)
-                hipLaunchKernelGGL(k_flat_sweep_wl, dim3(gw), dim3(256), 0, t->stream, A, R, al[cur], al[cur ^ 1], cnt + 4, stamp, dh[pp], dh[pp ^ 1],
-                                   dl[pp], dl[pp ^ 1], sweep, source_tol);
+            if (na <= small_cap) {
+                const int ns = 256;           // (an even number: the ping-pong parity below is that of `sweep`)
+                hipLaunchKernelGGL(k_flat_sweep_small, dim3(1), dim3(1024), 0, t->stream, A, R, al[0], al[1], cnt + 4, stamp, dh[0], dh[1], dl[0], dl[1],
+                                   sweep, ns, source_tol);
+                sweep += ns;
+            } else {
+                for (int b = 0; b < 32; b++, sweep++) {
+                    const int q = (sweep - 1) & 1;
+                    hipLaunchKernelGGL(k_flat_sweep_wl, dim3(gw), dim3(256), 0, t->stream, A, R, al[q], al[q ^ 1], cnt + 4, stamp, dh[q], dh[q ^ 1],
+                                       dl[q], dl[q ^ 1], sweep, source_tol);
+                }
+            }
+            pp = cur = (sweep - 1) & 1;
             HIP_TRY(hipMemcpyAsync(t->h_counters + 4, cnt + 4, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
             na = t->h_counters[4 + sweep % 3];
