@@ -223,3 +223,27 @@ def test_stencil_mask_path_equals_exact_path(dtype, monkeypatch):
     assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True), 'mag'
     assert np.array_equal(outs[0][1], outs[1][1], equal_nan=True), 'direction'
     assert (outs[0][0] == -1).any() and (outs[0][0] > 0).any()
+
+
+def test_config1_cone256_device_vs_reference_pinned_oracle():
+    """BASELINE.json config 1 on the device: the reference's 256 x 256 cone with default options (conditioning on).  The
+    oracle pipeline of tests/test_oracle_golden.py::test_config1_cone256_matches_reference_checksums is bit-identical to
+    the unmodified reference there; the device path must match it (masks exactly, float fields within RTOL)."""
+    import warnings
+    import conditioning_numpy as CN
+    from oracle import oracle as O
+    from pydem_amd import DEMProcessor
+    nn = 256
+    x, y = np.mgrid[-1:1:complex(0, nn), -1:1:complex(0, nn)]
+    elev = 1 - np.sqrt(y ** 2 + x ** 2) / np.sqrt(2.)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        filled = CN.fill_flats(elev)
+        drained, _, _ = CN.pit_drain_paths(np.array(filled), np.ones(nn - 1), np.ones(nn - 1))
+        o = O.OracleDEM(drained, dX=1.0, dY=1.0); twi_o = o.calc_twi()
+        dp = DEMProcessor(elev=elev.copy())
+        twi = dp.calc_twi()
+    assert np.array_equal(np.asarray(dp.elev), drained), 'conditioned surface'
+    assert np.array_equal(np.asarray(dp.flats, bool), np.asarray(o.flats, bool))
+    assert np.array_equal(dp.edge_todo, o.edge_todo) and np.array_equal(dp.edge_done, o.edge_done)
+    _close(dp.mag, o.mag, 'mag'); _close(dp.direction, o.direction, 'direction'); _close(dp.uca, o.uca, 'uca'); _close(twi, twi_o, 'twi')

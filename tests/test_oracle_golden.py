@@ -85,3 +85,34 @@ def test_synth_generators_agree():
     a = synth.fractal(33, 31, seed=1)
     b = O.synth_fractal(33, 31, seed=1)
     assert np.array_equal(a, b)
+
+
+def test_config1_cone256_matches_reference_checksums():
+    """BASELINE.json config 1: the reference's own 256 x 256 cone (pydem/utils_test_pydem.py case_cone :98-124) through
+    DEMProcessor.calc_twi() with default options.  The unmodified reference's arrays are pinned as sha256 of their bytes
+    (tests/golden/cone256_reference.json, written by oracle/ref_harness/gen_cone256_checksums.py); the conditioning twins
+    (tests/conditioning_numpy.py) + the oracle must reproduce every one of them bit for bit."""
+    import hashlib
+    import json
+    import os
+    import warnings
+    import conditioning_numpy as CN
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cone256_reference.json')))
+    sha = lambda a, dt: hashlib.sha256(np.ascontiguousarray(np.asarray(a), dt).tobytes()).hexdigest()
+    nn = 256
+    x, y = np.mgrid[-1:1:complex(0, nn), -1:1:complex(0, nn)]
+    elev = 1 - np.sqrt(y ** 2 + x ** 2) / np.sqrt(2.)
+    assert sha(elev, np.float64) == want['elev_sha256']
+    dX = np.ones(nn - 1); dY = np.ones(nn - 1)                     # the defaults of DEMProcessor(elev=array) (:244-254)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        filled = CN.fill_flats(elev)
+        drained, _, _ = CN.pit_drain_paths(np.array(filled), dX, dY)
+        o = O.OracleDEM(drained, dX=1.0, dY=1.0)
+        twi = o.calc_twi()
+    assert sha(o.mag, np.float64) == want['mag_sha256']
+    assert sha(o.direction, np.float64) == want['direction_sha256']
+    assert sha(o.flats, np.uint8) == want['flats_sha256'] and int(np.asarray(o.flats).sum()) == want['n_flats']
+    assert sha(o.uca, np.float64) == want['uca_sha256']
+    assert sha(twi, np.float64) == want['twi_sha256']
+    assert sha(o.edge_todo, np.uint8) == want['edge_todo_sha256'] and sha(o.edge_done, np.uint8) == want['edge_done_sha256']

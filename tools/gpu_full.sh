@@ -1,5 +1,7 @@
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2f
-timeout 1200 python -m pytest tests -m gpu -q -x > gpurun_out/r2f/gpu_tests.log 2>&1; echo "pytest rc $?" >> gpurun_out/r2f/gpu_tests.log
-python bench.py --steps 5 --warmup 2 > gpurun_out/r2f/bench.json 2> gpurun_out/r2f/bench.err
-PM_WORKERS=8 PM_EDGE_MODE=pool timeout 600 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/r2f/pm_pool_16384.log 2>&1
+#!/bin/bash
+# the driver's round-end sequence: GPU tests, smoke, default bench
+mkdir -p gpurun_out/full
+timeout 3000 python -m pytest tests -x -q -m gpu > gpurun_out/full/tests.log 2>&1; echo "pytest rc $?" >> gpurun_out/full/tests.log
+tail -5 gpurun_out/full/tests.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/full/smoke.log 2>&1; tail -2 gpurun_out/full/smoke.log
+timeout 900 python bench.py > gpurun_out/full/bench.json 2> gpurun_out/full/bench.err; cat gpurun_out/full/bench.json | cut -c1-400
