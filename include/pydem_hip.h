@@ -238,6 +238,12 @@ int pydem_board_set_desc(pydem_board *b, int index, int32_t n, int32_t m, const 
 int pydem_board_set_lines(pydem_board *b, int index, int64_t mb_start, int64_t size, pydem_tile *tile, int count,
                           const int *fields, const int *axes, const int64_t *indices, const int64_t *rel_offsets);
 int pydem_board_refresh(pydem_board *b, pydem_comm *c, int n_wave, const int *wave_tiles);
+/* the same refresh with the sum over ranks done by the caller on the host (transports without RCCL: the torch.distributed
+ * fallback, pydem_amd/parallel.py DistTransport): stage = zero + pack this rank's lines of the wave + copy to host_out
+ * (*n_doubles values, at most cap); the caller sums the buffers of all ranks; unstage files the sum on the board.
+ * Replaces the same store round trip as pydem_board_refresh (process_manager.py:243-255). */
+int pydem_board_refresh_stage(pydem_board *b, int n_wave, const int *wave_tiles, double *host_out, int64_t cap, int64_t *n_doubles);
+int pydem_board_refresh_unstage(pydem_board *b, int n_wave, const int *wave_tiles, const double *host_in, int64_t n_doubles);
 int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *full, unsigned long long *out);
 int pydem_board_download(pydem_board *b, double *out);
 

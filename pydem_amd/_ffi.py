@@ -98,6 +98,8 @@ SYMBOLS = {
     'pydem_board_set_desc': (C.c_int, [_P, C.c_int, C.c_int32, C.c_int32, _P, _P, _P]),
     'pydem_board_set_lines': (C.c_int, [_P, C.c_int, C.c_int64, C.c_int64, _P, C.c_int, _P, _P, _P, _P]),
     'pydem_board_refresh': (C.c_int, [_P, _P, C.c_int, _P]),
+    'pydem_board_refresh_stage': (C.c_int, [_P, C.c_int, _P, _P, C.c_int64, _P]),
+    'pydem_board_refresh_unstage': (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
     'pydem_board_eval': (C.c_int, [_P, C.c_int, _P, _P, _P]),
     'pydem_board_download': (C.c_int, [_P, _P]),
 }
@@ -330,12 +332,23 @@ class Board(object):
         check(self.lib.pydem_board_set_lines(self._h, index, int(mb_start), int(size), tile._h if tile is not None else None,
                                              k, fields, axes, idx, offs))
 
-    def refresh(self, comm, tiles):
+    def refresh(self, comm, tiles, host_sum=None):
+        """Replicate the lines of `tiles` on the board: pack, sum over ranks, scatter.  comm: an RCCL communicator (or None in
+        a single process); host_sum: a function that sums a float64 array over all ranks in place, for transports without
+        RCCL (the staging buffer then makes the round trip through host memory)."""
         tiles = list(tiles)
         for k0 in range(0, len(tiles), 64):
             part = tiles[k0:k0 + 64]
             arr = (C.c_int * len(part))(*part)
-            check(self.lib.pydem_board_refresh(self._h, comm._h if comm is not None else None, len(part), arr))
+            if host_sum is None:
+                check(self.lib.pydem_board_refresh(self._h, comm._h if comm is not None else None, len(part), arr))
+                continue
+            buf = np.empty(self.n_doubles, np.float64)
+            n = C.c_int64(0)
+            check(self.lib.pydem_board_refresh_stage(self._h, len(part), arr, buf.ctypes.data_as(_P), buf.size, C.byref(n)))
+            part_buf = buf[:n.value]
+            host_sum(part_buf)
+            check(self.lib.pydem_board_refresh_unstage(self._h, len(part), arr, part_buf.ctypes.data_as(_P), n.value))
 
     def eval(self, tiles, full):
         k = len(tiles)

@@ -458,7 +458,70 @@ int pydem_board_set_lines(pydem_board *b, int index, int64_t mb_start, int64_t s
 // call): the tiles of this rank gather their lines into the wave staging buffer (one kernel each, on the tile's own
 // stream behind the round it just ran), with a communicator the staging buffer is summed over the ranks (disjoint
 // fills), then one kernel copies it into the board.
+// the staging buffer of a wave: segment table, capacity, zero fill (when the buffer is summed over ranks) and the pack kernels
+// of this rank's tiles, ordered against the board's stream by events
+static int board_stage(pydem_board *b, int n_wave, const int *wave_tiles, bool summed, pydem_board_segs &S, int64_t &total)
+{
+    if (n_wave > 64) { pydem_set_error("pydem_board_refresh: at most 64 tiles per call"); return -2; }
+    S.n = n_wave;
+    total = 0;
+    for (int k = 0; k < n_wave; k++) {
+        const int i = wave_tiles[k];
+        if (i < 0 || i >= (int)b->tl.size()) { pydem_set_error("pydem_board_refresh: tile without lines (pydem_board_set_lines)"); return -2; }
+        S.src[k] = total; S.dst[k] = b->tl[(size_t)i].mb_start; S.cnt[k] = b->tl[(size_t)i].size;
+        total += b->tl[(size_t)i].size;
+    }
+    if (total > b->wcap) {
+        if (b->wb) HIP_TRY(hipFree(b->wb));
+        HIP_TRY(hipMalloc((void **)&b->wb, (size_t)total * 8));
+        b->wcap = total;
+    }
+    if (summed) HIP_TRY(hipMemsetAsync(b->wb, 0, (size_t)total * 8, b->stream));
+    HIP_TRY(hipEventRecord(b->ev, b->stream));
+    for (int k = 0; k < n_wave; k++) {
+        pydem_board::TileLines &T = b->tl[(size_t)wave_tiles[k]];
+        if (!T.tile || T.count == 0) continue;
+        pydem_tile *t = T.tile;
+        HIP_TRY(hipStreamWaitEvent(t->stream, b->ev, 0));
+        hipLaunchKernelGGL(k_board_pack, dim3(8, T.count), dim3(256), 0, t->stream, T.lines, T.count, b->wb + S.src[k]);
+        HIP_TRY(hipEventRecord(t->ev_snap, t->stream));
+        HIP_TRY(hipStreamWaitEvent(b->stream, t->ev_snap, 0));
+    }
+    return 0;
+}
+
 int pydem_board_refresh(pydem_board *b, pydem_comm *c, int n_wave, const int *wave_tiles)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    if (n_wave <= 0) return 0;
+    pydem_board_segs S;
+    int64_t total = 0;
+    PYDEM_TRY(board_stage(b, n_wave, wave_tiles, c != nullptr, S, total));
+    if (c) NCCL_TRY(ncclAllReduce(b->wb, b->wb, (size_t)total, ncclDouble, ncclSum, c->comm, b->stream));   // also for world == 1
+    hipLaunchKernelGGL(k_board_scatter, dim3(16, n_wave), dim3(256), 0, b->stream, b->wb, b->mb, S);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The same refresh with the sum over ranks done by the caller on the host (transports without RCCL: the torch.distributed
+// fallback of pydem_amd/parallel.py): `stage` packs this rank's lines of the wave into the zeroed staging buffer and
+// returns it, the caller sums the buffers of all ranks, `unstage` files the result on the board.
+int pydem_board_refresh_stage(pydem_board *b, int n_wave, const int *wave_tiles, double *host_out, int64_t cap, int64_t *n_doubles)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    *n_doubles = 0;
+    if (n_wave <= 0) return 0;
+    pydem_board_segs S;
+    int64_t total = 0;
+    PYDEM_TRY(board_stage(b, n_wave, wave_tiles, true, S, total));
+    if (total > cap) { pydem_set_error("pydem_board_refresh_stage: the wave needs %lld doubles, the buffer holds %lld", (long long)total, (long long)cap); return -2; }
+    HIP_TRY(hipMemcpyAsync(host_out, b->wb, (size_t)total * 8, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    *n_doubles = total;
+    return 0;
+}
+
+int pydem_board_refresh_unstage(pydem_board *b, int n_wave, const int *wave_tiles, const double *host_in, int64_t n_doubles)
 {
     HIP_TRY(hipSetDevice(b->device));
     if (n_wave <= 0) return 0;
@@ -472,25 +535,11 @@ int pydem_board_refresh(pydem_board *b, pydem_comm *c, int n_wave, const int *wa
         S.src[k] = total; S.dst[k] = b->tl[(size_t)i].mb_start; S.cnt[k] = b->tl[(size_t)i].size;
         total += b->tl[(size_t)i].size;
     }
-    if (total > b->wcap) {
-        if (b->wb) HIP_TRY(hipFree(b->wb));
-        HIP_TRY(hipMalloc((void **)&b->wb, (size_t)total * 8));
-        b->wcap = total;
-    }
-    if (c) HIP_TRY(hipMemsetAsync(b->wb, 0, (size_t)total * 8, b->stream));
-    HIP_TRY(hipEventRecord(b->ev, b->stream));
-    for (int k = 0; k < n_wave; k++) {
-        pydem_board::TileLines &T = b->tl[(size_t)wave_tiles[k]];
-        if (!T.tile || T.count == 0) continue;
-        pydem_tile *t = T.tile;
-        HIP_TRY(hipStreamWaitEvent(t->stream, b->ev, 0));
-        hipLaunchKernelGGL(k_board_pack, dim3(8, T.count), dim3(256), 0, t->stream, T.lines, T.count, b->wb + S.src[k]);
-        HIP_TRY(hipEventRecord(t->ev_snap, t->stream));
-        HIP_TRY(hipStreamWaitEvent(b->stream, t->ev_snap, 0));
-    }
-    if (c) NCCL_TRY(ncclAllReduce(b->wb, b->wb, (size_t)total, ncclDouble, ncclSum, c->comm, b->stream));   // also for world == 1
+    if (total != n_doubles || total > b->wcap) { pydem_set_error("pydem_board_refresh_unstage: buffer does not belong to this wave"); return -2; }
+    HIP_TRY(hipMemcpyAsync(b->wb, host_in, (size_t)total * 8, hipMemcpyHostToDevice, b->stream));
     hipLaunchKernelGGL(k_board_scatter, dim3(16, n_wave), dim3(256), 0, b->stream, b->wb, b->mb, S);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(b->stream));      // (host_in is the caller's pageable memory)
     return 0;
 }
 

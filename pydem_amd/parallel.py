@@ -53,6 +53,13 @@ class DistTransport(EdgeTransport):
         self.dist.all_gather_object(parts, float(value))
         return max(parts)
 
+    def sum_inplace(self, arr):
+        """Sum a contiguous float64 array over all ranks, in place (the edge board's staging buffer when the strips
+        cannot travel by RCCL: ProcessManager._process_uca_edges_pool_device)."""
+        import torch
+        t = torch.from_numpy(arr)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
     def barrier(self):
         self.dist.barrier()
 

@@ -906,7 +906,9 @@ class ProcessManager(object):
             return False
         if type(self.transport) is EdgeTransport:
             return len(owned) == self.n_inputs
-        return hasattr(self.transport, 'comm') and hasattr(self.transport.comm, '_h')
+        if hasattr(self.transport, 'comm') and hasattr(self.transport.comm, '_h'):
+            return True
+        return hasattr(self.transport, 'sum_inplace')          # no RCCL: the staging buffer is summed on the host
 
     def _process_uca_edges_pool_device(self, mets_type=0):
         """`_process_uca_edges_pool` with the edge board of csrc/comm.hip: the lines every tile reads live in one
@@ -964,8 +966,10 @@ class ProcessManager(object):
             else:
                 board.set_lines(t, start[t], size[t])
 
+        host_sum = None if (comm is not None or type(self.transport) is EdgeTransport) else self.transport.sum_inplace
+
         def refresh(tiles):
-            board.refresh(comm, sorted(tiles))
+            board.refresh(comm, sorted(tiles), host_sum)
 
         def check_against_host_rules(tiles, scal):
             # PYDEM_BOARD_CHECK=1 (tests): the numbers of the evaluation kernel against the host rules on the same lines

@@ -1,5 +1,5 @@
-"""Worker for test_dist_process_manager.py: launched by torch.distributed.run with WORLD_SIZE=2
-(gloo, CPU).  Each rank owns every second tile, strips travel through DistTransport, the per-tile
+"""Worker for test_dist_process_manager.py (and, with the HIP processor, tests/test_gpu_process_manager.py): launched by
+torch.distributed.run with WORLD_SIZE=2 (gloo).  Each rank owns every second tile, strips travel through DistTransport, the per-tile
 arithmetic is the oracle-backed processor; every rank checks its own tiles against the golden."""
 import os
 import sys
@@ -21,12 +21,13 @@ def main():
     from pydem_amd.parallel import DistTransport
     name, path = sys.argv[1], sys.argv[2]
     mode = sys.argv[3] if len(sys.argv) > 3 else 'reference'
+    on_device = len(sys.argv) > 4 and sys.argv[4] == 'device'     # the HIP processor (both ranks share the box's one GPU)
+    pkw = {} if on_device else {'processor_cls': OracleProcessor}
     g = load_golden(name)
     dkw = {k: v for k, v in g['kwargs'].items() if k not in ('ny_grid', 'nx_grid', 'overlap')}
     process_manager.DEBUG = True
-    pm = process_manager.ProcessManager(in_path=path, dem_proc_kwargs=dkw, elev_conditioned=True,
-                                        processor_cls=OracleProcessor, transport=False,
-                                        n_workers=(1 if mode == 'reference' else world), edge_mode=mode)
+    pm = process_manager.ProcessManager(in_path=path, dem_proc_kwargs=dkw, elev_conditioned=True, transport=False,
+                                        n_workers=(1 if mode == 'reference' else world), edge_mode=mode, **pkw)
     pm.transport = DistTransport(pm, rank, world)
     import warnings
     with warnings.catch_warnings():
@@ -38,13 +39,14 @@ def main():
     if mode == 'pool':
         # pool mode is checked against the single-process pool run of the same mosaic: same waves, identical results
         # (what the waves converge to is tested in tests/test_process_manager_pool.py)
-        pm1 = process_manager.ProcessManager(in_path=path, dem_proc_kwargs=dkw, elev_conditioned=True,
-                                             processor_cls=OracleProcessor, n_workers=world, edge_mode='pool')
+        pm1 = process_manager.ProcessManager(in_path=path, dem_proc_kwargs=dkw, elev_conditioned=True, n_workers=world, edge_mode='pool', **pkw)
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             pm1.process_twi()
         assert (pm.edge_waves, pm.edge_rounds) == (pm1.edge_waves, pm1.edge_rounds), (pm.edge_waves, pm1.edge_waves)
         assert pm.edge_waves < pm.edge_rounds
+        if on_device:        # the strips stayed on the device: replicated edge board, staging buffer summed over the ranks
+            assert pm._device_board_usable() and pm1._device_board_usable()
         for i in range(pm.n_inputs):
             if not pm.transport.owns(i):
                 assert pm.tiles[i] is None

@@ -4,6 +4,8 @@ tests).  Tiles start from the reference's conditioned elevation (conditioning is
 yet).  The edge fix-up follows the reference's serial visiting order; the sums inside a round differ in order, so
 float fields are compared at 1e-9 relative; masks, NaN patterns and facet-derived fields exactly.
 Pool mode (the multi-worker schedule): the reference's acceptance cases and the oracle-backed flow."""
+import os
+
 import numpy as np
 import pytest
 
@@ -173,3 +175,24 @@ def test_resume_from_tile_store_on_device(stop_after, n_workers, tmp_path):
         process_manager.DEBUG = False
     for key in want:
         _close(got[key], want[key], key)
+
+
+@pytest.mark.parametrize('name', ['pm_fractal_2x3_ov1', 'pm_cone32_4x5_ov3'])
+def test_two_rank_pool_mode_with_device_board(name, tmp_path):
+    """N > 1 with the strips on the device: two processes (tiles i % 2, both on this box's one GPU -- RCCL refuses two
+    ranks on one device, so the board's staging buffer is summed over the ranks through gloo:
+    pydem_board_refresh_stage / _unstage), replicated edge board, deterministic waves.  Every rank must see the waves,
+    round counts and per-tile results of the single-process pool run."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from test_process_manager_grid import write_tiles
+    g = load_golden(name)
+    write_tiles(g, str(tmp_path), key='elev')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(29600 + (os.getpid() % 300)), os.path.join(ROOT, 'tests', '_dist_pm_worker.py'), name, str(tmp_path), 'pool', 'device']
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = res.stdout.decode()
+    assert res.returncode == 0, out[-3000:]
+    assert out.count(' ok: ') == 2, out[-3000:]
