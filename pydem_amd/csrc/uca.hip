@@ -2299,6 +2299,41 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         }
         return p;
     };
+    // ---- circular drainage: replay of the reference's re-seed loop over the unfinished cells (K5c), after either schedule
+    auto replay_unfinished = [&](uint32_t pass) -> int {
+        HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if ((int64_t)t->h_counters[3] >= t->NN) return 0;
+        {
+            const int64_t unfinished = t->NN - (int64_t)t->h_counters[3];
+            ReseedCell *U = (ReseedCell *)t->queue[0];                       // scratch: the queue buffers are idle in this schedule
+            const int64_t cap64 = t->NN * 4 / (int64_t)sizeof(ReseedCell);
+            if (unfinished > cap64 || unfinished > (1 << 22)) {
+                pydem_set_error("circular drainage: %lld unfinished cells are more than the sequential replay of the re-seed loop is meant for", (long long)unfinished);
+                return -5;
+            }
+            uint8_t *stf = (uint8_t *)t->queue[1];                           // state bytes, then taint bytes
+            int32_t *rc = t->counters + 60;                                  // [60] collected, [61] NaN flag, [62] finished by the replay
+            HIP_TRY(hipMemsetAsync(rc, 0, 3 * sizeof(int32_t), t->stream));
+            hipLaunchKernelGGL(k_reseed_collect, dim3(grid_for(t->NN, 4096)), dim3(256), 0, t->stream, A, U, rc, (int32_t)cap64,
+                               (const double *)t->elev, rc + 1);
+            std::vector<ReseedCell> hu((size_t)unfinished);
+            HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipMemcpyAsync(hu.data(), U, hu.size() * sizeof(ReseedCell), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            if ((int64_t)t->h_counters[60] != unfinished) { pydem_set_error("circular drainage: unfinished-cell count mismatch (%d collected, %lld expected)", t->h_counters[60], (long long)unfinished); return -5; }
+            std::sort(hu.begin(), hu.end(), [](const ReseedCell &a, const ReseedCell &b) { return a.c < b.c; });
+            HIP_TRY(hipMemcpyAsync(U, hu.data(), hu.size() * sizeof(ReseedCell), hipMemcpyHostToDevice, t->stream));
+            hipLaunchKernelGGL(k_reseed_replay, dim3(1), dim3(64), 0, t->stream, A, (const ReseedCell *)U, (int32_t)unfinished,
+                               (const double *)t->elev, (const double *)t->pits.w, stf, stf + unfinished, t->h_counters[61],
+                               (int)opt->circular_ref_maxcount, pass, total, rc + 2);
+            launches += 2;
+            HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "circular drainage: %lld unfinished cells, %d finished by the re-seed replay\n", (long long)unfinished, t->h_counters[62]);
+        }
+        return 0;
+    };
     static int sweep_mode = -1;     // 0: tile passes only (default), 1: tile pass + queue rounds + listed tail
     if (sweep_mode < 0) { const char *e = getenv("PYDEM_SWEEP_MODE"); sweep_mode = (e && !strcmp(e, "queue")) ? 1 : 0; }
     const unsigned full_grid = (unsigned)(((tiles_total + 31) / 32) * 8);
@@ -2329,35 +2364,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         t->tm.sweep_tile_passes = (int64_t)pass;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
-        // ---- circular drainage: replay of the reference's re-seed loop over the unfinished cells (K5c)
-        if ((int64_t)t->h_counters[3] < t->NN) {
-            const int64_t unfinished = t->NN - (int64_t)t->h_counters[3];
-            ReseedCell *U = (ReseedCell *)t->queue[0];                       // scratch: the queue buffers are idle in this schedule
-            const int64_t cap64 = t->NN * 4 / (int64_t)sizeof(ReseedCell);
-            if (unfinished > cap64 || unfinished > (1 << 22)) {
-                pydem_set_error("circular drainage: %lld unfinished cells are more than the sequential replay of the re-seed loop is meant for", (long long)unfinished);
-                return -5;
-            }
-            uint8_t *stf = (uint8_t *)t->queue[1];                           // state bytes, then taint bytes
-            int32_t *rc = t->counters + 60;                                  // [60] collected, [61] NaN flag, [62] finished by the replay
-            HIP_TRY(hipMemsetAsync(rc, 0, 3 * sizeof(int32_t), t->stream));
-            hipLaunchKernelGGL(k_reseed_collect, dim3(grid_for(t->NN, 4096)), dim3(256), 0, t->stream, A, U, rc, (int32_t)cap64,
-                               (const double *)t->elev, rc + 1);
-            std::vector<ReseedCell> hu((size_t)unfinished);
-            HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipMemcpyAsync(hu.data(), U, hu.size() * sizeof(ReseedCell), hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipStreamSynchronize(t->stream));
-            if ((int64_t)t->h_counters[60] != unfinished) { pydem_set_error("circular drainage: unfinished-cell count mismatch (%d collected, %lld expected)", t->h_counters[60], (long long)unfinished); return -5; }
-            std::sort(hu.begin(), hu.end(), [](const ReseedCell &a, const ReseedCell &b) { return a.c < b.c; });
-            HIP_TRY(hipMemcpyAsync(U, hu.data(), hu.size() * sizeof(ReseedCell), hipMemcpyHostToDevice, t->stream));
-            hipLaunchKernelGGL(k_reseed_replay, dim3(1), dim3(64), 0, t->stream, A, (const ReseedCell *)U, (int32_t)unfinished,
-                               (const double *)t->elev, (const double *)t->pits.w, stf, stf + unfinished, t->h_counters[61],
-                               (int)opt->circular_ref_maxcount, pass, total, rc + 2);
-            launches += 2;
-            HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipStreamSynchronize(t->stream));
-            if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "circular drainage: %lld unfinished cells, %d finished by the re-seed replay\n", (long long)unfinished, t->h_counters[62]);
-        }
+        PYDEM_TRY(replay_unfinished(pass));
         if (A.dbg & 4) {
             const unsigned long long *acc = (const unsigned long long *)(t->h_counters + 32);
             fprintf(stderr, "tile phases (10 ns ticks summed over %llu tile runs, %llu of them finished nothing): stage %llu, setup %llu, rounds %llu (%llu rounds), stamp %llu\n",
@@ -2464,6 +2471,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "round %d: frontier %lld, processed %d\n", r, (long long)last, t->h_counters[3]);
         if (r > (int)CI_LEVEL_INF - 256) { pydem_set_error("flow paths longer than %u rounds are not supported", CI_LEVEL_INF); return -5; }
     }
+        PYDEM_TRY(replay_unfinished((uint32_t)r));
     }   // sweep_mode == 1
     if (t->h_counters[15] > 0) { pydem_set_error("sweep frontier exceeded the queue capacity (%lld entries)", (long long)A.qcap); return -5; }
     const int64_t processed = (int64_t)t->h_counters[3];     // tile passes + queue rounds ([4], [10]: tile-pass statistics)

@@ -35,3 +35,13 @@ def test_queue_schedule_matches_oracle(env):
     e = dict(os.environ); e.update(env)
     r = subprocess.run([sys.executable, '-c', SCRIPT % {'root': root}], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'MODES-OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_circular_drainage_replay_in_queue_schedule():
+    """The re-seed replay over the cells on / below a drainage loop (csrc/uca.hip K5c) runs after either schedule: the
+    hand-made loop fields of tests/test_gpu_parity.py, once more with PYDEM_SWEEP_MODE=queue."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, PYDEM_SWEEP_MODE='queue')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), '-q', '-x', '-k', 'circular_drainage'],
+                       env=e, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
