@@ -758,7 +758,7 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
             HIP_TRY(hipStreamSynchronize(t->stream));
             na = t->h_counters[4 + sweep % 3];
             cell_sweeps += na;
-            if (sweep > sweep_cap) { pydem_set_error("fill_flats: distance sweeps did not terminate"); return -5; }
+            if (na > 0 && sweep > sweep_cap + 256) { pydem_set_error("fill_flats: distance sweeps did not terminate"); return -5; }
         }
         if (getenv("PYDEM_COND_DEBUG"))
             fprintf(stderr, "fill_flats: %d flat cells in %d regions, %d sweeps, %lld cell-sweeps\n", nf, nreg, sweep - 1, (long long)cell_sweeps);

@@ -1669,7 +1669,7 @@ __global__ void k_edge_cleanup(EdgeArgs E, const int32_t *nr, const int32_t *nt)
 // (:836-842), the areas agree up to the order of the additions.  'done' / 'todo' masks after every round are
 // the reference's: edge_done = not downstream of a remaining 'todo' inlet (:848-856), edge_todo = the inlets
 // that stay 'todo' (:817).
-constexpr uint32_t EF_FINAL = 16u;
+constexpr uint32_t EF_FINAL = 16u, EF_NAN = 32u;      // EF_NAN: flooded by a NaN seed (k_einc_nan_flood)
 
 struct IncArgs {
     SweepArgs G;
@@ -1680,6 +1680,8 @@ struct IncArgs {
     double *uca;
     const int2 *pit_off;
     int set_done;            // 0 in the final flush: the cells stay 'not done'
+    int32_t *nanq, *n_nan;   // cells whose seed value is NaN (k_einc_nan_flood)
+    uint32_t round16;        // this round's number (mod 2^16, never 0); flag bits 16-31 = round that last seeded the cell
     int32_t *prof;           // -DPYDEM_EINC_PROF: levels / 10 ns ticks by frontier width (<=8, <=64, <=512, more)
 };
 
@@ -1732,13 +1734,15 @@ __global__ void k_einc_seed(IncArgs E, const double *__restrict__ sdata, const u
     const uint32_t cw = E.G.cinfo[c] & CI_STATIC_MASK;
     if (dn) {
         const double d = E.flats[c] ? NAN : init - E.uca[c];                     // :806-809, :815
+        if (!own_done) E.flag[c] = (E.flag[c] & 0xFFFFu) | (E.round16 << 16);     // a seed of this round: upstream values do not enter it
         if (!(E.flag[c] & EF_FINAL) && !own_done) {
             // a seed (:798), or a cell below one of the tile's own unresolved inlets whose neighbour copy is finished:
             // it adopts the finished value (it will not pull) and holds the difference for the cells below it.  It is
             // 'done' -- and lets go of its targets -- once nothing unresolved is left upstream of it inside the tile
             E.uca[c] += d;
             E.delta[c] = d;
-            E.flag[c] = EF_FINAL;
+            E.flag[c] = (E.flag[c] & (EF_NAN | 0xFFFF0000u)) | EF_FINAL;
+            if (d != d) E.nanq[atomicAdd(E.n_nan, 1)] = c;
             E.edge_todo[c] = 0;
             if (own_todo) {
                 const uint32_t old = atomicSub(&E.G.cinfo[c], CI_EONE);          // the outside of the tile
@@ -1747,6 +1751,10 @@ __global__ void k_einc_seed(IncArgs E, const double *__restrict__ sdata, const u
         } else {
             E.uca[c] += d;                                                      // finished on both sides: re-synchronised
             E.edge_todo[c] = 0;
+            if (!own_done) {                                                    // ... or a seed of an earlier round that still waits: the
+                E.delta[c] += d;                                                // difference joins what it holds for its targets
+                if (d != d) E.nanq[atomicAdd(E.n_nan, 1)] = c;
+            }
         }
     } else if (own_todo && !td) {
         // the 'todo' flag was dropped without a value (rule :274 / the mosaic border): the outside edge goes away
@@ -1808,7 +1816,7 @@ __device__ __forceinline__ void einc_cell(const IncArgs &E, QE q, Push push)
                 if (E.flag[A.pin_src[e]] & EF_FINAL) acc += E.delta[A.pin_src[e]] * A.pin_w[e];
         E.delta[c] = acc;
         E.uca[c] = own_uca + acc;
-        E.flag[c] = EF_FINAL;
+        E.flag[c] = (own_flag & EF_NAN) | EF_FINAL;
     }
     if (E.set_done) E.edge_done[c] = 1;
     const int s = ci_section(cw);
@@ -1820,6 +1828,37 @@ __device__ __forceinline__ void einc_cell(const IncArgs &E, QE q, Push push)
     if (cw & CI_OUT2) release(c + fe2r(s) * m + fe2c(s));
     if (cw & CI_PIT_OUT)
         for (int32_t e = po.y; e < A.n_pit && A.pit_src[e] == c; e++) release(A.pit_dst[e]);
+}
+
+// NaN is absorbing in the reference's rounds and floods everything below the seed in the round it arrives (see
+// k_cinc_nan_flood for the argument); cell-indexed form: breadth first over the out-edges of the graph words
+__global__ __launch_bounds__(1024) void k_einc_nan_flood(IncArgs E)
+{
+    __shared__ int32_t s_tail;
+    const SweepArgs &A = E.G;
+    if (threadIdx.x == 0) s_tail = *E.n_nan;
+    __syncthreads();
+    int32_t head = 0, tail = s_tail;
+    const int32_t n_origin = tail;             // the NaN seeds themselves
+    while (head < tail) {
+        for (int32_t q = head + threadIdx.x; q < tail; q += blockDim.x) {
+            const int32_t c = E.nanq[q];
+            if (q >= n_origin && (E.flag[c] >> 16) == E.round16) continue;       // a seed of this round keeps its value
+            if (atomicOr(&E.flag[c], EF_NAN) & EF_NAN) continue;
+            E.uca[c] = NAN;
+            const uint32_t cw = A.cinfo[c];
+            const int s = ci_section(cw);
+            auto visit = [&](int32_t t) { if (!(E.flag[t] & EF_NAN)) E.nanq[atomicAdd(&s_tail, 1)] = t; };
+            if (cw & CI_OUT1) visit(c + fe1r(s) * A.m + fe1c(s));
+            if (cw & CI_OUT2) visit(c + fe2r(s) * A.m + fe2c(s));
+            if (cw & CI_PIT_OUT)
+                for (int32_t e = E.pit_off[c].y; e < A.n_pit && A.pit_src[e] == c; e++) visit(A.pit_dst[e]);
+        }
+        __syncthreads();
+        head = tail; tail = s_tail;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *E.n_nan = 0;
 }
 
 __global__ __launch_bounds__(256) void k_einc_level(IncArgs E, const QE *__restrict__ qc, QE *__restrict__ qn, int32_t *cnt3, int r)
@@ -1902,7 +1941,7 @@ struct __attribute__((aligned(128))) NDRec {
     uint32_t cw;
     int32_t out_id[2];       // compact ids of the two targets (-1: no such edge)
     uint8_t out_slot[2];     // which in-slot of the target this cell feeds (the target's neighbour index NW..SE)
-    uint16_t pad_;
+    uint16_t seed_round;     // round (mod 2^16) in which the strips last initialised the cell: a NaN flood of that round stops here
     int32_t cnt;             // unresolved in-edges (+1 for the outside of the tile while the cell is a 'todo' inlet)
     uint32_t flag;
     double delta;
@@ -1910,7 +1949,7 @@ struct __attribute__((aligned(128))) NDRec {
     double in_delta[8];      // what the finished in-neighbour NW..SE has handed over (0 until then)
 };
 static_assert(sizeof(NDRec) == 128, "one cache line per ND cell");
-constexpr uint32_t NF_FINAL = 1u, NF_DONE = 2u, NF_APPLIED = 4u, NF_SEED = 8u;
+constexpr uint32_t NF_FINAL = 1u, NF_DONE = 2u, NF_APPLIED = 4u, NF_SEED = 8u, NF_NAN = 16u;
 constexpr uint32_t ND_FLAT = 1u << 16;            // in the record's graph word: the cell is a flat (its delta is NaN, :815)
 constexpr int64_t ND_COMPACT_MAX = 6 << 20;      // records (768 MiB)
 
@@ -1924,6 +1963,8 @@ struct CIncArgs {
     double *uca;
     int set_done;
     int32_t *prof;
+    int32_t *nanq, *n_nan;   // records whose delta is NaN (k_cinc_nan_flood)
+    uint32_t round16;        // this round's number (mod 2^16, never 0)
 };
 
 __global__ __launch_bounds__(256) void k_nd_count(const uint8_t *__restrict__ edge_done, int64_t NN, unsigned long long *count)
@@ -1943,7 +1984,7 @@ __global__ __launch_bounds__(256) void k_nd_assign(CIncArgs E, int64_t NN, int32
         NDRec &R = E.rec[k];
         R.cell = (int32_t)c64;
         R.cw = (E.G.cinfo[c64] & CI_STATIC_MASK) | (E.flats[c64] ? ND_FLAT : 0u);
-        R.flag = 0; R.delta = 0.0;
+        R.flag = 0; R.delta = 0.0; R.seed_round = 0;
     }
 }
 
@@ -2009,14 +2050,22 @@ __global__ void k_cinc_seed(CIncArgs E, const double *__restrict__ sdata, const 
         const double d = E.flats[c] ? NAN : init - E.uca[c];
         E.uca[c] += d;
         E.edge_todo[c] = 0;
+        if (k >= 0 && !own_done) E.rec[k].seed_round = (uint16_t)E.round16;     // a seed of this round (:798): upstream values do not enter it
         if (k >= 0 && !own_done && !(E.rec[k].flag & NF_FINAL)) {
             NDRec &R = E.rec[k];
             R.delta = d;
-            R.flag = NF_FINAL | NF_SEED;
+            R.flag = (R.flag & NF_NAN) | NF_FINAL | NF_SEED;
+            if (d != d) E.nanq[atomicAdd(E.n_nan, 1)] = k;                       // (k_cinc_nan_flood)
             if (own_todo) {
                 const int32_t old = atomicSub(&R.cnt, 1);
                 if (old == 1) { QE e; e.c = k; e.cw = 0; q[agg_slot(nq)] = e; }
             }
+        } else if (k >= 0 && !own_done) {
+            // a seed of an earlier round that still waits for its own upstream cells, and the neighbour's copy has moved
+            // on since: the reference re-initialises it in every round (`area_edges - uca`, :806-809) and lets the
+            // difference run down; here it joins what the cell holds for its targets
+            E.rec[k].delta += d;
+            if (d != d) E.nanq[atomicAdd(E.n_nan, 1)] = k;
         }
     } else if (own_todo && !td) {
         E.edge_todo[c] = 0;
@@ -2072,7 +2121,7 @@ __device__ __forceinline__ void cinc_cell(const CIncArgs &E, QE q, Push push)
         }
         delta = acc;
         R.delta = acc;
-        R.flag = NF_FINAL | NF_DONE;
+        R.flag = (V.flag & NF_NAN) | NF_FINAL | NF_DONE;
     } else {
         R.flag = V.flag | NF_DONE;                                               // a seed keeps the value it adopted
     }
@@ -2092,6 +2141,46 @@ __device__ __forceinline__ void cinc_cell(const CIncArgs &E, QE q, Push push)
             if (kt >= 0 && atomicSub(&E.rec[kt].cnt, 1) == 1) push(kt, 0u);
         }
     }
+}
+
+// A round of the reference propagates whatever a seed carries through ALL cells below it at once (:826-840), and NaN is
+// absorbing there: a cell that received NaN in one round stays NaN when a later round re-initialises it from a finished
+// neighbour (`area_edges - uca`, :806-809).  The incremental rounds hold deltas back until a cell's last upstream cell is
+// done, and a cell that adopts a neighbour's value in the meantime drops them -- harmless for numbers (the adopted value
+// contains them), wrong for NaN.  So a NaN seed floods its NaN through everything downstream in the round it arrives --
+// except the other seeds of that round, which are 'done' from the start in the reference's sweep and take nothing from
+// upstream (:826-829): one workgroup, breadth first over the out-links of the records, each record claimed once.
+__global__ __launch_bounds__(1024) void k_cinc_nan_flood(CIncArgs E)
+{
+    __shared__ int32_t s_tail;
+    if (threadIdx.x == 0) s_tail = *E.n_nan;
+    __syncthreads();
+    int32_t head = 0, tail = s_tail;
+    const int32_t n_origin = tail;             // the NaN seeds themselves
+    while (head < tail) {
+        for (int32_t q = head + threadIdx.x; q < tail; q += blockDim.x) {
+            const int32_t k = E.nanq[q];
+            NDRec &R = E.rec[k];
+            if (q >= n_origin && R.seed_round == (uint16_t)E.round16) continue;  // a seed of this round keeps its value
+            if (atomicOr(&R.flag, NF_NAN) & NF_NAN) continue;                     // flooded in an earlier round
+            E.uca[R.cell] = NAN;
+            for (int o = 0; o < 2; o++) {
+                const int32_t t = R.out_id[o];
+                if (t >= 0 && !(E.rec[t].flag & NF_NAN)) E.nanq[atomicAdd(&s_tail, 1)] = t;
+            }
+            if (R.cw & CI_PIT_OUT) {
+                const SweepArgs &A = E.G;
+                for (int32_t e = E.pit_off[R.cell].y; e < A.n_pit && A.pit_src[e] == R.cell; e++) {
+                    const int32_t t = E.cid[A.pit_dst[e]] - 1;
+                    if (t >= 0 && !(E.rec[t].flag & NF_NAN)) E.nanq[atomicAdd(&s_tail, 1)] = t;
+                }
+            }
+        }
+        __syncthreads();
+        head = tail; tail = s_tail;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *E.n_nan = 0;
 }
 
 __global__ __launch_bounds__(256) void k_cinc_level(CIncArgs E, const QE *__restrict__ qc, QE *__restrict__ qn, int32_t *cnt3, int r)
@@ -2649,6 +2738,8 @@ static int einc_args(pydem_tile *t, IncArgs &E)
     E.flag = (uint32_t *)t->estamp; E.delta = t->edelta; E.flats = t->flats; E.edge_done = t->edge_done; E.edge_todo = t->edge_todo;
     E.uca = t->uca; E.pit_off = reinterpret_cast<const int2 *>(t->contrib); E.set_done = 1;
     E.prof = t->counters + 40;
+    E.nanq = reinterpret_cast<int32_t *>(t->queue[1]); E.n_nan = t->counters + 53;   // (queue 1 is empty until the cascade's first level)
+    E.round16 = (uint32_t)(t->einc_round % 65535) + 1u;
     return 0;
 }
 
@@ -2694,6 +2785,8 @@ static int cinc_args(pydem_tile *t, CIncArgs &E)
     E.pit_off = reinterpret_cast<const int2 *>(t->contrib);
     E.flats = t->flats; E.edge_done = t->edge_done; E.edge_todo = t->edge_todo; E.uca = t->uca; E.set_done = 1;
     E.prof = t->counters + 40;
+    E.nanq = reinterpret_cast<int32_t *>(t->edelta); E.n_nan = t->counters + 53;     // (the delta plane is idle in the compact form)
+    E.round16 = (uint32_t)(t->einc_round % 65535) + 1u;
     return 0;
 }
 
@@ -2745,13 +2838,13 @@ static int einc_prepare(pydem_tile *t, IncArgs &E)
                            reinterpret_cast<int2 *>(t->contrib));
     HIP_TRY(hipMemsetAsync(t->estamp, 0, (size_t)t->NN * 4, t->stream));
     unsigned long long *cnt64 = reinterpret_cast<unsigned long long *>(t->counters + 48);
-    HIP_TRY(hipMemsetAsync(t->counters + 48, 0, 4 * sizeof(int32_t), t->stream));
+    HIP_TRY(hipMemsetAsync(t->counters + 48, 0, 8 * sizeof(int32_t), t->stream));       // ([53]: NaN seeds of a round)
     hipLaunchKernelGGL(k_nd_count, dim3(grid_for(t->NN, 4096)), dim3(256), 0, t->stream, t->edge_done, t->NN, cnt64);
     HIP_TRY(hipMemcpyAsync(t->h_counters + 48, t->counters + 48, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     const int64_t nd = (int64_t)*reinterpret_cast<unsigned long long *>(t->h_counters + 48);
-    static int64_t compact_max = -1;
-    if (compact_max < 0) { const char *e = getenv("PYDEM_EINC_COMPACT_MAX"); compact_max = e ? atoll(e) : ND_COMPACT_MAX; }
+    int64_t compact_max = ND_COMPACT_MAX;            // (read per fix-up: the tests switch the form)
+    { const char *e = getenv("PYDEM_EINC_COMPACT_MAX"); if (e) compact_max = atoll(e); }
     t->einc_compact = nd <= compact_max;
     if (t->einc_compact) {
         if (nd > t->nd_cap) {
@@ -2790,6 +2883,7 @@ int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *
     const int n = (int)t->n, m = (int)t->m;
     const int L = n > m ? n : m;
     const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
+    t->einc_round++;
     IncArgs E;
     PYDEM_TRY(einc_args(t, E));
     PYDEM_TRY(tile_alloc(t, &t->s_data, (size_t)L * 4));
@@ -2827,10 +2921,12 @@ int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *
         PYDEM_TRY(cinc_args(t, C));
         hipLaunchKernelGGL(k_cinc_seed, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, C, t->s_data, t->s_flags,
                            t->s_flags + (size_t)4 * L, L, (QE *)t->queue[0], &t->counters[0]);
+        hipLaunchKernelGGL(k_cinc_nan_flood, dim3(1), dim3(1024), 0, t->stream, C);
         PYDEM_TRY(cinc_cascade(t, C, &levels));
     } else {
         hipLaunchKernelGGL(k_einc_seed, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, E, t->s_data, t->s_flags,
                            t->s_flags + (size_t)4 * L, L, (QE *)t->queue[0], &t->counters[0]);
+        hipLaunchKernelGGL(k_einc_nan_flood, dim3(1), dim3(1024), 0, t->stream, E);
         PYDEM_TRY(einc_cascade(t, E, &levels));
     }
     if (getenv("PYDEM_EDGE_DEBUG"))

@@ -60,3 +60,40 @@ def test_circular_drainage_is_replayed_like_the_reference():
             assert np.allclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True), (i, key)
         for key in ('edge_todo', 'edge_done'):
             assert np.array_equal(dev.tile_result(i, key), ref.tile_result(i, key)), (i, key)
+
+
+def _same_flow(dev, ref, rec):
+    import numpy as np
+    assert (dev.edge_rounds, dev.edge_waves) == (ref.edge_rounds, ref.edge_waves), rec
+    for i in range(ref.n_inputs):
+        zero_area = np.abs(np.asarray(ref.tile_result(i, 'uca_total'), float)) < 1e-9
+        for key in ('uca_total', 'twi'):
+            a, b = np.asarray(dev.tile_result(i, key), float), np.asarray(ref.tile_result(i, key), float)
+            if key == 'twi':
+                a = np.where(zero_area, 0.0, a); b = np.where(zero_area, 0.0, b)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (rec, i, key)
+            assert np.allclose(a, b, rtol=1e-9, atol=1e-12, equal_nan=True), (rec, i, key)
+        for key in ('edge_todo', 'edge_done'):
+            assert np.array_equal(dev.tile_result(i, key), ref.tile_result(i, key)), (rec, i, key)
+
+
+@pytest.mark.parametrize('compact', ['1', '0'])
+def test_random_mosaics_in_pool_mode(compact, monkeypatch):
+    """The pool schedule on the device (waves, incremental rounds, edge board) against the same schedule with the numpy
+    strip rules and the oracle processor, on the first mosaics of the soak (SOAK_POOL=1) and on three it found.  94: a NaN seed
+    sits above an edge cell that adopts its neighbour's finished value a wave later -- the reference's rounds keep the NaN
+    (it is absorbing in `area_edges - uca`), so the incremental rounds flood it at once (k_cinc_nan_flood /
+    k_einc_nan_flood; compact = '0' forces the cell-indexed form); 53: ... but not into the other seeds of the same round;
+    264: a seed that still waits for its own upstream cells is re-initialised when its neighbour's copy has moved on."""
+    import numpy as np
+    import soak_pm
+    from oracle_processor import OracleProcessor
+    if compact == '0':
+        monkeypatch.setenv('PYDEM_EINC_COMPACT_MAX', '0')
+    monkeypatch.setattr(soak_pm, 'POOL', True)
+    for k in list(range(12)) + [53, 94, 264]:
+        rec, z, ny, nx, ov, dkw = soak_pm.make_case(k)
+        width = int(np.random.default_rng(77 + k + 1).choice([2, 3, 8]))
+        ref = soak_pm.run(z, ny, nx, ov, dkw, OracleProcessor, width)
+        dev = soak_pm.run(z, ny, nx, ov, dkw, None, width)
+        _same_flow(dev, ref, rec)

@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Randomised directory-flow soak: ProcessManager with the device DEMProcessor against the same ProcessManager with
 the CPU-oracle processor (tests/oracle_processor.py) on random mosaics (raster, tile grid, overlap, nodata, sea level,
-pit handling on/off).  Exercises the device edge-update rounds in the reference's visiting order.  Stops at the first
-mismatch.   soak_pm.py [seconds] [first_case]"""
+pit handling on/off).  Exercises the device edge-update rounds in the reference's visiting order, or -- SOAK_POOL=1 -- the
+multi-worker schedule (deterministic waves, incremental rounds, device edge board) against the numpy strip rules with the
+oracle processor at a random pool width.  Stops at the first mismatch.   soak_pm.py [seconds] [first_case]"""
 import os
 import shutil
 import sys
@@ -50,13 +51,18 @@ def make_case(k):
     return dict(case=k, shape=(n, m), grid=(ny, nx), overlap=ov, options=dkw), z, ny, nx, ov, dkw
 
 
-def run(z, ny, nx, ov, dkw, cls):
+POOL = os.environ.get('SOAK_POOL') == '1'
+
+
+def run(z, ny, nx, ov, dkw, cls, width=1):
     d = tempfile.mkdtemp()
     try:
         for t, (elev, bounds) in enumerate(synth.split_mosaic(z, ny, nx, ov)):
             np.savez(os.path.join(d, 'tile_%03d.npz' % t), elev=elev, bounds=bounds)
         process_manager.DEBUG = True
         kw = dict(tiles_in_flight=int(os.environ.get('SOAK_IN_FLIGHT', '1'))) if cls is None else dict(processor_cls=cls)
+        if POOL:
+            kw.update(n_workers=width, edge_mode='pool')
         pm = process_manager.ProcessManager(in_path=d, elev_conditioned=True, dem_proc_kwargs=dict(dkw), **kw)
         if cls is None and os.environ.get('SOAK_RCCL') == '1':      # strips through the RCCL transport (one rank)
             pm.transport = RcclTransport(pm, comm())
@@ -77,12 +83,13 @@ def main():
         rec, z, ny, nx, ov, dkw = make_case(k)
         k += 1
         try:
-            ref = run(z, ny, nx, ov, dkw, OracleProcessor)
+            width = int(np.random.default_rng(77 + k).choice([2, 3, 8]))
+            ref = run(z, ny, nx, ov, dkw, OracleProcessor, width)
         except Exception as e:                      # e.g. a degenerate tile grid the host logic rejects for both
             skipped += 1
             continue
         try:
-            dev = run(z, ny, nx, ov, dkw, None)
+            dev = run(z, ny, nx, ov, dkw, None, width)
         except RuntimeError as e:
             if 'circular drainage' in str(e):       # more unfinished cells than the sequential re-seed replay accepts
                 cyclic.append(rec['case'])
@@ -90,8 +97,8 @@ def main():
             print('DEVICE RUN FAILED', rec, repr(e)[:300])
             sys.exit(1)
         errs = []
-        if dev.edge_rounds != ref.edge_rounds:
-            errs.append('edge rounds %d vs %d' % (dev.edge_rounds, ref.edge_rounds))
+        if dev.edge_rounds != ref.edge_rounds or getattr(dev, 'edge_waves', 0) != getattr(ref, 'edge_waves', 0):
+            errs.append('edge rounds %d vs %d, waves %d vs %d' % (dev.edge_rounds, ref.edge_rounds, getattr(dev, 'edge_waves', 0), getattr(ref, 'edge_waves', 0)))
         for i in range(ref.n_inputs):
             # where the edge corrections cancel a cell's area to (almost) exactly zero, the two summation orders leave
             # 0.0 on one side and +-1e-16 on the other: log() turns that into -inf vs NaN / -36; such cells are exempt
