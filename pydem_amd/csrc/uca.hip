@@ -2334,6 +2334,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     PYDEM_TRY(tile_alloc(t, &t->queue[1], (size_t)t->NN));
     PYDEM_TRY(tile_alloc(t, &t->row_area, (size_t)t->n));
     PYDEM_TRY(tile_alloc(t, &t->contrib, (size_t)t->NN * 2));
+    t->circular_cells = 0;
     int32_t *cnt3 = t->counters;        // [0..2] rotating frontier sizes
     int32_t *total = t->counters + 3;   // cells processed by rounds >= 1
     int32_t *nsrc = t->counters + 4;    // source cells (round 0)
@@ -2395,6 +2396,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         if ((int64_t)t->h_counters[3] >= t->NN) return 0;
         {
             const int64_t unfinished = t->NN - (int64_t)t->h_counters[3];
+            t->circular_cells = unfinished;
             ReseedCell *U = (ReseedCell *)t->queue[0];                       // scratch: the queue buffers are idle in this schedule
             const int64_t cap64 = t->NN * 4 / (int64_t)sizeof(ReseedCell);
             if (unfinished > cap64 || unfinished > (1 << 22)) {
@@ -2648,19 +2650,24 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
         hipLaunchKernelGGL(k_edge_restore, dim3(grid_for(t->etodo_prev, 1024)), dim3(256), 0, t->stream, t->flatlist, t->etodo_prev,
                            t->edge_done);
     }
-    // strips -> device (left, right, top, bottom), padded to L entries each
-    std::vector<double> hd((size_t)L * 4, 0.0);
-    std::vector<uint8_t> hf((size_t)L * 8, 0);
-    for (int s = 0; s < 4; s++) {
-        const int len = s < 2 ? n : m;
-        for (int k = 0; k < len; k++) {
-            hd[(size_t)s * L + k] = data[s][k];
-            hf[(size_t)s * L + k] = done[s][k] != 0;
-            hf[(size_t)(4 + s) * L + k] = todo[s][k] != 0;
+    // strips -> device (left, right, top, bottom), padded to L entries each (data == NULL: they are there already, written
+    // by the edge board)
+    std::vector<double> hd;
+    std::vector<uint8_t> hf;
+    if (data) {
+        hd.assign((size_t)L * 4, 0.0);
+        hf.assign((size_t)L * 8, 0);
+        for (int s = 0; s < 4; s++) {
+            const int len = s < 2 ? n : m;
+            for (int k = 0; k < len; k++) {
+                hd[(size_t)s * L + k] = data[s][k];
+                hf[(size_t)s * L + k] = done[s][k] != 0;
+                hf[(size_t)(4 + s) * L + k] = todo[s][k] != 0;
+            }
         }
+        HIP_TRY(hipMemcpyAsync(t->s_data, hd.data(), hd.size() * 8, hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->s_flags, hf.data(), hf.size(), hipMemcpyHostToDevice, t->stream));
     }
-    HIP_TRY(hipMemcpyAsync(t->s_data, hd.data(), hd.size() * 8, hipMemcpyHostToDevice, t->stream));
-    HIP_TRY(hipMemcpyAsync(t->s_flags, hf.data(), hf.size(), hipMemcpyHostToDevice, t->stream));
     HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
     int32_t *cnt3 = t->counters;      // rotating frontier sizes; level r reads queue[r % 2] / cnt3[r % 3]
     int32_t *n_seed = t->counters + 8;
@@ -2879,6 +2886,11 @@ int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *
         pydem_set_error("incremental edge rounds do not support apply_uca_limit_edges; use pydem_uca_edge_update");
         return -6;
     }
+    // The counts of the incremental form assume that the cells that are not done form a DAG.  A tile with circular drainage
+    // (the re-seed replay ran in its sweep: cells on and below a loop never count down to zero, while the reference's masks
+    // only ask whether a 'todo' inlet lies upstream) runs the plain round instead; so does a tile resumed from the store,
+    // whose sweep did not run in this process.
+    if (t->circular_cells != 0) return stage_edge_update(t, opt, data, done, todo);
     const double t_begin = host_now_ms();
     const int n = (int)t->n, m = (int)t->m;
     const int L = n > m ? n : m;

@@ -84,14 +84,15 @@ def test_random_mosaics_in_pool_mode(compact, monkeypatch):
     sits above an edge cell that adopts its neighbour's finished value a wave later -- the reference's rounds keep the NaN
     (it is absorbing in `area_edges - uca`), so the incremental rounds flood it at once (k_cinc_nan_flood /
     k_einc_nan_flood; compact = '0' forces the cell-indexed form); 53: ... but not into the other seeds of the same round;
-    264: a seed that still waits for its own upstream cells is re-initialised when its neighbour's copy has moved on."""
+    264: a seed that still waits for its own upstream cells is re-initialised when its neighbour's copy has moved on; 8483: a
+    tile with a drainage loop (the counts never reach zero there) takes the plain rounds."""
     import numpy as np
     import soak_pm
     from oracle_processor import OracleProcessor
     if compact == '0':
         monkeypatch.setenv('PYDEM_EINC_COMPACT_MAX', '0')
     monkeypatch.setattr(soak_pm, 'POOL', True)
-    for k in list(range(12)) + [53, 94, 264]:
+    for k in list(range(12)) + [53, 94, 264, 8483]:
         rec, z, ny, nx, ov, dkw = soak_pm.make_case(k)
         width = int(np.random.default_rng(77 + k + 1).choice([2, 3, 8]))
         ref = soak_pm.run(z, ny, nx, ov, dkw, OracleProcessor, width)
