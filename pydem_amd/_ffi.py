@@ -222,6 +222,8 @@ class Tile(object):
     def pit_drain_paths(self, below_sea, max_iter, max_dist, max_dist_XY):
         """calc_pit_drain_paths on the resident elevation.  Returns (n_failed, iterations used, rounds), or None when the tile
         must go through the host loop (no-data cells, float32 surface, or the parallel schedule gave up: surface restored)."""
+        import time
+        t0 = time.perf_counter()
         n = C.c_int64(0)
         check(self.lib.pydem_pit_candidates(self._h, int(bool(below_sea)), C.byref(n)))
         if n.value < 0:
@@ -229,11 +231,17 @@ class Tile(object):
         cells = np.empty(max(n.value, 1), np.int32); elev = np.empty(max(n.value, 1), np.float64)
         check(self.lib.pydem_pit_candidates_read(self._h, n.value, cells.ctypes.data_as(_P), elev.ctypes.data_as(_P)))
         cells, elev = cells[:n.value], elev[:n.value]
+        t1 = time.perf_counter()
         order = np.ascontiguousarray(cells[np.argsort(elev)], np.int32)       # the reference's call (:450): same tie order
+        t2 = time.perf_counter()
         failed, used, rounds, flag = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
         check(self.lib.pydem_pit_paths(self._h, order.ctypes.data_as(_P), n.value, int(max_iter), int(max_dist or 0),
                                        float(max_dist_XY) if max_dist_XY else 0.0, C.byref(failed), C.byref(used), C.byref(rounds),
                                        C.byref(flag)))
+        if os.environ.get('PYDEM_PATHS_DEBUG'):
+            import sys
+            sys.stderr.write("pit paths host side: candidates %.1f ms, argsort %.1f ms, pydem_pit_paths %.1f ms\n"
+                             % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3))
         if flag.value:
             return None
         return int(failed.value), int(used.value), int(rounds.value)

@@ -541,12 +541,17 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     if (npits >= (1ll << 30)) { pydem_set_error("too many pits"); return -2; }
     if (!t->spacing_set) { pydem_set_error("pit drain paths: call pydem_tile_set_spacing first"); return -3; }
     if (max_iter > 300) return 1;                             // the large window is sized for the reference's 300 iterations
-    static int win_cap = -1, big_max = -1;
-    if (win_cap < 0) { const char *e = getenv("PYDEM_PATHS_WINDOW"); win_cap = e ? atoi(e) : 32768; if (win_cap < 64) win_cap = 64; }
-    if (big_max < 0) { const char *e = getenv("PYDEM_PATHS_BIG"); big_max = e ? atoi(e) : 256; if (big_max < 1) big_max = 1; }
+    // speculation window and large-window simulations per round: measured on the 8192^2 SRTM-like tile (341 090 pits, 4885 of
+    // them plateau pits): 32768 / 256 -> 56 rounds, 247 ms; 131072 / 2048 -> 26 rounds, 170 ms; larger does not pay
+    static int win_cap = -1, big_env = -1;
+    if (win_cap < 0) { const char *e = getenv("PYDEM_PATHS_WINDOW"); win_cap = e ? atoi(e) : 131072; if (win_cap < 64) win_cap = 64; }
+    if (big_env < 0) { const char *e = getenv("PYDEM_PATHS_BIG"); big_env = e ? atoi(e) : 2048; if (big_env < 1) big_env = 1; }
+    int big_max = big_env;
+    struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
     const int W = (int)(npits < win_cap ? npits : win_cap);
     const int FCAP = STCAP + SRCAP, CCAP = STCAP + 1;
-    const int64_t BIGF = (int64_t)BWIN * BWIN;                // footprint / trail capacity of a large-window simulation
+    const int64_t BIGF = std::min<int64_t>((int64_t)BWIN * BWIN, t->NN);   // footprint / trail capacity of a large-window simulation
+    if ((int64_t)big_max > npits) big_max = (int)npits;
     Buf b_bown, b_rstamp, b_tent;
     Buf b_order, b_window, b_rown, b_wown, b_stamp, b_status, b_nF, b_nC, b_iters, b_F, b_C, b_CV, b_flags, b_done, b_counts, b_slots,
         b_backup, b_bigtrail, b_bigF, b_bigC, b_bigCV, b_Fp, b_Cp, b_CVp, b_fcap, b_ccap;
@@ -587,6 +592,8 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     bool fallback = false;
     const size_t big_lds = (size_t)2 * (BWIN * BWIN / 8) + (size_t)BRCAP * 12 + 64 * 4;
     bool big_ready = false;
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    const double ms_setup = now_ms() - (ts0.tv_sec * 1e3 + ts0.tv_nsec * 1e-6);
     while (!pending.empty() || next < npits) {
         while ((int)pending.size() < W && next < npits) pending.push_back((int32_t)next++);
         // only as many large-window pits as one launch holds can take part in a round, and nobody after the first one
@@ -665,8 +672,8 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     if (rounds_out) *rounds_out = rounds;
     if (getenv("PYDEM_PATHS_DEBUG"))
         fprintf(stderr, "pit drain paths: %lld pits, %lld rounds, %lld small-window and %lld large-window simulations; ms: small %.1f, large %.1f, "
-                        "commit %.1f%s\n", (long long)npits, (long long)rounds, (long long)small_runs, (long long)big_runs, ms_small, ms_big, ms_commit,
-                fallback ? " -> host loop" : "");
+                        "commit %.1f, buffers %.1f%s\n", (long long)npits, (long long)rounds, (long long)small_runs, (long long)big_runs, ms_small, ms_big, ms_commit,
+                ms_setup, fallback ? " -> host loop" : "");
     if (fallback) {
         HIP_TRY(hipMemcpyAsync(t->elev, b_backup.p, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
