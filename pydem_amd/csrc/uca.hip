@@ -2395,24 +2395,33 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         HIP_TRY(hipStreamSynchronize(t->stream));
         if ((int64_t)t->h_counters[3] >= t->NN) return 0;
         {
-            const int64_t unfinished = t->NN - (int64_t)t->h_counters[3];
-            t->circular_cells = unfinished;
-            ReseedCell *U = (ReseedCell *)t->queue[0];                       // scratch: the queue buffers are idle in this schedule
-            const int64_t cap64 = t->NN * 4 / (int64_t)sizeof(ReseedCell);
-            if (unfinished > cap64 || unfinished > (1 << 22)) {
-                pydem_set_error("circular drainage: %lld unfinished cells are more than the sequential replay of the re-seed loop is meant for", (long long)unfinished);
-                return -5;
-            }
+            // (the counter says how many cells the schedule processed; what is unfinished is decided by the level stamps:
+            // the queue schedule does not count every cell it settles)
+            ReseedCell *U = (ReseedCell *)t->queue[0];                       // scratch: the queue buffers are idle by now
+            const int64_t cap64 = std::min<int64_t>(t->NN * 4 / (int64_t)sizeof(ReseedCell), (int64_t)1 << 22);
             uint8_t *stf = (uint8_t *)t->queue[1];                           // state bytes, then taint bytes
             int32_t *rc = t->counters + 60;                                  // [60] collected, [61] NaN flag, [62] finished by the replay
             HIP_TRY(hipMemsetAsync(rc, 0, 3 * sizeof(int32_t), t->stream));
             hipLaunchKernelGGL(k_reseed_collect, dim3(grid_for(t->NN, 4096)), dim3(256), 0, t->stream, A, U, rc, (int32_t)cap64,
                                (const double *)t->elev, rc + 1);
-            std::vector<ReseedCell> hu((size_t)unfinished);
             HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            const int64_t unfinished = (int64_t)t->h_counters[60];
+            if (unfinished == 0) {
+                // every cell carries a level stamp although the schedule did not process all of them: seen with the queue
+                // schedule on tiles with circular drainage (a queued cell of a loop is never processed).  Not silently.
+                pydem_set_error("sweep: %lld cells were scheduled but never processed (PYDEM_SWEEP_MODE=queue does not support this tile's "
+                                "circular drainage; use the default schedule)", (long long)(t->NN - (int64_t)t->h_counters[3]));
+                return -5;
+            }
+            t->circular_cells = unfinished;
+            if (unfinished > cap64) {
+                pydem_set_error("circular drainage: %lld unfinished cells are more than the sequential replay of the re-seed loop is meant for", (long long)unfinished);
+                return -5;
+            }
+            std::vector<ReseedCell> hu((size_t)unfinished);
             HIP_TRY(hipMemcpyAsync(hu.data(), U, hu.size() * sizeof(ReseedCell), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
-            if ((int64_t)t->h_counters[60] != unfinished) { pydem_set_error("circular drainage: unfinished-cell count mismatch (%d collected, %lld expected)", t->h_counters[60], (long long)unfinished); return -5; }
             std::sort(hu.begin(), hu.end(), [](const ReseedCell &a, const ReseedCell &b) { return a.c < b.c; });
             HIP_TRY(hipMemcpyAsync(U, hu.data(), hu.size() * sizeof(ReseedCell), hipMemcpyHostToDevice, t->stream));
             hipLaunchKernelGGL(k_reseed_replay, dim3(1), dim3(64), 0, t->stream, A, (const ReseedCell *)U, (int32_t)unfinished,
