@@ -52,6 +52,7 @@ struct CondArgs {
     const int32_t *count;
     int32_t *labels;         // root cell per mask cell
     int32_t *rid;            // [NN] region index of a ROOT cell
+    int32_t *creg;           // [NN] region index of every mask cell (one hop instead of two in the per-cell kernels)
     int f32;                 // the elevations are float32 values: `rim - 1` rounds in float32 (:424)
     int below_sea;
 };
@@ -112,6 +113,15 @@ __global__ void k_region_index(CondArgs A, int32_t *nreg)
     }
 }
 
+__global__ void k_cell_region(CondArgs A)
+{
+    const int32_t nf = *A.count;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
+        const int32_t c = A.list[q];
+        A.creg[c] = A.rid[A.labels[c]];
+    }
+}
+
 __global__ void k_region_init(Regions R, int32_t nreg, int n, int m)
 {
     for (int32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nreg; r += gridDim.x * blockDim.x) {
@@ -156,7 +166,7 @@ __global__ void k_art_scan(CondArgs A, Regions R, double max_area)
         bool bad = false;
         if (valid) {
             const int32_t c = A.list[q];
-            r = A.rid[A.labels[c]];
+            r = A.creg[c];
             const int i = c / m, j = c - i * m;
             bad = (i == 0 || j == 0 || i == n - 1 || j == m - 1);                 // the one-pixel rim must lie inside (:414-415)
             const double level = A.elev[c];
@@ -190,7 +200,7 @@ __global__ void k_art_apply(CondArgs A, Regions R, double max_area)
     const int32_t nf = *A.count;
     for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
         const int32_t c = A.list[q];
-        const int32_t r = A.rid[A.labels[c]];
+        const int32_t r = A.creg[c];
         if ((R.flags[r] & RF_BAD) || (double)R.size[r] > max_area) continue;     // :419-420
         const double v = A.elev[c];
         A.elev[c] = A.f32 ? (double)((float)v + 1.0f) : v + 1;                   // :425 (in the array's dtype)
@@ -213,7 +223,7 @@ __global__ void k_flat_scan(CondArgs A, Regions R)
         unsigned long long low = ~0ull;
         if (valid) {
             const int32_t c = A.list[q];
-            r = A.rid[A.labels[c]];
+            r = A.creg[c];
             i = c / m; j = c - i * m;
             edge = (i == 0 || j == 0 || i == n - 1 || j == m - 1);
             const double level = A.elev[c];
@@ -333,7 +343,7 @@ __global__ void k_centre_pass(CondArgs A, Regions R, int pass)
         bool want = false;
         if (valid) {
             c = A.list[q];
-            r = A.rid[A.labels[c]];
+            r = A.creg[c];
             want = (R.flags[r] & RF_NEED_CENTRE) != 0;
             if (want) { const int i = c / m, j = c - i * m; k = dkey(centre_dist(R, r, i, j, n, m)); }
         }
@@ -367,7 +377,7 @@ __global__ void k_flat_seed(CondArgs A, Regions R, double *dh, double *dl)
         bool wait_hi = false, wait_lo = false;
         if (valid) {
             const int32_t c = A.list[q];
-            r = A.rid[A.labels[c]];
+            r = A.creg[c];
             const int32_t fl = R.flags[r];
             const int i = c / m, j = c - i * m;
             const bool on_edge = (i == 0 || j == 0 || i == n - 1 || j == m - 1);
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(256) void k_flat_sweep(CondArgs A, Regions R, const
     const int n = A.n, m = A.m;
     for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < na; q += gridDim.x * blockDim.x) {
         const int32_t c = alist[q];
-        const int32_t r = A.rid[A.labels[c]];
+        const int32_t r = A.creg[c];
         const int32_t fl = R.flags[r];
         const bool act_hi = R.done_hi[r] >= sweep, act_lo = R.done_lo[r] >= sweep;
         const double oh = dh0[c], ol = dl0[c];
@@ -468,7 +478,7 @@ __device__ __forceinline__ void flat_sweep_entry(const CondArgs &A, const Region
                                                  const double *__restrict__ dl0, double *__restrict__ dl1, int sweep, double source_tol)
 {
     const int n = A.n, m = A.m;
-    const int32_t r = A.rid[A.labels[c]];
+    const int32_t r = A.creg[c];
     const int32_t fl = R.flags[r];
     const bool act_hi = R.done_hi[r] >= sweep, act_lo = R.done_lo[r] >= sweep;
     const double oh = dh0[c], ol = dl0[c];
@@ -478,15 +488,23 @@ __device__ __forceinline__ void flat_sweep_entry(const CondArgs &A, const Region
         const double level = A.elev[c];
         const double src_max = (fl & RF_SOURCE) ? dunkey(R.lowest_bits[r]) + source_tol : 0.0;   // lowest + tol (:347)
         double card_h = oh, all_h = oh, card_l = ol, all_l = ol;
+        // all loads of the 8 neighbours in one batch (mask, both distances, elevation): the sweeps are chains of dependent
+        // round trips, a few hundred cells per sweep
+        uint8_t nmask[9]; double ndh[9], ndl[9], nz[9]; bool inb[9];
+#pragma unroll
         for (int d = 0; d < 9; d++) {
-            if (d == 4) continue;
             const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
-            if (ii < 0 || ii >= n || jj < 0 || jj >= m) continue;
-            const int32_t nb = ii * m + jj;
+            inb[d] = d != 4 && ii >= 0 && ii < n && jj >= 0 && jj < m;
+            const int32_t nb = inb[d] ? ii * m + jj : c;
+            nmask[d] = A.mask[nb]; ndh[d] = dh0[nb]; ndl[d] = dl0[nb]; nz[d] = A.elev[nb];
+        }
+#pragma unroll
+        for (int d = 0; d < 9; d++) {
+            if (!inb[d]) continue;
             double vh, vl;
-            if (A.mask[nb]) { vh = dh0[nb]; vl = dl0[nb]; }
+            if (nmask[d]) { vh = ndh[d]; vl = ndl[d]; }
             else {
-                const double z = A.elev[nb];
+                const double z = nz[d];
                 vh = ((fl & RF_SOURCE) && z > level && z <= src_max) ? 0.0 : INFINITY;
                 vl = ((fl & RF_DRAIN) && z == level) ? 0.0 : INFINITY;
             }
@@ -569,7 +587,7 @@ __global__ void k_flat_active(CondArgs A, Regions R, const int32_t *__restrict__
 {
     for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < na; q += gridDim.x * blockDim.x) {
         const int32_t c = alist[q];
-        const int32_t r = A.rid[A.labels[c]];
+        const int32_t r = A.creg[c];
         // (a region that stopped in the last sweep stays for one more batch: those sweeps copy its final values
         // into the other buffer of the ping-pong pair, so that both agree when the region leaves the list)
         if ((R.flags[r] & RF_GENERAL) && (R.done_hi[r] >= sweep - 1 || R.done_lo[r] >= sweep - 1)) out[agg_slot_c(nout)] = c;
@@ -583,7 +601,7 @@ __global__ void k_flat_interp(CondArgs A, Regions R, const double *__restrict__ 
     const int n = A.n, m = A.m;
     for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
         const int32_t c = A.list[q];
-        const int32_t r = A.rid[A.labels[c]];
+        const int32_t r = A.creg[c];
         const int32_t fl = R.flags[r];
         if (!(fl & RF_INTERP)) continue;
         const int i = c / m, j = c - i * m;
@@ -648,6 +666,7 @@ int label_regions(pydem_tile *t, CondArgs &A, int32_t *nf_out, int32_t *nreg_out
     hipLaunchKernelGGL(k_label_union, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, A.mask, t->labels, A.n, A.m);
     hipLaunchKernelGGL(k_label_flatten, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, t->labels);
     hipLaunchKernelGGL(k_region_index, dim3(g1), dim3(256), 0, t->stream, A, cnt + 1);
+    hipLaunchKernelGGL(k_cell_region, dim3(g1), dim3(256), 0, t->stream, A);
     HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     *nreg_out = t->h_counters[1];
@@ -666,9 +685,10 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
     PYDEM_TRY(tile_alloc(t, &t->labels, (size_t)t->NN));
     PYDEM_TRY(tile_alloc(t, &t->flatlist, (size_t)t->NN));
     PYDEM_TRY(tile_alloc(t, &t->queue[0], (size_t)t->NN));
+    PYDEM_TRY(tile_alloc(t, &t->queue[1], (size_t)t->NN));
     CondArgs A;
     A.n = n; A.m = m; A.NN = t->NN; A.elev = t->elev; A.built = nullptr; A.mask = t->flat0; A.list = t->flatlist; A.count = t->counters;
-    A.labels = t->labels; A.rid = t->queue[0]; A.f32 = t->elev_f32 ? 1 : 0; A.below_sea = below_sea;
+    A.labels = t->labels; A.rid = t->queue[0]; A.creg = t->queue[1]; A.f32 = t->elev_f32 ? 1 : 0; A.below_sea = below_sea;
     const int big = grid_of(t->NN, 8192);
     int32_t nf = 0, nreg = 0;
     // ---- quantisation artefacts
