@@ -169,6 +169,14 @@ int pydem_twi(pydem_tile *t, pydem_options *opt);
  * the count. */
 int pydem_tile_pit_edges(pydem_tile *t, int64_t *n, int32_t *src, int32_t *dst, double *w);
 
+/* The flow graph the sweep runs on, one packed word per cell [n,m] -- the device's form of the adjacency matrix A of
+ * _mk_adjacency_matrix (pydem/dem_processing.py:1072-1153; A is never materialised here): bits 0-7 = which of the 8
+ * neighbours (NW N NE W E SW S SE) drain into the cell, bit 8 / 9 = the regular out-edge to the facet's first / second
+ * neighbour survived the keep-filter (:1136-1137; weights = proportion, 1 - proportion), bit 10 / 11 = the cell has pit
+ * out- / in-edges (pydem_tile_pit_edges), bits 12-14 = facet index.  For tests and debugging (the edge set can be held
+ * against scipy's / the oracle's triplets). */
+int pydem_tile_graph_words(pydem_tile *t, uint32_t *out);
+
 /* Undo the slope patch of the drained pits (mag[pit] = -1 again, flats untouched).  In the
  * reference's directory flow the calc_uca worker never writes its patched slope back to the store
  * (pydem/process_manager.py:192-194), so later phases see slope == -1 at drained pits; the

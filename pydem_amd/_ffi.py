@@ -81,6 +81,7 @@ SYMBOLS = {
     'pydem_uca_edge_flush': (C.c_int, [_P]),
     'pydem_twi': (C.c_int, [_P, C.POINTER(Options)]),
     'pydem_tile_pit_edges': (C.c_int, [_P, C.POINTER(C.c_int64), _P, _P, _P]),
+    'pydem_tile_graph_words': (C.c_int, [_P, _P]),
     'pydem_tile_restore_pit_slopes': (C.c_int, [_P]),
     'pydem_bench_stencil': (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     'pydem_drain_area': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, _P, _P, C.c_int, C.c_int]),
@@ -274,6 +275,12 @@ class Tile(object):
 
     def twi(self, opt):
         check(self.lib.pydem_twi(self._h, C.byref(opt)))
+
+    def graph_words(self):
+        """The packed graph word of every cell (static bits: in-mask, out flags, pit flags, facet), uint32 [n, m]."""
+        out = np.empty(self.shape, np.uint32)
+        check(self.lib.pydem_tile_graph_words(self._h, out.ctypes.data_as(_P)))
+        return out
 
     def pit_edges(self):
         """(pit, drain, weight) triplets of the last uca() call, in emission order."""

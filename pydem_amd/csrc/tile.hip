@@ -605,6 +605,18 @@ int pydem_tile_pit_edges(pydem_tile *t, int64_t *n, int32_t *src, int32_t *dst, 
     return 0;
 }
 
+// the static half of the packed graph word of every cell (uca.hip): bits 0-7 in-mask (NW N NE W E SW S SE), 8 / 9 regular
+// out-edge to the facet's first / second neighbour, 10 / 11 pit out- / in-edges, 12-14 facet index
+int pydem_tile_graph_words(pydem_tile *t, uint32_t *out)
+{
+    HIP_TRY(hipSetDevice(t->device));
+    if (!t->graph_valid || !t->indeg) { pydem_set_error("pydem_tile_graph_words: no flow graph on this tile (pydem_uca / pydem_build_graph first)"); return -3; }
+    HIP_TRY(hipMemcpyAsync(out, t->indeg, (size_t)t->NN * 4, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    for (int64_t c = 0; c < t->NN; c++) out[c] &= 0x7FFFu;
+    return 0;
+}
+
 int pydem_tile_restore_pit_slopes(pydem_tile *t)
 {
     t->edge_clean = false;      // these stages reuse the edge-round work lists

@@ -247,3 +247,57 @@ def test_config1_cone256_device_vs_reference_pinned_oracle():
     assert np.array_equal(np.asarray(dp.flats, bool), np.asarray(o.flats, bool))
     assert np.array_equal(dp.edge_todo, o.edge_todo) and np.array_equal(dp.edge_done, o.edge_done)
     _close(dp.mag, o.mag, 'mag'); _close(dp.direction, o.direction, 'direction'); _close(dp.uca, o.uca, 'uca'); _close(twi, twi_o, 'twi')
+
+
+@pytest.mark.parametrize('quantised', [False, True])
+def test_device_edge_set_equals_oracle_adjacency(quantised):
+    """A4 directly: the device never materialises the adjacency matrix of _mk_adjacency_matrix (:1072-1153), it keeps one
+    packed word per cell (in-mask, out flags, facet) plus the pit -> drain side list.  The edge set those words describe
+    -- regular out-edges with weights (proportion, 1 - proportion), pit edges through the same keep-filter (:1136-1137) --
+    must be the oracle's CSC triplets (themselves pinned against scipy's in tests/test_oracle_golden.py): same (source,
+    target) pairs exactly, weights within RTOL, and every edge present in its target's in-mask."""
+    from oracle import oracle as O
+    from pydem_amd import DEMProcessor, synth
+    n, m = 310, 270
+    z = synth.fractal(n, m, seed=33, top_shift=6, n_octaves=6, zrange=(35.0 if quantised else 400.0))
+    if quantised:
+        z = np.rint(z)
+    o = O.OracleDEM(z, dX=10.0, dY=12.0, drain_pits=True); o.calc_uca()
+    indptr, indices, data = o.A
+    dp = DEMProcessor(elev=z, dX=10.0, dY=12.0, fill_flats=False, drain_pits_path=False, drain_pits=True)
+    dp.calc_uca()
+    words = dp._tile.graph_words().ravel()
+    prop = np.asarray(dp.proportion, float).ravel()
+    sec = ((words >> 12) & 7).astype(int)
+    e1r = np.array([0, -1, -1, 0, 0, 1, 1, 0]); e1c = np.array([1, 0, 0, -1, -1, 0, 0, 1])
+    e2r = np.array([-1, -1, -1, -1, 1, 1, 1, 1]); e2c = np.array([1, 1, -1, -1, -1, -1, 1, 1])
+    cells = np.arange(n * m)
+    dev = {}
+    for bit, dr, dc, w in ((8, e1r, e1c, prop), (9, e2r, e2c, 1 - prop)):
+        has = ((words >> bit) & 1).astype(bool)
+        src = cells[has]; dst = src + dr[sec[has]] * m + dc[sec[has]]
+        for a, b, x in zip(src.tolist(), dst.tolist(), w[has].tolist()):
+            dev[(a, b)] = dev.get((a, b), 0.0) + x
+    ps, pd, pw = dp._tile.pit_edges()
+    zz = z.ravel()
+    keep = ~np.isnan(pw) & (pw > 1e-8) & (zz[pd] <= zz[ps])                       # :1136-1137
+    assert (((words[ps] >> 10) & 1) == 1).all() and (((words[pd[keep]] >> 11) & 1) == 1).all()
+    for a, b, x in zip(ps[keep].tolist(), pd[keep].tolist(), pw[keep].tolist()):
+        dev[(a, b)] = dev.get((a, b), 0.0) + x
+    ref = {}
+    for i in range(n * m):
+        for q in range(indptr[i], indptr[i + 1]):
+            ref[(i, int(indices[q]))] = float(data[q])
+    assert set(dev) == set(ref), (len(dev), len(ref), sorted(set(dev) ^ set(ref))[:5])
+    worst = max(abs(dev[k] - ref[k]) / max(abs(ref[k]), 1e-300) for k in ref)
+    assert worst <= RTOL, worst
+    # the in-mask of a target holds the bit of every regular edge into it (bit order NW N NE W E SW S SE)
+    nb = {(-1, -1): 0, (-1, 0): 1, (-1, 1): 2, (0, -1): 3, (0, 1): 4, (1, -1): 5, (1, 0): 6, (1, 1): 7}
+    inmask = np.zeros(n * m, np.uint32)
+    for bit, dr, dc in ((8, e1r, e1c), (9, e2r, e2c)):
+        has = ((words >> bit) & 1).astype(bool)
+        src = cells[has]; ddr = dr[sec[has]]; ddc = dc[sec[has]]
+        dst = src + ddr * m + ddc
+        bits = np.array([nb[(-a, -b)] for a, b in zip(ddr.tolist(), ddc.tolist())], np.uint32)
+        np.bitwise_or.at(inmask, dst, (1 << bits).astype(np.uint32))
+    assert np.array_equal(inmask, words & 0xFF)
