@@ -5,7 +5,8 @@ pydem/process_manager.py:393-1318) for the part SURVEY.md section 8 puts in scop
 discovery (compute_grid :517-565), overlap / edge-line bookkeeping (compute_grid_overlaps
 :601-740), the four phases (process_elevation :993, process_aspect_slope :1010, process_uca :1032,
 process_uca_edges :1090), TWI (:1290-1317) and the stitched non-overlap arrays
-(save_non_overlap_data :742-766).  GeoTIFF export / overviews are out of scope.
+(save_non_overlap_data :742-766), GeoTIFF export with 'average' overviews (:862-931) and the overview pyramid
+(process_overviews :933-991).
 
 What is different by design:
   * tiles stay resident on their GPU between phases (the reference round-trips every array
@@ -1139,14 +1140,43 @@ class ProcessManager(object):
         self.out_file_noverlap = out
         return out
 
+    def process_overviews(self, out_path=None, keys=('elev', 'uca', 'aspect', 'slope', 'twi'), overviews=(3, 3 ** 2, 3 ** 3, 3 ** 4, 3 ** 5, 3 ** 6, 3 ** 7)):
+        """The overview pyramid of the stitched results (reference :933-991 with calc_overview :317-352): level `ov` is the
+        block mean of the previous level by the factor between them, named '<key>_<ov>'; a key's pyramid ends before the
+        first level that would have a side of <= factor cells.  The reference walks its zarr store chunk by chunk; here a
+        level is one array = one chunk (`raster.block_mean_overview`, bit-identical to calc_overview on that chunk).
+        Returns {name: array}; with `out_path` every level is also written as '<name>.npy' there."""
+        from . import raster
+        if not getattr(self, 'out_file_noverlap', None):
+            self.save_non_overlap_data(keys=[k for k in keys])
+        out = {}
+        for key in keys:
+            last, last_ov = np.asarray(self.out_file_noverlap[key], np.float64), 1
+            for ov in overviews:
+                factor = ov // last_ov
+                new_shape = [-(-n // factor) for n in last.shape]
+                if any(n <= factor for n in new_shape):
+                    break
+                last = raster.block_mean_overview(last, factor).astype(self.dtype)
+                last_ov = ov
+                out['%s_%d' % (key.split('_')[0], ov)] = last
+        if out_path is not None:
+            os.makedirs(out_path, exist_ok=True)
+            for name, arr in out.items():
+                np.save(os.path.join(out_path, name + '.npy'), arr)
+        self.overviews = out
+        return out
+
     def save_geotiff(self, filename, key, dtype, crs=None, max_files=2, rescale=None, overview_type=None, overview_factors=None):
         """One stitched result as a GeoTIFF (reference :862-931): same geotransform rules (one pixel size for the whole
-        mosaic, else NotImplementedError), same optional rescaling.  Written by pydem_amd/raster.py as one Deflate strip;
-        tiling / BigTIFF / overviews of the reference's rasterio call are not reproduced (`overview_type` must be None).
+        mosaic, else NotImplementedError), same optional rescaling.  Written by pydem_amd/raster.py, one Deflate strip per
+        image (tiling / BigTIFF of the reference's rasterio call are not reproduced).  `overview_type='average'` adds
+        reduced-resolution images (block means; default factors 3, 9, ... like :928-929) behind the full one; the other
+        resampling kinds of rasterio are not implemented.
         `crs`: 'projected' or anything else = geographic WGS-84 (the default follows the first input tile)."""
         from . import raster
-        if overview_type is not None:
-            raise NotImplementedError("overviews are not written (use rasterio / gdaladdo on the result)")
+        if overview_type not in (None, 'average'):
+            raise NotImplementedError("overview_type %r: only 'average' overviews are written" % (overview_type,))
         data = self.out_file_noverlap[key]
         dlats = np.unique(np.round(self.index[self.grid_id2i.max(axis=1), 5], decimals=6))
         dlons = np.unique(np.round(self.index[self.grid_id2i.max(axis=0), 4], decimals=6))
@@ -1161,5 +1191,17 @@ class ProcessManager(object):
             crs = 'projected' if meta.get('is_projected', 'dX' not in meta) else 'geographic'
         if rescale:
             data = (data - rescale[0]) / (rescale[1] - rescale[0]) * rescale[2]
+        levels = []
+        if overview_type is not None:
+            if overview_factors is None:
+                overview_factors = [3 ** i for i in range(1, int(np.log(max(self.grid_size_tot_unique)) / np.log(3)))]   # :928-929
+            last, last_f = np.asarray(data, np.float64), 1
+            for fct in overview_factors:
+                if fct % last_f == 0 and fct > last_f:
+                    last = raster.block_mean_overview(last, fct // last_f, like_reference=False)
+                else:
+                    last = raster.block_mean_overview(np.asarray(data, np.float64), fct, like_reference=False)
+                last_f = fct
+                levels.append(last)
         raster.write_geotiff(filename, np.asarray(data).astype(dtype), (dlon, 0.0, left, 0.0, dlat, top),
-                             projected=(crs == 'projected'), compress=True)
+                             projected=(crs == 'projected'), compress=True, overviews=levels)

@@ -112,7 +112,8 @@ class GeoTiff(object):
         return self.array
 
 
-def read_geotiff(path):
+def read_geotiff(path, page=0):
+    """`page` = index in the file's IFD chain: 0 is the full-resolution raster, the overviews written by write_geotiff follow."""
     with open(path, 'rb') as fh:
         buf = fh.read()
     if buf[:2] == b'II':
@@ -130,6 +131,15 @@ def read_geotiff(path):
         ifd = struct.unpack(bo + 'Q', buf[8:16])[0]
     else:
         raise ValueError("%s: unknown TIFF version %d" % (path, magic))
+    for _ in range(int(page)):                                          # walk the chain of image file directories
+        if big:
+            cnt_ = struct.unpack(bo + 'Q', buf[ifd:ifd + 8])[0]
+            ifd = struct.unpack(bo + 'Q', buf[ifd + 8 + 20 * cnt_: ifd + 16 + 20 * cnt_])[0]
+        else:
+            cnt_ = struct.unpack(bo + 'H', buf[ifd:ifd + 2])[0]
+            ifd = struct.unpack(bo + 'I', buf[ifd + 2 + 12 * cnt_: ifd + 6 + 12 * cnt_])[0]
+        if ifd == 0:
+            raise IndexError("%s has no page %d" % (path, page))
     if big:
         n = struct.unpack(bo + 'Q', buf[ifd:ifd + 8])[0]
         base, esz, cnt_fmt, inline = ifd + 8, 20, 'Q', 8
@@ -247,57 +257,108 @@ def read_geotiff(path):
     return GeoTiff(out, transform, projected, ellipsoid, nodata)
 
 
-def write_geotiff(path, array, transform, projected=False, nodata=None, compress=False):
-    """Single-band little-endian GeoTIFF, one strip (uncompressed or Deflate).  `transform` = (a, b, c, d, e, f)."""
-    arr = np.ascontiguousarray(array)
-    if arr.dtype.byteorder == '>':
-        arr = arr.astype(arr.dtype.newbyteorder('<'))
-    kind = {'u': 1, 'i': 2, 'f': 3}[arr.dtype.kind]
-    h, w = arr.shape
-    payload = arr.tobytes()
-    if compress:
-        payload = zlib.compress(payload, 6)
+def write_geotiff(path, array, transform, projected=False, nodata=None, compress=False, overviews=()):
+    """Single-band little-endian GeoTIFF, one strip per image (uncompressed or Deflate).  `transform` = (a, b, c, d, e, f).
+    `overviews`: reduced-resolution copies (arrays, largest first) written as further image file directories behind the
+    full-resolution one (NewSubfileType = 1: what GDAL / rasterio list as the dataset's overviews)."""
     a, b, c, d, e, f = transform
-    entries = []      # (tag, type, count, packed bytes)
+    images = [np.ascontiguousarray(array)] + [np.ascontiguousarray(o).astype(np.asarray(array).dtype) for o in overviews]
+    h0, w0 = images[0].shape
+    blocks = []       # per image: (entries, payload)
+    for level, arr in enumerate(images):
+        if arr.dtype.byteorder == '>':
+            arr = arr.astype(arr.dtype.newbyteorder('<'))
+        kind = {'u': 1, 'i': 2, 'f': 3}[arr.dtype.kind]
+        h, w = arr.shape
+        payload = arr.tobytes()
+        if compress:
+            payload = zlib.compress(payload, 6)
+        entries = []      # (tag, type, count, packed bytes)
 
-    def add(tag, typ, values):
-        fmt = _TYPE_FMT[typ]
-        if typ == 2:
-            raw = values.encode('latin-1') + b'\x00'
-            entries.append((tag, typ, len(raw), raw))
-        else:
-            entries.append((tag, typ, len(values), struct.pack('<' + fmt * len(values), *values)))
+        def add(tag, typ, values, entries=entries):
+            fmt = _TYPE_FMT[typ]
+            if typ == 2:
+                raw = values.encode('latin-1') + b'\x00'
+                entries.append((tag, typ, len(raw), raw))
+            else:
+                entries.append((tag, typ, len(values), struct.pack('<' + fmt * len(values), *values)))
 
-    add(256, 4, [w]); add(257, 4, [h]); add(258, 3, [arr.dtype.itemsize * 8]); add(259, 3, [8 if compress else 1])
-    add(262, 3, [1]); add(273, 4, [0]); add(277, 3, [1]); add(278, 4, [h]); add(279, 4, [len(payload)]); add(339, 3, [kind])
-    add(33550, 12, [a, -e, 0.0]); add(33922, 12, [0.0, 0.0, 0.0, c, f, 0.0])
-    add(34735, 3, [1, 1, 0, 3, 1024, 0, 1, 1 if projected else 2, 1025, 0, 1, 1, 2048, 0, 1, 4326])
-    if nodata is not None:
-        add(42113, 2, repr(float(nodata)))
-    entries.sort(key=lambda t: t[0])
-    ifd_off = 8
-    ifd_len = 2 + 12 * len(entries) + 4
-    extra_off = ifd_off + ifd_len
-    extra = b''
-    strip_entry = None
-    body = b''
-    for k, (tag, typ, cnt, raw) in enumerate(entries):
-        if len(raw) <= 4:
-            val = raw + b'\x00' * (4 - len(raw))
-        else:
-            val = struct.pack('<I', extra_off + len(extra))
-            extra += raw + (b'\x00' if len(raw) % 2 else b'')
-        if tag == 273:
-            strip_entry = k
-        body += struct.pack('<HHI', tag, typ, cnt) + val
-    data_off = extra_off + len(extra)
-    k = strip_entry
-    body = body[:12 * k + 8] + struct.pack('<I', data_off) + body[12 * k + 12:]
+        if level > 0:
+            add(254, 4, [1])                                            # reduced-resolution version of another image
+        add(256, 4, [w]); add(257, 4, [h]); add(258, 3, [arr.dtype.itemsize * 8]); add(259, 3, [8 if compress else 1])
+        add(262, 3, [1]); add(273, 4, [0]); add(277, 3, [1]); add(278, 4, [h]); add(279, 4, [len(payload)]); add(339, 3, [kind])
+        # (an overview covers the same ground with fewer, larger pixels)
+        add(33550, 12, [a * w0 / w, -e * h0 / h, 0.0]); add(33922, 12, [0.0, 0.0, 0.0, c, f, 0.0])
+        add(34735, 3, [1, 1, 0, 3, 1024, 0, 1, 1 if projected else 2, 1025, 0, 1, 1, 2048, 0, 1, 4326])
+        if nodata is not None:
+            add(42113, 2, repr(float(nodata)))
+        entries.sort(key=lambda t: t[0])
+        blocks.append((entries, payload))
+    # layout: header | IFD 0 | its long values | its strip | IFD 1 | ...
+    out = bytearray(b'II' + struct.pack('<HI', 42, 8))
+    for level, (entries, payload) in enumerate(blocks):
+        ifd_off = len(out)
+        ifd_len = 2 + 12 * len(entries) + 4
+        extra_off = ifd_off + ifd_len
+        extra = b''
+        body = b''
+        strip_entry = None
+        for k, (tag, typ, cnt, raw) in enumerate(entries):
+            if len(raw) <= 4:
+                val = raw + b'\x00' * (4 - len(raw))
+            else:
+                val = struct.pack('<I', extra_off + len(extra))
+                extra += raw + (b'\x00' if len(raw) % 2 else b'')
+            if tag == 273:
+                strip_entry = k
+            body += struct.pack('<HHI', tag, typ, cnt) + val
+        data_off = extra_off + len(extra)
+        k = strip_entry
+        body = body[:12 * k + 8] + struct.pack('<I', data_off) + body[12 * k + 12:]
+        end = data_off + len(payload)
+        end += end % 2                                                  # IFDs start on a word boundary
+        nxt = end if level + 1 < len(blocks) else 0
+        if end >= 1 << 32:
+            raise ValueError("write_geotiff: the file would exceed the 4 GiB of classic TIFF")
+        out += struct.pack('<H', len(entries)) + body + struct.pack('<I', nxt) + extra + payload
+        if len(out) < end:
+            out += b'\x00'
     with open(path, 'wb') as fh:
-        fh.write(b'II' + struct.pack('<HI', 42, ifd_off))
-        fh.write(struct.pack('<H', len(entries)) + body + struct.pack('<I', 0))
-        fh.write(extra)
-        fh.write(payload)
+        fh.write(bytes(out))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# overviews (reduced-resolution copies)
+# ---------------------------------------------------------------------------------------------------------------
+def block_mean_overview(data, factor, like_reference=True):
+    """One level of the overview pyramid: every output cell is the mean of a factor x factor block of `data`; the output
+    has ceil(n / factor) rows and columns, the last row / column hold the blocks that stick out of the array.
+
+    like_reference=True reproduces calc_overview of the reference (pydem/process_manager.py:317-352) bit for bit -- same
+    summation order (numpy's mean over a contiguous run of factor^2 values) and its treatment of the partial blocks: the
+    right-hand blocks are means over the columns that are left, the corner is the mean of what is left of it, and the
+    BOTTOM row is written with the reference's reshape (:340-342), which averages the leftover rows over every
+    (n_cols // factor)-th column instead of over the block's own columns.  like_reference=False gives the plain partial-
+    block means there too (what GDAL's 'average' overview resampling does), used for the GeoTIFF overviews."""
+    data = np.asarray(data, np.float64)
+    f = int(factor)
+    n, m = data.shape
+    R, C = n // f, m // f
+    out = np.zeros((-(-n // f), -(-m // f)), np.float64)
+    full = np.ascontiguousarray(data[:R * f, :C * f].reshape(R, f, C, f).transpose(0, 2, 1, 3)).reshape(R, C, f * f)
+    out[:R, :C] = full.mean(axis=-1)
+    with np.errstate(invalid='ignore'):
+        if m > C * f:
+            out[:R, C:] = np.ascontiguousarray(data[:R * f, C * f:]).reshape(R, -1).mean(axis=1)[:, None]
+        if n > R * f:
+            rest = np.ascontiguousarray(data[R * f:, :C * f])
+            if like_reference:
+                out[R:, :C] = rest.reshape(-1, C).mean(axis=0)[None, :]
+            else:
+                out[R:, :C] = rest.reshape(n - R * f, C, f).transpose(1, 0, 2).reshape(C, -1).mean(axis=1)[None, :]
+        if n > R * f and m > C * f:
+            out[R:, C:] = data[R * f:, C * f:].mean()
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------

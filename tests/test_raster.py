@@ -236,3 +236,44 @@ def test_directory_flow_from_geotiff_tiles(tmp_path):
     ds = raster.read_geotiff(out)
     assert ds.array.dtype == np.float32 and np.array_equal(ds.array, compact1['uca'].astype('float32'), equal_nan=True)
     assert ds.is_projected and abs(ds.bounds[0] - pm1.index[:, 0].min()) < 1e-9 and abs(ds.bounds[3] - pm1.index[:, 3].max()) < 1e-9
+    # ... with 'average' overviews (:927-931): further images in the file, same ground, block means of the full raster
+    out2 = str(tmp_path / 'uca_ov.tif')
+    pm1.save_geotiff(out2, 'uca', 'float64', overview_type='average', overview_factors=[3, 9])
+    full = raster.read_geotiff(out2)
+    ov1, ov2 = raster.read_geotiff(out2, 1), raster.read_geotiff(out2, 2)
+    assert np.array_equal(full.array, compact1['uca'], equal_nan=True)
+    want1 = raster.block_mean_overview(compact1['uca'], 3, like_reference=False)
+    assert np.array_equal(ov1.array, want1, equal_nan=True) and ov1.shape == tuple(-(-n // 3) for n in full.shape)
+    assert np.array_equal(ov2.array, raster.block_mean_overview(want1, 3, like_reference=False), equal_nan=True)
+    assert np.allclose(ov1.bounds, full.bounds) and np.allclose(ov2.bounds, full.bounds)
+    with pytest.raises(IndexError):
+        raster.read_geotiff(out2, 3)
+    with pytest.raises(NotImplementedError):
+        pm1.save_geotiff(out2, 'uca', 'float64', overview_type='cubic')
+    # the overview pyramid of the stitched arrays (process_overviews :933-991)
+    pyr = pm1.process_overviews(out_path=str(tmp_path / 'ov'), keys=('uca', 'twi'), overviews=(3, 9, 27, 81))
+    lvl = np.asarray(compact1['uca'], np.float64)
+    names = []
+    for ov in (3, 9, 27, 81):
+        if any(-(-n // 3) <= 3 for n in lvl.shape):
+            break
+        lvl = raster.block_mean_overview(lvl, 3)
+        names.append('uca_%d' % ov)
+        assert np.array_equal(pyr['uca_%d' % ov], lvl, equal_nan=True)
+        assert np.array_equal(np.load(str(tmp_path / 'ov' / ('uca_%d.npy' % ov))), lvl, equal_nan=True)
+    assert names and sorted(k for k in pyr if k.startswith('uca_')) == sorted(names)
+
+
+def test_block_mean_overview_equals_the_reference_function():
+    """raster.block_mean_overview against calc_overview of the unmodified reference (pydem/process_manager.py:317-352;
+    tests/golden/overview_cases.npz, written by oracle/ref_harness/gen_golden_overview.py): full blocks, partial blocks on
+    the right / bottom / corner (including the reference's reshape of the bottom row), NaN cells, an all-zero array --
+    bit for bit.  With like_reference=False the bottom row holds the plain partial-block means."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'overview_cases.npz'))
+    for k in range(int(g['n_cases'])):
+        out = raster.block_mean_overview(g['in_%d' % k], int(g['factor_%d' % k]))
+        assert out.shape == g['out_%d' % k].shape and np.array_equal(out, g['out_%d' % k], equal_nan=True), k
+    z = np.arange(35, dtype=float).reshape(5, 7)
+    plain = raster.block_mean_overview(z, 2, like_reference=False)
+    assert plain.shape == (3, 4)
+    assert plain[2, 1] == z[4, 2:4].mean() and plain[0, 3] == z[0:2, 6].mean() and plain[2, 3] == z[4, 6] and plain[1, 1] == z[2:4, 2:4].mean()
