@@ -1140,6 +1140,21 @@ class ProcessManager(object):
         self.out_file_noverlap = out
         return out
 
+    def save_non_overlap_data_geotiff(self, dtype, crs=None, new_path=None, keys=('elev', 'uca', 'aspect', 'slope', 'twi'), chunks=None,
+                                      overview_type=None, overview_factors=None, rescale=None):
+        """One GeoTIFF per key, '<new_path>/<key>.tiff', of the stitched non-overlap arrays (reference :786-860; 'uca'
+        includes the edge corrections).  Same geotransform, rescaling and overview options as `save_geotiff`; the block
+        size `chunks` of the reference's tiled BigTIFF has no meaning for the single-strip files written here."""
+        if new_path is None:
+            new_path = str(getattr(self, 'out_path', None) or self.in_path).replace('.zarr', '')
+        os.makedirs(new_path, exist_ok=True)
+        have = getattr(self, 'out_file_noverlap', None) or {}
+        if any(k not in have for k in keys):
+            self.save_non_overlap_data(keys=tuple(keys))
+        for key in keys:
+            self.save_geotiff(os.path.join(new_path, key + '.tiff'), key, dtype, crs=crs, rescale=rescale,
+                              overview_type=overview_type, overview_factors=overview_factors)
+
     def process_overviews(self, out_path=None, keys=('elev', 'uca', 'aspect', 'slope', 'twi'), overviews=(3, 3 ** 2, 3 ** 3, 3 ** 4, 3 ** 5, 3 ** 6, 3 ** 7)):
         """The overview pyramid of the stitched results (reference :933-991 with calc_overview :317-352): level `ov` is the
         block mean of the previous level by the factor between them, named '<key>_<ov>'; a key's pyramid ends before the

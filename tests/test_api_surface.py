@@ -15,7 +15,7 @@ REF = json.load(open(os.path.join(HERE, 'golden', 'ref_api_surface.json')))
 # file-name helpers / loaders of the reference's on-disk layout, the multiprocessing pool
 NOT_PROVIDED_DP = {'trait_names', 'get_fn', 'get_full_fn', 'load_array', 'load_direction', 'load_elevation', 'load_slope',
                    'load_uca'}
-NOT_PROVIDED_PM = {'trait_names', 'queue_processes', 'save_non_overlap_data_geotiff', 'update_uca_edge_metrics'}
+NOT_PROVIDED_PM = {'trait_names', 'queue_processes'}
 # state attributes of the reference instance that are results, not options
 RESULT_ATTRS = {'A', 'direction', 'done', 'flats', 'mag', 'proportion', 'section', 'twi', 'uca'}
 

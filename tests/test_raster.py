@@ -250,6 +250,12 @@ def test_directory_flow_from_geotiff_tiles(tmp_path):
         raster.read_geotiff(out2, 3)
     with pytest.raises(NotImplementedError):
         pm1.save_geotiff(out2, 'uca', 'float64', overview_type='cubic')
+    # one file per key (save_non_overlap_data_geotiff :786-860)
+    pm1.save_non_overlap_data_geotiff('float32', new_path=str(tmp_path / 'tiffs'), keys=('elev', 'twi'), overview_type='average')
+    for key in ('elev', 'twi'):
+        ds2 = raster.read_geotiff(str(tmp_path / 'tiffs' / (key + '.tiff')))
+        assert np.array_equal(ds2.array, compact1[key].astype('float32'), equal_nan=True), key
+        assert raster.read_geotiff(str(tmp_path / 'tiffs' / (key + '.tiff')), 1).shape == tuple(-(-n // 3) for n in ds2.shape)
     # the overview pyramid of the stitched arrays (process_overviews :933-991)
     pyr = pm1.process_overviews(out_path=str(tmp_path / 'ov'), keys=('uca', 'twi'), overviews=(3, 9, 27, 81))
     lvl = np.asarray(compact1['uca'], np.float64)
