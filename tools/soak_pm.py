@@ -34,7 +34,8 @@ def make_case(k):
     rng = np.random.default_rng(5000 + k)
     ny, nx = int(rng.integers(1, 4)), int(rng.integers(1, 4))
     ov = int(rng.integers(1, 4))
-    n, m = int(rng.integers(12 * ny, 90 * ny + 1)), int(rng.integers(12 * nx, 90 * nx + 1))
+    scale = int(os.environ.get('SOAK_SCALE', '1'))            # larger tiles: longer cascades, wide frontiers, the level kernels
+    n, m = int(rng.integers(12 * ny, 90 * ny + 1)) * scale, int(rng.integers(12 * nx, 90 * nx + 1)) * scale
     ts = int(rng.integers(2, 7))
     z = synth.fractal(n, m, seed=int(rng.integers(0, 1 << 30)), top_shift=ts, n_octaves=int(rng.integers(2, ts + 1)),
                       zmin=float(rng.choice([1.0, -15.0])), zrange=float(rng.choice([500.0, 60.0, 12.0])))
