@@ -91,6 +91,9 @@ typedef struct pydem_timings {
 const char *pydem_hip_last_error(void);
 int pydem_hip_device_count(int *count);
 int pydem_hip_device_name(int device, char *buf, int buflen);
+/* free / total bytes of the device's HBM (hipMemGetInfo): what a directory run sizes `tiles_in_flight` against, and the leak
+ * check of the test suite (no counterpart in the reference, whose tiles live in host memory). */
+int pydem_hip_device_memory(int device, int64_t *free_bytes, int64_t *total_bytes);
 
 int pydem_tile_create(int64_t n_rows, int64_t n_cols, int device, pydem_tile **out);
 int pydem_tile_destroy(pydem_tile *t);

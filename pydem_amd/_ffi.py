@@ -49,6 +49,7 @@ _PP = C.POINTER(C.c_void_p)
 SYMBOLS = {
     'pydem_hip_last_error': (C.c_char_p, []),
     'pydem_hip_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'pydem_hip_device_memory': (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'pydem_hip_device_name': (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     'pydem_tile_create': (C.c_int, [C.c_int64, C.c_int64, C.c_int, _PP]),
     'pydem_tile_destroy': (C.c_int, [_P]),
@@ -137,6 +138,13 @@ def device_count():
     n = C.c_int(0)
     check(load().pydem_hip_device_count(C.byref(n)))
     return n.value
+
+
+def device_memory(device=0):
+    """(free, total) bytes of the device's HBM."""
+    f, tot = C.c_int64(0), C.c_int64(0)
+    check(load().pydem_hip_device_memory(int(device), C.byref(f), C.byref(tot)))
+    return f.value, tot.value
 
 
 class Tile(object):

@@ -1354,10 +1354,9 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             t->pits.sorted_cap = ne;
         }
         // one persistent scratch block (allocating and freeing eight buffers per call costs more than the sorts)
-        size_t tmp_bytes = 0, tb2 = 0;
+        size_t tmp_bytes = 0;
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr,
                                                    (int32_t *)nullptr, ne, 0, 64, t->stream));
-        tb2 = tmp_bytes;
         const size_t ne8 = ((size_t)ne * 8 + 255) & ~(size_t)255, ne4 = ((size_t)ne * 4 + 255) & ~(size_t)255;
         const size_t need_sort = 4 * ne8 + 3 * ne4 + tmp_bytes + 256;
         if (t->pits.sort_bytes < need_sort) {
@@ -1369,14 +1368,10 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         uint64_t *k1 = (uint64_t *)sb, *k2 = (uint64_t *)(sb + ne8), *k1s = (uint64_t *)(sb + 2 * ne8), *k2s = (uint64_t *)(sb + 3 * ne8);
         int32_t *idx = (int32_t *)(sb + 4 * ne8), *i1 = (int32_t *)(sb + 4 * ne8 + ne4), *i2 = (int32_t *)(sb + 4 * ne8 + 2 * ne4);
         void *tmp = sb + 4 * ne8 + 3 * ne4;
-        (void)tb2;
         const int g = (int)(cdiv(ne, 256) < 1024 ? cdiv(ne, 256) : 1024);
         hipLaunchKernelGGL(k_pit_keys, dim3(g), dim3(256), 0, t->stream, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w, t->elev,
                            ne, k1, k2, idx);
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k1, k1s, idx, i1, ne, 0, 64, t->stream));
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, k2, k2s, idx, i2, ne, 0, 64, t->stream));
-        if (tb2 > tmp_bytes) tmp_bytes = tb2;
-        HIP_TRY(hipMalloc(&tmp, tmp_bytes));
+        // (the temporary storage of both sorts is the tail of the persistent block: its size only depends on ne)
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k1, k1s, idx, i1, ne, 0, 64, t->stream));
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k2, k2s, idx, i2, ne, 0, 64, t->stream));
         HIP_TRY(hipMemsetAsync(cnt + 10, 0, sizeof(int32_t), t->stream));

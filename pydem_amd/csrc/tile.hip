@@ -130,6 +130,16 @@ int pydem_hip_device_count(int *count)
     return 0;
 }
 
+int pydem_hip_device_memory(int device, int64_t *free_bytes, int64_t *total_bytes)
+{
+    size_t f = 0, tot = 0;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemGetInfo(&f, &tot));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)tot;
+    return 0;
+}
+
 int pydem_hip_device_name(int device, char *buf, int buflen)
 {
     hipDeviceProp_t p;

@@ -147,3 +147,24 @@ def test_hip_pits_with_nodata_vs_oracle(seed):
     assert np.array_equal(dp.section, o.section) and np.array_equal(dp.flats, o.flats.astype(bool))
     _close(dp.mag, o.mag, 'mag'); _close(dp.uca, o.uca, 'uca'); _close(twi, o.twi / 10, 'twi')
     assert np.array_equal(dp.edge_todo, o.edge_todo) and np.array_equal(dp.edge_done, o.edge_done)
+
+
+def test_repeated_steps_do_not_leak_device_memory():
+    """A tile that is recomputed step after step (bench.py, a directory run that revisits its tiles) must reach a steady
+    device footprint: every buffer of the terrain path is persistent or freed.  (Round 2 found a per-call allocation of
+    the pit edge sort's temporary storage that was never freed.)"""
+    import warnings
+    from pydem_amd import DEMProcessor, _ffi, synth
+    elev = synth.fractal(2048, 2048, seed=5, top_shift=7, n_octaves=7)
+    dp = DEMProcessor(elev=elev, dX=30.0, dY=30.0, fill_flats=False, drain_pits_path=False, drain_pits=True)
+    free = []
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for _ in range(12):
+            dp.calc_slopes_directions()
+            dp.calc_uca()
+            dp.calc_twi()
+            free.append(_ffi.device_memory(0)[0])
+    assert dp._tile.timings()['n_pit_edges'] > 10000
+    # the first steps may still grow persistent scratch; after that the free memory must not move
+    assert free[3] - free[-1] <= 0, "device memory shrinks by %d bytes over 8 repeated steps" % (free[3] - free[-1])
