@@ -98,3 +98,12 @@ def test_random_mosaics_in_pool_mode(compact, monkeypatch):
         ref = soak_pm.run(z, ny, nx, ov, dkw, OracleProcessor, width)
         dev = soak_pm.run(z, ny, nx, ov, dkw, None, width)
         _same_flow(dev, ref, rec)
+
+
+def test_device_memory_reaches_a_steady_state():
+    """tools/leak_probe.py: tiles (plain, conditioned) and directory runs (serial order, pool mode) created and dropped over
+    and over must not keep shrinking the free device memory."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(TOOLS, 'leak_probe.py'), '6'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'STEADY' in r.stdout
