@@ -9,54 +9,68 @@
 
 // stream compaction of flat0 != 0 into a list of cell ids.  Each thread reads 16 mask bytes with
 // one 16 B load; ranks come from a wavefront prefix (shuffles) plus a per-block LDS prefix over
-// the 4 waves, and the block reserves its output range with ONE global atomic per 4096 cells
+// the 4 waves, and the block reserves its output range with ONE global atomic per 64 Ki cells
 // (a first version issued one atomic per wavefront on a single address: 22 ms at 16384^2).
 __global__ __launch_bounds__(256) void k_compact_flats(const uint8_t *__restrict__ flat0, int64_t NN,
                                                        int32_t *__restrict__ list, int32_t *__restrict__ count)
 {
-    // 64 cells per thread (four 16 B loads), 16 Ki cells per block trip: the trip is bound by its barrier + atomic
-    // round trip, not by the 1 B/cell it reads
-    __shared__ int32_t wave_tot[4];
+    // 4 x 64 cells per thread (sixteen 16 B loads), 64 Ki cells per block trip and ONE atomic for them: the counter is a
+    // single address, whose returning atomics the L2 serialises at ~12 ns each (16 Ki-cell trips: 16384 atomics = 200 us
+    // at 16384^2, four times the time the 1 B/cell takes to read)
+    __shared__ int32_t wave_tot[4][4];
     __shared__ int32_t blk_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t base = (int64_t)blockIdx.x * 16384; base < NN; base += (int64_t)gridDim.x * 16384) {
-        const int64_t c0 = base + (int64_t)threadIdx.x * 64;
-        unsigned long long bits = 0;   // bit k set <=> cell c0+k is set
-        if (c0 + 64 <= NN) {
-            uint4 v[4];
+    for (int64_t base = (int64_t)blockIdx.x * 65536; base < NN; base += (int64_t)gridDim.x * 65536) {
+        unsigned long long bits[4];   // bit k of bits[j] set <=> cell base + j * 16384 + threadIdx.x * 64 + k is set
+        int32_t mine[4], incl[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const uint4 *>(flat0 + c0 + 16 * q);
+        for (int j = 0; j < 4; j++) {
+            const int64_t c0 = base + j * 16384 + (int64_t)threadIdx.x * 64;
+            bits[j] = 0;
+            if (c0 + 64 <= NN) {
+                uint4 v[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+                for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const uint4 *>(flat0 + c0 + 16 * q);
 #pragma unroll
-                for (int k = 0; k < 16; k++)
-                    bits |= (unsigned long long)(((w[k >> 2] >> (8 * (k & 3))) & 0xffu) ? 1u : 0u) << (16 * q + k);
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        bits[j] |= (unsigned long long)(((w[k >> 2] >> (8 * (k & 3))) & 0xffu) ? 1u : 0u) << (16 * q + k);
+                }
+            } else {
+                for (int k = 0; k < 64; k++)
+                    if (c0 + k < NN && flat0[c0 + k]) bits[j] |= 1ull << k;
             }
-        } else {
-            for (int k = 0; k < 64; k++)
-                if (c0 + k < NN && flat0[c0 + k]) bits |= 1ull << k;
-        }
-        const int32_t mine = __popcll(bits);
-        int32_t incl = mine;
+            mine[j] = __popcll(bits[j]);
+            incl[j] = mine[j];
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int32_t o = __shfl_up(incl, off);
-            if (lane >= off) incl += o;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int32_t o = __shfl_up(incl[j], off);
+                if (lane >= off) incl[j] += o;
+            }
+            if (lane == 63) wave_tot[j][wave] = incl[j];
         }
-        if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            int32_t tot = 0;
+            for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) tot += wave_tot[j][k];
             blk_base = tot ? atomicAdd(count, tot) : 0;
         }
         __syncthreads();
-        int32_t off = blk_base + incl - mine;
-        for (int k = 0; k < wave; k++) off += wave_tot[k];
-        while (bits) {
-            const int k = __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-            list[off++] = (int32_t)(c0 + k);
+        int32_t off = blk_base;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {           // ascending cell order within the trip: sub-chunk, wavefront, lane, bit
+            int32_t o = off + incl[j] - mine[j];
+            for (int k = 0; k < wave; k++) o += wave_tot[j][k];
+            const int64_t c0 = base + j * 16384 + (int64_t)threadIdx.x * 64;
+            unsigned long long b = bits[j];
+            while (b) {
+                const int k = __ffsll((long long)b) - 1;
+                b &= b - 1;
+                list[o++] = (int32_t)(c0 + k);
+            }
+            off += wave_tot[j][0] + wave_tot[j][1] + wave_tot[j][2] + wave_tot[j][3];
         }
         __syncthreads();
     }

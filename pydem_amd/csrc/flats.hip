@@ -61,8 +61,16 @@ __global__ void k_flats_patch(const int32_t *__restrict__ list, const int32_t *_
 __global__ void k_count_flats(const uint8_t *__restrict__ flats, int64_t NN, int32_t *count)
 {
     int32_t local = 0;
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < NN; c += (int64_t)gridDim.x * blockDim.x)
-        local += flats[c] != 0;
+    const int64_t nvec = NN >> 4, stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t v = t0; v < nvec; v += stride) {                // 16 mask bytes per load
+        const uint4 f4 = reinterpret_cast<const uint4 *>(flats)[v];
+        const uint32_t fw[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) local += ((fw[q] >> (8 * b)) & 0xFFu) != 0;
+    }
+    for (int64_t c = (nvec << 4) + t0; c < NN; c += stride) local += flats[c] != 0;
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
 }

@@ -1114,46 +1114,127 @@ __global__ __launch_bounds__(256) void k_pits_block(PitParams P, const int32_t *
     }
 }
 
+// (16 cells per thread; the elevation is only read under a flat)
 __global__ void k_pitmask(const uint8_t *__restrict__ flats, const double *__restrict__ elev, int64_t NN, uint8_t *pitmask)
 {
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < NN; c += (int64_t)gridDim.x * blockDim.x)
-        pitmask[c] = flats[c] && (elev[c] > 0);                                  // :1284
+    const int64_t nvec = NN >> 4, stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t v = t0; v < nvec; v += stride) {
+        const uint4 f4 = reinterpret_cast<const uint4 *>(flats)[v];
+        const uint32_t fw[4] = {f4.x, f4.y, f4.z, f4.w};
+        uint32_t pw[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t p = 0;
+            if (fw[q])
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if (((fw[q] >> (8 * b)) & 0xFFu) && elev[v * 16 + q * 4 + b] > 0) p |= 1u << (8 * b);      // :1284
+            pw[q] = p;
+        }
+        reinterpret_cast<uint4 *>(pitmask)[v] = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+    }
+    for (int64_t c = (nvec << 4) + t0; c < NN; c += stride) pitmask[c] = flats[c] && (elev[c] > 0);
 }
 
 // same block-aggregated compaction as the flats stage (mask -> list of cell ids)
 __global__ __launch_bounds__(256) void k_compact_mask(const uint8_t *__restrict__ mask, int64_t NN,
                                                        int32_t *__restrict__ list, int32_t *__restrict__ count)
 {
-    // 64 cells per thread (four 16 B loads), 16 Ki cells per block trip: the trip is bound by its barrier + atomic
-    // round trip, not by the 1 B/cell it reads
+    // 4 x 64 cells per thread (sixteen 16 B loads), 64 Ki cells per block trip and ONE atomic for them: the counter is a
+    // single address, whose returning atomics the L2 serialises at ~12 ns each (16 Ki-cell trips: 16384 atomics = 200 us
+    // at 16384^2, four times the time the 1 B/cell takes to read)
+    __shared__ int32_t wave_tot[4][4];
+    __shared__ int32_t blk_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 65536; base < NN; base += (int64_t)gridDim.x * 65536) {
+        unsigned long long bits[4];   // bit k of bits[j] set <=> cell base + j * 16384 + threadIdx.x * 64 + k is set
+        int32_t mine[4], incl[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int64_t c0 = base + j * 16384 + (int64_t)threadIdx.x * 64;
+            bits[j] = 0;
+            if (c0 + 64 <= NN) {
+                uint4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const uint4 *>(mask + c0 + 16 * q);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        bits[j] |= (unsigned long long)(((w[k >> 2] >> (8 * (k & 3))) & 0xffu) ? 1u : 0u) << (16 * q + k);
+                }
+            } else {
+                for (int k = 0; k < 64; k++)
+                    if (c0 + k < NN && mask[c0 + k]) bits[j] |= 1ull << k;
+            }
+            mine[j] = __popcll(bits[j]);
+            incl[j] = mine[j];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int32_t o = __shfl_up(incl[j], off);
+                if (lane >= off) incl[j] += o;
+            }
+            if (lane == 63) wave_tot[j][wave] = incl[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int32_t tot = 0;
+            for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) tot += wave_tot[j][k];
+            blk_base = tot ? atomicAdd(count, tot) : 0;
+        }
+        __syncthreads();
+        int32_t off = blk_base;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {           // ascending cell order within the trip: sub-chunk, wavefront, lane, bit
+            int32_t o = off + incl[j] - mine[j];
+            for (int k = 0; k < wave; k++) o += wave_tot[j][k];
+            const int64_t c0 = base + j * 16384 + (int64_t)threadIdx.x * 64;
+            unsigned long long b = bits[j];
+            while (b) {
+                const int k = __ffsll((long long)b) - 1;
+                b &= b - 1;
+                list[o++] = (int32_t)(c0 + k);
+            }
+            off += wave_tot[j][0] + wave_tot[j][1] + wave_tot[j][2] + wave_tot[j][3];
+        }
+        __syncthreads();
+    }
+}
+
+// keep-filter of _mk_adjacency_matrix applied to the pit edges (:1136-1137) + 64-bit sort keys, COMPACTED: unused output
+// slots (every wavefront of the pit tiers leaves a partly used chunk behind: a third of the raw slots at 16384^2) and
+// dropped edges never reach the sorts.  The order of the compacted entries does not matter (the sorts define it); one
+// atomic per 4096 raw slots.
+__global__ __launch_bounds__(256) void k_pit_keys(const int32_t *__restrict__ src, const int32_t *__restrict__ dst, const double *__restrict__ w,
+                                                  const double *__restrict__ elev, int32_t ne, uint64_t *key_out, uint64_t *key_in, int32_t *idx,
+                                                  int32_t *count)
+{
+    constexpr int PER = 16;
     __shared__ int32_t wave_tot[4];
     __shared__ int32_t blk_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int64_t base = (int64_t)blockIdx.x * 16384; base < NN; base += (int64_t)gridDim.x * 16384) {
-        const int64_t c0 = base + (int64_t)threadIdx.x * 64;
-        unsigned long long bits = 0;   // bit k set <=> cell c0+k is set
-        if (c0 + 64 <= NN) {
-            uint4 v[4];
+    for (int64_t base = (int64_t)blockIdx.x * (256 * PER); base < ne; base += (int64_t)gridDim.x * (256 * PER)) {
+        uint32_t keep = 0;
+        int32_t sv[PER], dv[PER];
 #pragma unroll
-            for (int q = 0; q < 4; q++) v[q] = *reinterpret_cast<const uint4 *>(mask + c0 + 16 * q);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-                for (int k = 0; k < 16; k++)
-                    bits |= (unsigned long long)(((w[k >> 2] >> (8 * (k & 3))) & 0xffu) ? 1u : 0u) << (16 * q + k);
-            }
-        } else {
-            for (int k = 0; k < 64; k++)
-                if (c0 + k < NN && mask[c0 + k]) bits |= 1ull << k;
+        for (int j = 0; j < PER; j++) {
+            const int64_t e = base + j * 256 + threadIdx.x;
+            sv[j] = -1; dv[j] = 0;
+            if (e < ne) { sv[j] = src[e]; dv[j] = dst[e]; }
         }
-        const int32_t mine = __popcll(bits);
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int64_t e = base + j * 256 + threadIdx.x;
+            if (sv[j] >= 0) {
+                const double we = w[e];
+                if (!isnan(we) && we > 1e-8 && elev[dv[j]] <= elev[sv[j]]) keep |= 1u << j;
+            }
+        }
+        const int32_t mine = __popc(keep);
         int32_t incl = mine;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int32_t o = __shfl_up(incl, off);
-            if (lane >= off) incl += o;
-        }
+        for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
         if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1161,41 +1242,29 @@ __global__ __launch_bounds__(256) void k_compact_mask(const uint8_t *__restrict_
             blk_base = tot ? atomicAdd(count, tot) : 0;
         }
         __syncthreads();
-        int32_t off = blk_base + incl - mine;
-        for (int k = 0; k < wave; k++) off += wave_tot[k];
-        while (bits) {
-            const int k = __ffsll((long long)bits) - 1;
-            bits &= bits - 1;
-            list[off++] = (int32_t)(c0 + k);
-        }
+        int32_t o = blk_base + incl - mine;
+        for (int k = 0; k < wave; k++) o += wave_tot[k];
+#pragma unroll
+        for (int j = 0; j < PER; j++)
+            if (keep & (1u << j)) {
+                key_out[o] = ((uint64_t)(uint32_t)sv[j] << 32) | (uint32_t)dv[j];
+                key_in[o] = ((uint64_t)(uint32_t)dv[j] << 32) | (uint32_t)sv[j];
+                idx[o] = (int32_t)(base + j * 256 + threadIdx.x);
+                o++;
+            }
         __syncthreads();
     }
 }
 
-// keep-filter of _mk_adjacency_matrix applied to the pit edges (:1136-1137) + 64-bit sort keys
-__global__ void k_pit_keys(const int32_t *__restrict__ src, const int32_t *__restrict__ dst, const double *__restrict__ w,
-                           const double *__restrict__ elev, int32_t ne, uint64_t *key_out, uint64_t *key_in, int32_t *idx)
-{
-    for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
-        const bool keep = src[e] >= 0 && !isnan(w[e]) && w[e] > 1e-8 && elev[dst[e]] <= elev[src[e]];
-        // dropped edges sort to the end
-        key_out[e] = keep ? (((uint64_t)(uint32_t)src[e] << 32) | (uint32_t)dst[e]) : ~0ull;
-        key_in[e] = keep ? (((uint64_t)(uint32_t)dst[e] << 32) | (uint32_t)src[e]) : ~0ull;
-        idx[e] = e;
-    }
-}
-
 __global__ void k_pit_gather(const uint64_t *__restrict__ keys, const int32_t *__restrict__ idx, const double *__restrict__ w,
-                             int32_t ne, int swap, int32_t *a, int32_t *b, double *wo, int32_t *nkept)
+                             int32_t ne, int swap, int32_t *a, int32_t *b, double *wo)
 {
     for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
         const uint64_t k = keys[e];
-        if (k == ~0ull) { a[e] = 0x7fffffff; b[e] = 0x7fffffff; wo[e] = 0; continue; }
         const int32_t hi = (int32_t)(k >> 32), lo = (int32_t)(k & 0xffffffffu);
         a[e] = swap ? lo : hi;      // a = src, b = dst in both views
         b[e] = swap ? hi : lo;
         wo[e] = w[idx[e]];
-        if (nkept && (e + 1 == ne || keys[e + 1] == ~0ull)) *nkept = e + 1;
     }
 }
 
@@ -1368,22 +1437,25 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         uint64_t *k1 = (uint64_t *)sb, *k2 = (uint64_t *)(sb + ne8), *k1s = (uint64_t *)(sb + 2 * ne8), *k2s = (uint64_t *)(sb + 3 * ne8);
         int32_t *idx = (int32_t *)(sb + 4 * ne8), *i1 = (int32_t *)(sb + 4 * ne8 + ne4), *i2 = (int32_t *)(sb + 4 * ne8 + 2 * ne4);
         void *tmp = sb + 4 * ne8 + 3 * ne4;
-        const int g = (int)(cdiv(ne, 256) < 1024 ? cdiv(ne, 256) : 1024);
-        hipLaunchKernelGGL(k_pit_keys, dim3(g), dim3(256), 0, t->stream, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w, t->elev,
-                           ne, k1, k2, idx);
-        // (the temporary storage of both sorts is the tail of the persistent block: its size only depends on ne)
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k1, k1s, idx, i1, ne, 0, 64, t->stream));
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k2, k2s, idx, i2, ne, 0, 64, t->stream));
         HIP_TRY(hipMemsetAsync(cnt + 10, 0, sizeof(int32_t), t->stream));
-        hipLaunchKernelGGL(k_pit_gather, dim3(g), dim3(256), 0, t->stream, k1s, i1, t->pits.raw_w, ne, 0, t->pits.src, t->pits.dst,
-                           t->pits.w, cnt + 10);
-        hipLaunchKernelGGL(k_pit_gather, dim3(g), dim3(256), 0, t->stream, k2s, i2, t->pits.raw_w, ne, 1, t->pits.in_src,
-                           t->pits.in_dst, t->pits.in_w, (int32_t *)nullptr);
+        hipLaunchKernelGGL(k_pit_keys, dim3((unsigned)(cdiv(ne, 4096) < 2048 ? cdiv(ne, 4096) : 2048)), dim3(256), 0, t->stream, t->pits.raw_src,
+                           t->pits.raw_dst, t->pits.raw_w, t->elev, ne, k1, k2, idx, cnt + 10);
         HIP_TRY(hipMemcpyAsync(t->h_counters, cnt + 10, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
+        const int32_t nk = t->h_counters[0];        // kept edges
+        if (nk > 0) {
+            // (the temporary storage of both sorts is the tail of the persistent block, sized for ne >= nk entries)
+            const int g = (int)(cdiv(nk, 256) < 1024 ? cdiv(nk, 256) : 1024);
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k1, k1s, idx, i1, nk, 0, 64, t->stream));
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k2, k2s, idx, i2, nk, 0, 64, t->stream));
+            hipLaunchKernelGGL(k_pit_gather, dim3(g), dim3(256), 0, t->stream, k1s, i1, t->pits.raw_w, nk, 0, t->pits.src, t->pits.dst,
+                               t->pits.w);
+            hipLaunchKernelGGL(k_pit_gather, dim3(g), dim3(256), 0, t->stream, k2s, i2, t->pits.raw_w, nk, 1, t->pits.in_src,
+                               t->pits.in_dst, t->pits.in_w);
+        }
         HIP_TRY(hipGetLastError());
-        t->pits.n_edges = t->h_counters[0];     // kept edges (a prefix of both sorted views)
-        t->tm.n_pit_edges = t->pits.n_edges;
+        t->pits.n_edges = nk;
+        t->tm.n_pit_edges = nk;
     }
     HIP_TRY(hipEventRecord(t->ev[5], t->stream));
     HIP_TRY(hipEventSynchronize(t->ev[5]));

@@ -609,6 +609,7 @@ __device__ __forceinline__ void tile_wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+constexpr int TILE_PEND = 48;    // woken tiles a wavefront collects before it appends them to the next pass's list
 struct TileNext {            // LISTED passes: tiles that must run again in the next pass
     int32_t *flag;           // per tile: last pass it was listed for
     int32_t *list, *count;
@@ -627,7 +628,8 @@ __device__ __forceinline__ double in_edge(const SweepArgs &A, int32_t c, int m, 
 
 template <bool LISTED>
 __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uint32_t pass, int tiles_x, int tid, int lane,
-                                               uint8_t *__restrict__ tile_done, int32_t *n_final, const TileNext &N)
+                                               uint8_t *__restrict__ tile_done, int32_t &n_final, const TileNext &N,
+                                               int32_t *pend, int &npend)
 {
     const int by = tid / tiles_x, bx = tid - by * tiles_x;
     const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
@@ -878,16 +880,22 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
         }
     for (int off = 32; off > 0; off >>= 1) { finalized += __shfl_down(finalized, off); n_open += __shfl_down(n_open, off); }
     if (LISTED) {
+        // the tiles this visit wakes (lanes 0-8: the neighbours a finished cell drains into; lane 9: the tile itself when
+        // its ready ring overflowed) go to the wavefront's pending list; the kernel appends the pending lists to the
+        // global one with one add per wavefront / workgroup (tile_list_flush): the list counter is a single address too
         for (int off = 32; off > 0; off >>= 1) wake |= __shfl_xor(wake, off);
-        if (lane < 9 && ((wake >> lane) & 1u)) {
-            const int tt = tid + (lane / 3 - 1) * tiles_x + (lane % 3 - 1);
-            if (atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tt;
-        }
+        bool win = false;
+        int tt = 0;
+        if (lane < 9 && ((wake >> lane) & 1u)) { tt = tid + (lane / 3 - 1) * tiles_x + (lane % 3 - 1); win = true; }
+        if (lane == 9 && L.limit != INT32_MAX) { tt = tid; win = true; }
+        if (win) win = atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1;
+        const unsigned long long bw = __ballot(win);
+        if (win) pend[npend + __popcll(bw & ((1ull << lane) - 1ull))] = tt;
+        npend += __popcll(bw);
     }
     if (lane == 0) {
-        if (finalized) atomicAdd(n_final, finalized);
+        n_final += finalized;          // (lane 0's running count: the kernel adds it to the global counter once, see there)
         if (finalized == n_open) tile_done[tid] = 1;
-        if (LISTED && L.limit != INT32_MAX && atomicExch(&N.flag[tid], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tid;
         if (prof) {      // cycles per phase, summed over tiles (PYDEM_TILE_DEBUG=4)
             const long long tk4 = wall_clock64();
             unsigned long long *acc = reinterpret_cast<unsigned long long *>(A.err + 1 + 16);   // counters[32..] region: see stage_sweep
@@ -907,12 +915,31 @@ __global__ __launch_bounds__(256, 8) void k_sweep_tiles(SweepArgs A, uint32_t pa
                                                      uint8_t *__restrict__ tile_done, int32_t *n_final, TileNext N)
 {
     __shared__ TileW L[4];
+    __shared__ int32_t s_fin[4], s_np[4], s_pend[4][TILE_PEND], s_base;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     // workgroup b runs on XCD b % 8: give every XCD one contiguous band of tiles (gridDim.x is a multiple of 8)
     const int per = (gridDim.x >> 3) * 4;
     const int tid = (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + wave;
-    if (tid >= tiles_total || tile_done[tid]) return;
-    sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, n_final, N);
+    int32_t fin = 0;
+    int npend = 0;
+    if (tid < tiles_total && !tile_done[tid])
+        sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend);
+    // the counter of finished cells and the counter of the next pass's tile list are single addresses: a quarter of a
+    // million tile runs per pass adding to them one by one keep their L2 channel busy for ~10 ns each -- one add per
+    // workgroup for either
+    if (lane == 0) { s_fin[wave] = fin; s_np[wave] = npend; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int32_t tot = s_fin[0] + s_fin[1] + s_fin[2] + s_fin[3];
+        if (tot) atomicAdd(n_final, tot);
+        if (LISTED) { const int32_t np = s_np[0] + s_np[1] + s_np[2] + s_np[3]; s_base = np ? atomicAdd(N.count, np) : 0; }
+    }
+    if (LISTED) {
+        __syncthreads();
+        int32_t base = s_base;
+        for (int w = 0; w < wave; w++) base += s_np[w];
+        if (lane < npend) N.list[base + lane] = s_pend[wave][lane];
+    }
 }
 
 // later passes: only the listed tiles (those a finished cell of the previous pass drains into); lists the next ones
@@ -926,8 +953,24 @@ __global__ __launch_bounds__(256, 6) void k_sweep_tiles_listed(SweepArgs A, uint
     if (blockIdx.x == 0 && threadIdx.x == 0) *clear_count = 0;      // the list of the pass after the next one
     // (the tile id is the same for the whole wavefront: as a scalar it keeps the tile's coordinates and every address
     // derived from them out of the vector registers)
-    for (int32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); k < nt; k += gridDim.x * 4)
-        sweep_one_tile<true>(A, L[wave], pass, tiles_x, __builtin_amdgcn_readfirstlane(list_in[k]), lane, tile_done, n_final, N);
+    __shared__ int32_t s_pend[4][TILE_PEND];
+    int32_t fin = 0;               // finished cells of all tiles of this wavefront: one add at the end
+    int npend = 0;                 // tiles woken by this wavefront's visits that are not on the global list yet
+    auto flush = [&]() {
+        tile_wave_sync();
+        int32_t base = 0;
+        if (lane == 0) base = atomicAdd(N.count, npend);
+        base = __shfl(base, 0);
+        if (lane < npend) N.list[base + lane] = s_pend[wave][lane];
+        npend = 0;
+        tile_wave_sync();
+    };
+    for (int32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); k < nt; k += gridDim.x * 4) {
+        sweep_one_tile<true>(A, L[wave], pass, tiles_x, __builtin_amdgcn_readfirstlane(list_in[k]), lane, tile_done, fin, N, s_pend[wave], npend);
+        if (npend > TILE_PEND - 10) flush();            // (a visit adds at most ten)
+    }
+    if (npend) flush();
+    if (lane == 0 && fin) atomicAdd(n_final, fin);
 }
 
 // ------------------------------------------------------------------------------- K5a
@@ -1285,18 +1328,39 @@ __global__ void k_reseed_replay(SweepArgs A, const ReseedCell *__restrict__ U, i
 }
 
 // finalisation of _calc_uca_chunk (:966-980): NaN on flats, edge_done = ~edge_todo etc.
+// (16 cells per thread: the byte masks travel as 16-byte words; uca and elev are only touched where the masks ask for
+// them -- flats, cells still on `todo` -- unless the saturation limit needs every value: 3 instead of 19 bytes per cell)
+__device__ __forceinline__ bool finalize_cell(double *__restrict__ uca, const double *__restrict__ elev, int64_t c, uint32_t f, uint32_t td,
+                                              int apply_limit, double limit)
+{
+    if (f) uca[c] = NAN;                                                         // :972
+    bool dn = !td;                                                               // :974
+    if (td && isnan(elev[c])) dn = true;                                         // :975
+    if (apply_limit && !f && uca[c] > limit) dn = true;                          // :977-980 (NaN > limit is false)
+    return dn;
+}
+
 __global__ __launch_bounds__(256) void k_uca_finalize(double *__restrict__ uca, const uint8_t *__restrict__ flats,
                                                       const uint8_t *__restrict__ todo_work, const double *__restrict__ elev,
                                                       uint8_t *__restrict__ edge_done, int64_t NN, int apply_limit, double limit)
 {
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < NN; c += (int64_t)gridDim.x * blockDim.x) {
-        double a = uca[c];
-        if (flats[c]) { a = NAN; uca[c] = a; }                                   // :972
-        bool dn = !todo_work[c];                                                 // :974
-        if (isnan(elev[c])) dn = true;                                           // :975
-        if (apply_limit && a > limit) dn = true;                                 // :977-980
-        edge_done[c] = dn;
+    const int64_t nvec = NN >> 4, stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t v = t0; v < nvec; v += stride) {
+        const uint4 f4 = reinterpret_cast<const uint4 *>(flats)[v], t4 = reinterpret_cast<const uint4 *>(todo_work)[v];
+        const uint32_t fw[4] = {f4.x, f4.y, f4.z, f4.w}, tw[4] = {t4.x, t4.y, t4.z, t4.w};
+        uint32_t dw[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t d = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                d |= (finalize_cell(uca, elev, v * 16 + q * 4 + b, (fw[q] >> (8 * b)) & 0xFFu, (tw[q] >> (8 * b)) & 0xFFu, apply_limit, limit) ? 1u : 0u) << (8 * b);
+            dw[q] = d;
+        }
+        reinterpret_cast<uint4 *>(edge_done)[v] = make_uint4(dw[0], dw[1], dw[2], dw[3]);
     }
+    for (int64_t c = (nvec << 4) + t0; c < NN; c += stride)
+        edge_done[c] = finalize_cell(uca, elev, c, flats[c], todo_work[c], apply_limit, limit);
 }
 
 // ------------------------------------------------------------------------------- K6
