@@ -16,6 +16,7 @@ cp gpurun_out/prof/ks/t_kernel_stats.csv gpurun_out/prof/kernel_stats.csv
 rm -f gpurun_out/prof/*/t_kernel_trace.csv gpurun_out/prof/*/t_counter_collection.csv
 head -14 gpurun_out/prof/kernel_stats.csv; head -8 gpurun_out/prof/pmc_fetch_write.csv; cat gpurun_out/prof/pmc_sq_stencil.csv
 timeout 600 python bench.py > gpurun_out/prof/bench_default.json 2> gpurun_out/prof/bench_default.err
+timeout 600 python bench.py --drain-pits 0 --cpu-sample 0 > gpurun_out/prof/bench_nopits.json 2> gpurun_out/prof/bench_nopits.err
 timeout 300 python bench.py --config 2 > gpurun_out/prof/bench_config2.json 2> gpurun_out/prof/bench_config2.err
 timeout 600 python bench.py --config 5 > gpurun_out/prof/bench_config5.json 2> gpurun_out/prof/bench_config5.err
 cat gpurun_out/prof/bench_*.json
