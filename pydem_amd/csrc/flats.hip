@@ -58,7 +58,7 @@ __global__ void k_flats_patch(const int32_t *__restrict__ list, const int32_t *_
     }
 }
 
-__global__ void k_count_flats(const uint8_t *__restrict__ flats, int64_t NN, int32_t *count)
+__global__ __launch_bounds__(256) void k_count_flats(const uint8_t *__restrict__ flats, int64_t NN, int32_t *count)
 {
     int32_t local = 0;
     const int64_t nvec = NN >> 4, stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,7 +72,10 @@ __global__ void k_count_flats(const uint8_t *__restrict__ flats, int64_t NN, int
     }
     for (int64_t c = (nvec << 4) + t0; c < NN; c += stride) local += flats[c] != 0;
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(count, local);
+    __shared__ int32_t s_w[4];                                   // one add per workgroup: the counter is a single address
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) { const int32_t tot = s_w[0] + s_w[1] + s_w[2] + s_w[3]; if (tot) atomicAdd(count, tot); }
 }
 
 }  // namespace

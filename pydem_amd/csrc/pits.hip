@@ -1205,12 +1205,12 @@ __global__ __launch_bounds__(256) void k_compact_mask(const uint8_t *__restrict_
 // keep-filter of _mk_adjacency_matrix applied to the pit edges (:1136-1137) + 64-bit sort keys, COMPACTED: unused output
 // slots (every wavefront of the pit tiers leaves a partly used chunk behind: a third of the raw slots at 16384^2) and
 // dropped edges never reach the sorts.  The order of the compacted entries does not matter (the sorts define it); one
-// atomic per 4096 raw slots.
+// atomic per 1024 raw slots.
 __global__ __launch_bounds__(256) void k_pit_keys(const int32_t *__restrict__ src, const int32_t *__restrict__ dst, const double *__restrict__ w,
                                                   const double *__restrict__ elev, int32_t ne, uint64_t *key_out, uint64_t *key_in, int32_t *idx,
                                                   int32_t *count)
 {
-    constexpr int PER = 16;
+    constexpr int PER = 4;
     __shared__ int32_t wave_tot[4];
     __shared__ int32_t blk_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1438,7 +1438,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         int32_t *idx = (int32_t *)(sb + 4 * ne8), *i1 = (int32_t *)(sb + 4 * ne8 + ne4), *i2 = (int32_t *)(sb + 4 * ne8 + 2 * ne4);
         void *tmp = sb + 4 * ne8 + 3 * ne4;
         HIP_TRY(hipMemsetAsync(cnt + 10, 0, sizeof(int32_t), t->stream));
-        hipLaunchKernelGGL(k_pit_keys, dim3((unsigned)(cdiv(ne, 4096) < 2048 ? cdiv(ne, 4096) : 2048)), dim3(256), 0, t->stream, t->pits.raw_src,
+        hipLaunchKernelGGL(k_pit_keys, dim3((unsigned)(cdiv(ne, 1024) < 8192 ? cdiv(ne, 1024) : 8192)), dim3(256), 0, t->stream, t->pits.raw_src,
                            t->pits.raw_dst, t->pits.raw_w, t->elev, ne, k1, k2, idx, cnt + 10);
         HIP_TRY(hipMemcpyAsync(t->h_counters, cnt + 10, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));

@@ -2436,7 +2436,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         TileNext N;
         N.flag = tile_flag;
         while (ntiles > 0) {
-            const int batch = 8;            // passes between two looks at the list size (the grid only shrinks below 8192 listed tiles)
+            const int batch = ntiles < 2048 ? 16 : 8;    // passes between two looks at the list size (a look idles the GPU for ~30 us; the grid only shrinks below 8192 listed tiles)
             const int grid = (int)(ntiles < 8192 ? (ntiles > 64 ? ntiles : 64) : 8192);
             for (int b = 0; b < batch; b++, p++) {
                 N.list = tile_list[(p + 1) % 2]; N.count = &cntT[(p + 1) % 3];
