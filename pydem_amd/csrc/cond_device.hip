@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_cond_mask(CondArgs A, int corners_off, 
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < A.NN; c += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(c / m), j = (int)(c - (int64_t)i * m);
         const double z = A.elev[c];
-        if (isnan(z)) { atomicAdd(nan_count, 1); A.mask[c] = 0; continue; }
+        if (isnan(z)) { *nan_count = 1; A.mask[c] = 0; continue; }     // (a flag: the host only asks whether any cell is NaN -- no atomic on one address per no-data cell)
         bool low = true;
         for (int di = -1; di <= 1 && low; di++) {
             const int ii = i + di;
@@ -104,12 +104,44 @@ __global__ __launch_bounds__(256) void k_cond_mask(CondArgs A, int corners_off, 
     }
 }
 
-__global__ void k_region_index(CondArgs A, int32_t *nreg)
+// region numbers for the roots (any order): 8 list entries per thread, ONE add to the region counter per workgroup trip --
+// the counter is a single address, and one add per wavefront of roots kept its L2 channel busy for the whole kernel
+// (140 k adds of ~10 ns: 1.4 ms for the 8.9 M flat cells of the 8192^2 SRTM-like tile)
+__global__ __launch_bounds__(256) void k_region_index(CondArgs A, int32_t *nreg)
 {
+    constexpr int PER = 8;
+    __shared__ int32_t wave_tot[4];
+    __shared__ int32_t blk_base;
     const int32_t nf = *A.count;
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) {
-        const int32_t c = A.list[q];
-        if (A.labels[c] == c) A.rid[c] = atomicAdd(nreg, 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * (256 * PER); base < nf; base += (int64_t)gridDim.x * (256 * PER)) {
+        int32_t cell[PER];
+        uint32_t root = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int64_t q = base + j * 256 + threadIdx.x;
+            cell[j] = q < nf ? A.list[q] : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; j++)
+            if (cell[j] >= 0 && A.labels[cell[j]] == cell[j]) root |= 1u << j;
+        const int32_t mine = __popc(root);
+        int32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            blk_base = tot ? atomicAdd(nreg, tot) : 0;
+        }
+        __syncthreads();
+        int32_t o = blk_base + incl - mine;
+        for (int k = 0; k < wave; k++) o += wave_tot[k];
+#pragma unroll
+        for (int j = 0; j < PER; j++)
+            if (root & (1u << j)) A.rid[cell[j]] = o++;
+        __syncthreads();
     }
 }
 

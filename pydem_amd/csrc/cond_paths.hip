@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256) void k_paths_pits(const double *__restrict__ e
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < NN; c += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(c / m), j = (int)(c - (int64_t)i * m);
         const double z = e[c];
-        if (isnan(z)) { atomicAdd(nan_count, 1); mask[c] = 0; continue; }
+        if (isnan(z)) { *nan_count = 1; mask[c] = 0; continue; }       // (a flag, see k_cond_mask)
         // scipy's 'reflect' border mirrors the cell itself into the footprint on the array edge: e > e is false there
         bool low = !(i == 0 || j == 0 || i == n - 1 || j == m - 1);
         for (int d = 0; d < 9 && low; d++) {

@@ -31,6 +31,19 @@ __global__ void k_cy_mark_done(const int32_t *__restrict__ front, int32_t nf, ui
     }
 }
 
+// a list slot for every lane that is active here, ONE atomic per wavefront: the list counters are single addresses, and
+// one returning atomic per pushed node serialises in the L2 (~10 ns each)
+__device__ __forceinline__ int32_t agg_slot(int32_t *count)
+{
+    const unsigned long long bal = __ballot(true);
+    const int lane = (int)__lane_id();
+    const int leader = __ffsll((long long)bal) - 1;
+    int32_t base = 0;
+    if (lane == leader) base = atomicAdd(count, (int32_t)__popcll(bal));
+    base = __shfl(base, leader);
+    return base + __popcll(bal & ((1ull << lane) - 1ull));
+}
+
 // phase 1 of a round: the distinct targets of the frontier (cyutils.pyx:155-161)
 __global__ void k_cy_targets(const int32_t *__restrict__ front, int32_t nf, const uint8_t *__restrict__ done,
                              const int32_t *__restrict__ col_indptr, const int32_t *__restrict__ col_indices, int64_t n_rows,
@@ -41,7 +54,7 @@ __global__ void k_cy_targets(const int32_t *__restrict__ front, int32_t nf, cons
         for (int32_t j = col_indptr[i]; j < col_indptr[i + 1]; j++) {
             const int32_t row = col_indices[j];
             if ((skip_edge || done[row]) && cy_on_edge(row, n_rows, n_cols)) continue;          // :159-161
-            if (atomicExch(&tmark[row], tag) != tag) targets[atomicAdd(n_targets, 1)] = row;
+            if (atomicExch(&tmark[row], tag) != tag) targets[agg_slot(n_targets)] = row;
         }
     }
 }
@@ -78,7 +91,7 @@ __global__ void k_cy_pull(const int32_t *__restrict__ targets, int32_t nt, doubl
         if (!wait) {
             const int32_t old = atomicExch(&mark[row], tag);
             if (old != tag) {
-                next[atomicAdd(n_next, 1)] = row;
+                next[agg_slot(n_next)] = row;
                 if (old == tag - 1) atomicAdd(n_repeat, 1);                                      // was in the previous frontier too
             }
         }
@@ -95,7 +108,7 @@ __global__ void k_cy_flood(const int32_t *__restrict__ front, int32_t nf, int32_
             const int32_t row = indices[j];
             if (atomicExch(&arr[row], set_to) != set_to) {                                       // :69-70
                 const int32_t old = atomicExch(&mark[row], tag);
-                if (old != tag) { next[atomicAdd(n_next, 1)] = row; if (old == tag - 1) atomicAdd(n_repeat, 1); }
+                if (old != tag) { next[agg_slot(n_next)] = row; if (old == tag - 1) atomicAdd(n_repeat, 1); }
             }
         }
     }
