@@ -60,7 +60,7 @@ bad = 0
 for name, fn in (('plain tile', plain_tile), ('conditioned int16 tile', conditioned_tile),
                  ('directory, serial order', directory(1)), ('directory, pool mode', directory(8))):
     d = series(name, fn)
-    if any(x > 0 for x in d[2:]):
+    if sum(x > 0 for x in d[2:]) >= 2:          # a leak shrinks the free memory run after run; one late one-off allocation does not count
         bad += 1
 print('leak probe:', 'STEADY' if bad == 0 else '%d scenario(s) keep shrinking' % bad)
 sys.exit(1 if bad else 0)
