@@ -90,6 +90,13 @@ def run_pm_case(name, raster, ny_grid, nx_grid, overlap, dp_kwargs):
 def main():
     cone = synth.cone_scaled(32)          # the input of the reference's own multi-tile test (case 33, NN=32)
     nopath = dict(drain_pits_path=False)
+    if '--twilimits-only' in sys.argv:     # (added later: writes this one fixture and the manifest, leaves the others alone)
+        fr = synth.fractal(60, 72, seed=17, top_shift=5, n_octaves=5, zrange=200.0)
+        # the TWI limits in the directory flow: the calc_twi worker builds a fresh processor (twi_min_area = inf unless given)
+        run_pm_case('pm_fractal_twilimits_2x2_ov2', fr, 2, 2, 2, dict(drain_pits_path=False, apply_twi_limits=True, apply_twi_limits_on_uca=True,
+                                                                       twi_min_slope=0.01, uca_saturation_limit=4.0))
+        write_manifest()
+        return
     run_pm_case('pm_cone32_3x3_ov2', cone, 3, 3, 2, {})
     run_pm_case('pm_cone32_3x3_ov1', cone, 3, 3, 1, {})
     run_pm_case('pm_cone32_4x5_ov3', cone, 4, 5, 3, {})

@@ -17,7 +17,11 @@ class OracleProcessor(object):
         self.mag = None if mag is None else np.array(mag, float)
         self.direction = None if direction is None else np.array(direction, float)
         self.flats = self.uca = self.twi = self.edge_todo = self.edge_done = None
-        self.twi_min_area = np.inf
+        self.twi_min_area = kw.get('twi_min_area', np.inf)
+        self.twi_min_slope = kw.get('twi_min_slope', 1e-3)
+        self.uca_saturation_limit = kw.get('uca_saturation_limit', 32.0)
+        self.apply_twi_limits = kw.get('apply_twi_limits', False)
+        self.apply_twi_limits_on_uca = kw.get('apply_twi_limits_on_uca', False)
         self._graph = None
         self._pits = []
 
@@ -80,7 +84,8 @@ class OracleProcessor(object):
             self.mag.ravel()[self._pits] = -1.0
 
     def calc_twi(self):
-        t = O.twi(self.uca, self.mag, 1e-3, self.twi_min_area)
+        t = O.twi(self.uca, self.mag, self.twi_min_slope, self.twi_min_area, self.uca_saturation_limit,
+                  self.apply_twi_limits, self.apply_twi_limits_on_uca)
         self.twi = t * 10
         return t
 
