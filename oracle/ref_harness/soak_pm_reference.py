@@ -47,6 +47,14 @@ def make_case(k):
         dkw['fill_flats'] = False
     if rng.random() < 0.25:
         dkw['drain_pits'] = False
+    # TWI options (their own random stream: the cases keep the rasters and grids they had before these were added).  The
+    # reference's calc_twi worker builds a fresh processor from dem_proc_kwargs (process_manager.py:296-307).
+    rng2 = np.random.default_rng(99000 + k)
+    if rng2.random() < 0.35:
+        dkw.update(apply_twi_limits=bool(rng2.random() < 0.7), apply_twi_limits_on_uca=bool(rng2.random() < 0.7),
+                   twi_min_slope=float(rng2.choice([0.01, 1e-3, 0.2])), uca_saturation_limit=float(rng2.choice([4.0, 32.0, 1.5])))
+        if rng2.random() < 0.5:
+            dkw['twi_min_area'] = float(rng2.choice([1.0, 25.0]))
     return dict(case=k, shape=(n, m), grid=(ny, nx), overlap=ov, options=dkw), z, ny, nx, ov, dkw
 
 

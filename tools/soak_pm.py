@@ -49,6 +49,12 @@ def make_case(k):
     dkw = dict(drain_pits_path=False, fill_flats=False)
     if rng.random() < 0.25:
         dkw['drain_pits'] = False
+    rng2 = np.random.default_rng(77000 + k)                   # TWI options on their own stream (earlier cases keep their rasters)
+    if rng2.random() < 0.3:
+        dkw.update(apply_twi_limits=bool(rng2.random() < 0.7), apply_twi_limits_on_uca=bool(rng2.random() < 0.7),
+                   twi_min_slope=float(rng2.choice([0.01, 1e-3, 0.2])), uca_saturation_limit=float(rng2.choice([4.0, 32.0, 1.5])))
+        if rng2.random() < 0.5:
+            dkw['twi_min_area'] = float(rng2.choice([1.0, 25.0]))
     return dict(case=k, shape=(n, m), grid=(ny, nx), overlap=ov, options=dkw), z, ny, nx, ov, dkw
 
 
