@@ -1,0 +1,160 @@
+#!/usr/bin/env python
+"""CPU prototype of an edge fix-up by transfer operators (not product code; oracle-backed tiles).
+
+Every tile computes its own UCA (first pass).  A perimeter cell that is still `todo` and lies in the interior of another
+tile ("supplier") will end up with the supplier's value; the correction a tile receives is linear in those values:
+
+    final_i(c) = own_i(c) + sum_{e in S_i} Tcut_i(c, e) * (x_i(e) - own_i(e)),      x_i(e) = final_j(supplier cell of e)
+
+with S_i the replaced perimeter cells and Tcut_i(c, e) the sum over flow paths e -> c that pass through no other replaced
+cell of the products of the edge weights (a replaced cell takes nothing from upstream: its value is authoritative).  The
+interfaces are iterated to their fixed point; tile interiors are written once.  Checked here against the single-tile
+answer on the pit-free slope of tests/test_process_manager_pool.py and on the reference's cone cases (its acceptance
+test, pydem/test/test_end_to_end.py:86-149): overlap >= 2 reaches the single-tile answer to rounding in 3-6 interface
+sweeps.  Not modelled: overlap 1 (both copies of the shared line are perimeter cells; the reference patches those
+tiles, process_manager.py `_patch_overlap1_edges`), the masks (edge_todo / edge_done as a boolean transfer), NaN / flats,
+pit edges across interfaces.  The full cells x inlets operator is built here; a product version needs the perimeter x
+inlets part for the sweeps (tools/sim_edge_transfer.py: 3-4 entries per inlet) and one interior cascade at the end.
+    python tools/proto_edge_transfer.py"""
+import os
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from oracle_processor import OracleProcessor            # noqa: E402  (checker / stand-in processor)
+from pydem_amd import process_manager, synth            # noqa: E402
+from pydem_amd.synth import chunk_edges                 # noqa: E402
+
+warnings.simplefilter('ignore')
+
+
+def single(raster, **kw):
+    nn = raster.shape[0]
+    dp = OracleProcessor(elev=raster, dX=np.ones(nn - 1), dY=np.ones(nn - 1), dX2=np.ones(nn), dY2=np.ones(nn), **kw)
+    dp.calc_slopes_directions(); dp.calc_uca()
+    return dp
+
+
+def run(raster, ny, nx, ov, dkw):
+    d = tempfile.mkdtemp()
+    for t, (elev, bounds) in enumerate(synth.split_mosaic(raster, ny, nx, ov)):
+        np.savez(os.path.join(d, 'tile_%03d.npz' % t), elev=elev, bounds=bounds)
+    process_manager.DEBUG = True
+    try:
+        pm = process_manager.ProcessManager(in_path=d, elev_conditioned=True, processor_cls=OracleProcessor, n_workers=8, dem_proc_kwargs=dkw)
+        pm.compute_grid(); pm.process_elevation(); pm.process_aspect_slope(); pm.process_uca()
+    finally:
+        process_manager.DEBUG = False
+    ni, nj = raster.shape
+    te_, be_ = chunk_edges(ni, ny, ov); le_, re_ = chunk_edges(nj, nx, ov)
+    win = [(te, be, le, re) for te, be in zip(te_, be_) for le, re in zip(le_, re_)]      # raster windows, tile order of split_mosaic
+    # the ProcessManager orders its tiles by bounds; map through the tile's elevation
+    order = []
+    for i in range(pm.n_inputs):
+        e = np.asarray(pm.tiles[i].elev)
+        k = [q for q, (te, be, le, re) in enumerate(win) if (be - te, re - le) == e.shape and np.array_equal(raster[te:be, le:re], e, equal_nan=True)]
+        order.append(k[0])
+    W = [win[k] for k in order]
+    T = pm.n_inputs
+    own, A, todo, shape = [], [], [], []
+    for i in range(T):
+        dp = pm.tiles[i]
+        n, m = dp.uca.shape
+        indptr, indices, data = dp._A
+        A.append(sp.csc_matrix((data, indices, indptr), shape=(n * m, n * m)).tocsr())      # A[to, from]
+        own.append(np.nan_to_num(np.array(dp.uca).ravel()))
+        todo.append(np.array(dp.edge_todo, bool))
+        shape.append((n, m))
+    # suppliers: for a perimeter cell of tile i, the tile j that holds the same raster cell deepest in its interior
+    S, sup = [], []
+    for i in range(T):
+        te, be, le, re = W[i]; n, m = shape[i]
+        ii, jj = np.divmod(np.arange(n * m), m)
+        per = np.flatnonzero(((ii == 0) | (ii == n - 1) | (jj == 0) | (jj == m - 1)) & todo[i].ravel())
+        cells, where = [], []
+        for c in per:
+            R, C = te + ii[c], le + jj[c]
+            best, bd = None, (-1, 0)
+            big = 1 << 30
+            mine = min(ii[c] if te > 0 else big, n - 1 - ii[c] if be < ni else big, jj[c] if le > 0 else big, m - 1 - jj[c] if re < nj else big)
+            for j in range(T):
+                if j == i: continue
+                tj, bj, lj, rj = W[j]
+                if tj <= R < bj and lj <= C < rj:
+                    big = 1 << 30                         # sides on the mosaic border are not interfaces
+                    depth = min(R - tj if tj > 0 else big, bj - 1 - R if bj < ni else big, C - lj if lj > 0 else big, rj - 1 - C if rj < nj else big)
+                    # side neighbours (same tile row or column) before diagonal ones, then the deepest copy
+                    side = (tj == te and bj == be) or (lj == le and rj == re)
+                    key = (1 if side else 0, depth)
+                    # on a mosaic-border line a cell of the overlap band lies on the perimeter of both tiles: the copy that is
+                    # deeper with respect to the interfaces is the authoritative one (ties: the lower tile number)
+                    if depth > 0 and (depth > mine or (depth == mine and j < i)) and key > bd:
+                        best, bd = (j, (R - tj) * shape[j][1] + (C - lj)), key
+            if best is not None:
+                cells.append(c); where.append(best)
+        S.append(np.array(cells, np.int64)); sup.append(where)
+    # transfer operators with the paths cut at replaced cells
+    Tcut = []
+    for i in range(T):
+        N = A[i].shape[0]
+        keep = np.ones(N); keep[S[i]] = 0.0
+        Ac = sp.diags(keep) @ A[i]                       # replaced cells take nothing from upstream
+        E = sp.csr_matrix((np.ones(S[i].size), (S[i], np.arange(S[i].size))), shape=(N, S[i].size))
+        X, acc = E, E
+        while X.nnz:
+            X = (Ac @ X).tocsr()
+            acc = acc + X
+        Tcut.append(acc.tocsr())
+    # interface fixed point
+    final = [o.copy() for o in own]
+    for it in range(4 * T + 4):
+        x = [np.array([final[j][c] for j, c in sup[i]]) for i in range(T)]
+        new = [own[i] + (Tcut[i] @ (x[i] - own[i][S[i]]) if S[i].size else 0.0) for i in range(T)]
+        delta = max(float(np.max(np.abs(new[i] - final[i]))) for i in range(T))
+        final = new
+        if delta == 0.0:
+            break
+    nnz = sum(t.nnz for t in Tcut)
+    # stitch: every raster cell from the tile that holds it deepest
+    out = np.full(raster.shape, np.nan); depth = -np.ones(raster.shape)
+    for i in range(T):
+        te, be, le, re = W[i]; n, m = shape[i]
+        ii, jj = np.mgrid[0:n, 0:m]
+        big = 1e9
+        dd = np.minimum(np.minimum(ii if te > 0 else big, n - 1 - ii if be < ni else big),
+                        np.minimum(jj if le > 0 else big, m - 1 - jj if re < nj else big)).astype(float) + 0 * ii
+        sel = dd > depth[te:be, le:re]
+        out[te:be, le:re][sel] = final[i].reshape(n, m)[sel]
+        depth[te:be, le:re][sel] = dd[sel]
+    return out, it + 1, nnz, sum(s.size for s in S)
+
+
+def main():
+    nn = 120
+    ii, jj = np.mgrid[0:nn, 0:nn]
+    z = synth.fractal(nn, nn, seed=1, top_shift=7, n_octaves=7) + 40.0 * (0.7 * ii + 1.3 * jj)
+    ref = single(z, drain_pits=False)
+    for tiles, ov in (((3, 3), 2), ((2, 4), 1), ((4, 3), 3)):
+        out, its, nnz, ns = run(z, tiles[0], tiles[1], ov, {'drain_pits': False})
+        a, b = out[1:-1, 1:-1], ref.uca[1:-1, 1:-1]
+        err = np.nanmax(np.abs(a - b) / b)
+        print('pit-free slope %dx%d ov %d: %d replaced perimeter cells, %d transfer entries, %d interface sweeps, max rel. diff to the single tile %.2e'
+              % (tiles[0], tiles[1], ov, ns, nnz, its, err))
+    cone = synth.cone_scaled(32)
+    refc = single(cone)
+    for tiles, ov in (((3, 3), 2), ((4, 5), 2), ((4, 5), 3), ((3, 3), 1), ((4, 3), 1)):
+        out, its, nnz, ns = run(cone, tiles[0], tiles[1], ov, {})
+        a, b = out[1:-1, 1:-1], refc.uca[1:-1, 1:-1]
+        ok = np.isfinite(a) & np.isfinite(b)
+        print('cone %dx%d ov %d: %d sweeps, max abs diff %.2e (NaN pattern equal: %s)' % (tiles[0], tiles[1], ov, its, np.max(np.abs(a[ok] - b[ok])),
+              bool(np.array_equal(np.isnan(a), np.isnan(b)))))
+
+
+if __name__ == '__main__':
+    main()
