@@ -12,8 +12,9 @@ interfaces are iterated to their fixed point; tile interiors are written once.  
 answer on the pit-free slope of tests/test_process_manager_pool.py and on the reference's cone cases (its acceptance
 test, pydem/test/test_end_to_end.py:86-149): overlap >= 2 reaches the single-tile answer to rounding in 3-6 interface
 sweeps; on fractal terrain with flats (no pit edges) it gives the pool schedule's result cell for cell (and both differ
-from the single tile where flats touch the tile borders); with pit edges 0.1-2 % of the cells differ from the pool
-schedule (open).  Not modelled: overlap 1 (both copies of the shared line are perimeter cells; the reference patches those
+from the single tile where flats touch the tile borders); with pit edges 1-3 % of the cells differ from the pool
+schedule (which gates every replacement on the supplier's `done` mask and applies rule :274; here every perimeter cell with
+an authoritative copy is replaced -- open).  Not modelled: overlap 1 (both copies of the shared line are perimeter cells; the reference patches those
 tiles, process_manager.py `_patch_overlap1_edges`), the masks (edge_todo / edge_done as a boolean transfer), NaN / flats,
 pit edges across interfaces.  The full cells x inlets operator is built here; a product version needs the perimeter x
 inlets part for the sweeps (tools/sim_edge_transfer.py: 3-4 entries per inlet) and one interior cascade at the end.
@@ -78,7 +79,9 @@ def run(raster, ny, nx, ov, dkw):
     for i in range(T):
         te, be, le, re = W[i]; n, m = shape[i]
         ii, jj = np.divmod(np.arange(n * m), m)
-        per = np.flatnonzero(((ii == 0) | (ii == n - 1) | (jj == 0) | (jj == m - 1)) & todo[i].ravel())
+        # every perimeter cell that has an authoritative copy elsewhere (the reference overwrites finished edge cells with the
+        # neighbour's value whether or not they were `todo`: with pit edges a perimeter cell's own value can be wrong without being todo)
+        per = np.flatnonzero((ii == 0) | (ii == n - 1) | (jj == 0) | (jj == m - 1))
         cells, where = [], []
         for c in per:
             R, C = te + ii[c], le + jj[c]
@@ -134,6 +137,7 @@ def run(raster, ny, nx, ov, dkw):
         sel = dd > depth[te:be, le:re]
         out[te:be, le:re][sel] = final[i].reshape(n, m)[sel]
         depth[te:be, le:re][sel] = dd[sel]
+    run.last = dict(pm=pm, W=W, final=[f.reshape(sh) for f, sh in zip(final, shape)], S=S, shape=shape)      # for inspection
     return out, it + 1, nnz, sum(s.size for s in S)
 
 
