@@ -2,9 +2,9 @@
 """bench.py -- headline benchmark: Mcells/s of the per-tile terrain hot path
 (slope + aspect + flats + section/proportion + UCA sweep + TWI) on synthetic DEM tiles.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W        (any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE)
 
 Workload (BASELINE.json: the metric is quoted on the 16384x16384 fp64 tile, configs[2]): every
 rank owns ONE 16384x16384 float64 fractal tile (deterministic generator, evaluated at the tile's
@@ -14,11 +14,14 @@ region).  One step = one full pass of the hot path over the resident tile
 units: weak scaling, no data-path collective in the timed region (the cross-tile edge fix-up is
 a separate, latency-bound exchange -- DESIGN.md).
 
-Prints ONE JSON line on rank 0.  `roofline` is measured live inside the timed region: every step
-brackets the interior stencil kernel with hipEvents on the tile's own HIP stream (stage timings of
-the C-ABI), `avg_kernel_ms` is the mean over the K timed steps; algorithmic bytes = 24 B/cell (read
-elev 8 + write mag 8 + direction 8).  `back_to_back_ms` re-launches the same
-kernel `--roof-iters` times in a row after the run (pydem_bench_stencil): warm clocks / TLB, ~15 % less.  `cpu_baseline` times the CPU oracle (a port of the reference algorithm,
+Prints ONE JSON line on rank 0.  `roofline` describes the DOMINANT stage of the step, the UCA sweep (the
+tile-pass kernels k_sweep_tiles*): algorithmic bytes 40 B per cell (12 read: graph word 4 + proportion 8;
+28 written: area 8, the two contributions 16, level stamp 4 -- DESIGN.md section 4) over the stage time that
+the C-ABI brackets with hipEvents on the tile's own HIP stream in every timed step.  `roofline_stages` lists
+the same three numbers (algorithmic bytes, time, PMC traffic from the committed rocprofv3 passes) for the
+stencil, the pit search, the sweep and TWI; `roofline_stencil` is the slope/aspect kernel alone (24 B/cell:
+read elev 8 + write mag 8 + direction 8, SURVEY.md section 8d -- the kernel BASELINE.json's 40 % target is
+about); its `back_to_back_ms` re-launches the kernel `--roof-iters` times in a row after the run.  `cpu_baseline` times the CPU oracle (a port of the reference algorithm,
 bit-exact against golden vectors of the reference) on a bounded sample of the same workload.
 """
 import argparse
@@ -178,25 +181,43 @@ def run_config5(args):
         "not_in_value": {"h2d_ms": stages['h2d_ms'], "what": "upload of the raw int16 tile (pageable host memory) at the start of the step"}}))
 
 
-def pmc_traffic(kernel, size):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*pmc*.csv:
-    separate FETCH_SIZE / WRITE_SIZE runs of this same command at 16384^2).  FETCH_SIZE counts half of
-    the bytes of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section; calibrated on k_twi
-    in profiles/README.md), so bytes = (2 * FETCH_KiB + WRITE_KiB) * 1024.  None when no profile of
-    this tile size is present (PMC counters cannot be read from inside the timed process)."""
+def pmc_traffic(kernels, size):
+    """HBM bytes per STEP of the kernels whose names contain one of `kernels` (a name or a tuple of names), from the
+    committed rocprofv3 PMC passes (profiles/r*_pmc_fetch_write_16384*.csv: separate FETCH_SIZE / WRITE_SIZE runs of
+    this same command with --steps 1 --warmup 0, so `dispatches` is per step).  FETCH_SIZE counts half of the bytes of
+    wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section; calibrated on k_twi in profiles/README.md), so
+    bytes = (2 * FETCH_KiB + WRITE_KiB) * 1024, summed over the dispatches.  None when no profile of this tile size is
+    present (PMC counters cannot be read from inside the timed process)."""
     import csv
     import glob
     if size != 16384:
         return None
+    if isinstance(kernels, str):
+        kernels = (kernels,)
     best = None
     for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_fetch_write_16384*.csv'))):
-        vals = {}
+        tot = {'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0}
+        seen = set()
         for row in csv.DictReader(open(fn)):
-            if kernel in row['kernel']:
-                vals[row['counter']] = float(row['mean_per_dispatch_KB'])
-        if 'FETCH_SIZE' in vals and 'WRITE_SIZE' in vals:
-            best = (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0
+            if any(k in row['kernel'] for k in kernels) and row['counter'] in tot:
+                # the stencil is re-launched for `back_to_back_ms` after the step: one dispatch per step counts
+                disp = 1 if 'k_stencil' in row['kernel'] else int(row['dispatches'])
+                tot[row['counter']] += float(row['mean_per_dispatch_KB']) * disp
+                seen.add(row['counter'])
+        if len(seen) == 2:
+            best = (2.0 * tot['FETCH_SIZE'] + tot['WRITE_SIZE']) * 1024.0
     return best
+
+
+# stages of the step for `roofline_stages`: (name, kernels of the stage, algorithmic bytes per cell, timing key, what the bytes are)
+STAGES = [
+    ('stencil', ('k_stencil_march', 'k_stencil_perimeter'), 24.0, 'stencil_kernel_ms', 'read elev 8 + write mag 8 + direction 8'),
+    ('pits', ('k_pits_', 'k_pitmask', 'k_pit_keys', 'k_pit_gather', 'radix_sort'), 9.4, 'pits_ms',
+     'read elev 8 + flats 1 per cell + write 16 B per pit edge (6.49 M edges on the bench tile: 0.4 B/cell)'),
+    ('sweep', ('k_sweep_tiles', 'k_pit_stash', 'k_uca_finalize'), 40.0, 'sweep_ms',
+     'read graph word 4 + proportion 8, write area 8 + two contributions 16 + level stamp 4 per cell'),
+    ('twi', ('k_twi',), 24.0, 'twi_ms', 'read uca 8 + mag 8, write twi 8'),
+]
 
 
 def tile_specs(world, n, m, px=30.0):
@@ -220,6 +241,10 @@ def main():
         if int(os.environ.get('WORLD_SIZE', '1')) > 1:
             raise SystemExit("bench --config %d is a single-GPU line" % args.config)
         return run_config2(args) if args.config == 2 else run_config5(args)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # no launcher: one process per GPU, started here (rank 0 prints the line)
+        from pydem_amd import rendezvous
+        sys.exit(rendezvous.spawn_ranks([sys.executable] + sys.argv, args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -234,26 +259,24 @@ def main():
                                         keep_first_pass_uca=False, n_workers=world,
                                         edge_mode=('pool' if world > 1 else 'reference'))
     exchange = "in-process"
+    group = None
     if world > 1:
-        # process-group plumbing only (hands the RCCL id around); the strips themselves travel over RCCL
-        import torch.distributed as dist
+        # process-group plumbing only (hands the RCCL id around: pydem_amd/rendezvous.py); the strips travel over RCCL
+        from pydem_amd import parallel, rendezvous
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
-        from pydem_amd import parallel
+        group = rendezvous.SocketGroup(rank, world)
         rccl = None
         try:
-            rccl = parallel.make_rccl_transport(pm, device, dist)
+            rccl = parallel.make_rccl_transport(pm, device, group)
         except Exception as e:      # keep the scaling run alive and say so in the JSON line
             sys.stderr.write("bench: rank %d: RCCL transport unavailable (%s)\n" % (rank, e))
         # every rank must take the same path: one failed communicator sends all of them to the host fallback
-        ok = [None] * world
-        dist.all_gather_object(ok, rccl is not None)
-        if all(ok):
+        if all(group.all_gather_object(rccl is not None)):
             pm.transport = rccl
             exchange = "rccl"
         else:
-            pm.transport = parallel.DistTransport(pm, rank, world)
-            exchange = "gloo-host-fallback"
+            pm.transport = parallel.DistTransport(pm, group)
+            exchange = "socket-host-fallback"
     pm.compute_grid()
     pm.process_elevation()          # tiles are generated on their GPU: HBM-resident before the timed region
     mine = [i for i in range(pm.n_inputs) if pm.transport.owns(i)]
@@ -274,7 +297,10 @@ def main():
         t3 = time.perf_counter()
         phase['tile_ms'] = (t1 - t0 + t3 - t2) * 1e3
         phase['edge_fixup_ms'] = (t2 - t1) * 1e3
-        stencil_ms.append(pm.tiles[mine[0]]._tile.timings()['stencil_kernel_ms'])
+        tmk = pm.tiles[mine[0]]._tile.timings()
+        stencil_ms.append(tmk['stencil_kernel_ms'])
+        for _, _, _, key, _ in STAGES:
+            stage_ms.setdefault(key, []).append(tmk[key])
 
     def barrier():
         for i in mine:
@@ -282,11 +308,12 @@ def main():
         if world > 1:
             pm.transport.barrier()
 
-    stencil_ms = []
+    stencil_ms, stage_ms = [], {}
     for _ in range(args.warmup):
         step()
     barrier()
     del stencil_ms[:]
+    stage_ms.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -302,13 +329,24 @@ def main():
     if rank == 0:
         cells = float(n) * m
         value = world * cells * args.steps / dt / 1e6
-        st_b2b = tile.bench_stencil(args.roof_iters)
+        st_b2b = tile.bench_stencil(args.roof_iters) if args.roof_iters > 0 else None
         st_ms = sum(stencil_ms) / len(stencil_ms)
         achieved = STENCIL_BYTES_PER_CELL * cells / (st_ms * 1e-3) / 1e9
+        ms_step = dt / args.steps * 1e3
+        stages = []
+        for name, kernels, bpc, key, what in STAGES:
+            ms = sum(stage_ms[key]) / len(stage_ms[key])
+            if ms <= 0:
+                continue
+            gbs = bpc * cells / (ms * 1e-3) / 1e9
+            stages.append({"stage": name, "kernels": list(kernels), "ms": ms, "share_of_step": ms / ms_step,
+                           "algorithmic_bytes": bpc * cells, "algorithmic_bytes_per_cell": bpc, "bytes_are": what,
+                           "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(kernels, n)})
+        dom = max(stages, key=lambda d: d["ms"])
         out = {
             "metric": "Mcells/s (slope+aspect+UCA+TWI end-to-end) per tile; % HBM roofline",
             "value": value, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%dx%d fp64 fractal tile per GPU (seed 1, dX=dY=30 m, %d-tile mosaic with 1-pixel "
                                    "overlap), fill_flats=False, drain_pits_path=False, drain_pits=%s: "
@@ -316,11 +354,20 @@ def main():
                                    % (n, m, world, bool(args.drain_pits)),
                        "tile": [n, m], "tiles_per_gpu": 1, "parallelism": "tile-per-gpu x%d" % world,
                        "edge_exchange": exchange},
-            "roofline": {"bound": "hbm", "kernel": "k_stencil_march", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_stencil_march", n),
-                         "algorithmic_bytes": STENCIL_BYTES_PER_CELL * cells,
-                         "avg_kernel_ms": st_ms, "back_to_back_ms": st_b2b,
-                         "algorithmic_bytes_per_cell": STENCIL_BYTES_PER_CELL},
+            # the dominant stage of the step (largest share of ms_per_step); stage time = hipEvents on the tile's stream
+            "roofline": {"bound": "hbm", "kernel": "/".join(dom["kernels"]) + " (stage '%s')" % dom["stage"], "achieved": dom["achieved"],
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": dom["traffic"],
+                         "algorithmic_bytes": dom["algorithmic_bytes"], "avg_kernel_ms": dom["ms"],
+                         "algorithmic_bytes_per_cell": dom["algorithmic_bytes_per_cell"], "share_of_step": dom["share_of_step"],
+                         "note": "stage = the kernels listed, bracketed by hipEvents on the tile's stream in every timed step; "
+                                 "latency-bound tile passes (DESIGN.md section 4), not a streaming kernel"},
+            "roofline_stages": stages,
+            # the slope / aspect kernel alone: the kernel BASELINE.json's 40 % target is about
+            "roofline_stencil": {"bound": "hbm", "kernel": "k_stencil_march", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_stencil_march", n),
+                                 "algorithmic_bytes": STENCIL_BYTES_PER_CELL * cells,
+                                 "avg_kernel_ms": st_ms, "back_to_back_ms": st_b2b,
+                                 "algorithmic_bytes_per_cell": STENCIL_BYTES_PER_CELL},
             "end_to_end_GBs": E2E_BYTES_PER_CELL * world * cells * args.steps / dt / 1e9,
             "stages_ms": dict({k: tm[k] for k in ('slopes_directions_ms', 'stencil_kernel_ms', 'flats_ms', 'graph_ms',
                                                    'pits_ms', 'sweep_ms', 'twi_ms')}, **phase),
@@ -334,8 +381,8 @@ def main():
         print(json.dumps(out))
     if world > 1:
         pm.transport.barrier()
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        group.barrier()
+        group.close()
 
 
 if __name__ == '__main__':

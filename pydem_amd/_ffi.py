@@ -390,7 +390,7 @@ class Comm(object):
 
     def __init__(self, world, rank, uid, device=0):
         self.lib = load()
-        self.world, self.rank = world, rank
+        self.world, self.rank, self.device = world, rank, device
         self._h = C.c_void_p()
         check(self.lib.pydem_comm_create(world, rank, uid, device, C.byref(self._h)))
 

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libpydem_hip.so')
-SOURCES = ['tile.hip', 'stencil.hip', 'flats.hip', 'uca.hip', 'pits.hip', 'synth.hip', 'comm.hip', 'cyutils.hip', 'conditioning.hip', 'cond_device.hip', 'cond_paths.hip']
+SOURCES = ['tile.hip', 'stencil.hip', 'flats.hip', 'uca.hip', 'pits.hip', 'synth.hip', 'comm.hip', 'cyutils.hip', 'cond_host.cpp', 'cond_device.hip', 'cond_paths.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-fno-fast-math',
          '-Wall', '-Wno-unused-function', '-Wno-unused-result']
@@ -28,12 +28,13 @@ def _deps_mtime():
 
 
 def _compile(src, force):
-    obj = os.path.join(LIBDIR, src.replace('.hip', '.o'))
+    obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + '.o')
     path = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime())):
         return obj, False
-    subprocess.check_call([HIPCC] + FLAGS + ['-c', path, '-o', obj])
+    lang = ['-x', 'hip'] if src.endswith('.cpp') else []     # host-only units share internal.h (HIP types): same front end
+    subprocess.check_call([HIPCC] + FLAGS + lang + ['-c', path, '-o', obj])
     return obj, True
 
 

@@ -9,7 +9,7 @@ no-data cells (the order in which scipy's filters meet a NaN is not reproduced o
 surfaces whose pit paths are rounded in the array's own dtype, and the rare tile on which the order-preserving
 parallel schedule of the pit paths gives up.  The vectorised prologues stay in numpy / scipy.ndimage (3x3 filters,
 connected-component labels, the argsort whose tie order is part of the result); the per-region / per-pit loops run in
-the native library (csrc/conditioning.hip, host code behind the same C-ABI).  Results are pinned bit for bit by
+the native library (csrc/cond_host.cpp, host code behind the same C-ABI).  Results are pinned bit for bit by
 tests/golden/g5_* and g7_* (captured from the reference); the numpy statements the native loops were written from are
 test infrastructure (tests/conditioning_numpy.py).
 """

@@ -18,7 +18,7 @@
 //     every region frozen at the sweep at which utils.get_distance would have stopped for it -- as soon as all of
 //     its cells have SOME finite value, not at convergence (:392-401): the sweep number is part of the result.
 // Every floating-point expression keeps numpy's operation order (-ffp-contract=off); the host implementation
-// (conditioning.hip behind pydem_amd/conditioning.py, pinned bit for bit by tests/golden/g5_* and g7_*) is the
+// (cond_host.cpp behind pydem_amd/conditioning.py, pinned bit for bit by tests/golden/g5_* and g7_*) is the
 // twin the tests compare with.  Tiles with no-data (NaN) cells are left to the host path: the order in which
 // scipy's filters meet a NaN is an implementation detail this file does not reproduce.
 #include "internal.h"

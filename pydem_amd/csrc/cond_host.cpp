@@ -1,4 +1,4 @@
-// conditioning.hip -- host-side inner loops of the elevation conditioning (no device code).
+// cond_host.cpp -- host-side inner loops of the elevation conditioning (no device code).
 //
 // The reference conditions a tile before the slope stencil (pydem/dem_processing.py:
 // calc_fill_pit_artifacts :396-426, calc_fill_flats :551-579 with _fill_flat :308-394,

@@ -16,7 +16,7 @@
 // One thing the reservations cannot see: a pit that has to wait may, after an earlier path lowered its rim, grow in a
 // new direction and meet a cell that a LATER pit has already rewritten.  Committed cells carry the order of their
 // writer; a simulation that reads a cell written by a later pit raises a flag and the caller falls back to the host
-// loop (conditioning.hip: pydem_cond_pit_paths) on the untouched surface.  The soak tools count how often
+// loop (cond_host.cpp: pydem_cond_pit_paths) on the untouched surface.  The soak tools count how often
 // that happens.
 //
 // A simulation is a wavefront: membership of region + rim in a window bitmap in LDS (64 x 64 cells; pits that leave

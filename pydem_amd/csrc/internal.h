@@ -87,7 +87,6 @@ struct pydem_tile {
     bool edge_clean = false;        // edge flags / counts are zero and the masks only differ from their defaults on etodo_prev cells
     bool einc_compact = false;      // ... in the compact record form (one 128-byte record per not-done cell)
     void *nd_rec = nullptr; int64_t nd_cap = 0; int32_t nd = 0;
-    void *crec = nullptr; int64_t crec_cap = 0;   // compact records of the open cells (tile passes >= 3 of the sweep, uca.hip K5d)
     int64_t circular_cells = -1;    // cells the last sweep found on / below a drainage loop (-1: no sweep ran on this handle)
     int64_t einc_round = 0;         // incremental edge rounds run on this tile so far (stamps of the NaN flood)
     bool einc_ready = false;        // incremental edge rounds: counts / deltas / FINAL flags are live (uca.hip K7i)

@@ -3,8 +3,11 @@
 // Replaces _tarboton_slopes_directions (reference pydem/dem_processing.py:1753-1903) with its
 // helpers _get_d1_d2 (:1905-1938) and _calc_direction (:1942-1991).  The reference makes 8
 // full-array numpy passes (one per facet) plus 4 edge and 4 corner passes; here one kernel
-// handles every interior cell (all 8 facets in registers, elevation staged through an LDS halo
-// tile) and a second O(perimeter) kernel applies the edge/corner rules.
+// handles every interior cell and a second O(perimeter) kernel applies the edge/corner rules.
+// The default interior kernel is k_stencil_march: one lane per column, rows marched in registers
+// band by band, the neighbours' quotients through DPP wavefront shifts, facet states as mask algebra
+// on the scalar unit; k_stencil_interior -- all 8 facets per cell from an LDS
+// halo tile -- is the first version, kept as PYDEM_STENCIL=tile (5.3 ms against 3.0 ms at 16384^2).
 //
 // Bounded by HBM: algorithmic traffic 24 B/cell (read elev 8, write mag 8 + direction 8), plus
 // 1 B/cell for the flat0 mask consumed by the flats stage.  No MFMA: there is no contraction.

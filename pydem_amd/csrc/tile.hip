@@ -178,7 +178,7 @@ int pydem_tile_destroy(pydem_tile *t)
                     t->counters, t->scratch, t->pits.src, t->pits.dst, t->pits.w, t->pits.in_src,
                     t->pits.in_dst, t->pits.in_w, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w,
                     t->estamp, t->edelta, t->p_delta, t->s_data, t->p_flags, t->s_flags, t->line_stage, t->contrib,
-                    t->eseed, t->lines_stage, t->pits.sort_buf, t->nd_rec, t->crec};
+                    t->eseed, t->lines_stage, t->pits.sort_buf, t->nd_rec};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     if (t->h_strip_d) (void)hipHostFree(t->h_strip_d);

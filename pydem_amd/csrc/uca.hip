@@ -226,9 +226,6 @@ struct SweepArgs {
     int64_t n_pit;
     int dbg;                     // timing experiments only (PYDEM_TILE_DEBUG)
     int32_t qcap;                // frontier queue capacity (entries)
-    int32_t *tile_open;          // per 32x32 tile: cells that are still open after the tile's last visit (the compact passes size their segments by it)
-    int32_t *tile_off;           // per tile: first record of its segment; seg_cursor (pass 2 only): the allocator, [0] records, [1] tiles of the big class
-    int32_t *seg_cursor;
     int32_t *err;                // queue overflow counter
 };
 
@@ -612,7 +609,6 @@ __device__ __forceinline__ void tile_wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
-constexpr int CS_SMALL = 256;    // compact passes (K5d): records of a tile of the small class
 constexpr int TILE_PEND = 48;    // woken tiles a wavefront collects before it appends them to the next pass's list
 struct TileNext {            // LISTED passes: tiles that must run again in the next pass
     int32_t *flag;           // per tile: last pass it was listed for
@@ -633,7 +629,7 @@ __device__ __forceinline__ double in_edge(const SweepArgs &A, int32_t c, int m, 
 template <bool LISTED>
 __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uint32_t pass, int tiles_x, int tid, int lane,
                                                uint8_t *__restrict__ tile_done, int32_t &n_final, const TileNext &N,
-                                               int32_t *pend, int &npend, int32_t &remaining)
+                                               int32_t *pend, int &npend)
 {
     const int by = tid / tiles_x, bx = tid - by * tiles_x;
     const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
@@ -900,8 +896,6 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
     if (lane == 0) {
         n_final += finalized;          // (lane 0's running count: the kernel adds it to the global counter once, see there)
         if (finalized == n_open) tile_done[tid] = 1;
-        remaining = n_open - finalized;          // (lane 0) what the compact passes will find in this tile
-        if (A.tile_open) A.tile_open[tid] = remaining;
         if (prof) {      // cycles per phase, summed over tiles (PYDEM_TILE_DEBUG=4)
             const long long tk4 = wall_clock64();
             unsigned long long *acc = reinterpret_cast<unsigned long long *>(A.err + 1 + 16);   // counters[32..] region: see stage_sweep
@@ -926,30 +920,19 @@ __global__ __launch_bounds__(256, 8) void k_sweep_tiles(SweepArgs A, uint32_t pa
     // workgroup b runs on XCD b % 8: give every XCD one contiguous band of tiles (gridDim.x is a multiple of 8)
     const int per = (gridDim.x >> 3) * 4;
     const int tid = (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + wave;
-    int32_t fin = 0, remaining = 0;
+    int32_t fin = 0;
     int npend = 0;
     if (tid < tiles_total && !tile_done[tid])
-        sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend, remaining);
+        sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend);
     // the counter of finished cells and the counter of the next pass's tile list are single addresses: a quarter of a
     // million tile runs per pass adding to them one by one keep their L2 channel busy for ~10 ns each -- one add per
     // workgroup for either
-    __shared__ int32_t s_rem[4];
-    if (lane == 0) { s_fin[wave] = fin; s_np[wave] = npend; s_rem[wave] = remaining; }
+    if (lane == 0) { s_fin[wave] = fin; s_np[wave] = npend; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const int32_t tot = s_fin[0] + s_fin[1] + s_fin[2] + s_fin[3];
         if (tot) atomicAdd(n_final, tot);
         if (LISTED) { const int32_t np = s_np[0] + s_np[1] + s_np[2] + s_np[3]; s_base = np ? atomicAdd(N.count, np) : 0; }
-        if (A.seg_cursor) {
-            // the record segments of the compact passes (K5d): one allocation per workgroup, the four tiles side by side
-            const int32_t need = s_rem[0] + s_rem[1] + s_rem[2] + s_rem[3];
-            if (need) {
-                int32_t off = atomicAdd(A.seg_cursor, need), big = 0;
-                const int t0 = tid - wave;
-                for (int w = 0; w < 4; w++) { if (t0 + w < tiles_total) A.tile_off[t0 + w] = off; off += s_rem[w]; big += s_rem[w] > CS_SMALL ? 1 : 0; }
-                if (big) atomicAdd(A.seg_cursor + 1, big);
-            }
-        }
     }
     if (LISTED) {
         __syncthreads();
@@ -971,7 +954,7 @@ __global__ __launch_bounds__(256, 6) void k_sweep_tiles_listed(SweepArgs A, uint
     // (the tile id is the same for the whole wavefront: as a scalar it keeps the tile's coordinates and every address
     // derived from them out of the vector registers)
     __shared__ int32_t s_pend[4][TILE_PEND];
-    int32_t fin = 0, remaining = 0;   // finished cells of all tiles of this wavefront: one add at the end
+    int32_t fin = 0;               // finished cells of all tiles of this wavefront: one add at the end
     int npend = 0;                 // tiles woken by this wavefront's visits that are not on the global list yet
     auto flush = [&]() {
         tile_wave_sync();
@@ -983,7 +966,7 @@ __global__ __launch_bounds__(256, 6) void k_sweep_tiles_listed(SweepArgs A, uint
         tile_wave_sync();
     };
     for (int32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); k < nt; k += gridDim.x * 4) {
-        sweep_one_tile<true>(A, L[wave], pass, tiles_x, __builtin_amdgcn_readfirstlane(list_in[k]), lane, tile_done, fin, N, s_pend[wave], npend, remaining);
+        sweep_one_tile<true>(A, L[wave], pass, tiles_x, __builtin_amdgcn_readfirstlane(list_in[k]), lane, tile_done, fin, N, s_pend[wave], npend);
         if (npend > TILE_PEND - 10) flush();            // (a visit adds at most ten)
     }
     if (npend) flush();
@@ -1020,7 +1003,7 @@ __device__ __forceinline__ void lds_sync()
 }
 
 __global__ __launch_bounds__(256) void k_sweep_first(SweepArgs A, int tiles_x, int tiles_total, uint8_t *__restrict__ tile_done,
-                                                     int32_t *n_final, int max_rounds, int chain)
+                                                     int32_t *n_final)
 {
     __shared__ TileFirst L;
     __shared__ int32_t s_fin[2], s_any[2];
@@ -1071,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_sweep_first(SweepArgs A, int tiles_x, i
     // ---- rounds.  A thread that counts a target down to zero goes on with that target itself ("chain": a river is
     // walked by one thread within one round instead of one cell per round); whatever else becomes ready waits for
     // its owner's next look
-    for (int round = 0; round < max_rounds; round++) {
+    for (;;) {
         uint32_t ready = 0;
 #pragma unroll
         for (int k = 0; k < NSET; k++)
@@ -1119,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_sweep_first(SweepArgs A, int tiles_x, i
                     if (tr >= 0 && tr < TT && tc >= 0 && tc < TT &&
                         (atomicSub(&L.cs[tr * TT + tc], 1u) & (FC_COUNT | FC_BLOCKED)) == 1u && next < 0) next = tr * TT + tc;
                 }
-                cur = chain ? next : -1;
+                cur = next;
             } while (cur >= 0);
         }
         lds_sync();
@@ -1144,416 +1127,6 @@ __global__ __launch_bounds__(256) void k_sweep_first(SweepArgs A, int tiles_x, i
         if (s_fin[0]) atomicAdd(n_final, s_fin[0]);
         if (s_fin[0] == s_fin[1]) tile_done[tid] = 1;
     }
-}
-
-// ------------------------------------------------------------------------------- K5d
-// Compact passes.  After the first two tile passes ~85 % of the grid is final and what is left of a tile is a thin
-// network of valley lines (~150 of its 1024 cells), yet a generic visit still stages and scans the whole tile and pays
-// one or two global-memory round trips (plus the store fence) in every round -- under load 10-15 us per round
-// (profiles/r02_tile_pass_phases.txt).  Here the OPEN cells of every tile are written once as 32-byte records (one
-// contiguous segment per tile, allocated by pass 2 with one atomic per workgroup); a visit loads the tile's records into
-// LDS, checks only the in-edges that cross the tile border against the level stamps, and runs its rounds on LDS alone:
-// K = cell area + everything the cell has received from finished upstream cells so far, the shares of cells that finish
-// during the visit are pulled from their LDS records (a * p, a * (1 - p): the same products the generic pass stores as
-// contributions).  Results (area, contribution, level stamp, todo flag) are written when the visit ends; the surviving
-// records go back to the front of the segment with what they received during the visit added to K.  Summation order: a
-// cell's in-edges are added in the order in which they become final (ascending neighbour order within one visit), not
-// in one ascending sweep like the generic pass -- the fixed point is the same, uca differs by rounding only (measured
-// <= 3e-15 relative at 4096^2; BASELINE.json allows 1e-6), masks and level semantics are identical.  Pit in-edges are
-// pulled when the drain finishes (all their sources are final by then), in list order like the generic pass.
-// Tiles with more than CS_SMALL records are visited by a second instantiation with room for all 1024 cells (28 KB of
-// LDS: 5 tiles per CU instead of 18); records only disappear, so every tile ends up in the small class.
-struct CRec {
-    double K;            // cell area + shares of the finished upstream cells (regular in-edges) accounted so far
-    double p;            // proportion (0 when the cell has no regular out-edge)
-    uint32_t meta;       // bits 0-7 regular in-edges NOT in K yet, 8-14 static graph bits of the cell word, 15 edge_todo taint
-    uint16_t cell;       // cell of the tile: row * 32 + column
-    uint16_t inmask;     // the cell's full in-mask (for the level stamp the visit writes)
-    int32_t pin_off, pout_off;   // first pit in-edge / out-edge (the stash of the cell's area slot)
-};
-static_assert(sizeof(CRec) == 32, "two records per 64-byte sector");
-constexpr uint32_t CM_TAINT = 1u << 15, CM_FIN = 1u << 16;
-constexpr int CM_COUNT_SHIFT = 20;
-constexpr int CM_PIN_SHIFT = 18, CM_PIN_NONE = 127, CT_PIN_TAB = 64;     // cm bits 18-24: the record's entry of the pit in-edge offset table
-
-// neighbours (bits of an in-mask) that lie outside the tile for a cell at (li, lj)
-__device__ __forceinline__ uint32_t outside_tile_mask(int li, int lj)
-{
-    return (li == 0 ? 0x07u : 0u) | (li == TT - 1 ? 0xE0u : 0u) | (lj == 0 ? 0x29u : 0u) | (lj == TT - 1 ? 0x94u : 0u);
-}
-// tile-local cell of in-edge d's source
-__device__ __forceinline__ int nb_local(int cell, int d)
-{
-    const int q = d + (d >> 2), di = (q * 11) >> 5;
-    return cell + (di - 1) * TT + (q - 3 * di - 1);
-}
-
-// records of the cells that are not final before `pass`, in row-major order per tile (one wavefront per tile): the level
-// stamps of tile + halo become a bitmap in LDS (like the staging of the generic pass), then per open cell the in-edges
-// from final cells are gathered in batches
-__global__ __launch_bounds__(256) void k_compact_build(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total, CRec *__restrict__ recs, int32_t *err)
-{
-    __shared__ unsigned long long s_fin[4][HW];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int per = (gridDim.x >> 3) * 4;
-    const int tid = (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + wave;
-    if (tid >= tiles_total) return;
-    const int32_t expect = A.tile_open[tid];
-    if (expect == 0) return;
-    unsigned long long *fin = s_fin[wave];
-    CRec *seg = recs + A.tile_off[tid];
-    const int by = tid / tiles_x, bx = tid - by * tiles_x;
-    const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
-    const int half = lane >> 5, l32 = lane & 31;
-    auto stage_word = [&](int gi, int gj) -> uint32_t { return (gi >= 0 && gi < n && gj >= 0 && gj < m) ? A.cinfo[(int64_t)gi * m + gj] : 0xFFFFFFFFu; };
-    auto final_before = [&](uint32_t w) -> bool { if (w == 0xFFFFFFFFu) return true; const uint32_t lv = ci_level(w); return lv >= 1 && lv < pass; };
-    constexpr int NSET = TT / 2;
-    uint32_t wst[NSET];
-#pragma unroll
-    for (int k = 0; k < NSET; k++) wst[k] = stage_word(i0 + 2 * k + half, j0 + l32);
-    uint32_t colL, colR;
-    {
-        const uint32_t wc = stage_word(i0 + l32, half ? j0 + TT : j0 - 1);
-        const uint32_t wr = stage_word(half ? i0 + TT : i0 - 1, j0 + l32);
-        uint32_t wk = 0xFFFFFFFFu;
-        if (lane < 4) wk = stage_word((lane & 2) ? i0 + TT : i0 - 1, (lane & 1) ? j0 + TT : j0 - 1);
-        const unsigned long long bc = __ballot(final_before(wc)), br = __ballot(final_before(wr)), bk = __ballot(lane < 4 && final_before(wk));
-        colL = (uint32_t)bc; colR = (uint32_t)(bc >> 32);
-        if (lane == 0) {
-            fin[0] = ((br & 0xFFFFFFFFull) << 1) | (bk & 1ull) | (((bk >> 1) & 1ull) << 33);
-            fin[HW - 1] = ((br >> 32) << 1) | ((bk >> 2) & 1ull) | (((bk >> 3) & 1ull) << 33);
-        }
-    }
-    uint32_t openbits = 0;
-    int slot[NSET];
-    int base = 0;
-#pragma unroll
-    for (int k = 0; k < NSET; k++) {
-        const int r = 2 * k;
-        const bool f = final_before(wst[k]);
-        const unsigned long long b = __ballot(f), bo = __ballot(!f);
-        if (lane == 0) {
-            fin[r + 1] = ((b & 0xFFFFFFFFull) << 1) | ((colL >> r) & 1u) | ((unsigned long long)((colR >> r) & 1u) << 33);
-            fin[r + 2] = ((b >> 32) << 1) | ((colL >> (r + 1)) & 1u) | ((unsigned long long)((colR >> (r + 1)) & 1u) << 33);
-        }
-        if (!f) openbits |= 1u << k;
-        slot[k] = base + __popcll(bo & ((1ull << lane) - 1ull));
-        base += __popcll(bo);
-    }
-    tile_wave_sync();
-    constexpr int KB = 4;
-#pragma unroll
-    for (int kb = 0; kb < NSET; kb += KB) {
-        if (!((openbits >> kb) & ((1u << KB) - 1u))) continue;
-        double xs[KB][4], pv[KB];
-        uint32_t keep[KB], rest[KB];
-        int2 po[KB];
-        uint8_t tdw[KB];
-#pragma unroll
-        for (int q = 0; q < KB; q++) {
-            const int k = kb + q;
-            keep[q] = 0; rest[q] = 0; pv[q] = 0.0; po[q] = make_int2(0, 0); tdw[q] = 0;
-#pragma unroll
-            for (int z = 0; z < 4; z++) xs[q][z] = 0.0;
-            if (!((openbits >> k) & 1u)) continue;
-            const int li = 2 * k + half + 1, gi = i0 + li - 1, gj = j0 + l32;
-            const int32_t c = gi * m + gj;
-            const uint32_t w = wst[k];
-            const unsigned long long f0 = fin[li - 1], f1 = fin[li], f2 = fin[li + 1];
-            const uint32_t nf = ((uint32_t)(f0 >> l32) & 7u) | (((uint32_t)(f1 >> l32) & 1u) << 3) |
-                                (((uint32_t)(f1 >> (l32 + 2)) & 1u) << 4) | (((uint32_t)(f2 >> l32) & 7u) << 5);
-            keep[q] = w & 0xFFu & ~nf;
-            uint32_t mm = w & 0xFFu & nf;
-#pragma unroll
-            for (int z = 0; z < 4; z++)
-                if (mm) { const int d = __ffs(mm) - 1; mm &= mm - 1u; xs[q][z] = in_edge(A, c, m, d); }
-            rest[q] = mm;
-            if (w & (CI_OUT1 | CI_OUT2)) pv[q] = A.prop[c];
-            if (w & (CI_PIT_IN | CI_PIT_OUT)) po[q] = pit_stash(A, c);
-            if (gi == 0 || gi == n - 1 || gj == 0 || gj == m - 1) tdw[q] = A.todo_work[c];
-        }
-#pragma unroll
-        for (int q = 0; q < KB; q++) {
-            const int k = kb + q;
-            if (!((openbits >> k) & 1u)) continue;
-            const int li = 2 * k + half, gi = i0 + li, gj = j0 + l32;
-            const int32_t c = gi * m + gj;
-            const uint32_t w = wst[k];
-            double K = A.a0[gi];
-            bool td = tdw[q] != 0;
-#pragma unroll
-            for (int z = 0; z < 4; z++) { K += fabs(xs[q][z]); td = td || (xs[q][z] < 0); }
-            uint32_t mm = rest[q];
-            while (mm) { const int d = __ffs(mm) - 1; mm &= mm - 1u; const double x = in_edge(A, c, m, d); K += fabs(x); td = td || (x < 0); }
-            CRec r;
-            r.K = K; r.p = pv[q];
-            r.meta = (w & 0x7F00u) | keep[q] | (td ? CM_TAINT : 0u);
-            r.cell = (uint16_t)(li * TT + l32);
-            r.inmask = (uint16_t)(w & 0xFFu);
-            r.pin_off = po[q].x; r.pout_off = po[q].y;
-            seg[slot[k]] = r;
-        }
-    }
-    if (lane == 0 && base != expect) atomicAdd(err, 1);
-}
-
-template <int CAP>
-struct CTileW {
-    double Kd[CAP];             // K while the cell is open, its area once it is finished
-    double Pd[CAP];             // proportion; a cell with pit out-edges has no regular ones: its slot carries the list offset
-    uint32_t meta[CAP];         // CRec::meta | CM_FIN (finished in this visit) | open in-edge count << CM_COUNT_SHIFT
-    uint32_t cm[CAP];           // bits 0-9 cell, 10-17 full in-mask, 18-24 entry of pin_tab
-    uint16_t ready[CAP];        // slots in the order they became ready (every record enters at most once)
-    uint16_t map[TT * TT];      // cell of the tile -> slot (0xFFFF: the cell has no record, i.e. it was final before this visit)
-    int32_t pin_tab[CT_PIN_TAB];  // first pit in-edge of the drains among the records
-    int tail, npin;
-};
-
-template <int CAP>
-__device__ __forceinline__ void compact_visit(const SweepArgs &A, CTileW<CAP> &L, CRec *__restrict__ seg, int nrec,
-                                              uint32_t pass, int tiles_x, int tid, int lane, uint8_t *__restrict__ tile_done,
-                                              int32_t &n_final, const TileNext &N, int32_t *pend, int &npend, int32_t *n_big)
-{
-    const int by = tid / tiles_x, bx = tid - by * tiles_x;
-    const int i0 = by * TT, j0 = bx * TT, m = A.m;
-    for (int k = lane; k < TT * TT / 2; k += 64) reinterpret_cast<uint32_t *>(L.map)[k] = 0xFFFFFFFFu;
-    if (lane == 0) { L.tail = 0; L.npin = 0; }
-    tile_wave_sync();
-    // a record's pit lists: the out-edge offset of a pit travels in its proportion slot, the in-edge offsets in a small table
-    auto pout_of = [&](int s, uint32_t meta) -> int32_t {
-        return (meta & (CI_OUT1 | CI_OUT2)) ? seg[s].pout_off : (int32_t)__double_as_longlong(L.Pd[s]);
-    };
-    auto pin_of = [&](int s) -> int32_t {
-        const int q = (L.cm[s] >> CM_PIN_SHIFT) & 127;
-        return q == CM_PIN_NONE ? seg[s].pin_off : L.pin_tab[q];
-    };
-    // ---- load the records; in-edges that cross the tile border: has an earlier pass finished their source?
-    for (int s = lane; s < nrec; s += 64) {
-        const CRec r = seg[s];
-        const int cell = r.cell, li = cell >> 5, lj = cell & 31;
-        const int32_t c = (i0 + li) * m + j0 + lj;
-        uint32_t meta = r.meta & 0xFFFFu;
-        double K = r.K;
-        uint32_t ext = meta & 0xFFu & outside_tile_mask(li, lj);
-        if (ext) {
-            // (both loads of an edge in flight together: the share is only used when the stamp says final)
-            uint32_t lu[5]; double xs[5]; int dd[5];
-#pragma unroll
-            for (int z = 0; z < 5; z++) {
-                dd[z] = -1; lu[z] = 0; xs[z] = 0.0;
-                if (ext) {
-                    const int d = __ffs(ext) - 1; ext &= ext - 1u; dd[z] = d;
-                    lu[z] = ci_level(A.cinfo[c + NB_DI[d] * m + NB_DJ[d]]);
-                    xs[z] = in_edge(A, c, m, d);
-                }
-            }
-#pragma unroll
-            for (int z = 0; z < 5; z++)
-                if (dd[z] >= 0 && lu[z] >= 1 && lu[z] < pass) {
-                    K += fabs(xs[z]);
-                    if (xs[z] < 0) meta |= CM_TAINT;
-                    meta &= ~(1u << dd[z]);
-                }
-        }
-        uint32_t q = CM_PIN_NONE;
-        if (meta & CI_PIT_IN) { const int o = atomicAdd(&L.npin, 1); if (o < CT_PIN_TAB) { q = (uint32_t)o; L.pin_tab[o] = r.pin_off; } }
-        double pd = r.p;
-        if ((meta & CI_PIT_OUT) && !(meta & (CI_OUT1 | CI_OUT2))) pd = __longlong_as_double((long long)r.pout_off);
-        L.Kd[s] = K; L.Pd[s] = pd; L.meta[s] = meta;
-        L.cm[s] = (uint32_t)cell | ((uint32_t)r.inmask << 10) | (q << CM_PIN_SHIFT);
-        L.map[cell] = (uint16_t)s;
-    }
-    tile_wave_sync();
-    // ---- open in-edge counts (regular ones: the bits left in the mask; pit in-edges: sources that are open in this
-    // tile -- released on chip -- or not final elsewhere -- blocked for this pass)
-    for (int s = lane; s < nrec; s += 64) {
-        uint32_t meta = L.meta[s];
-        uint32_t count = __popc(meta & 0xFFu);
-        if (meta & CI_PIT_IN) {
-            const int cell = L.cm[s] & 1023;
-            const int32_t c = (i0 + (cell >> 5)) * m + j0 + (cell & 31);
-            for (int32_t e = pin_of(s); e < A.n_pit && A.pin_dst[e] == c; e++) {
-                const int32_t sc = A.pin_src[e];
-                const int si = sc / m - i0, sj = sc % m - j0;
-                if (si >= 0 && si < TT && sj >= 0 && sj < TT) count += L.map[si * TT + sj] != 0xFFFFu ? 1u : 0u;
-                else { const uint32_t lu = ci_level(A.cinfo[sc]); count += (lu >= 1 && lu < pass) ? 0u : 1u; }
-            }
-        }
-        L.meta[s] = meta | (count << CM_COUNT_SHIFT);
-        if (count == 0) L.ready[atomicAdd(&L.tail, 1)] = (uint16_t)s;
-    }
-    tile_wave_sync();
-    // ---- rounds on LDS
-    uint32_t wake = 0;
-    int head = 0;
-    for (;;) {
-        const int tail = L.tail;
-        if (head >= tail) break;
-        const int idx = head + lane;
-        if (idx < tail) {
-            const int s = L.ready[idx];
-            const uint32_t meta = L.meta[s];
-            const int cell = L.cm[s] & 1023, li = cell >> 5, lj = cell & 31;
-            double a = L.Kd[s];
-            bool td = (meta & CM_TAINT) != 0u;
-            uint32_t mm = meta & 0xFFu;             // what is left are sources of this tile that finished during this visit
-            while (mm) {
-                const int d = __ffs(mm) - 1; mm &= mm - 1u;
-                const int ss = L.map[nb_local(cell, d)];
-                const double as = L.Kd[ss], ps = L.Pd[ss];
-                const double x = ((0x5A >> d) & 1) ? as * ps : as * (1 - ps);
-                a += fabs(x);
-                td = td || (L.meta[ss] & CM_TAINT);
-            }
-            const int32_t c = (i0 + li) * m + j0 + lj;
-            if (meta & CI_PIT_IN)
-                for (int32_t e = pin_of(s); e < A.n_pit && A.pin_dst[e] == c; e++) {
-                    const int32_t sc = A.pin_src[e];
-                    const int si = sc / m - i0, sj = sc % m - j0;
-                    int ss = 0xFFFF;
-                    if (si >= 0 && si < TT && sj >= 0 && sj < TT) ss = L.map[si * TT + sj];
-                    if (ss != 0xFFFF) { a += L.Kd[ss] * A.pin_w[e]; td = td || (L.meta[ss] & CM_TAINT); }
-                    else { a += A.area[sc] * A.pin_w[e]; td = td || (A.todo_work[sc] != 0); }
-                }
-            L.Kd[s] = a;
-            L.meta[s] = (meta & 0x7F00u) | (td ? CM_TAINT : 0u) | CM_FIN;
-            // release the targets
-            auto release = [&](int ti, int tj) {            // tile-local coordinates 0..TT-1 when inside
-                if (ti >= 0 && ti < TT && tj >= 0 && tj < TT) {
-                    const int st = L.map[ti * TT + tj];
-                    if (st != 0xFFFF && (atomicSub(&L.meta[st], 1u << CM_COUNT_SHIFT) >> CM_COUNT_SHIFT) == 1u)
-                        L.ready[atomicAdd(&L.tail, 1)] = (uint16_t)st;
-                } else {
-                    const int dti = ti < 0 ? -1 : (ti >= TT ? 1 : 0), dtj = tj < 0 ? -1 : (tj >= TT ? 1 : 0);
-                    if (ti >= -TT && ti < 2 * TT && tj >= -TT && tj < 2 * TT) wake |= 1u << ((dti + 1) * 3 + dtj + 1);
-                    else {
-                        const int tt = ((i0 + ti) / TT) * tiles_x + (j0 + tj) / TT;
-                        if (atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tt;
-                    }
-                }
-            };
-            const int sct = (int)((meta >> CI_SEC_SHIFT) & 7u);
-            if (meta & CI_OUT1) release(li + fe1r(sct), lj + fe1c(sct));
-            if (meta & CI_OUT2) release(li + fe2r(sct), lj + fe2c(sct));
-            if (meta & CI_PIT_OUT)
-                for (int32_t e = pout_of(s, meta); e < A.n_pit && A.pit_src[e] == c; e++) {
-                    const int32_t dc = A.pit_dst[e];
-                    release(dc / m - i0, dc % m - j0);
-                }
-        }
-        head = tail < head + 64 ? tail : head + 64;
-        tile_wave_sync();
-    }
-    // ---- results of the finished cells; the surviving records move to the front of the segment
-    int nsurv = 0, nfin = 0;
-    for (int s0 = 0; s0 < nrec; s0 += 64) {
-        const int s = s0 + lane;
-        const bool valid = s < nrec;
-        const uint32_t meta = valid ? L.meta[s] : 0u;
-        const bool fin = valid && (meta & CM_FIN), surv = valid && !fin;
-        const unsigned long long bs = __ballot(surv);
-        if (fin) {
-            const uint32_t cmv = L.cm[s];
-            const int cell = cmv & 1023;
-            const int32_t c = (i0 + (cell >> 5)) * m + j0 + (cell & 31);
-            const double a = L.Kd[s], pv = L.Pd[s];
-            double2 o = make_double2(0.0, 0.0);
-            if (meta & CI_OUT1) o.x = a * pv;
-            if (meta & CI_OUT2) o.y = a * (1 - pv);
-            if (meta & CM_TAINT) { o.x = -o.x; o.y = -o.y; A.todo_work[c] = 1; }
-            A.area[c] = a;
-            A.contrib[c] = o;
-            A.cinfo[c] = ci_with_level((meta & 0x7F00u) | ((cmv >> 10) & 0xFFu), pass);
-        }
-        if (surv) {
-            const uint32_t cmv = L.cm[s];
-            const int cell = cmv & 1023;
-            uint32_t mnew = meta & 0xFFFFu;
-            double K = L.Kd[s];
-            uint32_t mm = meta & 0xFFu & ~outside_tile_mask(cell >> 5, cell & 31);
-            while (mm) {
-                const int d = __ffs(mm) - 1; mm &= mm - 1u;
-                const int ss = L.map[nb_local(cell, d)];
-                if (ss != 0xFFFF && (L.meta[ss] & CM_FIN)) {
-                    const double as = L.Kd[ss], ps = L.Pd[ss];
-                    const double x = ((0x5A >> d) & 1) ? as * ps : as * (1 - ps);
-                    K += fabs(x);
-                    if (L.meta[ss] & CM_TAINT) mnew |= CM_TAINT;
-                    mnew &= ~(1u << d);
-                }
-            }
-            CRec r;
-            r.K = K; r.p = L.Pd[s]; r.meta = mnew; r.cell = (uint16_t)cell; r.inmask = (uint16_t)((cmv >> 10) & 0xFFu);
-            r.pin_off = 0; r.pout_off = 0;
-            if (meta & CI_PIT_IN) r.pin_off = pin_of(s);
-            if (meta & CI_PIT_OUT) { r.pout_off = pout_of(s, meta); if (!(meta & (CI_OUT1 | CI_OUT2))) r.p = 0.0; }
-            seg[nsurv + __popcll(bs & ((1ull << lane) - 1ull))] = r;     // (new position <= s: every record at or behind it has been read)
-        }
-        nsurv += __popcll(bs);
-        nfin += __popcll(__ballot(fin));
-    }
-    for (int off = 32; off > 0; off >>= 1) wake |= __shfl_xor(wake, off);
-    bool win = false;
-    int tt = 0;
-    if (lane < 9 && ((wake >> lane) & 1u)) { tt = tid + (lane / 3 - 1) * tiles_x + (lane % 3 - 1); win = true; }
-    if (win) win = atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1;
-    const unsigned long long bw = __ballot(win);
-    if (win) pend[npend + __popcll(bw & ((1ull << lane) - 1ull))] = tt;
-    npend += __popcll(bw);
-    if (lane == 0) {
-        n_final += nfin;
-        A.tile_open[tid] = nsurv;
-        if (nsurv == 0) tile_done[tid] = 1;
-        if (nrec > CS_SMALL && nsurv <= CS_SMALL) atomicSub(n_big, 1);
-    }
-    tile_wave_sync();
-}
-
-// one wavefront per listed tile of its class (BIG: the lanes look at 64 list entries at a time: the class is sparse)
-template <int CAP, bool BIG>
-__global__ __launch_bounds__(64) void k_compact_tiles(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
-                                                     const int32_t *n_in, uint8_t *__restrict__ tile_done, int32_t *n_final, TileNext N,
-                                                     int32_t *clear_count, CRec *__restrict__ recs, int32_t *n_big)
-{
-    __shared__ CTileW<CAP> L;
-    __shared__ int32_t s_pend[TILE_PEND];
-    const int lane = threadIdx.x;
-    const int32_t nt = *n_in;
-    if (!BIG && blockIdx.x == 0 && lane == 0) *clear_count = 0;
-    int32_t fin = 0;
-    int npend = 0;
-    auto flush = [&]() {
-        tile_wave_sync();
-        int32_t base = 0;
-        if (lane == 0) base = atomicAdd(N.count, npend);
-        base = __shfl(base, 0);
-        if (lane < npend) N.list[base + lane] = s_pend[lane];
-        npend = 0;
-        tile_wave_sync();
-    };
-    if (!BIG) {
-        for (int32_t k = blockIdx.x; k < nt; k += gridDim.x) {
-            const int tid = __builtin_amdgcn_readfirstlane(list_in[k]);
-            const int nrec = __builtin_amdgcn_readfirstlane(A.tile_open[tid]);
-            if (nrec > 0 && nrec <= CS_SMALL)
-                compact_visit<CAP>(A, L, recs + A.tile_off[tid], nrec, pass, tiles_x, tid, lane, tile_done, fin, N, s_pend, npend, n_big);
-            if (npend > TILE_PEND - 10) flush();
-        }
-    } else {
-        for (int32_t k0 = blockIdx.x * 64; k0 < nt; k0 += gridDim.x * 64) {
-            int tid_l = 0, nrec_l = 0;
-            if (k0 + lane < nt) { tid_l = list_in[k0 + lane]; nrec_l = A.tile_open[tid_l]; }
-            unsigned long long todo = __ballot(nrec_l > CS_SMALL);
-            while (todo) {
-                const int src = __ffsll((long long)todo) - 1; todo &= todo - 1ull;
-                const int tid = __shfl(tid_l, src), nrec = __shfl(nrec_l, src);
-                compact_visit<CAP>(A, L, recs + A.tile_off[tid], nrec, pass, tiles_x, tid, lane, tile_done, fin, N, s_pend, npend, n_big);
-                if (npend > TILE_PEND - 10) flush();
-            }
-        }
-    }
-    if (npend) flush();
-    if (lane == 0 && fin) atomicAdd(n_final, fin);
 }
 
 // switch from queue rounds to listed tile passes: the tiles that hold the current frontier
@@ -2815,7 +2388,6 @@ static void fill_sweep_args(pydem_tile *t, SweepArgs &A)
     A.pin_dst = t->pits.in_dst; A.pin_src = t->pits.in_src; A.pin_w = t->pits.in_w;
     A.qcap = (int32_t)(t->NN / 2 < INT32_MAX ? t->NN / 2 : INT32_MAX);      // queue buffers hold NN ints = NN/2 entries
     A.err = t->counters + 15;
-    A.tile_open = nullptr; A.tile_off = nullptr; A.seg_cursor = nullptr;
     { const char *e = getenv("PYDEM_TILE_DEBUG"); A.dbg = e ? atoi(e) : 0; }
 }
 
@@ -2841,7 +2413,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     const int tiles_x = (int)cdiv(m, TT), tiles_total = tiles_x * (int)cdiv(n, TT);
     // scratch: tile_done bytes | per-tile "listed for pass" stamps | two tile lists
     const size_t tiles_pad = ((size_t)tiles_total + 255) & ~(size_t)255;
-    const size_t scratch_need = tiles_pad * (1 + 4 + 4 + 4 + 4 + 4);
+    const size_t scratch_need = tiles_pad * (1 + 4 + 4 + 4);
     if (t->scratch_bytes < scratch_need) {
         if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->device_bytes -= (int64_t)t->scratch_bytes; }
         HIP_TRY(hipMalloc(&t->scratch, scratch_need));
@@ -2850,9 +2422,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     uint8_t *tile_done = (uint8_t *)t->scratch;
     int32_t *tile_flag = (int32_t *)(tile_done + tiles_pad);
     int32_t *tile_list[2] = {tile_flag + tiles_pad, tile_flag + 2 * tiles_pad};
-    int32_t *tile_open = tile_flag + 3 * tiles_pad, *tile_off = tile_flag + 4 * tiles_pad;   // compact passes: open cells / segment offset per tile
     int32_t *cntT = t->counters + 56;          // rotating tile-list sizes
-    A.tile_open = tile_open; A.tile_off = tile_off;
     HIP_TRY(hipMemsetAsync(tile_done, 0, tiles_pad * 5, t->stream));      // done bytes + stamps
     HIP_TRY(hipMemsetAsync(cntT, 0, 4 * sizeof(int32_t), t->stream));
     if (A.dbg & 4) HIP_TRY(hipMemsetAsync(t->counters + 32, 0, 24 * sizeof(int32_t), t->stream));
@@ -2879,44 +2449,6 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
             if (hipStreamSynchronize(t->stream) != hipSuccess) return -1;
             ntiles = t->h_counters[56 + p % 3];
             if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "listed tile pass %d: %lld tiles listed next, processed %d\n", p, (long long)ntiles, t->h_counters[3]);
-            if (p > (int)CI_LEVEL_INF - 256) return -2;
-        }
-        return p;
-    };
-    auto run_compact = [&](int p, int64_t ntiles, int64_t nbig) -> int {
-        TileNext N;
-        N.flag = tile_flag;
-        while (ntiles > 0) {
-            const int batch = ntiles < 2048 ? 16 : 8;
-            const int grid = (int)(ntiles < 16384 ? (ntiles > 64 ? ntiles : 64) : 16384);
-            for (int b = 0; b < batch; b++, p++) {
-                N.list = tile_list[(p + 1) % 2]; N.count = &cntT[(p + 1) % 3];
-                hipLaunchKernelGGL((k_compact_tiles<CS_SMALL, false>), dim3(grid), dim3(64), 0, t->stream, A, (uint32_t)p, tiles_x,
-                                   (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
-                                   &cntT[(p + 2) % 3], (CRec *)t->crec, t->counters + 10);
-                launches++;
-                if (nbig > 0) {     // tiles with more records than the small class holds (their number only shrinks; re-read with the list size)
-                    const int gb = (int)std::min<int64_t>(std::max<int64_t>(nbig, 64), 4096);
-                    hipLaunchKernelGGL((k_compact_tiles<TT * TT, true>), dim3(gb), dim3(64), 0, t->stream, A, (uint32_t)p, tiles_x,
-                                       (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
-                                       &cntT[(p + 2) % 3], (CRec *)t->crec, t->counters + 10);
-                    launches++;
-                }
-            }
-            if (hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream) != hipSuccess) return -1;
-            if (hipStreamSynchronize(t->stream) != hipSuccess) return -1;
-            ntiles = t->h_counters[56 + p % 3];
-            nbig = t->h_counters[10];
-            if (getenv("PYDEM_SWEEP_DEBUG")) {
-                fprintf(stderr, "compact tile pass %d: %lld tiles listed next (%lld big), processed %d\n", p, (long long)ntiles, (long long)nbig, t->h_counters[3]);
-                std::vector<int32_t> ho((size_t)tiles_total);
-                if (hipMemcpy(ho.data(), tile_open, ho.size() * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess) {
-                    long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cells = 0;
-                    for (int32_t v : ho) { cells += v; h[v == 0 ? 0 : v <= 64 ? 1 : v <= 128 ? 2 : v <= 256 ? 3 : v <= 384 ? 4 : v <= 512 ? 5 : v <= 768 ? 6 : 7]++; }
-                    fprintf(stderr, "   open cells %lld; tiles by records: 0: %lld, <=64: %lld, <=128: %lld, <=256: %lld, <=384: %lld, <=512: %lld, <=768: %lld, more: %lld\n",
-                            cells, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
-                }
-            }
             if (p > (int)CI_LEVEL_INF - 256) return -2;
         }
         return p;
@@ -2978,50 +2510,18 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         static int first_kind = -1;
         if (first_kind < 0) { const char *e = getenv("PYDEM_SWEEP_FIRST"); first_kind = (e && !strcmp(e, "lds")) ? 1 : 0; }
         if (first_kind == 1)
-        {
-            static int fr = -1, fc = -1;
-            if (fr < 0) { const char *e = getenv("PYDEM_FIRST_ROUNDS"); fr = e ? atoi(e) : 1 << 20; e = getenv("PYDEM_FIRST_CHAIN"); fc = e ? atoi(e) : 1; }
-            hipLaunchKernelGGL(k_sweep_first, dim3((unsigned)(((tiles_total + 7) / 8) * 8)), dim3(256), 0, t->stream, A, tiles_x, tiles_total, tile_done, total, fr, fc);
-        }
+            hipLaunchKernelGGL(k_sweep_first, dim3((unsigned)(((tiles_total + 7) / 8) * 8)), dim3(256), 0, t->stream, A, tiles_x, tiles_total, tile_done, total);
         else {
             TileNext N0; N0.flag = nullptr; N0.list = nullptr; N0.count = nullptr;
             hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, 1u, tiles_x, tiles_total, tile_done, total, N0);
         }
-        static int compact = -1;        // PYDEM_SWEEP_COMPACT=0: generic listed passes from pass 3 on (the round-2 schedule)
-        if (compact < 0) { const char *e = getenv("PYDEM_SWEEP_COMPACT"); compact = e ? atoi(e) : 1; }
-        const bool use_compact = compact && first_kind == 0;
         TileNext N; N.flag = tile_flag; N.list = tile_list[3 % 2]; N.count = &cntT[3 % 3];
-        {
-            SweepArgs A2 = A;
-            if (use_compact) A2.seg_cursor = t->counters + 9;        // [9] records, [10] tiles of the big class (pass 2 allocates the segments)
-            hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A2, 2u, tiles_x, tiles_total, tile_done, total, N);
-        }
+        hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, 2u, tiles_x, tiles_total, tile_done, total, N);
         launches += 2;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "tile passes 1-2: %d cells of %lld, %d tiles listed\n", t->h_counters[3], (long long)t->NN, t->h_counters[56]);
-        int p_end = 0;
-        const int64_t listed3 = t->h_counters[56 + 3 % 3];
-        if (use_compact && listed3 > 0) {
-            // ---- compact passes (K5d): records of the open cells, then LDS-resident visits
-            const int64_t n_open_total = t->h_counters[9];
-            if (n_open_total > t->crec_cap) {
-                if (t->crec) { HIP_TRY(hipFree(t->crec)); t->device_bytes -= t->crec_cap * (int64_t)sizeof(CRec); t->crec = nullptr; t->crec_cap = 0; }
-                const int64_t cap = n_open_total + n_open_total / 8 + 1024;
-                HIP_TRY(hipMalloc(&t->crec, (size_t)cap * sizeof(CRec)));
-                t->crec_cap = cap; t->device_bytes += cap * (int64_t)sizeof(CRec);
-            }
-            hipLaunchKernelGGL(k_compact_build, dim3(full_grid), dim3(256), 0, t->stream, A, 3u, tiles_x, tiles_total, (CRec *)t->crec, t->counters + 11);
-            launches++;
-            if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "compact passes: %lld open cells in records, %d tiles of the big class\n", (long long)n_open_total, t->h_counters[10]);
-            p_end = run_compact(3, listed3, t->h_counters[10]);
-            if (p_end >= 0) {
-                HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
-                HIP_TRY(hipStreamSynchronize(t->stream));
-                if (t->h_counters[11] != 0) { pydem_set_error("compact passes: the open counts of %d tiles do not match their level stamps", t->h_counters[11]); return -5; }
-            }
-        } else
-            p_end = run_listed(3, listed3);
+        const int p_end = run_listed(3, t->h_counters[56 + 3 % 3]);
         if (p_end == -1) { pydem_set_error("HIP error in the listed tile passes"); return -4; }
         if (p_end == -2) { pydem_set_error("flow paths longer than %u passes are not supported", CI_LEVEL_INF); return -5; }
         pass = (uint32_t)p_end;

@@ -133,8 +133,11 @@ class DEMProcessor(object):
 
     def __init__(self, elev_fn=None, device=0, **kwargs):
         if elev_fn:
-            raise NotImplementedError("raster IO is outside the accelerated path: pass elev=array, dX=, dY= "
-                                      "(reference: utils.dem_processor_from_raster_kwargs)")
+            # reference :229-232: the raster's array, spacing, bounds and transform, overridden by explicit keywords
+            from .raster import dem_processor_from_raster_kwargs
+            kwds = dem_processor_from_raster_kwargs(elev_fn)
+            kwds.update(kwargs)
+            kwargs = kwds
         self._shape = None
         if kwargs.get('elev') is None:
             if kwargs.get('shape') is None:
@@ -184,6 +187,8 @@ class DEMProcessor(object):
                 self.twi = v
             elif k in self._OPTION_NAMES:
                 setattr(self, k, v)
+            elif k in ('bounds', 'transform'):
+                setattr(self, k, list(v))              # tl.List() traits of the reference (:201-202)
             # unknown keywords are dropped, as traitlets' HasTraits.__init__ does
 
     # ------------------------------------------------------------------ device plumbing

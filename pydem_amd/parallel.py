@@ -6,8 +6,8 @@ on-disk zarr store (pydem/process_manager.py:1214-1288, :243-255).  Here:
 
   * RcclTransport -- the production path: every rank packs the lines it owns into a device buffer
     and one ncclAllReduce(sum) over xGMI leaves all lines on all ranks (csrc/comm.hip);
-  * DistTransport -- the same protocol over torch.distributed object collectives (gloo); used by
-    the CPU test tier (world_size 2) and as a fallback when RCCL cannot be initialised.
+  * DistTransport -- the same protocol over the socket group of `pydem_amd.rendezvous` (host memory, no framework);
+    used by the CPU test tier (world_size 2) and as a fallback when RCCL cannot be initialised.
 
 Both are driven in lock-step by the (deterministic) host logic of ProcessManager, so every rank
 issues the same sequence of gathers.
@@ -24,13 +24,12 @@ def rank_world():
 
 
 class DistTransport(EdgeTransport):
-    """Strips over torch.distributed (host memory, any backend with object collectives)."""
+    """Strips through host memory: python objects gathered over a `rendezvous.SocketGroup`."""
 
-    def __init__(self, pm, rank, world):
+    def __init__(self, pm, group):
         EdgeTransport.__init__(self, pm)
-        self.rank, self.world = rank, world
-        import torch.distributed as dist
-        self.dist = dist
+        self.group = group
+        self.rank, self.world = group.rank, group.world
 
     def owns(self, i):
         return i % self.world == self.rank
@@ -40,28 +39,22 @@ class DistTransport(EdgeTransport):
         for k, (t, name, axis, index) in enumerate(requests):
             if t >= 0 and self.owns(t):
                 mine[k] = self.pm.tiles[t].get_line(name, axis, index)
-        parts = [None] * self.world
-        self.dist.all_gather_object(parts, mine)
         out = [None] * len(requests)
-        for part in parts:
+        for part in self.group.all_gather_object(mine):
             for k, v in part.items():
                 out[k] = v
         return out
 
     def allreduce_max(self, value):
-        parts = [None] * self.world
-        self.dist.all_gather_object(parts, float(value))
-        return max(parts)
+        return self.group.allreduce_max(value)
 
     def sum_inplace(self, arr):
         """Sum a contiguous float64 array over all ranks, in place (the edge board's staging buffer when the strips
         cannot travel by RCCL: ProcessManager._process_uca_edges_pool_device)."""
-        import torch
-        t = torch.from_numpy(arr)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self.group.sum_inplace(arr)
 
     def barrier(self):
-        self.dist.barrier()
+        self.group.barrier()
 
 
 class RcclTransport(EdgeTransport):
@@ -114,14 +107,10 @@ class RcclTransport(EdgeTransport):
         self.allreduce_max(0.0)
 
 
-def make_rccl_transport(pm, device, dist=None):
-    """Create the RCCL communicator for this rank.  The 128-byte id travels from rank 0 over the
-    already initialised torch.distributed group (plumbing only)."""
+def make_rccl_transport(pm, device, group):
+    """Create the RCCL communicator for this rank.  The 128-byte id travels from rank 0 over the socket group
+    (plumbing only)."""
     from . import _ffi
-    rank, world = rank_world()
-    if dist is None:
-        import torch.distributed as dist
-    box = [_ffi.Comm.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    comm = _ffi.Comm(world, rank, box[0], device)
+    uid = group.broadcast_object(_ffi.Comm.unique_id() if group.rank == 0 else None, src=0)
+    comm = _ffi.Comm(group.world, group.rank, uid, device)
     return RcclTransport(pm, comm)

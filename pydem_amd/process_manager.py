@@ -24,6 +24,7 @@ What is different by design:
 """
 import logging
 import os
+import threading
 import time
 
 import numpy as np
@@ -324,35 +325,59 @@ class ProcessManager(object):
     def _store_fn(self, i, key):
         return os.path.join(self.out_path, 'tile_%04d_%s.npy' % (i, key))
 
+    def _store_lock(self):
+        # _store() runs in the per-tile worker threads (tiles_in_flight > 1): one lock per manager for the table and its file
+        lk = self.__dict__.get('_success_lock')
+        if lk is None:
+            lk = self.__dict__.setdefault('_success_lock', threading.RLock())
+        return lk
+
     def _success(self):
-        if getattr(self, '_success_table', None) is None:
-            fn = os.path.join(self.out_path, 'success.npy')
-            if self.checkpoint and os.path.exists(fn):
-                tab = np.load(fn)
-                if tab.shape != (self.n_inputs, 4):
-                    raise ValueError("%s belongs to another mosaic" % fn)
-                self._success_table = tab.astype(bool)
-            else:
-                self._success_table = np.zeros((self.n_inputs, 4), bool)
-        return self._success_table
+        with self._store_lock():
+            if getattr(self, '_success_table', None) is None:
+                fn = os.path.join(self.out_path, 'success.npy')
+                if self.checkpoint and os.path.exists(fn):
+                    tab = np.load(fn)
+                    if tab.shape != (self.n_inputs, 4):
+                        raise ValueError("%s belongs to another mosaic" % fn)
+                    self._success_table = tab.astype(bool)
+                else:
+                    self._success_table = np.zeros((self.n_inputs, 4), bool)
+            return self._success_table
 
     def _store(self, i, phase, fields):
-        """Write the fields of one finished tile, then its success flag."""
+        """Write the fields of one finished tile, then its success flag.  Safe with several worker threads and with several
+        ranks sharing one `out_path`: temporary names are unique per process and thread, and the table that is published
+        is the OR of what is on disk and what this process knows, merged under a file lock (a rank only ever sets flags
+        of its own tiles, so the last writer must not erase the others')."""
         if not self.checkpoint:
             return
         if self.out_format != 'npy':
             raise NotImplementedError("out_format %r (only 'npy' tile stores are written)" % (self.out_format,))
         os.makedirs(self.out_path, exist_ok=True)
+        uniq = '.%d.%d.tmp.npy' % (os.getpid(), threading.get_ident())
         for key, arr in fields.items():
-            tmp = self._store_fn(i, key) + '.tmp.npy'
+            tmp = self._store_fn(i, key) + uniq
             np.save(tmp, np.asarray(arr))
             os.replace(tmp, self._store_fn(i, key))
         if phase is not None:
-            tab = self._success()
-            tab[i, self._SUCCESS_COLS[phase]] = True
-            tmp = os.path.join(self.out_path, 'success.tmp.npy')
-            np.save(tmp, tab)
-            os.replace(tmp, os.path.join(self.out_path, 'success.npy'))
+            import fcntl
+            fn = os.path.join(self.out_path, 'success.npy')
+            with self._store_lock():
+                tab = self._success()
+                tab[i, self._SUCCESS_COLS[phase]] = True
+                with open(os.path.join(self.out_path, 'success.lock'), 'a') as lockf:
+                    fcntl.flock(lockf, fcntl.LOCK_EX)
+                    try:
+                        if os.path.exists(fn):
+                            disk = np.load(fn)
+                            if disk.shape == tab.shape:
+                                tab |= disk.astype(bool)
+                        tmp = fn[:-4] + uniq
+                        np.save(tmp, tab)
+                        os.replace(tmp, fn)
+                    finally:
+                        fcntl.flock(lockf, fcntl.LOCK_UN)
 
     def _stored(self, i, phase):
         return bool(self.checkpoint and self._success()[i, self._SUCCESS_COLS[phase]])
@@ -894,22 +919,30 @@ class ProcessManager(object):
         return mets
 
     # ---- the same schedule with the strips resident on the device ------------------------------------------
-    def _device_board_usable(self):
-        """Device processors, all of this process's tiles on one GPU, strips carried in-process or by RCCL."""
-        if not getattr(self, 'edge_device_board', True) or not getattr(self, 'edge_incremental', True):
-            return False
+    def _board_device(self):
+        """The GPU this process keeps its replica of the edge board on: the one its tiles live on; a rank that owns no
+        tile (more ranks than tiles) still takes part in the board's collectives, on its communicator's device."""
         owned = self._owned()
-        if not owned or any(not hasattr(self.tiles[i], 'run_edge_round_dev') for i in owned):
-            return False
-        if self.dem_proc_kwargs.get('apply_uca_limit_edges'):
-            return False
-        if len(set(self.tiles[i]._device for i in owned)) != 1:
-            return False
+        if owned:
+            return self.tiles[owned[0]]._device
+        comm = getattr(self.transport, 'comm', None)
+        return getattr(comm, 'device', self._device_of(getattr(self.transport, 'rank', 0)))
+
+    def _device_board_usable(self):
+        """Device processors, all of this process's tiles on one GPU, strips carried in-process or by RCCL.  The
+        answer is COLLECTIVE: the host pool path and the device board issue different collectives, so every rank must
+        take the same branch -- each rank judges its own tiles (a rank without tiles has no objection) and the ranks
+        agree on the minimum."""
+        ok = bool(getattr(self, 'edge_device_board', True) and getattr(self, 'edge_incremental', True))
+        owned = self._owned()
+        ok = ok and all(hasattr(self.tiles[i], 'run_edge_round_dev') for i in owned)
+        ok = ok and not self.dem_proc_kwargs.get('apply_uca_limit_edges')
+        ok = ok and len(set(self.tiles[i]._device for i in owned)) <= 1
         if type(self.transport) is EdgeTransport:
-            return len(owned) == self.n_inputs
-        if hasattr(self.transport, 'comm') and hasattr(self.transport.comm, '_h'):
-            return True
-        return hasattr(self.transport, 'sum_inplace')          # no RCCL: the staging buffer is summed on the host
+            return ok and len(owned) == self.n_inputs and self.n_inputs > 0
+        if not (hasattr(getattr(self.transport, 'comm', None), '_h') or hasattr(self.transport, 'sum_inplace')):
+            ok = False                                         # neither RCCL nor a host sum for the staging buffer
+        return self.transport.allreduce_max(0.0 if ok else 1.0) == 0.0
 
     def _process_uca_edges_pool_device(self, mets_type=0):
         """`_process_uca_edges_pool` with the edge board of csrc/comm.hip: the lines every tile reads live in one
@@ -931,7 +964,7 @@ class ProcessManager(object):
             size[t] = off - start[t]
         owned = self._owned()
         comm = getattr(self.transport, 'comm', None)
-        board = _ffi.Board(self.tiles[owned[0]]._device, n_t, off)
+        board = _ffi.Board(self._board_device(), n_t, off)
         readers = {t: set([t]) for t in range(n_t)}
         for i in range(n_t):
             o28, f8 = [], []

@@ -1,4 +1,4 @@
-"""The numpy / scipy statements the native conditioning loops (pydem_amd/csrc/conditioning.hip) and the device
+"""The numpy / scipy statements the native conditioning loops (pydem_amd/csrc/cond_host.cpp) and the device
 kernels (csrc/cond_device.hip, csrc/cond_paths.hip) were written from: region by region, pit by pit, one scipy.ndimage
 call at a time like the reference (pydem/dem_processing.py:308-579, helpers pydem/utils.py:270-468).  TEST
 INFRASTRUCTURE ONLY: the product never imports this module; tests compare the native host loops with it on random

@@ -42,7 +42,7 @@ def test_conditioning_matches_reference(name):
 @pytest.mark.parametrize('kind,shape,seed', [('srtm', (160, 200), 5), ('srtm', (257, 129), 6), ('quant', (192, 192), 7),
                                             ('fractal', (128, 160), 8), ('f32', (150, 170), 9)])
 def test_native_loops_match_numpy_loops(kind, shape, seed):
-    """csrc/conditioning.hip against the numpy versions it was written from, on tiles with thousands of flats,
+    """csrc/cond_host.cpp against the numpy versions it was written from, on tiles with thousands of flats,
     quantisation pits, plateaus on the tile edge and summit plateaus (bit for bit, all three stages)."""
     from pydem_amd import synth
     n, m = shape

@@ -144,6 +144,37 @@ def test_full_pipeline_with_conditioning(name):
     _close(dp.twi, g['twi_attr'], 'twi attr')
 
 
+def test_geotiff_tile_through_elev_fn_constructor():
+    """The reference's README entry point: DEMProcessor(elev_fn=<GeoTIFF>) (dem_processing.py:229-232).  The reference's
+    own test raster goes through pydem_amd/raster.py into the device flow; with the spacing of the golden capture
+    (the harness ran the reference with dX = dY = 1) every output must equal the reference's."""
+    import os
+    import warnings
+    from pydem_amd import DEMProcessor
+    g = load_golden('g3_tif32')
+    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_test_NN032_033_elev.tif')
+    dp = DEMProcessor(elev_fn=fn, dX=g['in_dX'], dY=g['in_dY'], dX2=g['in_dX2'], dY2=g['in_dY2'], **g['kwargs'])
+    assert len(dp.bounds) == 4 and len(dp.transform) >= 6
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        twi = dp.calc_twi()
+    assert np.array_equal(np.asarray(dp.elev, float), g['elev_final'].astype(float))
+    _close(dp.mag, g['mag_final'], 'mag')
+    _close(dp.direction, g['direction'], 'direction')
+    assert np.array_equal(dp.flats, g['flats_final']) and np.array_equal(dp.section, g['section'])
+    _close(dp.uca, g['uca'], 'uca')
+    assert np.array_equal(dp.edge_todo, g['edge_todo']) and np.array_equal(dp.edge_done, g['edge_done'])
+    _close(twi, g['twi_ret'], 'twi')
+    # ... and with the raster's own geodesic spacing (WGS-84 tile): the flow runs and every cell carries at least its own area
+    dp2 = DEMProcessor(elev_fn=fn, fill_flats=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        dp2.calc_twi()
+    assert dp2.dX.shape == (31,) and np.all(dp2.dX > 0)
+    ok = ~np.isnan(dp2.uca)
+    assert ok.any() and np.all(dp2.uca[ok] >= (dp2.dX2 * dp2.dY2).min() * (1 - 1e-12))
+
+
 def test_hip_results_are_run_to_run_identical():
     """The sweep pulls in a fixed order and the pit edges are sorted before use, so two runs over the same tile must
     agree bit for bit although the tile passes, frontier appends and pit output slots are scheduled differently each

@@ -1,7 +1,7 @@
 """GPU: the ProcessManager drop-in on multi-tile mosaics against per-tile results of the unmodified
 reference ProcessManager (tests/golden/pm_*.npz; n_workers=1, DEBUG spacing like the reference's own
-tests).  Tiles start from the reference's conditioned elevation (conditioning is not on the device
-yet).  The edge fix-up follows the reference's serial visiting order; the sums inside a round differ in order, so
+tests).  Tiles start from the reference's conditioned elevation (the conditioning kernels are held to the
+reference in tests/test_gpu_conditioning.py).  The edge fix-up follows the reference's serial visiting order; the sums inside a round differ in order, so
 float fields are compared at 1e-9 relative; masks, NaN patterns and facet-derived fields exactly.
 Pool mode (the multi-worker schedule): the reference's acceptance cases and the oracle-backed flow."""
 import os
@@ -180,7 +180,7 @@ def test_resume_from_tile_store_on_device(stop_after, n_workers, tmp_path):
 @pytest.mark.parametrize('name', ['pm_fractal_2x3_ov1', 'pm_cone32_4x5_ov3'])
 def test_two_rank_pool_mode_with_device_board(name, tmp_path):
     """N > 1 with the strips on the device: two processes (tiles i % 2, both on this box's one GPU -- RCCL refuses two
-    ranks on one device, so the board's staging buffer is summed over the ranks through gloo:
+    ranks on one device, so the board's staging buffer is summed over the ranks through the socket group:
     pydem_board_refresh_stage / _unstage), replicated edge board, deterministic waves.  Every rank must see the waves,
     round counts and per-tile results of the single-process pool run."""
     import subprocess
@@ -189,10 +189,30 @@ def test_two_rank_pool_mode_with_device_board(name, tmp_path):
     from test_process_manager_grid import write_tiles
     g = load_golden(name)
     write_tiles(g, str(tmp_path), key='elev')
+    from pydem_amd.rendezvous import spawn_ranks
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-           '--master-port', str(29600 + (os.getpid() % 300)), os.path.join(ROOT, 'tests', '_dist_pm_worker.py'), name, str(tmp_path), 'pool', 'device']
-    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
-    out = res.stdout.decode()
-    assert res.returncode == 0, out[-3000:]
+    rc, out = spawn_ranks([sys.executable, os.path.join(ROOT, 'tests', '_dist_pm_worker.py'), name, str(tmp_path), 'pool', 'device'], 2,
+                          env=env, master_port=29600 + (os.getpid() % 300), capture=True, timeout=600)
+    assert rc == 0, out[-3000:]
+    assert out.count(' ok: ') == 2, out[-3000:]
+
+
+@pytest.mark.parametrize('name', ['pm_fractal_2x3_ov1', 'pm_cone32_4x5_ov3'])
+def test_two_rank_pool_mode_over_rccl(name, tmp_path):
+    """The same with one GPU per rank and a real communicator of world size 2: `pydem_board_refresh` replicates the
+    staging buffer with ncclAllReduce (csrc/comm.hip), the RCCL id travels over pydem_amd.rendezvous.  Needs two GPUs
+    (the driver's single-GPU test box skips it; reference: the strips of pydem/process_manager.py:243-255)."""
+    import sys
+    from conftest import ROOT
+    from pydem_amd import _ffi
+    from pydem_amd.rendezvous import spawn_ranks
+    from test_process_manager_grid import write_tiles
+    if _ffi.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    g = load_golden(name)
+    write_tiles(g, str(tmp_path), key='elev')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    rc, out = spawn_ranks([sys.executable, os.path.join(ROOT, 'tests', '_dist_pm_worker.py'), name, str(tmp_path), 'pool', 'rccl'], 2,
+                          env=env, master_port=29300 + (os.getpid() % 300), capture=True, timeout=600)
+    assert rc == 0, out[-3000:]
     assert out.count(' ok: ') == 2, out[-3000:]

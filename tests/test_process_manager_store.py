@@ -65,3 +65,40 @@ def test_resume_from_tile_store(stop_after, n_workers, tmp_path):
         assert np.allclose(got[key], want[key], rtol=1e-12, atol=1e-13, equal_nan=True), key
     tab = np.load(str(tmp_path / 'store' / 'success.npy'))
     assert tab.shape == (n, 4) and tab.all()
+
+
+def test_success_table_with_worker_threads_and_several_ranks(tmp_path):
+    """`_store` is called from the per-tile worker threads (tiles_in_flight > 1) and, in a multi-rank job, from several
+    processes that share one `out_path`: every flag that was set must be in the published table (no lost update, no
+    clash of temporary files), and a manager that starts later sees all of them."""
+    from concurrent.futures import ThreadPoolExecutor
+    from pydem_amd import process_manager
+    g = load_golden('pm_fractal_2x3_ov1')
+    src = str(tmp_path / 'tiles')
+    write_tiles(g, src, key='elev')
+    process_manager.DEBUG = True
+    try:
+        out = str(tmp_path / 'store')
+        ranks = [_pm(src, out, checkpoint=True) for _ in range(2)]      # two "ranks": tile i belongs to manager i % 2
+        for pm in ranks:
+            pm.compute_grid()
+        n = ranks[0].n_inputs
+        field = np.arange(12.0).reshape(3, 4)
+
+        def work(job):
+            i, phase = job
+            ranks[i % 2]._store(i, phase, {phase + '_x': field + i})
+        jobs = [(i, ph) for ph in ('elev', 'aspect_slope', 'uca', 'twi') for i in range(n)]
+        for _ in range(5):
+            with ThreadPoolExecutor(max_workers=8) as ex:
+                list(ex.map(work, jobs))
+        tab = np.load(str(tmp_path / 'store' / 'success.npy'))
+        assert tab.shape == (n, 4) and tab.all(), tab
+        import os
+        assert not [f for f in os.listdir(out) if '.tmp' in f], "temporary files left behind"
+        late = _pm(src, out, checkpoint=True)
+        late.compute_grid()
+        assert all(late._stored(i, ph) for i, ph in jobs)
+        assert np.array_equal(late._load(3, 'uca_x'), field + 3)
+    finally:
+        process_manager.DEBUG = False

@@ -283,3 +283,22 @@ def test_block_mean_overview_equals_the_reference_function():
     plain = raster.block_mean_overview(z, 2, like_reference=False)
     assert plain.shape == (3, 4)
     assert plain[2, 1] == z[4, 2:4].mean() and plain[0, 3] == z[0:2, 6].mean() and plain[2, 3] == z[4, 6] and plain[1, 1] == z[2:4, 2:4].mean()
+
+
+def test_dem_processor_elev_fn_constructor(monkeypatch):
+    """DEMProcessor(elev_fn=...) (reference dem_processing.py:229-232 -> utils.dem_processor_from_raster_kwargs :46-51): the
+    raster's array, per-row spacing, bounds and transform become constructor arguments; explicit keywords win.  (No device
+    call here: the constructor only stores host arrays.)"""
+    from pydem_amd import DEMProcessor
+    fn = os.path.join(HERE, 'golden', 'ref_test_NN032_033_elev.tif')
+    ds = raster.read_geotiff(fn)
+    dp = DEMProcessor(elev_fn=fn)
+    assert np.array_equal(np.asarray(dp.elev), np.asarray(ds.read(1)))
+    want = raster.dem_processor_from_raster_kwargs(fn)
+    for k in ('dX', 'dY', 'dX2', 'dY2'):
+        assert np.array_equal(getattr(dp, k), want[k]), k
+    assert dp.dX.shape == (ds.shape[0] - 1,) and dp.dX2.shape == (ds.shape[0],)
+    assert list(dp.bounds) == list(ds.bounds) and list(dp.transform) == list(ds.transform)
+    dp2 = DEMProcessor(elev_fn=fn, dX=2.0, fill_flats=False)
+    assert np.array_equal(dp2.dX, np.full(ds.shape[0] - 1, 2.0)) and dp2.fill_flats is False
+    assert np.array_equal(dp2.dY, want['dY'])
