@@ -1257,10 +1257,14 @@ __global__ __launch_bounds__(256) void k_pit_keys(const int32_t *__restrict__ sr
 }
 
 __global__ void k_pit_gather(const uint64_t *__restrict__ keys, const int32_t *__restrict__ idx, const double *__restrict__ w,
-                             int32_t ne, int swap, int32_t *a, int32_t *b, double *wo)
+                             int32_t ne, int swap, int32_t *a, int32_t *b, double *wo, int32_t *dup)
 {
     for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
         const uint64_t k = keys[e];
+        // a pit's drains are a set and every pit is solved once, so (src, dst) is unique and the sorted order does not depend on
+        // the (scheduling-dependent) order of the compacted entries; counted so that a violation is an error, not a silent
+        // change of the summation order
+        if (dup && e > 0 && keys[e - 1] == k) atomicAdd(dup, 1);
         const int32_t hi = (int32_t)(k >> 32), lo = (int32_t)(k & 0xffffffffu);
         a[e] = swap ? lo : hi;      // a = src, b = dst in both views
         b[e] = swap ? hi : lo;
@@ -1448,10 +1452,14 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             const int g = (int)(cdiv(nk, 256) < 1024 ? cdiv(nk, 256) : 1024);
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k1, k1s, idx, i1, nk, 0, 64, t->stream));
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k2, k2s, idx, i2, nk, 0, 64, t->stream));
+            HIP_TRY(hipMemsetAsync(cnt + 11, 0, sizeof(int32_t), t->stream));
             hipLaunchKernelGGL(k_pit_gather, dim3(g), dim3(256), 0, t->stream, k1s, i1, t->pits.raw_w, nk, 0, t->pits.src, t->pits.dst,
-                               t->pits.w);
+                               t->pits.w, cnt + 11);
             hipLaunchKernelGGL(k_pit_gather, dim3(g), dim3(256), 0, t->stream, k2s, i2, t->pits.raw_w, nk, 1, t->pits.in_src,
-                               t->pits.in_dst, t->pits.in_w);
+                               t->pits.in_dst, t->pits.in_w, (int32_t *)nullptr);
+            HIP_TRY(hipMemcpyAsync(t->h_counters, cnt + 11, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            if (t->h_counters[0] != 0) { pydem_set_error("pit search: %d duplicate pit -> drain edges", t->h_counters[0]); return -5; }
         }
         HIP_TRY(hipGetLastError());
         t->pits.n_edges = nk;

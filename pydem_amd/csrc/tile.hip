@@ -252,9 +252,12 @@ int pydem_tile_set_spacing(pydem_tile *t, const double *dX, const double *dY, co
 
 int pydem_tile_upload(pydem_tile *t, int field, const void *src, int dtype)
 {
+    HIP_TRY(hipSetDevice(t->device));
+    // incremental edge rounds keep the deltas of cells below unresolved inlets pending until the flush: an upload between
+    // two rounds must not discard them silently (a new UCA plane replaces what they would have been added to)
+    if (t->einc_ready && field != PYDEM_UCA) PYDEM_TRY(stage_edge_flush(t));
     t->edge_clean = false;
     t->einc_ready = false;
-    HIP_TRY(hipSetDevice(t->device));
     void **pp; size_t elem;
     PYDEM_TRY(field_ptr(t, field, &pp, &elem));
     PYDEM_TRY(ensure_field(t, field));
@@ -414,9 +417,10 @@ static int need(pydem_tile *t, int field, const char *what)
 
 int pydem_slopes_directions(pydem_tile *t)
 {
+    HIP_TRY(hipSetDevice(t->device));
+    if (t->einc_ready) PYDEM_TRY(stage_edge_flush(t));      // (the resident UCA plane survives this stage: pending deltas first)
     t->edge_clean = false;      // these stages reuse the edge-round work lists
     t->einc_ready = false;
-    HIP_TRY(hipSetDevice(t->device));
     PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_slopes_directions"));
     if (!t->spacing_set) { pydem_set_error("pydem_slopes_directions: call pydem_tile_set_spacing first"); return -3; }
     PYDEM_TRY(ensure_fields(t, {PYDEM_MAG, PYDEM_DIRECTION, PYDEM_FLATS}));

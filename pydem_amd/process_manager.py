@@ -1215,16 +1215,18 @@ class ProcessManager(object):
         self.overviews = out
         return out
 
-    def save_geotiff(self, filename, key, dtype, crs=None, max_files=2, rescale=None, overview_type=None, overview_factors=None):
+    def save_geotiff(self, filename, key, dtype, crs=None, max_files=2, rescale=None, overview_type=None, overview_factors=None,
+                     blocksize=512, bigtiff=True, nodata=None):
         """One stitched result as a GeoTIFF (reference :862-931): same geotransform rules (one pixel size for the whole
-        mosaic, else NotImplementedError), same optional rescaling.  Written by pydem_amd/raster.py, one Deflate strip per
-        image (tiling / BigTIFF of the reference's rasterio call are not reproduced).  `overview_type='average'` adds
-        reduced-resolution images (block means; default factors 3, 9, ... like :928-929) behind the full one; the other
-        resampling kinds of rasterio are not implemented.
+        mosaic, else NotImplementedError), same optional rescaling, same file layout as the reference's rasterio call --
+        512 x 512 tiles in a BigTIFF (`blocksize=None` / `bigtiff=False`: one strip, classic TIFF) -- with Deflate where the
+        reference asks for LZW (both lossless).  `overview_type`: one of raster.OVERVIEW_KINDS ('average', 'nearest', 'mode',
+        'max', 'min', 'med', 'q1', 'q3', 'sum', 'rms'; GDAL's interpolating kernels are not reproduced) adds reduced-resolution
+        images (default factors 3, 9, ... like :928-929) behind the full one; the kind is recorded like :931.
         `crs`: 'projected' or anything else = geographic WGS-84 (the default follows the first input tile)."""
         from . import raster
-        if overview_type not in (None, 'average'):
-            raise NotImplementedError("overview_type %r: only 'average' overviews are written" % (overview_type,))
+        if overview_type is not None and overview_type not in raster.OVERVIEW_KINDS:
+            raise NotImplementedError("overview_type %r (available: %s)" % (overview_type, ', '.join(raster.OVERVIEW_KINDS)))
         data = self.out_file_noverlap[key]
         dlats = np.unique(np.round(self.index[self.grid_id2i.max(axis=1), 5], decimals=6))
         dlons = np.unique(np.round(self.index[self.grid_id2i.max(axis=0), 4], decimals=6))
@@ -1243,13 +1245,20 @@ class ProcessManager(object):
         if overview_type is not None:
             if overview_factors is None:
                 overview_factors = [3 ** i for i in range(1, int(np.log(max(self.grid_size_tot_unique)) / np.log(3)))]   # :928-929
+            chain = overview_type in ('average', 'max', 'min', 'sum')          # kinds whose level k is the same statistic of level k-1
             last, last_f = np.asarray(data, np.float64), 1
             for fct in overview_factors:
-                if fct % last_f == 0 and fct > last_f:
-                    last = raster.block_mean_overview(last, fct // last_f, like_reference=False)
+                if chain and fct % last_f == 0 and fct > last_f:
+                    last = raster.block_overview(last, fct // last_f, overview_type)
                 else:
-                    last = raster.block_mean_overview(np.asarray(data, np.float64), fct, like_reference=False)
+                    last = raster.block_overview(np.asarray(data, np.float64), fct, overview_type)
                 last_f = fct
                 levels.append(last)
+        tags = {}
+        if rescale:
+            tags['rescale'] = ','.join(str(r) for r in rescale)                # (:925; the reference's own call fails on rescale=None)
+        if overview_type is not None:
+            tags['rio_overview_resampling'] = overview_type                    # :931
         raster.write_geotiff(filename, np.asarray(data).astype(dtype), (dlon, 0.0, left, 0.0, dlat, top),
-                             projected=(crs == 'projected'), compress=True, overviews=levels)
+                             projected=(crs == 'projected'), compress=True, overviews=levels, tile=blocksize, bigtiff=bigtiff,
+                             nodata=nodata, tags=tags or None)

@@ -10,8 +10,8 @@ reproduces the reference's spacing rules with Vincenty's inverse formula on the 
 geographiclib -- what geopy calls -- to ~1e-10 relative on pixel-sized lines; the results of the terrain path are
 compared at 1e-6).  If rasterio is importable it is NOT used: one code path, testable here.
 
-`write_geotiff` is the small counterpart (uncompressed or Deflate strips) used by the tests and by
-`ProcessManager.save_non_overlap_data`.
+`write_geotiff` is the counterpart (strips or tiles, uncompressed or Deflate, classic or BigTIFF, overviews) used by the
+tests and by `ProcessManager.save_non_overlap_data_geotiff` / `save_geotiff`.
 """
 import struct
 import zlib
@@ -257,74 +257,121 @@ def read_geotiff(path, page=0):
     return GeoTiff(out, transform, projected, ellipsoid, nodata)
 
 
-def write_geotiff(path, array, transform, projected=False, nodata=None, compress=False, overviews=()):
-    """Single-band little-endian GeoTIFF, one strip per image (uncompressed or Deflate).  `transform` = (a, b, c, d, e, f).
+def write_geotiff(path, array, transform, projected=False, nodata=None, compress=False, overviews=(), tile=None, bigtiff=False,
+                  tags=None):
+    """Single-band little-endian GeoTIFF.  `transform` = (a, b, c, d, e, f).
+
+    Layout: one strip per image (`tile=None`) or square tiles of `tile` pixels (a multiple of 16; the reference writes
+    512 x 512 blocks, pydem/process_manager.py:906-913), uncompressed or Deflate (`compress`; the reference asks rasterio
+    for LZW -- both are lossless, GDAL reads either); classic TIFF (offsets of 32 bits: < 4 GiB, checked) or BigTIFF
+    (`bigtiff=True`, 64-bit offsets, what the reference always writes).
     `overviews`: reduced-resolution copies (arrays, largest first) written as further image file directories behind the
-    full-resolution one (NewSubfileType = 1: what GDAL / rasterio list as the dataset's overviews)."""
+    full-resolution one (NewSubfileType = 1: what GDAL / rasterio list as the dataset's overviews).
+    `tags`: dict of GDAL metadata items (name -> value) stored in the GDAL_METADATA tag of the first image (the reference's
+    `update_tags`, :925, :931).
+    The pixel data are streamed to the file image by image, block by block; the directories follow at the end."""
     a, b, c, d, e, f = transform
-    images = [np.ascontiguousarray(array)] + [np.ascontiguousarray(o).astype(np.asarray(array).dtype) for o in overviews]
+    base_dtype = np.asarray(array).dtype
+    images = [np.ascontiguousarray(array)]
+    for o in overviews:
+        o = np.asarray(o)
+        if base_dtype.kind in 'iu' and o.dtype.kind == 'f':
+            # block means of an integer raster: a block without valid cells is NaN, which no integer can carry -- it becomes the
+            # nodata value (tag 42113 announces it) or the export is refused; the other means are truncated like the base cast.
+            # (Chained levels are means of means and edge blocks are partial: not GDAL's 'average' on the last row / column.)
+            bad = np.isnan(o)
+            if bad.any():
+                if nodata is None:
+                    raise ValueError("overview blocks without data in an integer GeoTIFF need a nodata value")
+                o = np.where(bad, nodata, o)
+        images.append(np.ascontiguousarray(o).astype(base_dtype))
+    if tile is not None and (int(tile) <= 0 or int(tile) % 16):
+        raise ValueError("TIFF tile edges are multiples of 16, not %r" % (tile,))
     h0, w0 = images[0].shape
-    blocks = []       # per image: (entries, payload)
-    for level, arr in enumerate(images):
-        if arr.dtype.byteorder == '>':
-            arr = arr.astype(arr.dtype.newbyteorder('<'))
-        kind = {'u': 1, 'i': 2, 'f': 3}[arr.dtype.kind]
-        h, w = arr.shape
-        payload = arr.tobytes()
-        if compress:
-            payload = zlib.compress(payload, 6)
-        entries = []      # (tag, type, count, packed bytes)
-
-        def add(tag, typ, values, entries=entries):
-            fmt = _TYPE_FMT[typ]
-            if typ == 2:
-                raw = values.encode('latin-1') + b'\x00'
-                entries.append((tag, typ, len(raw), raw))
-            else:
-                entries.append((tag, typ, len(values), struct.pack('<' + fmt * len(values), *values)))
-
-        if level > 0:
-            add(254, 4, [1])                                            # reduced-resolution version of another image
-        add(256, 4, [w]); add(257, 4, [h]); add(258, 3, [arr.dtype.itemsize * 8]); add(259, 3, [8 if compress else 1])
-        add(262, 3, [1]); add(273, 4, [0]); add(277, 3, [1]); add(278, 4, [h]); add(279, 4, [len(payload)]); add(339, 3, [kind])
-        # (an overview covers the same ground with fewer, larger pixels)
-        add(33550, 12, [a * w0 / w, -e * h0 / h, 0.0]); add(33922, 12, [0.0, 0.0, 0.0, c, f, 0.0])
-        add(34735, 3, [1, 1, 0, 3, 1024, 0, 1, 1 if projected else 2, 1025, 0, 1, 1, 2048, 0, 1, 4326])
-        if nodata is not None:
-            add(42113, 2, repr(float(nodata)))
-        entries.sort(key=lambda t: t[0])
-        blocks.append((entries, payload))
-    # layout: header | IFD 0 | its long values | its strip | IFD 1 | ...
-    out = bytearray(b'II' + struct.pack('<HI', 42, 8))
-    for level, (entries, payload) in enumerate(blocks):
-        ifd_off = len(out)
-        ifd_len = 2 + 12 * len(entries) + 4
-        extra_off = ifd_off + ifd_len
-        extra = b''
-        body = b''
-        strip_entry = None
-        for k, (tag, typ, cnt, raw) in enumerate(entries):
-            if len(raw) <= 4:
-                val = raw + b'\x00' * (4 - len(raw))
-            else:
-                val = struct.pack('<I', extra_off + len(extra))
-                extra += raw + (b'\x00' if len(raw) % 2 else b'')
-            if tag == 273:
-                strip_entry = k
-            body += struct.pack('<HHI', tag, typ, cnt) + val
-        data_off = extra_off + len(extra)
-        k = strip_entry
-        body = body[:12 * k + 8] + struct.pack('<I', data_off) + body[12 * k + 12:]
-        end = data_off + len(payload)
-        end += end % 2                                                  # IFDs start on a word boundary
-        nxt = end if level + 1 < len(blocks) else 0
-        if end >= 1 << 32:
-            raise ValueError("write_geotiff: the file would exceed the 4 GiB of classic TIFF")
-        out += struct.pack('<H', len(entries)) + body + struct.pack('<I', nxt) + extra + payload
-        if len(out) < end:
-            out += b'\x00'
+    off_t, off_fmt = (16, 'Q') if bigtiff else (4, 'I')
     with open(path, 'wb') as fh:
-        fh.write(bytes(out))
+        fh.write(b'II' + (struct.pack('<HHHQ', 43, 8, 0, 0) if bigtiff else struct.pack('<HI', 42, 0)))     # first IFD offset: patched below
+        dirs = []          # per image: sorted entries (tag, type, count, packed bytes)
+        for level, arr in enumerate(images):
+            if arr.dtype.byteorder == '>':
+                arr = arr.astype(arr.dtype.newbyteorder('<'))
+            kind = {'u': 1, 'i': 2, 'f': 3}[arr.dtype.kind]
+            h, w = arr.shape
+            offs, cnts = [], []
+
+            def put(block):
+                payload = block.tobytes()
+                if compress:
+                    payload = zlib.compress(payload, 6)
+                if fh.tell() % 2:
+                    fh.write(b'\x00')
+                offs.append(fh.tell()); cnts.append(len(payload))
+                fh.write(payload)
+            if tile is None:
+                put(arr)
+            else:
+                t = int(tile)
+                for r0 in range(0, h, t):
+                    for c0 in range(0, w, t):
+                        blk = np.zeros((t, t), arr.dtype)                     # edge tiles are padded to the full size
+                        part = arr[r0:r0 + t, c0:c0 + t]
+                        blk[:part.shape[0], :part.shape[1]] = part
+                        put(blk)
+            entries = []
+
+            def add(tag, typ, values, entries=entries):
+                fmt = _TYPE_FMT[typ]
+                if typ == 2:
+                    raw = values.encode('latin-1') + b'\x00'
+                    entries.append((tag, typ, len(raw), raw))
+                else:
+                    entries.append((tag, typ, len(values), struct.pack('<' + fmt * len(values), *values)))
+
+            if level > 0:
+                add(254, 4, [1])                                            # reduced-resolution version of another image
+            add(256, 4, [w]); add(257, 4, [h]); add(258, 3, [arr.dtype.itemsize * 8]); add(259, 3, [8 if compress else 1])
+            add(262, 3, [1]); add(277, 3, [1]); add(339, 3, [kind])
+            if tile is None:
+                add(273, off_t, offs); add(278, 4, [h]); add(279, off_t, cnts)
+            else:
+                add(322, 4, [int(tile)]); add(323, 4, [int(tile)]); add(324, off_t, offs); add(325, off_t, cnts)
+            # (an overview covers the same ground with fewer, larger pixels)
+            add(33550, 12, [a * w0 / w, -e * h0 / h, 0.0]); add(33922, 12, [0.0, 0.0, 0.0, c, f, 0.0])
+            add(34735, 3, [1, 1, 0, 3, 1024, 0, 1, 1 if projected else 2, 1025, 0, 1, 1, 2048, 0, 1, 4326])
+            if tags and level == 0:
+                items = ''.join('<Item name="%s">%s</Item>' % (k, v) for k, v in tags.items())
+                add(42112, 2, '<GDALMetadata>' + items + '</GDALMetadata>')
+            if nodata is not None:
+                add(42113, 2, repr(float(nodata)))
+            entries.sort(key=lambda t: t[0])
+            dirs.append(entries)
+        # ---- the image file directories: count | entries | next | long values
+        inline = 8 if bigtiff else 4
+        first = None
+        for level, entries in enumerate(dirs):
+            if fh.tell() % 2:
+                fh.write(b'\x00')
+            ifd_off = fh.tell()
+            if first is None:
+                first = ifd_off
+            ifd_len = (8 + 20 * len(entries) + 8) if bigtiff else (2 + 12 * len(entries) + 4)
+            extra_off = ifd_off + ifd_len
+            extra, body = b'', b''
+            for tag, typ, cnt, raw in entries:
+                if len(raw) <= inline:
+                    val = raw + b'\x00' * (inline - len(raw))
+                else:
+                    val = struct.pack('<' + off_fmt, extra_off + len(extra))
+                    extra += raw + (b'\x00' if len(raw) % 2 else b'')
+                body += struct.pack('<HHQ' if bigtiff else '<HHI', tag, typ, cnt) + val
+            end = extra_off + len(extra)
+            end += end % 2
+            nxt = end if level + 1 < len(dirs) else 0
+            if not bigtiff and end >= 1 << 32:
+                raise ValueError("write_geotiff: the file would exceed the 4 GiB of classic TIFF (use bigtiff=True)")
+            fh.write(struct.pack('<Q' if bigtiff else '<H', len(entries)) + body + struct.pack('<' + off_fmt, nxt) + extra)
+        fh.seek(8 if bigtiff else 4)
+        fh.write(struct.pack('<' + off_fmt, first))
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -359,6 +406,55 @@ def block_mean_overview(data, factor, like_reference=True):
         if n > R * f and m > C * f:
             out[R:, C:] = data[R * f:, C * f:].mean()
     return out
+
+
+# block statistics GDAL / rasterio offer as overview resampling besides 'average' (rasterio.enums.Resampling); the
+# interpolating kernels (bilinear, cubic, cubic_spline, lanczos, gauss) are GDAL's own and are not reproduced
+_BLOCK_STATS = {
+    'max': lambda v: np.nanmax(v, axis=-1), 'min': lambda v: np.nanmin(v, axis=-1), 'med': lambda v: np.nanmedian(v, axis=-1),
+    'q1': lambda v: np.nanquantile(v, 0.25, axis=-1), 'q3': lambda v: np.nanquantile(v, 0.75, axis=-1),
+    'sum': lambda v: np.nansum(v, axis=-1), 'rms': lambda v: np.sqrt(np.nanmean(v * v, axis=-1)),
+}
+OVERVIEW_KINDS = ('average', 'nearest', 'mode') + tuple(sorted(_BLOCK_STATS))
+
+
+def block_overview(data, factor, kind='average'):
+    """One overview level of `data` with one of OVERVIEW_KINDS: every output cell summarises a factor x factor block (the
+    blocks that stick out of the array are partial), NaN = no data is ignored by the statistics.  'average' is
+    block_mean_overview(like_reference=False); 'nearest' takes the block's centre cell like GDAL's nearest-neighbour
+    decimation; 'mode' the most frequent value (ties: the smallest)."""
+    data = np.asarray(data, np.float64)
+    f = int(factor)
+    if kind == 'average':
+        return block_mean_overview(data, f, like_reference=False)
+    n, m = data.shape
+    N, M = -(-n // f), -(-m // f)
+    if kind == 'nearest':
+        ii = np.minimum(np.arange(N) * f + f // 2, n - 1)
+        jj = np.minimum(np.arange(M) * f + f // 2, m - 1)
+        return data[np.ix_(ii, jj)].copy()
+    pad = np.full((N * f, M * f), np.nan)
+    pad[:n, :m] = data
+    blocks = np.ascontiguousarray(pad.reshape(N, f, M, f).transpose(0, 2, 1, 3)).reshape(N, M, f * f)
+    if kind == 'mode':
+        srt = np.sort(blocks, axis=-1)                      # NaN sorts last
+        out = np.full((N, M), np.nan)
+        best = np.zeros((N, M), np.int64)
+        run = np.ones((N, M), np.int64)
+        for k in range(f * f):
+            v = srt[..., k]
+            if k > 0:
+                run = np.where(v == srt[..., k - 1], run + 1, 1)
+            take = (run > best) & ~np.isnan(v)
+            out = np.where(take, v, out)
+            best = np.where(take, run, best)
+        return out
+    if kind not in _BLOCK_STATS:
+        raise NotImplementedError("overview resampling %r (available: %s)" % (kind, ', '.join(OVERVIEW_KINDS)))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)         # all-NaN blocks stay NaN
+        return _BLOCK_STATS[kind](blocks)
 
 
 # ---------------------------------------------------------------------------------------------------------------

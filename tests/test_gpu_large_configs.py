@@ -138,3 +138,31 @@ def test_config4_mosaic_against_oracle_backed_flow(n_workers, tmp_path):
         ta, tb = pm.tile_result(i, 'twi'), po.tile_result(i, 'twi')
         fin = np.isfinite(ta) & np.isfinite(tb)
         assert np.allclose(ta[fin], tb[fin], rtol=1e-9, atol=1e-9), i
+
+
+def test_config4_mosaic_2048_against_oracle_checksums():
+    """The directory path above toy sizes: 2 x 4 tiles of 2048 x 2048 (bench layout, one-pixel overlap, pits), pool schedule of
+    width 8 with the device edge board, against checksums of the same flow with the oracle-backed processor
+    (tools/gen_large_checksums.py 4: 4-5 minutes of oracle time on the build box).  Same waves and rounds, edge masks bit for
+    bit, uca_total / twi per tile through NaN counts, extrema, sums and quantiles.  Reference: pydem/process_manager.py:224-284,
+    1090-1246 (the multi-worker schedule as deterministic waves)."""
+    key = 'config4_8x2048'
+    if key not in SUMS:
+        pytest.skip("no checksums for %s (tools/gen_large_checksums.py 4)" % key)
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from pydem_amd import process_manager
+    want = SUMS[key]
+    n = want['tile']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        pm = process_manager.ProcessManager(elev_source_files=bench.tile_specs(8, n, n), elev_conditioned=True,
+                                            dem_proc_kwargs={'drain_pits': True}, n_workers=want['n_workers'])
+        pm.process_twi()
+    assert (pm.edge_rounds, pm.edge_waves) == (want['edge_rounds'], want['edge_waves'])
+    for i, w in enumerate(want['tiles']):
+        assert sha(np.asarray(pm.tile_result(i, 'edge_todo'), np.uint8)) == w['edge_todo_sha256'], (i, 'edge_todo')
+        assert sha(np.asarray(pm.tile_result(i, 'edge_done'), np.uint8)) == w['edge_done_sha256'], (i, 'edge_done')
+        check_float('tile %d uca_total' % i, pm.tile_result(i, 'uca_total'), w['uca_total'])
+        check_float('tile %d twi' % i, pm.tile_result(i, 'twi'), w['twi'])

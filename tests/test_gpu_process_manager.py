@@ -31,6 +31,38 @@ def test_directory_flow_matches_reference(name, tmp_path):
     assert pm.edge_rounds >= 1
 
 
+@pytest.mark.parametrize('name', ['pm_fractal_2x3_ov1', 'pm_int16_defaults_2x2_ov2'])
+def test_directory_flow_from_geotiff_tiles_on_the_device(name, tmp_path):
+    """Real input format: the mosaic's tiles as (projected, Deflate, 16 x 16-tiled) GeoTIFF files read by pydem_amd/raster.py
+    (the reference opens them with rasterio, pydem/utils.py:43-51) and fed to the device flow -- the same per-tile and stitched
+    results as the reference's run on these tiles."""
+    from pydem_amd import process_manager, raster
+    from test_process_manager_cpu import compare_with_golden
+    g = load_golden(name)
+    for i in range(int(g['n_tiles'])):
+        elev = g['t%02d_elev' % i]
+        left, bottom, right, top = [float(v) for v in g['t%02d_bounds' % i]]
+        n, m = elev.shape
+        raster.write_geotiff(str(tmp_path / ('tile_%03d.tif' % i)), elev, ((right - left) / m, 0.0, left, 0.0, -(top - bottom) / n, top),
+                             projected=True, compress=True, tile=16)
+    dkw = {k: v for k, v in g['kwargs'].items() if k not in ('ny_grid', 'nx_grid', 'overlap')}
+    process_manager.DEBUG = True
+    try:
+        pm = process_manager.ProcessManager(in_path=str(tmp_path), dem_proc_kwargs=dkw, elev_conditioned=True)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            pm.process_twi()
+            compact = pm.save_non_overlap_data()
+    finally:
+        process_manager.DEBUG = False
+    order = [int(np.argmin([np.abs(g['t%02d_bounds' % j] - pm.index[i, :4]).sum() for j in range(pm.n_inputs)])) for i in range(pm.n_inputs)]
+    compare_with_golden(pm, compact, order, g, _close)
+    out = str(tmp_path / 'twi.tif')
+    pm.save_geotiff(out, 'twi', 'float32', overview_type='average')
+    assert np.array_equal(raster.read_geotiff(out).array, compact['twi'].astype('float32'), equal_nan=True)
+
+
 @pytest.mark.parametrize('name', ['pm_fractal_2x3_ov1', 'pm_cone32_4x5_ov3'])
 def test_directory_flow_with_tiles_in_flight(name, tmp_path):
     """Several tiles of one GPU worked on at once (worker threads, one HIP stream per tile): same results."""

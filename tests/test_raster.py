@@ -250,6 +250,20 @@ def test_directory_flow_from_geotiff_tiles(tmp_path):
         raster.read_geotiff(out2, 3)
     with pytest.raises(NotImplementedError):
         pm1.save_geotiff(out2, 'uca', 'float64', overview_type='cubic')
+    # the reference's file layout (:906-913: 512 x 512 blocks, BigTIFF) is the default; other resampling kinds; rescale tag (:925)
+    with open(out2, 'rb') as fh:
+        assert struct_magic(fh.read(4)) == 43
+    out3 = str(tmp_path / 'uca_max.tif')
+    pm1.save_geotiff(out3, 'uca', 'int32', rescale=(0.0, 10.0, 100.0), overview_type='max', overview_factors=[3], blocksize=16,
+                     bigtiff=False, nodata=-1)
+    scaled = (compact1['uca'] - 0.0) / 10.0 * 100.0
+    with np.errstate(invalid='ignore'):
+        assert np.array_equal(raster.read_geotiff(out3).array, scaled.astype('int32'))
+        ovm = raster.block_overview(scaled, 3, 'max')
+        assert np.array_equal(raster.read_geotiff(out3, 1).array, np.where(np.isnan(ovm), -1, ovm).astype('int32'))
+    with open(out3, 'rb') as fh:
+        raw = fh.read()
+    assert struct_magic(raw[:4]) == 42 and b'<Item name="rescale">0.0,10.0,100.0</Item>' in raw and b'rio_overview_resampling">max<' in raw
     # one file per key (save_non_overlap_data_geotiff :786-860)
     pm1.save_non_overlap_data_geotiff('float32', new_path=str(tmp_path / 'tiffs'), keys=('elev', 'twi'), overview_type='average')
     for key in ('elev', 'twi'):
@@ -302,3 +316,109 @@ def test_dem_processor_elev_fn_constructor(monkeypatch):
     dp2 = DEMProcessor(elev_fn=fn, dX=2.0, fill_flats=False)
     assert np.array_equal(dp2.dX, np.full(ds.shape[0] - 1, 2.0)) and dp2.fill_flats is False
     assert np.array_equal(dp2.dY, want['dY'])
+
+
+def test_integer_overviews_carry_nodata_not_nan(tmp_path):
+    """Block-mean overviews of an integer raster: a block without valid cells is NaN in the float mean; in the file it must be
+    the nodata value (announced by the GDAL_NODATA tag), never an undefined integer -- and without a nodata value the export
+    is refused."""
+    import warnings
+    base = np.arange(36, dtype=np.int16).reshape(6, 6)
+    ov = np.array([[1.5, np.nan], [20.25, 30.0]])
+    out = str(tmp_path / 'i16.tif')
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                          # (the NaN -> int cast used to raise a RuntimeWarning)
+        raster.write_geotiff(out, base, (1.0, 0.0, 0.0, 0.0, -1.0, 6.0), projected=True, nodata=-32768, overviews=[ov])
+    got = raster.read_geotiff(out, 1)
+    assert got.array.dtype == np.int16 and got.nodata == -32768
+    assert got.array.tolist() == [[1, -32768], [20, 30]]
+    with pytest.raises(ValueError):
+        raster.write_geotiff(out, base, (1.0, 0.0, 0.0, 0.0, -1.0, 6.0), projected=True, overviews=[ov])
+
+
+def test_geodesic_known_answers():
+    """Published known answers for the geodesic that replaces geopy.distance in the spacing rules (pydem/utils.py:127-174 calls
+    geopy, which is not available here; the harness cannot capture its output):
+      * Vincenty's own check line Flinders Peak -> Buninyong on GRS-80 (Geoscience Australia's worked example): 54 972.271 m;
+      * the WGS-84 quarter meridian (equator to pole): 10 001 965.729 m;
+      * one degree of longitude on the equator: a * pi / 180."""
+    d = raster.geodesic_m(-(37 + 57 / 60 + 3.72030 / 3600), 144 + 25 / 60 + 29.52440 / 3600,
+                          -(37 + 39 / 60 + 10.15610 / 3600), 143 + 55 / 60 + 35.38390 / 3600, 'GRS-80')
+    assert abs(d - 54972.271) < 1e-3
+    assert abs(raster.geodesic_m(0.0, 10.0, 90.0, 10.0) - 10001965.729) < 1e-3
+    assert abs(raster.geodesic_m(0.0, 0.0, 0.0, 1.0) - 6378137.0 * np.pi / 180) < 1e-6
+    # symmetry and additivity along a meridian (what dY of consecutive rows relies on)
+    a, b, c = raster.geodesic_m(40.0, 7.0, 40.5, 7.0), raster.geodesic_m(40.5, 7.0, 41.0, 7.0), raster.geodesic_m(40.0, 7.0, 41.0, 7.0)
+    assert abs(a + b - c) < 1e-6 and raster.geodesic_m(41.0, 7.0, 40.0, 7.0) == c
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32', 'int16', 'uint8'])
+@pytest.mark.parametrize('bigtiff', [False, True])
+def test_tiled_and_bigtiff_round_trip(dtype, bigtiff, tmp_path):
+    """The layout of the reference's export (512 x 512 blocks in a BigTIFF, pydem/process_manager.py:906-913): tiles whose
+    edge blocks stick out of the raster, 64-bit offsets, overviews as further directories, metadata items -- written by
+    write_geotiff and read back by read_geotiff (which also reads what GDAL writes: tests above)."""
+    rng = np.random.default_rng(5)
+    arr = (rng.random((150, 233)) * 200).astype(dtype)
+    ovs = [raster.block_overview(arr, 3, 'nearest'), raster.block_overview(arr, 9, 'nearest')]
+    out = str(tmp_path / 't.tif')
+    raster.write_geotiff(out, arr, (0.5, 0.0, 10.0, 0.0, -0.5, 99.0), projected=True, compress=True, overviews=ovs, tile=64,
+                         bigtiff=bigtiff, nodata=(None if dtype.startswith('f') else 0), tags={'rescale': '0,1,2'})
+    with open(out, 'rb') as fh:
+        assert struct_magic(fh.read(4)) == (43 if bigtiff else 42)
+    ds = raster.read_geotiff(out)
+    assert ds.array.dtype == np.dtype(dtype) and np.array_equal(ds.array, arr)
+    assert ds.transform == (0.5, 0.0, 10.0, 0.0, -0.5, 99.0) and ds.is_projected
+    for k, o in enumerate(ovs):
+        got = raster.read_geotiff(out, k + 1)
+        assert np.array_equal(got.array, o.astype(dtype)) and got.shape == o.shape
+    with pytest.raises(IndexError):
+        raster.read_geotiff(out, 3)
+    with pytest.raises(ValueError):
+        raster.write_geotiff(out, arr, (0.5, 0.0, 10.0, 0.0, -0.5, 99.0), tile=100)
+
+
+def struct_magic(b):
+    import struct
+    assert b[:2] == b'II'
+    return struct.unpack('<H', b[2:4])[0]
+
+
+def test_block_overview_kinds_against_loops():
+    """Every overview resampling kind against a plain loop over the blocks (partial edge blocks, NaN = no data ignored)."""
+    rng = np.random.default_rng(11)
+    a = np.round(rng.random((14, 17)) * 6)
+    a[rng.random(a.shape) < 0.15] = np.nan
+    a[:3, :3] = np.nan                                     # one block without data
+    f = 3
+    N, M = -(-a.shape[0] // f), -(-a.shape[1] // f)
+    import warnings
+
+    def loop(fn):
+        out = np.full((N, M), np.nan)
+        for i in range(N):
+            for j in range(M):
+                v = a[i * f:(i + 1) * f, j * f:(j + 1) * f].ravel()
+                v = v[~np.isnan(v)]
+                if v.size:
+                    out[i, j] = fn(v)
+        return out
+
+    def mode(v):
+        vals, cnt = np.unique(v, return_counts=True)
+        return vals[np.argmax(cnt)]
+    want = {'max': np.max, 'min': np.min, 'med': np.median, 'q1': lambda v: np.quantile(v, 0.25), 'q3': lambda v: np.quantile(v, 0.75),
+            'sum': np.sum, 'rms': lambda v: np.sqrt(np.mean(v * v)), 'mode': mode}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for kind, fn in want.items():
+            got = raster.block_overview(a, f, kind)
+            ref = loop(fn)
+            if kind == 'sum':
+                ref = np.where(np.isnan(ref), 0.0, ref)         # numpy's nansum of nothing is 0
+            assert np.allclose(got, ref, rtol=1e-14, atol=0, equal_nan=True), kind
+    near = raster.block_overview(a, f, 'nearest')
+    assert near.shape == (N, M) and np.array_equal(near[:4, :5], a[1:11:3, 1:14:3], equal_nan=True)
+    assert np.array_equal(raster.block_overview(a, f, 'average'), raster.block_mean_overview(a, f, like_reference=False), equal_nan=True)
+    with pytest.raises(NotImplementedError):
+        raster.block_overview(a, f, 'lanczos')

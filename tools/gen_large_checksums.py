@@ -6,9 +6,13 @@
                conditioning by the host implementation (pydem_amd/conditioning.py, pinned bit for bit by the reference's
                g5_* / g7_* goldens), everything after it by the oracle
 
+    config 4   8-tile 2 x 4 mosaic (one-pixel overlap, the bench layout) at 2048^2 per tile, pool edge schedule of width 8
+               through the ProcessManager with the oracle-backed processor: per tile the edge masks, uca_total and twi after
+               the fix-up, plus the round / wave counts of the schedule (4-5 minutes of oracle time)
+
 Exact fields (section, flats, pit -> drain pairs, the conditioned surface) are recorded as sha256, float fields as NaN
 count / min / max / pairwise sum / quantiles.  tests/test_gpu_large_configs.py compares the device results with them.
-Run on the build box (oracle only -- the reference is not needed):  python tools/gen_large_checksums.py [3] [5] [small]
+Run on the build box (oracle only -- the reference is not needed):  python tools/gen_large_checksums.py [3] [4] [5] [small]
 """
 import hashlib
 import json
@@ -77,6 +81,34 @@ def config5(size=8192):
                          'host_fill_flats_seconds': t1 - t0, 'host_pit_paths_seconds': t2 - t1, 'oracle_seconds': time.time() - t2})
 
 
+def config4(size=2048, n_workers=8):
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import bench
+    from oracle_processor import OracleProcessor
+    from pydem_amd import process_manager
+    specs = []
+    for sp in bench.tile_specs(8, size, size):
+        sp2 = dict(sp)
+        sy = sp2.pop('synth')
+        sp2['elev'] = O.synth_fractal(size, size, seed=sy['seed'], row0=sy['row0'], col0=sy['col0'])
+        specs.append(sp2)
+    t0 = time.time()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        po = process_manager.ProcessManager(elev_source_files=specs, elev_conditioned=True, dem_proc_kwargs={'drain_pits': True},
+                                            n_workers=n_workers, processor_cls=OracleProcessor)
+        po.process_twi()
+    tiles = []
+    for i in range(8):
+        twi = np.asarray(po.tile_result(i, 'twi'), np.float64)
+        tiles.append({'edge_todo_sha256': sha(np.asarray(po.tile_result(i, 'edge_todo'), np.uint8)),
+                      'edge_done_sha256': sha(np.asarray(po.tile_result(i, 'edge_done'), np.uint8)),
+                      'uca_total': fstats(po.tile_result(i, 'uca_total')), 'twi': fstats(twi)})
+    return {'what': '2 x 4 mosaic of %d^2 fp64 fractal tiles (bench.tile_specs), drain_pits=True, pool schedule n_workers=%d, oracle-backed processor'
+                    % (size, n_workers), 'tile': size, 'n_workers': n_workers, 'edge_rounds': int(po.edge_rounds), 'edge_waves': int(po.edge_waves),
+            'tiles': tiles, 'quantile_levels': QS, 'oracle_seconds': time.time() - t0}
+
+
 def main():
     which = sys.argv[1:] or ['3', '5']
     small = 'small' in which
@@ -84,6 +116,11 @@ def main():
     if '3' in which:
         key = 'config3_%d' % (1024 if small else 16384)
         res[key] = config3(1024 if small else 16384)
+        print(key, 'done in %.0f s' % res[key]['oracle_seconds'], flush=True)
+        json.dump(res, open(OUT, 'w'), indent=1, sort_keys=True)
+    if '4' in which:
+        key = 'config4_8x%d' % (512 if small else 2048)
+        res[key] = config4(512 if small else 2048)
         print(key, 'done in %.0f s' % res[key]['oracle_seconds'], flush=True)
         json.dump(res, open(OUT, 'w'), indent=1, sort_keys=True)
     if '5' in which:
