@@ -705,252 +705,6 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pair version (between the lane and the wavefront version): TWO pits per wavefront, 32 lanes each.  The wavefront
-// version is bound by instruction issue (~240 wave64 instructions per round, 26 M rounds at 16384^2) with most
-// lanes idle -- a typical round promotes one cell and reads a border of 50-100 entries -- and by the 6.4 KB of LDS a pit
-// needs (24 pits per CU).  Here a pit gets a 64 x 64 window and a 128-entry border list (3.3 KB), the two halves of a
-// wavefront run their rounds in lockstep on the same instruction stream (per-half state in vector registers, ballots
-// split in two 32-bit words, minima reduced inside each half on the DPP crossbar), so an instruction serves two pits
-// and a CU holds 48 of them.  The drain selection / slope arithmetic of a finished pit is the full-width code of the
-// wavefront version (finish_pit_wave), run for one half at a time.  Pits that leave the window or outgrow the list go
-// on to the wavefront version.  Same arithmetic, same order of the drains: results are bit-identical.
-// ---------------------------------------------------------------------------------------------
-constexpr int PR_W = 64, PR_CAP = 128, PR_SLOTS = PR_CAP / 32;
-struct PairLds {
-    static constexpr uint16_t HOLE = 0xFFFFu, PITBIT = 1u << 14;
-    uint32_t seen[PR_W * PR_W / 32];
-    double le[PR_CAP];
-    uint16_t lpos[PR_CAP];          // window position | PITBIT; HOLE = free slot
-    uint16_t holes[PR_CAP];
-    union {
-        uint16_t pq[PR_CAP];
-        struct { int32_t dl[WV_MAXD]; double dxy[WV_MAXD], sv[WV_MAXD]; } fin;
-    } u;
-};
-
-// minimum over each half of the wavefront (lanes 0-31 / 32-63)
-__device__ __forceinline__ double half_min(double v, int half)
-{
-    v = dpp_fmin<0xB1>(v);
-    v = dpp_fmin<0x4E>(v);
-    v = dpp_fmin<0x141>(v);
-    v = dpp_fmin<0x140>(v);
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const double a = min_f64(__hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0)),
-                             __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16)));
-    const double b = min_f64(__hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)),
-                             __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48)));
-    return half ? b : a;
-}
-__device__ __forceinline__ uint32_t half_bits(unsigned long long bal, int half) { return half ? (uint32_t)(bal >> 32) : (uint32_t)bal; }
-__device__ __forceinline__ double readlane_f64(double v, int src)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
-}
-
-#ifndef PYDEM_PR_OCC
-#define PYDEM_PR_OCC 6
-#endif
-__global__ __launch_bounds__(256, PYDEM_PR_OCC) void k_pits_pair(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits)
-{
-    __shared__ PairLds s_l[4][2];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
-    PairLds &L = s_l[wave][half];
-    const int32_t np = *npits;
-    const uint32_t hlt = (1u << hl) - 1u;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const int n = P.n, m = P.m;
-    int32_t chunk_base = 0, chunk_left = 0;              // wave-uniform: the output chunk serves both halves
-    int32_t q = (blockIdx.x * 4 + wave) * 2 + half;      // this half's next entry of the pit list
-    const int32_t qstride = gridDim.x * 8;
-    // per-half state (the same value in the 32 lanes of a half).  state: 0 wants a pit, 1 in its rounds, 2 rounds over, 3 no pit left
-    int state = 0, fresh = 0;
-    int32_t pit = 0;
-    int ipit = 0, jpit = 0, r0 = 0, c0 = 0, nb = 0, nh = 0, n_alive = 0, it = 0, over = 0, mode = 0, nq = 0;
-    double epit = 0.0, epit_border = 0.0;
-    bool has_np = false, has_p = false, has_nan = false;
-    for (;;) {
-        // ---- a half without a pit takes the next one: pit_area = [pit] (:1289-1292), its neighbours join the border below
-        if (state == 0) {
-            if (q < np) {
-                pit = pits[q]; q += qstride;
-                ipit = pit / m; jpit = pit - ipit * m;
-                r0 = ipit - PR_W / 2; c0 = jpit - PR_W / 2;
-                if (r0 > n - PR_W) r0 = n - PR_W;
-                if (c0 > m - PR_W) c0 = m - PR_W;
-                if (r0 < 0) r0 = 0;
-                if (c0 < 0) c0 = 0;
-                for (int w = hl; w < PR_W * PR_W / 32; w += 32) L.seen[w] = 0;
-                epit = P.elev[pit]; epit_border = epit;
-                nb = 0; nh = 0; n_alive = 0; it = 0; over = 0; mode = 0;
-                has_np = false; has_p = false; has_nan = false;
-                state = 1; fresh = 1; nq = 1;
-            } else state = 3;
-        }
-        if (!__ballot(state != 3)) break;
-        wave_sync();                                       // (the cleared bitmap before the seed bit)
-        if (state == 1 && fresh && hl == 0) {
-            const int pos = (ipit - r0) * PR_W + (jpit - c0);
-            L.seen[pos >> 5] = 1u << (pos & 31);
-            L.u.pq[0] = (uint16_t)pos;
-        }
-        // ---- halves in their rounds: the stop tests of :1300-1320, then border[eborder == emin] leaves the list
-        const bool rounds = state == 1 && !fresh;
-        bool sel = false;
-        if (rounds) {
-            nq = 0;
-            if (over || it >= P.max_iter || n_alive == 0) state = 2;
-            else if (has_nan) { if (has_p) mode = 2; state = 2; }      // numpy's min propagates NaN: no non-pit drain, no growth
-            else if (has_np) { mode = 1; state = 2; }
-            else if (has_p) { mode = 2; state = 2; }
-            else { sel = true; it++; }
-        }
-        if (__ballot(sel)) {
-            double e[PR_SLOTS];
-            double mn = INFINITY;
-#pragma unroll
-            for (int j = 0; j < PR_SLOTS; j++) {
-                const int k = hl + 32 * j;
-                e[j] = (sel && k < nb) ? L.le[k] : INFINITY;
-                mn = min_f64(mn, e[j]);
-            }
-            mn = half_min(mn, half);
-#pragma unroll
-            for (int j = 0; j < PR_SLOTS; j++) {
-                const int k = hl + 32 * j;
-                bool match = sel && k < nb && e[j] == mn;
-                uint16_t ps = 0;
-                if (match) { ps = L.lpos[k]; match = ps != PairLds::HOLE; }
-                const uint32_t hb = half_bits(__ballot(match), half);
-                if (match) {
-                    const int r = nq + __popc(hb & hlt);
-                    L.u.pq[r] = (uint16_t)(ps & (PairLds::PITBIT - 1));
-                    L.holes[nh + r] = (uint16_t)k;
-                    L.le[k] = INFINITY; L.lpos[k] = PairLds::HOLE;
-                }
-                if (sel) nq += __popc(hb);
-            }
-            if (sel) { nh += nq; n_alive -= nq; }
-        }
-        wave_sync();
-        // ---- the unseen neighbours of the nq promoted cells join the border
-        {
-            const int nq8 = (state == 1) ? nq * 8 : 0;
-            bool xstop = false;
-            for (int base = 0;; base += 32) {
-                const bool go = base < nq8 && !xstop;
-                if (!__ballot(go)) break;
-                const int idx = base + hl;
-                bool isnew = false, out = false;
-                double e = 0.0; uint32_t pm = 0; int npos = 0;
-                if (go && idx < nq8) {
-                    const int pos = L.u.pq[idx >> 3], d = idx & 7;
-                    const int di = d < 3 ? -1 : (d < 5 ? 0 : 1);
-                    const int dj = d < 3 ? d - 1 : (d == 3 ? -1 : (d == 4 ? 1 : d - 6));
-                    const int r = pos / PR_W, c = pos % PR_W;
-                    const int ii = r0 + r + di, jj = c0 + c + dj;
-                    if (ii >= 0 && ii < n && jj >= 0 && jj < m) {
-                        const int rr = r + di, cc = c + dj;
-                        if (rr < 0 || rr >= PR_W || cc < 0 || cc >= PR_W) out = true;
-                        else {
-                            npos = rr * PR_W + cc;
-                            const uint32_t bit = 1u << (npos & 31);
-                            const uint32_t old = atomicOr(&L.seen[npos >> 5], bit);
-                            if (!(old & bit)) {
-                                isnew = true;
-                                const int64_t cell = (int64_t)ii * m + jj;
-                                e = P.elev[cell]; pm = P.pitmask[cell];
-                            }
-                        }
-                    }
-                }
-                if (half_bits(__ballot(out), half)) over = 1;
-                const uint32_t hb = half_bits(__ballot(isnew), half);
-                const uint32_t hp = half_bits(__ballot(isnew && pm && e < epit), half);
-                const uint32_t hn = half_bits(__ballot(isnew && !pm && e < epit_border), half);
-                const uint32_t hx = half_bits(__ballot(isnew && e != e), half);
-                if (go) {
-                    const int cnt = __popc(hb);
-                    const int grow = cnt > nh ? cnt - nh : 0;                       // slots taken beyond the list end
-                    if (nb + grow > PR_CAP) { over = 2; xstop = true; }
-                    else {
-                        if (isnew) {
-                            const int rk = __popc(hb & hlt);
-                            const int k = rk < nh ? (int)L.holes[nh - 1 - rk] : nb + (rk - nh);
-                            L.le[k] = e; L.lpos[k] = (uint16_t)((uint16_t)npos | (pm ? PairLds::PITBIT : (uint16_t)0));
-                        }
-                        if (hp) has_p = true;
-                        if (hn) has_np = true;
-                        if (hx) has_nan = true;
-                        nh -= cnt - grow; nb += grow; n_alive += cnt;
-                    }
-                }
-            }
-        }
-        wave_sync();
-        if (__ballot(state == 1 && fresh && P.min_border)) {                    // :1294-1295
-            double mn = INFINITY;
-            const bool mine = state == 1 && fresh;
-            for (int k0 = 0; k0 < PR_CAP; k0 += 32) { const int k = k0 + hl; if (mine && k < nb) mn = min_f64(mn, L.le[k]); }
-            mn = half_min(mn, half);
-            if (mine && P.min_border) { if (nb) epit_border = mn; has_np = false; }
-        }
-        fresh = 0;
-        // ---- a half whose rounds are over: drains, weights, output -- the full-width code of the wavefront version
-#pragma unroll 1
-        for (int h = 0; h < 2; h++) {
-            const int src = 32 * h;
-            if (__builtin_amdgcn_readlane(state, src) != 2) continue;
-            PairLds &F = s_l[wave][h];
-            const int32_t u_pit = __builtin_amdgcn_readlane(pit, src);
-            const int u_ipit = __builtin_amdgcn_readlane(ipit, src), u_jpit = __builtin_amdgcn_readlane(jpit, src);
-            const int u_r0 = __builtin_amdgcn_readlane(r0, src), u_c0 = __builtin_amdgcn_readlane(c0, src);
-            const int u_nb = __builtin_amdgcn_readlane(nb, src), u_mode = __builtin_amdgcn_readlane(mode, src);
-            int u_over = __builtin_amdgcn_readlane(over, src);
-            const double u_epit = readlane_f64(epit, src), u_eb = readlane_f64(epit_border, src);
-            int ndrain = -1;
-            if (!u_over && u_mode) {
-                // drains: ballot-compacted, then rank-sorted into ascending cell order (the order of setdiff1d)
-                int nd = 0;
-                for (int base = 0; base < u_nb; base += 64) {
-                    const int k = base + lane;
-                    bool pred = false;
-                    int32_t cell = 0;
-                    if (k < u_nb && F.lpos[k] != PairLds::HOLE) {
-                        const int pos = (int)(F.lpos[k] & (PairLds::PITBIT - 1));
-                        const bool pm = (F.lpos[k] & PairLds::PITBIT) != 0;
-                        const double ev = F.le[k];
-                        pred = u_mode == 1 ? (!pm && ev < u_eb) : (pm && ev < u_epit);
-                        cell = (int32_t)((int64_t)(u_r0 + pos / PR_W) * m + (u_c0 + pos % PR_W));
-                    }
-                    const unsigned long long bal = __ballot(pred);
-                    const int rank = nd + __popcll(bal & lt);
-                    wave_sync();                                                 // (u.pq is dead: the drain scratch may be written)
-                    if (pred && rank < WV_MAXD) F.u.fin.dl[rank] = cell;
-                    nd += __popcll(bal);
-                }
-                if (nd > WV_MAXD) u_over = 3;
-                else {
-                    wave_sync();
-                    const int32_t key = lane < nd ? F.u.fin.dl[lane] : INT32_MAX;
-                    int rank = 0;
-                    for (int t = 0; t < nd; t++) rank += F.u.fin.dl[t] < key;
-                    wave_sync();
-                    if (lane < nd) F.u.fin.dl[rank] = key;
-                    wave_sync();
-                    ndrain = nd;
-                }
-            }
-            if (u_over) { if (lane == 0) P.overflow_list[atomicAdd(P.overflow_count, 1)] = u_pit; }       // on to the wavefront version
-            else if (ndrain < 0) { if (lane == 0) atomicAdd(&P.out_count[1], 1); }                          // :1327-1329
-            else finish_pit_wave(P, u_pit, u_ipit, u_jpit, u_epit, ndrain, F.u.fin.dl, F.u.fin.dxy, F.u.fin.sv, chunk_base, chunk_left, lane);
-            if (half == h) state = 0;
-            wave_sync();
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Lane version (first pass over ALL pits).  The wavefront version spends ~700 VALU issues per round
 // with 64 lanes serving a border of ~10-20 cells, so it is instruction-bound with most lanes idle.
 // Here every LANE owns one pit: the border is an unordered list (elevation + window position) in
@@ -1539,7 +1293,6 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
     PYDEM_TRY(tile_alloc(t, &t->flatlist, (size_t)t->NN));    // reused as the pit list
     PYDEM_TRY(tile_alloc(t, &t->labels, (size_t)t->NN));      // reused as the overflow list
     PYDEM_TRY(tile_alloc(t, &t->queue[0], (size_t)t->NN));    // (sweep queue, idle here) lane -> wavefront hand-over list
-    PYDEM_TRY(tile_alloc(t, &t->queue[1], (size_t)t->NN));    // (the other one) pair -> wavefront hand-over list
     int32_t *cnt = t->counters + 40;                            // [0] npits, [1..4] out_count, scratch
     HIP_TRY(hipMemsetAsync(cnt, 0, 16 * sizeof(int32_t), t->stream));
     const int big = (int)(cdiv(t->NN, 256) < 8192 ? cdiv(t->NN, 256) : 8192);
@@ -1563,7 +1316,6 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             t->pits.raw_cap = cap;
         }
         HIP_TRY(hipMemsetAsync(cnt + 1, 0, 8 * sizeof(int32_t), t->stream));
-        HIP_TRY(hipMemsetAsync(cnt + 12, 0, sizeof(int32_t), t->stream));
         PitParams P;
         P.dbg = nullptr; P.prof = nullptr;
         const char *dbg_env = getenv("PYDEM_PITS_DEBUG");
@@ -1594,25 +1346,9 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
                     h[4], h[4] ? (double)h[3] / (double)h[4] : 0.0, h[0], h[5], h[1], h[2]);
             (void)hipFree(P.prof); P.prof = nullptr;
         }
-        int32_t n_pair_over = 0;
-        static int use_pair = -1;           // PYDEM_PITS_PAIR=0: the pits that leave the lane window go straight to the wavefront version
-        if (use_pair < 0) { const char *e = getenv("PYDEM_PITS_PAIR"); use_pair = e ? atoi(e) : 1; }
-        const int32_t *wave_list = t->queue[0], *wave_count = cnt + 5;
-        if (n_lane_over > 0 && use_pair) {
-            // pass 2a: two pits per wavefront (64x64 window, 128 border cells); what outgrows it goes on to pass 2b
-            PitParams P2 = P;
-            P2.overflow_list = t->queue[1]; P2.overflow_count = cnt + 12;
-            const int gp = (int)(cdiv(n_lane_over, 8) < 16384 ? cdiv(n_lane_over, 8) : 16384);
-            hipLaunchKernelGGL(k_pits_pair, dim3(gp), dim3(256), 0, t->stream, P2, t->queue[0], cnt + 5);
-            HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipStreamSynchronize(t->stream));
-            n_pair_over = t->h_counters[12];
-            wave_list = t->queue[1]; wave_count = cnt + 12;
-        }
-        const int32_t n_for_wave = use_pair ? n_pair_over : n_lane_over;
-        if (n_for_wave > 0) {
-            const int gw = (int)(cdiv(n_for_wave, 4) < 16384 ? cdiv(n_for_wave, 4) : 16384);
-            hipLaunchKernelGGL(k_pits_wave, dim3(gw), dim3(256), 0, t->stream, P, wave_list, wave_count);
+        if (n_lane_over > 0) {
+            const int gw = (int)(cdiv(n_lane_over, 4) < 16384 ? cdiv(n_lane_over, 4) : 16384);
+            hipLaunchKernelGGL(k_pits_wave, dim3(gw), dim3(256), 0, t->stream, P, t->queue[0], cnt + 5);
             HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
         }
@@ -1627,7 +1363,6 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             HIP_TRY(hipStreamSynchronize(t->stream));
             n_over = t->h_counters[9];
         }
-        if (dbg_env) fprintf(stderr, "pits: %d of the pairs' pits went on to the wavefront pass\n", n_pair_over);
         if (dbg_env) fprintf(stderr, "pits: %d candidates, %d left the 16x16 lane window, %d left the 128x128 / 256-cell pass, %d left the 256x256 / 2048-cell pass, %d edge slots, %d undrained\n", npits, n_lane_over, n_wave_over, n_over, t->h_counters[1], t->h_counters[2]);
         if (P.dbg) {
             const int nrec = t->h_counters[7];
