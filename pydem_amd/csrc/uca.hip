@@ -226,7 +226,6 @@ struct SweepArgs {
     int64_t n_pit;
     int dbg;                     // timing experiments only (PYDEM_TILE_DEBUG)
     int32_t qcap;                // frontier queue capacity (entries)
-    int lv_scale, max_sub;       // level stamps of the tile passes: pass * lv_scale + sub-pass (below); sub-passes per launch
     int32_t *err;                // queue overflow counter
 };
 
@@ -611,20 +610,9 @@ __device__ __forceinline__ void tile_wave_sync()
 }
 
 constexpr int TILE_PEND = 48;    // woken tiles a wavefront collects before it appends them to the next pass's list
-// Tiles are scheduled in GROUPS of 2 x 2: ONE WAVEFRONT owns a group for a launch and visits its tiles one after the
-// other; a finished cell that drains into a sibling tile of the group makes the wavefront visit that tile (again) in the
-// same launch instead of in the next pass -- flow paths cross several tiles per kernel boundary, the latency-bound tail of
-// the sweep needs fewer launches, and nothing waits (same wavefront: program order plus the fence that ends a visit).
-// Cells finished by visit k (0, 1, ...) of pass p carry level p * lv_scale + k; a visit accepts the cells of its OWN
-// group as final when their level is below its own (the earlier visits of this wavefront), every other cell only when
-// an earlier launch finished it (level < p * lv_scale), as before: tiles never read what another wavefront wrote in
-// the same kernel.
-struct TileNext {            // LISTED passes: what must run again in the next pass
-    int32_t *flag;           // [2][flag_stride] per tile: the pass it is listed for (slot = pass & 1: this launch reads one slot and writes the other)
-    int32_t *gflag;          // per group: last pass the group was put on the list for
-    int32_t *list, *count;   // groups of the next pass
-    int32_t flag_stride;
-    int groups_x;
+struct TileNext {            // LISTED passes: tiles that must run again in the next pass
+    int32_t *flag;           // per tile: last pass it was listed for
+    int32_t *list, *count;
 };
 
 // contribution of in-edge d (0..7 = NW N NE W E SW S SE, the order of the in-mask bits) into cell c: one 8-byte load,
@@ -641,14 +629,10 @@ __device__ __forceinline__ double in_edge(const SweepArgs &A, int32_t c, int m, 
 template <bool LISTED>
 __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uint32_t pass, int tiles_x, int tid, int lane,
                                                uint8_t *__restrict__ tile_done, int32_t &n_final, const TileNext &N,
-                                               int32_t *pend, int &npend, int sub, uint32_t &woken)
+                                               int32_t *pend, int &npend)
 {
     const int by = tid / tiles_x, bx = tid - by * tiles_x;
     const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
-    // level stamps: what this visit writes / what it accepts as final from its own group / from everybody else
-    const uint32_t lv_foreign = pass * (uint32_t)A.lv_scale, lv_now = lv_foreign + (A.lv_scale > 1 ? (uint32_t)sub : 0u);
-    const int grp_i = i0 >> 6, grp_j = j0 >> 6;             // the 2 x 2 group = a 64 x 64 block of cells
-    auto lv_limit = [&](int gi, int gj) -> uint32_t { return ((gi >> 6) == grp_i && (gj >> 6) == grp_j) ? lv_now : lv_foreign; };
     const int half = lane >> 5, l32 = lane & 31;         // interior cell k of a lane: row 2k + half, column l32 of the tile
     // ready-list push; `consumed` = entries already processed (ring occupancy = tail - consumed)
     auto push_ready = [&](int cell, int consumed) {
@@ -672,22 +656,18 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
     auto stage_word = [&](int gi, int gj) -> uint32_t {                  // 0xFFFFFFFF: outside the grid
         return (gi >= 0 && gi < n && gj >= 0 && gj < m) ? A.cinfo[(int64_t)gi * m + gj] : 0xFFFFFFFFu;
     };
-    auto final_before = [&](uint32_t w, uint32_t limit) -> bool {        // outside the grid: nothing drains from there
+    auto final_before = [&](uint32_t w) -> bool {                        // outside the grid: nothing drains from there
         if (w == 0xFFFFFFFFu) return true;
         const uint32_t lv = ci_level(w);
-        return lv >= 1 && lv < limit;
+        return lv >= 1 && lv < pass;
     };
     uint32_t colL, colR;
     {
-        const int ci_ = i0 + l32, cj_ = half ? j0 + TT : j0 - 1;                      // left / right halo column
-        const int ri_ = half ? i0 + TT : i0 - 1, rj_ = j0 + l32;                      // top / bottom halo row
-        const int ki_ = (lane & 2) ? i0 + TT : i0 - 1, kj_ = (lane & 1) ? j0 + TT : j0 - 1;   // corners
-        const uint32_t wc = stage_word(ci_, cj_);
-        const uint32_t wr = stage_word(ri_, rj_);
+        const uint32_t wc = stage_word(i0 + l32, half ? j0 + TT : j0 - 1);          // left / right halo column
+        const uint32_t wr = stage_word(half ? i0 + TT : i0 - 1, j0 + l32);          // top / bottom halo row
         uint32_t wk = 0xFFFFFFFFu;
-        if (lane < 4) wk = stage_word(ki_, kj_);
-        const bool fc = final_before(wc, lv_limit(ci_, cj_)), fr = final_before(wr, lv_limit(ri_, rj_)),
-                   fk = lane < 4 && final_before(wk, lv_limit(ki_, kj_));
+        if (lane < 4) wk = stage_word((lane & 2) ? i0 + TT : i0 - 1, (lane & 1) ? j0 + TT : j0 - 1);   // corners
+        const bool fc = final_before(wc), fr = final_before(wr), fk = lane < 4 && final_before(wk);
         const unsigned long long bc = __ballot(fc), br = __ballot(fr), bk = __ballot(fk);
         colL = (uint32_t)bc; colR = (uint32_t)(bc >> 32);
         if (lane == 0) {
@@ -704,7 +684,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
 #pragma unroll
         for (int k = 0; k < STG_B; k++) {
             const int r = 2 * (kb + k);                                  // this load: local rows r + 1 (lanes 0-31), r + 2
-            const bool f = final_before(wst[k], lv_now);
+            const bool f = final_before(wst[k]);
             L.cs[lane + 64 * (kb + k)] = ((wst[k] == 0xFFFFFFFFu ? 0u : (wst[k] & CI_STATIC_MASK)) << 16) | ((f ? 1u : 0u) << SP_STATE_SHIFT);
             const unsigned long long b = __ballot(f);
             if (lane == 0) {
@@ -765,7 +745,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
                         if (si >= 0 && si < TT && sj >= 0 && sj < TT)
                             return sp_state(L, si * TT + sj) ? 0u : 1u;          // released on chip when the pit finishes
                         const uint32_t lv = ci_level(A.cinfo[sc]);
-                        return (lv >= 1 && lv < lv_limit(sc / m, sc % m)) ? 0u : SP_BLOCKED;      // another tile's business: blocked for this visit
+                        return (lv >= 1 && lv < pass) ? 0u : SP_BLOCKED;                   // another tile's business: blocked for this pass
                     };
                     uint32_t ba = 0, bb = 0;
                     if (va) ba = blocked(sa);
@@ -848,7 +828,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
             if (td) { o.x = -o.x; o.y = -o.y; }
             A.area[c] = a;
             A.contrib[c] = o;
-            if (LISTED) A.cinfo[c] = ci_with_level(cw, lv_now);      // finished in this (pass, sub-pass)
+            if (LISTED) A.cinfo[c] = ci_with_level(cw, pass);        // finished in this pass (other tiles treat levels < their pass as final)
             if (td) A.todo_work[c] = 1;
             sp_of(L, idx) = (uint16_t)(2u << SP_STATE_SHIFT);
             finalized++;
@@ -870,12 +850,8 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
                     const int dti = ti < 1 ? -1 : (ti > TT ? 1 : 0), dtj = tj < 1 ? -1 : (tj > TT ? 1 : 0);
                     if (ti >= 1 - TT && ti <= 2 * TT && tj >= 1 - TT && tj <= 2 * TT) wake |= 1u << ((dti + 1) * 3 + dtj + 1);
                     else {                                            // a pit draining further away than the next tile
-                        const int ty = (i0 + ti - 1) / TT, tx = (j0 + tj - 1) / TT;
-                        int32_t *fl = N.flag + (size_t)((pass + 1) & 1u) * N.flag_stride;
-                        if (atomicExch(&fl[ty * tiles_x + tx], (int32_t)pass + 1) != (int32_t)pass + 1) {
-                            const int g = (ty >> 1) * N.groups_x + (tx >> 1);
-                            if (atomicExch(&N.gflag[g], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = g;
-                        }
+                        const int tt = ((i0 + ti - 1) / TT) * tiles_x + (j0 + tj - 1) / TT;
+                        if (atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tt;
                     }
                 }
             };
@@ -900,7 +876,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
         for (int k = 0; k < NSET; k++) {
             const int li = 2 * k + half + 1, idx = lane + 64 * k;
             const uint32_t w = L.cs[idx];
-            if (((w >> SP_STATE_SHIFT) & 3u) == 2u) A.cinfo[(int64_t)(i0 + li - 1) * m + j0 + l32] = ci_with_level(w >> 16, lv_now);
+            if (((w >> SP_STATE_SHIFT) & 3u) == 2u) A.cinfo[(int64_t)(i0 + li - 1) * m + j0 + l32] = ci_with_level(w >> 16, pass);
         }
     for (int off = 32; off > 0; off >>= 1) { finalized += __shfl_down(finalized, off); n_open += __shfl_down(n_open, off); }
     if (LISTED) {
@@ -909,26 +885,12 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
         // global one with one add per wavefront / workgroup (tile_list_flush): the list counter is a single address too
         for (int off = 32; off > 0; off >>= 1) wake |= __shfl_xor(wake, off);
         bool win = false;
-        int ty = 0, tx = 0;
-        if (lane < 9 && ((wake >> lane) & 1u)) { ty = by + lane / 3 - 1; tx = bx + lane % 3 - 1; win = true; }
-        if (lane == 9 && L.limit != INT32_MAX) { ty = by; tx = bx; win = true; }
-        // a sibling of this tile's 2 x 2 group (or the tile itself): the wavefront visits it later in this launch (sweep_group) ...
-        {
-            const bool ingrp = win && A.lv_scale > 1 && (ty >> 1) == (by >> 1) && (tx >> 1) == (bx >> 1);
-            const int sib = (ty & 1) * 2 + (tx & 1);
-#pragma unroll
-            for (int q = 0; q < 4; q++) if (__ballot(ingrp && sib == q)) woken |= 1u << q;
-            if (ingrp) win = false;
-        }
-        // ... everybody else in the next pass: the tile gets its stamp, its group goes on the list once
-        if (win) {
-            int32_t *fl = N.flag + (size_t)((pass + 1) & 1u) * N.flag_stride;
-            win = atomicExch(&fl[ty * tiles_x + tx], (int32_t)pass + 1) != (int32_t)pass + 1;
-        }
-        const int gg = (ty >> 1) * N.groups_x + (tx >> 1);
-        if (win) win = atomicExch(&N.gflag[gg], (int32_t)pass + 1) != (int32_t)pass + 1;
+        int tt = 0;
+        if (lane < 9 && ((wake >> lane) & 1u)) { tt = tid + (lane / 3 - 1) * tiles_x + (lane % 3 - 1); win = true; }
+        if (lane == 9 && L.limit != INT32_MAX) { tt = tid; win = true; }
+        if (win) win = atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1;
         const unsigned long long bw = __ballot(win);
-        if (win) pend[npend + __popcll(bw & ((1ull << lane) - 1ull))] = gg;
+        if (win) pend[npend + __popcll(bw & ((1ull << lane) - 1ull))] = tt;
         npend += __popcll(bw);
     }
     if (lane == 0) {
@@ -946,75 +908,23 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
     tile_wave_sync();
 }
 
-// append the wavefront's pending groups to the next pass's list (one add per call: the counter is a single address)
-__device__ __forceinline__ void pend_flush(const TileNext &N, int32_t *pend, int &npend, int lane)
-{
-    tile_wave_sync();
-    int32_t base = 0;
-    if (lane == 0) base = atomicAdd(N.count, npend);
-    base = __shfl(base, 0);
-    for (int k = lane; k < npend; k += 64) N.list[base + k] = pend[k];
-    npend = 0;
-    tile_wave_sync();
-}
-
-// One wavefront, one 2 x 2 group, one launch: the tiles of `todo` (bit = tile of the group, row-major) one after the
-// other, then the siblings those visits woke, at most A.max_sub visits; what is still waiting then goes to the next pass.
+// every tile that is not done yet, four tiles per workgroup, XCD-contiguous bands of tiles (LISTED: also
+// lists the tiles of the next pass)
 template <bool LISTED>
-__device__ __forceinline__ void sweep_group(const SweepArgs &A, TileW &L, uint32_t pass, int tiles_x, int tiles_y, int g, uint32_t todo, int lane,
-                                            uint8_t *__restrict__ tile_done, int32_t &fin, const TileNext &N, int32_t *pend, int &npend,
-                                            int pend_cap)
-{
-    const int ty0 = (g / N.groups_x) * 2, tx0 = (g % N.groups_x) * 2;
-    int visits = 0;
-    while (todo && visits < A.max_sub) {
-        const int w = __ffs(todo) - 1;
-        todo &= todo - 1u;
-        const int ty = ty0 + (w >> 1), tx = tx0 + (w & 1);
-        if (ty >= tiles_y || tx >= tiles_x) continue;
-        const int tid = ty * tiles_x + tx;
-        if (tile_done[tid]) continue;
-        uint32_t woken = 0;
-        sweep_one_tile<LISTED>(A, L, pass, tiles_x, tid, lane, tile_done, fin, N, pend, npend, visits, woken);
-        todo |= woken;
-        visits++;
-        if (LISTED && npend > pend_cap - 10) pend_flush(N, pend, npend, lane);     // (a visit adds at most ten)
-    }
-    if (LISTED && todo) {
-        // out of visits: the waiting tiles get the next pass's stamp, the group goes on its list
-        bool win = false;
-        if (lane < 4 && ((todo >> lane) & 1u)) {
-            const int ty = ty0 + (lane >> 1), tx = tx0 + (lane & 1);
-            if (ty < tiles_y && tx < tiles_x && !tile_done[ty * tiles_x + tx]) {
-                int32_t *fl = N.flag + (size_t)((pass + 1) & 1u) * N.flag_stride;
-                win = atomicExch(&fl[ty * tiles_x + tx], (int32_t)pass + 1) != (int32_t)pass + 1;
-            }
-        }
-        if (__ballot(win)) {
-            bool gw = false;
-            if (lane == 0) gw = atomicExch(&N.gflag[g], (int32_t)pass + 1) != (int32_t)pass + 1;
-            if (__ballot(gw)) { if (lane == 0) pend[npend] = g; npend++; }
-        }
-    }
-}
-
-// every tile that is not done yet: one wavefront per 2 x 2 group of tiles, four groups per workgroup, XCD-contiguous
-// bands of groups (LISTED: also lists the groups of the next pass)
-template <bool LISTED>
-__global__ __launch_bounds__(256, 8) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_y,
+__global__ __launch_bounds__(256, 8) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total,
                                                      uint8_t *__restrict__ tile_done, int32_t *n_final, TileNext N)
 {
     __shared__ TileW L[4];
     __shared__ int32_t s_fin[4], s_np[4], s_pend[4][TILE_PEND], s_base;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    // workgroup b runs on XCD b % 8: give every XCD one contiguous band of groups (gridDim.x is a multiple of 8)
-    const int groups_total = N.groups_x * ((tiles_y + 1) >> 1);
+    // workgroup b runs on XCD b % 8: give every XCD one contiguous band of tiles (gridDim.x is a multiple of 8)
     const int per = (gridDim.x >> 3) * 4;
-    const int g = (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + wave;
+    const int tid = (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + wave;
     int32_t fin = 0;
     int npend = 0;
-    if (g < groups_total) sweep_group<LISTED>(A, L[wave], pass, tiles_x, tiles_y, g, 0xFu, lane, tile_done, fin, N, s_pend[wave], npend, TILE_PEND);
-    // the counter of finished cells and the counter of the next pass's list are single addresses: a quarter of a
+    if (tid < tiles_total && !tile_done[tid])
+        sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend);
+    // the counter of finished cells and the counter of the next pass's tile list are single addresses: a quarter of a
     // million tile runs per pass adding to them one by one keep their L2 channel busy for ~10 ns each -- one add per
     // workgroup for either
     if (lane == 0) { s_fin[wave] = fin; s_np[wave] = npend; }
@@ -1032,31 +942,34 @@ __global__ __launch_bounds__(256, 8) void k_sweep_tiles(SweepArgs A, uint32_t pa
     }
 }
 
-// later passes: only the listed groups (those with a tile a finished cell of the previous pass drains into); of a group
-// the tiles that carry this pass's stamp are visited first; lists the groups of the next pass
-__global__ __launch_bounds__(256, 6) void k_sweep_tiles_listed(SweepArgs A, uint32_t pass, int tiles_x, int tiles_y, const int32_t *__restrict__ list_in,
+// later passes: only the listed tiles (those a finished cell of the previous pass drains into); lists the next ones
+__global__ __launch_bounds__(256, 6) void k_sweep_tiles_listed(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
                                                             const int32_t *n_in, uint8_t *__restrict__ tile_done, int32_t *n_final,
                                                             TileNext N, int32_t *clear_count)
 {
     __shared__ TileW L[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int32_t ng = *n_in;
+    const int32_t nt = *n_in;
     if (blockIdx.x == 0 && threadIdx.x == 0) *clear_count = 0;      // the list of the pass after the next one
+    // (the tile id is the same for the whole wavefront: as a scalar it keeps the tile's coordinates and every address
+    // derived from them out of the vector registers)
     __shared__ int32_t s_pend[4][TILE_PEND];
     int32_t fin = 0;               // finished cells of all tiles of this wavefront: one add at the end
-    int npend = 0;                 // groups woken by this wavefront's visits that are not on the global list yet
-    const int32_t *fl = N.flag + (size_t)(pass & 1u) * N.flag_stride;
-    for (int32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); k < ng; k += gridDim.x * 4) {
-        const int g = __builtin_amdgcn_readfirstlane(list_in[k]);
-        const int ty0 = (g / N.groups_x) * 2, tx0 = (g % N.groups_x) * 2;
-        uint32_t todo = 0;
-        for (int w = 0; w < 4; w++) {
-            const int ty = ty0 + (w >> 1), tx = tx0 + (w & 1);
-            if (ty < tiles_y && tx < tiles_x && fl[ty * tiles_x + tx] == (int32_t)pass) todo |= 1u << w;
-        }
-        sweep_group<true>(A, L[wave], pass, tiles_x, tiles_y, g, todo, lane, tile_done, fin, N, s_pend[wave], npend, TILE_PEND);
+    int npend = 0;                 // tiles woken by this wavefront's visits that are not on the global list yet
+    auto flush = [&]() {
+        tile_wave_sync();
+        int32_t base = 0;
+        if (lane == 0) base = atomicAdd(N.count, npend);
+        base = __shfl(base, 0);
+        if (lane < npend) N.list[base + lane] = s_pend[wave][lane];
+        npend = 0;
+        tile_wave_sync();
+    };
+    for (int32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); k < nt; k += gridDim.x * 4) {
+        sweep_one_tile<true>(A, L[wave], pass, tiles_x, __builtin_amdgcn_readfirstlane(list_in[k]), lane, tile_done, fin, N, s_pend[wave], npend);
+        if (npend > TILE_PEND - 10) flush();            // (a visit adds at most ten)
     }
-    if (npend) pend_flush(N, s_pend[wave], npend, lane);
+    if (npend) flush();
     if (lane == 0 && fin) atomicAdd(n_final, fin);
 }
 
@@ -1203,7 +1116,7 @@ __global__ __launch_bounds__(256) void k_sweep_first(SweepArgs A, int tiles_x, i
         done |= 1u << k;
         const int64_t c = (int64_t)(i0 + 8 * k + r0) * m + gj;
         A.contrib[c] = L.slot[t + 256 * k];
-        A.cinfo[c] = ci_with_level(word >> 16, (uint32_t)A.lv_scale);
+        A.cinfo[c] = ci_with_level(word >> 16, 1u);
         if (word & FC_TODO) A.todo_work[c] = 1;
     }
     const int32_t finalized = __popc(done), n_cells = __popc(ingrid);
@@ -1220,14 +1133,10 @@ __global__ __launch_bounds__(256) void k_sweep_first(SweepArgs A, int tiles_x, i
 __global__ void k_tiles_of_frontier(const QE *__restrict__ q, const int32_t *nq, int m, int tiles_x, int32_t stamp, TileNext N)
 {
     const int32_t n = *nq;
-    int32_t *fl = N.flag + (size_t)(stamp & 1) * N.flag_stride;
     for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const int32_t c = q[k].c;
-        const int ty = c / m / TT, tx = (c % m) / TT;
-        if (atomicExch(&fl[ty * tiles_x + tx], stamp) != stamp) {
-            const int g = (ty >> 1) * N.groups_x + (tx >> 1);
-            if (atomicExch(&N.gflag[g], stamp) != stamp) N.list[atomicAdd(N.count, 1)] = g;
-        }
+        const int tt = (c / m / TT) * tiles_x + (c % m) / TT;
+        if (atomicExch(&N.flag[tt], stamp) != stamp) N.list[atomicAdd(N.count, 1)] = tt;
     }
 }
 
@@ -2479,7 +2388,6 @@ static void fill_sweep_args(pydem_tile *t, SweepArgs &A)
     A.pin_dst = t->pits.in_dst; A.pin_src = t->pits.in_src; A.pin_w = t->pits.in_w;
     A.qcap = (int32_t)(t->NN / 2 < INT32_MAX ? t->NN / 2 : INT32_MAX);      // queue buffers hold NN ints = NN/2 entries
     A.err = t->counters + 15;
-    A.lv_scale = 1; A.max_sub = 4;          // (queue schedule: plain pass numbers, every tile of a group visited once)
     { const char *e = getenv("PYDEM_TILE_DEBUG"); A.dbg = e ? atoi(e) : 0; }
 }
 
@@ -2502,11 +2410,10 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     if (A.n_pit > 0)   // the unused area slots of pit sources / drains carry their edge-list offsets until they are processed
         hipLaunchKernelGGL(k_pit_stash, dim3(grid_for(A.n_pit, 2048)), dim3(256), 0, t->stream, A.pin_dst, A.pit_src, A.n_pit, t->uca);
     // ---- tile-local passes until they stop paying, then the queue rounds take over
-    const int tiles_x = (int)cdiv(m, TT), tiles_y = (int)cdiv(n, TT), tiles_total = tiles_x * tiles_y;
-    const int groups_x = (tiles_x + 1) / 2, groups_total = groups_x * ((tiles_y + 1) / 2);      // 2 x 2 tiles: one workgroup
-    // scratch: tile_done bytes | per-tile "listed for pass" stamps (two slots) | per-group stamps | two group lists
+    const int tiles_x = (int)cdiv(m, TT), tiles_total = tiles_x * (int)cdiv(n, TT);
+    // scratch: tile_done bytes | per-tile "listed for pass" stamps | two tile lists
     const size_t tiles_pad = ((size_t)tiles_total + 255) & ~(size_t)255;
-    const size_t scratch_need = tiles_pad * (1 + 4 * 5);
+    const size_t scratch_need = tiles_pad * (1 + 4 + 4 + 4);
     if (t->scratch_bytes < scratch_need) {
         if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->device_bytes -= (int64_t)t->scratch_bytes; }
         HIP_TRY(hipMalloc(&t->scratch, scratch_need));
@@ -2514,15 +2421,9 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     }
     uint8_t *tile_done = (uint8_t *)t->scratch;
     int32_t *tile_flag = (int32_t *)(tile_done + tiles_pad);
-    int32_t *group_flag = tile_flag + 2 * tiles_pad;
-    int32_t *tile_list[2] = {tile_flag + 3 * tiles_pad, tile_flag + 4 * tiles_pad};
-    auto tile_next = [&](int32_t *list, int32_t *count) {
-        TileNext N;
-        N.flag = tile_flag; N.gflag = group_flag; N.list = list; N.count = count; N.flag_stride = (int32_t)tiles_pad; N.groups_x = groups_x;
-        return N;
-    };
+    int32_t *tile_list[2] = {tile_flag + tiles_pad, tile_flag + 2 * tiles_pad};
     int32_t *cntT = t->counters + 56;          // rotating tile-list sizes
-    HIP_TRY(hipMemsetAsync(tile_done, 0, tiles_pad * 13, t->stream));     // done bytes + tile and group stamps
+    HIP_TRY(hipMemsetAsync(tile_done, 0, tiles_pad * 5, t->stream));      // done bytes + stamps
     HIP_TRY(hipMemsetAsync(cntT, 0, 4 * sizeof(int32_t), t->stream));
     if (A.dbg & 4) HIP_TRY(hipMemsetAsync(t->counters + 32, 0, 24 * sizeof(int32_t), t->stream));
     int64_t launches = 0;
@@ -2531,22 +2432,24 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     static int lds_pad = -1;        // occupancy experiments only: extra dynamic LDS per workgroup (PYDEM_TILE_LDS_PAD)
     if (lds_pad < 0) { const char *e = getenv("PYDEM_TILE_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
     // listed tile passes from pass p on (the list of pass p is in tile_list[p % 2] / cntT[p % 3]); returns the next pass number
-    auto run_listed = [&](int p, int64_t ngroups) -> int {
-        while (ngroups > 0) {
-            const int batch = ngroups < 2048 ? 16 : 8;   // passes between two looks at the list size (a look idles the GPU for ~30 us; the grid only shrinks below 8192 listed groups)
-            const int grid = (int)(ngroups < 8192 ? (ngroups > 64 ? ngroups : 64) : 8192);
+    auto run_listed = [&](int p, int64_t ntiles) -> int {
+        TileNext N;
+        N.flag = tile_flag;
+        while (ntiles > 0) {
+            const int batch = ntiles < 2048 ? 16 : 8;    // passes between two looks at the list size (a look idles the GPU for ~30 us; the grid only shrinks below 8192 listed tiles)
+            const int grid = (int)(ntiles < 8192 ? (ntiles > 64 ? ntiles : 64) : 8192);
             for (int b = 0; b < batch; b++, p++) {
-                const TileNext N = tile_next(tile_list[(p + 1) % 2], &cntT[(p + 1) % 3]);
-                hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), (size_t)lds_pad, t->stream, A, (uint32_t)p, tiles_x, tiles_y,
+                N.list = tile_list[(p + 1) % 2]; N.count = &cntT[(p + 1) % 3];
+                hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), (size_t)lds_pad, t->stream, A, (uint32_t)p, tiles_x,
                                    (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
                                    &cntT[(p + 2) % 3]);
                 launches++;
             }
             if (hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream) != hipSuccess) return -1;
             if (hipStreamSynchronize(t->stream) != hipSuccess) return -1;
-            ngroups = t->h_counters[56 + p % 3];
-            if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "listed tile pass %d: %lld groups listed next, processed %d\n", p, (long long)ngroups, t->h_counters[3]);
-            if ((int64_t)(p + 2) * A.lv_scale + A.max_sub > (int64_t)CI_LEVEL_INF - 256) return -2;
+            ntiles = t->h_counters[56 + p % 3];
+            if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "listed tile pass %d: %lld tiles listed next, processed %d\n", p, (long long)ntiles, t->h_counters[3]);
+            if (p > (int)CI_LEVEL_INF - 256) return -2;
         }
         return p;
     };
@@ -2587,7 +2490,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
             HIP_TRY(hipMemcpyAsync(U, hu.data(), hu.size() * sizeof(ReseedCell), hipMemcpyHostToDevice, t->stream));
             hipLaunchKernelGGL(k_reseed_replay, dim3(1), dim3(64), 0, t->stream, A, (const ReseedCell *)U, (int32_t)unfinished,
                                (const double *)t->elev, (const double *)t->pits.w, stf, stf + unfinished, t->h_counters[61],
-                               (int)opt->circular_ref_maxcount, pass * (uint32_t)A.lv_scale, total, rc + 2);
+                               (int)opt->circular_ref_maxcount, pass, total, rc + 2);
             launches += 2;
             HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
@@ -2597,12 +2500,8 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     };
     static int sweep_mode = -1;     // 0: tile passes only (default), 1: tile pass + queue rounds + listed tail
     if (sweep_mode < 0) { const char *e = getenv("PYDEM_SWEEP_MODE"); sweep_mode = (e && !strcmp(e, "queue")) ? 1 : 0; }
-    const unsigned full_grid = (unsigned)(((groups_total + 31) / 32) * 8);      // four groups (wavefronts) per workgroup
+    const unsigned full_grid = (unsigned)(((tiles_total + 31) / 32) * 8);
     if (sweep_mode == 0) {
-        // visits per launch of the wavefront that owns a 2 x 2 group of tiles (PYDEM_SWEEP_VISITS, 4..16; its four tiles, then woken siblings)
-        static int max_sub = -1;
-        if (max_sub < 0) { const char *e = getenv("PYDEM_SWEEP_VISITS"); max_sub = e ? atoi(e) : 8; if (max_sub < 4) max_sub = 4; if (max_sub > 16) max_sub = 16; }
-        A.lv_scale = 16; A.max_sub = max_sub;
         // pass 1 over every tile, pass 2 over every tile that is not done (it also lists the tiles of pass 3),
         // then only the listed tiles until no tile is listed any more
         // PYDEM_SWEEP_FIRST=lds: pass 1 by the LDS-resident kernel (K5a).  Measured at 16384^2: 9.9 ms against 7.8 ms of the
@@ -2613,18 +2512,18 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         if (first_kind == 1)
             hipLaunchKernelGGL(k_sweep_first, dim3((unsigned)(((tiles_total + 7) / 8) * 8)), dim3(256), 0, t->stream, A, tiles_x, tiles_total, tile_done, total);
         else {
-            const TileNext N0 = tile_next(nullptr, nullptr);
-            hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, 1u, tiles_x, tiles_y, tile_done, total, N0);
+            TileNext N0; N0.flag = nullptr; N0.list = nullptr; N0.count = nullptr;
+            hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, 1u, tiles_x, tiles_total, tile_done, total, N0);
         }
-        const TileNext N = tile_next(tile_list[3 % 2], &cntT[3 % 3]);
-        hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, 2u, tiles_x, tiles_y, tile_done, total, N);
+        TileNext N; N.flag = tile_flag; N.list = tile_list[3 % 2]; N.count = &cntT[3 % 3];
+        hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, 2u, tiles_x, tiles_total, tile_done, total, N);
         launches += 2;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
-        if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "tile passes 1-2: %d cells of %lld, %d groups listed\n", t->h_counters[3], (long long)t->NN, t->h_counters[56]);
+        if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "tile passes 1-2: %d cells of %lld, %d tiles listed\n", t->h_counters[3], (long long)t->NN, t->h_counters[56]);
         const int p_end = run_listed(3, t->h_counters[56 + 3 % 3]);
         if (p_end == -1) { pydem_set_error("HIP error in the listed tile passes"); return -4; }
-        if (p_end == -2) { pydem_set_error("flow paths longer than %u passes are not supported", CI_LEVEL_INF / 16); return -5; }
+        if (p_end == -2) { pydem_set_error("flow paths longer than %u passes are not supported", CI_LEVEL_INF); return -5; }
         pass = (uint32_t)p_end;
         t->tm.sweep_tile_passes = (int64_t)pass;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
@@ -2643,8 +2542,8 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     if (max_passes < 0) { const char *e = getenv("PYDEM_TILE_PASSES"); max_passes = e ? atoi(e) : 1; if (max_passes < 1) max_passes = 1; }
     for (;;) {
         pass++;
-        { const TileNext N0 = tile_next(nullptr, nullptr);
-          hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), 0, t->stream, A, pass, tiles_x, tiles_y, tile_done, total, N0); }
+        { TileNext N0; N0.flag = nullptr; N0.list = nullptr; N0.count = nullptr;
+          hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), 0, t->stream, A, pass, tiles_x, tiles_total, tile_done, total, N0); }
         launches++;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
@@ -2676,27 +2575,26 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
             // ---- the rivers: listed tile passes.  A queue round moves every river by ONE cell per kernel
             // boundary; a listed pass moves it through a whole tile (the on-chip rounds) for the same boundary.
             int p = r;
-            {
-                const TileNext N = tile_next(tile_list[p % 2], &cntT[p % 3]);
-                hipLaunchKernelGGL(k_tiles_of_frontier, dim3(grid_for(last, 256)), dim3(256), 0, t->stream, (const QE *)t->queue[r % 2],
-                                   (const int32_t *)&cnt3[r % 3], m, tiles_x, (int32_t)p, N);
-            }
+            TileNext N;
+            N.flag = tile_flag; N.list = tile_list[p % 2]; N.count = &cntT[p % 3];
+            hipLaunchKernelGGL(k_tiles_of_frontier, dim3(grid_for(last, 256)), dim3(256), 0, t->stream, (const QE *)t->queue[r % 2],
+                               (const int32_t *)&cnt3[r % 3], m, tiles_x, (int32_t)p, N);
             launches++;
-            int64_t ngroups = last;     // upper bound for the first batch
-            while (ngroups > 0) {
+            int64_t ntiles = last;      // upper bound for the first batch
+            while (ntiles > 0) {
                 const int batch = 8;
-                const int grid = (int)(ngroups < 2048 ? (ngroups > 64 ? ngroups : 64) : 2048);
+                const int grid = (int)(ntiles * 2 < 2048 ? (ntiles * 2 > 64 ? ntiles * 2 : 64) : 2048);
                 for (int b = 0; b < batch; b++, p++) {
-                    const TileNext N = tile_next(tile_list[(p + 1) % 2], &cntT[(p + 1) % 3]);
-                    hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), 0, t->stream, A, (uint32_t)p, tiles_x, tiles_y,
+                    N.list = tile_list[(p + 1) % 2]; N.count = &cntT[(p + 1) % 3];
+                    hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), 0, t->stream, A, (uint32_t)p, tiles_x,
                                        (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
                                        &cntT[(p + 2) % 3]);
                     launches++;
                 }
                 HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
                 HIP_TRY(hipStreamSynchronize(t->stream));
-                ngroups = t->h_counters[56 + p % 3];
-                if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "listed tile pass %d: %lld groups listed next, processed %d\n", p, (long long)ngroups, t->h_counters[3]);
+                ntiles = t->h_counters[56 + p % 3];
+                if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "listed tile pass %d: %lld tiles listed next, processed %d\n", p, (long long)ntiles, t->h_counters[3]);
                 if (p > (int)CI_LEVEL_INF - 256) { pydem_set_error("flow paths longer than %u passes are not supported", CI_LEVEL_INF); return -5; }
             }
             t->tm.sweep_tile_passes += p - r;
