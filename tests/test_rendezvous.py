@@ -1,0 +1,52 @@
+"""pydem_amd.rendezvous: the framework-free process group (stream sockets around rank 0) that hands the RCCL id around and
+carries the host fallback of the edge exchange.  Three ranks started by spawn_ranks (what bench.py --gpus N does without a
+launcher): every collective on every rank."""
+import os
+import sys
+
+from conftest import ROOT
+
+CHILD = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from pydem_amd.rendezvous import SocketGroup
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+g = SocketGroup(rank, world)
+parts = g.all_gather_object({'rank': rank, 'blob': b'x' * (1000 * (rank + 1))})
+assert [p['rank'] for p in parts] == list(range(world)) and [len(p['blob']) for p in parts] == [1000 * (r + 1) for r in range(world)]
+uid = g.broadcast_object(bytes(range(128)) if rank == 0 else None, src=0)
+assert uid == bytes(range(128))
+assert g.broadcast_object('from-2' if rank == 2 else None, src=2) == 'from-2'
+assert g.allreduce_max(10.0 + rank) == 10.0 + world - 1
+a = np.full(5000, float(rank + 1)); a[rank] = np.nan if rank == 1 else a[rank]
+g.sum_inplace(a)
+want = np.full(5000, float(sum(range(1, world + 1)))); want[1] = np.nan
+assert np.array_equal(a, want, equal_nan=True)
+for _ in range(20):
+    g.barrier()
+g.close()
+print('rank %%d fine' %% rank)
+'''
+
+
+def test_socket_group_collectives():
+    from pydem_amd.rendezvous import spawn_ranks
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    rc, out = spawn_ranks([sys.executable, '-c', CHILD % {'root': ROOT}], 3, env=env, master_port=28000 + os.getpid() % 1000, capture=True, timeout=120)
+    assert rc == 0 and out.count(' fine') == 3, out[-2000:]
+
+
+def test_socket_group_over_tcp():
+    from pydem_amd.rendezvous import spawn_ranks
+    port = 28100 + os.getpid() % 800
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', PYDEM_RDZV='tcp://127.0.0.1:%d' % port)
+    rc, out = spawn_ranks([sys.executable, '-c', CHILD % {'root': ROOT}], 3, env=env, master_port=port, capture=True, timeout=120)
+    assert rc == 0 and out.count(' fine') == 3, out[-2000:]
+
+
+def test_single_rank_group_is_a_no_op():
+    from pydem_amd.rendezvous import SocketGroup
+    g = SocketGroup(0, 1)
+    assert g.all_gather_object(7) == [7] and g.broadcast_object('x') == 'x' and g.allreduce_max(3) == 3.0
+    g.barrier(); g.close()
