@@ -95,6 +95,11 @@ int pydem_hip_device_name(int device, char *buf, int buflen);
  * check of the test suite (no counterpart in the reference, whose tiles live in host memory). */
 int pydem_hip_device_memory(int device, int64_t *free_bytes, int64_t *total_bytes);
 
+/* The conditioning stages (pydem_fill_flats, pydem_pit_candidates_read, pydem_pit_paths) lease one scratch arena per device
+ * for the duration of a call (it grows to the largest request seen: ~6 GB + up to 17 GB for the large-window simulations
+ * of a 8192 x 8192 tile); this returns every arena to the driver.  No counterpart in the reference (host arrays). */
+int pydem_hip_release_scratch(void);
+
 int pydem_tile_create(int64_t n_rows, int64_t n_cols, int device, pydem_tile **out);
 int pydem_tile_destroy(pydem_tile *t);
 /* dX, dY: n_rows-1 values; dX2, dY2: n_rows values (DEMProcessor.__init__ :229-258) */

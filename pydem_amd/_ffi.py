@@ -50,6 +50,7 @@ SYMBOLS = {
     'pydem_hip_last_error': (C.c_char_p, []),
     'pydem_hip_device_count': (C.c_int, [C.POINTER(C.c_int)]),
     'pydem_hip_device_memory': (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    'pydem_hip_release_scratch': (C.c_int, []),
     'pydem_hip_device_name': (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     'pydem_tile_create': (C.c_int, [C.c_int64, C.c_int64, C.c_int, _PP]),
     'pydem_tile_destroy': (C.c_int, [_P]),
@@ -138,6 +139,11 @@ def device_count():
     n = C.c_int(0)
     check(load().pydem_hip_device_count(C.byref(n)))
     return n.value
+
+
+def release_scratch():
+    """Return the per-device scratch arenas of the conditioning stages to the driver."""
+    check(load().pydem_hip_release_scratch())
 
 
 def device_memory(device=0):

@@ -660,9 +660,10 @@ __global__ void k_roots(CondArgs A, int32_t *root_of)
 
 int grid_of(int64_t work, int cap) { const int64_t g = cdiv(work, 256); return (int)(g < cap ? (g > 0 ? g : 1) : cap); }
 
-struct Scratch {
+struct Scratch {            // the region records: one block of the device's conditioning arena, leased for the call
+    ArenaLease lease;
     void *p = nullptr;
-    ~Scratch() { if (p) (void)hipFree(p); }
+    int device = 0;
 };
 
 // carve the region records out of one allocation
@@ -670,7 +671,9 @@ int alloc_regions(Scratch &S, Regions &R, int32_t **root_of, int32_t **alist0, i
 {
     const size_t n4 = (size_t)nf * 4, n8 = (size_t)nf * 8;
     const size_t total = 15 * n4 + 5 * n8 + 256;
-    HIP_TRY(hipMalloc(&S.p, total));
+    if (!S.lease.held) PYDEM_TRY(arena_acquire(S.device, &S.lease));
+    S.p = arena_take(&S.lease, total);
+    if (!S.p) return -1;
     char *p = (char *)S.p;
     auto take4 = [&]() { int32_t *q = (int32_t *)p; p += n4; return q; };
     auto take8 = [&]() { unsigned long long *q = (unsigned long long *)p; p += n8; return q; };
@@ -732,7 +735,7 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
         if (t->h_counters[8] > 0) return 1;
         PYDEM_TRY(label_regions(t, A, &nf, &nreg));
         if (nf > 0) {
-            Scratch S; Regions R; int32_t *root_of, *al0, *al1;
+            Scratch S; S.device = t->device; Regions R; int32_t *root_of, *al0, *al1;
             PYDEM_TRY(alloc_regions(S, R, &root_of, &al0, &al1, nf));
             const int g1 = grid_of(nf, 2048), gr = grid_of(nreg, 2048);
             hipLaunchKernelGGL(k_region_init, dim3(gr), dim3(256), 0, t->stream, R, nreg, n, m);
@@ -759,7 +762,7 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
     if (t->h_counters[8] > 0) return 1;
     PYDEM_TRY(label_regions(t, A, &nf, &nreg));
     if (nf > 0) {
-        Scratch S; Regions R; int32_t *root_of, *al0, *al1;
+        Scratch S; S.device = t->device; Regions R; int32_t *root_of, *al0, *al1;
         PYDEM_TRY(alloc_regions(S, R, &root_of, &al0, &al1, nf));
         const int g1 = grid_of(nf, 2048), gr = grid_of(nreg, 2048);
         double *dh[2] = {t->mag, t->dir}, *dl[2] = {t->uca, t->twi};

@@ -26,6 +26,7 @@
 // metric reach, np.sum's pairwise order for the dY sums, np.linspace) follows the host implementation line by line.
 #include "internal.h"
 #include <math.h>
+#include <string.h>
 #include <algorithm>
 #include <time.h>
 
@@ -484,10 +485,10 @@ __global__ void k_gather_f64(const double *__restrict__ e, const int32_t *__rest
 
 #include "ccl.h"
 
+// a buffer carved out of the device's conditioning arena for the duration of the call (internal.h: ArenaLease)
 struct Buf {
     void *p = nullptr;
-    ~Buf() { if (p) (void)hipFree(p); }
-    int get(size_t bytes) { if (p) { (void)hipFree(p); p = nullptr; } HIP_TRY(hipMalloc(&p, bytes ? bytes : 8)); return 0; }
+    int get(ArenaLease &L, size_t bytes) { p = arena_take(&L, bytes ? bytes : 8); return p ? 0 : -1; }
 };
 
 int gridp(int64_t work, int cap) { const int64_t g = cdiv(work, 256); return (int)(g < cap ? (g > 0 ? g : 1) : cap); }
@@ -516,17 +517,26 @@ int stage_pit_candidates(pydem_tile *t, int below_sea, int64_t *npits)
 int stage_pit_candidates_read(pydem_tile *t, int64_t npits, int32_t *cells, double *elev)
 {
     if (npits <= 0) return 0;
+    ArenaLease lease;
+    PYDEM_TRY(arena_acquire(t->device, &lease));
     Buf tmp;
-    PYDEM_TRY(tmp.get((size_t)npits * 8));
-    // (the compaction emits blocks out of order: sort the ids on the host side of this call)
-    HIP_TRY(hipMemcpyAsync(cells, t->flatlist, (size_t)npits * 4, hipMemcpyDeviceToHost, t->stream));
+    PYDEM_TRY(tmp.get(lease, (size_t)npits * 8));
+    // (the compaction emits blocks out of order: sort the ids on the host side of this call; transfers through the tile's pinned
+    // staging buffer, never straight from / to the caller's pageable arrays)
+    void *pin = nullptr;
+    PYDEM_TRY(tile_pinned(t, (size_t)npits * 8, &pin));
+    HIP_TRY(hipMemcpyAsync(pin, t->flatlist, (size_t)npits * 4, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
+    memcpy(cells, pin, (size_t)npits * 4);
     std::sort(cells, cells + npits);
-    HIP_TRY(hipMemcpyAsync(t->flatlist, cells, (size_t)npits * 4, hipMemcpyHostToDevice, t->stream));
+    memcpy(pin, cells, (size_t)npits * 4);
+    HIP_TRY(hipMemcpyAsync(t->flatlist, pin, (size_t)npits * 4, hipMemcpyHostToDevice, t->stream));
     hipLaunchKernelGGL(k_gather_f64, dim3(gridp(npits, 2048)), dim3(256), 0, t->stream, t->elev, t->flatlist, (int32_t)npits, (double *)tmp.p);
-    HIP_TRY(hipMemcpyAsync(elev, tmp.p, (size_t)npits * 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));           // (the staging buffer is free again before the elevations land in it)
+    HIP_TRY(hipMemcpyAsync(pin, tmp.p, (size_t)npits * 8, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(t->stream));
+    memcpy(elev, pin, (size_t)npits * 8);
     return 0;
 }
 
@@ -552,20 +562,27 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     const int FCAP = STCAP + SRCAP, CCAP = STCAP + 1;
     const int64_t BIGF = std::min<int64_t>((int64_t)BWIN * BWIN, t->NN);   // footprint / trail capacity of a large-window simulation
     if ((int64_t)big_max > npits) big_max = (int)npits;
+    ArenaLease lease;
+    PYDEM_TRY(arena_acquire(t->device, &lease));
     Buf b_bown, b_rstamp, b_tent;
     Buf b_order, b_window, b_rown, b_wown, b_stamp, b_status, b_nF, b_nC, b_iters, b_F, b_C, b_CV, b_flags, b_done, b_counts, b_slots,
         b_backup, b_bigtrail, b_bigF, b_bigC, b_bigCV, b_Fp, b_Cp, b_CVp, b_fcap, b_ccap;
-    PYDEM_TRY(b_order.get((size_t)npits * 4)); PYDEM_TRY(b_window.get((size_t)W * 4));
-    PYDEM_TRY(b_rown.get((size_t)t->NN * 4)); PYDEM_TRY(b_wown.get((size_t)t->NN * 4)); PYDEM_TRY(b_stamp.get((size_t)t->NN * 4));
-    PYDEM_TRY(b_bown.get((size_t)t->NN * 4)); PYDEM_TRY(b_rstamp.get((size_t)t->NN * 4)); PYDEM_TRY(b_tent.get((size_t)W * 4));
-    PYDEM_TRY(b_status.get((size_t)W * 4)); PYDEM_TRY(b_nF.get((size_t)W * 4)); PYDEM_TRY(b_nC.get((size_t)W * 4)); PYDEM_TRY(b_iters.get((size_t)W * 4));
-    PYDEM_TRY(b_F.get((size_t)W * FCAP * 4)); PYDEM_TRY(b_C.get((size_t)W * CCAP * 4)); PYDEM_TRY(b_CV.get((size_t)W * CCAP * 8));
-    PYDEM_TRY(b_Fp.get((size_t)W * 8)); PYDEM_TRY(b_Cp.get((size_t)W * 8)); PYDEM_TRY(b_CVp.get((size_t)W * 8));
-    PYDEM_TRY(b_fcap.get((size_t)W * 4)); PYDEM_TRY(b_ccap.get((size_t)W * 4));
-    PYDEM_TRY(b_flags.get(16)); PYDEM_TRY(b_done.get((size_t)W * 4)); PYDEM_TRY(b_counts.get(16)); PYDEM_TRY(b_slots.get((size_t)W * 4));
-    PYDEM_TRY(b_backup.get((size_t)t->NN * 8));
+    PYDEM_TRY(b_order.get(lease, (size_t)npits * 4)); PYDEM_TRY(b_window.get(lease, (size_t)W * 4));
+    PYDEM_TRY(b_rown.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_wown.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_stamp.get(lease, (size_t)t->NN * 4));
+    PYDEM_TRY(b_bown.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_rstamp.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_tent.get(lease, (size_t)W * 4));
+    PYDEM_TRY(b_status.get(lease, (size_t)W * 4)); PYDEM_TRY(b_nF.get(lease, (size_t)W * 4)); PYDEM_TRY(b_nC.get(lease, (size_t)W * 4)); PYDEM_TRY(b_iters.get(lease, (size_t)W * 4));
+    PYDEM_TRY(b_F.get(lease, (size_t)W * FCAP * 4)); PYDEM_TRY(b_C.get(lease, (size_t)W * CCAP * 4)); PYDEM_TRY(b_CV.get(lease, (size_t)W * CCAP * 8));
+    PYDEM_TRY(b_Fp.get(lease, (size_t)W * 8)); PYDEM_TRY(b_Cp.get(lease, (size_t)W * 8)); PYDEM_TRY(b_CVp.get(lease, (size_t)W * 8));
+    PYDEM_TRY(b_fcap.get(lease, (size_t)W * 4)); PYDEM_TRY(b_ccap.get(lease, (size_t)W * 4));
+    PYDEM_TRY(b_flags.get(lease, 16)); PYDEM_TRY(b_done.get(lease, (size_t)W * 4)); PYDEM_TRY(b_counts.get(lease, 16)); PYDEM_TRY(b_slots.get(lease, (size_t)W * 4));
+    PYDEM_TRY(b_backup.get(lease, (size_t)t->NN * 8));
     HIP_TRY(hipMemcpyAsync(b_backup.p, t->elev, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
-    HIP_TRY(hipMemcpyAsync(b_order.p, order_host, (size_t)npits * 4, hipMemcpyHostToDevice, t->stream));
+    // pinned staging: [order | window | status | done | big slots]
+    void *pin_v = nullptr;
+    PYDEM_TRY(tile_pinned(t, ((size_t)npits + 4 * (size_t)W + 64) * 4, &pin_v));
+    int32_t *pin_order = (int32_t *)pin_v, *pin_window = pin_order + npits, *pin_status = pin_window + W, *pin_done = pin_status + W, *pin_slots = pin_done + W;
+    memcpy(pin_order, order_host, (size_t)npits * 4);
+    HIP_TRY(hipMemcpyAsync(b_order.p, pin_order, (size_t)npits * 4, hipMemcpyHostToDevice, t->stream));
     const int gN = gridp(t->NN, 8192);
     hipLaunchKernelGGL(k_fill_i32, dim3(gN), dim3(256), 0, t->stream, (int32_t *)b_rown.p, t->NN, 0x7FFFFFFF);
     hipLaunchKernelGGL(k_fill_i32, dim3(gN), dim3(256), 0, t->stream, (int32_t *)b_wown.p, t->NN, 0x7FFFFFFF);
@@ -605,15 +622,17 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
                 if (known_big[(size_t)pending[(size_t)s2]] && ++seen_big > big_max) { nw = s2; break; }
         }
         A.nw = nw;
-        HIP_TRY(hipMemcpyAsync(b_window.p, pending.data(), (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
+        memcpy(pin_window, pending.data(), (size_t)nw * 4);
+        HIP_TRY(hipMemcpyAsync(b_window.p, pin_window, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemsetAsync(b_done.p, 0, (size_t)nw * 4, t->stream));
         const double t_a = now_ms();
         small_runs += nw;
         hipLaunchKernelGGL(k_paths_slots, dim3(gridp(nw, 256)), dim3(256), 0, t->stream, A, (int32_t *)b_F.p, (int32_t *)b_C.p, (double *)b_CV.p, FCAP, CCAP);
         hipLaunchKernelGGL(k_paths_small, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A, nw);
-        HIP_TRY(hipMemcpyAsync(h_status.data(), b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(pin_status, b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(t->stream));
+        memcpy(h_status.data(), pin_status, (size_t)nw * 4);
         const double t_b = now_ms();
         ms_small += t_b - t_a;
         big.clear();
@@ -623,16 +642,17 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
             // as many large-window simulations as one launch holds take part in this round; the first one left out
             // closes the round for everybody after it: a pit commits only when every earlier pending pit was simulated
             if (!big_ready) {
-                PYDEM_TRY(b_bigtrail.get((size_t)big_max * BIGF * 4));
-                PYDEM_TRY(b_bigF.get((size_t)big_max * BIGF * 4));
-                PYDEM_TRY(b_bigC.get((size_t)big_max * (BIGF + 1) * 4));
-                PYDEM_TRY(b_bigCV.get((size_t)big_max * (BIGF + 1) * 8));
+                PYDEM_TRY(b_bigtrail.get(lease, (size_t)big_max * BIGF * 4));
+                PYDEM_TRY(b_bigF.get(lease, (size_t)big_max * BIGF * 4));
+                PYDEM_TRY(b_bigC.get(lease, (size_t)big_max * (BIGF + 1) * 4));
+                PYDEM_TRY(b_bigCV.get(lease, (size_t)big_max * (BIGF + 1) * 8));
                 HIP_TRY(hipFuncSetAttribute((const void *)k_paths_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
                 big_ready = true;
             }
             if ((int)big.size() > big_max) { k_limit = pending[(size_t)big[(size_t)big_max]]; big.resize((size_t)big_max); }
             const int nb = (int)big.size();
-            HIP_TRY(hipMemcpyAsync(b_slots.p, big.data(), (size_t)nb * 4, hipMemcpyHostToDevice, t->stream));
+            memcpy(pin_slots, big.data(), (size_t)nb * 4);
+            HIP_TRY(hipMemcpyAsync(b_slots.p, pin_slots, (size_t)nb * 4, hipMemcpyHostToDevice, t->stream));
             hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nb, 64)), dim3(256), 0, t->stream, A, (const int32_t *)b_slots.p, nb, (int32_t *)b_bigF.p,
                                (int32_t *)b_bigC.p, (double *)b_bigCV.p, BIGF, BIGF + 1);
             hipLaunchKernelGGL(k_paths_big, dim3(nb), dim3(64), big_lds, t->stream, A, (const int32_t *)b_slots.p, nb, (int32_t *)b_bigtrail.p, BIGF);
@@ -645,11 +665,13 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         hipLaunchKernelGGL(k_paths_blocked, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A);
         hipLaunchKernelGGL(k_paths_commit, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A, (int32_t *)b_done.p, (int32_t *)b_counts.p);
         hipLaunchKernelGGL(k_paths_release, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A);
-        HIP_TRY(hipMemcpyAsync(h_done.data(), b_done.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
-        HIP_TRY(hipMemcpyAsync(h_status.data(), b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(pin_done, b_done.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(pin_status, b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipMemcpyAsync(t->h_counters, b_flags.p, 16, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(t->stream));
+        memcpy(h_done.data(), pin_done, (size_t)nw * 4);
+        memcpy(h_status.data(), pin_status, (size_t)nw * 4);
         rounds++;
         ms_commit += now_ms() - t_c;
         if (getenv("PYDEM_PATHS_DEBUG") && atoi(getenv("PYDEM_PATHS_DEBUG")) >= 2) {

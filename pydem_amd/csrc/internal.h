@@ -91,6 +91,7 @@ struct pydem_tile {
     int64_t einc_round = 0;         // incremental edge rounds run on this tile so far (stamps of the NaN flood)
     bool einc_ready = false;        // incremental edge rounds: counts / deltas / FINAL flags are live (uca.hip K7i)
     double *h_strip_d = nullptr; uint8_t *h_strip_f = nullptr; size_t h_strip_cap = 0;   // pinned strip staging
+    void *h_stage = nullptr; size_t h_stage_bytes = 0;      // pinned host staging of the conditioning stages (tile_pinned)
     int32_t etodo_prev = 0;         // cells whose edge_done byte the previous round cleared (tlist = flatlist)
     double *line_stage = nullptr;   // max(n, m) doubles: staging for column get/set
     void *lines_stage = nullptr; int lines_cap = 0;   // staging for pydem_tile_get_lines
@@ -103,7 +104,26 @@ struct pydem_tile {
 template <typename T>
 int tile_alloc(pydem_tile *t, T **p, size_t count);
 
+// Scratch of the conditioning stages (region records of pydem_fill_flats, reservation planes / footprints / trails of
+// pydem_pit_paths: 6 GB + up to 17 GB for the large-window simulations of a 8192^2 tile).  Allocating and freeing that
+// per call costs hundreds of milliseconds in the driver, so every device keeps ONE arena that the stages lease for the
+// duration of a call (a mutex: conditioning stages of two tiles on one device run one after the other); it grows to the
+// largest request seen and is released by pydem_hip_release_scratch().
+struct ArenaLease {
+    int device = -1;
+    char *base = nullptr; size_t bytes = 0, off = 0, want = 0;
+    std::vector<void *> extra;          // what did not fit this time (plain allocations, freed when the lease ends)
+    bool held = false;
+    ~ArenaLease();
+};
+int arena_acquire(int device, ArenaLease *L);
+void *arena_take(ArenaLease *L, size_t bytes);       // 256-byte aligned; nullptr on allocation failure (error set)
+
 int ensure_fields(pydem_tile *t, std::initializer_list<int> fields);
+// pinned host memory of at least `bytes` that lives with the tile (grown on demand): every per-round transfer of the
+// conditioning stages goes through it -- asynchronous copies from / to pageable memory make the runtime pin and unpin
+// the pages behind the caller's back, and the NEXT GPU call then waits ~20 ms for that housekeeping
+int tile_pinned(pydem_tile *t, size_t bytes, void **out);
 
 // stage entry points implemented in the .hip files
 int stage_stencil(pydem_tile *t);

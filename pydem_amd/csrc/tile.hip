@@ -38,6 +38,58 @@ template int tile_alloc<int32_t>(pydem_tile *, int32_t **, size_t);
 template int tile_alloc<RowTab>(pydem_tile *, RowTab **, size_t);
 template int tile_alloc<uint16_t>(pydem_tile *, uint16_t **, size_t);
 
+// ---- per-device scratch arena of the conditioning stages (internal.h)
+#include <map>
+#include <time.h>
+#include <mutex>
+namespace {
+struct DevArena { std::mutex busy; void *p = nullptr; size_t bytes = 0; };
+std::mutex g_arena_table;
+std::map<int, DevArena *> g_arenas;
+DevArena *arena_of(int device)
+{
+    std::lock_guard<std::mutex> g(g_arena_table);
+    DevArena *&a = g_arenas[device];
+    if (!a) a = new DevArena();
+    return a;
+}
+}  // namespace
+
+int arena_acquire(int device, ArenaLease *L)
+{
+    DevArena *a = arena_of(device);
+    a->busy.lock();
+    L->device = device; L->base = (char *)a->p; L->bytes = a->bytes; L->off = 0; L->want = 0; L->held = true;
+    return 0;
+}
+
+void *arena_take(ArenaLease *L, size_t bytes)
+{
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    L->want += need ? need : 256;
+    if (L->base && L->off + need <= L->bytes) { void *q = L->base + L->off; L->off += need ? need : 256; return q; }
+    void *q = nullptr;
+    const hipError_t e = hipMalloc(&q, need ? need : 256);
+    if (e != hipSuccess) { pydem_set_error("hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e)); return nullptr; }
+    L->extra.push_back(q);
+    return q;
+}
+
+ArenaLease::~ArenaLease()
+{
+    if (!held) return;
+    DevArena *a = arena_of(device);
+    (void)hipSetDevice(device);
+    for (void *q : extra) (void)hipFree(q);
+    if (want > a->bytes) {              // next time everything fits
+        if (a->p) (void)hipFree(a->p);
+        a->p = nullptr; a->bytes = 0;
+        void *q = nullptr;
+        if (hipMalloc(&q, want + want / 8) == hipSuccess) { a->p = q; a->bytes = want + want / 8; }
+    }
+    a->busy.unlock();
+}
+
 namespace {
 
 template <typename T>
@@ -114,6 +166,18 @@ int ensure_field(pydem_tile *t, int field)
 
 }  // namespace
 
+int tile_pinned(pydem_tile *t, size_t bytes, void **out)
+{
+    if (t->h_stage_bytes < bytes) {
+        if (t->h_stage) { (void)hipHostFree(t->h_stage); t->h_stage = nullptr; t->h_stage_bytes = 0; }
+        const size_t want = bytes + bytes / 4 + 4096;
+        HIP_TRY(hipHostMalloc(&t->h_stage, want, hipHostMallocDefault));
+        t->h_stage_bytes = want;
+    }
+    *out = t->h_stage;
+    return 0;
+}
+
 int ensure_fields(pydem_tile *t, std::initializer_list<int> fields)
 {
     for (int f : fields) PYDEM_TRY(ensure_field(t, f));
@@ -123,6 +187,16 @@ int ensure_fields(pydem_tile *t, std::initializer_list<int> fields)
 extern "C" {
 
 const char *pydem_hip_last_error(void) { return g_err; }
+
+int pydem_hip_release_scratch(void)
+{
+    std::lock_guard<std::mutex> g(g_arena_table);
+    for (auto &kv : g_arenas) {
+        std::lock_guard<std::mutex> b(kv.second->busy);
+        if (kv.second->p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second->p); kv.second->p = nullptr; kv.second->bytes = 0; }
+    }
+    return 0;
+}
 
 int pydem_hip_device_count(int *count)
 {
@@ -182,6 +256,7 @@ int pydem_tile_destroy(pydem_tile *t)
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     if (t->h_strip_d) (void)hipHostFree(t->h_strip_d);
+    if (t->h_stage) (void)hipHostFree(t->h_stage);
     if (t->h_strip_f) (void)hipHostFree(t->h_strip_f);
     for (int i = 0; i < 8; i++) if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
@@ -320,6 +395,13 @@ static int line_copy(pydem_tile *t, int field, int axis, int64_t index, void *ho
     if (index < 0) index += lim;
     if (index < 0 || index >= lim || (axis != 0 && axis != 1)) { pydem_set_error("line index out of range"); return -2; }
     char *base = (char *)*pp;
+    // the caller's array is pageable: the transfer goes through the tile's pinned staging buffer (tile_pinned)
+    const size_t nbytes = (size_t)(axis == 0 ? t->m : t->n) * elem;
+    void *pin = nullptr;
+    PYDEM_TRY(tile_pinned(t, nbytes, &pin));
+    void *user = host;
+    host = pin;
+    if (!to_host) memcpy(pin, user, nbytes);
     if (axis == 0) {
         char *row = base + (size_t)index * t->m * elem;
         if (to_host) HIP_TRY(hipMemcpyAsync(host, row, (size_t)t->m * elem, hipMemcpyDeviceToHost, t->stream));
@@ -341,6 +423,7 @@ static int line_copy(pydem_tile *t, int field, int axis, int64_t index, void *ho
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(t->stream));
+    if (to_host) memcpy(user, pin, nbytes);
     if (!to_host && (field == PYDEM_ELEV || field == PYDEM_MAG || field == PYDEM_DIRECTION || field == PYDEM_FLATS)) t->graph_valid = false;
     return 0;
 }
@@ -359,6 +442,10 @@ int pydem_tile_get_lines(pydem_tile *t, int count, const int *fields, const int 
         HIP_TRY(hipMalloc(&t->lines_stage, (size_t)cap * L * 8));
         t->lines_cap = cap; t->device_bytes += (int64_t)((size_t)cap * L * 8);
     }
+    void *pin_v = nullptr;                                  // (pinned staging: the callers' arrays are pageable)
+    PYDEM_TRY(tile_pinned(t, (size_t)(count > 0 ? count : 1) * L * 8, &pin_v));
+    char *pin = (char *)pin_v;
+    std::vector<size_t> nbytes((size_t)(count > 0 ? count : 0));
     for (int k = 0; k < count; k++) {
         void **pp; size_t elem;
         PYDEM_TRY(field_ptr(t, fields[k], &pp, &elem));
@@ -369,7 +456,8 @@ int pydem_tile_get_lines(pydem_tile *t, int count, const int *fields, const int 
         if (index < 0 || index >= lim || (axes[k] != 0 && axes[k] != 1)) { pydem_set_error("line index out of range"); return -2; }
         char *base = (char *)*pp;
         if (axes[k] == 0) {
-            HIP_TRY(hipMemcpyAsync(dsts[k], base + (size_t)index * t->m * elem, (size_t)t->m * elem, hipMemcpyDeviceToHost, t->stream));
+            nbytes[(size_t)k] = (size_t)t->m * elem;
+            HIP_TRY(hipMemcpyAsync(pin + (size_t)k * L * 8, base + (size_t)index * t->m * elem, (size_t)t->m * elem, hipMemcpyDeviceToHost, t->stream));
         } else {
             const int64_t cnt = t->n;
             const int g = (int)(cdiv(cnt, 256) < 64 ? cdiv(cnt, 256) : 64);
@@ -377,11 +465,13 @@ int pydem_tile_get_lines(pydem_tile *t, int count, const int *fields, const int 
             double *stage = (double *)t->lines_stage + (size_t)k * L;
             if (elem == 8) hipLaunchKernelGGL(k_line_gather<double>, dim3(g), dim3(256), 0, t->stream, (const double *)col, t->m, cnt, stage);
             else hipLaunchKernelGGL(k_line_gather<uint8_t>, dim3(g), dim3(256), 0, t->stream, (const uint8_t *)col, t->m, cnt, (uint8_t *)stage);
-            HIP_TRY(hipMemcpyAsync(dsts[k], stage, (size_t)cnt * elem, hipMemcpyDeviceToHost, t->stream));
+            nbytes[(size_t)k] = (size_t)cnt * elem;
+            HIP_TRY(hipMemcpyAsync(pin + (size_t)k * L * 8, stage, (size_t)cnt * elem, hipMemcpyDeviceToHost, t->stream));
         }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(t->stream));
+    for (int k = 0; k < count; k++) memcpy(dsts[k], pin + (size_t)k * L * 8, nbytes[(size_t)k]);
     return 0;
 }
 int pydem_tile_set_line(pydem_tile *t, int field, int axis, int64_t index, const void *src) { return line_copy(t, field, axis, index, (void *)src, false); }

@@ -2725,11 +2725,19 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
     }
     // strips -> device (left, right, top, bottom), padded to L entries each (data == NULL: they are there already, written
     // by the edge board)
-    std::vector<double> hd;
-    std::vector<uint8_t> hf;
     if (data) {
-        hd.assign((size_t)L * 4, 0.0);
-        hf.assign((size_t)L * 8, 0);
+        // (pinned staging like the incremental rounds: asynchronous copies from pageable memory make the runtime pin and unpin pages
+        // behind the caller's back, and the next GPU call waits for that)
+        if (t->h_strip_cap < (size_t)L) {
+            if (t->h_strip_d) { (void)hipHostFree(t->h_strip_d); (void)hipHostFree(t->h_strip_f); }
+            HIP_TRY(hipHostMalloc((void **)&t->h_strip_d, (size_t)L * 4 * sizeof(double)));
+            HIP_TRY(hipHostMalloc((void **)&t->h_strip_f, (size_t)L * 8));
+            t->h_strip_cap = (size_t)L;
+        }
+        double *hd = t->h_strip_d;
+        uint8_t *hf = t->h_strip_f;
+        memset(hd, 0, (size_t)L * 4 * sizeof(double));
+        memset(hf, 0, (size_t)L * 8);
         for (int s = 0; s < 4; s++) {
             const int len = s < 2 ? n : m;
             for (int k = 0; k < len; k++) {
@@ -2738,8 +2746,8 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
                 hf[(size_t)(4 + s) * L + k] = todo[s][k] != 0;
             }
         }
-        HIP_TRY(hipMemcpyAsync(t->s_data, hd.data(), hd.size() * 8, hipMemcpyHostToDevice, t->stream));
-        HIP_TRY(hipMemcpyAsync(t->s_flags, hf.data(), hf.size(), hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->s_data, hd, (size_t)L * 4 * 8, hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->s_flags, hf, (size_t)L * 8, hipMemcpyHostToDevice, t->stream));
     }
     HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
     int32_t *cnt3 = t->counters;      // rotating frontier sizes; level r reads queue[r % 2] / cnt3[r % 3]

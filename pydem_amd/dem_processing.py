@@ -289,7 +289,15 @@ class DEMProcessor(object):
 
     @property
     def shape(self):
-        return self._shape if self._shape is not None else self.elev.shape
+        # never a reason to bring the elevation back from the device (a 8192^2 float64 surface is 512 MB over PCIe)
+        if self._shape is not None:
+            return self._shape
+        h = self._host.get('elev')
+        if h is not None:
+            return tuple(np.shape(h))
+        if self._tile is not None:
+            return tuple(self._tile.shape)
+        return self.elev.shape
 
     # ------------------------------------------------------------------ reference API
     def find_flats(self):
@@ -340,14 +348,19 @@ class DEMProcessor(object):
 
     def calc_pit_drain_paths(self):
         """Carve monotone paths from pits to their outlets (reference :428-548).  Works on a copy of the
-        array (the reference edits the caller's array in place)."""
+        array (the reference edits the caller's array in place).  Returns the drained surface like the reference;
+        `run_pit_drain_paths` is the same step without bringing it back to the host."""
+        self.run_pit_drain_paths()
+        return self.elev
+
+    def run_pit_drain_paths(self):
         res = self._pit_paths_on_device()
         if res is not None:
             n_failed, used, self._pit_path_rounds = res
             if n_failed:
                 warnings.warn("Warning %d pits had no place to drain to in this chunk" % n_failed)
             logger.info("... done draining pits with maxiter = %d", used)
-            return self.elev
+            return
         from . import conditioning
         elev = np.array(self.elev)
         elev, n_failed, used = conditioning.pit_drain_paths(elev, self.dX, self.dY, self.drain_pits_max_iter,
@@ -355,7 +368,6 @@ class DEMProcessor(object):
                                                             self.fill_flats_below_sea)
         logger.info("... done draining pits with maxiter = %d", used)
         self.elev = elev
-        return elev
 
     def _pit_paths_on_device(self):
         """(n_failed, iterations, rounds) when the library carved the paths on the resident float64 surface, else None:
@@ -386,7 +398,7 @@ class DEMProcessor(object):
         if self.fill_flats:
             self.calc_fill_flats()
         if self.drain_pits_path:
-            self.calc_pit_drain_paths()
+            self.run_pit_drain_paths()
         self._ensure_tile()
         self._push('elev')
         logger.info("Starting slope/direction calculation")
