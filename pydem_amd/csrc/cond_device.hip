@@ -505,9 +505,12 @@ __global__ __launch_bounds__(256) void k_flat_sweep(CondArgs A, Regions R, const
 // sweeps, and a lake that takes 1500 sweeps to cross has millions of settled cells.  A cell is looked at in sweep s + 1
 // only if it or one of its region neighbours changed in sweep s (a cell that changed is listed itself, so that its new
 // value reaches the other buffer of the ping-pong pair); cells that are not listed have the same value in both buffers.
+// (`wl_lds` / `lds_cap`: the single-workgroup kernel keeps the first lds_cap entries of the next list in LDS and only what does not
+// fit there in the global list; the multi-workgroup kernel passes lds_cap = 0)
 __device__ __forceinline__ void flat_sweep_entry(const CondArgs &A, const Regions &R, int32_t c, int32_t *__restrict__ wl_out, int32_t *n_out,
                                                  int32_t *stamp, const double *__restrict__ dh0, double *__restrict__ dh1,
-                                                 const double *__restrict__ dl0, double *__restrict__ dl1, int sweep, double source_tol)
+                                                 const double *__restrict__ dl0, double *__restrict__ dl1, int sweep, double source_tol,
+                                                 int32_t *wl_lds = nullptr, int32_t lds_cap = 0)
 {
     const int n = A.n, m = A.m;
     const int32_t r = A.creg[c];
@@ -558,10 +561,13 @@ __device__ __forceinline__ void flat_sweep_entry(const CondArgs &A, const Region
         }
     }
     dh1[c] = nh; dl1[c] = nl;
+    int32_t nbs[9];
+    bool take[9];
+    int cnt = 0;
+#pragma unroll
+    for (int d = 0; d < 9; d++) take[d] = false;
     if (nh != oh || nl != ol) {
         // the cell and its region neighbours are looked at in the next sweep: all nine stamps travel together
-        int32_t nbs[9];
-        bool take[9];
 #pragma unroll
         for (int d = 0; d < 9; d++) {
             const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
@@ -570,13 +576,28 @@ __device__ __forceinline__ void flat_sweep_entry(const CondArgs &A, const Region
         }
 #pragma unroll
         for (int d = 0; d < 9; d++) take[d] = take[d] && atomicExch(&stamp[nbs[d]], sweep + 1) != sweep + 1;
-        int cnt = 0;
 #pragma unroll
         for (int d = 0; d < 9; d++) cnt += take[d] ? 1 : 0;
-        if (cnt) {
-            int32_t at = atomicAdd(n_out, cnt);
+    }
+    // list slots: ONE atomic per wavefront (the counter is a single address: a few thousand changed cells adding to it one
+    // by one keep its L2 channel busy for ~10 ns each); the lanes that are in this call -- the others sit out the caller's
+    // loop -- share their counts (0..9) bit by bit through ballots
+    {
+        const unsigned long long act = __ballot(true);
+        const unsigned long long b0 = __ballot((cnt & 1) != 0), b1 = __ballot((cnt & 2) != 0), b2 = __ballot((cnt & 4) != 0), b3 = __ballot((cnt & 8) != 0);
+        if (b0 | b1 | b2 | b3) {
+            const int lane = (int)__lane_id();
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int excl = __popcll(b0 & lt) + 2 * __popcll(b1 & lt) + 4 * __popcll(b2 & lt) + 8 * __popcll(b3 & lt);
+            const int tot = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2) + 8 * __popcll(b3);
+            const int leader = __ffsll((long long)act) - 1;
+            int32_t base = 0;
+            if (lane == leader) base = atomicAdd(n_out, tot);
+            base = __shfl(base, leader);
+            int32_t at = base + excl;
 #pragma unroll
-            for (int d = 0; d < 9; d++) if (take[d]) wl_out[at++] = nbs[d];
+            for (int d = 0; d < 9; d++)
+                if (take[d]) { if (at < lds_cap) wl_lds[at] = nbs[d]; else wl_out[at] = nbs[d]; at++; }
         }
     }
 }
@@ -596,21 +617,46 @@ __global__ __launch_bounds__(256) void k_flat_sweep_wl(CondArgs A, Regions R, co
 // thousand sweeps and more -- is nothing but kernel boundaries when every sweep is a launch.  One workgroup runs
 // `nsweeps` sweeps in a row: the lists, distances and region records it touches were written by itself (visible
 // through the CU's L1 after a workgroup barrier); the list counters and stamps are only ever touched by atomics.
+constexpr int FS_CAP = 12288;        // entries of a work list kept in LDS by the single-workgroup sweeps (two lists: 96 KB)
 __global__ __launch_bounds__(1024) void k_flat_sweep_small(CondArgs A, Regions R, int32_t *al0, int32_t *al1, int32_t *cnt3, int32_t *stamp,
                                                            double *dhA, double *dhB, double *dlA, double *dlB, int sweep0, int nsweeps,
-                                                           double source_tol)
+                                                           double source_tol, int32_t *sweeps_done)
 {
-    for (int s = sweep0; s < sweep0 + nsweeps; s++) {
+    // The work lists live in LDS: a sweep of the tail is a chain of dependent round trips (list length, list entry, region
+    // record, neighbours, stamps, list append); with the lists and their counters on chip three of them are gone.  Entries
+    // beyond FS_CAP go to the global list; if that happens the kernel completes the sweep, writes the LDS part behind them
+    // and hands back to the multi-workgroup kernel.
+    __shared__ int32_t s_list[2][FS_CAP];
+    __shared__ int32_t s_n[2];
+    const int t = threadIdx.x;
+    int32_t na = cnt3[sweep0 % 3];
+    {
+        const int32_t *wl_in = ((sweep0 - 1) & 1) ? al1 : al0;
+        for (int32_t q = t; q < na; q += blockDim.x) s_list[0][q] = wl_in[q];      // (the host enters with na <= small_cap <= FS_CAP)
+        if (t < 2) s_n[t] = 0;
+    }
+    __syncthreads();
+    int in = 0, s = sweep0;
+    for (; s < sweep0 + nsweeps; s++) {
         const int cur = (s - 1) & 1;
-        const int32_t *wl_in = cur ? al1 : al0;
         int32_t *wl_out = cur ? al0 : al1;
         const double *dh0 = cur ? dhB : dhA, *dl0 = cur ? dlB : dlA;
         double *dh1 = cur ? dhA : dhB, *dl1 = cur ? dlA : dlB;
-        const int32_t na = __hip_atomic_load(&cnt3[s % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (threadIdx.x == 0) __hip_atomic_store(&cnt3[(s + 2) % 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int32_t q = threadIdx.x; q < na; q += blockDim.x)
-            flat_sweep_entry(A, R, wl_in[q], wl_out, &cnt3[(s + 1) % 3], stamp, dh0, dh1, dl0, dl1, s, source_tol);
+        for (int32_t q = t; q < na; q += blockDim.x)
+            flat_sweep_entry(A, R, s_list[in][q], wl_out, &s_n[in ^ 1], stamp, dh0, dh1, dl0, dl1, s, source_tol, s_list[in ^ 1], FS_CAP);
         __syncthreads();
+        na = s_n[in ^ 1];
+        in ^= 1;
+        __syncthreads();
+        if (t == 0) s_n[in ^ 1] = 0;
+        if (na > FS_CAP) { s++; break; }            // the next list continues in global memory: back to the launches per sweep
+    }
+    // the list of sweep `s` (the next one to run) goes back to global memory with its length; the counter of the sweep after it is zero
+    {
+        int32_t *wl = ((s - 1) & 1) ? al1 : al0;
+        const int32_t keep = na < FS_CAP ? na : FS_CAP;
+        for (int32_t q = t; q < keep; q += blockDim.x) wl[q] = s_list[in][q];
+        if (t == 0) { cnt3[s % 3] = na; cnt3[(s + 1) % 3] = 0; cnt3[(s + 2) % 3] = 0; *sweeps_done = s - sweep0; }
     }
 }
 
@@ -794,13 +840,14 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
         int64_t cell_sweeps = 0;
         const int gw = grid_of(nf, 2048);
         static int small_cap = -1;          // lists up to this length are swept by one workgroup, many sweeps per launch
-        if (small_cap < 0) { const char *e = getenv("PYDEM_FLAT_SMALL"); small_cap = e ? atoi(e) : 4096; }
+        if (small_cap < 0) { const char *e = getenv("PYDEM_FLAT_SMALL"); small_cap = e ? atoi(e) : 4096; if (small_cap > FS_CAP) small_cap = FS_CAP; }
         while (na > 0) {
+            bool small_run = false;
             if (na <= small_cap) {
-                const int ns = 256;           // (an even number: the ping-pong parity below is that of `sweep`)
+                const int ns = 256;
                 hipLaunchKernelGGL(k_flat_sweep_small, dim3(1), dim3(1024), 0, t->stream, A, R, al[0], al[1], cnt + 4, stamp, dh[0], dh[1], dl[0], dl[1],
-                                   sweep, ns, source_tol);
-                sweep += ns;
+                                   sweep, ns, source_tol, cnt + 7);
+                small_run = true;
             } else {
                 for (int b = 0; b < 32; b++, sweep++) {
                     const int q = (sweep - 1) & 1;
@@ -808,9 +855,10 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
                                        dl[q], dl[q ^ 1], sweep, source_tol);
                 }
             }
-            pp = cur = (sweep - 1) & 1;
-            HIP_TRY(hipMemcpyAsync(t->h_counters + 4, cnt + 4, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipMemcpyAsync(t->h_counters + 4, cnt + 4, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
+            if (small_run) sweep += t->h_counters[7];           // (it stops early when a list outgrows its LDS buffer)
+            pp = cur = (sweep - 1) & 1;
             na = t->h_counters[4 + sweep % 3];
             cell_sweeps += na;
             if (na > 0 && sweep > sweep_cap + 256) { pydem_set_error("fill_flats: distance sweeps did not terminate"); return -5; }
