@@ -234,7 +234,7 @@ class Tile(object):
                                         int(bool(pits)), int(bool(artefacts_only)), C.byref(flag)))
         return flag.value == 0
 
-    def pit_drain_paths(self, below_sea, max_iter, max_dist, max_dist_XY):
+    def pit_drain_paths(self, below_sea, max_iter, max_dist, max_dist_XY, sort_dtype=None):
         """calc_pit_drain_paths on the resident elevation.  Returns (n_failed, iterations used, rounds), or None when the tile
         must go through the host loop (no-data cells, float32 surface, or the parallel schedule gave up: surface restored)."""
         import time
@@ -247,7 +247,9 @@ class Tile(object):
         check(self.lib.pydem_pit_candidates_read(self._h, n.value, cells.ctypes.data_as(_P), elev.ctypes.data_as(_P)))
         cells, elev = cells[:n.value], elev[:n.value]
         t1 = time.perf_counter()
-        order = np.ascontiguousarray(cells[np.argsort(elev)], np.int32)       # the reference's call (:450): same tie order
+        # the reference's call (:450) on the array's own dtype: the tie order of numpy's sort is part of the result and differs between dtypes
+        keys = elev if sort_dtype is None or np.dtype(sort_dtype) == np.float64 else elev.astype(sort_dtype)
+        order = np.ascontiguousarray(cells[np.argsort(keys)], np.int32)
         t2 = time.perf_counter()
         failed, used, rounds, flag = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
         check(self.lib.pydem_pit_paths(self._h, order.ctypes.data_as(_P), n.value, int(max_iter), int(max_dist or 0),

@@ -873,6 +873,6 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
     // built -> elev
     HIP_TRY(hipMemcpyAsync(t->elev, A.built, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
-    t->elev_f32 = false;                 // float64 from here on, like the reference's data.astype('float64') (:562)
+    t->elev_f32 = false; t->elev_dtype = PYDEM_F64;      // float64 from here on, like the reference's data.astype('float64') (:562)
     return 0;
 }

@@ -42,6 +42,7 @@ struct PathArgs {
     int nw;
     const double *dX, *dY; int ndX;
     int max_iter, max_dist; double max_dist_XY;
+    int dtype_mode;          // the dtype the reference edits the array in (:535-539): 0 float64, 1 integer (path values truncate), 2 float32 (they round)
     int32_t *rown, *wown;    // [NN] smallest order among the pending readers / writers of a cell (INT_MAX: none)
     int32_t *bown;           // [NN] smallest order among the pits that read the cell and stay pending after this round
     int32_t *wstamp, *rstamp;   // [NN] largest order among the committed writers / readers of a cell (-1: none)
@@ -306,11 +307,15 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
                     for (int q = 0; q < nC; q++) { const double z = A.e[C[q]]; if (z > e_end && z < mn) mn = z; }
                     base = mn;
                 }
-                const double drop = e_end - base;
+                // (a float32 surface takes the difference in float32, :537; the stored values get the array's dtype, :539)
+                const double drop = A.dtype_mode == 2 ? (double)((float)e_end - (float)base) : e_end - base;
                 const double step = 1.0 / (double)(nC - 1);  // np.linspace(0, 1, L): arange * step, last = 1
                 for (int q = 0; q < nC; q++) {
                     const double f = (q == nC - 1) ? 1.0 : (double)q * step;
-                    CV[q] = base + f * drop;
+                    double v = base + f * drop;
+                    if (A.dtype_mode == 1) v = trunc(v);
+                    else if (A.dtype_mode == 2) v = (double)(float)v;
+                    CV[q] = v;
                 }
             }
         }
@@ -543,7 +548,7 @@ int stage_pit_candidates_read(pydem_tile *t, int64_t npits, int32_t *cells, doub
 // step 2: the paths, in the given order.  Returns 0 (done), 1 (the caller must use the host loop on the ORIGINAL surface,
 // which this call has restored) or a negative error.
 int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int max_iter, int max_dist, double max_dist_XY,
-                    int64_t *n_failed, int64_t *iter_used, int64_t *rounds_out)
+                    int64_t *n_failed, int64_t *iter_used, int64_t *rounds_out, int dtype_mode)
 {
     const int n = (int)t->n, m = (int)t->m;
     *n_failed = 0; *iter_used = 0; if (rounds_out) *rounds_out = 0;
@@ -594,6 +599,7 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     PathArgs A;
     A.e = t->elev; A.n = n; A.m = m; A.order = (const int32_t *)b_order.p; A.window = (const int32_t *)b_window.p; A.nw = 0;
     A.dX = t->dX; A.dY = t->dY; A.ndX = n - 1; A.max_iter = max_iter; A.max_dist = max_dist; A.max_dist_XY = max_dist_XY;
+    A.dtype_mode = dtype_mode;
     A.rown = (int32_t *)b_rown.p; A.wown = (int32_t *)b_wown.p; A.wstamp = (int32_t *)b_stamp.p;
     A.bown = (int32_t *)b_bown.p; A.rstamp = (int32_t *)b_rstamp.p; A.tent = (int32_t *)b_tent.p;
     A.status = (int32_t *)b_status.p; A.nF = (int32_t *)b_nF.p; A.nC = (int32_t *)b_nC.p; A.iters = (int32_t *)b_iters.p;

@@ -72,6 +72,7 @@ struct pydem_tile {
     bool spacing_set = false;
     int stencil_exact_only = 0;    // a spacing outside [2^-500, 2^500] (or PYDEM_STENCIL_EXACT=1): the marching stencil keeps to its exact path
     bool elev_f32 = false;          // the resident elevation was uploaded as float32: differences are float32 subtractions (stencil, pit drops)
+    int elev_dtype = 0;             // pydem_dtype of the last elevation upload (the conditioning keeps the array's dtype where the reference does)
     // graph / sweep scratch
     uint8_t *inmask = nullptr, *gflags = nullptr, *todo_work = nullptr;   // inmask/gflags: unused since the cinfo word
     double *contrib = nullptr;     // [2*NN] outgoing contributions per cell (double2)
@@ -141,7 +142,7 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
 int stage_pit_candidates(pydem_tile *t, int below_sea, int64_t *npits);
 int stage_pit_candidates_read(pydem_tile *t, int64_t npits, int32_t *cells, double *elev);
 int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int max_iter, int max_dist, double max_dist_XY,
-                    int64_t *n_failed, int64_t *iter_used, int64_t *rounds_out);
+                    int64_t *n_failed, int64_t *iter_used, int64_t *rounds_out, int dtype_mode);
 int stage_synth(pydem_tile *t, uint32_t seed, int64_t row0, int64_t col0, int n_oct, int top_shift,
                 double zmin, double zrange);
 int bench_stencil(pydem_tile *t, int iters, double *avg_ms);

@@ -364,7 +364,7 @@ int pydem_tile_upload(pydem_tile *t, int field, const void *src, int dtype)
         HIP_TRY(hipStreamSynchronize(t->stream));
     }
     t->have[field] = true;
-    if (field == PYDEM_ELEV) t->elev_f32 = (dtype == PYDEM_F32);
+    if (field == PYDEM_ELEV) { t->elev_f32 = (dtype == PYDEM_F32); t->elev_dtype = dtype; }
     if (field == PYDEM_ELEV || field == PYDEM_MAG || field == PYDEM_DIRECTION || field == PYDEM_FLATS) t->graph_valid = false;
     return 0;
 }
@@ -494,7 +494,7 @@ int pydem_tile_synth_fractal(pydem_tile *t, uint32_t seed, int64_t row0, int64_t
     PYDEM_TRY(ensure_field(t, PYDEM_ELEV));
     PYDEM_TRY(stage_synth(t, seed, row0, col0, n_octaves, top_shift, zmin, zrange));
     t->have[PYDEM_ELEV] = true;
-    t->elev_f32 = false;
+    t->elev_f32 = false; t->elev_dtype = PYDEM_F64;
     for (int f = PYDEM_MAG; f < PYDEM_FIELD_COUNT; f++) t->have[f] = false;
     return 0;
 }
@@ -557,9 +557,10 @@ int pydem_pit_paths(pydem_tile *t, const int32_t *order, int64_t npits, int max_
     t->einc_ready = false;
     HIP_TRY(hipSetDevice(t->device));
     PYDEM_TRY(need(t, PYDEM_ELEV, "pydem_pit_paths"));
-    if (t->elev_f32) { if (needs_host) *needs_host = 1; return 0; }            // the path values round in the array's own dtype (:539)
+    // the path values get the dtype of the array the reference edits (:539): integer surfaces truncate them, float32 ones round
+    const int dtype_mode = t->elev_dtype == PYDEM_F64 ? 0 : (t->elev_dtype == PYDEM_F32 ? 2 : 1);
     t->graph_valid = false;
-    const int r = stage_pit_paths(t, order, npits, max_iter, max_dist, max_dist_XY, n_failed, iter_used, rounds);
+    const int r = stage_pit_paths(t, order, npits, max_iter, max_dist, max_dist_XY, n_failed, iter_used, rounds, dtype_mode);
     if (r < 0) return r;
     if (needs_host) *needs_host = r;
     for (int f = PYDEM_MAG; f < PYDEM_FIELD_COUNT; f++) t->have[f] = false;

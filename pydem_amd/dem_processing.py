@@ -355,6 +355,9 @@ class DEMProcessor(object):
 
     def run_pit_drain_paths(self):
         res = self._pit_paths_on_device()
+        if res is None and self._tile is not None and 'elev' in self._on_device:
+            warnings.warn("calc_pit_drain_paths: the device schedule handed this tile to the sequential host loop "
+                          "(no-data cells or a conflict of the speculative rounds): same result, much slower")
         if res is not None:
             n_failed, used, self._pit_path_rounds = res
             if n_failed:
@@ -370,22 +373,31 @@ class DEMProcessor(object):
         self.elev = elev
 
     def _pit_paths_on_device(self):
-        """(n_failed, iterations, rounds) when the library carved the paths on the resident float64 surface, else None:
-        integer / float32 surfaces keep numpy's in-dtype arithmetic (:539) and tiles with no-data go through the host."""
+        """(n_failed, iterations, rounds) when the library carved the paths on the resident surface, else None (tiles with
+        no-data cells, dtypes the device cannot hold, or the parallel schedule gave up: the caller runs the host loop).
+        Integer / float32 surfaces keep numpy's in-dtype arithmetic (:537-539): the library truncates / rounds the path
+        values like the array's dtype would, the pits are sorted on keys of that dtype, and the surface comes back in it."""
         elev = self._host.get('elev')
-        if elev is not None and (np.ma.isMaskedArray(elev) or np.asarray(elev).dtype != np.float64 or np.asarray(elev).ndim != 2):
-            return None
+        dtype = None
+        if elev is not None:
+            if np.ma.isMaskedArray(elev) or np.asarray(elev).ndim != 2:
+                return None
+            dtype = np.asarray(elev).dtype
+            if dtype not in (np.dtype('float64'), np.dtype('float32'), np.dtype('int16'), np.dtype('int32'), np.dtype('uint8'), np.dtype('int8')):
+                return None
         if min(self.shape) < 3:
             return None
         self._ensure_tile()
         self._push('elev')
         res = self._tile.pit_drain_paths(self.fill_flats_below_sea, self.drain_pits_max_iter, self.drain_pits_max_dist,
-                                         self.drain_pits_max_dist_XY)
+                                         self.drain_pits_max_dist_XY, sort_dtype=dtype)
         if res is None:
             return None
         self._produced('elev')
         for nm in ('mag', 'direction', 'flats', 'uca', 'section', 'proportion', 'edge_todo', 'edge_done'):
             self._on_device.discard(nm)
+        if dtype is not None and dtype != np.float64:
+            self.elev = self.elev.astype(dtype)                # the reference edits the array in place: it keeps its dtype
         return res
 
     def calc_slopes_directions(self, plotflag=False):

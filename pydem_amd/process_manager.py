@@ -424,7 +424,7 @@ class ProcessManager(object):
                 dp = self._make_processor(i, elev=meta['elev'], **kw)
             if not self.elev_conditioned and not self._stored(i, 'elev'):
                 dp.calc_fill_flats()
-                dp.run_pit_drain_paths()
+                getattr(dp, 'run_pit_drain_paths', dp.calc_pit_drain_paths)()     # (the device processor's variant leaves the surface in HBM)
             self.tiles[i] = dp
             if not self._stored(i, 'elev') and self.checkpoint:
                 self._store(i, 'elev', {'elev': np.asarray(dp.elev, float)})

@@ -174,3 +174,32 @@ def test_device_pit_paths_plateau_tile():
     assert res is not None, "fell back to the host loop"
     assert np.array_equal(np.asarray(dp.elev), want)
     assert (res[0], res[1]) == (bad, used)
+
+
+@pytest.mark.parametrize('dtype', ['int16', 'int32', 'float32'])
+def test_device_pit_paths_keep_the_arrays_dtype(dtype):
+    """calc_pit_drain_paths on an integer / float32 surface (fill_flats off): the reference edits the array in ITS dtype
+    (dem_processing.py:535-539: float32 difference, path values truncated / rounded on assignment) and sorts the pits on keys of
+    that dtype (:450).  The device path does the same (dtype modes of csrc/cond_paths.hip) and must equal the sequential host
+    loop, which the reference's int16 / float32 goldens pin, on random tiles -- without falling back to it."""
+    from pydem_amd import DEMProcessor, conditioning as C, synth
+    done = 0
+    for k in range(12):
+        rng = np.random.default_rng(500 + k)
+        n, m = int(rng.integers(40, 300)), int(rng.integers(40, 300))
+        z = synth.fractal(n, m, seed=int(rng.integers(0, 1 << 30)), top_shift=5, n_octaves=4, zmin=1.0, zrange=float(rng.choice([40.0, 400.0])))
+        z = (np.rint(z) if dtype != 'float32' else z).astype(dtype)
+        dX = np.full(n - 1, 30.0); dY = np.full(n - 1, 25.0)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            want, bad, used = C.pit_drain_paths(z.copy(), dX, dY)
+            dp = DEMProcessor(elev=z.copy(), dX=dX, dY=dY, fill_flats=False)
+            res = dp._pit_paths_on_device()
+        if res is None:
+            continue                                   # (the speculative schedule may give up: rare, counted below)
+        got = np.asarray(dp.elev)
+        assert got.dtype == np.dtype(dtype) and want.dtype == np.dtype(dtype)
+        assert np.array_equal(got, want), "case %d: %d cells differ" % (k, int((got != want).sum()))
+        assert (res[0], res[1]) == (bad, used)
+        done += 1
+    assert done >= 10
