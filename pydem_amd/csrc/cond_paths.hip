@@ -32,6 +32,13 @@
 
 namespace {
 
+#ifdef PYDEM_PATHS_PROF
+__device__ unsigned long long g_paths_prof[8];     // ticks of the large-window simulations: clear, min scan, fresh pass, emit, ring, footprint, path, iterations
+#define PPROF(i, expr) do { const long long t0_ = wall_clock64(); expr; if (WIN > 64 && lane == 0) atomicAdd(&g_paths_prof[i], (unsigned long long)(wall_clock64() - t0_)); } while (0)
+#else
+#define PPROF(i, expr) do { expr; } while (0)
+#endif
+
 constexpr int ST_PENDING = 0, ST_FAILED = 1, ST_PATH = 2, ST_OVERFLOW = 3, ST_TOOBIG = 4;
 
 struct PathArgs {
@@ -42,6 +49,8 @@ struct PathArgs {
     int nw;
     const double *dX, *dY; int ndX;
     int max_iter, max_dist; double max_dist_XY;
+    unsigned long long mmagic;   // ceil(2^63 / m): cell / m = umul64hi(2 * cell, mmagic), exact for every cell id (the simulations decode
+                             // cell ids all the time and a 32-bit division by a run-time divisor is ~40 instructions)
     int dtype_mode;          // the dtype the reference edits the array in (:535-539): 0 float64, 1 integer (path values truncate), 2 float32 (they round)
     int32_t *rown, *wown;    // [NN] smallest order among the pending readers / writers of a cell (INT_MAX: none)
     int32_t *bown;           // [NN] smallest order among the pits that read the cell and stay pending after this round
@@ -95,7 +104,7 @@ __device__ double pit_reach(const PathArgs &A, int pi, int pj, int32_t t)
 // One pit, one wavefront.  WIN: window edge, RCAP: rim capacity; the trail lives in LDS for the small window and in
 // global scratch for the large one.
 template <int WIN, int RCAP>
-__device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32_t *freshmap, int32_t *rim, double *rimz, int32_t *flist, int32_t *trail, int tcap)
+__device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32_t *freshmap, int32_t *rim, double *rimz, uint16_t *holes, int32_t *flist, int32_t *trail, int tcap)
 {
     const int lane = (int)(threadIdx.x & 63);
     const int k = A.window[slot];
@@ -104,12 +113,18 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
     const int pi = pit / m, pj = pit - pi * m;
     const int oi = pi - WIN / 2, oj = pj - WIN / 2;          // window origin (may be negative)
     constexpr int WORDS = WIN * WIN / 32;
-    for (int w = lane; w < WORDS; w += 64) { seen[w] = 0; freshmap[w] = 0; }
+    PPROF(0, for (int w = lane; w < WORDS; w += 64) { seen[w] = 0; freshmap[w] = 0; });
     __builtin_amdgcn_wave_barrier();
-    int nrim = 0, ntrail = 0;
+    // the rim is an unordered list with HOLES: a cell that leaves it (promoted into the region) frees its slot (rim = -1,
+    // height +inf), the slot goes on a stack and the next cell that joins takes it -- nothing is compacted per iteration.
+    // nrim = slots in use incl. holes, nh = holes on the stack, n_alive = cells on the rim.  Nothing depends on the order of
+    // the list: the cells at the lowest height are sorted by cell id before they join the trail (:470).
+    int nrim = 0, ntrail = 0, nh = 0, n_alive = 0;
     bool overflow = false, later = false;
+    auto row_of = [&](int32_t c) -> int { return (int)__umul64hi((unsigned long long)(uint32_t)c << 1, A.mmagic); };
     auto bit_of = [&](int32_t c, int &word, uint32_t &mask) -> bool {
-        const int i = c / m - oi, j = c % m - oj;
+        const int ci = row_of(c);
+        const int i = ci - oi, j = c - ci * m - oj;
         if (i < 0 || i >= WIN || j < 0 || j >= WIN) return false;
         const int b = i * WIN + j;
         word = b >> 5; mask = 1u << (b & 31);
@@ -123,32 +138,40 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
             if (q < cnt * 8) {
                 const int32_t c = src[q >> 3];
                 int d = q & 7; d += (d >= 4);
-                const int ii = c / m + d / 3 - 1, jj = c % m + d % 3 - 1;
+                const int ci = row_of(c);
+                const int ii = ci + d / 3 - 1, jj = c - ci * m + d % 3 - 1;
                 if (ii >= 0 && ii < n && jj >= 0 && jj < m) {
                     t = ii * m + jj;
-                    int word; uint32_t mask;
-                    if (!bit_of(t, word, mask)) overflow = true;
-                    else add = !(atomicOr(&seen[word], mask) & mask);
+                    const int wi = ii - oi, wj = jj - oj;                            // (window coordinates straight from ii, jj: no second decode)
+                    if (wi < 0 || wi >= WIN || wj < 0 || wj >= WIN) overflow = true;
+                    else {
+                        const int b = wi * WIN + wj;
+                        const uint32_t mask = 1u << (b & 31);
+                        add = !(atomicOr(&seen[b >> 5], mask) & mask);
+                    }
                 }
             }
             const unsigned long long bal = __ballot(add);
-            const int pos = nrim + __popcll(bal & ((1ull << lane) - 1ull));
+            const int cnt = __popcll(bal), rk = __popcll(bal & ((1ull << lane) - 1ull));
+            const int grow = cnt > nh ? cnt - nh : 0;                                  // slots taken beyond the list end
             if (add) {
                 // the cell's elevation is read ONCE, when it joins the rim (nothing changes the surface while the round simulates)
+                const int pos = rk < nh ? (int)holes[nh - 1 - rk] : nrim + (rk - nh);
                 if (pos < RCAP) { rim[pos] = t; rimz[pos] = A.e[t]; if (A.wstamp[t] > k) later = true; }
                 else overflow = true;
             }
-            nrim += __popcll(bal);
+            nh -= cnt - grow; nrim += grow; n_alive += cnt;
+            __builtin_amdgcn_wave_barrier();                                           // (the stack entries are spent before the next batch reads it)
         }
         overflow = __any(overflow);
         if (nrim > RCAP) nrim = RCAP;
         __builtin_amdgcn_wave_barrier();
     };
     // bits of a window bitmap (optionally AND NOT a second one) -> cells in raster = ascending cell order
-    auto emit_bits = [&](const uint32_t *map, const uint32_t *minus, bool clear, int32_t *dst, int start, int cap, int stop_at) -> int {
+    auto emit_bits = [&](const uint32_t *map, const uint32_t *minus, bool clear, int32_t *dst, int start, int cap, int stop_at, int first_word = 0) -> int {
         int emitted = start;
         bool spill = false;
-        for (int base = 0; base < WORDS; base += 64) {
+        for (int base = first_word & ~63; base < WORDS; base += 64) {
             const int w = base + lane;
             uint32_t bits = (w < WORDS) ? (minus ? (map[w] & ~minus[w]) : map[w]) : 0u;
             const int cntw = __popc(bits);
@@ -180,36 +203,44 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
     int32_t *outlet = rim;       // the outlet candidates overwrite the rim list once the growth is over
     if (!overflow) {
         for (it = 0; it < A.max_iter; it++) {
-            if (nrim == 0) break;
+            if (n_alive == 0) break;
             double lowest = INFINITY; bool has_nan = false;
-            for (int q = lane; q < nrim; q += 64) {
+            PPROF(1, for (int q = lane; q < nrim; q += 64) {
                 const double z = rimz[q];
                 if (z < lowest) lowest = z;
                 if (isnan(z)) has_nan = true;
             }
-            lowest = wave_min(lowest);
+            lowest = wave_min(lowest));
             if (__any(has_nan)) break;                       // np.min propagates NaN: the pit fails (:468)
-            // cells at the lowest height: bits in `freshmap`; the others stay in the rim (compacted in place)
-            int keep = 0, nfresh = 0;
+            // cells at the lowest height leave the rim (their slots become holes): the first 64 go to a list (sorted in registers
+            // below), any further ones into the `freshmap` bitmap
+            int nfresh = 0, wlow = WORDS;          // (wlow: the first bitmap word that holds one of them -- the scan below starts there)
+#ifdef PYDEM_PATHS_PROF
+            const long long tf0_ = wall_clock64();
+#endif
             for (int base = 0; base < nrim; base += 64) {
                 const int q = base + lane;
-                bool is_fresh = false, is_rest = false; int32_t t = -1; double z = 0.0;
-                if (q < nrim) { t = rim[q]; z = rimz[q]; is_fresh = z == lowest; is_rest = !is_fresh; }
-                // the first 64 fresh cells go to a list (sorted in registers below), any further ones into the bitmap
+                bool is_fresh = false; int32_t t = -1;
+                if (q < nrim) { t = rim[q]; is_fresh = t >= 0 && rimz[q] == lowest; }
                 const unsigned long long bf = __ballot(is_fresh);
-                const int pf = nfresh + __popcll(bf & ((1ull << lane) - 1ull));
+                if (!bf) continue;
+                const int rkf = __popcll(bf & ((1ull << lane) - 1ull));
+                const int pf = nfresh + rkf;
                 if (is_fresh) {
+                    int word = 0; uint32_t mask = 0; bit_of(t, word, mask);
+                    if (word < wlow) wlow = word;
                     if (pf < 64) flist[pf] = t;
-                    else { int word = 0; uint32_t mask = 0; bit_of(t, word, mask); atomicOr(&freshmap[word], mask); }
+                    else atomicOr(&freshmap[word], mask);
+                    rim[q] = -1; rimz[q] = INFINITY; holes[nh + rkf] = (uint16_t)q;
                 }
-                const unsigned long long br = __ballot(is_rest);
-                const int pos = keep + __popcll(br & ((1ull << lane) - 1ull));
-                __builtin_amdgcn_wave_barrier();
-                if (is_rest) { rim[pos] = t; rimz[pos] = z; }   // pos <= q: never overtakes a cell that is still to be read
-                keep += __popcll(br);
+                nh += __popcll(bf);
                 nfresh += __popcll(bf);
-                __builtin_amdgcn_wave_barrier();
             }
+            n_alive -= nfresh;
+            __builtin_amdgcn_wave_barrier();
+#ifdef PYDEM_PATHS_PROF
+            if (WIN > 64 && lane == 0) atomicAdd(&g_paths_prof[2], (unsigned long long)(wall_clock64() - tf0_));
+#endif
             // ascending cell order (:470): up to 64 cells by rank (one cell per lane), more through the window bitmap
             auto emit_fresh = [&](int32_t *dst, int start, int cap) -> int {
                 if (nfresh <= 64) {
@@ -224,7 +255,11 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
                 }
                 for (int q = lane; q < 64; q += 64) { int word = 0; uint32_t mask = 0; bit_of(flist[q], word, mask); atomicOr(&freshmap[word], mask); }
                 __builtin_amdgcn_wave_barrier();
-                return emit_bits(freshmap, nullptr, true, dst, start, cap, nfresh);
+                // plateau pits promote a whole ring per iteration: the scan of the 640 x 640 bitmap starts at the ring's first row
+                // and stops after its last cell instead of walking 100 x 64 words from the window's top every time
+                int w0 = wlow;
+                for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(w0, o); w0 = v < w0 ? v : w0; }
+                return emit_bits(freshmap, nullptr, true, dst, start, cap, nfresh, w0);
             };
             if (lowest < floor_) {                           // the first lower rim cells: outlet candidates (:471-473)
                 const int got = emit_fresh(outlet, 0, RCAP);
@@ -233,12 +268,14 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
                 break;
             }
             if (nfresh > tcap - ntrail) { overflow = true; break; }
-            emit_fresh(trail, ntrail, tcap);
-            nrim = keep;
+            PPROF(3, emit_fresh(trail, ntrail, tcap));
             const int first = ntrail;
             ntrail += nfresh;
-            add_ring(trail + first, nfresh);
+            PPROF(4, add_ring(trail + first, nfresh));
             if (overflow) break;
+#ifdef PYDEM_PATHS_PROF
+            if (WIN > 64 && lane == 0) atomicAdd(&g_paths_prof[7], 1ull);
+#endif
         }
     }
     if (__any(later) && lane == 0) atomicOr(&A.flags[0], 1);
@@ -247,7 +284,8 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
     // ---- what the simulation read: region + everything that was ever on the rim = the `seen` map
     int32_t *F = A.Fp[slot];
     const int fcap = A.fcap[slot];
-    int nF = emit_bits(seen, nullptr, false, F, 0, fcap, -1);
+    int nF = 0;
+    PPROF(5, nF = emit_bits(seen, nullptr, false, F, 0, fcap, -1));
     if (nF < 0) { if (lane == 0) { A.status[slot] = ST_OVERFLOW; A.nF[slot] = 0; A.nC[slot] = 0; } return; }
     // ---- the path: one lane does what the host loop does (:485-539)
     int32_t *C = A.Cp[slot];
@@ -260,7 +298,8 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
             int w = 0;
             for (int q = 0; q < no; q++) {
                 const int32_t t = outlet[q];
-                const double di = (double)(pi - t / m), dj = (double)(pj - t % m);
+                const int tr = row_of(t);
+                const double di = (double)(pi - tr), dj = (double)(pj - (t - tr * m));
                 if (sqrt(di * di + dj * dj) <= (double)A.max_dist) outlet[w++] = t;
             }
             no = w;
@@ -289,12 +328,12 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
             else {
                 int w = 0;
                 C[w++] = end;
-                int32_t last = end;
+                int bi = row_of(end), bj = end - bi * m;                 // the entry kept last
                 for (int q = ntrail - 1; q >= 1; q--) {
                     const int32_t a = trail[q];
-                    const int ai = a / m, aj = a % m, bi = last / m, bj = last % m;
+                    const int ai = row_of(a), aj = a - ai * m;
                     const int dii = ai > bi ? ai - bi : bi - ai, djj = aj > bj ? aj - bj : bj - aj;
-                    if (dii <= 1 && djj <= 1) { C[w++] = a; last = a; }
+                    if (dii <= 1 && djj <= 1) { C[w++] = a; bi = ai; bj = aj; }
                 }
                 C[w++] = pit;
                 for (int a = 0, b = w - 1; a < b; a++, b--) { const int32_t tt = C[a]; C[a] = C[b]; C[b] = tt; }
@@ -341,10 +380,11 @@ __global__ __launch_bounds__(256) void k_paths_small(PathArgs A, int nslots)
     __shared__ int32_t s_rim[4][SRCAP], s_trail[4][STCAP];
     __shared__ double s_rimz[4][SRCAP];
     __shared__ int32_t s_flist[4][64];
+    __shared__ uint16_t s_holes[4][SRCAP];
     const int wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
     if (q >= nslots) return;
-    simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_flist[wv], s_trail[wv], STCAP);
+    simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_holes[wv], s_flist[wv], s_trail[wv], STCAP);
 }
 
 // pits that left the small window: one wavefront per workgroup, the window in dynamic LDS, the trail in global scratch
@@ -355,9 +395,10 @@ __global__ __launch_bounds__(64) void k_paths_big(PathArgs A, const int32_t *__r
     double *rimz = (double *)(fresh + BWIN * BWIN / 32);
     int32_t *rim = (int32_t *)(rimz + BRCAP);
     int32_t *flist = rim + BRCAP;
+    uint16_t *holes = (uint16_t *)(flist + 64);
     const int q = blockIdx.x;
     if (q >= nslots) return;
-    simulate_pit<BWIN, BRCAP>(A, slots[q], seen, fresh, rim, rimz, flist, bigtrail + (int64_t)q * trail_cap, (int)trail_cap);
+    simulate_pit<BWIN, BRCAP>(A, slots[q], seen, fresh, rim, rimz, holes, flist, bigtrail + (int64_t)q * trail_cap, (int)trail_cap);
 }
 
 // Which pits commit.  Pit k saw what the sequential loop would have shown it when
@@ -600,6 +641,7 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     A.e = t->elev; A.n = n; A.m = m; A.order = (const int32_t *)b_order.p; A.window = (const int32_t *)b_window.p; A.nw = 0;
     A.dX = t->dX; A.dY = t->dY; A.ndX = n - 1; A.max_iter = max_iter; A.max_dist = max_dist; A.max_dist_XY = max_dist_XY;
     A.dtype_mode = dtype_mode;
+    A.mmagic = (((unsigned long long)1 << 63) + (unsigned long long)m - 1) / (unsigned long long)m;
     A.rown = (int32_t *)b_rown.p; A.wown = (int32_t *)b_wown.p; A.wstamp = (int32_t *)b_stamp.p;
     A.bown = (int32_t *)b_bown.p; A.rstamp = (int32_t *)b_rstamp.p; A.tent = (int32_t *)b_tent.p;
     A.status = (int32_t *)b_status.p; A.nF = (int32_t *)b_nF.p; A.nC = (int32_t *)b_nC.p; A.iters = (int32_t *)b_iters.p;
@@ -613,7 +655,7 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     const bool prof = getenv("PYDEM_PATHS_DEBUG") != nullptr;
     auto now_ms = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     bool fallback = false;
-    const size_t big_lds = (size_t)2 * (BWIN * BWIN / 8) + (size_t)BRCAP * 12 + 64 * 4;
+    const size_t big_lds = (size_t)2 * (BWIN * BWIN / 8) + (size_t)BRCAP * 12 + 64 * 4 + (size_t)BRCAP * 2;     // + the hole stack
     bool big_ready = false;
     HIP_TRY(hipStreamSynchronize(t->stream));
     const double ms_setup = now_ms() - (ts0.tv_sec * 1e3 + ts0.tv_nsec * 1e-6);
@@ -698,6 +740,16 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         pending.swap(win);
     }
     if (rounds_out) *rounds_out = rounds;
+#ifdef PYDEM_PATHS_PROF
+    {
+        unsigned long long h[8];
+        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_paths_prof), sizeof(h)));
+        fprintf(stderr, "large-window simulations, 10 ns ticks summed over %lld of them: clear %llu, min scan %llu, fresh pass %llu, emit %llu, ring %llu, footprint %llu; %llu iterations\n",
+                (long long)big_runs, h[0], h[1], h[2], h[3], h[4], h[5], h[7]);
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_paths_prof), z, sizeof(z)));
+    }
+#endif
     if (getenv("PYDEM_PATHS_DEBUG"))
         fprintf(stderr, "pit drain paths: %lld pits, %lld rounds, %lld small-window and %lld large-window simulations; ms: small %.1f, large %.1f, "
                         "commit %.1f, buffers %.1f%s\n", (long long)npits, (long long)rounds, (long long)small_runs, (long long)big_runs, ms_small, ms_big, ms_commit,
