@@ -227,6 +227,7 @@ struct SweepArgs {
     int dbg;                     // timing experiments only (PYDEM_TILE_DEBUG)
     int32_t qcap;                // frontier queue capacity (entries)
     int32_t *err;                // queue overflow counter
+    int32_t *tile_open;          // per 32x32 tile: cells still open after its last visit (INT_MAX pattern: not visited yet)
 };
 
 // A frontier entry carries the cell AND its graph word: the round that processes it starts its
@@ -626,33 +627,16 @@ __device__ __forceinline__ const double *in_edge_ptr(const SweepArgs &A, int32_t
 }
 __device__ __forceinline__ double in_edge(const SweepArgs &A, int32_t c, int m, int d) { return *in_edge_ptr(A, c, m, d); }
 
-template <bool LISTED>
-__device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uint32_t pass, int tiles_x, int tid, int lane,
-                                               uint8_t *__restrict__ tile_done, int32_t &n_final, const TileNext &N,
-                                               int32_t *pend, int &npend)
+// staging of a tile visit: the graph words of the tile (high half of L.cs, state bit "final before this pass" in the low
+// half) and the final bitmap of tile + halo
+__device__ __forceinline__ void tile_stage(const SweepArgs &A, TileW &L, uint32_t pass, int i0, int j0, int lane)
 {
-    const int by = tid / tiles_x, bx = tid - by * tiles_x;
-    const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
-    const int half = lane >> 5, l32 = lane & 31;         // interior cell k of a lane: row 2k + half, column l32 of the tile
-    // ready-list push; `consumed` = entries already processed (ring occupancy = tail - consumed)
-    auto push_ready = [&](int cell, int consumed) {
-        const int slot = atomicAdd(&L.tail, 1);
-        if (slot - consumed < TILE_RING) L.list[slot % TILE_RING] = (uint16_t)cell;
-        else atomicMin(&L.limit, slot);
-    };
-#ifdef PYDEM_TILE_PROF
-    const bool prof = (A.dbg & 4) != 0 && (int)pass >= (A.dbg >> 8);      // PYDEM_TILE_DEBUG = 4 + 256 * first pass to account
-#else
-    constexpr bool prof = false;       // (the phase timers cost registers: build with -DPYDEM_TILE_PROF to use PYDEM_TILE_DEBUG=4)
-#endif
-    long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
-    int nrounds = 0;
-    if (prof) tk0 = wall_clock64();
+    const int n = A.n, m = A.m;
+    const int half = lane >> 5, l32 = lane & 31;
+    constexpr int NSET = TT * TT / 64;
     // ---- stage the graph words of tile + halo by rows (two 32-cell rows per wavefront load, the halo ring in three
     // loads), a few loads of a lane in flight at a time: the passes are latency-bound.  The "final before this pass"
     // bits come out of wave ballots, one 64-bit word per row.
-    if (lane == 0) { L.tail = 0; L.limit = INT32_MAX; }
-    const double a0_row = (lane < TT && i0 + lane < n) ? A.a0[i0 + lane] : 0.0;       // lands in LDS once the final bitmap is no longer needed
     auto stage_word = [&](int gi, int gj) -> uint32_t {                  // 0xFFFFFFFF: outside the grid
         return (gi >= 0 && gi < n && gj >= 0 && gj < m) ? A.cinfo[(int64_t)gi * m + gj] : 0xFFFFFFFFu;
     };
@@ -675,7 +659,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
             L.fin[HW - 1] = ((br >> 32) << 1) | ((bk >> 2) & 1ull) | (((bk >> 3) & 1ull) << 33);
         }
     }
-    constexpr int NSET = TT * TT / 64, STG_B = PYDEM_STG_B;
+    constexpr int STG_B = PYDEM_STG_B;
 #pragma unroll 1
     for (int kb = 0; kb < NSET; kb += STG_B) {
         uint32_t wst[STG_B];
@@ -693,6 +677,34 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
             }
         }
     }
+}
+
+template <bool LISTED>
+__device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uint32_t pass, int tiles_x, int tid, int lane,
+                                               uint8_t *__restrict__ tile_done, int32_t &n_final, const TileNext &N,
+                                               int32_t *pend, int &npend)
+{
+    const int by = tid / tiles_x, bx = tid - by * tiles_x;
+    const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
+    const int half = lane >> 5, l32 = lane & 31;         // interior cell k of a lane: row 2k + half, column l32 of the tile
+    // ready-list push; `consumed` = entries already processed (ring occupancy = tail - consumed)
+    auto push_ready = [&](int cell, int consumed) {
+        const int slot = atomicAdd(&L.tail, 1);
+        if (slot - consumed < TILE_RING) L.list[slot % TILE_RING] = (uint16_t)cell;
+        else atomicMin(&L.limit, slot);
+    };
+#ifdef PYDEM_TILE_PROF
+    const bool prof = (A.dbg & 4) != 0 && (int)pass >= (A.dbg >> 8);      // PYDEM_TILE_DEBUG = 4 + 256 * first pass to account
+#else
+    constexpr bool prof = false;       // (the phase timers cost registers: build with -DPYDEM_TILE_PROF to use PYDEM_TILE_DEBUG=4)
+#endif
+    long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+    int nrounds = 0;
+    if (prof) tk0 = wall_clock64();
+    if (lane == 0) { L.tail = 0; L.limit = INT32_MAX; }
+    const double a0_row = (lane < TT && i0 + lane < n) ? A.a0[i0 + lane] : 0.0;       // lands in LDS once the final bitmap is no longer needed
+    constexpr int NSET = TT * TT / 64;
+    tile_stage(A, L, pass, i0, j0, lane);
     tile_wave_sync();
     if (prof) tk1 = wall_clock64();
     // ---- per-cell setup: how many upstream cells are still open = in-mask bits whose neighbour is not final (three row
@@ -896,6 +908,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
     if (lane == 0) {
         n_final += finalized;          // (lane 0's running count: the kernel adds it to the global counter once, see there)
         if (finalized == n_open) tile_done[tid] = 1;
+        A.tile_open[tid] = n_open - finalized;
         if (prof) {      // cycles per phase, summed over tiles (PYDEM_TILE_DEBUG=4)
             const long long tk4 = wall_clock64();
             unsigned long long *acc = reinterpret_cast<unsigned long long *>(A.err + 1 + 16);   // counters[32..] region: see stage_sweep
@@ -968,6 +981,258 @@ __global__ __launch_bounds__(256, 6) void k_sweep_tiles_listed(SweepArgs A, uint
     for (int32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); k < nt; k += gridDim.x * 4) {
         sweep_one_tile<true>(A, L[wave], pass, tiles_x, __builtin_amdgcn_readfirstlane(list_in[k]), lane, tile_done, fin, N, s_pend[wave], npend);
         if (npend > TILE_PEND - 10) flush();            // (a visit adds at most ten)
+    }
+    if (npend) flush();
+    if (lane == 0 && fin) atomicAdd(n_final, fin);
+}
+
+// ------------------------------------------------------------------------------- K5e
+// Resident visits for the river passes.  After a dozen passes the listed tiles have a few dozen open cells each, and a
+// pass lasts as long as its longest dependency chain: rounds per visit x time per round.  The generic round goes
+// through global memory for every cell (proportion, in-edge shares, results, a fence that waits for the stores); here
+// the open cells of the tile get SLOTS in LDS -- (K, p) = constant part of the area (cell area + shares of the upstream
+// cells that are final already) and proportion, fetched for all open cells at once before the rounds --, the rounds
+// only touch LDS, and the results leave the CU once after the last round.  A tile with more open cells than slots
+// takes the generic visit (sweep_one_tile).  The sum of a cell's in-edges is taken over the final ones first and the
+// ones finished in this visit second, both ascending (the generic visit: ascending over all of them).
+constexpr int RCAP = 256;
+constexpr uint32_t RS_TAINT = 1u << 18, RS_FIN = 1u << 19;      // slot word: bits 0-9 cell, 10-17 in-edges from cells open at setup
+constexpr int RS_OPEN_SHIFT = 10, RS_FINAL_SHIFT = 20;          //            bits 20-27 in-edges from cells final at setup
+
+struct TileR {
+    TileW W;                    // staging, final bitmap, count-downs as in the generic visit; W.list = ready SLOTS (each enters once)
+    uint16_t map[TT * TT];      // cell -> slot (only read for cells that were open at setup)
+    double Kd[RCAP];            // constant part while the cell is open, its area once it is finished
+    double Pd[RCAP];            // proportion
+    uint32_t sm[RCAP];          // slot word
+};
+
+// orders LDS traffic of the wavefront only (the rounds have no global stores to wait for)
+__device__ __forceinline__ void tile_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// tile-local id of the neighbour in-edge d (0..7 = NW N NE W E SW S SE) comes from
+__device__ __forceinline__ int nb_local(int cell, int d)
+{
+    const int q = d + (d >> 2);
+    const int di = (q * 11) >> 5;
+    return cell + (di - 1) * TT + (q - 3 * di - 1);
+}
+
+__device__ __forceinline__ void sweep_tile_resident(const SweepArgs &A, TileR &R, uint32_t pass, int tiles_x, int tid, int lane,
+                                                    uint8_t *__restrict__ tile_done, int32_t &n_final, const TileNext &N,
+                                                    int32_t *pend, int &npend)
+{
+    TileW &L = R.W;
+    const int by = tid / tiles_x, bx = tid - by * tiles_x;
+    const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
+    const int half = lane >> 5, l32 = lane & 31;
+    constexpr int NSET = TT * TT / 64;
+    if (lane == 0) L.tail = 0;
+    const double a0_row = (lane < TT && i0 + lane < n) ? A.a0[i0 + lane] : 0.0;
+    tile_stage(A, L, pass, i0, j0, lane);
+    tile_wave_sync();
+    // ---- setup: open-upstream counts (as in the generic visit) and a slot per open cell
+    uint32_t pitmask = 0;
+    int nslot = 0;
+#pragma unroll 2
+    for (int k = 0; k < NSET; k++) {
+        const int li = 2 * k + half + 1, idx = lane + 64 * k;
+        const uint32_t w = L.cs[idx];
+        const bool open = !((w >> SP_STATE_SHIFT) & 3u);
+        const unsigned long long bo = __ballot(open);
+        if (open) {
+            const unsigned long long f0 = L.fin[li - 1], f1 = L.fin[li], f2 = L.fin[li + 1];
+            const uint32_t nf = ((uint32_t)(f0 >> l32) & 7u) | (((uint32_t)(f1 >> l32) & 1u) << 3) |
+                                (((uint32_t)(f1 >> (l32 + 2)) & 1u) << 4) | (((uint32_t)(f2 >> l32) & 7u) << 5);
+            const uint32_t im = (w >> 16) & 0xFFu;
+            const uint32_t cnt = __popc(im & ~nf);
+            sp_of(L, idx) = (uint16_t)cnt;
+            const int s = nslot + __popcll(bo & ((1ull << lane) - 1ull));
+            R.map[idx] = (uint16_t)s;
+            R.sm[s] = (uint32_t)idx | ((im & ~nf) << RS_OPEN_SHIFT) | ((im & nf) << RS_FINAL_SHIFT);
+            if (w & (CI_PIT_IN << 16)) pitmask |= 1u << k;
+            else if (cnt == 0) L.list[atomicAdd(&L.tail, 1)] = (uint16_t)s;
+        }
+        nslot += __popcll(bo);
+    }
+    // pit in-edges of the lane's drains: sources open in this tile are released on chip, sources another tile has not
+    // finished block the drain for this pass
+    if (pitmask) {
+#pragma unroll 1
+        for (int k = 0; k < NSET; k++) {
+            if (!(pitmask & (1u << k))) continue;
+            const int cell = lane + 64 * k;
+            const int32_t c = (i0 + (cell >> 5)) * m + j0 + (cell & 31);
+            uint32_t cnt = sp_of(L, cell);
+            for (int32_t e = pit_stash(A, c).x; e < A.n_pit && A.pin_dst[e] == c; e++) {
+                const int32_t sc = A.pin_src[e];
+                const int si = sc / m - i0, sj = sc % m - j0;
+                if (si >= 0 && si < TT && sj >= 0 && sj < TT) cnt += sp_state(L, si * TT + sj) ? 0u : 1u;
+                else { const uint32_t lv = ci_level(A.cinfo[sc]); if (!(lv >= 1 && lv < pass)) cnt |= SP_BLOCKED; }
+            }
+            sp_of(L, cell) = (uint16_t)cnt;
+            if (cnt == 0) L.list[atomicAdd(&L.tail, 1)] = R.map[cell];
+        }
+    }
+    tile_wave_sync();
+    if (lane < TT) L.a0[lane] = a0_row;                  // (the final bitmap is dead now)
+    tile_wave_sync();
+    // ---- the constant part of every open cell: all its loads in flight together
+    for (int s = lane; s < nslot; s += 64) {
+        uint32_t smv = R.sm[s];
+        const int cell = smv & 1023;
+        const int gi = i0 + (cell >> 5), gj = j0 + (cell & 31);
+        const int32_t c = gi * m + gj;
+        const uint32_t cw = L.cs[cell] >> 16;
+        double pv = 0.0;
+        if (cw & (CI_OUT1 | CI_OUT2)) pv = A.prop[c];
+        bool td = (gi == 0 || gi == n - 1 || gj == 0 || gj == m - 1) && A.todo_work[c] != 0;
+        uint32_t mm = (smv >> RS_FINAL_SHIFT) & 0xFFu;
+        double xs[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            xs[q] = 0.0;
+            if (mm) { const int d = __ffs(mm) - 1; mm &= mm - 1u; xs[q] = in_edge(A, c, m, d); }
+        }
+        double K = L.a0[cell >> 5];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { K += fabs(xs[q]); td = td || (xs[q] < 0); }
+        while (mm) { const int d = __ffs(mm) - 1; mm &= mm - 1u; const double x = in_edge(A, c, m, d); K += fabs(x); td = td || (x < 0); }
+        R.Kd[s] = K; R.Pd[s] = pv;
+        R.sm[s] = (smv & 0x3FFFFu) | (td ? RS_TAINT : 0u);
+    }
+    tile_lds_sync();
+    // ---- rounds on LDS
+    uint32_t wake = 0;
+    int head = 0;
+    for (;;) {
+        const int tail = L.tail;
+        if (head >= tail) break;
+        const int idx = head + lane;
+        if (idx < tail) {
+            // (a lane that went on at once with a target its cell released -- no list, no barrier -- was measured: slower,
+            // the other branch of a braided river waits in the list meanwhile)
+            const int s = L.list[idx];
+            const uint32_t smv = R.sm[s];
+            const int cell = smv & 1023, li = cell >> 5, lj = cell & 31;
+            const uint32_t cw = L.cs[cell] >> 16;
+            double a = R.Kd[s];
+            bool td = (smv & RS_TAINT) != 0u;
+            uint32_t mm = (smv >> RS_OPEN_SHIFT) & 0xFFu;       // sources of this tile that were open at setup: finished in this visit
+            while (mm) {
+                const int d = __ffs(mm) - 1; mm &= mm - 1u;
+                const int ss = R.map[nb_local(cell, d)];
+                const double as = R.Kd[ss], ps = R.Pd[ss];
+                a += ((0x5A >> d) & 1) ? as * ps : as * (1 - ps);
+                td = td || (R.sm[ss] & RS_TAINT);
+            }
+            const int32_t c = (i0 + li) * m + j0 + lj;
+            int2 po = make_int2(0, 0);
+            if (cw & (CI_PIT_IN | CI_PIT_OUT)) po = pit_stash(A, c);
+            if (cw & CI_PIT_IN)
+                for (int32_t e = po.x; e < A.n_pit && A.pin_dst[e] == c; e++) {
+                    const int32_t sc = A.pin_src[e];
+                    const int si = sc / m - i0, sj = sc % m - j0;
+                    bool here = false;
+                    if (si >= 0 && si < TT && sj >= 0 && sj < TT) here = sp_state(L, si * TT + sj) == 2u;      // finished in this visit
+                    if (here) { const int ss = R.map[si * TT + sj]; a += R.Kd[ss] * A.pin_w[e]; td = td || (R.sm[ss] & RS_TAINT); }
+                    else { a += A.area[sc] * A.pin_w[e]; td = td || (A.todo_work[sc] != 0); }
+                }
+            R.Kd[s] = a;
+            R.sm[s] = (smv & 0x3FFu) | (td ? RS_TAINT : 0u) | RS_FIN;
+            sp_of(L, cell) = (uint16_t)(2u << SP_STATE_SHIFT);
+            auto release = [&](int ti, int tj) {            // tile-local coordinates 0..TT-1 when inside
+                if (ti >= 0 && ti < TT && tj >= 0 && tj < TT) {
+                    const int tcell = ti * TT + tj;
+                    if (sp_dec(L, tcell) == 1u) L.list[atomicAdd(&L.tail, 1)] = R.map[tcell];
+                } else {
+                    const int dti = ti < 0 ? -1 : (ti >= TT ? 1 : 0), dtj = tj < 0 ? -1 : (tj >= TT ? 1 : 0);
+                    if (ti >= -TT && ti < 2 * TT && tj >= -TT && tj < 2 * TT) wake |= 1u << ((dti + 1) * 3 + dtj + 1);
+                    else {
+                        const int tt = ((i0 + ti) / TT) * tiles_x + (j0 + tj) / TT;
+                        if (atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tt;
+                    }
+                }
+            };
+            const int sct = ci_section(cw);
+            if (cw & CI_OUT1) release(li + fe1r(sct), lj + fe1c(sct));
+            if (cw & CI_OUT2) release(li + fe2r(sct), lj + fe2c(sct));
+            if (cw & CI_PIT_OUT)
+                for (int32_t e = po.y; e < A.n_pit && A.pit_src[e] == c; e++) {
+                    const int32_t dc = A.pit_dst[e];
+                    release(dc / m - i0, dc % m - j0);
+                }
+        }
+        head = tail < head + 64 ? tail : head + 64;
+        tile_lds_sync();
+    }
+    // ---- results of the finished cells
+    int nfin = 0;
+    for (int s = lane; s < nslot; s += 64) {
+        const uint32_t smv = R.sm[s];
+        if (!(smv & RS_FIN)) continue;
+        const int cell = smv & 1023;
+        const int32_t c = (i0 + (cell >> 5)) * m + j0 + (cell & 31);
+        const uint32_t cw = L.cs[cell] >> 16;
+        const double a = R.Kd[s], pv = R.Pd[s];
+        double2 o = make_double2(0.0, 0.0);
+        if (cw & CI_OUT1) o.x = a * pv;
+        if (cw & CI_OUT2) o.y = a * (1 - pv);
+        if (smv & RS_TAINT) { o.x = -o.x; o.y = -o.y; A.todo_work[c] = 1; }
+        A.area[c] = a;
+        A.contrib[c] = o;
+        A.cinfo[c] = ci_with_level(cw, pass);
+        nfin++;
+    }
+    for (int off = 32; off > 0; off >>= 1) { nfin += __shfl_down(nfin, off); wake |= __shfl_xor(wake, off); }
+    bool win = false;
+    int tt = 0;
+    if (lane < 9 && ((wake >> lane) & 1u)) { tt = tid + (lane / 3 - 1) * tiles_x + (lane % 3 - 1); win = true; }
+    if (win) win = atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1;
+    const unsigned long long bw = __ballot(win);
+    if (win) pend[npend + __popcll(bw & ((1ull << lane) - 1ull))] = tt;
+    npend += __popcll(bw);
+    if (lane == 0) {
+        n_final += nfin;
+        A.tile_open[tid] = nslot - nfin;
+        if (nfin == nslot) tile_done[tid] = 1;
+    }
+    tile_wave_sync();
+}
+
+// listed passes with few tiles: one wavefront (= one workgroup) per tile, resident visit when the tile's open cells fit
+__global__ __launch_bounds__(64) void k_sweep_tiles_resident(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
+                                                             const int32_t *n_in, uint8_t *__restrict__ tile_done, int32_t *n_final,
+                                                             TileNext N, int32_t *clear_count)
+{
+    __shared__ TileR R;
+    __shared__ int32_t s_pend[TILE_PEND];
+    const int lane = threadIdx.x;
+    const int32_t nt = *n_in;
+    if (blockIdx.x == 0 && lane == 0) *clear_count = 0;
+    int32_t fin = 0;
+    int npend = 0;
+    auto flush = [&]() {
+        tile_wave_sync();
+        int32_t base = 0;
+        if (lane == 0) base = atomicAdd(N.count, npend);
+        base = __shfl(base, 0);
+        if (lane < npend) N.list[base + lane] = s_pend[lane];
+        npend = 0;
+        tile_wave_sync();
+    };
+    for (int32_t k = blockIdx.x; k < nt; k += gridDim.x) {
+        const int tid = __builtin_amdgcn_readfirstlane(list_in[k]);
+        if (__builtin_amdgcn_readfirstlane(A.tile_open[tid]) <= RCAP)
+            sweep_tile_resident(A, R, pass, tiles_x, tid, lane, tile_done, fin, N, s_pend, npend);
+        else
+            sweep_one_tile<true>(A, R.W, pass, tiles_x, tid, lane, tile_done, fin, N, s_pend, npend);
+        if (npend > TILE_PEND - 10) flush();
     }
     if (npend) flush();
     if (lane == 0 && fin) atomicAdd(n_final, fin);
@@ -2388,6 +2653,7 @@ static void fill_sweep_args(pydem_tile *t, SweepArgs &A)
     A.pin_dst = t->pits.in_dst; A.pin_src = t->pits.in_src; A.pin_w = t->pits.in_w;
     A.qcap = (int32_t)(t->NN / 2 < INT32_MAX ? t->NN / 2 : INT32_MAX);      // queue buffers hold NN ints = NN/2 entries
     A.err = t->counters + 15;
+    A.tile_open = nullptr;           // (stage_sweep points it at its scratch)
     { const char *e = getenv("PYDEM_TILE_DEBUG"); A.dbg = e ? atoi(e) : 0; }
 }
 
@@ -2411,9 +2677,9 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         hipLaunchKernelGGL(k_pit_stash, dim3(grid_for(A.n_pit, 2048)), dim3(256), 0, t->stream, A.pin_dst, A.pit_src, A.n_pit, t->uca);
     // ---- tile-local passes until they stop paying, then the queue rounds take over
     const int tiles_x = (int)cdiv(m, TT), tiles_total = tiles_x * (int)cdiv(n, TT);
-    // scratch: tile_done bytes | per-tile "listed for pass" stamps | two tile lists
+    // scratch: tile_done bytes | per-tile "listed for pass" stamps | two tile lists | open cells per tile
     const size_t tiles_pad = ((size_t)tiles_total + 255) & ~(size_t)255;
-    const size_t scratch_need = tiles_pad * (1 + 4 + 4 + 4);
+    const size_t scratch_need = tiles_pad * (1 + 4 + 4 + 4 + 4);
     if (t->scratch_bytes < scratch_need) {
         if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->device_bytes -= (int64_t)t->scratch_bytes; }
         HIP_TRY(hipMalloc(&t->scratch, scratch_need));
@@ -2423,7 +2689,9 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     int32_t *tile_flag = (int32_t *)(tile_done + tiles_pad);
     int32_t *tile_list[2] = {tile_flag + tiles_pad, tile_flag + 2 * tiles_pad};
     int32_t *cntT = t->counters + 56;          // rotating tile-list sizes
+    A.tile_open = tile_flag + 3 * tiles_pad;
     HIP_TRY(hipMemsetAsync(tile_done, 0, tiles_pad * 5, t->stream));      // done bytes + stamps
+    HIP_TRY(hipMemsetAsync(A.tile_open, 0x7f, tiles_pad * 4, t->stream));
     HIP_TRY(hipMemsetAsync(cntT, 0, 4 * sizeof(int32_t), t->stream));
     if (A.dbg & 4) HIP_TRY(hipMemsetAsync(t->counters + 32, 0, 24 * sizeof(int32_t), t->stream));
     int64_t launches = 0;
@@ -2432,17 +2700,25 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     static int lds_pad = -1;        // occupancy experiments only: extra dynamic LDS per workgroup (PYDEM_TILE_LDS_PAD)
     if (lds_pad < 0) { const char *e = getenv("PYDEM_TILE_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
     // listed tile passes from pass p on (the list of pass p is in tile_list[p % 2] / cntT[p % 3]); returns the next pass number
+    static int res_switch = -1;     // listed tiles at or below which the passes use resident visits (K5e)
+    if (res_switch < 0) { const char *e = getenv("PYDEM_SWEEP_RESIDENT"); res_switch = e ? atoi(e) : 4096; }
     auto run_listed = [&](int p, int64_t ntiles) -> int {
         TileNext N;
         N.flag = tile_flag;
         while (ntiles > 0) {
             const int batch = ntiles < 2048 ? 16 : 8;    // passes between two looks at the list size (a look idles the GPU for ~30 us; the grid only shrinks below 8192 listed tiles)
             const int grid = (int)(ntiles < 8192 ? (ntiles > 64 ? ntiles : 64) : 8192);
+            const bool resident = ntiles <= res_switch;
             for (int b = 0; b < batch; b++, p++) {
                 N.list = tile_list[(p + 1) % 2]; N.count = &cntT[(p + 1) % 3];
-                hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), (size_t)lds_pad, t->stream, A, (uint32_t)p, tiles_x,
-                                   (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
-                                   &cntT[(p + 2) % 3]);
+                if (resident)
+                    hipLaunchKernelGGL(k_sweep_tiles_resident, dim3((unsigned)(ntiles > 256 ? ntiles : 256)), dim3(64), 0, t->stream, A, (uint32_t)p, tiles_x,
+                                       (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
+                                       &cntT[(p + 2) % 3]);
+                else
+                    hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), (size_t)lds_pad, t->stream, A, (uint32_t)p, tiles_x,
+                                       (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
+                                       &cntT[(p + 2) % 3]);
                 launches++;
             }
             if (hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream) != hipSuccess) return -1;
