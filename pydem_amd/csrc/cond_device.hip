@@ -447,6 +447,25 @@ __global__ void k_flat_seed_done(Regions R, int32_t nreg)
     }
 }
 
+// "This cell got its first finite value": count-down of the region's open cells, the sweep that brings it to zero stops
+// the region.  A front that crosses a lake is thousands of cells of ONE region per sweep -- one atomic each on the same
+// address kept its L2 channel busy for the whole sweep (~10 ns per add: 30-50 us for a front of 5000 cells).  The lanes
+// of a wavefront that report for the same region subtract once.  Call from the converged part of the caller's loop body.
+__device__ __forceinline__ void region_arrivals(int32_t *rem, int32_t *done, int32_t r, bool arrived, int sweep)
+{
+    unsigned long long pend = __ballot(arrived);
+    while (pend) {
+        const int leader = __ffsll((long long)pend) - 1;
+        const int32_t lr = __shfl(r, leader);
+        const unsigned long long same = __ballot(arrived && r == lr);
+        if ((int)__lane_id() == leader) {
+            const int k = __popcll(same);
+            if (atomicSub(&rem[lr], k) == k) done[lr] = sweep;
+        }
+        pend &= ~same;
+    }
+}
+
 // One Jacobi sweep of utils.get_distance (:392-401) for both distances of every region that has not stopped yet:
 //   d = min(d, min(d over the cell and its 4 cardinal neighbours) + 1, min(d over the 3x3) + sqrt 2)
 // with d = 0 on the seeds of the rim and "no value yet" everywhere else outside the region.  A region stops
@@ -488,15 +507,15 @@ __global__ __launch_bounds__(256) void k_flat_sweep(CondArgs A, Regions R, const
                 const double s = card_h + 1, g = all_h + SQRT2;
                 const double best = s < g ? s : g;
                 nh = best < oh ? best : oh;
-                if (isinf(oh) && !isinf(nh) && atomicSub(&R.rem_hi[r], 1) == 1) R.done_hi[r] = sweep;
             }
             if (act_lo) {
                 const double s = card_l + 1, g = all_l + SQRT2;
                 const double best = s < g ? s : g;
                 nl = best < ol ? best : ol;
-                if (isinf(ol) && !isinf(nl) && atomicSub(&R.rem_lo[r], 1) == 1) R.done_lo[r] = sweep;
             }
         }
+        region_arrivals(R.rem_hi, R.done_hi, r, act_hi && isinf(oh) && !isinf(nh), sweep);
+        region_arrivals(R.rem_lo, R.done_lo, r, act_lo && isinf(ol) && !isinf(nl), sweep);
         dh1[c] = nh; dl1[c] = nl;
     }
 }
@@ -551,15 +570,15 @@ __device__ __forceinline__ void flat_sweep_entry(const CondArgs &A, const Region
             const double sv = card_h + 1, g = all_h + SQRT2;
             const double best = sv < g ? sv : g;
             nh = best < oh ? best : oh;
-            if (isinf(oh) && !isinf(nh) && atomicSub(&R.rem_hi[r], 1) == 1) R.done_hi[r] = sweep;
         }
         if (act_lo) {
             const double sv = card_l + 1, g = all_l + SQRT2;
             const double best = sv < g ? sv : g;
             nl = best < ol ? best : ol;
-            if (isinf(ol) && !isinf(nl) && atomicSub(&R.rem_lo[r], 1) == 1) R.done_lo[r] = sweep;
         }
     }
+    region_arrivals(R.rem_hi, R.done_hi, r, act_hi && isinf(oh) && !isinf(nh), sweep);
+    region_arrivals(R.rem_lo, R.done_lo, r, act_lo && isinf(ol) && !isinf(nl), sweep);
     dh1[c] = nh; dl1[c] = nl;
     int32_t nbs[9];
     bool take[9];
@@ -658,6 +677,48 @@ __global__ __launch_bounds__(1024) void k_flat_sweep_small(CondArgs A, Regions R
         for (int32_t q = t; q < keep; q += blockDim.x) wl[q] = s_list[in][q];
         if (t == 0) { cnt3[s % 3] = na; cnt3[(s + 1) % 3] = 0; cnt3[(s + 2) % 3] = 0; *sweeps_done = s - sweep0; }
     }
+}
+
+// Between the two: lists of a few thousand to a few ten thousand entries for hundreds of sweeps (the fronts crossing the
+// big plateaus of an integer surface).  A launch per sweep costs ~48 us there, the single workgroup ~27 us (four entries
+// per thread, one after the other).  Here a few dozen workgroups stay resident and separate the sweeps by a barrier of
+// their own: an arrival counter in global memory, agent-scope release / acquire around it.  `xcd_only`: only the
+// workgroups the dispatcher places on one XCD take part (workgroup b goes to XCD b % 8 -- the others exit at once), so
+// that lists, distances and the counter stay in ONE L2; correctness does not depend on the placement.
+__device__ __forceinline__ void coop_barrier(int32_t *bar, int nwg, int &phase)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        phase++;
+        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase * nwg) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__global__ __launch_bounds__(256) void k_flat_sweep_coop(CondArgs A, Regions R, int32_t *al0, int32_t *al1, int32_t *cnt3, int32_t *stamp,
+                                                         double *dhA, double *dhB, double *dlA, double *dlB, int sweep0, int nsweeps,
+                                                         double source_tol, int32_t *sweeps_done, int32_t *bar, int nwg, int cap, int xcd_only)
+{
+    int wg = blockIdx.x;
+    if (xcd_only) { if (blockIdx.x & 7) return; wg = blockIdx.x >> 3; }
+    int phase = 0, s = sweep0;
+    for (; s < sweep0 + nsweeps; s++) {
+        const int32_t na = __hip_atomic_load(&cnt3[s % 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (nobody writes it during sweep s)
+        if (na == 0 || na > cap) break;
+        if (wg == 0 && threadIdx.x == 0) __hip_atomic_store(&cnt3[(s + 2) % 3], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int cur = (s - 1) & 1;
+        const int32_t *wl_in = cur ? al1 : al0;
+        int32_t *wl_out = cur ? al0 : al1;
+        const double *dh0 = cur ? dhB : dhA, *dl0 = cur ? dlB : dlA;
+        double *dh1 = cur ? dhA : dhB, *dl1 = cur ? dlA : dlB;
+        for (int32_t q = wg * 256 + threadIdx.x; q < na; q += nwg * 256)
+            flat_sweep_entry(A, R, wl_in[q], wl_out, &cnt3[(s + 1) % 3], stamp, dh0, dh1, dl0, dl1, s, source_tol);
+        coop_barrier(bar, nwg, phase);
+    }
+    if (wg == 0 && threadIdx.x == 0) *sweeps_done = s - sweep0;
 }
 
 // cells of regions that are still sweeping -> next active list
@@ -841,9 +902,23 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
         const int gw = grid_of(nf, 2048);
         static int small_cap = -1;          // lists up to this length are swept by one workgroup, many sweeps per launch
         if (small_cap < 0) { const char *e = getenv("PYDEM_FLAT_SMALL"); small_cap = e ? atoi(e) : 4096; if (small_cap > FS_CAP) small_cap = FS_CAP; }
+        static int coop_cap = -1, coop_wg = 32, coop_xcd = 0, coop_min = 0;      // lists up to coop_cap: resident workgroups, a barrier per sweep
+        if (coop_cap < 0) {
+            const char *e = getenv("PYDEM_FLAT_COOP"); coop_cap = e ? atoi(e) : 8192;
+            if ((e = getenv("PYDEM_FLAT_COOP_WG"))) coop_wg = atoi(e) > 0 ? atoi(e) : 32;
+            if ((e = getenv("PYDEM_FLAT_COOP_XCD"))) coop_xcd = atoi(e);
+            if ((e = getenv("PYDEM_FLAT_COOP_MIN"))) coop_min = atoi(e);
+        }
+        static int cond_debug = -1;
+        if (cond_debug < 0) { const char *e = getenv("PYDEM_COND_DEBUG"); cond_debug = e ? atoi(e) : 0; }
         while (na > 0) {
             bool small_run = false;
-            if (na <= small_cap) {
+            if (na <= coop_cap && na > coop_min) {
+                HIP_TRY(hipMemsetAsync(cnt + 48, 0, sizeof(int32_t), t->stream));      // the barrier's arrival counter: a cache line of its own
+                hipLaunchKernelGGL(k_flat_sweep_coop, dim3((unsigned)(coop_xcd ? coop_wg * 8 : coop_wg)), dim3(256), 0, t->stream, A, R, al[0], al[1], cnt + 4, stamp,
+                                   dh[0], dh[1], dl[0], dl[1], sweep, 512, source_tol, cnt + 7, cnt + 48, coop_wg, coop_cap, coop_xcd);
+                small_run = true;
+            } else if (na <= small_cap) {
                 const int ns = 256;
                 hipLaunchKernelGGL(k_flat_sweep_small, dim3(1), dim3(1024), 0, t->stream, A, R, al[0], al[1], cnt + 4, stamp, dh[0], dh[1], dl[0], dl[1],
                                    sweep, ns, source_tol, cnt + 7);
@@ -861,6 +936,7 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
             pp = cur = (sweep - 1) & 1;
             na = t->h_counters[4 + sweep % 3];
             cell_sweeps += na;
+            if (cond_debug > 1) fprintf(stderr, "fill_flats: sweep %d, list %d\n", sweep, na);
             if (na > 0 && sweep > sweep_cap + 256) { pydem_set_error("fill_flats: distance sweeps did not terminate"); return -5; }
         }
         if (getenv("PYDEM_COND_DEBUG"))
