@@ -25,6 +25,7 @@
 // scanning it (the reference sorts them, :470), the trail in visiting order.  The arithmetic of the path (index and
 // metric reach, np.sum's pairwise order for the dY sums, np.linspace) follows the host implementation line by line.
 #include "internal.h"
+#include <hipcub/hipcub.hpp>
 #include <math.h>
 #include <string.h>
 #include <algorithm>
@@ -60,7 +61,9 @@ struct PathArgs {
     int32_t *status, *nF, *nC, *iters;
     int32_t **Fp, **Cp; double **CVp;      // where the slot's footprint / chain / chain values live
     int32_t *fcap, *ccap;
-    int32_t *flags;          // [0] a simulation met a cell written by a later pit, [1] capacity exceeded
+    int32_t *flags;          // [0] a simulation met a cell written by a later pit, [1] capacity exceeded, [2] first pit of the order whose
+                             // simulation left the window of its tier in this round (nobody from it on may commit; INT_MAX: none)
+    const int32_t *tier;     // per slot: 0 small window, 1 medium, 2 large (what earlier rounds learned about the pit)
 };
 
 __device__ __forceinline__ double wave_min(double v)
@@ -372,7 +375,12 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
 }
 
 constexpr int SWIN = 64, SRCAP = 512, STCAP = 1024;
-constexpr int BWIN = 640, BRCAP = 4096;
+#ifndef PYDEM_MWIN
+#define PYDEM_MWIN 256
+#define PYDEM_MRCAP 2048
+#endif
+constexpr int MWIN = PYDEM_MWIN, MRCAP = PYDEM_MRCAP;       // 16 + 28 KB of LDS: three medium-window simulations per CU
+constexpr int BWIN = 640, BRCAP = 4096;                    // 102 + 56 KB: one per CU
 
 __global__ __launch_bounds__(256) void k_paths_small(PathArgs A, int nslots)
 {
@@ -384,21 +392,32 @@ __global__ __launch_bounds__(256) void k_paths_small(PathArgs A, int nslots)
     const int wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
     if (q >= nslots) return;
+    if (A.tier[q] > 0) {             // known to leave the small window: not simulated here again
+        if ((threadIdx.x & 63) == 0) { A.status[q] = ST_OVERFLOW; A.nF[q] = 0; A.nC[q] = 0; A.iters[q] = 0; }
+        return;
+    }
     simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_holes[wv], s_flist[wv], s_trail[wv], STCAP);
 }
 
-// pits that left the small window: one wavefront per workgroup, the window in dynamic LDS, the trail in global scratch
-__global__ __launch_bounds__(64) void k_paths_big(PathArgs A, const int32_t *__restrict__ slots, int nslots, int32_t *bigtrail, int64_t trail_cap)
+// pits that left the small window: one wavefront per workgroup, the window in dynamic LDS, the trail in global scratch.
+// Two sizes: the large window holds whatever the reference's 300 iterations can reach and fills the LDS of a CU; most
+// plateau pits need far less, and the medium window lets three of them share a CU.  A simulation that leaves the medium
+// window closes the round for every pit from it on (flags[2]) and runs in the large one from the next round.
+template <int WIN, int RCAP>
+__global__ __launch_bounds__(64) void k_paths_big(PathArgs A, const int32_t *__restrict__ slots, const int32_t *__restrict__ qidx, int nslots,
+                                                 int32_t *bigtrail, int64_t trail_cap)
 {
     extern __shared__ uint32_t dyn[];
-    uint32_t *seen = dyn, *fresh = dyn + BWIN * BWIN / 32;
-    double *rimz = (double *)(fresh + BWIN * BWIN / 32);
-    int32_t *rim = (int32_t *)(rimz + BRCAP);
-    int32_t *flist = rim + BRCAP;
+    uint32_t *seen = dyn, *fresh = dyn + WIN * WIN / 32;
+    double *rimz = (double *)(fresh + WIN * WIN / 32);
+    int32_t *rim = (int32_t *)(rimz + RCAP);
+    int32_t *flist = rim + RCAP;
     uint16_t *holes = (uint16_t *)(flist + 64);
     const int q = blockIdx.x;
     if (q >= nslots) return;
-    simulate_pit<BWIN, BRCAP>(A, slots[q], seen, fresh, rim, rimz, holes, flist, bigtrail + (int64_t)q * trail_cap, (int)trail_cap);
+    const int slot = slots[q];
+    simulate_pit<WIN, RCAP>(A, slot, seen, fresh, rim, rimz, holes, flist, bigtrail + (int64_t)qidx[q] * trail_cap, (int)trail_cap);
+    if (WIN < BWIN && threadIdx.x == 0 && A.status[slot] == ST_OVERFLOW) atomicMin(&A.flags[2], A.window[slot]);
 }
 
 // Which pits commit.  Pit k saw what the sequential loop would have shown it when
@@ -415,7 +434,7 @@ __global__ __launch_bounds__(256) void k_paths_tentative(PathArgs A, int k_limit
     if (slot >= A.nw) return;
     const int k = A.window[slot];
     const int st = A.status[slot];
-    bool ok = (st == ST_FAILED || st == ST_PATH) && k < k_limit;
+    bool ok = (st == ST_FAILED || st == ST_PATH) && k < k_limit && k < A.flags[2];
     if (ok) {
         const int32_t *F = A.Fp[slot];
         const int32_t *C = A.Cp[slot];
@@ -485,6 +504,7 @@ __global__ __launch_bounds__(256) void k_paths_release(PathArgs A)
 // slot tables of a round: small slots point into the per-slot arrays
 __global__ void k_paths_slots(PathArgs A, int32_t *F, int32_t *C, double *CV, int fcap, int ccap)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.flags[2] = 0x7FFFFFFF;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < A.nw; s += gridDim.x * blockDim.x) {
         A.Fp[s] = F + (int64_t)s * fcap; A.Cp[s] = C + (int64_t)s * ccap; A.CVp[s] = CV + (int64_t)s * ccap;
         A.fcap[s] = fcap; A.ccap[s] = ccap;
@@ -565,23 +585,22 @@ int stage_pit_candidates_read(pydem_tile *t, int64_t npits, int32_t *cells, doub
     if (npits <= 0) return 0;
     ArenaLease lease;
     PYDEM_TRY(arena_acquire(t->device, &lease));
-    Buf tmp;
-    PYDEM_TRY(tmp.get(lease, (size_t)npits * 8));
-    // (the compaction emits blocks out of order: sort the ids on the host side of this call; transfers through the tile's pinned
-    // staging buffer, never straight from / to the caller's pageable arrays)
+    // the compaction emits blocks out of order: the ids are sorted on the device (they were sorted on the host: 8-10 ms of
+    // std::sort and two more transfers for the 341 k candidates of the 8192^2 SRTM-like tile), the elevations gathered in that
+    // order, and both leave through the tile's pinned staging buffer in one go
+    Buf sorted, vals, scratch;
+    size_t sort_bytes = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, (const int32_t *)nullptr, (int32_t *)nullptr, (int)npits, 0, 32, t->stream));
+    PYDEM_TRY(sorted.get(lease, (size_t)npits * 4)); PYDEM_TRY(vals.get(lease, (size_t)npits * 8)); PYDEM_TRY(scratch.get(lease, sort_bytes + 256));
+    HIP_TRY(hipcub::DeviceRadixSort::SortKeys(scratch.p, sort_bytes, (const int32_t *)t->flatlist, (int32_t *)sorted.p, (int)npits, 0, 32, t->stream));
+    hipLaunchKernelGGL(k_gather_f64, dim3(gridp(npits, 2048)), dim3(256), 0, t->stream, t->elev, (const int32_t *)sorted.p, (int32_t)npits, (double *)vals.p);
     void *pin = nullptr;
-    PYDEM_TRY(tile_pinned(t, (size_t)npits * 8, &pin));
-    HIP_TRY(hipMemcpyAsync(pin, t->flatlist, (size_t)npits * 4, hipMemcpyDeviceToHost, t->stream));
-    HIP_TRY(hipStreamSynchronize(t->stream));
-    memcpy(cells, pin, (size_t)npits * 4);
-    std::sort(cells, cells + npits);
-    memcpy(pin, cells, (size_t)npits * 4);
-    HIP_TRY(hipMemcpyAsync(t->flatlist, pin, (size_t)npits * 4, hipMemcpyHostToDevice, t->stream));
-    hipLaunchKernelGGL(k_gather_f64, dim3(gridp(npits, 2048)), dim3(256), 0, t->stream, t->elev, t->flatlist, (int32_t)npits, (double *)tmp.p);
-    HIP_TRY(hipStreamSynchronize(t->stream));           // (the staging buffer is free again before the elevations land in it)
-    HIP_TRY(hipMemcpyAsync(pin, tmp.p, (size_t)npits * 8, hipMemcpyDeviceToHost, t->stream));
+    PYDEM_TRY(tile_pinned(t, (size_t)npits * 12, &pin));
+    HIP_TRY(hipMemcpyAsync(pin, vals.p, (size_t)npits * 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync((char *)pin + (size_t)npits * 8, sorted.p, (size_t)npits * 4, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(t->stream));
+    memcpy(cells, (char *)pin + (size_t)npits * 8, (size_t)npits * 4);
     memcpy(elev, pin, (size_t)npits * 8);
     return 0;
 }
@@ -610,23 +629,24 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     if ((int64_t)big_max > npits) big_max = (int)npits;
     ArenaLease lease;
     PYDEM_TRY(arena_acquire(t->device, &lease));
-    Buf b_bown, b_rstamp, b_tent;
+    Buf b_bown, b_rstamp, b_tent, b_tier;
     Buf b_order, b_window, b_rown, b_wown, b_stamp, b_status, b_nF, b_nC, b_iters, b_F, b_C, b_CV, b_flags, b_done, b_counts, b_slots,
         b_backup, b_bigtrail, b_bigF, b_bigC, b_bigCV, b_Fp, b_Cp, b_CVp, b_fcap, b_ccap;
     PYDEM_TRY(b_order.get(lease, (size_t)npits * 4)); PYDEM_TRY(b_window.get(lease, (size_t)W * 4));
     PYDEM_TRY(b_rown.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_wown.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_stamp.get(lease, (size_t)t->NN * 4));
-    PYDEM_TRY(b_bown.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_rstamp.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_tent.get(lease, (size_t)W * 4));
+    PYDEM_TRY(b_bown.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_rstamp.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_tent.get(lease, (size_t)W * 4)); PYDEM_TRY(b_tier.get(lease, (size_t)W * 4));
     PYDEM_TRY(b_status.get(lease, (size_t)W * 4)); PYDEM_TRY(b_nF.get(lease, (size_t)W * 4)); PYDEM_TRY(b_nC.get(lease, (size_t)W * 4)); PYDEM_TRY(b_iters.get(lease, (size_t)W * 4));
     PYDEM_TRY(b_F.get(lease, (size_t)W * FCAP * 4)); PYDEM_TRY(b_C.get(lease, (size_t)W * CCAP * 4)); PYDEM_TRY(b_CV.get(lease, (size_t)W * CCAP * 8));
     PYDEM_TRY(b_Fp.get(lease, (size_t)W * 8)); PYDEM_TRY(b_Cp.get(lease, (size_t)W * 8)); PYDEM_TRY(b_CVp.get(lease, (size_t)W * 8));
     PYDEM_TRY(b_fcap.get(lease, (size_t)W * 4)); PYDEM_TRY(b_ccap.get(lease, (size_t)W * 4));
-    PYDEM_TRY(b_flags.get(lease, 16)); PYDEM_TRY(b_done.get(lease, (size_t)W * 4)); PYDEM_TRY(b_counts.get(lease, 16)); PYDEM_TRY(b_slots.get(lease, (size_t)W * 4));
+    PYDEM_TRY(b_flags.get(lease, 16)); PYDEM_TRY(b_done.get(lease, (size_t)W * 4)); PYDEM_TRY(b_counts.get(lease, 16)); PYDEM_TRY(b_slots.get(lease, (size_t)W * 12));
     PYDEM_TRY(b_backup.get(lease, (size_t)t->NN * 8));
     HIP_TRY(hipMemcpyAsync(b_backup.p, t->elev, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
-    // pinned staging: [order | window | status | done | big slots]
+    // pinned staging: [order | window | status | done | tiers | slots of the medium / large simulations (three lists)]
     void *pin_v = nullptr;
-    PYDEM_TRY(tile_pinned(t, ((size_t)npits + 4 * (size_t)W + 64) * 4, &pin_v));
-    int32_t *pin_order = (int32_t *)pin_v, *pin_window = pin_order + npits, *pin_status = pin_window + W, *pin_done = pin_status + W, *pin_slots = pin_done + W;
+    PYDEM_TRY(tile_pinned(t, ((size_t)npits + 7 * (size_t)W + 64) * 4, &pin_v));
+    int32_t *pin_order = (int32_t *)pin_v, *pin_window = pin_order + npits, *pin_status = pin_window + W, *pin_done = pin_status + W, *pin_tier = pin_done + W,
+            *pin_slots = pin_tier + W;
     memcpy(pin_order, order_host, (size_t)npits * 4);
     HIP_TRY(hipMemcpyAsync(b_order.p, pin_order, (size_t)npits * 4, hipMemcpyHostToDevice, t->stream));
     const int gN = gridp(t->NN, 8192);
@@ -646,9 +666,9 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     A.bown = (int32_t *)b_bown.p; A.rstamp = (int32_t *)b_rstamp.p; A.tent = (int32_t *)b_tent.p;
     A.status = (int32_t *)b_status.p; A.nF = (int32_t *)b_nF.p; A.nC = (int32_t *)b_nC.p; A.iters = (int32_t *)b_iters.p;
     A.Fp = (int32_t **)b_Fp.p; A.Cp = (int32_t **)b_Cp.p; A.CVp = (double **)b_CVp.p; A.fcap = (int32_t *)b_fcap.p; A.ccap = (int32_t *)b_ccap.p;
-    A.flags = (int32_t *)b_flags.p;
+    A.flags = (int32_t *)b_flags.p; A.tier = (const int32_t *)b_tier.p;
     std::vector<int32_t> pending, win, h_status((size_t)W), h_done((size_t)W), big;
-    std::vector<uint8_t> known_big((size_t)npits, 0);       // pits that left the small window in an earlier round
+    std::vector<uint8_t> tier((size_t)npits, 0);            // what earlier rounds learned: 1 = the pit leaves the small window, 2 = the medium one too
     int64_t next = 0;                 // first pit of the order that has not entered a window yet
     int64_t rounds = 0, big_runs = 0, small_runs = 0;
     double ms_small = 0, ms_big = 0, ms_commit = 0;
@@ -656,6 +676,10 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     auto now_ms = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     bool fallback = false;
     const size_t big_lds = (size_t)2 * (BWIN * BWIN / 8) + (size_t)BRCAP * 12 + 64 * 4 + (size_t)BRCAP * 2;     // + the hole stack
+    const size_t mid_lds = (size_t)2 * (MWIN * MWIN / 8) + (size_t)MRCAP * 12 + 64 * 4 + (size_t)MRCAP * 2;
+    static int use_mid = -1;          // PYDEM_PATHS_MID=0: every pit that leaves the small window goes straight to the large one
+    if (use_mid < 0) { const char *e = getenv("PYDEM_PATHS_MID"); use_mid = e ? atoi(e) : 1; }
+    int64_t mid_runs = 0;
     bool big_ready = false;
     HIP_TRY(hipStreamSynchronize(t->stream));
     const double ms_setup = now_ms() - (ts0.tv_sec * 1e3 + ts0.tv_nsec * 1e-6);
@@ -667,11 +691,13 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         {
             int seen_big = 0;
             for (int s2 = 0; s2 < nw; s2++)
-                if (known_big[(size_t)pending[(size_t)s2]] && ++seen_big > big_max) { nw = s2; break; }
+                if (tier[(size_t)pending[(size_t)s2]] && ++seen_big > big_max) { nw = s2; break; }
         }
         A.nw = nw;
         memcpy(pin_window, pending.data(), (size_t)nw * 4);
+        for (int s2 = 0; s2 < nw; s2++) pin_tier[s2] = tier[(size_t)pending[(size_t)s2]];
         HIP_TRY(hipMemcpyAsync(b_window.p, pin_window, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(b_tier.p, pin_tier, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemsetAsync(b_done.p, 0, (size_t)nw * 4, t->stream));
         const double t_a = now_ms();
         small_runs += nw;
@@ -684,7 +710,12 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         const double t_b = now_ms();
         ms_small += t_b - t_a;
         big.clear();
-        for (int s = 0; s < nw; s++) if (h_status[(size_t)s] == ST_OVERFLOW) { big.push_back(s); known_big[(size_t)pending[(size_t)s]] = 1; }
+        for (int s = 0; s < nw; s++)
+            if (h_status[(size_t)s] == ST_OVERFLOW) {
+                big.push_back(s);
+                uint8_t &tr = tier[(size_t)pending[(size_t)s]];
+                if (tr == 0) tr = use_mid ? 1 : 2;
+            }
         int k_limit = 0x7FFFFFFF;
         if (!big.empty()) {
             // as many large-window simulations as one launch holds take part in this round; the first one left out
@@ -694,17 +725,29 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
                 PYDEM_TRY(b_bigF.get(lease, (size_t)big_max * BIGF * 4));
                 PYDEM_TRY(b_bigC.get(lease, (size_t)big_max * (BIGF + 1) * 4));
                 PYDEM_TRY(b_bigCV.get(lease, (size_t)big_max * (BIGF + 1) * 8));
-                HIP_TRY(hipFuncSetAttribute((const void *)k_paths_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+                HIP_TRY(hipFuncSetAttribute((const void *)k_paths_big<BWIN, BRCAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+                HIP_TRY(hipFuncSetAttribute((const void *)k_paths_big<MWIN, MRCAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds));
                 big_ready = true;
             }
             if ((int)big.size() > big_max) { k_limit = pending[(size_t)big[(size_t)big_max]]; big.resize((size_t)big_max); }
             const int nb = (int)big.size();
+            // [all of them, in order: entry q owns block q of the scratch arrays | (slot, q) of the medium ones | (slot, q) of the large ones]
             memcpy(pin_slots, big.data(), (size_t)nb * 4);
-            HIP_TRY(hipMemcpyAsync(b_slots.p, pin_slots, (size_t)nb * 4, hipMemcpyHostToDevice, t->stream));
-            hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nb, 64)), dim3(256), 0, t->stream, A, (const int32_t *)b_slots.p, nb, (int32_t *)b_bigF.p,
+            int nm = 0, nl = 0;
+            for (int q = 0; q < nb; q++) if (tier[(size_t)pending[(size_t)big[(size_t)q]]] == 1) nm++;
+            int32_t *ms = pin_slots + nb, *mq = ms + nm, *ls = mq + nm, *lq = ls + (nb - nm);
+            nm = 0;
+            for (int q = 0; q < nb; q++) {
+                if (tier[(size_t)pending[(size_t)big[(size_t)q]]] == 1) { ms[nm] = big[(size_t)q]; mq[nm++] = q; }
+                else { ls[nl] = big[(size_t)q]; lq[nl++] = q; }
+            }
+            HIP_TRY(hipMemcpyAsync(b_slots.p, pin_slots, (size_t)nb * 12, hipMemcpyHostToDevice, t->stream));
+            const int32_t *d_all = (const int32_t *)b_slots.p, *d_ms = d_all + nb, *d_mq = d_ms + nm, *d_ls = d_mq + nm, *d_lq = d_ls + nl;
+            hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nb, 64)), dim3(256), 0, t->stream, A, d_all, nb, (int32_t *)b_bigF.p,
                                (int32_t *)b_bigC.p, (double *)b_bigCV.p, BIGF, BIGF + 1);
-            hipLaunchKernelGGL(k_paths_big, dim3(nb), dim3(64), big_lds, t->stream, A, (const int32_t *)b_slots.p, nb, (int32_t *)b_bigtrail.p, BIGF);
-            big_runs += nb;
+            if (nl) hipLaunchKernelGGL((k_paths_big<BWIN, BRCAP>), dim3(nl), dim3(64), big_lds, t->stream, A, d_ls, d_lq, nl, (int32_t *)b_bigtrail.p, BIGF);
+            if (nm) hipLaunchKernelGGL((k_paths_big<MWIN, MRCAP>), dim3(nm), dim3(64), mid_lds, t->stream, A, d_ms, d_mq, nm, (int32_t *)b_bigtrail.p, BIGF);
+            big_runs += nl; mid_runs += nm;
         }
         if (prof) { HIP_TRY(hipStreamSynchronize(t->stream)); }
         const double t_c = now_ms();
@@ -722,6 +765,12 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         memcpy(h_status.data(), pin_status, (size_t)nw * 4);
         rounds++;
         ms_commit += now_ms() - t_c;
+        if (prof) {
+            int ncommit = 0;
+            for (int s2 = 0; s2 < nw; s2++) ncommit += h_done[(size_t)s2] ? 1 : 0;
+            fprintf(stderr, "  round %lld: window %d, medium + large-window %d, committed %d; ms small %.2f large %.2f commit %.2f\n", (long long)rounds, nw, (int)big.size(),
+                    ncommit, t_b - t_a, t_c - t_b, now_ms() - t_c);
+        }
         if (getenv("PYDEM_PATHS_DEBUG") && atoi(getenv("PYDEM_PATHS_DEBUG")) >= 2) {
             std::vector<int32_t> h_it((size_t)nw);
             HIP_TRY(hipMemcpy(h_it.data(), b_iters.p, (size_t)nw * 4, hipMemcpyDeviceToHost));
@@ -730,12 +779,17 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
                                                  h_status[(size_t)s2], h_it[(size_t)s2]);
         }
         if (t->h_counters[0] || t->h_counters[1]) { fallback = true; break; }
-        bool stuck = false;
-        for (int s : big) if (h_status[(size_t)s] == ST_OVERFLOW) stuck = true;      // does not even fit the large window
+        bool stuck = false, escalated = false;
+        for (int s : big)
+            if (h_status[(size_t)s] == ST_OVERFLOW) {
+                uint8_t &tr = tier[(size_t)pending[(size_t)s]];
+                if (tr == 1) { tr = 2; escalated = true; }       // left the medium window: the large one from the next round on
+                else stuck = true;                               // does not even fit the large window
+            }
         if (stuck) { fallback = true; break; }
         win.clear();
         for (int s = 0; s < nw; s++) if (!h_done[(size_t)s]) win.push_back(pending[(size_t)s]);
-        if ((int)win.size() == nw) { fallback = true; break; }                        // (cannot happen: the first pit always commits)
+        if ((int)win.size() == nw && !escalated) { fallback = true; break; }          // (cannot happen: the first pit always commits)
         for (size_t s = (size_t)nw; s < pending.size(); s++) win.push_back(pending[s]);   // the part of the window that sat this round out
         pending.swap(win);
     }
@@ -751,8 +805,8 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     }
 #endif
     if (getenv("PYDEM_PATHS_DEBUG"))
-        fprintf(stderr, "pit drain paths: %lld pits, %lld rounds, %lld small-window and %lld large-window simulations; ms: small %.1f, large %.1f, "
-                        "commit %.1f, buffers %.1f%s\n", (long long)npits, (long long)rounds, (long long)small_runs, (long long)big_runs, ms_small, ms_big, ms_commit,
+        fprintf(stderr, "pit drain paths: %lld pits, %lld rounds, %lld small-window, %lld medium-window and %lld large-window simulations; ms: small %.1f, medium + large %.1f, "
+                        "commit %.1f, buffers %.1f%s\n", (long long)npits, (long long)rounds, (long long)small_runs, (long long)mid_runs, (long long)big_runs, ms_small, ms_big, ms_commit,
                 ms_setup, fallback ? " -> host loop" : "");
     if (fallback) {
         HIP_TRY(hipMemcpyAsync(t->elev, b_backup.p, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
