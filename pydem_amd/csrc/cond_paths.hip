@@ -374,15 +374,25 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
     if (st == ST_PATH) for (int q = lane; q < nC; q += 64) atomicMin(&A.wown[C[q]], k);
 }
 
-constexpr int SWIN = 64, SRCAP = 512, STCAP = 1024;
+// small window: rim / trail capacities and the wavefronts per SIMD the kernel is compiled for.  Measured on the 8192^2
+// SRTM-like tile (989 k small-window simulations): 512 / 1024 / 3 (49 KB of LDS per four simulations, 140 VGPRs) 34.9 ms;
+// 384 / 896 / 4 28.2; 256 / 512 / 4 23.2 (+2400 pits that go on to the medium window: +1 ms there); 192 / 384 and 128 / 256
+// lose more to the medium window and to extra rounds than they gain
+#ifndef PYDEM_SRCAP
+#define PYDEM_SRCAP 256
+#define PYDEM_STCAP 512
+#define PYDEM_SMALL_WAVES 4
+#endif
+constexpr int SWIN = 64, SRCAP = PYDEM_SRCAP, STCAP = PYDEM_STCAP;
 #ifndef PYDEM_MWIN
 #define PYDEM_MWIN 256
-#define PYDEM_MRCAP 2048
+#define PYDEM_MRCAP 1024
 #endif
-constexpr int MWIN = PYDEM_MWIN, MRCAP = PYDEM_MRCAP;       // 16 + 28 KB of LDS: three medium-window simulations per CU
+constexpr int MWIN = PYDEM_MWIN, MRCAP = PYDEM_MRCAP;       // 16 + 14 KB of LDS: five medium-window simulations per CU (measured: 192^2 and 128^2
+                                                           // windows or a rim of 512 send too many pits on to the large window; 320^2 / 2048 cost occupancy)
 constexpr int BWIN = 640, BRCAP = 4096;                    // 102 + 56 KB: one per CU
 
-__global__ __launch_bounds__(256) void k_paths_small(PathArgs A, int nslots)
+__global__ __launch_bounds__(256, PYDEM_SMALL_WAVES) void k_paths_small(PathArgs A, int nslots)
 {
     __shared__ uint32_t s_seen[4][SWIN * SWIN / 32], s_fresh[4][SWIN * SWIN / 32];
     __shared__ int32_t s_rim[4][SRCAP], s_trail[4][STCAP];
