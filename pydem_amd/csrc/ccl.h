@@ -76,16 +76,35 @@ __global__ __launch_bounds__(256) void k_compact_flats(const uint8_t *__restrict
     }
 }
 
-__global__ void k_label_init(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *labels)
+// Initial labels: a cell points at the first cell of its horizontal RUN as far as the wavefront sees it (consecutive list
+// entries c - 1, c of one row: the list is in raster order within a compaction trip), not at itself.  A lake is rows of
+// thousands of cells; with self-labels every union along a row lengthens a chain that every later find walks.
+__global__ void k_label_init(const int32_t *__restrict__ list, const int32_t *__restrict__ count, int32_t *labels, int m)
 {
     const int32_t nf = *count;
-    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nf; q += gridDim.x * blockDim.x) labels[list[q]] = list[q];
+    const int lane = threadIdx.x & 63;
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x;; q += gridDim.x * blockDim.x) {
+        const bool valid = q < nf;
+        if (!__ballot(valid)) break;
+        const int32_t c = valid ? list[q] : -1;
+        const int32_t prev = __shfl_up(c, 1);
+        const bool head = lane == 0 || !valid || prev != c - 1 || c % m == 0;       // (lane 0: the union pass joins it to the run before it)
+        const unsigned long long heads = __ballot(head);
+        const int s = 63 - __clzll((long long)(heads & ((2ull << lane) - 1ull)));   // the last head at or before this lane
+        const int32_t start = __shfl(c, s);
+        if (valid) labels[c] = start;
+    }
 }
 
+// root of x; a walk of two hops or more leaves x pointing at the root (labels only ever decrease, and the root is the
+// smallest id on the path: atomicMin keeps whatever another thread put there in the meantime if that is smaller still)
 __device__ __forceinline__ int32_t uf_find(int32_t *L, int32_t x)
 {
+    const int32_t x0 = x;
     int32_t p = RLX_LOAD(&L[x]);
-    while (p != x) { x = p; p = RLX_LOAD(&L[x]); }
+    int hops = 0;
+    while (p != x) { x = p; p = RLX_LOAD(&L[x]); hops++; }
+    if (hops >= 2) atomicMin(&L[x0], x);
     return x;
 }
 

@@ -804,7 +804,7 @@ int label_regions(pydem_tile *t, CondArgs &A, int32_t *nf_out, int32_t *nreg_out
     *nf_out = nf; *nreg_out = 0;
     if (nf == 0) return 0;
     const int g1 = grid_of(nf, 2048);
-    hipLaunchKernelGGL(k_label_init, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, t->labels);
+    hipLaunchKernelGGL(k_label_init, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, t->labels, A.m);
     hipLaunchKernelGGL(k_label_union, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, A.mask, t->labels, A.n, A.m);
     hipLaunchKernelGGL(k_label_flatten, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, t->labels);
     hipLaunchKernelGGL(k_region_index, dim3(g1), dim3(256), 0, t->stream, A, cnt + 1);

@@ -97,7 +97,7 @@ int stage_flats(pydem_tile *t)
     if (nf > 0) {
         const int g1 = (int)(cdiv(nf, 256) < 2048 ? cdiv(nf, 256) : 2048);
         const int g8 = (int)(cdiv((int64_t)nf * 9, 256) < 4096 ? cdiv((int64_t)nf * 9, 256) : 4096);
-        hipLaunchKernelGGL(k_label_init, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, t->labels);
+        hipLaunchKernelGGL(k_label_init, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, t->labels, m);
         hipLaunchKernelGGL(k_label_union, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, t->flat0, t->labels, n, m);
         hipLaunchKernelGGL(k_label_flatten, dim3(g1), dim3(256), 0, t->stream, t->flatlist, cnt, t->labels);
         hipLaunchKernelGGL(k_flats_extend, dim3(g8), dim3(256), 0, t->stream, t->flatlist, cnt, t->flat0, t->labels,
