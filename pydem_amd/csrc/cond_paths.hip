@@ -402,10 +402,7 @@ __global__ __launch_bounds__(256, PYDEM_SMALL_WAVES) void k_paths_small(PathArgs
     const int wv = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wv;
     if (q >= nslots) return;
-    if (A.tier[q] > 0) {             // known to leave the small window: not simulated here again
-        if ((threadIdx.x & 63) == 0) { A.status[q] = ST_OVERFLOW; A.nF[q] = 0; A.nC[q] = 0; A.iters[q] = 0; }
-        return;
-    }
+    if (A.tier[q] > 0) return;       // known to leave the small window: its medium / large-window simulation runs beside this kernel
     simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_holes[wv], s_flist[wv], s_trail[wv], STCAP);
 }
 
@@ -415,7 +412,7 @@ __global__ __launch_bounds__(256, PYDEM_SMALL_WAVES) void k_paths_small(PathArgs
 // window closes the round for every pit from it on (flags[2]) and runs in the large one from the next round.
 template <int WIN, int RCAP>
 __global__ __launch_bounds__(64) void k_paths_big(PathArgs A, const int32_t *__restrict__ slots, const int32_t *__restrict__ qidx, int nslots,
-                                                 int32_t *bigtrail, int64_t trail_cap)
+                                                 int32_t *bigtrail, int64_t trail_cap, int close_round)
 {
     extern __shared__ uint32_t dyn[];
     uint32_t *seen = dyn, *fresh = dyn + WIN * WIN / 32;
@@ -427,7 +424,7 @@ __global__ __launch_bounds__(64) void k_paths_big(PathArgs A, const int32_t *__r
     if (q >= nslots) return;
     const int slot = slots[q];
     simulate_pit<WIN, RCAP>(A, slot, seen, fresh, rim, rimz, holes, flist, bigtrail + (int64_t)qidx[q] * trail_cap, (int)trail_cap);
-    if (WIN < BWIN && threadIdx.x == 0 && A.status[slot] == ST_OVERFLOW) atomicMin(&A.flags[2], A.window[slot]);
+    if (close_round && threadIdx.x == 0 && A.status[slot] == ST_OVERFLOW) atomicMin(&A.flags[2], A.window[slot]);
 }
 
 // Which pits commit.  Pit k saw what the sequential loop would have shown it when
@@ -521,11 +518,12 @@ __global__ void k_paths_slots(PathArgs A, int32_t *F, int32_t *C, double *CV, in
     }
 }
 
-__global__ void k_paths_bigslots(PathArgs A, const int32_t *slots, int nb, int32_t *F, int32_t *C, double *CV, int64_t fcap, int64_t ccap)
+__global__ void k_paths_bigslots(PathArgs A, const int32_t *slots, const int32_t *qidx, int nb, int32_t *F, int32_t *C, double *CV, int64_t fcap, int64_t ccap)
 {
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nb; q += gridDim.x * blockDim.x) {
         const int s = slots[q];
-        A.Fp[s] = F + q * fcap; A.Cp[s] = C + q * ccap; A.CVp[s] = CV + q * ccap;
+        const int64_t blk = qidx[q];             // block of the scratch arrays
+        A.Fp[s] = F + blk * fcap; A.Cp[s] = C + blk * ccap; A.CVp[s] = CV + blk * ccap;
         A.fcap[s] = (int32_t)fcap; A.ccap[s] = (int32_t)ccap;
         A.status[s] = ST_PENDING;
     }
@@ -649,12 +647,12 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     PYDEM_TRY(b_F.get(lease, (size_t)W * FCAP * 4)); PYDEM_TRY(b_C.get(lease, (size_t)W * CCAP * 4)); PYDEM_TRY(b_CV.get(lease, (size_t)W * CCAP * 8));
     PYDEM_TRY(b_Fp.get(lease, (size_t)W * 8)); PYDEM_TRY(b_Cp.get(lease, (size_t)W * 8)); PYDEM_TRY(b_CVp.get(lease, (size_t)W * 8));
     PYDEM_TRY(b_fcap.get(lease, (size_t)W * 4)); PYDEM_TRY(b_ccap.get(lease, (size_t)W * 4));
-    PYDEM_TRY(b_flags.get(lease, 16)); PYDEM_TRY(b_done.get(lease, (size_t)W * 4)); PYDEM_TRY(b_counts.get(lease, 16)); PYDEM_TRY(b_slots.get(lease, (size_t)W * 12));
+    PYDEM_TRY(b_flags.get(lease, 16)); PYDEM_TRY(b_done.get(lease, (size_t)W * 4)); PYDEM_TRY(b_counts.get(lease, 16)); PYDEM_TRY(b_slots.get(lease, (size_t)W * 16 + 64));
     PYDEM_TRY(b_backup.get(lease, (size_t)t->NN * 8));
     HIP_TRY(hipMemcpyAsync(b_backup.p, t->elev, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
-    // pinned staging: [order | window | status | done | tiers | slots of the medium / large simulations (three lists)]
+    // pinned staging: [order | window | status | done | tiers | (slot, block) lists of the medium / large simulations: known, fresh, re-run]
     void *pin_v = nullptr;
-    PYDEM_TRY(tile_pinned(t, ((size_t)npits + 7 * (size_t)W + 64) * 4, &pin_v));
+    PYDEM_TRY(tile_pinned(t, ((size_t)npits + 8 * (size_t)W + 64) * 4, &pin_v));
     int32_t *pin_order = (int32_t *)pin_v, *pin_window = pin_order + npits, *pin_status = pin_window + W, *pin_done = pin_status + W, *pin_tier = pin_done + W,
             *pin_slots = pin_tier + W;
     memcpy(pin_order, order_host, (size_t)npits * 4);
@@ -679,6 +677,7 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     A.flags = (int32_t *)b_flags.p; A.tier = (const int32_t *)b_tier.p;
     std::vector<int32_t> pending, win, h_status((size_t)W), h_done((size_t)W), big;
     std::vector<uint8_t> tier((size_t)npits, 0);            // what earlier rounds learned: 1 = the pit leaves the small window, 2 = the medium one too
+    std::vector<uint8_t> proven((size_t)npits, 0);          // a medium-window simulation of the pit has completed
     int64_t next = 0;                 // first pit of the order that has not entered a window yet
     int64_t rounds = 0, big_runs = 0, small_runs = 0;
     double ms_small = 0, ms_big = 0, ms_commit = 0;
@@ -712,24 +711,10 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         const double t_a = now_ms();
         small_runs += nw;
         hipLaunchKernelGGL(k_paths_slots, dim3(gridp(nw, 256)), dim3(256), 0, t->stream, A, (int32_t *)b_F.p, (int32_t *)b_C.p, (double *)b_CV.p, FCAP, CCAP);
-        hipLaunchKernelGGL(k_paths_small, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A, nw);
-        HIP_TRY(hipMemcpyAsync(pin_status, b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(t->stream));
-        memcpy(h_status.data(), pin_status, (size_t)nw * 4);
-        const double t_b = now_ms();
-        ms_small += t_b - t_a;
-        big.clear();
-        for (int s = 0; s < nw; s++)
-            if (h_status[(size_t)s] == ST_OVERFLOW) {
-                big.push_back(s);
-                uint8_t &tr = tier[(size_t)pending[(size_t)s]];
-                if (tr == 0) tr = use_mid ? 1 : 2;
-            }
-        int k_limit = 0x7FFFFFFF;
-        if (!big.empty()) {
-            // as many large-window simulations as one launch holds take part in this round; the first one left out
-            // closes the round for everybody after it: a pit commits only when every earlier pending pit was simulated
+        // the medium / large-window simulations of a round: entry q of `big` owns block q of the scratch arrays.  Those of
+        // the pits whose tier is known run on the side stream BESIDE the small-window kernel (all simulations of a round read
+        // the same committed surface); what the small-window kernel newly sends on follows on the main stream.
+        auto launch_large = [&](const std::vector<int> &qs, size_t stage_at, hipStream_t st, int close_round) -> int {
             if (!big_ready) {
                 PYDEM_TRY(b_bigtrail.get(lease, (size_t)big_max * BIGF * 4));
                 PYDEM_TRY(b_bigF.get(lease, (size_t)big_max * BIGF * 4));
@@ -739,25 +724,85 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
                 HIP_TRY(hipFuncSetAttribute((const void *)k_paths_big<MWIN, MRCAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds));
                 big_ready = true;
             }
-            if ((int)big.size() > big_max) { k_limit = pending[(size_t)big[(size_t)big_max]]; big.resize((size_t)big_max); }
-            const int nb = (int)big.size();
-            // [all of them, in order: entry q owns block q of the scratch arrays | (slot, q) of the medium ones | (slot, q) of the large ones]
-            memcpy(pin_slots, big.data(), (size_t)nb * 4);
+            const int nb = (int)qs.size();
+            if (nb == 0) return 0;
+            // staging: [(slot, q) of the medium ones | (slot, q) of the large ones]
             int nm = 0, nl = 0;
-            for (int q = 0; q < nb; q++) if (tier[(size_t)pending[(size_t)big[(size_t)q]]] == 1) nm++;
-            int32_t *ms = pin_slots + nb, *mq = ms + nm, *ls = mq + nm, *lq = ls + (nb - nm);
+            for (int q : qs) if (tier[(size_t)pending[(size_t)big[(size_t)q]]] == 1) nm++;
+            int32_t *ms = pin_slots + 2 * stage_at, *mq = ms + nm, *ls = mq + nm, *lq = ls + (nb - nm);
             nm = 0;
-            for (int q = 0; q < nb; q++) {
+            for (int q : qs) {
                 if (tier[(size_t)pending[(size_t)big[(size_t)q]]] == 1) { ms[nm] = big[(size_t)q]; mq[nm++] = q; }
                 else { ls[nl] = big[(size_t)q]; lq[nl++] = q; }
             }
-            HIP_TRY(hipMemcpyAsync(b_slots.p, pin_slots, (size_t)nb * 12, hipMemcpyHostToDevice, t->stream));
-            const int32_t *d_all = (const int32_t *)b_slots.p, *d_ms = d_all + nb, *d_mq = d_ms + nm, *d_ls = d_mq + nm, *d_lq = d_ls + nl;
-            hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nb, 64)), dim3(256), 0, t->stream, A, d_all, nb, (int32_t *)b_bigF.p,
-                               (int32_t *)b_bigC.p, (double *)b_bigCV.p, BIGF, BIGF + 1);
-            if (nl) hipLaunchKernelGGL((k_paths_big<BWIN, BRCAP>), dim3(nl), dim3(64), big_lds, t->stream, A, d_ls, d_lq, nl, (int32_t *)b_bigtrail.p, BIGF);
-            if (nm) hipLaunchKernelGGL((k_paths_big<MWIN, MRCAP>), dim3(nm), dim3(64), mid_lds, t->stream, A, d_ms, d_mq, nm, (int32_t *)b_bigtrail.p, BIGF);
+            int32_t *d_ms = (int32_t *)b_slots.p + 2 * stage_at;
+            HIP_TRY(hipMemcpyAsync(d_ms, ms, (size_t)nb * 8, hipMemcpyHostToDevice, st));
+            const int32_t *d_mq = d_ms + nm, *d_ls = d_mq + nm, *d_lq = d_ls + nl;
+            if (nm) hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nm, 64)), dim3(256), 0, st, A, (const int32_t *)d_ms, d_mq, nm, (int32_t *)b_bigF.p,
+                                       (int32_t *)b_bigC.p, (double *)b_bigCV.p, BIGF, BIGF + 1);
+            if (nl) hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nl, 64)), dim3(256), 0, st, A, d_ls, d_lq, nl, (int32_t *)b_bigF.p,
+                                       (int32_t *)b_bigC.p, (double *)b_bigCV.p, BIGF, BIGF + 1);
+            if (nl) hipLaunchKernelGGL((k_paths_big<BWIN, BRCAP>), dim3(nl), dim3(64), big_lds, st, A, d_ls, d_lq, nl, (int32_t *)b_bigtrail.p, BIGF, 0);
+            if (nm) hipLaunchKernelGGL((k_paths_big<MWIN, MRCAP>), dim3(nm), dim3(64), mid_lds, st, A, (const int32_t *)d_ms, d_mq, nm, (int32_t *)b_bigtrail.p, BIGF,
+                                       close_round);
             big_runs += nl; mid_runs += nm;
+            return 0;
+        };
+        big.clear();
+        for (int s = 0; s < nw; s++) if (tier[(size_t)pending[(size_t)s]]) big.push_back(s);      // (at most big_max: the window was cut there)
+        const int n_known = (int)big.size();
+        // A pit whose medium-window simulation has never completed may leave that window too.  While such pits take part the
+        // host looks at the states after the simulations and re-runs those in the large window IN THIS ROUND (one more
+        // synchronisation; the first rounds); once every medium-window pit of a round is proven, a simulation that leaves the
+        // window anyway (its surroundings changed) closes the round behind it (flags[2]) and moves up for the next one.
+        auto unproven = [&](int q) { const int kk = pending[(size_t)big[(size_t)q]]; return tier[(size_t)kk] == 1 && !proven[(size_t)kk]; };
+        bool check = false;
+        for (int q = 0; q < n_known; q++) check = check || unproven(q);
+        std::vector<int> qs;
+        if (n_known) {
+            for (int q = 0; q < n_known; q++) qs.push_back(q);
+            HIP_TRY(hipEventRecord(t->ev_fork, t->stream));
+            HIP_TRY(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
+            // (whether the round is checked is only known after the small-window kernel; the known ones never close the round when unproven ones are among them)
+            PYDEM_TRY(launch_large(qs, 0, t->stream2, check ? 0 : 1));
+            HIP_TRY(hipEventRecord(t->ev_join, t->stream2));
+        }
+        hipLaunchKernelGGL(k_paths_small, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A, nw);
+        HIP_TRY(hipMemcpyAsync(pin_status, b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        memcpy(h_status.data(), pin_status, (size_t)nw * 4);
+        const double t_b = now_ms();
+        ms_small += t_b - t_a;
+        for (int s = 0; s < nw; s++) {               // (the status of a known pit is in the making on the side stream: not looked at here)
+            uint8_t &tr = tier[(size_t)pending[(size_t)s]];
+            if (tr == 0 && h_status[(size_t)s] == ST_OVERFLOW) { big.push_back(s); tr = use_mid ? 1 : 2; }
+        }
+        int k_limit = 0x7FFFFFFF;
+        // as many medium / large-window simulations as one launch holds take part in this round; the first one left out
+        // closes the round for everybody after it: a pit commits only when every earlier pending pit was simulated
+        if ((int)big.size() > big_max) {
+            for (size_t q = (size_t)big_max; q < big.size(); q++) { const int kk = pending[(size_t)big[q]]; if (kk < k_limit) k_limit = kk; }
+            big.resize((size_t)big_max);
+        }
+        const int nb_all = (int)big.size();
+        if (nb_all > n_known) {
+            qs.clear();
+            for (int q = n_known; q < nb_all; q++) { qs.push_back(q); check = check || unproven(q); }
+            PYDEM_TRY(launch_large(qs, (size_t)n_known, t->stream, 0));      // (fresh ones are unproven: the round is checked)
+        }
+        if (n_known) HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0));
+        if (check) {
+            HIP_TRY(hipMemcpyAsync(pin_status, b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            qs.clear();
+            for (int q = 0; q < nb_all; q++) {
+                const int kk = pending[(size_t)big[(size_t)q]];
+                if (tier[(size_t)kk] != 1) continue;
+                if (pin_status[big[(size_t)q]] == ST_OVERFLOW) { tier[(size_t)kk] = 2; qs.push_back(q); }
+                else proven[(size_t)kk] = 1;
+            }
+            PYDEM_TRY(launch_large(qs, (size_t)nb_all, t->stream, 0));
         }
         if (prof) { HIP_TRY(hipStreamSynchronize(t->stream)); }
         const double t_c = now_ms();
