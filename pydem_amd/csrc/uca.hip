@@ -2625,6 +2625,9 @@ int stage_section_graph(pydem_tile *t, const pydem_options *opt)
     hipLaunchKernelGGL(k_graph_inmask, grid2, dim3(256), 0, t->stream2, t->prop, t->elev, n, m,
                        (uint32_t *)t->indeg, t->edge_todo, t->todo_work, corner_sums);
     HIP_TRY(hipEventRecord(t->ev_join, t->stream2));
+    static int graph_serial = -1;      // PYDEM_GRAPH_SERIAL=1 (measurements): the graph kernels before the pit search instead of beside it
+    if (graph_serial < 0) { const char *e = getenv("PYDEM_GRAPH_SERIAL"); graph_serial = e ? atoi(e) : 0; }
+    if (graph_serial) HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0));
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
     if (opt->drain_pits) PYDEM_TRY(stage_pits(t, opt));
     HIP_TRY(hipEventRecord(t->ev[2], t->stream));
