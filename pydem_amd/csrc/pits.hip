@@ -717,7 +717,10 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
 // capacity go to the wavefront version.
 // ---------------------------------------------------------------------------------------------
 constexpr int LN_W = 16;          // window edge
-constexpr int LN_B = 32;          // border list capacity (one bit per slot in a 32-bit register)
+#ifndef PYDEM_LN_B
+#define PYDEM_LN_B 32
+#endif
+constexpr int LN_B = PYDEM_LN_B;  // border list capacity (one bit per slot in a 32-bit register)
 #ifndef PYDEM_LN_T
 #define PYDEM_LN_T 64
 #endif
