@@ -29,7 +29,9 @@ print("MODES-OK", dp.timings['sweep_rounds'], dp.timings['sweep_kernel_launches'
 
 @pytest.mark.parametrize('env', [{'PYDEM_SWEEP_MODE': 'queue'}, {'PYDEM_SWEEP_MODE': 'queue', 'PYDEM_SWEEP_TILE_SWITCH': '0'},
                                  {'PYDEM_SWEEP_MODE': 'queue', 'PYDEM_TILE_PASSES': '3'},
-                                 {'PYDEM_SWEEP_FIRST': 'lds'}])          # pass 1 by the LDS-resident kernel (csrc/uca.hip K5a)
+                                 {'PYDEM_SWEEP_FIRST': 'lds'},           # pass 1 by the LDS-resident kernel (csrc/uca.hip K5a)
+                                 {'PYDEM_SWEEP_RESIDENT': '0'},          # generic visits in every listed pass
+                                 {'PYDEM_SWEEP_RESIDENT': '100000000'}]) # resident visits (K5e) from pass 3 on, tiles with > 256 open cells generic
 def test_queue_schedule_matches_oracle(env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ); e.update(env)
@@ -44,4 +46,18 @@ def test_circular_drainage_replay_in_queue_schedule():
     e = dict(os.environ, PYDEM_SWEEP_MODE='queue')
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), '-q', '-x', '-k', 'circular_drainage'],
                        env=e, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize('env', [{'PYDEM_FLAT_COOP': '0'},                       # fill_flats sweeps: a launch per sweep / one workgroup, as in round 2
+                                 {'PYDEM_FLAT_COOP': '1000000', 'PYDEM_FLAT_COOP_WG': '7'},     # resident workgroups from the second look on
+                                 {'PYDEM_PATHS_MID': '0'},                       # pit drain paths without the medium window
+                                 {'PYDEM_PATHS_WINDOW': '64', 'PYDEM_PATHS_BIG': '2'}])         # tiny speculation windows: many rounds, capped large simulations
+def test_conditioning_schedules_match_the_host_twin(env):
+    """The schedule switches of the device conditioning (csrc/cond_device.hip, csrc/cond_paths.hip) change how the work is
+    cut, never the result: the conditioning tests once more per setting (read once per process, hence the subprocess)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_conditioning.py'), '-q', '-x'],
+                       env=e, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
