@@ -532,26 +532,28 @@ __device__ __forceinline__ void flat_sweep_entry(const CondArgs &A, const Region
                                                  int32_t *wl_lds = nullptr, int32_t lds_cap = 0)
 {
     const int n = A.n, m = A.m;
+    const int i = c / m, j = c - i * m;
+    // all loads of the 8 neighbours in one batch (mask, both distances, elevation), issued BEFORE the region record is known
+    // (its index is a load of its own): the sweeps are chains of dependent round trips, a few thousand cells per sweep, and
+    // nearly every listed cell belongs to a region that is still sweeping
+    uint8_t nmask[9]; double ndh[9], ndl[9], nz[9]; bool inb[9];
+#pragma unroll
+    for (int d = 0; d < 9; d++) {
+        const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
+        inb[d] = d != 4 && ii >= 0 && ii < n && jj >= 0 && jj < m;
+        const int32_t nb = inb[d] ? ii * m + jj : c;
+        nmask[d] = A.mask[nb]; ndh[d] = dh0[nb]; ndl[d] = dl0[nb]; nz[d] = A.elev[nb];
+    }
     const int32_t r = A.creg[c];
     const int32_t fl = R.flags[r];
     const bool act_hi = R.done_hi[r] >= sweep, act_lo = R.done_lo[r] >= sweep;
+    const unsigned long long lowest_bits = R.lowest_bits[r];
     const double oh = dh0[c], ol = dl0[c];
     double nh = oh, nl = ol;
-    const int i = c / m, j = c - i * m;
     if (act_hi || act_lo) {
         const double level = A.elev[c];
-        const double src_max = (fl & RF_SOURCE) ? dunkey(R.lowest_bits[r]) + source_tol : 0.0;   // lowest + tol (:347)
+        const double src_max = (fl & RF_SOURCE) ? dunkey(lowest_bits) + source_tol : 0.0;   // lowest + tol (:347)
         double card_h = oh, all_h = oh, card_l = ol, all_l = ol;
-        // all loads of the 8 neighbours in one batch (mask, both distances, elevation): the sweeps are chains of dependent
-        // round trips, a few hundred cells per sweep
-        uint8_t nmask[9]; double ndh[9], ndl[9], nz[9]; bool inb[9];
-#pragma unroll
-        for (int d = 0; d < 9; d++) {
-            const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
-            inb[d] = d != 4 && ii >= 0 && ii < n && jj >= 0 && jj < m;
-            const int32_t nb = inb[d] ? ii * m + jj : c;
-            nmask[d] = A.mask[nb]; ndh[d] = dh0[nb]; ndl[d] = dl0[nb]; nz[d] = A.elev[nb];
-        }
 #pragma unroll
         for (int d = 0; d < 9; d++) {
             if (!inb[d]) continue;
