@@ -1,7 +1,8 @@
 // cond_paths.hip -- elevation conditioning on the device, part 2: pit drain paths.
 //
 // Replaces DEMProcessor.calc_pit_drain_paths (reference pydem/dem_processing.py:428-548; helpers
-// utils.get_border_index pydem/utils.py:313-340, _get_dX_mean :1993-1997) for a float64 surface resident in HBM.
+// utils.get_border_index pydem/utils.py:313-340, _get_dX_mean :1993-1997) for a surface resident in HBM (float64 values;
+// the dtype the reference would edit the array in decides how the path values round, PathArgs::dtype_mode).
 // The reference visits the strict local minima in ascending elevation (np.argsort, :450-452), grows a region from
 // each through its lowest rim cells until a rim cell lies below the pit, prunes the visiting order to an
 // 8-connected chain and rewrites the elevations along it IN PLACE (:535-539): pit k sees the paths of pits 0..k-1.
@@ -20,7 +21,9 @@
 // that happens.
 //
 // A simulation is a wavefront: membership of region + rim in a window bitmap in LDS (64 x 64 cells; pits that leave
-// it are re-run in a 640 x 640 window -- 300 iterations cannot leave that one), the rim as a list, the minimum by a
+// it are re-run in a 256 x 256 window, those that leave that one too in a 640 x 640 window -- 300 iterations cannot
+// leave that one; a pit remembers the window it needs, and the medium / large-window simulations of such pits run on
+// the side stream beside the small-window kernel of the round), the rim as a list with holes, the minimum by a
 // wave reduction, the cells at the minimum in ascending cell order by setting their bits in a second bitmap and
 // scanning it (the reference sorts them, :470), the trail in visiting order.  The arithmetic of the path (index and
 // metric reach, np.sum's pairwise order for the dY sums, np.linspace) follows the host implementation line by line.
