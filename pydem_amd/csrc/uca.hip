@@ -574,24 +574,29 @@ __global__ __launch_bounds__(1024) void k_sweep_small(SweepArgs A, QE *q0, QE *q
 // tile is listed for the next pass.  Flow paths advance by one tile per pass instead of one cell
 // per round.  Cells finished in pass p carry level p.  The arithmetic per cell (gather order,
 // products) is identical to process_cell().
-constexpr int TT = 32, HW = TT + 2;
+#ifndef PYDEM_TH
+#define PYDEM_TH 32
+#endif
+constexpr int TT = 32;                  // tile width (cells per row: two rows per wavefront load, a 34-bit row of the final bitmap)
+constexpr int TH = PYDEM_TH, HH = TH + 2;  // tile height (32 or 64 rows)
+static_assert(TH == 32 || TH == 64, "tile height");
 // sp half-word of a cell: bits 14-15 state (0 open, 1 final / outside, 2 finished in this pass), bit 13 "waits for
 // a cell another tile must finish", bits 0-12 upstream cells of this tile that are still open
 constexpr uint32_t SP_STATE_SHIFT = 14, SP_BLOCKED = 1u << 13;
 #ifndef PYDEM_STG_B
 #define PYDEM_STG_B 4
 #endif
-constexpr int TILE_RING = 256;  // ready-list ring (a push that does not fit is dropped: the cell stays open with a zero
+constexpr int TILE_RING = TH == 32 ? 256 : 512;  // ready-list ring (a push that does not fit is dropped: the cell stays open with a zero
                                 // count, the tile lists itself and the next pass picks the cell up in its setup)
 
 struct TileW {
-    uint32_t cs[TT * TT];           // per cell of the tile: high half = static graph bits, low half = sp (state / blocked / open-upstream
+    uint32_t cs[TH * TT];           // per cell of the tile: high half = static graph bits, low half = sp (state / blocked / open-upstream
                                     // count); one LDS word per cell: a count-down is a plain 32-bit atomic, setup and rounds read both
                                     // halves at once.  The halo ring only exists as bits of `fin`.
     union {
-        unsigned long long fin[HW]; // staging and setup: bit lj of row li (halo coordinates) = the cell was final before this pass
+        unsigned long long fin[HH]; // staging and setup: bit lj of row li (halo coordinates) = the cell was final before this pass
                                     // (or lies outside the grid)
-        double a0[TT];              // rounds: cell area of the tile's rows
+        double a0[TH];              // rounds: cell area of the tile's rows
     };
     uint16_t list[TILE_RING];       // ready cells in the order they became ready
     int tail;                       // list end (monotonic; slot = index % TILE_RING)
@@ -633,7 +638,7 @@ __device__ __forceinline__ void tile_stage(const SweepArgs &A, TileW &L, uint32_
 {
     const int n = A.n, m = A.m;
     const int half = lane >> 5, l32 = lane & 31;
-    constexpr int NSET = TT * TT / 64;
+    constexpr int NSET = TH * TT / 64;
     // ---- stage the graph words of tile + halo by rows (two 32-cell rows per wavefront load, the halo ring in three
     // loads), a few loads of a lane in flight at a time: the passes are latency-bound.  The "final before this pass"
     // bits come out of wave ballots, one 64-bit word per row.
@@ -645,18 +650,24 @@ __device__ __forceinline__ void tile_stage(const SweepArgs &A, TileW &L, uint32_
         const uint32_t lv = ci_level(w);
         return lv >= 1 && lv < pass;
     };
-    uint32_t colL, colR;
+    unsigned long long colL, colR;                                                  // bit r: the halo cell left / right of tile row r is final
     {
-        const uint32_t wc = stage_word(i0 + l32, half ? j0 + TT : j0 - 1);          // left / right halo column
-        const uint32_t wr = stage_word(half ? i0 + TT : i0 - 1, j0 + l32);          // top / bottom halo row
+        const uint32_t wr = stage_word(half ? i0 + TH : i0 - 1, j0 + l32);          // top / bottom halo row
         uint32_t wk = 0xFFFFFFFFu;
-        if (lane < 4) wk = stage_word((lane & 2) ? i0 + TT : i0 - 1, (lane & 1) ? j0 + TT : j0 - 1);   // corners
-        const bool fc = final_before(wc), fr = final_before(wr), fk = lane < 4 && final_before(wk);
-        const unsigned long long bc = __ballot(fc), br = __ballot(fr), bk = __ballot(fk);
-        colL = (uint32_t)bc; colR = (uint32_t)(bc >> 32);
+        if (lane < 4) wk = stage_word((lane & 2) ? i0 + TH : i0 - 1, (lane & 1) ? j0 + TT : j0 - 1);   // corners
+        if (TH == 32) {
+            const uint32_t wc = stage_word(i0 + l32, half ? j0 + TT : j0 - 1);      // left / right halo column
+            const unsigned long long bc = __ballot(final_before(wc));
+            colL = bc & 0xFFFFFFFFull; colR = bc >> 32;
+        } else {
+            const uint32_t wl = stage_word(i0 + lane, j0 - 1), wq = stage_word(i0 + lane, j0 + TT);
+            colL = __ballot(final_before(wl)); colR = __ballot(final_before(wq));
+        }
+        const bool fr = final_before(wr), fk = lane < 4 && final_before(wk);
+        const unsigned long long br = __ballot(fr), bk = __ballot(fk);
         if (lane == 0) {
             L.fin[0] = ((br & 0xFFFFFFFFull) << 1) | (bk & 1ull) | (((bk >> 1) & 1ull) << 33);
-            L.fin[HW - 1] = ((br >> 32) << 1) | ((bk >> 2) & 1ull) | (((bk >> 3) & 1ull) << 33);
+            L.fin[HH - 1] = ((br >> 32) << 1) | ((bk >> 2) & 1ull) | (((bk >> 3) & 1ull) << 33);
         }
     }
     constexpr int STG_B = PYDEM_STG_B;
@@ -672,8 +683,8 @@ __device__ __forceinline__ void tile_stage(const SweepArgs &A, TileW &L, uint32_
             L.cs[lane + 64 * (kb + k)] = ((wst[k] == 0xFFFFFFFFu ? 0u : (wst[k] & CI_STATIC_MASK)) << 16) | ((f ? 1u : 0u) << SP_STATE_SHIFT);
             const unsigned long long b = __ballot(f);
             if (lane == 0) {
-                L.fin[r + 1] = ((b & 0xFFFFFFFFull) << 1) | ((colL >> r) & 1u) | ((unsigned long long)((colR >> r) & 1u) << 33);
-                L.fin[r + 2] = ((b >> 32) << 1) | ((colL >> (r + 1)) & 1u) | ((unsigned long long)((colR >> (r + 1)) & 1u) << 33);
+                L.fin[r + 1] = ((b & 0xFFFFFFFFull) << 1) | ((colL >> r) & 1ull) | (((colR >> r) & 1ull) << 33);
+                L.fin[r + 2] = ((b >> 32) << 1) | ((colL >> (r + 1)) & 1ull) | (((colR >> (r + 1)) & 1ull) << 33);
             }
         }
     }
@@ -685,7 +696,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
                                                int32_t *pend, int &npend)
 {
     const int by = tid / tiles_x, bx = tid - by * tiles_x;
-    const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
+    const int i0 = by * TH, j0 = bx * TT, n = A.n, m = A.m;
     const int half = lane >> 5, l32 = lane & 31;         // interior cell k of a lane: row 2k + half, column l32 of the tile
     // ready-list push; `consumed` = entries already processed (ring occupancy = tail - consumed)
     auto push_ready = [&](int cell, int consumed) {
@@ -702,8 +713,8 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
     int nrounds = 0;
     if (prof) tk0 = wall_clock64();
     if (lane == 0) { L.tail = 0; L.limit = INT32_MAX; }
-    const double a0_row = (lane < TT && i0 + lane < n) ? A.a0[i0 + lane] : 0.0;       // lands in LDS once the final bitmap is no longer needed
-    constexpr int NSET = TT * TT / 64;
+    const double a0_row = (lane < TH && i0 + lane < n) ? A.a0[i0 + lane] : 0.0;       // lands in LDS once the final bitmap is no longer needed
+    constexpr int NSET = TH * TT / 64;
     tile_stage(A, L, pass, i0, j0, lane);
     tile_wave_sync();
     if (prof) tk1 = wall_clock64();
@@ -754,7 +765,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
                     const bool va = e < A.n_pit && da == c, vb = va && e + 1 < A.n_pit && db == c;
                     auto blocked = [&](int32_t sc) -> uint32_t {
                         const int si = sc / m - i0, sj = sc % m - j0;
-                        if (si >= 0 && si < TT && sj >= 0 && sj < TT)
+                        if (si >= 0 && si < TH && sj >= 0 && sj < TT)
                             return sp_state(L, si * TT + sj) ? 0u : 1u;          // released on chip when the pit finishes
                         const uint32_t lv = ci_level(A.cinfo[sc]);
                         return (lv >= 1 && lv < pass) ? 0u : SP_BLOCKED;                   // another tile's business: blocked for this pass
@@ -771,7 +782,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
         }
     }
     tile_wave_sync();
-    if (lane < TT) L.a0[lane] = a0_row;                  // (the final bitmap is dead now)
+    if (lane < TH) L.a0[lane] = a0_row;                  // (the final bitmap is dead now)
     tile_wave_sync();
     // ---- rounds: the ready cells [head, tail) are processed, the targets they release are appended
     if (prof) tk2 = wall_clock64();
@@ -848,7 +859,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
             // next pass (listing a tile whose cell still waits for somebody else costs one idle staging; whoever
             // finishes last lists it again)
             auto release = [&](int ti, int tj, double share, bool chainable) {      // tile-local coordinates 1..TT when inside
-                if (ti >= 1 && ti <= TT && tj >= 1 && tj <= TT) {
+                if (ti >= 1 && ti <= TH && tj >= 1 && tj <= TT) {
                     const int tcell = (ti - 1) * TT + (tj - 1);
                     if (sp_dec(L, tcell) == 1u) {
                         if (chainable && next < 0) {
@@ -859,10 +870,10 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
                 } else if (LISTED) {
                     // (out-edges only exist towards cells of the grid.)  The eight neighbour tiles are woken once, after
                     // the rounds: two dependent returning atomics per cell would sit on every round's critical path
-                    const int dti = ti < 1 ? -1 : (ti > TT ? 1 : 0), dtj = tj < 1 ? -1 : (tj > TT ? 1 : 0);
-                    if (ti >= 1 - TT && ti <= 2 * TT && tj >= 1 - TT && tj <= 2 * TT) wake |= 1u << ((dti + 1) * 3 + dtj + 1);
+                    const int dti = ti < 1 ? -1 : (ti > TH ? 1 : 0), dtj = tj < 1 ? -1 : (tj > TT ? 1 : 0);
+                    if (ti >= 1 - TH && ti <= 2 * TH && tj >= 1 - TT && tj <= 2 * TT) wake |= 1u << ((dti + 1) * 3 + dtj + 1);
                     else {                                            // a pit draining further away than the next tile
-                        const int tt = ((i0 + ti - 1) / TT) * tiles_x + (j0 + tj - 1) / TT;
+                        const int tt = ((i0 + ti - 1) / TH) * tiles_x + (j0 + tj - 1) / TT;
                         if (atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tt;
                     }
                 }
@@ -996,12 +1007,13 @@ __global__ __launch_bounds__(256, 6) void k_sweep_tiles_listed(SweepArgs A, uint
 // takes the generic visit (sweep_one_tile).  The sum of a cell's in-edges is taken over the final ones first and the
 // ones finished in this visit second, both ascending (the generic visit: ascending over all of them).
 constexpr int RCAP = 256;
-constexpr uint32_t RS_TAINT = 1u << 18, RS_FIN = 1u << 19;      // slot word: bits 0-9 cell, 10-17 in-edges from cells open at setup
-constexpr int RS_OPEN_SHIFT = 10, RS_FINAL_SHIFT = 20;          //            bits 20-27 in-edges from cells final at setup
+constexpr uint32_t RS_TAINT = 1u << 19, RS_FIN = 1u << 20;      // slot word: bits 0-10 cell, 11-18 in-edges from cells open at setup
+constexpr int RS_OPEN_SHIFT = 11, RS_FINAL_SHIFT = 21;          //            bits 21-28 in-edges from cells final at setup
+constexpr uint32_t RS_CELL = (1u << RS_OPEN_SHIFT) - 1u, RS_CELL_OPEN = (1u << 19) - 1u;
 
 struct TileR {
     TileW W;                    // staging, final bitmap, count-downs as in the generic visit; W.list = ready SLOTS (each enters once)
-    uint16_t map[TT * TT];      // cell -> slot (only read for cells that were open at setup)
+    uint16_t map[TH * TT];      // cell -> slot (only read for cells that were open at setup)
     double Kd[RCAP];            // constant part while the cell is open, its area once it is finished
     double Pd[RCAP];            // proportion
     uint32_t sm[RCAP];          // slot word
@@ -1029,11 +1041,11 @@ __device__ __forceinline__ void sweep_tile_resident(const SweepArgs &A, TileR &R
 {
     TileW &L = R.W;
     const int by = tid / tiles_x, bx = tid - by * tiles_x;
-    const int i0 = by * TT, j0 = bx * TT, n = A.n, m = A.m;
+    const int i0 = by * TH, j0 = bx * TT, n = A.n, m = A.m;
     const int half = lane >> 5, l32 = lane & 31;
-    constexpr int NSET = TT * TT / 64;
+    constexpr int NSET = TH * TT / 64;
     if (lane == 0) L.tail = 0;
-    const double a0_row = (lane < TT && i0 + lane < n) ? A.a0[i0 + lane] : 0.0;
+    const double a0_row = (lane < TH && i0 + lane < n) ? A.a0[i0 + lane] : 0.0;
     tile_stage(A, L, pass, i0, j0, lane);
     tile_wave_sync();
     // ---- setup: open-upstream counts (as in the generic visit) and a slot per open cell
@@ -1072,7 +1084,7 @@ __device__ __forceinline__ void sweep_tile_resident(const SweepArgs &A, TileR &R
             for (int32_t e = pit_stash(A, c).x; e < A.n_pit && A.pin_dst[e] == c; e++) {
                 const int32_t sc = A.pin_src[e];
                 const int si = sc / m - i0, sj = sc % m - j0;
-                if (si >= 0 && si < TT && sj >= 0 && sj < TT) cnt += sp_state(L, si * TT + sj) ? 0u : 1u;
+                if (si >= 0 && si < TH && sj >= 0 && sj < TT) cnt += sp_state(L, si * TT + sj) ? 0u : 1u;
                 else { const uint32_t lv = ci_level(A.cinfo[sc]); if (!(lv >= 1 && lv < pass)) cnt |= SP_BLOCKED; }
             }
             sp_of(L, cell) = (uint16_t)cnt;
@@ -1080,12 +1092,12 @@ __device__ __forceinline__ void sweep_tile_resident(const SweepArgs &A, TileR &R
         }
     }
     tile_wave_sync();
-    if (lane < TT) L.a0[lane] = a0_row;                  // (the final bitmap is dead now)
+    if (lane < TH) L.a0[lane] = a0_row;                  // (the final bitmap is dead now)
     tile_wave_sync();
     // ---- the constant part of every open cell: all its loads in flight together
     for (int s = lane; s < nslot; s += 64) {
         uint32_t smv = R.sm[s];
-        const int cell = smv & 1023;
+        const int cell = smv & RS_CELL;
         const int gi = i0 + (cell >> 5), gj = j0 + (cell & 31);
         const int32_t c = gi * m + gj;
         const uint32_t cw = L.cs[cell] >> 16;
@@ -1104,7 +1116,7 @@ __device__ __forceinline__ void sweep_tile_resident(const SweepArgs &A, TileR &R
         for (int q = 0; q < 4; q++) { K += fabs(xs[q]); td = td || (xs[q] < 0); }
         while (mm) { const int d = __ffs(mm) - 1; mm &= mm - 1u; const double x = in_edge(A, c, m, d); K += fabs(x); td = td || (x < 0); }
         R.Kd[s] = K; R.Pd[s] = pv;
-        R.sm[s] = (smv & 0x3FFFFu) | (td ? RS_TAINT : 0u);
+        R.sm[s] = (smv & RS_CELL_OPEN) | (td ? RS_TAINT : 0u);
     }
     tile_lds_sync();
     // ---- rounds on LDS
@@ -1119,7 +1131,7 @@ __device__ __forceinline__ void sweep_tile_resident(const SweepArgs &A, TileR &R
             // the other branch of a braided river waits in the list meanwhile)
             const int s = L.list[idx];
             const uint32_t smv = R.sm[s];
-            const int cell = smv & 1023, li = cell >> 5, lj = cell & 31;
+            const int cell = smv & RS_CELL, li = cell >> 5, lj = cell & 31;
             const uint32_t cw = L.cs[cell] >> 16;
             double a = R.Kd[s];
             bool td = (smv & RS_TAINT) != 0u;
@@ -1139,22 +1151,22 @@ __device__ __forceinline__ void sweep_tile_resident(const SweepArgs &A, TileR &R
                     const int32_t sc = A.pin_src[e];
                     const int si = sc / m - i0, sj = sc % m - j0;
                     bool here = false;
-                    if (si >= 0 && si < TT && sj >= 0 && sj < TT) here = sp_state(L, si * TT + sj) == 2u;      // finished in this visit
+                    if (si >= 0 && si < TH && sj >= 0 && sj < TT) here = sp_state(L, si * TT + sj) == 2u;      // finished in this visit
                     if (here) { const int ss = R.map[si * TT + sj]; a += R.Kd[ss] * A.pin_w[e]; td = td || (R.sm[ss] & RS_TAINT); }
                     else { a += A.area[sc] * A.pin_w[e]; td = td || (A.todo_work[sc] != 0); }
                 }
             R.Kd[s] = a;
-            R.sm[s] = (smv & 0x3FFu) | (td ? RS_TAINT : 0u) | RS_FIN;
+            R.sm[s] = (smv & RS_CELL) | (td ? RS_TAINT : 0u) | RS_FIN;
             sp_of(L, cell) = (uint16_t)(2u << SP_STATE_SHIFT);
             auto release = [&](int ti, int tj) {            // tile-local coordinates 0..TT-1 when inside
-                if (ti >= 0 && ti < TT && tj >= 0 && tj < TT) {
+                if (ti >= 0 && ti < TH && tj >= 0 && tj < TT) {
                     const int tcell = ti * TT + tj;
                     if (sp_dec(L, tcell) == 1u) L.list[atomicAdd(&L.tail, 1)] = R.map[tcell];
                 } else {
-                    const int dti = ti < 0 ? -1 : (ti >= TT ? 1 : 0), dtj = tj < 0 ? -1 : (tj >= TT ? 1 : 0);
-                    if (ti >= -TT && ti < 2 * TT && tj >= -TT && tj < 2 * TT) wake |= 1u << ((dti + 1) * 3 + dtj + 1);
+                    const int dti = ti < 0 ? -1 : (ti >= TH ? 1 : 0), dtj = tj < 0 ? -1 : (tj >= TT ? 1 : 0);
+                    if (ti >= -TH && ti < 2 * TH && tj >= -TT && tj < 2 * TT) wake |= 1u << ((dti + 1) * 3 + dtj + 1);
                     else {
-                        const int tt = ((i0 + ti) / TT) * tiles_x + (j0 + tj) / TT;
+                        const int tt = ((i0 + ti) / TH) * tiles_x + (j0 + tj) / TT;
                         if (atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tt;
                     }
                 }
@@ -1176,7 +1188,7 @@ __device__ __forceinline__ void sweep_tile_resident(const SweepArgs &A, TileR &R
     for (int s = lane; s < nslot; s += 64) {
         const uint32_t smv = R.sm[s];
         if (!(smv & RS_FIN)) continue;
-        const int cell = smv & 1023;
+        const int cell = smv & RS_CELL;
         const int32_t c = (i0 + (cell >> 5)) * m + j0 + (cell & 31);
         const uint32_t cw = L.cs[cell] >> 16;
         const double a = R.Kd[s], pv = R.Pd[s];
@@ -1400,7 +1412,7 @@ __global__ void k_tiles_of_frontier(const QE *__restrict__ q, const int32_t *nq,
     const int32_t n = *nq;
     for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const int32_t c = q[k].c;
-        const int tt = (c / m / TT) * tiles_x + (c % m) / TT;
+        const int tt = (c / m / TH) * tiles_x + (c % m) / TT;
         if (atomicExch(&N.flag[tt], stamp) != stamp) N.list[atomicAdd(N.count, 1)] = tt;
     }
 }
@@ -2679,7 +2691,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     if (A.n_pit > 0)   // the unused area slots of pit sources / drains carry their edge-list offsets until they are processed
         hipLaunchKernelGGL(k_pit_stash, dim3(grid_for(A.n_pit, 2048)), dim3(256), 0, t->stream, A.pin_dst, A.pit_src, A.n_pit, t->uca);
     // ---- tile-local passes until they stop paying, then the queue rounds take over
-    const int tiles_x = (int)cdiv(m, TT), tiles_total = tiles_x * (int)cdiv(n, TT);
+    const int tiles_x = (int)cdiv(m, TT), tiles_total = tiles_x * (int)cdiv(n, TH);
     // scratch: tile_done bytes | per-tile "listed for pass" stamps | two tile lists | open cells per tile
     const size_t tiles_pad = ((size_t)tiles_total + 255) & ~(size_t)255;
     const size_t scratch_need = tiles_pad * (1 + 4 + 4 + 4 + 4);
@@ -2788,7 +2800,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         // the LDS latency per cell is not hidden any more), and pass 2 inherits the cells with pit edges -- not the default
         static int first_kind = -1;
         if (first_kind < 0) { const char *e = getenv("PYDEM_SWEEP_FIRST"); first_kind = (e && !strcmp(e, "lds")) ? 1 : 0; }
-        if (first_kind == 1)
+        if (first_kind == 1 && TH == 32)
             hipLaunchKernelGGL(k_sweep_first, dim3((unsigned)(((tiles_total + 7) / 8) * 8)), dim3(256), 0, t->stream, A, tiles_x, tiles_total, tile_done, total);
         else {
             TileNext N0; N0.flag = nullptr; N0.list = nullptr; N0.count = nullptr;
