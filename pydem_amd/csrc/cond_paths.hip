@@ -628,21 +628,23 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     if (!t->spacing_set) { pydem_set_error("pit drain paths: call pydem_tile_set_spacing first"); return -3; }
     if (max_iter > 300) return 1;                             // the large window is sized for the reference's 300 iterations
     // speculation window and large-window simulations per round: measured on the 8192^2 SRTM-like tile (341 090 pits, 4885 of
-    // them plateau pits): 32768 / 256 -> 56 rounds, 247 ms; 131072 / 2048 -> 26 rounds, 170 ms; larger does not pay
+    // them plateau pits): 32768 / 256 -> 56 rounds, 247 ms; 131072 / 2048 -> 26 rounds, 170 ms; larger does not pay.  With the medium
+    // window (its scratch blocks are 65 k entries instead of 410 k): 131072 / 4096 is 3 ms faster than / 2048, 8192 no better
     static int win_cap = -1, big_env = -1;
     if (win_cap < 0) { const char *e = getenv("PYDEM_PATHS_WINDOW"); win_cap = e ? atoi(e) : 131072; if (win_cap < 64) win_cap = 64; }
-    if (big_env < 0) { const char *e = getenv("PYDEM_PATHS_BIG"); big_env = e ? atoi(e) : 2048; if (big_env < 1) big_env = 1; }
+    if (big_env < 0) { const char *e = getenv("PYDEM_PATHS_BIG"); big_env = e ? atoi(e) : 4096; if (big_env < 1) big_env = 1; }
     int big_max = big_env;
     struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
     const int W = (int)(npits < win_cap ? npits : win_cap);
     const int FCAP = STCAP + SRCAP, CCAP = STCAP + 1;
     const int64_t BIGF = std::min<int64_t>((int64_t)BWIN * BWIN, t->NN);   // footprint / trail capacity of a large-window simulation
     if ((int64_t)big_max > npits) big_max = (int)npits;
+    const int64_t MIDF = std::min<int64_t>((int64_t)MWIN * MWIN, t->NN);    // ... of a medium-window one
     ArenaLease lease;
     PYDEM_TRY(arena_acquire(t->device, &lease));
     Buf b_bown, b_rstamp, b_tent, b_tier;
     Buf b_order, b_window, b_rown, b_wown, b_stamp, b_status, b_nF, b_nC, b_iters, b_F, b_C, b_CV, b_flags, b_done, b_counts, b_slots,
-        b_backup, b_bigtrail, b_bigF, b_bigC, b_bigCV, b_Fp, b_Cp, b_CVp, b_fcap, b_ccap;
+        b_backup, b_bigtrail, b_bigF, b_bigC, b_bigCV, b_midtrail, b_midF, b_midC, b_midCV, b_Fp, b_Cp, b_CVp, b_fcap, b_ccap;
     PYDEM_TRY(b_order.get(lease, (size_t)npits * 4)); PYDEM_TRY(b_window.get(lease, (size_t)W * 4));
     PYDEM_TRY(b_rown.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_wown.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_stamp.get(lease, (size_t)t->NN * 4));
     PYDEM_TRY(b_bown.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_rstamp.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_tent.get(lease, (size_t)W * 4)); PYDEM_TRY(b_tier.get(lease, (size_t)W * 4));
@@ -691,6 +693,9 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     const size_t mid_lds = (size_t)2 * (MWIN * MWIN / 8) + (size_t)MRCAP * 12 + 64 * 4 + (size_t)MRCAP * 2;
     static int use_mid = -1;          // PYDEM_PATHS_MID=0: every pit that leaves the small window goes straight to the large one
     if (use_mid < 0) { const char *e = getenv("PYDEM_PATHS_MID"); use_mid = e ? atoi(e) : 1; }
+    static int large_env = -1;        // large-window simulations per round when the medium window exists (they are rare: 77 of 14 k on the SRTM-like tile)
+    if (large_env < 0) { const char *e = getenv("PYDEM_PATHS_LARGE"); large_env = e ? atoi(e) : 512; if (large_env < 1) large_env = 1; }
+    const int large_max = use_mid ? (big_max < large_env ? big_max : large_env) : big_max;
     int64_t mid_runs = 0;
     bool big_ready = false;
     HIP_TRY(hipStreamSynchronize(t->stream));
@@ -717,36 +722,52 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         // the medium / large-window simulations of a round: entry q of `big` owns block q of the scratch arrays.  Those of
         // the pits whose tier is known run on the side stream BESIDE the small-window kernel (all simulations of a round read
         // the same committed surface); what the small-window kernel newly sends on follows on the main stream.
+        int k_limit = 0x7FFFFFFF, mid_used = 0, large_used = 0;      // blocks of the two scratch pools handed out in this round
         auto launch_large = [&](const std::vector<int> &qs, size_t stage_at, hipStream_t st, int close_round) -> int {
             if (!big_ready) {
-                PYDEM_TRY(b_bigtrail.get(lease, (size_t)big_max * BIGF * 4));
-                PYDEM_TRY(b_bigF.get(lease, (size_t)big_max * BIGF * 4));
-                PYDEM_TRY(b_bigC.get(lease, (size_t)big_max * (BIGF + 1) * 4));
-                PYDEM_TRY(b_bigCV.get(lease, (size_t)big_max * (BIGF + 1) * 8));
+                // scratch blocks (trail, footprint, chain, chain values) sized by window: one pool per tier
+                PYDEM_TRY(b_bigtrail.get(lease, (size_t)large_max * BIGF * 4));
+                PYDEM_TRY(b_bigF.get(lease, (size_t)large_max * BIGF * 4));
+                PYDEM_TRY(b_bigC.get(lease, (size_t)large_max * (BIGF + 1) * 4));
+                PYDEM_TRY(b_bigCV.get(lease, (size_t)large_max * (BIGF + 1) * 8));
+                if (use_mid) {
+                    PYDEM_TRY(b_midtrail.get(lease, (size_t)big_max * MIDF * 4));
+                    PYDEM_TRY(b_midF.get(lease, (size_t)big_max * MIDF * 4));
+                    PYDEM_TRY(b_midC.get(lease, (size_t)big_max * (MIDF + 1) * 4));
+                    PYDEM_TRY(b_midCV.get(lease, (size_t)big_max * (MIDF + 1) * 8));
+                }
                 HIP_TRY(hipFuncSetAttribute((const void *)k_paths_big<BWIN, BRCAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
                 HIP_TRY(hipFuncSetAttribute((const void *)k_paths_big<MWIN, MRCAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mid_lds));
                 big_ready = true;
             }
             const int nb = (int)qs.size();
             if (nb == 0) return 0;
-            // staging: [(slot, q) of the medium ones | (slot, q) of the large ones]
-            int nm = 0, nl = 0;
+            // staging: [(slot, block) of the medium ones | (slot, block) of the large ones | (slot, 0) of the large ones left out]
+            // A round has room for large_max large-window simulations; a pit left out is not simulated and closes the round for
+            // everybody from it on (k_limit), like the pits beyond big_max.
+            int nm = 0, nl = 0, nd = 0;
             for (int q : qs) if (tier[(size_t)pending[(size_t)big[(size_t)q]]] == 1) nm++;
-            int32_t *ms = pin_slots + 2 * stage_at, *mq = ms + nm, *ls = mq + nm, *lq = ls + (nb - nm);
+            int nl_room = large_max - large_used; if (nl_room < 0) nl_room = 0;
+            const int nl_all = nb - nm, nl_take = nl_all < nl_room ? nl_all : nl_room;
+            int32_t *ms = pin_slots + 2 * stage_at, *mq = ms + nm, *ls = mq + nm, *lq = ls + nl_take, *ds = lq + nl_take, *dq = ds + (nl_all - nl_take);
             nm = 0;
             for (int q : qs) {
-                if (tier[(size_t)pending[(size_t)big[(size_t)q]]] == 1) { ms[nm] = big[(size_t)q]; mq[nm++] = q; }
-                else { ls[nl] = big[(size_t)q]; lq[nl++] = q; }
+                const int slot = big[(size_t)q], kk = pending[(size_t)slot];
+                if (tier[(size_t)kk] == 1) { ms[nm] = slot; mq[nm++] = mid_used++; }
+                else if (nl < nl_take) { ls[nl] = slot; lq[nl++] = large_used++; }
+                else { ds[nd] = slot; dq[nd++] = 0; if (kk < k_limit) k_limit = kk; }
             }
             int32_t *d_ms = (int32_t *)b_slots.p + 2 * stage_at;
             HIP_TRY(hipMemcpyAsync(d_ms, ms, (size_t)nb * 8, hipMemcpyHostToDevice, st));
-            const int32_t *d_mq = d_ms + nm, *d_ls = d_mq + nm, *d_lq = d_ls + nl;
-            if (nm) hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nm, 64)), dim3(256), 0, st, A, (const int32_t *)d_ms, d_mq, nm, (int32_t *)b_bigF.p,
-                                       (int32_t *)b_bigC.p, (double *)b_bigCV.p, BIGF, BIGF + 1);
+            const int32_t *d_mq = d_ms + nm, *d_ls = d_mq + nm, *d_lq = d_ls + nl, *d_ds = d_lq + nl, *d_dq = d_ds + nd;
+            if (nm) hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nm, 64)), dim3(256), 0, st, A, (const int32_t *)d_ms, d_mq, nm, (int32_t *)b_midF.p,
+                                       (int32_t *)b_midC.p, (double *)b_midCV.p, MIDF, MIDF + 1);
             if (nl) hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nl, 64)), dim3(256), 0, st, A, d_ls, d_lq, nl, (int32_t *)b_bigF.p,
                                        (int32_t *)b_bigC.p, (double *)b_bigCV.p, BIGF, BIGF + 1);
+            if (nd) hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nd, 64)), dim3(256), 0, st, A, d_ds, d_dq, nd, (int32_t *)b_bigF.p,      // (state "pending": not simulated)
+                                       (int32_t *)b_bigC.p, (double *)b_bigCV.p, BIGF, BIGF + 1);
             if (nl) hipLaunchKernelGGL((k_paths_big<BWIN, BRCAP>), dim3(nl), dim3(64), big_lds, st, A, d_ls, d_lq, nl, (int32_t *)b_bigtrail.p, BIGF, 0);
-            if (nm) hipLaunchKernelGGL((k_paths_big<MWIN, MRCAP>), dim3(nm), dim3(64), mid_lds, st, A, (const int32_t *)d_ms, d_mq, nm, (int32_t *)b_bigtrail.p, BIGF,
+            if (nm) hipLaunchKernelGGL((k_paths_big<MWIN, MRCAP>), dim3(nm), dim3(64), mid_lds, st, A, (const int32_t *)d_ms, d_mq, nm, (int32_t *)b_midtrail.p, MIDF,
                                        close_round);
             big_runs += nl; mid_runs += nm;
             return 0;
@@ -781,7 +802,6 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
             uint8_t &tr = tier[(size_t)pending[(size_t)s]];
             if (tr == 0 && h_status[(size_t)s] == ST_OVERFLOW) { big.push_back(s); tr = use_mid ? 1 : 2; }
         }
-        int k_limit = 0x7FFFFFFF;
         // as many medium / large-window simulations as one launch holds take part in this round; the first one left out
         // closes the round for everybody after it: a pit commits only when every earlier pending pit was simulated
         if ((int)big.size() > big_max) {

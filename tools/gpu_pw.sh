@@ -1,7 +1,7 @@
 #!/bin/bash
 # pit drain paths: speculation window / large simulations per round
 mkdir -p gpurun_out/coop
-for cfg in "131072 2048" "262144 4096" "262144 2048" "65536 2048" "524288 8192" "131072 4096"; do
+for cfg in ${PW_CFGS:-"131072 2048" "131072 4096" "131072 8192" "196608 4096" "131072 2048" "131072 4096"}; do
 set -- $cfg
 PYDEM_PATHS_DEBUG=1 PYDEM_PATHS_WINDOW=$1 PYDEM_PATHS_BIG=$2 timeout 300 python bench.py --config 5 --steps 2 --warmup 1 > gpurun_out/coop/b.json 2> gpurun_out/coop/b.err
 python - "$cfg" <<'PY'
