@@ -397,19 +397,13 @@ __global__ void k_centre_pass(CondArgs A, Regions R, int pass)
             if (want) { const int i = c / m, j = c - i * m; k = dkey(centre_dist(R, r, i, j, n, m)); }
         }
         if (!__ballot(want)) continue;
-        int32_t r0;
-        if (one_region(valid, r, r0)) {
-            if (pass == 0) {
-                const unsigned long long kw = wave_min(want ? k : ~0ull);
-                if ((threadIdx.x & 63) == 0) atomicMin(&R.cdist_bits[r0], kw);
-            } else {
-                const unsigned long long best = R.cdist_bits[r0];
-                const int cw = wave_min((want && k == best) ? c : 0x7FFFFFFF);
-                if ((threadIdx.x & 63) == 0 && cw != 0x7FFFFFFF) atomicMin(&R.centre[r0], cw);
-            }
-        } else if (want) {
-            if (pass == 0) atomicMin(&R.cdist_bits[r], k);
-            else if (k == R.cdist_bits[r]) atomicMin(&R.centre[r], c);
+        const Runs rq = wave_runs(valid, r);
+        if (pass == 0) {
+            const unsigned long long kw = run_reduce(want ? k : ~0ull, rq, OpMin());
+            if (rq.head && kw != ~0ull) atomicMin(&R.cdist_bits[r], kw);
+        } else {
+            const int cw = run_reduce((want && k == R.cdist_bits[r]) ? c : 0x7FFFFFFF, rq, OpMin());
+            if (rq.head && cw != 0x7FFFFFFF) atomicMin(&R.centre[r], cw);
         }
     }
 }
