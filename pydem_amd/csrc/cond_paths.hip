@@ -492,9 +492,12 @@ __global__ __launch_bounds__(256) void k_paths_commit(PathArgs A, int32_t *done,
     for (int q = lane; q < nF; q += 64) atomicMax(&A.rstamp[F[q]], k);
     if (lane == 0) {
         done[slot] = 1;
-        atomicAdd(&counts[0], 1);
+        // (single addresses: one atomic per committed pit on each of them kept their L2 channel busy for the length of the kernel
+        // -- 48 k commits per round.  Nobody reads a count of commits; the maximum is only sent when it would change what a
+        // plain load sees)
         if (st == ST_FAILED) atomicAdd(&counts[1], 1);
-        atomicMax(&counts[2], A.iters[slot]);
+        const int32_t its = A.iters[slot];
+        if (its > __hip_atomic_load(&counts[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&counts[2], its);
     }
 }
 
