@@ -181,13 +181,23 @@ def run_config5(args):
         "not_in_value": {"h2d_ms": stages['h2d_ms'], "what": "upload of the raw int16 tile (pageable host memory) at the start of the step"}}))
 
 
-def pmc_traffic(kernels, size):
+def csrc_hashes():
+    """sha256 per kernel source file (pydem_amd/csrc/*): the identity of the kernels a PMC profile was collected from"""
+    import hashlib
+    d = os.path.join(ROOT, 'pydem_amd', 'csrc')
+    return {f: hashlib.sha256(open(os.path.join(d, f), 'rb').read()).hexdigest() for f in sorted(os.listdir(d))}
+
+
+def pmc_traffic(kernels, size, sources=()):
     """HBM bytes per STEP of the kernels whose names contain one of `kernels` (a name or a tuple of names), from the
     committed rocprofv3 PMC passes (profiles/r*_pmc_fetch_write_16384*.csv: separate FETCH_SIZE / WRITE_SIZE runs of
     this same command with --steps 1 --warmup 0, so `dispatches` is per step).  FETCH_SIZE counts half of the bytes of
     wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section; calibrated on k_twi in profiles/README.md), so
     bytes = (2 * FETCH_KiB + WRITE_KiB) * 1024, summed over the dispatches.  None when no profile of this tile size is
-    present (PMC counters cannot be read from inside the timed process)."""
+    present (PMC counters cannot be read from inside the timed process) -- or when the profile is STALE: every profile
+    carries the sha256 of the kernel sources it was collected from (<csv>.meta.json, tools/csrc_stamp.py); `sources` are
+    the files of this stage's kernels, and a profile whose hashes of them (or of internal.h) differ from the tree's is not
+    quoted."""
     import csv
     import glob
     if size != 16384:
@@ -195,7 +205,14 @@ def pmc_traffic(kernels, size):
     if isinstance(kernels, str):
         kernels = (kernels,)
     best = None
+    now = csrc_hashes()
     for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_fetch_write_16384*.csv'))):
+        meta = fn[:-4] + '.meta.json'
+        if not os.path.exists(meta):
+            continue
+        then = json.load(open(meta)).get('csrc_sha256', {})
+        if any(then.get(f) != now.get(f) for f in tuple(sources) + ('internal.h',)):
+            continue
         tot = {'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0}
         seen = set()
         for row in csv.DictReader(open(fn)):
@@ -209,14 +226,16 @@ def pmc_traffic(kernels, size):
     return best
 
 
-# stages of the step for `roofline_stages`: (name, kernels of the stage, algorithmic bytes per cell, timing key, what the bytes are)
+# stages of the step for `roofline_stages`: (name, kernels of the stage, algorithmic bytes per cell, timing key, what the bytes are,
+# source files of the kernels: `traffic` is only quoted from a PMC profile of these very sources)
 STAGES = [
-    ('stencil', ('k_stencil_march', 'k_stencil_perimeter'), 24.0, 'stencil_kernel_ms', 'read elev 8 + write mag 8 + direction 8'),
+    ('stencil', ('k_stencil_march', 'k_stencil_perimeter'), 24.0, 'stencil_kernel_ms', 'read elev 8 + write mag 8 + direction 8',
+     ('stencil.hip',)),
     ('pits', ('k_pits_', 'k_pitmask', 'k_pit_keys', 'k_pit_gather', 'radix_sort'), 9.4, 'pits_ms',
-     'read elev 8 + flats 1 per cell + write 16 B per pit edge (6.49 M edges on the bench tile: 0.4 B/cell)'),
+     'read elev 8 + flats 1 per cell + write 16 B per pit edge (6.49 M edges on the bench tile: 0.4 B/cell)', ('pits.hip',)),
     ('sweep', ('k_sweep_tiles', 'k_pit_stash', 'k_uca_finalize'), 40.0, 'sweep_ms',
-     'read graph word 4 + proportion 8, write area 8 + two contributions 16 + level stamp 4 per cell'),
-    ('twi', ('k_twi',), 24.0, 'twi_ms', 'read uca 8 + mag 8, write twi 8'),
+     'read graph word 4 + proportion 8, write area 8 + two contributions 16 + level stamp 4 per cell', ('uca.hip',)),
+    ('twi', ('k_twi',), 24.0, 'twi_ms', 'read uca 8 + mag 8, write twi 8', ('uca.hip',)),
 ]
 
 
@@ -299,7 +318,7 @@ def main():
         phase['edge_fixup_ms'] = (t2 - t1) * 1e3
         tmk = pm.tiles[mine[0]]._tile.timings()
         stencil_ms.append(tmk['stencil_kernel_ms'])
-        for _, _, _, key, _ in STAGES:
+        for _, _, _, key, _, _ in STAGES:
             stage_ms.setdefault(key, []).append(tmk[key])
 
     def barrier():
@@ -334,14 +353,14 @@ def main():
         achieved = STENCIL_BYTES_PER_CELL * cells / (st_ms * 1e-3) / 1e9
         ms_step = dt / args.steps * 1e3
         stages = []
-        for name, kernels, bpc, key, what in STAGES:
+        for name, kernels, bpc, key, what, srcs in STAGES:
             ms = sum(stage_ms[key]) / len(stage_ms[key])
             if ms <= 0:
                 continue
             gbs = bpc * cells / (ms * 1e-3) / 1e9
             stages.append({"stage": name, "kernels": list(kernels), "ms": ms, "share_of_step": ms / ms_step,
                            "algorithmic_bytes": bpc * cells, "algorithmic_bytes_per_cell": bpc, "bytes_are": what,
-                           "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(kernels, n)})
+                           "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(kernels, n, srcs)})
         dom = max(stages, key=lambda d: d["ms"])
         out = {
             "metric": "Mcells/s (slope+aspect+UCA+TWI end-to-end) per tile; % HBM roofline",
@@ -364,7 +383,7 @@ def main():
             "roofline_stages": stages,
             # the slope / aspect kernel alone: the kernel BASELINE.json's 40 % target is about
             "roofline_stencil": {"bound": "hbm", "kernel": "k_stencil_march", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_stencil_march", n),
+                                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_stencil_march", n, ('stencil.hip',)),
                                  "algorithmic_bytes": STENCIL_BYTES_PER_CELL * cells,
                                  "avg_kernel_ms": st_ms, "back_to_back_ms": st_b2b,
                                  "algorithmic_bytes_per_cell": STENCIL_BYTES_PER_CELL},

@@ -654,28 +654,30 @@ __global__ __launch_bounds__(1024) void k_flat_sweep_small(CondArgs A, Regions R
     // beyond FS_CAP go to the global list; if that happens the kernel completes the sweep, writes the LDS part behind them
     // and hands back to the multi-workgroup kernel.
     __shared__ int32_t s_list[2][FS_CAP];
-    __shared__ int32_t s_n[2];
+    __shared__ int32_t s_n[3];       // list lengths, rotating: [ci] the list being read, [ci + 1] the one being written, [ci + 2] cleared
     const int t = threadIdx.x;
     int32_t na = cnt3[sweep0 % 3];
     {
         const int32_t *wl_in = ((sweep0 - 1) & 1) ? al1 : al0;
         for (int32_t q = t; q < na; q += blockDim.x) s_list[0][q] = wl_in[q];      // (the host enters with na <= small_cap <= FS_CAP)
-        if (t < 2) s_n[t] = 0;
+        if (t < 3) s_n[t] = 0;
     }
     __syncthreads();
-    int in = 0, s = sweep0;
+    int in = 0, ci = 0, s = sweep0;
     for (; s < sweep0 + nsweeps; s++) {
         const int cur = (s - 1) & 1;
         int32_t *wl_out = cur ? al0 : al1;
         const double *dh0 = cur ? dhB : dhA, *dl0 = cur ? dlB : dlA;
         double *dh1 = cur ? dhA : dhB, *dl1 = cur ? dlA : dlB;
         for (int32_t q = t; q < na; q += blockDim.x)
-            flat_sweep_entry(A, R, s_list[in][q], wl_out, &s_n[in ^ 1], stamp, dh0, dh1, dl0, dl1, s, source_tol, s_list[in ^ 1], FS_CAP);
+            flat_sweep_entry(A, R, s_list[in][q], wl_out, &s_n[(ci + 1) % 3], stamp, dh0, dh1, dl0, dl1, s, source_tol, s_list[in ^ 1], FS_CAP);
+        // the counter the NEXT sweep appends to is cleared before the barrier: it was last read (as `na`) two barriers ago, and
+        // nobody adds to it in this sweep (a store after the barrier would race with the next sweep's LDS atomics)
+        if (t == 0) s_n[(ci + 2) % 3] = 0;
         __syncthreads();
-        na = s_n[in ^ 1];
+        ci = (ci + 1) % 3;
+        na = s_n[ci];
         in ^= 1;
-        __syncthreads();
-        if (t == 0) s_n[in ^ 1] = 0;
         if (na > FS_CAP) { s++; break; }            // the next list continues in global memory: back to the launches per sweep
     }
     // the list of sweep `s` (the next one to run) goes back to global memory with its length; the counter of the sweep after it is zero
@@ -695,9 +697,12 @@ __global__ __launch_bounds__(1024) void k_flat_sweep_small(CondArgs A, Regions R
 // that lists, distances and the counter stay in ONE L2; correctness does not depend on the placement.
 __device__ __forceinline__ void coop_barrier(int32_t *bar, int nwg, int &phase)
 {
+    // EVERY thread releases its own stores at agent scope before the workgroup barrier: a workgroup-scope barrier does not
+    // wait for the other wavefronts' global stores (vmcnt), so a fence in thread 0 alone would let a remote workgroup read
+    // stale distances / list entries of wavefronts 1-3 after it sees the arrival
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         phase++;
         __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase * nwg) __builtin_amdgcn_s_sleep(1);

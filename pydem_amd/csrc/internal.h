@@ -112,6 +112,7 @@ int tile_alloc(pydem_tile *t, T **p, size_t count);
 // largest request seen and is released by pydem_hip_release_scratch().
 struct ArenaLease {
     int device = -1;
+    void *arena = nullptr;              // the device's arena record (kept here: the destructor must not take the table lock while it holds `busy`)
     char *base = nullptr; size_t bytes = 0, off = 0, want = 0;
     std::vector<void *> extra;          // what did not fit this time (plain allocations, freed when the lease ends)
     bool held = false;

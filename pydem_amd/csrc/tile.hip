@@ -59,7 +59,7 @@ int arena_acquire(int device, ArenaLease *L)
 {
     DevArena *a = arena_of(device);
     a->busy.lock();
-    L->device = device; L->base = (char *)a->p; L->bytes = a->bytes; L->off = 0; L->want = 0; L->held = true;
+    L->device = device; L->arena = a; L->base = (char *)a->p; L->bytes = a->bytes; L->off = 0; L->want = 0; L->held = true;
     return 0;
 }
 
@@ -78,7 +78,7 @@ void *arena_take(ArenaLease *L, size_t bytes)
 ArenaLease::~ArenaLease()
 {
     if (!held) return;
-    DevArena *a = arena_of(device);
+    DevArena *a = static_cast<DevArena *>(arena);
     (void)hipSetDevice(device);
     for (void *q : extra) (void)hipFree(q);
     if (want > a->bytes) {              // next time everything fits
@@ -190,8 +190,14 @@ const char *pydem_hip_last_error(void) { return g_err; }
 
 int pydem_hip_release_scratch(void)
 {
-    std::lock_guard<std::mutex> g(g_arena_table);
-    for (auto &kv : g_arenas) {
+    // lock order: never `busy` under the table lock (a lease holds `busy` for the length of a conditioning stage; records are
+    // never deleted, so the snapshot stays valid)
+    std::vector<std::pair<int, DevArena *>> all;
+    {
+        std::lock_guard<std::mutex> g(g_arena_table);
+        for (auto &kv : g_arenas) all.push_back(kv);
+    }
+    for (auto &kv : all) {
         std::lock_guard<std::mutex> b(kv.second->busy);
         if (kv.second->p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second->p); kv.second->p = nullptr; kv.second->bytes = 0; }
     }

@@ -485,6 +485,7 @@ __device__ __forceinline__ void process_cell(const SweepArgs &A, bool active, QE
     }
 }
 
+#ifdef PYDEM_SWEEP_QUEUE      // the frontier-queue schedule: a diagnostic build only (python -m pydem_amd.build with PYDEM_HIPCC_FLAGS=-DPYDEM_SWEEP_QUEUE)
 // one frontier round; counters rotate over 3 slots: in = r%3, out = (r+1)%3, (r+2)%3 is cleared
 template <bool LOWLAT>
 __global__ __launch_bounds__(256) void k_sweep_round(SweepArgs A, const QE *__restrict__ qc, QE *__restrict__ qn,
@@ -559,6 +560,8 @@ __global__ __launch_bounds__(1024) void k_sweep_small(SweepArgs A, QE *q0, QE *q
         state[0] = r;
     }
 }
+
+#endif  // PYDEM_SWEEP_QUEUE
 
 // ------------------------------------------------------------------------------- K5b
 // Tile passes.  A queue round moves every flow path by ONE cell per kernel boundary and re-streams
@@ -1406,6 +1409,7 @@ __global__ __launch_bounds__(256) void k_sweep_first(SweepArgs A, int tiles_x, i
     }
 }
 
+#ifdef PYDEM_SWEEP_QUEUE
 // switch from queue rounds to listed tile passes: the tiles that hold the current frontier
 __global__ void k_tiles_of_frontier(const QE *__restrict__ q, const int32_t *nq, int m, int tiles_x, int32_t stamp, TileNext N)
 {
@@ -1453,6 +1457,8 @@ __global__ __launch_bounds__(256) void k_sweep_rebuild_frontier(SweepArgs A, uin
     }
     stage_flush(A, S, qn, cn, true);
 }
+
+#endif  // PYDEM_SWEEP_QUEUE
 
 __global__ void k_row_area(const double *__restrict__ dX2, const double *__restrict__ dY2, int n, double *a0)
 {
@@ -2680,9 +2686,12 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     PYDEM_TRY(tile_alloc(t, &t->row_area, (size_t)t->n));
     PYDEM_TRY(tile_alloc(t, &t->contrib, (size_t)t->NN * 2));
     t->circular_cells = 0;
+    int32_t *total = t->counters + 3;   // cells processed so far
+#ifdef PYDEM_SWEEP_QUEUE
     int32_t *cnt3 = t->counters;        // [0..2] rotating frontier sizes
-    int32_t *total = t->counters + 3;   // cells processed by rounds >= 1
     int32_t *nsrc = t->counters + 4;    // source cells (round 0)
+    int64_t done_prev = 0;
+#endif
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
     HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
     hipLaunchKernelGGL(k_row_area, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, t->stream, t->dX2, t->dY2, n, t->row_area);
@@ -2711,7 +2720,6 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     if (A.dbg & 4) HIP_TRY(hipMemsetAsync(t->counters + 32, 0, 24 * sizeof(int32_t), t->stream));
     int64_t launches = 0;
     uint32_t pass = 0;
-    int64_t done_prev = 0;
     static int lds_pad = -1;        // occupancy experiments only: extra dynamic LDS per workgroup (PYDEM_TILE_LDS_PAD)
     if (lds_pad < 0) { const char *e = getenv("PYDEM_TILE_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
     // listed tile passes from pass p on (the list of pass p is in tile_list[p % 2] / cntT[p % 3]); returns the next pass number
@@ -2789,8 +2797,15 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         }
         return 0;
     };
-    static int sweep_mode = -1;     // 0: tile passes only (default), 1: tile pass + queue rounds + listed tail
+    // 0: tile passes only (the product schedule), 1: tile pass + queue rounds + listed tail.  The queue schedule refuses
+    // some valid inputs (circular drainage it cannot finish, frontiers above NN/2 entries): it only exists in builds with
+    // -DPYDEM_SWEEP_QUEUE, a product build ignores PYDEM_SWEEP_MODE
+#ifdef PYDEM_SWEEP_QUEUE
+    static int sweep_mode = -1;
     if (sweep_mode < 0) { const char *e = getenv("PYDEM_SWEEP_MODE"); sweep_mode = (e && !strcmp(e, "queue")) ? 1 : 0; }
+#else
+    constexpr int sweep_mode = 0;
+#endif
     const unsigned full_grid = (unsigned)(((tiles_total + 31) / 32) * 8);
     if (sweep_mode == 0) {
         // pass 1 over every tile, pass 2 over every tile that is not done (it also lists the tiles of pass 3),
@@ -2826,6 +2841,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
                     acc[5], acc[6], acc[0], acc[1], acc[2], acc[4], acc[3]);
         }
     }
+#ifdef PYDEM_SWEEP_QUEUE
     if (sweep_mode == 1) {
     // every pass re-stages all tiles that still have an open cell (rivers cross most tiles), so after the
     // first pass (which finishes ~3/4 of the grid) the queue rounds are cheaper than another pass
@@ -2928,6 +2944,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     }
         PYDEM_TRY(replay_unfinished((uint32_t)r));
     }   // sweep_mode == 1
+#endif  // PYDEM_SWEEP_QUEUE
     if (t->h_counters[15] > 0) { pydem_set_error("sweep frontier exceeded the queue capacity (%lld entries)", (long long)A.qcap); return -5; }
     const int64_t processed = (int64_t)t->h_counters[3];     // tile passes + queue rounds ([4], [10]: tile-pass statistics)
     t->tm.n_unresolved = t->NN - processed;

@@ -563,6 +563,9 @@ class ProcessManager(object):
     def process_uca(self):
         """Reference :1032-1059 + worker calc_uca :94-197 (overlap-1 patch, find_flats, calc_uca)."""
         self._patch_overlap1_edges()
+        if self.processor_cls is DEMProcessor:
+            from . import _ffi
+            _ffi.release_scratch()         # the conditioning stages are over: their per-device arena (10-20 GB after a large tile) goes back
 
         def one(i):
             dp = self.tiles[i]

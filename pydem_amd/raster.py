@@ -305,6 +305,8 @@ def write_geotiff(path, array, transform, projected=False, nodata=None, compress
                     payload = zlib.compress(payload, 6)
                 if fh.tell() % 2:
                     fh.write(b'\x00')
+                if not bigtiff and fh.tell() + len(payload) >= 1 << 32:     # (before the offsets are packed as 32-bit words)
+                    raise ValueError("write_geotiff: the file would exceed the 4 GiB of classic TIFF (use bigtiff=True)")
                 offs.append(fh.tell()); cnts.append(len(payload))
                 fh.write(payload)
             if tile is None:
@@ -339,7 +341,8 @@ def write_geotiff(path, array, transform, projected=False, nodata=None, compress
             add(33550, 12, [a * w0 / w, -e * h0 / h, 0.0]); add(33922, 12, [0.0, 0.0, 0.0, c, f, 0.0])
             add(34735, 3, [1, 1, 0, 3, 1024, 0, 1, 1 if projected else 2, 1025, 0, 1, 1, 2048, 0, 1, 4326])
             if tags and level == 0:
-                items = ''.join('<Item name="%s">%s</Item>' % (k, v) for k, v in tags.items())
+                from xml.sax.saxutils import escape, quoteattr
+                items = ''.join('<Item name=%s>%s</Item>' % (quoteattr(str(k)), escape(str(v))) for k, v in tags.items())
                 add(42112, 2, '<GDALMetadata>' + items + '</GDALMetadata>')
             if nodata is not None:
                 add(42113, 2, repr(float(nodata)))
@@ -413,7 +416,7 @@ def block_mean_overview(data, factor, like_reference=True):
 _BLOCK_STATS = {
     'max': lambda v: np.nanmax(v, axis=-1), 'min': lambda v: np.nanmin(v, axis=-1), 'med': lambda v: np.nanmedian(v, axis=-1),
     'q1': lambda v: np.nanquantile(v, 0.25, axis=-1), 'q3': lambda v: np.nanquantile(v, 0.75, axis=-1),
-    'sum': lambda v: np.nansum(v, axis=-1), 'rms': lambda v: np.sqrt(np.nanmean(v * v, axis=-1)),
+    'sum': lambda v: np.where(np.isnan(v).all(axis=-1), np.nan, np.nansum(v, axis=-1)), 'rms': lambda v: np.sqrt(np.nanmean(v * v, axis=-1)),
 }
 OVERVIEW_KINDS = ('average', 'nearest', 'mode') + tuple(sorted(_BLOCK_STATS))
 

@@ -36,11 +36,18 @@ def _default_address():
     return 'tcp://%s:%d' % (addr, port + 1)
 
 
+def _token():
+    """Shared secret of the job: PYDEM_RDZV_TOKEN (set it in the launcher's environment when the ranks span nodes: rank 0
+    unpickles what a connected peer sends, so only peers that know the token may stay connected); the default only keeps
+    unrelated jobs on one host apart."""
+    return os.environ.get('PYDEM_RDZV_TOKEN') or 'job-%s' % os.environ.get('MASTER_PORT', '0')
+
+
 def _send(sock, payload):
     sock.sendall(struct.pack('<Q', len(payload)) + payload)
 
 
-def _recv(sock):
+def _recv(sock, limit=None):
     def take(n):
         buf = bytearray()
         while len(buf) < n:
@@ -50,6 +57,8 @@ def _recv(sock):
             buf += chunk
         return bytes(buf)
     (n,) = struct.unpack('<Q', take(8))
+    if limit is not None and n > limit:
+        raise ConnectionError("rendezvous: oversized message from an unverified peer")
     return take(n)
 
 
@@ -78,8 +87,17 @@ class SocketGroup(object):
                 conn.settimeout(timeout)
                 if family == socket.AF_INET:
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                r = pickle.loads(_recv(conn))
-                self.peers[int(r)] = conn
+                # the hello is a fixed text line (token, rank) -- nothing is unpickled from a peer that has not shown the token
+                try:
+                    r = self._check_hello(_recv(conn, limit=256))
+                except (ConnectionError, socket.timeout):
+                    r = None
+                if r is None or r in self.peers:
+                    conn.close()
+                    continue
+                self.peers[r] = conn
+            for conn in self.peers.values():
+                conn.settimeout(None)          # the connect timeout must not outlive the rendezvous: a rank may lag minutes in a collective
         else:
             t_end = time.time() + timeout
             while True:
@@ -92,11 +110,23 @@ class SocketGroup(object):
                     if time.time() > t_end:
                         raise TimeoutError("rendezvous: rank 0 is not listening on %s" % self.address)
                     time.sleep(0.05)
-            s.settimeout(timeout)
+            s.settimeout(None)
             if family == socket.AF_INET:
                 s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            _send(s, pickle.dumps(self.rank))
+            _send(s, ('pydem-rdzv %s %d' % (_token(), self.rank)).encode())
             self.sock = s
+
+    def _check_hello(self, blob):
+        """Rank of a peer that presents the job's token (PYDEM_RDZV_TOKEN, default: derived from the address) and a rank in
+        1..world-1; None for anything else."""
+        try:
+            word, token, rank = blob.decode('ascii').split(' ')
+            rank = int(rank)
+        except (UnicodeDecodeError, ValueError):
+            return None
+        if word != 'pydem-rdzv' or token != _token() or not (1 <= rank < self.world):
+            return None
+        return rank
 
     @staticmethod
     def _parse(address):

@@ -414,11 +414,40 @@ def test_block_overview_kinds_against_loops():
         for kind, fn in want.items():
             got = raster.block_overview(a, f, kind)
             ref = loop(fn)
-            if kind == 'sum':
-                ref = np.where(np.isnan(ref), 0.0, ref)         # numpy's nansum of nothing is 0
             assert np.allclose(got, ref, rtol=1e-14, atol=0, equal_nan=True), kind
     near = raster.block_overview(a, f, 'nearest')
     assert near.shape == (N, M) and np.array_equal(near[:4, :5], a[1:11:3, 1:14:3], equal_nan=True)
     assert np.array_equal(raster.block_overview(a, f, 'average'), raster.block_mean_overview(a, f, like_reference=False), equal_nan=True)
     with pytest.raises(NotImplementedError):
         raster.block_overview(a, f, 'lanczos')
+
+
+def test_writer_nits_metadata_escaping_sum_overview_classic_limit(tmp_path):
+    """(1) GDAL_METADATA items are XML-escaped; (2) a 'sum' overview block that holds no data stays NaN like the other
+    block statistics; (3) a classic TIFF that would pass 4 GiB is refused with the bigtiff hint, not with struct.error."""
+    a = np.arange(36, dtype=np.float64).reshape(6, 6)
+    fn = str(tmp_path / 'm.tif')
+    raster.write_geotiff(fn, a, (1.0, 0.0, 0.0, 0.0, -1.0, 6.0), tags={'note': 'a<b & "c"', 'k&y': '1'})
+    raw = open(fn, 'rb').read()
+    assert b'<Item name="note">a&lt;b &amp; "c"</Item>' in raw and b'<Item name="k&amp;y">1</Item>' in raw
+    assert np.array_equal(raster.read_geotiff(fn).array, a)
+    b = a.copy(); b[:3, :3] = np.nan
+    s = raster.block_overview(b, 3, 'sum')
+    assert np.isnan(s[0, 0]) and s[0, 1] == a[:3, 3:].sum() and s[1, 0] == a[3:, :3].sum()
+    b[0, 0] = 2.0
+    assert raster.block_overview(b, 3, 'sum')[0, 0] == 2.0
+
+    class Big(object):              # a file object that pretends to be just below 4 GiB
+        def __init__(self, fh): self.fh = fh
+        def tell(self): return self.fh.tell() + (1 << 32) - 64
+        def __getattr__(self, k): return getattr(self.fh, k)
+        def __enter__(self): return self
+        def __exit__(self, *a): self.fh.close()
+    import builtins
+    real_open = builtins.open
+    try:
+        builtins.open = lambda f, mode='r', *a, **k: Big(real_open(f, mode, *a, **k)) if 'w' in mode and str(f).endswith('big.tif') else real_open(f, mode, *a, **k)
+        with pytest.raises(ValueError, match='bigtiff=True'):
+            raster.write_geotiff(str(tmp_path / 'big.tif'), a, (1.0, 0.0, 0.0, 0.0, -1.0, 6.0), bigtiff=False)
+    finally:
+        builtins.open = real_open

@@ -10,6 +10,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof/ks -o t --output
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof/pf -o t --output-format csv -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 --roof-iters 2 > gpurun_out/prof/pf.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof/pw -o t --output-format csv -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 --roof-iters 2 > gpurun_out/prof/pw.log 2>&1
 python tools/pmc_aggregate.py gpurun_out/prof/pf gpurun_out/prof/pw > gpurun_out/prof/pmc_fetch_write.csv
+python tools/csrc_stamp.py > gpurun_out/prof/pmc_fetch_write.meta.json      # identity of the kernels the counters belong to (bench.py: pmc_traffic)
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --kernel-include-regex 'k_stencil' -d gpurun_out/prof/sq -o t --output-format csv -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 --roof-iters 2 > gpurun_out/prof/sq.log 2>&1
 python tools/pmc_aggregate.py gpurun_out/prof/sq > gpurun_out/prof/pmc_sq_stencil.csv
 cp gpurun_out/prof/ks/t_kernel_stats.csv gpurun_out/prof/kernel_stats.csv

@@ -12,7 +12,8 @@
 
 Exact fields (section, flats, pit -> drain pairs, the conditioned surface) are recorded as sha256, float fields as NaN
 count / min / max / pairwise sum / quantiles.  tests/test_gpu_large_configs.py compares the device results with them.
-Run on the build box (oracle only -- the reference is not needed):  python tools/gen_large_checksums.py [3] [4] [5] [small]
+Run on the build box (oracle only -- the reference is not needed):  python tools/gen_large_checksums.py [3] [4] [5] [small] [size=8192]
+(config 4 at its BASELINE size, 8 x 8192^2: `4 size=8192`, about 75 minutes and 50 GB)
 """
 import hashlib
 import json
@@ -112,6 +113,7 @@ def config4(size=2048, n_workers=8):
 def main():
     which = sys.argv[1:] or ['3', '5']
     small = 'small' in which
+    tile4 = [int(w.split('=')[1]) for w in which if w.startswith('size=')]      # config 4 at another tile size: 4 size=8192
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
     if '3' in which:
         key = 'config3_%d' % (1024 if small else 16384)
@@ -119,8 +121,11 @@ def main():
         print(key, 'done in %.0f s' % res[key]['oracle_seconds'], flush=True)
         json.dump(res, open(OUT, 'w'), indent=1, sort_keys=True)
     if '4' in which:
-        key = 'config4_8x%d' % (512 if small else 2048)
-        res[key] = config4(512 if small else 2048)
+        size4 = tile4[0] if tile4 else (512 if small else 2048)
+        key = 'config4_8x%d' % size4
+        r4 = config4(size4)
+        res = json.load(open(OUT)) if os.path.exists(OUT) else {}       # (hours may have passed: re-read before writing)
+        res[key] = r4
         print(key, 'done in %.0f s' % res[key]['oracle_seconds'], flush=True)
         json.dump(res, open(OUT, 'w'), indent=1, sort_keys=True)
     if '5' in which:
