@@ -1000,6 +1000,79 @@ __global__ __launch_bounds__(256, 6) void k_sweep_tiles_listed(SweepArgs A, uint
     if (lane == 0 && fin) atomicAdd(n_final, fin);
 }
 
+// ------------------------------------------------------------------------------- K5d
+// Dense level prologue (PYDEM_SWEEP_DENSE=k, measured alternative -- see DESIGN.md section 4 "Round 4"): k full-grid
+// streaming kernels ahead of the tile passes.  Level p finishes every open cell whose sources all finished in a level
+// < p: one lane per cell, no lists, no atomics besides the count, the same gather order as the tile visits (NW ... SE,
+// then the pit in-edges by source), so the values are bit-identical to theirs.  A stamp of THIS level reads as "open"
+// (levels < p count), so concurrent stamps never let a cell read a value written in the same launch.
+constexpr int DENSE_BAND = 64;
+__global__ __launch_bounds__(256) void k_sweep_dense_level(SweepArgs A, uint32_t p, int32_t *n_final)
+{
+    const int n = A.n, m = A.m;
+    int32_t fin = 0;
+    // a workgroup walks a band of DENSE_BAND consecutive rows of its 256 columns: the neighbour rows it reads were touched by
+    // itself a row earlier (L1 / the XCD's L2), and the count of finished cells costs one atomic per band and column block
+    // (one per row and block kept the counter's L2 channel busy for 12 ms per level)
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i_end = min(n, (int)(blockIdx.y + 1) * DENSE_BAND);
+    if (j < m)
+    for (int i = blockIdx.y * DENSE_BAND; i < i_end; i++) {
+        const int32_t c = i * m + j;
+        const uint32_t w = A.cinfo[c];
+        const uint32_t lv = ci_level(w);
+        if (lv >= 1 && lv != CI_LEVEL_INF) continue;                     // finished in an earlier level
+        const uint32_t cw = w & CI_STATIC_MASK;
+        bool ready = true;
+#pragma unroll
+        for (int d = 0; d < 8; d++)
+            if (cw & (1u << d)) {
+                const uint32_t lu = ci_level(A.cinfo[c + NB_DI[d] * m + NB_DJ[d]]);
+                ready = ready && lu >= 1 && lu < p;
+            }
+        if (!ready) continue;
+        int2 po = make_int2(0, 0);
+        if (cw & CI_PIT_IN) {
+            po = pit_stash(A, c);
+            for (int32_t e = po.x; e < A.n_pit && A.pin_dst[e] == c; e++) {
+                const uint32_t lu = ci_level(A.cinfo[A.pin_src[e]]);
+                ready = ready && lu >= 1 && lu < p;
+            }
+            if (!ready) continue;
+        }
+        double a = A.a0[i];
+        bool td = (i == 0 || i == n - 1 || j == 0 || j == m - 1) && A.todo_work[c] != 0;
+#pragma unroll
+        for (int d = 0; d < 8; d++)
+            if (cw & (1u << d)) { const double x = in_edge(A, c, m, d); a += fabs(x); td = td || (x < 0); }
+        if (cw & CI_PIT_IN)
+            for (int32_t e = po.x; e < A.n_pit && A.pin_dst[e] == c; e++) {
+                const int32_t sc = A.pin_src[e];
+                a += A.area[sc] * A.pin_w[e];
+                td = td || (A.todo_work[sc] != 0);
+            }
+        double2 o = make_double2(0.0, 0.0);
+        if (cw & (CI_OUT1 | CI_OUT2)) {
+            const double pv = A.prop[c];
+            if (cw & CI_OUT1) o.x = a * pv;
+            if (cw & CI_OUT2) o.y = a * (1 - pv);
+            if (td) { o.x = -o.x; o.y = -o.y; }
+        }
+        A.area[c] = a;
+        A.contrib[c] = o;
+        A.cinfo[c] = ci_with_level(cw, p);
+        if (td) A.todo_work[c] = 1;
+        fin++;
+    }
+    for (int off = 32; off > 0; off >>= 1) fin += __shfl_down(fin, off);
+    __shared__ int32_t s_fin;
+    if (threadIdx.x == 0) s_fin = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && fin) atomicAdd(&s_fin, fin);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_fin) atomicAdd(n_final, s_fin);
+}
+
 // ------------------------------------------------------------------------------- K5e
 // Resident visits for the river passes.  After a dozen passes the listed tiles have a few dozen open cells each, and a
 // pass lasts as long as its longest dependency chain: rounds per visit x time per round.  The generic round goes
@@ -2815,19 +2888,29 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         // the LDS latency per cell is not hidden any more), and pass 2 inherits the cells with pit edges -- not the default
         static int first_kind = -1;
         if (first_kind < 0) { const char *e = getenv("PYDEM_SWEEP_FIRST"); first_kind = (e && !strcmp(e, "lds")) ? 1 : 0; }
-        if (first_kind == 1 && TH == 32)
+        // PYDEM_SWEEP_DENSE=k: k dense level kernels (K5d) first; the tile passes then start at pass k + 1.  Measured, not
+        // the default (profiles/r04_sweep_passes_dense*.txt)
+        static int dense_levels = -1;
+        if (dense_levels < 0) { const char *e = getenv("PYDEM_SWEEP_DENSE"); dense_levels = e ? atoi(e) : 0; if (dense_levels < 0) dense_levels = 0; }
+        for (int lv = 1; lv <= dense_levels; lv++) {
+            hipLaunchKernelGGL(k_sweep_dense_level, dim3((unsigned)cdiv(m, 256), (unsigned)cdiv(n, DENSE_BAND)), dim3(256), 0, t->stream,
+                               A, (uint32_t)lv, total);
+            launches++;
+        }
+        const uint32_t pb = (uint32_t)dense_levels;       // passes so far
+        if (first_kind == 1 && TH == 32 && pb == 0)
             hipLaunchKernelGGL(k_sweep_first, dim3((unsigned)(((tiles_total + 7) / 8) * 8)), dim3(256), 0, t->stream, A, tiles_x, tiles_total, tile_done, total);
         else {
             TileNext N0; N0.flag = nullptr; N0.list = nullptr; N0.count = nullptr;
-            hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, 1u, tiles_x, tiles_total, tile_done, total, N0);
+            hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, pb + 1u, tiles_x, tiles_total, tile_done, total, N0);
         }
-        TileNext N; N.flag = tile_flag; N.list = tile_list[3 % 2]; N.count = &cntT[3 % 3];
-        hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, 2u, tiles_x, tiles_total, tile_done, total, N);
+        TileNext N; N.flag = tile_flag; N.list = tile_list[(pb + 3) % 2]; N.count = &cntT[(pb + 3) % 3];
+        hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, pb + 2u, tiles_x, tiles_total, tile_done, total, N);
         launches += 2;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
-        if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "tile passes 1-2: %d cells of %lld, %d tiles listed\n", t->h_counters[3], (long long)t->NN, t->h_counters[56]);
-        const int p_end = run_listed(3, t->h_counters[56 + 3 % 3]);
+        if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "tile passes %u-%u: %d cells of %lld, %d tiles listed\n", pb + 1, pb + 2, t->h_counters[3], (long long)t->NN, t->h_counters[56 + (pb + 3) % 3]);
+        const int p_end = run_listed((int)pb + 3, t->h_counters[56 + (pb + 3) % 3]);
         if (p_end == -1) { pydem_set_error("HIP error in the listed tile passes"); return -4; }
         if (p_end == -2) { pydem_set_error("flow paths longer than %u passes are not supported", CI_LEVEL_INF); return -5; }
         pass = (uint32_t)p_end;

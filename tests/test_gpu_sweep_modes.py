@@ -37,6 +37,7 @@ needs_queue_build = pytest.mark.skipif(not QUEUE_BUILD, reason="the queue schedu
                                  pytest.param({'PYDEM_SWEEP_MODE': 'queue', 'PYDEM_SWEEP_TILE_SWITCH': '0'}, marks=needs_queue_build),
                                  pytest.param({'PYDEM_SWEEP_MODE': 'queue', 'PYDEM_TILE_PASSES': '3'}, marks=needs_queue_build),
                                  {'PYDEM_SWEEP_FIRST': 'lds'},           # pass 1 by the LDS-resident kernel (csrc/uca.hip K5a)
+                                 {'PYDEM_SWEEP_DENSE': '3'},             # three dense level kernels ahead of the tile passes (K5d)
                                  {'PYDEM_SWEEP_RESIDENT': '0'},          # generic visits in every listed pass
                                  {'PYDEM_SWEEP_RESIDENT': '100000000'}]) # resident visits (K5e) from pass 3 on, tiles with > 256 open cells generic
 def test_queue_schedule_matches_oracle(env):

@@ -8,7 +8,7 @@ f = sorted(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True))[-1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows = [r for r in csv.DictReader(open(f))]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-sw = [i for i, r in enumerate(rows) if any(k in r['Kernel_Name'] for k in ('k_sweep_tiles', 'k_sweep_first', 'k_compact_tiles', 'k_compact_build', 'k_tile_scan'))]
+sw = [i for i, r in enumerate(rows) if any(k in r['Kernel_Name'] for k in ('k_sweep_tiles', 'k_sweep_first', 'k_sweep_dense', 'k_compact_tiles', 'k_compact_build', 'k_tile_scan'))]
 n = len(sw) // steps
 last = sw[(steps - 1) * n:]
 t0 = int(rows[last[0]]['Start_Timestamp'])
