@@ -22,7 +22,7 @@ FLAGS += os.environ.get('PYDEM_HIPCC_FLAGS', '').split()     # kernel-tuning exp
 
 
 def _deps_mtime():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.h', '.inl'))]
     hdrs.append(os.path.join(HERE, '..', 'include', 'pydem_hip.h'))
     return max(os.path.getmtime(h) for h in hdrs)
 

@@ -103,6 +103,8 @@ static int pack_one(pydem_comm *c, pydem_tile *t, int field, int axis, int64_t i
     if (index < 0 || index >= lim) { pydem_set_error("line index out of range"); return -2; }
     const int64_t count = axis == 0 ? t->m : t->n;
     if ((size_t)(offset + count) > c->cap) { pydem_set_error("pydem_comm_pack_line: staging buffer too small"); return -2; }
+    if ((field == PYDEM_UCA || field == PYDEM_EDGE_DONE || field == PYDEM_EDGE_TODO) && !tile_line_watched(t, axis, index))
+        PYDEM_TRY(stage_edge_catchup(t));                       // condensed edge rounds only keep the watched lines current
     const int64_t stride = axis == 0 ? 1 : t->m;
     const int64_t first = axis == 0 ? index * t->m : index;
     const int g = (int)(cdiv(count, 256) < 64 ? cdiv(count, 256) : 64);
@@ -213,7 +215,8 @@ struct pydem_board {
     std::vector<pydem_board_desc> h_desc;
     unsigned long long *scal = nullptr, *h_scal = nullptr;   // [n_tiles][8]
     // per tile: where its lines live in the board, and (tiles of this rank) how to gather them from the tile
-    struct TileLines { int64_t mb_start = 0, size = 0; pydem_tile *tile = nullptr; int count = 0; pydem_pack_line *lines = nullptr; };
+    struct TileLines { int64_t mb_start = 0, size = 0; pydem_tile *tile = nullptr; int count = 0; pydem_pack_line *lines = nullptr;
+                       std::vector<std::pair<int, int64_t>> where; };      // (axis, index) of the lines: the tile's condensed edge rounds watch them
     std::vector<TileLines> tl;
 };
 
@@ -420,7 +423,7 @@ int pydem_board_set_lines(pydem_board *b, int index, int64_t mb_start, int64_t s
     if (mb_start < 0 || mb_start + size > b->cap) { pydem_set_error("pydem_board_set_lines: lines beyond the board"); return -2; }
     if ((int)b->tl.size() != b->n_tiles) b->tl.resize((size_t)b->n_tiles);
     pydem_board::TileLines &T = b->tl[(size_t)index];
-    T.mb_start = mb_start; T.size = size; T.tile = tile; T.count = 0;
+    T.mb_start = mb_start; T.size = size; T.tile = tile; T.count = 0; T.where.clear();
     if (!tile) return 0;
     if (tile->device != b->device) { pydem_set_error("pydem_board_set_lines: tile lives on another device"); return -2; }
     std::vector<pydem_pack_line> h((size_t)count);
@@ -439,6 +442,8 @@ int pydem_board_set_lines(pydem_board *b, int index, int64_t mb_start, int64_t s
         else { pydem_set_error("pydem_board_set_lines: field %d is not an edge field", f); return -2; }
         (void)pp;
         if (!base || !tile->have[f]) { pydem_set_error("pydem_board_set_lines: field %d is not resident", f); return -3; }
+        tile_watch_line(tile, axis, idx);          // the condensed edge rounds keep this line current between two rounds
+        T.where.emplace_back(axis, idx);
         pydem_pack_line &P = h[(size_t)k];
         P.count = axis == 0 ? tile->m : tile->n;
         P.stride = axis == 0 ? 1 : tile->m;
@@ -482,6 +487,8 @@ static int board_stage(pydem_board *b, int n_wave, const int *wave_tiles, bool s
         pydem_board::TileLines &T = b->tl[(size_t)wave_tiles[k]];
         if (!T.tile || T.count == 0) continue;
         pydem_tile *t = T.tile;
+        for (const auto &ln : T.where)             // (a line registered after the tile's condensed graph was built: the interior first)
+            if (!tile_line_watched(t, ln.first, ln.second)) { PYDEM_TRY(stage_edge_catchup(t)); break; }
         HIP_TRY(hipStreamWaitEvent(t->stream, b->ev, 0));
         hipLaunchKernelGGL(k_board_pack, dim3(8, T.count), dim3(256), 0, t->stream, T.lines, T.count, b->wb + S.src[k]);
         HIP_TRY(hipEventRecord(t->ev_snap, t->stream));

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string>
 #include <vector>
+#include <utility>
 #include <initializer_list>
 #include "../../include/pydem_hip.h"
 
@@ -91,6 +92,15 @@ struct pydem_tile {
     int64_t circular_cells = -1;    // cells the last sweep found on / below a drainage loop (-1: no sweep ran on this handle)
     int64_t einc_round = 0;         // incremental edge rounds run on this tile so far (stamps of the NaN flood)
     bool einc_ready = false;        // incremental edge rounds: counts / deltas / FINAL flags are live (uca.hip K7i)
+    // condensed form of the incremental rounds (uca_cond.inl): the cascade of a round runs on the watched cells only
+    std::vector<std::pair<int, int64_t>> watch;     // lines other tiles read (axis, index >= 0); the perimeter is always watched
+    size_t watch_built = 0;         // how many of them the live condensed graph covers
+    bool cond_live = false;         // (only meaningful while einc_ready)
+    bool cond_pending = false;      // rounds ran since the interior last caught up
+    int32_t cond_nw = 0, cond_nan_cap = 0;
+    void *cond_mem = nullptr; size_t cond_bytes = 0;
+    void *cond_node = nullptr, *cond_edge = nullptr; double *cond_slot = nullptr;
+    int32_t *cond_q0 = nullptr, *cond_q1 = nullptr, *cond_nanq = nullptr, *cond_cnt = nullptr;
     double *h_strip_d = nullptr; uint8_t *h_strip_f = nullptr; size_t h_strip_cap = 0;   // pinned strip staging
     void *h_stage = nullptr; size_t h_stage_bytes = 0;      // pinned host staging of the conditioning stages (tile_pinned)
     int32_t etodo_prev = 0;         // cells whose edge_done byte the previous round cleared (tlist = flatlist)
@@ -139,6 +149,11 @@ int stage_edge_update(pydem_tile *t, const pydem_options *opt, const double *con
 int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *const data[4], const uint8_t *const done[4],
                          const uint8_t *const todo[4]);
 int stage_edge_flush(pydem_tile *t);
+// condensed incremental rounds: the interior of the tile catches up with the watched lines (no-op otherwise); reads of the
+// edge fields that are not watched lines call it first
+int stage_edge_catchup(pydem_tile *t);
+void tile_watch_line(pydem_tile *t, int axis, int64_t index);
+bool tile_line_watched(const pydem_tile *t, int axis, int64_t index);
 int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double source_tol, int peaks, int pits, int artefacts_only);
 int stage_pit_candidates(pydem_tile *t, int below_sea, int64_t *npits);
 int stage_pit_candidates_read(pydem_tile *t, int64_t npits, int32_t *cells, double *elev);

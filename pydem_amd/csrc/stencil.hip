@@ -506,8 +506,10 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, Row
     ts = tnx;
 }
 
-template <bool F32>
-__global__ __launch_bounds__(256) void k_stencil_march(const double *__restrict__ elev, int n, int m,
+// OCC = workgroups the compiler must fit on a CU: 1 = free choice (135 VGPRs: three wavefronts per SIMD), 4 = at most 128
+// VGPRs for a fourth wavefront per SIMD (PYDEM_STENCIL_OCC=4; measured, DESIGN.md section 4 "Round 4")
+template <bool F32, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_stencil_march(const double *__restrict__ elev, int n, int m,
                                                        const RowTab *__restrict__ rowtab,
                                                        double *__restrict__ mag, double *__restrict__ dir,
                                                        uint8_t *__restrict__ flat0, int strips, int chunks, int rows_per_wave,
@@ -682,12 +684,13 @@ static void launch_stencil(pydem_tile *t)
     const int chunks = (int)cdiv(t->n - 2, rows);
     const int waves = strips * chunks;
     const int exact_only = t->stencil_exact_only;   // set with the row tables: a spacing outside [2^-500, 2^500] (or PYDEM_STENCIL_EXACT=1)
-    if (t->elev_f32)
-        hipLaunchKernelGGL(k_stencil_march<true>, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, t->stream, t->elev, (int)t->n, (int)t->m,
-                           t->rowtab, t->mag, t->dir, t->flat0, strips, chunks, rows, exact_only);
-    else
-        hipLaunchKernelGGL(k_stencil_march<false>, dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, t->stream, t->elev, (int)t->n, (int)t->m,
-                           t->rowtab, t->mag, t->dir, t->flat0, strips, chunks, rows, exact_only);
+    static int occ = -1;
+    if (occ < 0) { const char *e = getenv("PYDEM_STENCIL_OCC"); occ = (e && atoi(e) == 4) ? 4 : 1; }
+#define MARCH(F32, OCC) hipLaunchKernelGGL((k_stencil_march<F32, OCC>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, t->stream, t->elev, \
+                                           (int)t->n, (int)t->m, t->rowtab, t->mag, t->dir, t->flat0, strips, chunks, rows, exact_only)
+    if (t->elev_f32) { if (occ == 4) MARCH(true, 4); else MARCH(true, 1); }
+    else { if (occ == 4) MARCH(false, 4); else MARCH(false, 1); }
+#undef MARCH
 }
 
 int stage_stencil(pydem_tile *t)

@@ -258,7 +258,7 @@ int pydem_tile_destroy(pydem_tile *t)
                     t->counters, t->scratch, t->pits.src, t->pits.dst, t->pits.w, t->pits.in_src,
                     t->pits.in_dst, t->pits.in_w, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w,
                     t->estamp, t->edelta, t->p_delta, t->s_data, t->p_flags, t->s_flags, t->line_stage, t->contrib,
-                    t->eseed, t->lines_stage, t->pits.sort_buf, t->nd_rec};
+                    t->eseed, t->lines_stage, t->pits.sort_buf, t->nd_rec, t->cond_mem};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     if (t->h_strip_d) (void)hipHostFree(t->h_strip_d);
@@ -382,6 +382,7 @@ int pydem_tile_download(pydem_tile *t, int field, void *dst)
     PYDEM_TRY(field_ptr(t, field, &pp, &elem));
     if (!*pp || !t->have[field]) { pydem_set_error("field %d has not been computed or uploaded", field); return -3; }
     if (field == PYDEM_UCA) PYDEM_TRY(stage_edge_flush(t));     // incremental edge rounds: settle what is still waiting upstream
+    if (field == PYDEM_EDGE_DONE || field == PYDEM_EDGE_TODO) PYDEM_TRY(stage_edge_catchup(t));   // condensed rounds: the interior masks catch up
     HIP_TRY(hipMemcpyAsync(dst, *pp, (size_t)t->NN * elem, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     return 0;
@@ -400,6 +401,8 @@ static int line_copy(pydem_tile *t, int field, int axis, int64_t index, void *ho
     const int64_t lim = axis == 0 ? t->n : t->m;
     if (index < 0) index += lim;
     if (index < 0 || index >= lim || (axis != 0 && axis != 1)) { pydem_set_error("line index out of range"); return -2; }
+    if (to_host && (field == PYDEM_UCA || field == PYDEM_EDGE_DONE || field == PYDEM_EDGE_TODO) && !tile_line_watched(t, axis, index))
+        PYDEM_TRY(stage_edge_catchup(t));                       // condensed edge rounds only keep the watched lines current
     char *base = (char *)*pp;
     // the caller's array is pageable: the transfer goes through the tile's pinned staging buffer (tile_pinned)
     const size_t nbytes = (size_t)(axis == 0 ? t->m : t->n) * elem;
@@ -460,6 +463,8 @@ int pydem_tile_get_lines(pydem_tile *t, int count, const int *fields, const int 
         int64_t index = indices[k];
         if (index < 0) index += lim;
         if (index < 0 || index >= lim || (axes[k] != 0 && axes[k] != 1)) { pydem_set_error("line index out of range"); return -2; }
+        if ((fields[k] == PYDEM_UCA || fields[k] == PYDEM_EDGE_DONE || fields[k] == PYDEM_EDGE_TODO) && !tile_line_watched(t, axes[k], index))
+            PYDEM_TRY(stage_edge_catchup(t));
         char *base = (char *)*pp;
         if (axes[k] == 0) {
             nbytes[(size_t)k] = (size_t)t->m * elem;

@@ -1683,6 +1683,33 @@ __global__ void k_reseed_replay(SweepArgs A, const ReseedCell *__restrict__ U, i
     *n_done_out = n_done;
 }
 
+// Host replay (more unfinished cells than the one-thread replay above is meant for): what the host needs of an unfinished
+// cell -- its static graph word, elevation, proportion, pit-list offsets and what it has received from its finished
+// upstream cells -- gathered in parallel; the results come back through k_reseed_scatter.
+struct ReseedHost { int32_t c; uint32_t cw; int32_t pin_first, pout_first; double area, elev, prop; int32_t td, pad; };
+__global__ __launch_bounds__(256) void k_reseed_gather(SweepArgs A, const ReseedCell *__restrict__ U, int32_t nU, const double *__restrict__ elev,
+                                                       ReseedHost *__restrict__ out)
+{
+    for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nU; k += gridDim.x * blockDim.x) {
+        ReseedHost h;
+        h.c = U[k].c; h.cw = A.cinfo[h.c] & CI_STATIC_MASK; h.pin_first = U[k].pin_first; h.pout_first = U[k].pout_first;
+        double a; bool td;
+        gather_finished(A, h.c, h.cw, h.pin_first, a, td);
+        h.area = a; h.td = td; h.pad = 0; h.elev = elev[h.c]; h.prop = (h.cw & (CI_OUT1 | CI_OUT2)) ? A.prop[h.c] : 0.0;
+        out[k] = h;
+    }
+}
+struct ReseedBack { int32_t c; int32_t flags; double area; };      // flags: bit 0 finished by the replay, bit 1 taint
+__global__ __launch_bounds__(256) void k_reseed_scatter(SweepArgs A, const ReseedBack *__restrict__ B, int32_t nU, uint32_t pass)
+{
+    for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nU; k += gridDim.x * blockDim.x) {
+        const int32_t c = B[k].c;
+        A.area[c] = B[k].area;
+        if (B[k].flags & 2) A.todo_work[c] = 1;
+        if (B[k].flags & 1) A.cinfo[c] = ci_with_level(A.cinfo[c], pass);
+    }
+}
+
 // finalisation of _calc_uca_chunk (:966-980): NaN on flats, edge_done = ~edge_todo etc.
 // (16 cells per thread: the byte masks travel as 16-byte words; uca and elev are only touched where the masks ask for
 // them -- flats, cells still on `todo` -- unless the saturation limit needs every value: 3 instead of 19 bytes per cell)
@@ -2364,6 +2391,7 @@ struct __attribute__((aligned(128))) NDRec {
     uint16_t seed_round;     // round (mod 2^16) in which the strips last initialised the cell: a NaN flood of that round stops here
     int32_t cnt;             // unresolved in-edges (+1 for the outside of the tile while the cell is a 'todo' inlet)
     uint32_t flag;
+    int32_t wid;             // condensed form (uca_cond.inl): node of a watched cell, -1 otherwise
     double delta;
     double out_w[2];         // proportion, 1 - proportion (:1082)
     double in_delta[8];      // what the finished in-neighbour NW..SE has handed over (0 until then)
@@ -2404,7 +2432,7 @@ __global__ __launch_bounds__(256) void k_nd_assign(CIncArgs E, int64_t NN, int32
         NDRec &R = E.rec[k];
         R.cell = (int32_t)c64;
         R.cw = (E.G.cinfo[c64] & CI_STATIC_MASK) | (E.flats[c64] ? ND_FLAT : 0u);
-        R.flag = 0; R.delta = 0.0; R.seed_round = 0;
+        R.flag = 0; R.delta = 0.0; R.seed_round = 0; R.wid = -1;
     }
 }
 
@@ -2414,7 +2442,7 @@ __global__ __launch_bounds__(256) void k_nd_link(CIncArgs E)
     const int m = A.m;
     if (blockIdx.x == 0 && threadIdx.x == 0) {                                   // the sink of the missing edges
         NDRec &S = E.rec[E.nd];
-        S.cell = -1; S.cw = 0; S.out_id[0] = S.out_id[1] = -1; S.out_slot[0] = S.out_slot[1] = 0; S.cnt = 1 << 30; S.flag = 0; S.delta = 0.0;
+        S.cell = -1; S.cw = 0; S.out_id[0] = S.out_id[1] = -1; S.out_slot[0] = S.out_slot[1] = 0; S.cnt = 1 << 30; S.flag = 0; S.delta = 0.0; S.wid = -1;
     }
     for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < E.nd; k += gridDim.x * blockDim.x) {
         NDRec &R = E.rec[k];
@@ -2685,6 +2713,8 @@ __global__ __launch_bounds__(256) void k_cinc_apply(CIncArgs E)
 
 int grid_for(int64_t work, int cap) { const int64_t g = cdiv(work, 256); return (int)(g < cap ? (g > 0 ? g : 1) : cap); }
 
+#include "uca_cond.inl"
+
 }  // namespace
 
 int stage_section_graph(pydem_tile *t, const pydem_options *opt)
@@ -2749,6 +2779,80 @@ static void fill_sweep_args(pydem_tile *t, SweepArgs &A)
     A.err = t->counters + 15;
     A.tile_open = nullptr;           // (stage_sweep points it at its scratch)
     { const char *e = getenv("PYDEM_TILE_DEBUG"); A.dbg = e ? atoi(e) : 0; }
+}
+
+// The re-seed loop of the reference (dem_processing.py:951-964 around cyutils._drain_area, cyutils.pyx:119-187) over the
+// unfinished cells on the HOST: the same rules as k_reseed_replay, line by line, with the frontiers kept as sorted lists
+// instead of flag scans (a round costs its frontier, not the whole list).  H is sorted by cell.  Pit lists: out-edges
+// (src-sorted: pit_src / pit_dst / pit_w), in-edges (dst-sorted: pin_dst / pin_src).
+static int64_t reseed_replay_host(std::vector<ReseedHost> &H, std::vector<uint8_t> &done, int n, int m, int maxcount, bool tile_has_nan,
+                                  const std::vector<int32_t> &pit_src, const std::vector<int32_t> &pit_dst, const std::vector<double> &pit_w,
+                                  const std::vector<int32_t> &pin_dst, const std::vector<int32_t> &pin_src)
+{
+    const int32_t nU = (int32_t)H.size();
+    const int64_t n_pit = (int64_t)pit_src.size();
+    static const int DI[8] = {-1, -1, -1, 0, 0, 1, 1, 1}, DJ[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+    auto find = [&](int32_t c) -> int32_t {
+        int32_t lo = 0, hi = nU - 1;
+        while (lo <= hi) { const int32_t mid = (lo + hi) >> 1; if (H[(size_t)mid].c == c) return mid; if (H[(size_t)mid].c < c) lo = mid + 1; else hi = mid - 1; }
+        return -1;
+    };
+    auto on_edge = [&](int32_t c) { const int i = c / m, j = c - i * m; return i == 0 || i == n - 1 || j == 0 || j == m - 1; };
+    auto is_done = [&](int32_t c) -> bool { const int32_t k = find(c); return k < 0 || done[(size_t)k]; };   // not listed = finished by the passes
+    done.assign((size_t)nU, 0);
+    std::vector<uint8_t> in_cur((size_t)nU, 0);
+    std::vector<int32_t> cur, prev;
+    int64_t n_done = 0, done_prev = -1;
+    for (int count = 2; n_done < nU && count < maxcount && n_done != done_prev; count++) {          // :951-952
+        done_prev = n_done;
+        double mx = 0.0;                                                                            // :962-964
+        for (int32_t k = 0; k < nU; k++) if (!done[(size_t)k] && H[(size_t)k].elev > mx) mx = H[(size_t)k].elev;
+        if (tile_has_nan) mx = NAN;
+        cur.clear();
+        for (int32_t k = 0; k < nU; k++) {
+            const double v = done[(size_t)k] ? 0.0 : H[(size_t)k].elev;
+            if ((v - mx) / mx > -0.01) cur.push_back(k);
+        }
+        for (int64_t guard = 0; guard < 8 * (int64_t)nU + 64; guard++) {
+            for (int32_t k : cur) { if (!done[(size_t)k]) n_done++; done[(size_t)k] = 1; }          // cyutils.pyx:138-140
+            prev.swap(cur); cur.clear();
+            for (int32_t k : prev) {                                                                // ascending cell order
+                const ReseedHost &S = H[(size_t)k];
+                const int32_t i = S.c;
+                int32_t tg[2]; double fc[2]; int nt = 0;
+                if (S.cw & (CI_OUT1 | CI_OUT2)) {
+                    const int sct = (int)((S.cw >> CI_SEC_SHIFT) & 7u);
+                    if (S.cw & CI_OUT1) { tg[nt] = i + fe1r(sct) * m + fe1c(sct); fc[nt] = S.prop; nt++; }
+                    if (S.cw & CI_OUT2) { tg[nt] = i + fe2r(sct) * m + fe2c(sct); fc[nt] = 1 - S.prop; nt++; }
+                    if (nt == 2 && tg[1] < tg[0]) { std::swap(tg[0], tg[1]); std::swap(fc[0], fc[1]); }
+                }
+                int64_t e = (S.cw & CI_PIT_OUT) ? S.pout_first : 0;
+                for (int q = 0;; q++) {
+                    int32_t row; double factor;
+                    if (S.cw & CI_PIT_OUT) { if (!(e < n_pit && pit_src[(size_t)e] == i)) break; row = pit_dst[(size_t)e]; factor = pit_w[(size_t)e]; e++; }
+                    else { if (q >= nt) break; row = tg[q]; factor = fc[q]; }
+                    const int32_t kr = find(row);
+                    if (kr < 0) continue;
+                    if (done[(size_t)kr] && on_edge(row)) continue;                                  // :159-161
+                    H[(size_t)kr].area += S.area * factor;                                          // :163
+                    if (S.td) H[(size_t)kr].td = 1;
+                    bool wait = false;                                                              // :173-179
+                    const uint32_t cwr = H[(size_t)kr].cw;
+                    for (int d = 0; d < 8 && !wait; d++)
+                        if ((cwr & (1u << d)) && !is_done(row + DI[d] * m + DJ[d])) wait = true;
+                    if (!wait && (cwr & CI_PIT_IN))
+                        for (int64_t e2 = H[(size_t)kr].pin_first; e2 < n_pit && pin_dst[(size_t)e2] == row; e2++)
+                            if (!is_done(pin_src[(size_t)e2])) { wait = true; break; }
+                    if (!wait && !in_cur[(size_t)kr]) { in_cur[(size_t)kr] = 1; cur.push_back(kr); }
+                }
+            }
+            std::sort(cur.begin(), cur.end());
+            for (int32_t k : cur) in_cur[(size_t)k] = 0;
+            if (cur == prev) break;                                                                 // :187 (the frontier did not change)
+        }
+        cur.clear();
+    }
+    return n_done;
 }
 
 int stage_sweep(pydem_tile *t, const pydem_options *opt)
@@ -2851,9 +2955,49 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
                 return -5;
             }
             t->circular_cells = unfinished;
-            if (unfinished > cap64) {
-                pydem_set_error("circular drainage: %lld unfinished cells are more than the sequential replay of the re-seed loop is meant for", (long long)unfinished);
-                return -5;
+            static int64_t host_above = -1;        // PYDEM_RESEED_HOST_ABOVE (tests): unfinished cells above which the host replays
+            if (host_above < 0) { const char *e = getenv("PYDEM_RESEED_HOST_ABOVE"); host_above = e ? atoll(e) : ((int64_t)1 << 22); }
+            if (unfinished > cap64 || unfinished > host_above) {
+                // more cells than the one-thread replay is meant for (a loop at the head of a long river): the reference finishes
+                // such a tile, slowly (:951-964) -- so does the host here, with a note on stderr
+                fprintf(stderr, "pydem: circular drainage with %lld unfinished cells: the re-seed loop runs on the host\n", (long long)unfinished);
+                if (unfinished > INT32_MAX / 2) { pydem_set_error("circular drainage: %lld unfinished cells", (long long)unfinished); return -5; }
+                const int32_t nU = (int32_t)unfinished;
+                void *d_tmp = nullptr;
+                HIP_TRY(hipMalloc(&d_tmp, (size_t)nU * (sizeof(ReseedCell) + sizeof(ReseedHost))));
+                ReseedCell *U2 = (ReseedCell *)d_tmp;
+                ReseedHost *dH = (ReseedHost *)((char *)d_tmp + (size_t)nU * sizeof(ReseedCell));
+                HIP_TRY(hipMemsetAsync(rc, 0, 3 * sizeof(int32_t), t->stream));
+                hipLaunchKernelGGL(k_reseed_collect, dim3(grid_for(t->NN, 4096)), dim3(256), 0, t->stream, A, U2, rc, nU, (const double *)t->elev, rc + 1);
+                hipLaunchKernelGGL(k_reseed_gather, dim3(grid_for(nU, 1024)), dim3(256), 0, t->stream, A, (const ReseedCell *)U2, nU, (const double *)t->elev, dH);
+                std::vector<ReseedHost> H((size_t)nU);
+                HIP_TRY(hipMemcpyAsync(H.data(), dH, (size_t)nU * sizeof(ReseedHost), hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipStreamSynchronize(t->stream));
+                const bool has_nan = t->h_counters[61] != 0;
+                std::sort(H.begin(), H.end(), [](const ReseedHost &a, const ReseedHost &b) { return a.c < b.c; });
+                const size_t np = (size_t)A.n_pit;
+                std::vector<int32_t> h_ps(np), h_pd(np), h_is(np), h_id(np); std::vector<double> h_pw(np);
+                if (np) {
+                    HIP_TRY(hipMemcpy(h_ps.data(), A.pit_src, np * 4, hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemcpy(h_pd.data(), A.pit_dst, np * 4, hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemcpy(h_pw.data(), t->pits.w, np * 8, hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemcpy(h_id.data(), A.pin_dst, np * 4, hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemcpy(h_is.data(), A.pin_src, np * 4, hipMemcpyDeviceToHost));
+                }
+                std::vector<uint8_t> dn;
+                const int64_t n_done = reseed_replay_host(H, dn, n, m, (int)opt->circular_ref_maxcount, has_nan, h_ps, h_pd, h_pw, h_id, h_is);
+                std::vector<ReseedBack> back((size_t)nU);
+                for (int32_t k = 0; k < nU; k++) { back[(size_t)k].c = H[(size_t)k].c; back[(size_t)k].area = H[(size_t)k].area; back[(size_t)k].flags = (dn[(size_t)k] ? 1 : 0) | (H[(size_t)k].td ? 2 : 0); }
+                static_assert(sizeof(ReseedBack) <= sizeof(ReseedHost), "the gather buffer is reused for the results");
+                HIP_TRY(hipMemcpy(dH, back.data(), (size_t)nU * sizeof(ReseedBack), hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(k_reseed_scatter, dim3(grid_for(nU, 1024)), dim3(256), 0, t->stream, A, (const ReseedBack *)dH, nU, pass);
+                HIP_TRY(hipStreamSynchronize(t->stream));
+                HIP_TRY(hipFree(d_tmp));
+                t->h_counters[3] += (int32_t)n_done;
+                HIP_TRY(hipMemcpy(t->counters + 3, t->h_counters + 3, sizeof(int32_t), hipMemcpyHostToDevice));
+                if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "circular drainage: %lld unfinished cells, %lld finished by the re-seed replay on the host\n", (long long)unfinished, (long long)n_done);
+                return 0;
             }
             std::vector<ReseedCell> hu((size_t)unfinished);
             HIP_TRY(hipMemcpyAsync(hu.data(), U, hu.size() * sizeof(ReseedCell), hipMemcpyDeviceToHost, t->stream));
@@ -3350,6 +3494,275 @@ static int einc_prepare(pydem_tile *t, IncArgs &E)
     return 0;
 }
 
+// ---- condensed incremental rounds: host side (kernels in uca_cond.inl) ----------------------------------------
+void tile_watch_line(pydem_tile *t, int axis, int64_t index)
+{
+    const int64_t lim = axis == 0 ? t->n : t->m;
+    if (index < 0) index += lim;
+    if (index == 0 || index == lim - 1) return;                    // perimeter: always watched
+    for (const auto &w : t->watch) if (w.first == axis && w.second == index) return;
+    t->watch.emplace_back(axis, index);
+}
+
+bool tile_line_watched(const pydem_tile *t, int axis, int64_t index)
+{
+    if (!(t->einc_ready && t->cond_live)) return true;             // nothing is deferred
+    const int64_t lim = axis == 0 ? t->n : t->m;
+    if (index < 0) index += lim;
+    if (index == 0 || index == lim - 1) return true;
+    for (size_t k = 0; k < t->watch_built && k < t->watch.size(); k++)
+        if (t->watch[k].first == axis && t->watch[k].second == index) return true;
+    return false;
+}
+
+static int cond_args(pydem_tile *t, CondArgsE &X)
+{
+    PYDEM_TRY(cinc_args(t, X.C));
+    X.node = (CNode *)t->cond_node; X.nw = t->cond_nw; X.edge = (const CEdge *)t->cond_edge; X.slot = t->cond_slot;
+    X.q0 = t->cond_q0; X.q1 = t->cond_q1; X.nanq = t->cond_nanq; X.nan_cap = t->cond_nan_cap; X.cnt = t->cond_cnt;
+    return 0;
+}
+
+// Build the condensed graph of the watched cells from the compact records (just linked by einc_prepare).  Returns 0 and
+// leaves cond_live false when the tile does not qualify (switched off, too many records, a cycle among the records).
+static int cond_build(pydem_tile *t)
+{
+    t->cond_live = false; t->cond_pending = false;
+    static int enabled = -1;
+    if (enabled < 0) { const char *e = getenv("PYDEM_EDGE_COND"); enabled = e ? atoi(e) : 1; }
+    int64_t max_nd = 1 << 20;
+    { const char *e = getenv("PYDEM_EDGE_COND_MAX"); if (e) max_nd = atoll(e); }
+    if (!enabled || !t->einc_compact || t->nd <= 0 || t->nd > max_nd) return 0;
+    const double t_begin = host_now_ms();
+    const int32_t nd = t->nd;
+    const int n = (int)t->n, m = (int)t->m;
+    CIncArgs C;
+    PYDEM_TRY(cinc_args(t, C));
+    // ---- watched records: the perimeter and the lines other tiles read
+    auto mark = [&](int axis, int64_t index) {
+        const int64_t count = axis == 0 ? m : n;
+        hipLaunchKernelGGL(k_cond_mark, dim3((unsigned)std::min<int64_t>(cdiv(count, 256), 64)), dim3(256), 0, t->stream, C, axis, index);
+    };
+    mark(0, 0); mark(0, n - 1); mark(1, 0); mark(1, m - 1);
+    for (const auto &w : t->watch) mark(w.first, w.second);
+    // ---- pit -> drain edges between records and the records' graph fields (scratch: the two queue buffers, idle until the
+    // first cascade), through pinned staging
+    CPitEdge *d_pe = reinterpret_cast<CPitEdge *>(t->queue[1]);
+    const int32_t pe_cap = (int32_t)std::min<int64_t>(t->NN / 4, (int64_t)1 << 24);
+    int32_t *d_npe = t->counters + 54;
+    HIP_TRY(hipMemsetAsync(d_npe, 0, sizeof(int32_t), t->stream));
+    if (C.G.n_pit > 0)
+        hipLaunchKernelGGL(k_cond_pit_edges, dim3(grid_for(nd, 1024)), dim3(256), 0, t->stream, C, (const double *)t->pits.w, d_pe, d_npe, pe_cap);
+    CRecH *d_hr = reinterpret_cast<CRecH *>(t->queue[0]);
+    void *d_tmp = nullptr;
+    if ((int64_t)nd * (int64_t)sizeof(CRecH) > t->NN * 4) {       // (small tiles that are mostly 'not done': the queue buffer is too short)
+        HIP_TRY(hipMalloc(&d_tmp, (size_t)nd * sizeof(CRecH)));
+        d_hr = reinterpret_cast<CRecH *>(d_tmp);
+    }
+    hipLaunchKernelGGL(k_cond_extract, dim3(grid_for(nd, 1024)), dim3(256), 0, t->stream, C, d_hr);
+    void *pin_v = nullptr;
+    PYDEM_TRY(tile_pinned(t, (size_t)nd * sizeof(CRecH) + 64, &pin_v));
+    const CRecH *hr = reinterpret_cast<const CRecH *>((char *)pin_v + 64);
+    int32_t *h_npe = reinterpret_cast<int32_t *>(pin_v);
+    HIP_TRY(hipMemcpyAsync(h_npe, d_npe, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync((void *)hr, d_hr, (size_t)nd * sizeof(CRecH), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    if (d_tmp) HIP_TRY(hipFree(d_tmp));
+    const int32_t npe = *h_npe;
+    if (npe > pe_cap) return 0;
+    std::vector<CPitEdge> pe((size_t)npe);
+    if (npe) HIP_TRY(hipMemcpy(pe.data(), d_pe, (size_t)npe * sizeof(CPitEdge), hipMemcpyDeviceToHost));
+    const double t_copied = host_now_ms();
+    std::sort(pe.begin(), pe.end(), [](const CPitEdge &a, const CPitEdge &b) { return a.src != b.src ? a.src < b.src : a.dst < b.dst; });
+    // ---- out-edges per record (regular ones first, then the pit edges), in-degrees, predecessor lists
+    std::vector<int32_t> ob((size_t)nd + 1, 0);
+    for (int32_t k = 0; k < nd; k++) ob[(size_t)k + 1] = (hr[k].out_id[0] >= 0) + (hr[k].out_id[1] >= 0);
+    for (const auto &e : pe) ob[(size_t)e.src + 1]++;
+    for (int32_t k = 0; k < nd; k++) ob[(size_t)k + 1] += ob[(size_t)k];
+    const int64_t n_out = ob[(size_t)nd];
+    std::vector<int32_t> ot((size_t)n_out); std::vector<double> ow((size_t)n_out);
+    {
+        std::vector<int32_t> fill(ob.begin(), ob.end() - 1);
+        for (int32_t k = 0; k < nd; k++)
+            for (int j = 0; j < 2; j++)
+                if (hr[k].out_id[j] >= 0) { ot[(size_t)fill[(size_t)k]] = hr[k].out_id[j]; ow[(size_t)fill[(size_t)k]++] = hr[k].out_w[j]; }
+        for (const auto &e : pe) { ot[(size_t)fill[(size_t)e.src]] = e.dst; ow[(size_t)fill[(size_t)e.src]++] = e.w; }
+    }
+    std::vector<int32_t> indeg((size_t)nd, 0), pb((size_t)nd + 1, 0);
+    for (int64_t e = 0; e < n_out; e++) { if (ot[(size_t)e] < 0 || ot[(size_t)e] >= nd) return 0; indeg[(size_t)ot[(size_t)e]]++; }
+    for (int32_t k = 0; k < nd; k++) pb[(size_t)k + 1] = pb[(size_t)k] + indeg[(size_t)k];
+    std::vector<int32_t> pred((size_t)n_out);
+    {
+        std::vector<int32_t> fill(pb.begin(), pb.end() - 1);
+        for (int32_t k = 0; k < nd; k++)
+            for (int32_t e = ob[(size_t)k]; e < ob[(size_t)k + 1]; e++) pred[(size_t)fill[(size_t)ot[(size_t)e]]++] = k;
+    }
+    const double t_csr = host_now_ms();
+    // ---- watched records in ascending cell order
+    std::vector<int32_t> wrec;
+    for (int32_t k = 0; k < nd; k++) if (hr[k].wid == -2) wrec.push_back(k);
+    std::sort(wrec.begin(), wrec.end(), [&](int32_t a, int32_t b) { return hr[a].cell < hr[b].cell; });
+    const int32_t nw = (int32_t)wrec.size();
+    std::vector<int32_t> wid((size_t)nd, -1);
+    for (int32_t w = 0; w < nw; w++) wid[(size_t)wrec[(size_t)w]] = w;
+    const double t_wsort = host_now_ms();
+    // ---- reverse topological order: X(k) = the watched cells the water of k reaches next, with the path weights, kept as
+    // scale[k] * V(rep[k]): a cell with ONE out-edge shares the vector of its target (rep < 0: the unit vector of watched
+    // node -1 - rep), only the cells where the flow splits merge two (sorted) vectors into a new one in the arena
+    typedef std::pair<int32_t, double> Ent;
+    std::vector<Ent> arena;
+    std::vector<int64_t> vbeg(1, 0);                     // vector v = arena[vbeg[v] .. vbeg[v + 1])
+    arena.reserve((size_t)nd * 2);
+    std::vector<int32_t> rep((size_t)nd, INT32_MIN);     // INT32_MIN: the empty vector (the water ends inside the tile)
+    std::vector<double> scale((size_t)nd, 0.0);
+    std::vector<int32_t> out_left((size_t)nd), stack;
+    for (int32_t k = 0; k < nd; k++) { out_left[(size_t)k] = ob[(size_t)k + 1] - ob[(size_t)k]; if (!out_left[(size_t)k]) stack.push_back(k); }
+    int64_t processed = 0;
+    std::vector<Ent> acc, nxt;
+    // the vector of target tg as seen through an edge of weight w: (rep, factor)
+    auto through = [&](int32_t tg, double w, int32_t &r, double &f) {
+        if (wid[(size_t)tg] >= 0) { r = -1 - wid[(size_t)tg]; f = w; }
+        else { r = rep[(size_t)tg]; f = w * scale[(size_t)tg]; }
+    };
+    auto add_into = [&](int32_t r, double f) {            // acc += f * V(r), both sorted by node
+        if (r == INT32_MIN) return;
+        Ent unit(-1 - r, 1.0);
+        const Ent *vb = r < 0 ? &unit : arena.data() + vbeg[(size_t)r], *ve = r < 0 ? &unit + 1 : arena.data() + vbeg[(size_t)r + 1];
+        nxt.clear();
+        size_t i = 0;
+        for (const Ent *p = vb; p != ve; p++) {
+            while (i < acc.size() && acc[i].first < p->first) nxt.push_back(acc[i++]);
+            if (i < acc.size() && acc[i].first == p->first) { nxt.emplace_back(p->first, acc[i].second + f * p->second); i++; }
+            else nxt.emplace_back(p->first, f * p->second);
+        }
+        while (i < acc.size()) nxt.push_back(acc[i++]);
+        acc.swap(nxt);
+    };
+    while (!stack.empty()) {
+        const int32_t k = stack.back(); stack.pop_back();
+        processed++;
+        const int32_t e0 = ob[(size_t)k], e1 = ob[(size_t)k + 1];
+        if (e1 - e0 == 1) through(ot[(size_t)e0], ow[(size_t)e0], rep[(size_t)k], scale[(size_t)k]);
+        else if (e1 - e0 >= 2) {
+            acc.clear();
+            for (int32_t e = e0; e < e1; e++) { int32_t r; double f; through(ot[(size_t)e], ow[(size_t)e], r, f); add_into(r, f); }
+            if (!acc.empty()) {
+                rep[(size_t)k] = (int32_t)vbeg.size() - 1; scale[(size_t)k] = 1.0;
+                arena.insert(arena.end(), acc.begin(), acc.end());
+                vbeg.push_back((int64_t)arena.size());
+                if (arena.size() > ((size_t)1 << 27)) return 0;    // (a pathological fan: keep the cell-by-cell rounds)
+            }
+        }
+        for (int32_t e = pb[(size_t)k]; e < pb[(size_t)k + 1]; e++) if (--out_left[(size_t)pred[(size_t)e]] == 0) stack.push_back(pred[(size_t)e]);
+    }
+    if (processed != nd) return 0;                                   // a cycle among the records: not a DAG, plain cascade
+    const double t_swept = host_now_ms();
+    // ---- nodes, edges, slots
+    std::vector<CNode> nodes((size_t)nw);
+    auto vsize = [&](int32_t r) -> int64_t { return r == INT32_MIN ? 0 : (r < 0 ? 1 : vbeg[(size_t)r + 1] - vbeg[(size_t)r]); };
+    int64_t ne_all = 0;
+    for (int32_t w = 0; w < nw; w++) ne_all += vsize(rep[(size_t)wrec[(size_t)w]]);
+    if (ne_all > INT32_MAX / 2) return 0;
+    // all edges in source order first (dst, weight), in-degrees; then the split into inline / array parts
+    std::vector<int32_t> e_dst((size_t)ne_all); std::vector<double> e_w((size_t)ne_all);
+    std::vector<int32_t> ebeg((size_t)nw + 1, 0), n_in((size_t)nw, 0);
+    {
+        int64_t e = 0;
+        for (int32_t w = 0; w < nw; w++) {
+            const int32_t k = wrec[(size_t)w];
+            const int32_t r = rep[(size_t)k];
+            const double f = scale[(size_t)k];
+            if (r != INT32_MIN && r < 0) { e_dst[(size_t)e] = -1 - r; e_w[(size_t)e] = f; e++; }
+            else if (r != INT32_MIN)
+                for (int64_t q = vbeg[(size_t)r]; q < vbeg[(size_t)r + 1]; q++) { e_dst[(size_t)e] = arena[(size_t)q].first; e_w[(size_t)e] = f * arena[(size_t)q].second; e++; }
+            ebeg[(size_t)w + 1] = (int32_t)e;
+        }
+        for (int64_t q = 0; q < ne_all; q++) n_in[(size_t)e_dst[(size_t)q]]++;
+    }
+    std::vector<int32_t> in_base((size_t)nw + 1, 0), out_base((size_t)nw + 1, 0);
+    for (int32_t w = 0; w < nw; w++) {
+        in_base[(size_t)w + 1] = in_base[(size_t)w] + std::max(0, n_in[(size_t)w] - 2);
+        out_base[(size_t)w + 1] = out_base[(size_t)w] + std::max(0, ebeg[(size_t)w + 1] - ebeg[(size_t)w] - 2);
+    }
+    const int64_t ne = out_base[(size_t)nw], nslot = in_base[(size_t)nw];      // array parts
+    std::vector<CEdge> edges((size_t)std::max<int64_t>(ne, 1));
+    std::vector<int32_t> fill((size_t)nw, 0);                                    // next in-slot of a node (sources ascend with the edge order)
+    for (int32_t w = 0; w < nw; w++) {
+        CNode &N = nodes[(size_t)w];
+        memset(&N, 0, sizeof(N));
+        const int32_t k = wrec[(size_t)w];
+        N.rec = k; N.cell = hr[k].cell; N.cw = hr[k].cw;
+        N.n_in = n_in[(size_t)w]; N.n_out = ebeg[(size_t)w + 1] - ebeg[(size_t)w];
+        N.in_base = in_base[(size_t)w]; N.out_base = out_base[(size_t)w];
+        for (int e = 0; e < N.n_out; e++) {
+            const int64_t q = (int64_t)ebeg[(size_t)w] + e;
+            CEdge ed;
+            ed.dst = e_dst[(size_t)q]; ed.w = e_w[(size_t)q];
+            const int32_t sl = fill[(size_t)ed.dst]++;
+            ed.slot = sl < 2 ? -1 - sl : in_base[(size_t)ed.dst] + sl - 2;
+            if (e < 2) N.e_inl[e] = ed; else edges[(size_t)(N.out_base + e - 2)] = ed;
+        }
+        const int32_t outside = hr[k].cnt - indeg[(size_t)k];                    // +1 while the cell is a 'todo' inlet (k_nd_link)
+        if (outside != 0 && outside != 1) { pydem_set_error("condensed edge rounds: inconsistent count of record %d", k); return -5; }
+        N.cnt = N.n_in + outside;
+    }
+    // ---- device copy (one allocation: nodes | edges | slots | two queues | NaN list | counters)
+    const size_t nan_cap = (size_t)ne_all + (size_t)nw + 64;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_node = take((size_t)nw * sizeof(CNode)), o_edge = take((size_t)(ne + 1) * sizeof(CEdge)), o_slot = take((size_t)(nslot + 1) * 8),
+                 o_q0 = take((size_t)nw * 4), o_q1 = take((size_t)nw * 4), o_nan = take(nan_cap * 4), o_cnt = take(64);
+    if (off > t->cond_bytes) {
+        if (t->cond_mem) { HIP_TRY(hipFree(t->cond_mem)); t->device_bytes -= (int64_t)t->cond_bytes; t->cond_mem = nullptr; t->cond_bytes = 0; }
+        HIP_TRY(hipMalloc(&t->cond_mem, off + off / 8));
+        t->cond_bytes = off + off / 8; t->device_bytes += (int64_t)t->cond_bytes;
+    }
+    char *base = (char *)t->cond_mem;
+    t->cond_node = base + o_node; t->cond_edge = base + o_edge; t->cond_slot = (double *)(base + o_slot);
+    t->cond_q0 = (int32_t *)(base + o_q0); t->cond_q1 = (int32_t *)(base + o_q1); t->cond_nanq = (int32_t *)(base + o_nan);
+    t->cond_cnt = (int32_t *)(base + o_cnt); t->cond_nw = nw; t->cond_nan_cap = (int32_t)std::min<size_t>(nan_cap, (size_t)INT32_MAX);
+    HIP_TRY(hipMemsetAsync(base + o_slot, 0, off - o_slot, t->stream));
+    if (nw) HIP_TRY(hipMemcpyAsync(t->cond_node, nodes.data(), (size_t)nw * sizeof(CNode), hipMemcpyHostToDevice, t->stream));
+    if (ne) HIP_TRY(hipMemcpyAsync(t->cond_edge, edges.data(), (size_t)ne * sizeof(CEdge), hipMemcpyHostToDevice, t->stream));
+    CondArgsE X;
+    t->cond_live = true;                  // (cond_args reads the fields set above)
+    PYDEM_TRY(cond_args(t, X));
+    if (nw) hipLaunchKernelGGL(k_cond_attach, dim3(grid_for(nw, 256)), dim3(256), 0, t->stream, X);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));     // (nodes / edges are host vectors about to go out of scope)
+    t->watch_built = t->watch.size();
+    if (getenv("PYDEM_EDGE_DEBUG"))
+        fprintf(stderr, "condensed edge rounds: %d records -> %d watched nodes, %lld edges (%d pit edges among the records); %.2f ms "
+                "(copy %.2f, adjacency %.2f, node order %.2f, reverse sweep %.2f [%zu vectors, %zu entries], nodes + upload %.2f)\n",
+                nd, nw, (long long)ne_all, npe, host_now_ms() - t_begin, t_copied - t_begin, t_csr - t_copied, t_wsort - t_csr, t_swept - t_wsort,
+                vbeg.size() - 1, arena.size(), host_now_ms() - t_swept);
+    return 0;
+}
+
+// the interior catches up: done watched nodes -> their records, the NaN flood below the nodes it passed, ONE cascade
+static int cond_catchup(pydem_tile *t, int set_done)
+{
+    if (!(t->einc_ready && t->cond_live)) return 0;
+    CondArgsE X;
+    PYDEM_TRY(cond_args(t, X));
+    X.C.set_done = set_done;
+    HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
+    if (X.nw > 0) {
+        hipLaunchKernelGGL(k_cond_release, dim3(grid_for(X.nw, 256)), dim3(256), 0, t->stream, X, (QE *)t->queue[0], &t->counters[0]);
+        hipLaunchKernelGGL(k_cond_nan_interior, dim3(1), dim3(1024), 0, t->stream, X);
+    }
+    PYDEM_TRY(cinc_cascade(t, X.C, nullptr));
+    t->cond_pending = false;
+    return 0;
+}
+
+int stage_edge_catchup(pydem_tile *t)
+{
+    if (!(t->einc_ready && t->cond_live && t->cond_pending)) return 0;
+    HIP_TRY(hipSetDevice(t->device));
+    return cond_catchup(t, 1);
+}
+
 int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *const data[4], const uint8_t *const done[4],
                          const uint8_t *const todo[4])
 {
@@ -3372,7 +3785,7 @@ int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *
     PYDEM_TRY(einc_args(t, E));
     PYDEM_TRY(tile_alloc(t, &t->s_data, (size_t)L * 4));
     PYDEM_TRY(tile_alloc(t, &t->s_flags, (size_t)L * 8));
-    if (!t->einc_ready) PYDEM_TRY(einc_prepare(t, E));
+    if (!t->einc_ready) { PYDEM_TRY(einc_prepare(t, E)); PYDEM_TRY(cond_build(t)); }
     // strips -> device (left, right, top, bottom), padded to L entries each (pinned staging: the copies are asynchronous);
     // data == NULL: the edge board's evaluation kernel has already written them (comm.hip)
     if (data) {
@@ -3400,6 +3813,28 @@ int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *
     HIP_TRY(hipMemsetAsync(t->counters + 40, 0, 8 * sizeof(int32_t), t->stream));
 #endif
     int levels = 0;
+    if (t->einc_compact && t->cond_live) {
+        // condensed form: seeds + NaN flood + cascade on the watched nodes, two launches and no host look (the edge board's
+        // pack kernels follow on the same stream); the interior catches up later (stage_edge_catchup / the flush)
+        CondArgsE X;
+        PYDEM_TRY(cond_args(t, X));
+        hipLaunchKernelGGL(k_cond_seed, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, X, t->s_data, t->s_flags,
+                           t->s_flags + (size_t)4 * L, L);
+        hipLaunchKernelGGL(k_cond_run, dim3(1), dim3(1024), 0, t->stream, X);
+        t->cond_pending = true;
+        HIP_TRY(hipGetLastError());
+        static int sync_rounds = -1;       // PYDEM_EDGE_SYNC=1: wait for the round (per-round timings of tools/pm_multitile_timing.py)
+        if (sync_rounds < 0) { const char *e = getenv("PYDEM_EDGE_SYNC"); sync_rounds = e ? atoi(e) : 0; }
+        if (data || sync_rounds || getenv("PYDEM_EDGE_DEBUG")) {
+            HIP_TRY(hipStreamSynchronize(t->stream));            // (host strips: the pinned staging is reused by the next round)
+            if (getenv("PYDEM_EDGE_DEBUG")) {
+                int32_t lv[3];
+                HIP_TRY(hipMemcpy(lv, t->cond_cnt, sizeof(lv), hipMemcpyDeviceToHost));
+                fprintf(stderr, "condensed edge round: %d levels on %d nodes; %.3f ms\n", lv[2], t->cond_nw, host_now_ms() - t_begin);
+            }
+        }
+        return 0;
+    }
     if (t->einc_compact) {
         CIncArgs C;
         PYDEM_TRY(cinc_args(t, C));
@@ -3431,6 +3866,21 @@ int stage_edge_flush(pydem_tile *t)
     if (!t->einc_ready) return 0;
     const int n = (int)t->n, m = (int)t->m;
     const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
+    if (t->einc_compact && t->cond_live) {
+        // condensed form: the interior catches up with what is done, the remaining inlets let go on the watched graph
+        // (nothing becomes 'done' any more), and the interior follows once more
+        const double t_flush0 = host_now_ms();
+        PYDEM_TRY(cond_catchup(t, 1));
+        CondArgsE X;
+        PYDEM_TRY(cond_args(t, X));
+        X.C.set_done = 0;
+        hipLaunchKernelGGL(k_cond_release_todo, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, X);
+        hipLaunchKernelGGL(k_cond_run, dim3(1), dim3(1024), 0, t->stream, X);
+        PYDEM_TRY(cond_catchup(t, 0));
+        t->einc_ready = false; t->cond_live = false;
+        if (getenv("PYDEM_EDGE_DEBUG")) { HIP_TRY(hipStreamSynchronize(t->stream)); fprintf(stderr, "condensed edge rounds: flush (interior cascade) %.3f ms\n", host_now_ms() - t_flush0); }
+        return 0;
+    }
     HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));
     if (t->einc_compact) {
         CIncArgs C;

@@ -140,15 +140,17 @@ def test_config4_mosaic_against_oracle_backed_flow(n_workers, tmp_path):
         assert np.allclose(ta[fin], tb[fin], rtol=1e-9, atol=1e-9), i
 
 
-def test_config4_mosaic_2048_against_oracle_checksums():
-    """The directory path above toy sizes: 2 x 4 tiles of 2048 x 2048 (bench layout, one-pixel overlap, pits), pool schedule of
-    width 8 with the device edge board, against checksums of the same flow with the oracle-backed processor
-    (tools/gen_large_checksums.py 4: 4-5 minutes of oracle time on the build box).  Same waves and rounds, edge masks bit for
-    bit, uca_total / twi per tile through NaN counts, extrema, sums and quantiles.  Reference: pydem/process_manager.py:224-284,
-    1090-1246 (the multi-worker schedule as deterministic waves)."""
-    key = 'config4_8x2048'
+@pytest.mark.parametrize('tile', [2048, 8192])
+def test_config4_mosaic_2048_against_oracle_checksums(tile):
+    """The directory path above toy sizes: 2 x 4 tiles of 2048 x 2048 -- and of 8192 x 8192, BASELINE config 4 as stated, about
+    50 GB resident on the one GPU -- (bench layout, one-pixel overlap, pits), pool schedule of width 8 with the device edge
+    board, against checksums of the same flow with the oracle-backed processor (tools/gen_large_checksums.py 4 [size=8192]:
+    5 / 75 minutes of oracle time on the build box).  Same waves and rounds, edge masks bit for bit, uca_total / twi per tile
+    through NaN counts, extrema, sums and quantiles.  Reference: pydem/process_manager.py:224-284, 1090-1246 (the
+    multi-worker schedule as deterministic waves)."""
+    key = 'config4_8x%d' % tile
     if key not in SUMS:
-        pytest.skip("no checksums for %s (tools/gen_large_checksums.py 4)" % key)
+        pytest.skip("no checksums for %s (tools/gen_large_checksums.py 4 size=%d)" % (key, tile))
     import sys
     sys.path.insert(0, ROOT)
     import bench

@@ -209,12 +209,16 @@ def test_resume_from_tile_store_on_device(stop_after, n_workers, tmp_path):
         _close(got[key], want[key], key)
 
 
-@pytest.mark.parametrize('name', ['pm_fractal_2x3_ov1', 'pm_cone32_4x5_ov3'])
-def test_two_rank_pool_mode_with_device_board(name, tmp_path):
-    """N > 1 with the strips on the device: two processes (tiles i % 2, both on this box's one GPU -- RCCL refuses two
-    ranks on one device, so the board's staging buffer is summed over the ranks through the socket group:
+@pytest.mark.parametrize('name,world', [('pm_fractal_2x3_ov1', 2), ('pm_cone32_4x5_ov3', 2),
+                                        ('pm_cone32_4x5_ov3', 8),        # the node's real world size: 20 tiles over 8 ranks
+                                        ('pm_fractal_2x3_ov1', 8)])      # ... and more ranks than tiles (two ranks own nothing)
+def test_two_rank_pool_mode_with_device_board(name, world, tmp_path):
+    """N > 1 with the strips on the device: `world` processes (tiles i % world, all on this box's one GPU -- RCCL refuses
+    two ranks on one device, so the board's staging buffer is summed over the ranks through the socket group:
     pydem_board_refresh_stage / _unstage), replicated edge board, deterministic waves.  Every rank must see the waves,
-    round counts and per-tile results of the single-process pool run."""
+    round counts and per-tile results of the single-process pool run.  World size 8 runs every rank-count-dependent
+    branch of the N = 8 path (partition, collective board decision, staging offsets, ranks without tiles) except
+    ncclAllReduce itself (reference: the worker pool of pydem/process_manager.py:243-255, 1214-1246)."""
     import subprocess
     import sys
     from conftest import ROOT
@@ -223,14 +227,15 @@ def test_two_rank_pool_mode_with_device_board(name, tmp_path):
     write_tiles(g, str(tmp_path), key='elev')
     from pydem_amd.rendezvous import spawn_ranks
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
-    rc, out = spawn_ranks([sys.executable, os.path.join(ROOT, 'tests', '_dist_pm_worker.py'), name, str(tmp_path), 'pool', 'device'], 2,
-                          env=env, master_port=29600 + (os.getpid() % 300), capture=True, timeout=600)
+    rc, out = spawn_ranks([sys.executable, os.path.join(ROOT, 'tests', '_dist_pm_worker.py'), name, str(tmp_path), 'pool', 'device'], world,
+                          env=env, master_port=29600 + (os.getpid() % 300), capture=True, timeout=900)
     assert rc == 0, out[-3000:]
-    assert out.count(' ok: ') == 2, out[-3000:]
+    assert out.count(' ok: ') == world, out[-3000:]
 
 
+@pytest.mark.parametrize('world', [2, 8])
 @pytest.mark.parametrize('name', ['pm_fractal_2x3_ov1', 'pm_cone32_4x5_ov3'])
-def test_two_rank_pool_mode_over_rccl(name, tmp_path):
+def test_two_rank_pool_mode_over_rccl(name, world, tmp_path):
     """The same with one GPU per rank and a real communicator of world size 2: `pydem_board_refresh` replicates the
     staging buffer with ncclAllReduce (csrc/comm.hip), the RCCL id travels over pydem_amd.rendezvous.  Needs two GPUs
     (the driver's single-GPU test box skips it; reference: the strips of pydem/process_manager.py:243-255)."""
@@ -239,12 +244,12 @@ def test_two_rank_pool_mode_over_rccl(name, tmp_path):
     from pydem_amd import _ffi
     from pydem_amd.rendezvous import spawn_ranks
     from test_process_manager_grid import write_tiles
-    if _ffi.device_count() < 2:
-        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    if _ffi.device_count() < world:
+        pytest.skip("needs %d GPUs (RCCL refuses two ranks on one device)" % world)
     g = load_golden(name)
     write_tiles(g, str(tmp_path), key='elev')
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
-    rc, out = spawn_ranks([sys.executable, os.path.join(ROOT, 'tests', '_dist_pm_worker.py'), name, str(tmp_path), 'pool', 'rccl'], 2,
-                          env=env, master_port=29300 + (os.getpid() % 300), capture=True, timeout=600)
+    rc, out = spawn_ranks([sys.executable, os.path.join(ROOT, 'tests', '_dist_pm_worker.py'), name, str(tmp_path), 'pool', 'rccl'], world,
+                          env=env, master_port=29300 + (os.getpid() % 300), capture=True, timeout=900)
     assert rc == 0, out[-3000:]
-    assert out.count(' ok: ') == 2, out[-3000:]
+    assert out.count(' ok: ') == world, out[-3000:]

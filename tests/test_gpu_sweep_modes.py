@@ -71,3 +71,16 @@ def test_conditioning_schedules_match_the_host_twin(env):
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_conditioning.py'), '-q', '-x'],
                        env=e, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_circular_drainage_replay_on_the_host():
+    """Above 4 M unfinished cells (a drainage loop at the head of a long river) the re-seed loop of the reference
+    (pydem/dem_processing.py:951-964, cyutils.pyx:119-187) is replayed by the HOST instead of one GPU thread -- the tile is
+    finished like the reference finishes it, not refused.  PYDEM_RESEED_HOST_ABOVE=0 sends the hand-made loop fields of
+    tests/test_gpu_parity.py and the soak's mosaic with circular drainage down that path."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, PYDEM_RESEED_HOST_ABOVE='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_parity.py'), os.path.join(root, 'tests', 'test_gpu_soak.py'),
+                        '-q', '-x', '-s', '-k', 'circular'], env=e, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and ' passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert 'the re-seed loop runs on the host' in r.stdout + r.stderr, "the host replay did not run"
