@@ -280,6 +280,11 @@ int pydem_cond_pit_paths(double *elev, int64_t n_rows, int64_t n_cols, const int
                          double max_dist_XY, int dtype_mode /* 0 float64, 1 integer, 2 float32 surface (values as float64) */,
                          int64_t *n_failed, int64_t *iter_used);
 
+/* TIFF LZW encoder for the GeoTIFF export (host code): the reference writes its exports with rasterio's compress='lzw'
+ * (pydem/process_manager.py:905, :930).  dst must hold up to n * 3 / 2 + 16 bytes (incompressible data grows by 12 %);
+ * *out_n = bytes written.  The stream is libtiff's for the same input. */
+int pydem_tiff_lzw_encode(const uint8_t *src, int64_t n, uint8_t *dst, int64_t cap, int64_t *out_n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,7 @@ SYMBOLS = {
     'pydem_cond_fill_flats': (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int32, C.c_double, C.c_int, C.c_int]),
     'pydem_cond_pit_paths': (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, _P, C.c_int64, _P, C.c_int, C.c_int,
                                        C.c_double, C.c_int, _P, _P]),
+    'pydem_tiff_lzw_encode': (C.c_int, [_P, C.c_int64, _P, C.c_int64, _P]),
     'pydem_tile_synchronize': (C.c_int, [_P]),
     'pydem_tile_timings': (C.c_int, [_P, C.POINTER(Timings)]),
     'pydem_tile_device_bytes': (C.c_int64, [_P]),

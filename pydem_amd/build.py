@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libpydem_hip.so')
-SOURCES = ['tile.hip', 'stencil.hip', 'flats.hip', 'uca.hip', 'pits.hip', 'synth.hip', 'comm.hip', 'cyutils.hip', 'cond_host.cpp', 'cond_device.hip', 'cond_paths.hip']
+SOURCES = ['tile.hip', 'stencil.hip', 'flats.hip', 'uca.hip', 'pits.hip', 'synth.hip', 'comm.hip', 'cyutils.hip', 'cond_host.cpp', 'tiff_lzw.cpp', 'cond_device.hip', 'cond_paths.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-fno-fast-math',
          '-Wall', '-Wno-unused-function', '-Wno-unused-result']

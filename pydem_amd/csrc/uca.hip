@@ -970,7 +970,10 @@ __global__ __launch_bounds__(256, 8) void k_sweep_tiles(SweepArgs A, uint32_t pa
 }
 
 // later passes: only the listed tiles (those a finished cell of the previous pass drains into); lists the next ones
-__global__ __launch_bounds__(256, 6) void k_sweep_tiles_listed(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
+#ifndef PYDEM_LISTED_OCC
+#define PYDEM_LISTED_OCC 6
+#endif
+__global__ __launch_bounds__(256, PYDEM_LISTED_OCC) void k_sweep_tiles_listed(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
                                                             const int32_t *n_in, uint8_t *__restrict__ tile_done, int32_t *n_final,
                                                             TileNext N, int32_t *clear_count)
 {
@@ -3820,7 +3823,7 @@ int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *
         PYDEM_TRY(cond_args(t, X));
         hipLaunchKernelGGL(k_cond_seed, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, X, t->s_data, t->s_flags,
                            t->s_flags + (size_t)4 * L, L);
-        hipLaunchKernelGGL(k_cond_run, dim3(1), dim3(1024), 0, t->stream, X);
+        hipLaunchKernelGGL(k_cond_run, dim3(1), dim3(COND_THREADS), 0, t->stream, X);
         t->cond_pending = true;
         HIP_TRY(hipGetLastError());
         static int sync_rounds = -1;       // PYDEM_EDGE_SYNC=1: wait for the round (per-round timings of tools/pm_multitile_timing.py)
@@ -3875,7 +3878,7 @@ int stage_edge_flush(pydem_tile *t)
         PYDEM_TRY(cond_args(t, X));
         X.C.set_done = 0;
         hipLaunchKernelGGL(k_cond_release_todo, dim3((unsigned)cdiv(nper, 128)), dim3(128), 0, t->stream, X);
-        hipLaunchKernelGGL(k_cond_run, dim3(1), dim3(1024), 0, t->stream, X);
+        hipLaunchKernelGGL(k_cond_run, dim3(1), dim3(COND_THREADS), 0, t->stream, X);
         PYDEM_TRY(cond_catchup(t, 0));
         t->einc_ready = false; t->cond_live = false;
         if (getenv("PYDEM_EDGE_DEBUG")) { HIP_TRY(hipStreamSynchronize(t->stream)); fprintf(stderr, "condensed edge rounds: flush (interior cascade) %.3f ms\n", host_now_ms() - t_flush0); }

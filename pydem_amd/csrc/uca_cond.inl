@@ -29,6 +29,7 @@
 
 constexpr uint32_t CF_RELEASED = 1u << 8, CF_NANPASS = 1u << 9, CF_NANINT = 1u << 10;
 constexpr int COND_QCAP = 4096;
+constexpr int COND_THREADS = 1024;    // the cascade's workgroup (the first rounds of a fix-up are thousands of nodes wide; 256 threads: same median, slower maximum)
 constexpr int32_t W_BARRIER = 1 << 30;        // added to the full-graph count of a watched record: the interior cascade never fires it
 
 struct CEdge { int32_t dst, slot; double w; };      // slot >= 0: index into the slot array; < 0: inline slot -1 - slot of node dst
@@ -135,7 +136,7 @@ __global__ void k_cond_release_todo(CondArgsE X)
 
 // ONE workgroup: the NaN flood of the round (k_cinc_nan_flood on the condensed graph), then the cascade level after level
 // (cinc_cell on nodes).  No host look in between: a wave of the fix-up is seed kernel + this kernel + the board's pack.
-__global__ __launch_bounds__(1024) void k_cond_run(CondArgsE X)
+__global__ __launch_bounds__(COND_THREADS) void k_cond_run(CondArgsE X)
 {
     const CIncArgs &E = X.C;
     __shared__ int32_t s_tail, s_cnt[3];
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(1024) void k_cond_run(CondArgsE X)
     }
     // ---- cascade: the level queues live in LDS (entries beyond COND_QCAP in the global queues)
     __shared__ int32_t s_q[2][COND_QCAP];
-    if (threadIdx.x == 0) { s_cnt[0] = X.cnt[0]; s_cnt[1] = 0; s_cnt[2] = 0; }
+    __shared__ int32_t s_done;
+    if (threadIdx.x == 0) { s_cnt[0] = X.cnt[0]; s_cnt[1] = 0; s_cnt[2] = 0; s_done = 0; }
     __syncthreads();
     int r = 0;
     int32_t nq = s_cnt[0];
@@ -195,12 +197,13 @@ __global__ __launch_bounds__(1024) void k_cond_run(CondArgsE X)
                 for (int s2 = 2; s2 < V.n_in; s2++) acc += X.slot[V.in_base + s2 - 2];
                 delta = acc;
                 N.delta = acc;
-                E.uca[V.cell] += acc;
                 N.flag = (f & (NF_NAN | CF_NANPASS | CF_NANINT)) | NF_FINAL | NF_DONE | NF_APPLIED;
             } else {
                 N.flag = f | NF_DONE | NF_APPLIED;                                   // a seed took its value when the strip arrived
             }
-            if (E.set_done) E.edge_done[V.cell] = 1;
+            // (the cell's area and mask are written after the cascade, all cells at once: a read-modify-write of the area
+            // plane inside the level would make every level's barrier wait for an HBM round trip)
+            X.nanq[agg_slot(&s_done)] = (k < COND_QCAP ? lc[k] : qc[k]) | ((f & NF_FINAL) ? (int32_t)0x40000000 : 0);
             for (int e = 0; e < V.n_out; e++) {
                 const CEdge ed = e < 2 ? V.e_inl[e] : X.edge[V.out_base + e - 2];
                 if (ed.slot < 0) X.node[ed.dst].in_inl[-1 - ed.slot] = delta * ed.w;
@@ -214,6 +217,13 @@ __global__ __launch_bounds__(1024) void k_cond_run(CondArgsE X)
         __syncthreads();
         nq = *cn;
         r++;
+    }
+    // ---- areas and masks of the cells this round finished (the NaN list is idle after the flood: it holds them)
+    for (int32_t k = threadIdx.x; k < s_done; k += blockDim.x) {
+        const int32_t e = X.nanq[k];
+        const CNode &N = X.node[e & 0x3FFFFFFF];
+        if (!(e & 0x40000000)) E.uca[N.cell] += N.delta;                             // (a seed took its value when the strip arrived)
+        if (E.set_done) E.edge_done[N.cell] = 1;
     }
     if (threadIdx.x == 0) { X.cnt[0] = 0; X.cnt[1] = 0; X.cnt[2] = r; }
 }

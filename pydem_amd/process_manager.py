@@ -1219,11 +1219,11 @@ class ProcessManager(object):
         return out
 
     def save_geotiff(self, filename, key, dtype, crs=None, max_files=2, rescale=None, overview_type=None, overview_factors=None,
-                     blocksize=512, bigtiff=True, nodata=None):
+                     blocksize=512, bigtiff=True, nodata=None, compress='lzw'):
         """One stitched result as a GeoTIFF (reference :862-931): same geotransform rules (one pixel size for the whole
         mosaic, else NotImplementedError), same optional rescaling, same file layout as the reference's rasterio call --
-        512 x 512 tiles in a BigTIFF (`blocksize=None` / `bigtiff=False`: one strip, classic TIFF) -- with Deflate where the
-        reference asks for LZW (both lossless).  `overview_type`: one of raster.OVERVIEW_KINDS ('average', 'nearest', 'mode',
+        512 x 512 tiles in a BigTIFF (`blocksize=None` / `bigtiff=False`: one strip, classic TIFF), LZW compressed like
+        the reference's (:905; `compress`: 'lzw', 'deflate' or None).  `overview_type`: one of raster.OVERVIEW_KINDS ('average', 'nearest', 'mode',
         'max', 'min', 'med', 'q1', 'q3', 'sum', 'rms'; GDAL's interpolating kernels are not reproduced) adds reduced-resolution
         images (default factors 3, 9, ... like :928-929) behind the full one; the kind is recorded like :931.
         `crs`: 'projected' or anything else = geographic WGS-84 (the default follows the first input tile)."""
@@ -1263,5 +1263,5 @@ class ProcessManager(object):
         if overview_type is not None:
             tags['rio_overview_resampling'] = overview_type                    # :931
         raster.write_geotiff(filename, np.asarray(data).astype(dtype), (dlon, 0.0, left, 0.0, dlat, top),
-                             projected=(crs == 'projected'), compress=True, overviews=levels, tile=blocksize, bigtiff=bigtiff,
+                             projected=(crs == 'projected'), compress=compress, overviews=levels, tile=blocksize, bigtiff=bigtiff,
                              nodata=nodata, tags=tags or None)

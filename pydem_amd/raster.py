@@ -10,7 +10,7 @@ reproduces the reference's spacing rules with Vincenty's inverse formula on the 
 geographiclib -- what geopy calls -- to ~1e-10 relative on pixel-sized lines; the results of the terrain path are
 compared at 1e-6).  If rasterio is importable it is NOT used: one code path, testable here.
 
-`write_geotiff` is the counterpart (strips or tiles, uncompressed or Deflate, classic or BigTIFF, overviews) used by the
+`write_geotiff` is the counterpart (strips or tiles, uncompressed, LZW or Deflate, classic or BigTIFF, overviews) used by the
 tests and by `ProcessManager.save_non_overlap_data_geotiff` / `save_geotiff`.
 """
 import struct
@@ -257,20 +257,43 @@ def read_geotiff(path, page=0):
     return GeoTiff(out, transform, projected, ellipsoid, nodata)
 
 
+def _lzw_encode(payload):
+    """TIFF LZW through the native encoder (csrc/tiff_lzw.cpp: libtiff's stream for the same bytes)."""
+    import ctypes as C
+    from . import _ffi
+    lib = _ffi.load()
+    n = len(payload)
+    cap = n + n // 2 + 64
+    dst = (C.c_uint8 * cap)()
+    out_n = C.c_int64(0)
+    src = (C.c_uint8 * max(n, 1)).from_buffer_copy(payload if n else b'\0')
+    _ffi.check(lib.pydem_tiff_lzw_encode(src, n, dst, cap, C.byref(out_n)))
+    return bytes(memoryview(dst)[:out_n.value])
+
+
 def write_geotiff(path, array, transform, projected=False, nodata=None, compress=False, overviews=(), tile=None, bigtiff=False,
                   tags=None):
     """Single-band little-endian GeoTIFF.  `transform` = (a, b, c, d, e, f).
 
     Layout: one strip per image (`tile=None`) or square tiles of `tile` pixels (a multiple of 16; the reference writes
-    512 x 512 blocks, pydem/process_manager.py:906-913), uncompressed or Deflate (`compress`; the reference asks rasterio
-    for LZW -- both are lossless, GDAL reads either); classic TIFF (offsets of 32 bits: < 4 GiB, checked) or BigTIFF
-    (`bigtiff=True`, 64-bit offsets, what the reference always writes).
+    512 x 512 blocks, pydem/process_manager.py:906-913); `compress`: False / None = none, 'lzw' = TIFF LZW (what the
+    reference asks rasterio for, :905: libtiff's stream through the native encoder csrc/tiff_lzw.cpp), True / 'deflate' =
+    zlib; classic TIFF (offsets of 32 bits: < 4 GiB, checked) or BigTIFF (`bigtiff=True`, 64-bit offsets, what the
+    reference always writes).
     `overviews`: reduced-resolution copies (arrays, largest first) written as further image file directories behind the
     full-resolution one (NewSubfileType = 1: what GDAL / rasterio list as the dataset's overviews).
     `tags`: dict of GDAL metadata items (name -> value) stored in the GDAL_METADATA tag of the first image (the reference's
     `update_tags`, :925, :931).
     The pixel data are streamed to the file image by image, block by block; the directories follow at the end."""
     a, b, c, d, e, f = transform
+    if compress in (None, False, 0, 'none'):
+        codec = 1
+    elif compress == 'lzw':
+        codec = 5
+    elif compress in (True, 'deflate'):
+        codec = 8
+    else:
+        raise ValueError("compress must be None, 'lzw' or 'deflate', not %r" % (compress,))
     base_dtype = np.asarray(array).dtype
     images = [np.ascontiguousarray(array)]
     for o in overviews:
@@ -301,7 +324,9 @@ def write_geotiff(path, array, transform, projected=False, nodata=None, compress
 
             def put(block):
                 payload = block.tobytes()
-                if compress:
+                if codec == 5:
+                    payload = _lzw_encode(payload)
+                elif codec == 8:
                     payload = zlib.compress(payload, 6)
                 if fh.tell() % 2:
                     fh.write(b'\x00')
@@ -331,7 +356,7 @@ def write_geotiff(path, array, transform, projected=False, nodata=None, compress
 
             if level > 0:
                 add(254, 4, [1])                                            # reduced-resolution version of another image
-            add(256, 4, [w]); add(257, 4, [h]); add(258, 3, [arr.dtype.itemsize * 8]); add(259, 3, [8 if compress else 1])
+            add(256, 4, [w]); add(257, 4, [h]); add(258, 3, [arr.dtype.itemsize * 8]); add(259, 3, [codec])
             add(262, 3, [1]); add(277, 3, [1]); add(339, 3, [kind])
             if tile is None:
                 add(273, off_t, offs); add(278, 4, [h]); add(279, off_t, cnts)

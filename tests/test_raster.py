@@ -451,3 +451,46 @@ def test_writer_nits_metadata_escaping_sum_overview_classic_limit(tmp_path):
             raster.write_geotiff(str(tmp_path / 'big.tif'), a, (1.0, 0.0, 0.0, 0.0, -1.0, 6.0), bigtiff=False)
     finally:
         builtins.open = real_open
+
+
+@pytest.mark.parametrize('dtype', ['uint8', 'int16', 'int32', 'float32', 'float64'])
+def test_lzw_encoder_emits_libtiffs_stream(dtype, tmp_path):
+    """The native TIFF-LZW encoder (csrc/tiff_lzw.cpp; the reference exports with compress='lzw', pydem/process_manager.py:905)
+    against libtiff itself: the strip written for an array is byte for byte what Pillow's libtiff writes for the same
+    bytes (8-bit view: LZW works on the byte stream), our reader decodes both, and libtiff decodes ours."""
+    PIL = pytest.importorskip('PIL')
+    from PIL import Image, features
+    if not features.check('libtiff'):
+        pytest.skip("Pillow without libtiff")
+    rng = np.random.default_rng(5)
+    n, m = 96, 160
+    if dtype.startswith('float'):
+        a = np.round(rng.random((n, m)) * 50).astype(dtype) + np.arange(m, dtype=dtype) / 8        # smooth + repeats: long strings
+    else:
+        a = (rng.integers(0, 7, (n, m)) + np.arange(m) // 3).astype(dtype)
+    raw = a.tobytes()
+    # ---- libtiff's stream for the same bytes: one strip of an 8-bit image that is the byte view of the array
+    view = np.frombuffer(raw, np.uint8).reshape(n, m * a.dtype.itemsize)
+    ref_fn = str(tmp_path / 'ref.tif')
+    Image.fromarray(view).save(ref_fn, format='TIFF', compression='tiff_lzw', tiffinfo={278: n})       # RowsPerStrip = all rows
+    with Image.open(ref_fn) as im:
+        offs, cnts = im.tag_v2[273], im.tag_v2[279]
+        assert len(offs) == 1
+    ref_strip = open(ref_fn, 'rb').read()[offs[0]:offs[0] + cnts[0]]
+    mine = raster._lzw_encode(raw)
+    assert mine == ref_strip, "LZW stream differs from libtiff's (%d vs %d bytes)" % (len(mine), len(ref_strip))
+    assert raster._lzw_decode(mine, len(raw)) == raw
+    # ---- a whole file: ours decoded by libtiff and by our reader
+    fn = str(tmp_path / 'mine.tif')
+    raster.write_geotiff(fn, a, (1.0, 0.0, 0.0, 0.0, -1.0, float(n)), compress='lzw')
+    assert np.array_equal(raster.read_geotiff(fn).array, a)
+    if dtype in ('uint8', 'int16', 'int32', 'float32'):
+        with Image.open(fn) as im:
+            assert np.array_equal(np.asarray(im), a)
+    # tiled, with the table filling up several times (incompressible noise) and an empty payload
+    noise = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    assert raster._lzw_decode(raster._lzw_encode(noise), len(noise)) == noise
+    assert raster._lzw_decode(raster._lzw_encode(b''), 0) == b''
+    fn2 = str(tmp_path / 'tiled.tif')
+    raster.write_geotiff(fn2, a, (1.0, 0.0, 0.0, 0.0, -1.0, float(n)), compress='lzw', tile=32, bigtiff=True)
+    assert np.array_equal(raster.read_geotiff(fn2).array, a)
