@@ -4,10 +4,11 @@ These are the three steps the reference runs before the slope stencil when `fill
 `drain_pits_path` are set (creare-com/pydem v1.2.1, pydem/dem_processing.py: calc_fill_pit_artifacts
 :396-426, calc_fill_flats :551-579 with _fill_flat :308-394, calc_pit_drain_paths :428-548, helpers
 pydem/utils.py:270-468).  The product path runs them ON THE DEVICE (csrc/cond_device.hip, csrc/cond_paths.hip,
-through DEMProcessor.calc_fill_flats / calc_pit_drain_paths); this module is what remains on the host: tiles with
-no-data cells (the order in which scipy's filters meet a NaN is not reproduced on the device), surfaces of a dtype
-the device cannot hold (int64), and the rare tile on which the order-preserving parallel schedule of the pit paths
-gives up.  The vectorised prologues stay in numpy / scipy.ndimage (3x3 filters,
+through DEMProcessor.calc_fill_flats / calc_pit_drain_paths -- tiles with no-data cells included since round 4: the
+device replays scipy's ring filter where a NaN is near); this module is what remains on the host: masked arrays,
+surfaces of a dtype the device cannot hold (int64), a tile whose no-data cells alternate along a line for longer than
+the bounded replay looks back, and the rare tile on which the order-preserving parallel schedule of the pit paths
+gives up.  It is also the twin the device path is tested against (its masks come from scipy itself).  The vectorised prologues stay in numpy / scipy.ndimage (3x3 filters,
 connected-component labels, the argsort whose tie order is part of the result); the per-region / per-pit loops run in
 the native library (csrc/cond_host.cpp, host code behind the same C-ABI).  Results are pinned bit for bit by
 tests/golden/g5_* and g7_* (captured from the reference); the numpy statements the native loops were written from are

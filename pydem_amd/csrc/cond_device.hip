@@ -19,8 +19,8 @@
 //     its cells have SOME finite value, not at convergence (:392-401): the sweep number is part of the result.
 // Every floating-point expression keeps numpy's operation order (-ffp-contract=off); the host implementation
 // (cond_host.cpp behind pydem_amd/conditioning.py, pinned bit for bit by tests/golden/g5_* and g7_*) is the
-// twin the tests compare with.  Tiles with no-data (NaN) cells are left to the host path: the order in which
-// scipy's filters meet a NaN is an implementation detail this file does not reproduce.
+// twin the tests compare with.  Tiles with no-data (NaN) cells run here too: the candidate masks replay scipy's ring
+// filter value for value where a NaN is near (k_cond_ring_*), everything else compares like numpy (NaN: false).
 #include "internal.h"
 #include <math.h>
 
@@ -55,7 +55,13 @@ struct CondArgs {
     int32_t *creg;           // [NN] region index of every mask cell (one hop instead of two in the per-cell kernels)
     int f32;                 // the elevations are float32 values: `rim - 1` rounds in float32 (:424)
     int below_sea;
+    int nan_tile;            // the tile has no-data cells: a region may then hold cells of DIFFERENT heights (a NaN shields a lower
+                             // neighbour from scipy's filter), and "the region's level" is what the reference takes: its first cell
 };
+
+// the level the reference works with (:322, :418: `roi[region][0]`, the region's first cell in raster order = the root of the
+// min-index union-find).  Without no-data cells every cell of a region has that height and the extra load is skipped.
+__device__ __forceinline__ double region_level(const CondArgs &A, int32_t c) { return A.nan_tile ? A.elev[A.labels[c]] : A.elev[c]; }
 
 // one record per region (struct of arrays, sized by the number of mask cells)
 struct Regions {
@@ -100,6 +106,83 @@ __global__ __launch_bounds__(256) void k_cond_mask(CondArgs A, int corners_off, 
         }
         bool v = low && sea_ok(z, A.below_sea);
         if (corners_off && (i == 0 || i == n - 1) && (j == 0 || j == m - 1)) v = false;          // :569-572
+        A.mask[c] = v;
+    }
+}
+
+// ---- no-data (NaN) cells: scipy's minimum_filter, exactly ---------------------------------------------------
+// scipy.ndimage.minimum_filter(x, (3, 3)) is separable: NI_MinOrMaxFilter1D along axis 0, then along axis 1 on the result,
+// and that 1-D filter is a ring of (value, death) pairs (ni_filters.c): a new value that is <= the front REPLACES the
+// whole ring, otherwise it removes the entries >= itself from the back and is appended; the front is reported and leaves
+// after three steps.  Without NaN that is the running minimum; with NaN every comparison is false: a NaN is appended,
+// shields the entries in front of it from later (smaller) values and is reported itself while it is the front.  The masks
+// `minimum_filter(z) >= z` of the reference (:410-412, :565-568) depend on it, so on tiles with no-data cells the two
+// passes are replayed value for value (checked against scipy on random arrays: oracle/ref_harness / tests).  A clean
+// window needs no replay: three values without NaN -> their minimum, three NaN -> NaN.  Otherwise the ring is replayed
+// from the last point where its state is known: the line start, or three consecutive values of one kind (the ring then
+// holds just what those three leave).  RING_BACK bounds the look-back; a line that alternates longer than that sets the
+// give-up flag (the host path takes the tile).
+constexpr int RING_BACK = 48;
+
+template <typename Get>
+__device__ double ring3_at(Get get, int p, int L, int32_t *giveup)
+{
+    // stream index ll = 0 .. L + 1, value pv(ll) = x[clamp(ll - 1)] ('reflect' with one element on either side); the
+    // output of position p is the front after step ll = p + 2
+    auto pv = [&](int ll) -> double { const int q = ll - 1; return get(q < 0 ? 0 : (q >= L ? L - 1 : q)); };
+    const double a = pv(p), b = pv(p + 1), c = pv(p + 2);
+    const bool na = a != a, nb = b != b, nc = c != c;
+    if (!na && !nb && !nc) { double mn = a < b ? a : b; return c < mn ? c : mn; }
+    if (na && nb && nc) return a;
+    // ---- find the start: the latest s <= p + 1 with pv(s - 2 .. s) all of one kind, or the stream start
+    int s = -1;
+    for (int e = p + 1; e >= 2 && e >= p + 2 - RING_BACK; e--) {
+        const double u = pv(e - 2), v = pv(e - 1), w = pv(e);
+        const bool nu = u != u, nv = v != v, nw = w != w;
+        if (nu == nv && nv == nw) { s = e; break; }
+    }
+    int first;
+    if (s < 0) {
+        if (p + 2 - RING_BACK > 0) { *giveup = 1; return a; }
+        first = 0;                                   // from the stream start
+    } else first = s - 2;
+    // ---- replay: ring as arrays (at most 3 live entries)
+    double rv[4]; int rd[4]; int cnt = 1;
+    rv[0] = pv(first); rd[0] = first + 3;
+    for (int ll = first + 1; ll <= p + 2; ll++) {
+        const double val = pv(ll);
+        if (rd[0] == ll) { for (int k = 1; k < cnt; k++) { rv[k - 1] = rv[k]; rd[k - 1] = rd[k]; } cnt--; }
+        if (cnt == 0 || val <= rv[0]) { rv[0] = val; rd[0] = ll + 3; cnt = 1; }
+        else {
+            while (cnt > 0 && rv[cnt - 1] >= val) cnt--;
+            rv[cnt] = val; rd[cnt] = ll + 3; cnt++;
+        }
+    }
+    return rv[0];
+}
+
+// pass 1 (axis 0): tmp[i][j] = ring filter of column j at i
+__global__ __launch_bounds__(256) void k_cond_ring_cols(CondArgs A, double *__restrict__ tmp, int32_t *giveup)
+{
+    const int n = A.n, m = A.m;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < A.NN; c += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(c / m), j = (int)(c - (int64_t)i * m);
+        const double *col = A.elev + j;
+        tmp[c] = ring3_at([&](int q) { return col[(int64_t)q * m]; }, i, n, giveup);
+    }
+}
+
+// pass 2 (axis 1) + the mask: minimum_filter(elev, 3x3) >= elev, above (or not at) sea level
+__global__ __launch_bounds__(256) void k_cond_ring_rows_mask(CondArgs A, const double *__restrict__ tmp, int corners_off, int32_t *giveup)
+{
+    const int n = A.n, m = A.m;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < A.NN; c += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(c / m), j = (int)(c - (int64_t)i * m);
+        const double z = A.elev[c];
+        const double *row = tmp + (int64_t)i * m;
+        const double mn = ring3_at([&](int q) { return row[q]; }, j, m, giveup);
+        bool v = (mn >= z) && sea_ok(z, A.below_sea);
+        if (corners_off && (i == 0 || i == n - 1) && (j == 0 || j == m - 1)) v = false;
         A.mask[c] = v;
     }
 }
@@ -234,7 +317,7 @@ __global__ void k_art_scan(CondArgs A, Regions R, double max_area)
             r = A.creg[c];
             const int i = c / m, j = c - i * m;
             bad = (i == 0 || j == 0 || i == n - 1 || j == m - 1);                 // the one-pixel rim must lie inside (:414-415)
-            const double level = A.elev[c];
+            const double level = region_level(A, c);
             if (!bad) {
                 for (int d = 0; d < 9; d++) {
                     if (d == 4) continue;
@@ -286,7 +369,7 @@ __global__ void k_flat_scan(CondArgs A, Regions R)
             r = A.creg[c];
             i = c / m; j = c - i * m;
             edge = (i == 0 || j == 0 || i == n - 1 || j == m - 1);
-            const double level = A.elev[c];
+            const double level = region_level(A, c);
             for (int d = 0; d < 9; d++) {
                 if (d == 4) continue;
                 const int ii = i + d / 3 - 1, jj = j + d % 3 - 1;
@@ -490,7 +573,7 @@ __global__ __launch_bounds__(256) void k_flat_sweep(CondArgs A, Regions R, const
         double nh = oh, nl = ol;
         if (act_hi || act_lo) {
             const int i = c / m, j = c - i * m;
-            const double level = A.elev[c];
+            const double level = region_level(A, c);
             const double src_max = (fl & RF_SOURCE) ? dunkey(R.lowest_bits[r]) + source_tol : 0.0;   // lowest + tol (:347)
             double card_h = oh, all_h = oh, card_l = ol, all_l = ol;
             for (int d = 0; d < 9; d++) {
@@ -557,7 +640,7 @@ __device__ __forceinline__ void flat_sweep_entry(const CondArgs &A, const Region
     const double oh = dh0[c], ol = dl0[c];
     double nh = oh, nl = ol;
     if (act_hi || act_lo) {
-        const double level = A.elev[c];
+        const double level = region_level(A, c);
         const double src_max = (fl & RF_SOURCE) ? dunkey(lowest_bits) + source_tol : 0.0;   // lowest + tol (:347)
         double card_h = oh, all_h = oh, card_l = ol, all_l = ol;
 #pragma unroll
@@ -793,7 +876,7 @@ __global__ void k_flat_interp(CondArgs A, Regions R, const double *__restrict__ 
         else if (fl & RF_DRN_CENTRE) pinned = R.centre[r] == c;
         else if (fl & RF_SRC_CENTRE) pinned = R.centre[r] == c;
         if (pinned) continue;
-        const double level = A.elev[c], top = R.top[r];
+        const double level = region_level(A, c), top = R.top[r];
         const double h = dh[c], l = dl[c];
         A.built[c] = (top * (l * l) + level * (h * h)) / ((l * l) + (h * h));
     }
@@ -862,7 +945,8 @@ int label_regions(pydem_tile *t, CondArgs &A, int32_t *nf_out, int32_t *nreg_out
 }  // namespace
 
 // calc_fill_flats (:551-579) on the tile's resident elevation: artefact pits first when max_pit_area > 0 (:560-561),
-// then every flat is re-surfaced.  Returns 1 (and leaves the tile untouched) when the tile has NaN cells.
+// then every flat is re-surfaced.  Returns 1 (and leaves the tile untouched) only when a tile with no-data cells defeats the
+// bounded replay of scipy's filter (k_cond_ring_*: salt-and-pepper no-data along a whole line).
 int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double source_tol, int peaks, int pits, int artefacts_only)
 {
     const int n = (int)t->n, m = (int)t->m;
@@ -873,16 +957,28 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
     PYDEM_TRY(tile_alloc(t, &t->queue[1], (size_t)t->NN));
     CondArgs A;
     A.n = n; A.m = m; A.NN = t->NN; A.elev = t->elev; A.built = nullptr; A.mask = t->flat0; A.list = t->flatlist; A.count = t->counters;
-    A.labels = t->labels; A.rid = t->queue[0]; A.creg = t->queue[1]; A.f32 = t->elev_f32 ? 1 : 0; A.below_sea = below_sea;
+    A.labels = t->labels; A.rid = t->queue[0]; A.creg = t->queue[1]; A.f32 = t->elev_f32 ? 1 : 0; A.below_sea = below_sea; A.nan_tile = 0;
     const int big = grid_of(t->NN, 8192);
     int32_t nf = 0, nreg = 0;
+    // a tile with no-data cells: the candidate mask once more, with scipy's NaN behaviour replayed exactly (k_cond_ring_*;
+    // the `mag` plane is scratch here).  Returns 1 when a line defeats the bounded replay (the host path takes the tile).
+    auto nan_mask = [&](int corners_off) -> int {
+        PYDEM_TRY(tile_alloc(t, &t->mag, (size_t)t->NN));
+        HIP_TRY(hipMemsetAsync(t->counters + 9, 0, sizeof(int32_t), t->stream));
+        hipLaunchKernelGGL(k_cond_ring_cols, dim3(big), dim3(256), 0, t->stream, A, t->mag, t->counters + 9);
+        hipLaunchKernelGGL(k_cond_ring_rows_mask, dim3(big), dim3(256), 0, t->stream, A, (const double *)t->mag, corners_off, t->counters + 9);
+        HIP_TRY(hipMemcpyAsync(t->h_counters + 9, t->counters + 9, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        return t->h_counters[9] > 0 ? 1 : 0;
+    };
     // ---- quantisation artefacts
     if (max_pit_area > 0) {
         HIP_TRY(hipMemsetAsync(t->counters + 8, 0, sizeof(int32_t), t->stream));
         hipLaunchKernelGGL(k_cond_mask, dim3(big), dim3(256), 0, t->stream, A, 0, t->counters + 8);
         HIP_TRY(hipMemcpyAsync(t->h_counters + 8, t->counters + 8, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
-        if (t->h_counters[8] > 0) return 1;
+        if (t->h_counters[8] > 0) { const int r = nan_mask(0); if (r) return r; A.nan_tile = 1; }
         PYDEM_TRY(label_regions(t, A, &nf, &nreg));
         if (nf > 0) {
             Scratch S; S.device = t->device; Regions R; int32_t *root_of, *al0, *al1;
@@ -909,7 +1005,7 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
     HIP_TRY(hipMemcpyAsync(t->h_counters + 8, t->counters + 8, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipMemcpyAsync(A.built, t->elev, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
-    if (t->h_counters[8] > 0) return 1;
+    if (t->h_counters[8] > 0) { const int r = nan_mask(1); if (r) return r; A.nan_tile = 1; }
     PYDEM_TRY(label_regions(t, A, &nf, &nreg));
     if (nf > 0) {
         Scratch S; S.device = t->device; Regions R; int32_t *root_of, *al0, *al1;

@@ -542,12 +542,20 @@ __global__ __launch_bounds__(256) void k_paths_pits(const double *__restrict__ e
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < NN; c += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(c / m), j = (int)(c - (int64_t)i * m);
         const double z = e[c];
-        if (isnan(z)) { *nan_count = 1; mask[c] = 0; continue; }       // (a flag, see k_cond_mask)
-        // scipy's 'reflect' border mirrors the cell itself into the footprint on the array edge: e > e is false there
-        bool low = !(i == 0 || j == 0 || i == n - 1 || j == m - 1);
-        for (int d = 0; d < 9 && low; d++) {
-            if (d == 4) continue;
-            if (!(e[c + (d / 3 - 1) * m + (d % 3 - 1)] > z)) low = false;
+        (void)nan_count;
+        // scipy's 'reflect' border mirrors the cell itself into the footprint on the array edge: e > e is false there.
+        // The footprint filter (NI_MinOrMaxFilter) starts with its FIRST element -- the north-west neighbour -- and replaces
+        // it by every later one that compares smaller: a NaN in first place stays (NaN > e is false: no pit), a NaN anywhere
+        // else is never taken.  The same loop, value for value (no-data tiles; without NaN it is the plain minimum).
+        bool low = false;
+        if (!(i == 0 || j == 0 || i == n - 1 || j == m - 1)) {
+            double tmp = e[c - m - 1];
+            for (int d = 1; d < 9; d++) {
+                if (d == 4) continue;
+                const double v = e[c + (d / 3 - 1) * m + (d % 3 - 1)];
+                if (v < tmp) tmp = v;
+            }
+            low = tmp > z;
         }
         mask[c] = low && (below_sea ? (z != 0.0) : (z > 0.0));
     }
@@ -575,7 +583,7 @@ int gridp(int64_t work, int cap) { const int64_t g = cdiv(work, 256); return (in
 
 }  // namespace
 
-// step 1: the pits of the resident surface.  *npits = number of strict minima, or -1 when the tile has NaN cells.
+// step 1: the pits of the resident surface.  *npits = number of strict minima (no-data cells compare like numpy's NaN).
 // The caller reads their cells and elevations (stage_pit_paths_candidates), sorts them like the reference
 // (np.argsort) and passes the order to stage_pit_paths.
 int stage_pit_candidates(pydem_tile *t, int below_sea, int64_t *npits)
@@ -589,7 +597,7 @@ int stage_pit_candidates(pydem_tile *t, int below_sea, int64_t *npits)
     HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(t->stream));
-    *npits = t->h_counters[8] > 0 ? -1 : t->h_counters[0];
+    *npits = t->h_counters[0];
     return 0;
 }
 

@@ -307,8 +307,8 @@ class DEMProcessor(object):
         self._tile.find_flats()
         self._produced('flats')
 
-    # ---- elevation conditioning: artefacts and flats on the device (csrc/cond_device.hip); tiles with no-data cells and
-    # the pit drain paths go through the host implementation (pydem_amd/conditioning.py)
+    # ---- elevation conditioning: artefacts, flats and pit drain paths on the device (csrc/cond_device.hip, csrc/cond_paths.hip),
+    # tiles with no-data cells included; masked arrays / exotic dtypes go through the host implementation (pydem_amd/conditioning.py)
     def _condition_on_device(self, artefacts_only):
         """True when the resident elevation was conditioned by the library (False: the caller falls back to the host)."""
         elev = self._host.get('elev')
@@ -357,7 +357,7 @@ class DEMProcessor(object):
         res = self._pit_paths_on_device()
         if res is None and self._tile is not None and 'elev' in self._on_device:
             warnings.warn("calc_pit_drain_paths: the device schedule handed this tile to the sequential host loop "
-                          "(no-data cells or a conflict of the speculative rounds): same result, much slower")
+                          "(a conflict of the speculative rounds): same result, much slower")
         if res is not None:
             n_failed, used, self._pit_path_rounds = res
             if n_failed:

@@ -25,7 +25,7 @@ def test_conditioning_matches_reference(name):
         if kw.get('maximum_pit_area', 32.0):
             art = conditioning.fill_pit_artifacts(elev, kw.get('maximum_pit_area', 32.0), sea)
             assert art.dtype == g['elev_artifacts'].dtype
-            assert np.array_equal(art, g['elev_artifacts'])
+            assert np.array_equal(art, g['elev_artifacts'], equal_nan=True)
         filled = conditioning.fill_flats(elev, kw.get('maximum_pit_area', 32.0), sea, kw.get('fill_flats_source_tol', 1),
                                          kw.get('fill_flats_peaks', True), kw.get('fill_flats_pits', True))
         assert np.array_equal(filled, g['elev_filled'], equal_nan=True)

@@ -33,11 +33,10 @@ def test_device_conditioning_matches_reference(name):
         dp = _dp(g['in_elev'].copy(), **opts)
         dp.calc_fill_pit_artifacts()
         assert np.asarray(dp.elev).dtype == g['elev_artifacts'].dtype
-        assert np.array_equal(dp.elev, g['elev_artifacts'])
+        assert np.array_equal(dp.elev, g['elev_artifacts'], equal_nan=True)
     dp = _dp(g['in_elev'].copy(), **opts)
     dp.calc_fill_flats()
-    on_device = 'elev' in dp._on_device
-    assert on_device or np.isnan(np.asarray(g['in_elev'], float)).any()
+    assert 'elev' in dp._on_device              # (tiles with no-data cells too: the masks replay scipy's filter, csrc/cond_device.hip)
     assert np.asarray(dp.elev).dtype == np.float64
     assert np.array_equal(dp.elev, g['elev_filled'], equal_nan=True)
 
@@ -122,6 +121,47 @@ def test_device_pit_paths_match_reference(name):
     got = np.asarray(dp.elev)
     assert got.dtype == g['elev_drained'].dtype
     assert np.array_equal(got, g['elev_drained'], equal_nan=True)
+    if name.startswith('g7_nan'):               # no-data tiles stay on the device (round 4): neither step took the host loops
+        assert getattr(dp, '_pit_path_rounds', None) is not None
+
+
+@pytest.mark.parametrize('block', range(3))
+def test_device_conditioning_with_nodata_matches_host_twin(block):
+    """Random tiles with no-data cells (blocks, margins, scattered voids, the sea as NaN: tools/soak_conditioning_device.py with
+    SOAK_NAN=1) through the device conditioning against the host implementation, whose masks come from scipy itself: the
+    replay of scipy's ring filter (csrc/cond_device.hip k_cond_ring_*), regions of mixed height, pits next to voids -- bit for
+    bit after each step, on the device for both (reference: pydem/dem_processing.py:396-579 with utils.py:342-402)."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    old = os.environ.get('SOAK_NAN')
+    os.environ['SOAK_NAN'] = '1'
+    try:
+        import soak_conditioning_device as S
+        from pydem_amd import DEMProcessor, conditioning as C
+        seen_nan = 0
+        for k in range(block * 25, block * 25 + 25):
+            rec, z, o, dX, dY = S.make_case(k)
+            n = z.shape[0]
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                want1 = C.fill_flats(z, o['maximum_pit_area'], o['fill_flats_below_sea'], o['fill_flats_source_tol'], o['fill_flats_peaks'], o['fill_flats_pits'])
+                want2, _, _ = C.pit_drain_paths(want1.copy(), np.full(n - 1, dX), np.full(n - 1, dY), o['drain_pits_max_iter'], o['drain_pits_max_dist'],
+                                                o['drain_pits_max_dist_XY'], o['fill_flats_below_sea'])
+                dp = DEMProcessor(elev=z.copy(), dX=dX, dY=dY, **o)
+                dp.calc_fill_flats()
+                assert 'elev' in dp._on_device, rec
+                assert np.array_equal(np.array(dp.elev), want1, equal_nan=True), rec
+                dp.calc_pit_drain_paths()
+                assert np.array_equal(np.array(dp.elev), want2, equal_nan=True), rec
+            seen_nan += int(np.isnan(z).any())
+        assert seen_nan >= 15
+    finally:
+        if old is None:
+            os.environ.pop('SOAK_NAN', None)
+        else:
+            os.environ['SOAK_NAN'] = old
 
 
 @pytest.mark.parametrize('block', range(4))

@@ -36,6 +36,21 @@ def make_case(k):
         z = np.where(z < lvl, lvl, z)
     if rng.random() < 0.3:
         z[z < 0] = 0.0                                              # sea
+    if os.environ.get('SOAK_NAN') == '1' and rng.random() < 0.85:   # no-data: blocks, a margin, scattered cells, isolated cells in a lake
+        z = np.array(z, np.float64)
+        kindn = rng.random()
+        if kindn < 0.4:
+            for _ in range(int(rng.integers(1, 5))):
+                i0, j0 = int(rng.integers(0, n)), int(rng.integers(0, m))
+                z[i0:i0 + int(rng.integers(1, max(2, n // 3))), j0:j0 + int(rng.integers(1, max(2, m // 3)))] = np.nan
+        elif kindn < 0.6:
+            z[:, : int(rng.integers(1, max(2, m // 4)))] = np.nan
+            if rng.random() < 0.5:
+                z[-int(rng.integers(1, max(2, n // 4))):, :] = np.nan
+        elif kindn < 0.85:
+            z[rng.random(z.shape) < float(rng.choice([0.002, 0.02, 0.15]))] = np.nan
+        else:
+            z[z <= np.nanquantile(z, 0.3)] = np.nan                # the sea as no-data
     opts = dict(fill_flats_below_sea=bool(rng.random() < 0.3), fill_flats_source_tol=float(rng.choice([1, 0.5, 3])),
                 fill_flats_peaks=bool(rng.random() < 0.7), fill_flats_pits=bool(rng.random() < 0.7),
                 maximum_pit_area=float(rng.choice([32.0, 0.0, 4.0, 400.0])),
@@ -60,6 +75,8 @@ def main():
                                                       o['drain_pits_max_dist'], o['drain_pits_max_dist_XY'], o['fill_flats_below_sea'])
         dp = DEMProcessor(elev=z.copy(), dX=dX, dY=dY, **o)
         dp.calc_fill_flats()
+        if os.environ.get('SOAK_NAN') == '1' and 'elev' not in dp._on_device:
+            host_flats = globals().get('host_flats', 0) + 1; globals()['host_flats'] = host_flats
         got1 = np.array(dp.elev)
         if not np.array_equal(got1, want1, equal_nan=True):
             print('MISMATCH after fill_flats', rec, int((got1 != want1).sum()), 'cells'); sys.exit(1)
@@ -70,8 +87,8 @@ def main():
         if not np.array_equal(got2, want2, equal_nan=True):
             print('MISMATCH after pit_drain_paths', rec, int((got2 != want2).sum()), 'cells'); sys.exit(1)
         done += 1
-    print('device conditioning soak ok: %d random tiles up to case %d in %.0f s (%d took the host loop for the paths)'
-          % (done, k, time.time() - t0, host_fallbacks))
+    print('device conditioning soak ok: %d random tiles up to case %d in %.0f s (%d took the host loop for the paths, %d the host fill_flats)'
+          % (done, k, time.time() - t0, host_fallbacks, globals().get('host_flats', 0)))
 
 
 if __name__ == '__main__':
