@@ -1035,6 +1035,7 @@ class ProcessManager(object):
         width = max(1, 2 * int(self.n_workers))
         self.edge_tiebreaks = 0
         last_hash = {}
+        built = set()                      # tiles whose first round (the one that builds the fix-up state) has run
         mets = np.zeros((n_t, 2))
         def refresh_mets(tiles):
             for a in tiles:
@@ -1078,9 +1079,14 @@ class ProcessManager(object):
                 t0 = time.perf_counter()
                 self.tiles[a].run_edge_round_dev()
                 self.edge_round_log.append((self.edge_waves, a, (time.perf_counter() - t0) * 1e3))
-            if k > 1 and len(mine) > 1:
+            # a tile's FIRST round builds its fix-up state on the host (compact records + the condensed graph of the watched
+            # cells, csrc/uca_cond.inl: ~25 ms of C++ per 16384^2 tile, the GIL is released): tiles of one process build side by side
+            fresh = [a for a in mine if a not in built]
+            built.update(mine)
+            kk = max(k, min(len(fresh), 8)) if len(fresh) > 1 else k
+            if kk > 1 and len(mine) > 1:
                 from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(max_workers=k) as ex:
+                with ThreadPoolExecutor(max_workers=kk) as ex:
                     list(ex.map(one, mine))
             else:
                 for a in mine:
@@ -1099,8 +1105,13 @@ class ProcessManager(object):
             for a in wave:                      # like check_mets (:1116-1136): the tiles that ran and their four side
                 check.update(self._neighbours(a))   # neighbours; a diagonal neighbour keeps its old metric until then
             refresh_mets(sorted(check))
-        for a in owned:
-            self.tiles[a].flush_edge_rounds()
+        if len(owned) > 1:                 # the interiors catch up: one latency-bound cascade per tile, side by side on their streams
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(len(owned), 8)) as ex:
+                list(ex.map(lambda a: self.tiles[a].flush_edge_rounds(), owned))
+        else:
+            for a in owned:
+                self.tiles[a].flush_edge_rounds()
         self._mets = mets.copy()
         board.close()
         return mets

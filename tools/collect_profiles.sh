@@ -21,6 +21,8 @@ timeout 600 python bench.py --drain-pits 0 --cpu-sample 0 > gpurun_out/prof/benc
 timeout 300 python bench.py --config 2 > gpurun_out/prof/bench_config2.json 2> gpurun_out/prof/bench_config2.err
 timeout 600 python bench.py --config 5 > gpurun_out/prof/bench_config5.json 2> gpurun_out/prof/bench_config5.err
 cat gpurun_out/prof/bench_*.json
-PM_WORKERS=8 PM_EDGE_MODE=pool timeout 900 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/prof/pm_pool_8x16384.log 2>&1
+PYDEM_EDGE_SYNC=1 PM_WORKERS=8 PM_EDGE_MODE=pool timeout 900 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/prof/pm_pool_8x16384.log 2>&1
+PYDEM_EDGE_COND=0 PM_WORKERS=8 PM_EDGE_MODE=pool timeout 900 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/prof/pm_pool_8x16384_cell_by_cell.log 2>&1
+PM_WORKERS=8 PM_EDGE_MODE=pool timeout 900 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/prof/pm_pool_8x16384_async.log 2>&1
 PM_WORKERS=1 PM_EDGE_MODE=reference timeout 900 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/prof/pm_serial_8x16384.log 2>&1
 tail -2 gpurun_out/prof/pm_pool_8x16384.log | cut -c1-200; tail -2 gpurun_out/prof/pm_serial_8x16384.log | cut -c1-200
