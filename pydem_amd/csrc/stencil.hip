@@ -134,6 +134,9 @@ __device__ __forceinline__ void facet_lean(double s1, double s2, double sd, doub
 // operations instead of ~11 with a quarter-rate v_rcp_f64
 __device__ __forceinline__ double div_row(double x, double d, double r)
 {
+#ifdef PYDEM_STENCIL_CHEAP      // upper-bound experiment (DESIGN.md section 4 "Round 4" (5)): NOT exact, never the product build
+    (void)d; return x * r;
+#endif
     const double q = x * r;
     const double rem = __builtin_fma(-q, d, x);
     return __builtin_fma(rem, r, q);
@@ -294,6 +297,9 @@ __device__ __forceinline__ double pick(lmask m, double a, double b) { return ON(
 // exponent rescue of the generic expansion, which slopes cannot need: |slope| in [2^-500, 2^500] by the window test)
 __device__ __forceinline__ double div_pos(double a, double b)
 {
+#ifdef PYDEM_STENCIL_CHEAP
+    { double y0 = __builtin_amdgcn_rcp(b); const double e0 = __builtin_fma(-b, y0, 1.0); y0 = __builtin_fma(y0, e0, y0); return a * y0; }
+#endif
     double y = __builtin_amdgcn_rcp(b);
     double e = __builtin_fma(-b, y, 1.0);
     y = __builtin_fma(y, e, y);
@@ -456,7 +462,11 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, Row
         const double rs = __hiloint2double(__double2hiint(r) ^ (int)((unsigned)k << 31), __double2loint(r));   // ang[1] = -1 for odd facets
         const double direction = rs + (double)((k + 1) >> 1) * (PI_D / 2);
         const size_t cc = (size_t)b * m + cx.j;
+#ifdef PYDEM_STENCIL_CHEAP
+        cx.mag[cc] = M > 0 ? M * __builtin_amdgcn_rsq(M) : M;
+#else
         cx.mag[cc] = M > 0 ? sqrt(M) : M;                              // :1901
+#endif
         cx.dir[cc] = pick(flat, -1.0, direction);
         cx.flat0[cc] = ON(flat) ? 1 : 0;
     }

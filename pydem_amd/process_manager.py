@@ -1043,6 +1043,13 @@ class ProcessManager(object):
                 mets[a] = (nd / (1e-16 + float(scal[a, 1])), nd)
 
         refresh_mets(range(n_t))
+        prof = {'select': 0.0, 'rounds': 0.0, 'refresh': 0.0, 'eval': 0.0} if os.environ.get('PYDEM_EDGE_PROFILE') else None
+        tp = time.perf_counter()
+
+        def lap(key):                      # PYDEM_EDGE_PROFILE=1: host wall-clock of the wave loop by part
+            nonlocal tp
+            if prof is not None:
+                now = time.perf_counter(); prof[key] += now - tp; tp = now
         while self.edge_waves < self.max_edge_rounds:
             eff = np.zeros_like(mets)
             cand = []
@@ -1074,6 +1081,7 @@ class ProcessManager(object):
                 if self.keep_first_pass_uca and self.uca0[a] is None:
                     self.uca0[a] = np.array(dp.uca)
             k = self._in_flight()
+            lap('select')
 
             def one(a):
                 t0 = time.perf_counter()
@@ -1091,12 +1099,15 @@ class ProcessManager(object):
             else:
                 for a in mine:
                     one(a)
+            lap('rounds')
             refresh(wave)
+            lap('refresh')
             affected = set()
             for a in wave:
                 affected |= readers[a]
             affected = sorted(affected)
             scal = board.eval(affected, [0] * len(affected))
+            lap('eval')
             if checking:
                 check_against_host_rules(range(n_t), scal)
             self.edge_rounds += len(wave)
@@ -1105,6 +1116,9 @@ class ProcessManager(object):
             for a in wave:                      # like check_mets (:1116-1136): the tiles that ran and their four side
                 check.update(self._neighbours(a))   # neighbours; a diagonal neighbour keeps its old metric until then
             refresh_mets(sorted(check))
+        if prof is not None:
+            import sys
+            sys.stderr.write("edge fix-up wave loop (host ms): %s over %d waves\n" % (', '.join('%s %.1f' % (k2, v * 1e3) for k2, v in prof.items()), self.edge_waves))
         if len(owned) > 1:                 # the interiors catch up: one latency-bound cascade per tile, side by side on their streams
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=min(len(owned), 8)) as ex:

@@ -6,7 +6,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 TMP=$(mktemp -d)
 sed 's/if (__builtin_expect(!exact, 1)) {/if (true) {/' $ROOT/pydem_amd/csrc/stencil.hip > $TMP/stencil_cnt.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-unused-variable \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-unused-variable $STENCIL_EXTRA \
     -I$ROOT/pydem_amd/csrc -I$ROOT/include -S --cuda-device-only -o $TMP/cnt.s $TMP/stencil_cnt.hip 2>/dev/null
 awk '/^_ZN12_GLOBAL__N_115k_stencil_marchILb0E/{f=1} f{print} /^\.Lfunc_end/{if(f)exit}' $TMP/cnt.s > $TMP/m.s
 L0=$(grep -n "Loop Header" $TMP/m.s | head -1 | cut -d: -f1); L1=$(grep -n "s_cbranch_scc0" $TMP/m.s | tail -1 | cut -d: -f1)
