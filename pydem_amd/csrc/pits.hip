@@ -1078,10 +1078,23 @@ __global__ __launch_bounds__(256, PYDEM_WV_OCC) void k_pits_wave(PitParams P, co
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t np = *npits;
     int32_t chunk_base = 0, chunk_left = 0;
+#ifdef PYDEM_WV_STATIC
     for (int32_t q = blockIdx.x * 4 + wave; q < np; q += gridDim.x * 4) {
         solve_pit_wave(P, pits[q], lane, s_l[wave], chunk_base, chunk_left);
         wave_sync();
     }
+#else
+    // persistent wavefronts take the next pit from a counter: a pit needs 5 .. 300 rounds, and with a fixed stride the four
+    // wavefronts of a workgroup (one LDS allocation) wait for the one that drew the long pits
+    for (;;) {
+        int32_t q = 0;
+        if (lane == 0) q = atomicAdd(P.work_next, 1);
+        q = __shfl(q, 0);
+        if (q >= np) break;
+        solve_pit_wave(P, pits[q], lane, s_l[wave], chunk_base, chunk_left);
+        wave_sync();
+    }
+#endif
 }
 
 // the same with a 256x256 window and room for 2048 border cells: one pit per 64-thread workgroup
@@ -1350,7 +1363,12 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             (void)hipFree(P.prof); P.prof = nullptr;
         }
         if (n_lane_over > 0) {
+#ifdef PYDEM_WV_STATIC
             const int gw = (int)(cdiv(n_lane_over, 4) < 16384 ? cdiv(n_lane_over, 4) : 16384);
+#else
+            const int gw = (int)(cdiv(n_lane_over, 4) < 256 * PYDEM_WV_OCC ? cdiv(n_lane_over, 4) : 256 * PYDEM_WV_OCC);     // resident: every CU full
+            HIP_TRY(hipMemsetAsync(cnt + 10, 0, sizeof(int32_t), t->stream));
+#endif
             hipLaunchKernelGGL(k_pits_wave, dim3(gw), dim3(256), 0, t->stream, P, t->queue[0], cnt + 5);
             HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));

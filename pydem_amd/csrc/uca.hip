@@ -935,52 +935,70 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
     tile_wave_sync();
 }
 
-// every tile that is not done yet, four tiles per workgroup, XCD-contiguous bands of tiles (LISTED: also
-// lists the tiles of the next pass)
+// every tile that is not done yet (LISTED: also lists the tiles of the next pass).  Persistent wavefronts, XCD-contiguous
+// bands of tiles: workgroup b runs on XCD b % 8 and its wavefronts take the next tile of that XCD's band from the band's
+// counter -- a visit lasts 20 .. 100 rounds, and with four fixed tiles per workgroup the LDS of a workgroup (an eighth of
+// the CU's) sat behind its slowest visit (PYDEM_SWEEP_STATIC build: the round-3 mapping, for A/B runs)
 template <bool LISTED>
 __global__ __launch_bounds__(256, 8) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total,
-                                                     uint8_t *__restrict__ tile_done, int32_t *n_final, TileNext N)
+                                                     uint8_t *__restrict__ tile_done, int32_t *n_final, TileNext N, int32_t *work8)
 {
     __shared__ TileW L[4];
-    __shared__ int32_t s_fin[4], s_np[4], s_pend[4][TILE_PEND], s_base;
+    __shared__ int32_t s_pend[4][TILE_PEND];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    // workgroup b runs on XCD b % 8: give every XCD one contiguous band of tiles (gridDim.x is a multiple of 8)
-    const int per = (gridDim.x >> 3) * 4;
-    const int tid = (blockIdx.x & 7) * per + (blockIdx.x >> 3) * 4 + wave;
     int32_t fin = 0;
     int npend = 0;
-    if (tid < tiles_total && !tile_done[tid])
-        sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend);
-    // the counter of finished cells and the counter of the next pass's tile list are single addresses: a quarter of a
-    // million tile runs per pass adding to them one by one keep their L2 channel busy for ~10 ns each -- one add per
-    // workgroup for either
-    if (lane == 0) { s_fin[wave] = fin; s_np[wave] = npend; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int32_t tot = s_fin[0] + s_fin[1] + s_fin[2] + s_fin[3];
-        if (tot) atomicAdd(n_final, tot);
-        if (LISTED) { const int32_t np = s_np[0] + s_np[1] + s_np[2] + s_np[3]; s_base = np ? atomicAdd(N.count, np) : 0; }
-    }
-    if (LISTED) {
-        __syncthreads();
-        int32_t base = s_base;
-        for (int w = 0; w < wave; w++) base += s_np[w];
+    auto flush = [&]() {
+        tile_wave_sync();
+        int32_t base = 0;
+        if (lane == 0) base = atomicAdd(N.count, npend);
+        base = __shfl(base, 0);
         if (lane < npend) N.list[base + lane] = s_pend[wave][lane];
+        npend = 0;
+        tile_wave_sync();
+    };
+#ifdef PYDEM_SWEEP_STATIC
+    (void)work8;
+    const int per4 = (gridDim.x >> 3) * 4;
+    for (int tid = (blockIdx.x & 7) * per4 + (blockIdx.x >> 3) * 4 + wave, once = 0; once < 1; once++) {
+        if (tid < tiles_total && !tile_done[tid])
+            sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend);
     }
+#else
+    const int xcd = blockIdx.x & 7;
+    const int per = (tiles_total + 7) >> 3;
+    for (;;) {
+        int32_t q = 0;
+        if (lane == 0) q = atomicAdd(&work8[xcd], 1);
+        q = __builtin_amdgcn_readfirstlane(__shfl(q, 0));
+        const int tid = xcd * per + q;
+        if (q >= per || tid >= tiles_total) break;
+        if (tile_done[tid]) continue;
+        sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend);
+        if (LISTED && npend > TILE_PEND - 10) flush();      // (a visit adds at most ten)
+    }
+#endif
+    if (LISTED && npend) flush();
+    // the counter of finished cells is a single address: one add per wavefront
+    if (lane == 0 && fin) atomicAdd(n_final, fin);
 }
 
-// later passes: only the listed tiles (those a finished cell of the previous pass drains into); lists the next ones
+// later passes: only the listed tiles (those a finished cell of the previous pass drains into); lists the next ones.  The
+// wavefronts take the list entries from a counter (work3[pass % 3]; the counter of the next pass is cleared here).
 #ifndef PYDEM_LISTED_OCC
 #define PYDEM_LISTED_OCC 6
 #endif
 __global__ __launch_bounds__(256, PYDEM_LISTED_OCC) void k_sweep_tiles_listed(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
                                                             const int32_t *n_in, uint8_t *__restrict__ tile_done, int32_t *n_final,
-                                                            TileNext N, int32_t *clear_count)
+                                                            TileNext N, int32_t *clear_count, int32_t *work3)
 {
     __shared__ TileW L[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t nt = *n_in;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *clear_count = 0;      // the list of the pass after the next one
+#ifdef PYDEM_LISTED_DYNAMIC
+    if (blockIdx.x == 0 && threadIdx.x < 8) work3[((pass + 1) % 3) * 8 + threadIdx.x] = 0;         // the next pass's work counters
+#endif
+    if (blockIdx.x == 0 && threadIdx.x == 0) *clear_count = 0;                                     // the list of the pass after the next one
     // (the tile id is the same for the whole wavefront: as a scalar it keeps the tile's coordinates and every address
     // derived from them out of the vector registers)
     __shared__ int32_t s_pend[4][TILE_PEND];
@@ -995,7 +1013,25 @@ __global__ __launch_bounds__(256, PYDEM_LISTED_OCC) void k_sweep_tiles_listed(Sw
         npend = 0;
         tile_wave_sync();
     };
+#ifndef PYDEM_LISTED_DYNAMIC
+    // (taking the list entries from counters like the full passes do was measured and is slower here: 2.74 / 2.18 / 1.68 ms
+    // against 2.41 / 1.79 / 1.26 ms for passes 4-6 -- -DPYDEM_LISTED_DYNAMIC keeps the variant)
+    (void)work3;
     for (int32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); k < nt; k += gridDim.x * 4) {
+#else
+    // eight counters (one per XCD's workgroups, each over an eighth of the list): a single one would see a grab per visit
+    // from every wavefront of the chip -- 100 k returning atomics on one address per pass, ~10 ns each
+    const int xcd = blockIdx.x & 7;
+    const int32_t per = (nt + 7) >> 3;
+    int32_t *wk = &work3[(pass % 3) * 8 + xcd];
+    for (;;) {
+        int32_t k = 0;
+        if (lane == 0) k = atomicAdd(wk, 1);
+        k = __builtin_amdgcn_readfirstlane(__shfl(k, 0));
+        if (k >= per) break;
+        k += xcd * per;
+        if (k >= nt) break;
+#endif
         sweep_one_tile<true>(A, L[wave], pass, tiles_x, __builtin_amdgcn_readfirstlane(list_in[k]), lane, tile_done, fin, N, s_pend[wave], npend);
         if (npend > TILE_PEND - 10) flush();            // (a visit adds at most ten)
     }
@@ -2900,6 +2936,8 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     if (A.dbg & 4) HIP_TRY(hipMemsetAsync(t->counters + 32, 0, 24 * sizeof(int32_t), t->stream));
     int64_t launches = 0;
     uint32_t pass = 0;
+    int32_t *work16 = t->counters + 16, *work3 = t->counters + 16;      // band counters of the two full passes / rotating counters of the listed ones
+    HIP_TRY(hipMemsetAsync(work16, 0, 16 * sizeof(int32_t), t->stream));
     static int lds_pad = -1;        // occupancy experiments only: extra dynamic LDS per workgroup (PYDEM_TILE_LDS_PAD)
     if (lds_pad < 0) { const char *e = getenv("PYDEM_TILE_LDS_PAD"); lds_pad = e ? atoi(e) : 0; }
     // listed tile passes from pass p on (the list of pass p is in tile_list[p % 2] / cntT[p % 3]); returns the next pass number
@@ -2910,7 +2948,12 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         N.flag = tile_flag;
         while (ntiles > 0) {
             const int batch = ntiles < 2048 ? 16 : 8;    // passes between two looks at the list size (a look idles the GPU for ~30 us; the grid only shrinks below 8192 listed tiles)
+#ifndef PYDEM_LISTED_DYNAMIC
             const int grid = (int)(ntiles < 8192 ? (ntiles > 64 ? ntiles : 64) : 8192);
+#else
+            const int64_t want = cdiv(ntiles, 4);            // persistent wavefronts: no more workgroups than the chip holds at once
+            const int grid = (int)(want < 256 * PYDEM_LISTED_OCC ? (want > 16 ? want : 16) : 256 * PYDEM_LISTED_OCC);
+#endif
             const bool resident = ntiles <= res_switch;
             for (int b = 0; b < batch; b++, p++) {
                 N.list = tile_list[(p + 1) % 2]; N.count = &cntT[(p + 1) % 3];
@@ -2921,7 +2964,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
                 else
                     hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), (size_t)lds_pad, t->stream, A, (uint32_t)p, tiles_x,
                                        (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
-                                       &cntT[(p + 2) % 3]);
+                                       &cntT[(p + 2) % 3], work3);
                 launches++;
             }
             if (hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream) != hipSuccess) return -1;
@@ -3026,7 +3069,12 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
 #else
     constexpr int sweep_mode = 0;
 #endif
+#ifdef PYDEM_SWEEP_STATIC
     const unsigned full_grid = (unsigned)(((tiles_total + 31) / 32) * 8);
+#else
+    const unsigned full_grid = (unsigned)std::min<int64_t>(((tiles_total + 31) / 32) * 8, 256 * 8);    // persistent: eight workgroups per CU
+#endif
+
     if (sweep_mode == 0) {
         // pass 1 over every tile, pass 2 over every tile that is not done (it also lists the tiles of pass 3),
         // then only the listed tiles until no tile is listed any more
@@ -3049,10 +3097,11 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
             hipLaunchKernelGGL(k_sweep_first, dim3((unsigned)(((tiles_total + 7) / 8) * 8)), dim3(256), 0, t->stream, A, tiles_x, tiles_total, tile_done, total);
         else {
             TileNext N0; N0.flag = nullptr; N0.list = nullptr; N0.count = nullptr;
-            hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, pb + 1u, tiles_x, tiles_total, tile_done, total, N0);
+            hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, pb + 1u, tiles_x, tiles_total, tile_done, total, N0, work16);
         }
         TileNext N; N.flag = tile_flag; N.list = tile_list[(pb + 3) % 2]; N.count = &cntT[(pb + 3) % 3];
-        hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, pb + 2u, tiles_x, tiles_total, tile_done, total, N);
+        hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, pb + 2u, tiles_x, tiles_total, tile_done, total, N, work16 + 8);
+        HIP_TRY(hipMemsetAsync(work3, 0, 24 * sizeof(int32_t), t->stream));       // (the listed passes reuse the band counters' words: 3 x 8, rotating)
         launches += 2;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
@@ -3080,7 +3129,8 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     for (;;) {
         pass++;
         { TileNext N0; N0.flag = nullptr; N0.list = nullptr; N0.count = nullptr;
-          hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), 0, t->stream, A, pass, tiles_x, tiles_total, tile_done, total, N0); }
+          HIP_TRY(hipMemsetAsync(work16, 0, 16 * sizeof(int32_t), t->stream));
+          hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), 0, t->stream, A, pass, tiles_x, tiles_total, tile_done, total, N0, work16); }
         launches++;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
@@ -3125,7 +3175,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
                     N.list = tile_list[(p + 1) % 2]; N.count = &cntT[(p + 1) % 3];
                     hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), 0, t->stream, A, (uint32_t)p, tiles_x,
                                        (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
-                                       &cntT[(p + 2) % 3]);
+                                       &cntT[(p + 2) % 3], work3);
                     launches++;
                 }
                 HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
