@@ -402,11 +402,26 @@ __global__ __launch_bounds__(256, PYDEM_SMALL_WAVES) void k_paths_small(PathArgs
     __shared__ double s_rimz[4][SRCAP];
     __shared__ int32_t s_flist[4][64];
     __shared__ uint16_t s_holes[4][SRCAP];
-    const int wv = threadIdx.x >> 6;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#ifdef PYDEM_PATHS_STATIC
     const int q = blockIdx.x * 4 + wv;
     if (q >= nslots) return;
     if (A.tier[q] > 0) return;       // known to leave the small window: its medium / large-window simulation runs beside this kernel
     simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_holes[wv], s_flist[wv], s_trail[wv], STCAP);
+#else
+    // persistent wavefronts take the next slot from a counter (flags[3], cleared by k_paths_slots): a simulation lasts 1 .. 300
+    // iterations, and with four fixed slots per workgroup its LDS waits for the longest of the four
+    for (;;) {
+        int q = 0;
+        if (lane == 0) q = atomicAdd(&A.flags[3], 1);
+        q = __shfl(q, 0);
+        if (q >= nslots) break;
+        if (A.tier[q] > 0) continue;     // known to leave the small window: its medium / large-window simulation runs beside this kernel
+        simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_holes[wv], s_flist[wv], s_trail[wv], STCAP);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+#endif
 }
 
 // pits that left the small window: one wavefront per workgroup, the window in dynamic LDS, the trail in global scratch.
@@ -517,7 +532,7 @@ __global__ __launch_bounds__(256) void k_paths_release(PathArgs A)
 // slot tables of a round: small slots point into the per-slot arrays
 __global__ void k_paths_slots(PathArgs A, int32_t *F, int32_t *C, double *CV, int fcap, int ccap)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) A.flags[2] = 0x7FFFFFFF;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { A.flags[2] = 0x7FFFFFFF; A.flags[3] = 0; }
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < A.nw; s += gridDim.x * blockDim.x) {
         A.Fp[s] = F + (int64_t)s * fcap; A.Cp[s] = C + (int64_t)s * ccap; A.CVp[s] = CV + (int64_t)s * ccap;
         A.fcap[s] = fcap; A.ccap[s] = ccap;
@@ -802,7 +817,11 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
             PYDEM_TRY(launch_large(qs, 0, t->stream2, check ? 0 : 1));
             HIP_TRY(hipEventRecord(t->ev_join, t->stream2));
         }
+#ifdef PYDEM_PATHS_STATIC
         hipLaunchKernelGGL(k_paths_small, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A, nw);
+#else
+        hipLaunchKernelGGL(k_paths_small, dim3((unsigned)std::min<int64_t>(cdiv(nw, 4), 256 * PYDEM_SMALL_WAVES)), dim3(256), 0, t->stream, A, nw);
+#endif
         HIP_TRY(hipMemcpyAsync(pin_status, b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(t->stream));

@@ -1028,8 +1028,8 @@ __global__ __launch_bounds__(256, PYDEM_LISTED_OCC) void k_sweep_tiles_listed(Sw
         int32_t k = 0;
         if (lane == 0) k = atomicAdd(wk, 1);
         k = __builtin_amdgcn_readfirstlane(__shfl(k, 0));
-        if (k >= per) break;
-        k += xcd * per;
+        (void)per;
+        k = k * 8 + xcd;                   // interleaved: the list is in wake order, contiguous eighths would be regions of unequal work
         if (k >= nt) break;
 #endif
         sweep_one_tile<true>(A, L[wave], pass, tiles_x, __builtin_amdgcn_readfirstlane(list_in[k]), lane, tile_done, fin, N, s_pend[wave], npend);
