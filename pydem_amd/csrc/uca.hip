@@ -988,11 +988,15 @@ __global__ __launch_bounds__(256, 8) void k_sweep_tiles(SweepArgs A, uint32_t pa
 #ifndef PYDEM_LISTED_OCC
 #define PYDEM_LISTED_OCC 6
 #endif
-__global__ __launch_bounds__(256, PYDEM_LISTED_OCC) void k_sweep_tiles_listed(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
+#ifndef PYDEM_LISTED_WPB
+#define PYDEM_LISTED_WPB 2          // wavefronts (= tiles in flight) per workgroup of the listed passes (same-box A/B: 4: 30.36, 1: 29.83, 2: 29.68 ms of sweep)
+#endif
+constexpr int LWPB = PYDEM_LISTED_WPB;
+__global__ __launch_bounds__(64 * LWPB, (PYDEM_LISTED_OCC * 4) / LWPB) void k_sweep_tiles_listed(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
                                                             const int32_t *n_in, uint8_t *__restrict__ tile_done, int32_t *n_final,
                                                             TileNext N, int32_t *clear_count, int32_t *work3)
 {
-    __shared__ TileW L[4];
+    __shared__ TileW L[LWPB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t nt = *n_in;
 #ifdef PYDEM_LISTED_DYNAMIC
@@ -1001,7 +1005,7 @@ __global__ __launch_bounds__(256, PYDEM_LISTED_OCC) void k_sweep_tiles_listed(Sw
     if (blockIdx.x == 0 && threadIdx.x == 0) *clear_count = 0;                                     // the list of the pass after the next one
     // (the tile id is the same for the whole wavefront: as a scalar it keeps the tile's coordinates and every address
     // derived from them out of the vector registers)
-    __shared__ int32_t s_pend[4][TILE_PEND];
+    __shared__ int32_t s_pend[LWPB][TILE_PEND];
     int32_t fin = 0;               // finished cells of all tiles of this wavefront: one add at the end
     int npend = 0;                 // tiles woken by this wavefront's visits that are not on the global list yet
     auto flush = [&]() {
@@ -1017,7 +1021,7 @@ __global__ __launch_bounds__(256, PYDEM_LISTED_OCC) void k_sweep_tiles_listed(Sw
     // (taking the list entries from counters like the full passes do was measured and is slower here: 2.74 / 2.18 / 1.68 ms
     // against 2.41 / 1.79 / 1.26 ms for passes 4-6 -- -DPYDEM_LISTED_DYNAMIC keeps the variant)
     (void)work3;
-    for (int32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave); k < nt; k += gridDim.x * 4) {
+    for (int32_t k = __builtin_amdgcn_readfirstlane(blockIdx.x * LWPB + wave); k < nt; k += gridDim.x * LWPB) {
 #else
     // eight counters (one per XCD's workgroups, each over an eighth of the list): a single one would see a grab per visit
     // from every wavefront of the chip -- 100 k returning atomics on one address per pass, ~10 ns each
@@ -2949,7 +2953,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         while (ntiles > 0) {
             const int batch = ntiles < 2048 ? 16 : 8;    // passes between two looks at the list size (a look idles the GPU for ~30 us; the grid only shrinks below 8192 listed tiles)
 #ifndef PYDEM_LISTED_DYNAMIC
-            const int grid = (int)(ntiles < 8192 ? (ntiles > 64 ? ntiles : 64) : 8192);
+            const int grid = (int)(ntiles < 8192 ? (ntiles > 64 ? ntiles : 64) : 8192) * (4 / LWPB);
 #else
             const int64_t want = cdiv(ntiles, 4);            // persistent wavefronts: no more workgroups than the chip holds at once
             const int grid = (int)(want < 256 * PYDEM_LISTED_OCC ? (want > 16 ? want : 16) : 256 * PYDEM_LISTED_OCC);
@@ -2962,7 +2966,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
                                        (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
                                        &cntT[(p + 2) % 3]);
                 else
-                    hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), (size_t)lds_pad, t->stream, A, (uint32_t)p, tiles_x,
+                    hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(64 * LWPB), (size_t)lds_pad, t->stream, A, (uint32_t)p, tiles_x,
                                        (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
                                        &cntT[(p + 2) % 3], work3);
                 launches++;
