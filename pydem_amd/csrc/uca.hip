@@ -939,6 +939,9 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
 // bands of tiles: workgroup b runs on XCD b % 8 and its wavefronts take the next tile of that XCD's band from the band's
 // counter -- a visit lasts 20 .. 100 rounds, and with four fixed tiles per workgroup the LDS of a workgroup (an eighth of
 // the CU's) sat behind its slowest visit (PYDEM_SWEEP_STATIC build: the round-3 mapping, for A/B runs)
+#ifndef PYDEM_SWEEP_STEAL
+#define PYDEM_SWEEP_STEAL 1          // bands a workgroup works on: its own XCD (8 = the others afterwards: measured 31.1 vs 29.3 ms of sweep -- slower)
+#endif
 template <bool LISTED>
 __global__ __launch_bounds__(256, 8) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total,
                                                      uint8_t *__restrict__ tile_done, int32_t *n_final, TileNext N, int32_t *work8)
@@ -965,17 +968,20 @@ __global__ __launch_bounds__(256, 8) void k_sweep_tiles(SweepArgs A, uint32_t pa
             sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend);
     }
 #else
-    const int xcd = blockIdx.x & 7;
     const int per = (tiles_total + 7) >> 3;
-    for (;;) {
-        int32_t q = 0;
-        if (lane == 0) q = atomicAdd(&work8[xcd], 1);
-        q = __builtin_amdgcn_readfirstlane(__shfl(q, 0));
-        const int tid = xcd * per + q;
-        if (q >= per || tid >= tiles_total) break;
-        if (tile_done[tid]) continue;
-        sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend);
-        if (LISTED && npend > TILE_PEND - 10) flush();      // (a visit adds at most ten)
+    // own band first, then the other XCDs' bands (their tails: a band of rough terrain takes longer than its neighbours)
+    for (int st = 0; st < PYDEM_SWEEP_STEAL; st++) {
+        const int xcd = (int)((blockIdx.x + st) & 7);
+        for (;;) {
+            int32_t q = 0;
+            if (lane == 0) q = atomicAdd(&work8[xcd], 1);
+            q = __builtin_amdgcn_readfirstlane(__shfl(q, 0));
+            const int tid = xcd * per + q;
+            if (q >= per || tid >= tiles_total) break;
+            if (tile_done[tid]) continue;
+            sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend);
+            if (LISTED && npend > TILE_PEND - 10) flush();      // (a visit adds at most ten)
+        }
     }
 #endif
     if (LISTED && npend) flush();
