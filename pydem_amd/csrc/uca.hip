@@ -942,12 +942,16 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
 #ifndef PYDEM_SWEEP_STEAL
 #define PYDEM_SWEEP_STEAL 1          // bands a workgroup works on: its own XCD (8 = the others afterwards: measured 31.1 vs 29.3 ms of sweep -- slower)
 #endif
+#ifndef PYDEM_FULL_WPB
+#define PYDEM_FULL_WPB 4            // wavefronts per workgroup of the two full passes
+#endif
+constexpr int FWPB = PYDEM_FULL_WPB;
 template <bool LISTED>
-__global__ __launch_bounds__(256, 8) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total,
+__global__ __launch_bounds__(64 * FWPB, 32 / FWPB) void k_sweep_tiles(SweepArgs A, uint32_t pass, int tiles_x, int tiles_total,
                                                      uint8_t *__restrict__ tile_done, int32_t *n_final, TileNext N, int32_t *work8)
 {
-    __shared__ TileW L[4];
-    __shared__ int32_t s_pend[4][TILE_PEND];
+    __shared__ TileW L[FWPB];
+    __shared__ int32_t s_pend[FWPB][TILE_PEND];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int32_t fin = 0;
     int npend = 0;
@@ -3082,7 +3086,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
 #ifdef PYDEM_SWEEP_STATIC
     const unsigned full_grid = (unsigned)(((tiles_total + 31) / 32) * 8);
 #else
-    const unsigned full_grid = (unsigned)std::min<int64_t>(((tiles_total + 31) / 32) * 8, 256 * 8);    // persistent: eight workgroups per CU
+    const unsigned full_grid = (unsigned)std::min<int64_t>(((tiles_total + 31) / 32) * 8, 256 * (32 / FWPB));    // persistent: 32 wavefronts per CU
 #endif
 
     if (sweep_mode == 0) {
@@ -3107,10 +3111,10 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
             hipLaunchKernelGGL(k_sweep_first, dim3((unsigned)(((tiles_total + 7) / 8) * 8)), dim3(256), 0, t->stream, A, tiles_x, tiles_total, tile_done, total);
         else {
             TileNext N0; N0.flag = nullptr; N0.list = nullptr; N0.count = nullptr;
-            hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, pb + 1u, tiles_x, tiles_total, tile_done, total, N0, work16);
+            hipLaunchKernelGGL(k_sweep_tiles<false>, dim3(full_grid), dim3(64 * FWPB), (size_t)lds_pad, t->stream, A, pb + 1u, tiles_x, tiles_total, tile_done, total, N0, work16);
         }
         TileNext N; N.flag = tile_flag; N.list = tile_list[(pb + 3) % 2]; N.count = &cntT[(pb + 3) % 3];
-        hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(256), (size_t)lds_pad, t->stream, A, pb + 2u, tiles_x, tiles_total, tile_done, total, N, work16 + 8);
+        hipLaunchKernelGGL(k_sweep_tiles<true>, dim3(full_grid), dim3(64 * FWPB), (size_t)lds_pad, t->stream, A, pb + 2u, tiles_x, tiles_total, tile_done, total, N, work16 + 8);
         HIP_TRY(hipMemsetAsync(work3, 0, 24 * sizeof(int32_t), t->stream));       // (the listed passes reuse the band counters' words: 3 x 8, rotating)
         launches += 2;
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
