@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--drain-pits', type=int, default=int(os.environ.get('PYDEM_BENCH_DRAIN_PITS', '1')))
     ap.add_argument('--roof-iters', type=int, default=20)
     ap.add_argument('--cpu-sample', type=int, default=4096, help='edge of the CPU-baseline sample tile (0 = skip)')
+    ap.add_argument('--host-to-host', type=int, default=1, help='1: also time the drop-in call from a host array to the TWI on the host (N = 1; reported beside `value`)')
     ap.add_argument('--config', type=int, default=3, choices=[2, 3, 5],
                     help='BASELINE.json config: 3 = the headline line (default); 2 = 4096^2 stencil kernel only; 5 = 8192^2 int16 with the '
                          'reference defaults (conditioning on the device).  2 and 5 are single-GPU side lines, stored under profiles/')
@@ -179,6 +180,38 @@ def run_config5(args):
                      "avg_kernel_ms": st_ms, "algorithmic_bytes_per_cell": STENCIL_BYTES_PER_CELL},
         "stages_ms": dict({k: tm[k] for k in ('stencil_kernel_ms', 'flats_ms', 'graph_ms', 'pits_ms', 'sweep_ms', 'twi_ms')}, **stages),
         "not_in_value": {"h2d_ms": stages['h2d_ms'], "what": "upload of the raw int16 tile (pageable host memory) at the start of the step"}}))
+
+
+def host_to_host(dp_resident, drain_pits):
+    """The drop-in call as a user makes it -- DEMProcessor(elev=<host array>).calc_twi() -> TWI on the host -- timed once on
+    the bench tile (outside the timed region; PCIe-inclusive, reported beside `value`, never as it): upload of the
+    elevations, the device stages, download of the TWI through pageable host memory."""
+    import gc
+    import numpy as np
+    from pydem_amd import DEMProcessor
+    z = np.array(dp_resident.elev)                       # the tile as a host array (the bench generated it on the device)
+    best = None
+    for rep in range(3):                                 # (the first call of a process pays one-off allocations)
+        t0 = time.perf_counter()
+        dp = DEMProcessor(elev=z, dX=30.0, dY=30.0, fill_flats=False, drain_pits_path=False, drain_pits=drain_pits)
+        dp._ensure_tile(); dp._push('elev'); dp._tile.synchronize()
+        t1 = time.perf_counter()
+        dp.run_twi(); dp._tile.synchronize()
+        t2 = time.perf_counter()
+        twi = dp.calc_twi()                              # (the stages are done: this is the download)
+        t3 = time.perf_counter()
+        tm = dp.timings
+        dev = sum(tm[k] for k in ('slopes_directions_ms', 'flats_ms', 'graph_ms', 'pits_ms', 'sweep_ms', 'twi_ms'))
+        rec = {"ms": (t3 - t0) * 1e3, "upload_ms": (t1 - t0) * 1e3, "stages_wall_ms": (t2 - t1) * 1e3, "device_stages_ms": dev,
+               "twi_download_ms": (t3 - t2) * 1e3, "Mcells_per_s": z.size / (t3 - t0) / 1e6,
+               "what": "DEMProcessor(elev=host float64 array).calc_twi() -> host array, pageable memory; best of 3 calls"}
+        if os.environ.get('PYDEM_BENCH_DEBUG'):
+            print('host_to_host rep %d: %r' % (rep, rec), file=sys.stderr, flush=True)
+        if best is None or rec["ms"] < best["ms"]:
+            best = rec
+        del dp, twi
+        gc.collect()                                     # (the tile of this call is released here, not inside the next call)
+    return best
 
 
 def csrc_hashes():
@@ -397,6 +430,8 @@ def main():
         }
         if args.cpu_sample:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1, args.drain_pits)
+        if world == 1 and args.host_to_host:
+            out["host_to_host"] = host_to_host(pm.tiles[mine[0]], bool(args.drain_pits))
         print(json.dumps(out))
     if world > 1:
         pm.transport.barrier()

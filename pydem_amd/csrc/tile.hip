@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[1024] = "";
 
@@ -178,6 +179,126 @@ int tile_pinned(pydem_tile *t, size_t bytes, void **out)
     return 0;
 }
 
+// ---- whole-plane transfers between pageable host arrays and the device ------------------------------------------------
+// A plain hipMemcpy of a pageable array pins the caller's pages on the fly: measured here at ~3 GB/s for a fresh 2 GiB array
+// (0.7 s for the 16384^2 elevations).  Planes of XFER_MIN bytes or more go through per-device pinned chunks instead: XFER_T
+// host threads each copy their chunks between the caller's array and their two pinned buffers while their own stream moves
+// the previous chunk over PCIe (the threads also take the first-touch page faults of a fresh destination array in
+// parallel).  PYDEM_XFER_THREADS=0 restores the plain copy.
+#include <thread>
+#include <sys/mman.h>
+namespace {
+constexpr size_t XFER_CHUNK = (size_t)8 << 20;
+constexpr size_t XFER_MIN = (size_t)32 << 20;
+constexpr int XFER_TMAX = 16;
+struct XferLane { void *pin[2] = {nullptr, nullptr}; hipStream_t stream = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
+struct XferPool { std::mutex busy; XferLane lane[XFER_TMAX]; int ready = 0; };
+std::mutex g_xfer_table;
+std::map<int, XferPool *> g_xfer;
+
+int xfer_threads()
+{
+    static const int n = [] {
+        const char *e = getenv("PYDEM_XFER_THREADS");
+        int v = e ? atoi(e) : 8;
+        return v < 0 ? 0 : (v > XFER_TMAX ? XFER_TMAX : v);
+    }();
+    return n;
+}
+
+int xfer_pool(int device, int T, XferPool **out)
+{
+    XferPool *P;
+    {
+        std::lock_guard<std::mutex> g(g_xfer_table);
+        XferPool *&p = g_xfer[device];
+        if (!p) p = new XferPool();
+        P = p;
+    }
+    *out = P;
+    return 0;
+}
+
+int xfer_prepare(XferPool *P, int T)      // under P->busy
+{
+    for (int k = P->ready; k < T; ++k) {
+        XferLane &L = P->lane[k];
+        for (int b = 0; b < 2; ++b) {
+            if (!L.pin[b]) HIP_TRY(hipHostMalloc(&L.pin[b], XFER_CHUNK, hipHostMallocDefault));
+            if (!L.ev[b]) HIP_TRY(hipEventCreateWithFlags(&L.ev[b], hipEventDisableTiming));
+        }
+        if (!L.stream) HIP_TRY(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        P->ready = k + 1;
+    }
+    return 0;
+}
+
+// one lane's share of the plane: chunks k, k + T, ...
+hipError_t xfer_lane_run(int device, XferLane &L, char *dev, char *host, size_t bytes, int k, int T, bool to_host)
+{
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return e;
+    const size_t nchunk = (bytes + XFER_CHUNK - 1) / XFER_CHUNK;
+    size_t prev_off = 0, prev_len = 0; int prev_b = -1;
+    int it = 0;
+    for (size_t c = (size_t)k; c < nchunk; c += (size_t)T, ++it) {
+        const int b = it & 1;
+        const size_t off = c * XFER_CHUNK, len = (bytes - off < XFER_CHUNK) ? bytes - off : XFER_CHUNK;
+        if (!to_host) {
+            if (it >= 2 && (e = hipEventSynchronize(L.ev[b])) != hipSuccess) return e;     // the buffer's previous chunk has left
+            memcpy(L.pin[b], host + off, len);
+            if ((e = hipMemcpyAsync(dev + off, L.pin[b], len, hipMemcpyHostToDevice, L.stream)) != hipSuccess) return e;
+            if ((e = hipEventRecord(L.ev[b], L.stream)) != hipSuccess) return e;
+        } else {
+            if ((e = hipMemcpyAsync(L.pin[b], dev + off, len, hipMemcpyDeviceToHost, L.stream)) != hipSuccess) return e;
+            if ((e = hipEventRecord(L.ev[b], L.stream)) != hipSuccess) return e;
+            if (prev_b >= 0) {
+                if ((e = hipEventSynchronize(L.ev[prev_b])) != hipSuccess) return e;
+                memcpy(host + prev_off, L.pin[prev_b], prev_len);
+            }
+            prev_b = b; prev_off = off; prev_len = len;
+        }
+    }
+    if (to_host && prev_b >= 0) {
+        if ((e = hipEventSynchronize(L.ev[prev_b])) != hipSuccess) return e;
+        memcpy(host + prev_off, L.pin[prev_b], prev_len);
+    }
+    return hipStreamSynchronize(L.stream);
+}
+}  // namespace
+
+// copy `bytes` between a device plane and a (pageable) host array; the tile's stream is drained first and the call returns
+// with the transfer complete
+int tile_plane_copy(pydem_tile *t, void *dev, void *host, size_t bytes, bool to_host)
+{
+    const int T = xfer_threads();
+    if (T == 0 || bytes < XFER_MIN) {
+        if (to_host) HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, t->stream));
+        else HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        return 0;
+    }
+    HIP_TRY(hipStreamSynchronize(t->stream));          // what the plane holds (or what still reads it) is settled
+    if (to_host) {
+        // a fresh destination array is faulted in by the copy threads: ask for huge pages where the kernel gives them on request
+        const uintptr_t a = ((uintptr_t)host + 4095) & ~(uintptr_t)4095, b = ((uintptr_t)host + bytes) & ~(uintptr_t)4095;
+        if (b > a) (void)madvise((void *)a, b - a, MADV_HUGEPAGE);
+    }
+    XferPool *P;
+    PYDEM_TRY(xfer_pool(t->device, T, &P));
+    std::lock_guard<std::mutex> g(P->busy);
+    PYDEM_TRY(xfer_prepare(P, T));
+    hipError_t err[XFER_TMAX];
+    std::thread th[XFER_TMAX];
+    for (int k = 1; k < T; ++k)
+        th[k] = std::thread([&, k] { err[k] = xfer_lane_run(t->device, P->lane[k], (char *)dev, (char *)host, bytes, k, T, to_host); });
+    err[0] = xfer_lane_run(t->device, P->lane[0], (char *)dev, (char *)host, bytes, 0, T, to_host);
+    for (int k = 1; k < T; ++k) th[k].join();
+    for (int k = 0; k < T; ++k)
+        if (err[k] != hipSuccess) { pydem_set_error("plane transfer: %s", hipGetErrorString(err[k])); return -1; }
+    return 0;
+}
+
 int ensure_fields(pydem_tile *t, std::initializer_list<int> fields)
 {
     for (int f : fields) PYDEM_TRY(ensure_field(t, f));
@@ -345,8 +466,7 @@ int pydem_tile_upload(pydem_tile *t, int field, const void *src, int dtype)
     const size_t ds = dtype_size(dtype);
     if (!ds) { pydem_set_error("unknown dtype %d", dtype); return -2; }
     if (ds == elem && (elem == 1 || dtype == PYDEM_F64)) {
-        HIP_TRY(hipMemcpyAsync(*pp, src, (size_t)t->NN * elem, hipMemcpyHostToDevice, t->stream));
-        HIP_TRY(hipStreamSynchronize(t->stream));
+        PYDEM_TRY(tile_plane_copy(t, *pp, const_cast<void *>(src), (size_t)t->NN * elem, false));
     } else {
         if (elem != 8) { pydem_set_error("dtype conversion is only supported for float64 fields"); return -2; }
         const size_t bytes = (size_t)t->NN * ds;
@@ -355,7 +475,7 @@ int pydem_tile_upload(pydem_tile *t, int field, const void *src, int dtype)
             HIP_TRY(hipMalloc(&t->scratch, bytes));
             t->scratch_bytes = bytes; t->device_bytes += (int64_t)bytes;
         }
-        HIP_TRY(hipMemcpyAsync(t->scratch, src, bytes, hipMemcpyHostToDevice, t->stream));
+        PYDEM_TRY(tile_plane_copy(t, t->scratch, const_cast<void *>(src), bytes, false));
         const int grid = (int)(cdiv(t->NN, 256) < 8192 ? cdiv(t->NN, 256) : 8192);
         double *dst = (double *)*pp;
         switch (dtype) {
@@ -383,8 +503,7 @@ int pydem_tile_download(pydem_tile *t, int field, void *dst)
     if (!*pp || !t->have[field]) { pydem_set_error("field %d has not been computed or uploaded", field); return -3; }
     if (field == PYDEM_UCA) PYDEM_TRY(stage_edge_flush(t));     // incremental edge rounds: settle what is still waiting upstream
     if (field == PYDEM_EDGE_DONE || field == PYDEM_EDGE_TODO) PYDEM_TRY(stage_edge_catchup(t));   // condensed rounds: the interior masks catch up
-    HIP_TRY(hipMemcpyAsync(dst, *pp, (size_t)t->NN * elem, hipMemcpyDeviceToHost, t->stream));
-    HIP_TRY(hipStreamSynchronize(t->stream));
+    PYDEM_TRY(tile_plane_copy(t, *pp, dst, (size_t)t->NN * elem, true));
     return 0;
 }
 
