@@ -859,6 +859,248 @@ __global__ __launch_bounds__(256) void k_flat_active(CondArgs A, Regions R, cons
     }
 }
 
+// ---- several sweeps per pass: blocks with a halo ----------------------------------------------------------------
+// The tail of the sweeps is a front crossing the big plateaus: a few thousand listed cells per sweep, more than a thousand
+// sweeps, each of them a chain of dependent round trips to L2 plus a launch or a device-wide barrier (13-36 us per sweep).
+// A Jacobi sweep reads a 3x3 window, so a 32 x 32 block loaded with a halo of FT cells can run FT sweeps from LDS before it
+// needs anybody else's results: the values it writes for its interior are the ones FT single sweeps would have left there
+// (same operands, same operations, in the same order).  The blocks of a pass = those with a listed cell nearby; a block
+// whose interior changed lists itself and its eight neighbours for the next pass (and is thereby rewritten once more, so that
+// both buffers of the ping-pong pair agree on it when it leaves the list).
+// What a block cannot know is the sweep at which a region STOPS -- its last cell may get its first value anywhere.  A pass
+// runs as if no region stopped before its last sweep and counts the first arrivals per (region, sweep of the pass);
+// k_flat_accept then books them, and when a region turns out to have stopped in mid-pass the same pass runs once more over
+// the same input -- now with the stopping sweeps known -- for the blocks that hold cells of such a region.
+constexpr int FB = 32, FT = 8, FW = FB + 2 * FT;       // block edge, sweeps per pass = halo, edge of the loaded window
+constexpr int FB_THREADS = 512;
+constexpr uint32_t FI_MASK = 1u, FI_CARD_H = 2u, FI_ALL_H = 4u, FI_CARD_L = 8u, FI_ALL_L = 16u, FI_GEN = 32u;
+struct FlatBatch {
+    const double *dh_in, *dl_in;
+    double *dh_out, *dl_out;
+    const int32_t *blocks; int32_t nblk;
+    int nbi, nbj;                // blocks per column / row of the tile
+    int s0, T;                   // first sweep of the pass, sweeps in it (<= FT)
+    int first;                   // 1: the run that counts arrivals and lists the next blocks; 0: the repeat after k_flat_accept
+    const int32_t *slot_of;      // per region: row of the arrival table (-1: none)
+    int32_t *arr;                // [slot][2][FT] first arrivals of the pass
+    int32_t *bstamp, *next_list, *next_count; int32_t pass_id;
+    double source_tol;
+    int32_t *err;
+};
+
+__global__ __launch_bounds__(FB_THREADS) void k_flat_batch(CondArgs A, Regions R, FlatBatch P)
+{
+    __shared__ double s_dh[2][FW * FW], s_dl[2][FW * FW];
+    __shared__ uint32_t s_info[FW * FW];      // FI_* bits, bits 8-11 / 12-15: sweeps of this pass the cell's region takes part in (hi / lo), bits 16-31 table row
+    __shared__ int s_flag;
+    double *s_z = s_dh[1];                    // elevations of the window while the seeds are worked out
+    const int n = A.n, m = A.m, tid = (int)threadIdx.x, T = P.T;
+    for (int bq = blockIdx.x; bq < P.nblk; bq += gridDim.x) {
+        const int b = P.blocks[bq];
+        const int bi = b / P.nbj, bj = b - bi * P.nbj;
+        const int i0 = bi * FB - FT, j0 = bj * FB - FT;
+        if (tid == 0) s_flag = 0;
+        for (int idx = tid; idx < FW * FW; idx += FB_THREADS) {
+            const int li = idx / FW, lj = idx - li * FW;
+            const int gi = i0 + li, gj = j0 + lj;
+            const bool ing = gi >= 0 && gi < n && gj >= 0 && gj < m;
+            const int32_t c = ing ? gi * m + gj : 0;
+            s_z[idx] = ing ? A.elev[c] : NAN;                     // (NaN: never a seed, like a neighbour that does not exist)
+            s_info[idx] = (ing && A.mask[c]) ? FI_MASK : 0u;
+        }
+        __syncthreads();
+        bool needfix = false;
+        for (int idx = tid; idx < FW * FW; idx += FB_THREADS) {
+            if (!(s_info[idx] & FI_MASK)) continue;
+            const int li = idx / FW, lj = idx - li * FW;
+            const int32_t c = (i0 + li) * m + j0 + lj;
+            const int32_t r = A.creg[c];
+            const int32_t fl = R.flags[r];
+            uint32_t info = FI_MASK, jlh = 0, jll = 0, slot = 0xFFFFu;
+            if (fl & RF_GENERAL) {
+                info |= FI_GEN;
+                const int32_t dH = R.done_hi[r], dL = R.done_lo[r];
+                jlh = dH >= P.s0 + T - 1 ? (uint32_t)T : (dH < P.s0 ? 0u : (uint32_t)(dH - P.s0 + 1));
+                jll = dL >= P.s0 + T - 1 ? (uint32_t)T : (dL < P.s0 ? 0u : (uint32_t)(dL - P.s0 + 1));
+                if (jlh | jll) {
+                    const int32_t sl = P.slot_of[r];
+                    slot = sl >= 0 ? (uint32_t)sl : 0xFFFFu;
+                    const double level = region_level(A, c);
+                    const double src_max = (fl & RF_SOURCE) ? dunkey(R.lowest_bits[r]) + P.source_tol : 0.0;
+#pragma unroll
+                    for (int d = 0; d < 9; d++) {
+                        if (d == 4) continue;
+                        const int ni = li + d / 3 - 1, nj = lj + d % 3 - 1;
+                        if (ni < 0 || ni >= FW || nj < 0 || nj >= FW) continue;
+                        const int nidx = ni * FW + nj;
+                        if (s_info[nidx] & FI_MASK) continue;
+                        const double z = s_z[nidx];
+                        const bool sh = (fl & RF_SOURCE) && z > level && z <= src_max, sl2 = (fl & RF_DRAIN) && z == level;
+                        const bool cardinal = (d == 1 || d == 3 || d == 5 || d == 7);
+                        if (sh) info |= FI_ALL_H | (cardinal ? FI_CARD_H : 0u);
+                        if (sl2) info |= FI_ALL_L | (cardinal ? FI_CARD_L : 0u);
+                    }
+                    const bool interior = li >= FT && li < FT + FB && lj >= FT && lj < FT + FB;
+                    if (interior && ((jlh > 0 && (int)jlh < T) || (jll > 0 && (int)jll < T))) needfix = true;
+                }
+                s_dh[0][idx] = P.dh_in[c]; s_dl[0][idx] = P.dl_in[c];
+            }
+            // (the FI_MASK bit the neighbours look at does not change; the word is complete before the barrier)
+            atomicExch(&s_info[idx], info | (jlh << 8) | (jll << 12) | (slot << 16));
+        }
+        if (!P.first && needfix) s_flag = 1;
+        __syncthreads();
+        if (!P.first && !s_flag) { __syncthreads(); continue; }          // the repeat: nothing of a region that stopped in mid-pass in here
+        bool changed = false;
+        for (int j = 0; j < T; j++) {
+            const int p = j & 1, lo = j + 1, hi = FW - 2 - j;
+            for (int base = 0; base < FW * FW; base += FB_THREADS) {      // (the trip count is the same for all lanes of a wavefront: ballots below)
+                const int idx = base + tid;
+                bool arr_h = false, arr_l = false;
+                uint32_t slot = 0xFFFFu;
+                if (idx < FW * FW) {
+                    const int li = idx / FW, lj = idx - li * FW;
+                    const uint32_t info = s_info[idx];
+                    if (li >= lo && li <= hi && lj >= lo && lj <= hi && (info & FI_GEN)) {
+                        const bool act_h = j < (int)((info >> 8) & 15u), act_l = j < (int)((info >> 12) & 15u);
+                        const double oh = s_dh[p][idx], ol = s_dl[p][idx];
+                        double nh = oh, nl = ol;
+                        if (act_h || act_l) {
+                            double card_h = oh, all_h = oh, card_l = ol, all_l = ol;
+#pragma unroll
+                            for (int d = 0; d < 9; d++) {
+                                if (d == 4) continue;
+                                const int nidx = idx + (d / 3 - 1) * FW + (d % 3 - 1);        // (li, lj in 1 .. FW - 2: inside the window)
+                                if (!(s_info[nidx] & FI_MASK)) continue;
+                                const double vh = s_dh[p][nidx], vl = s_dl[p][nidx];
+                                const bool cardinal = (d == 1 || d == 3 || d == 5 || d == 7);
+                                if (cardinal) { card_h = vh < card_h ? vh : card_h; card_l = vl < card_l ? vl : card_l; }
+                                all_h = vh < all_h ? vh : all_h; all_l = vl < all_l ? vl : all_l;
+                            }
+                            if (info & FI_CARD_H) card_h = 0.0 < card_h ? 0.0 : card_h;
+                            if (info & FI_ALL_H) all_h = 0.0 < all_h ? 0.0 : all_h;
+                            if (info & FI_CARD_L) card_l = 0.0 < card_l ? 0.0 : card_l;
+                            if (info & FI_ALL_L) all_l = 0.0 < all_l ? 0.0 : all_l;
+                            if (act_h) {
+                                const double sv = card_h + 1, g = all_h + SQRT2;
+                                const double best = sv < g ? sv : g;
+                                nh = best < oh ? best : oh;
+                            }
+                            if (act_l) {
+                                const double sv = card_l + 1, g = all_l + SQRT2;
+                                const double best = sv < g ? sv : g;
+                                nl = best < ol ? best : ol;
+                            }
+                            if (li >= FT && li < FT + FB && lj >= FT && lj < FT + FB) {
+                                changed = changed || nh != oh || nl != ol;
+                                arr_h = act_h && isinf(oh) && !isinf(nh);
+                                arr_l = act_l && isinf(ol) && !isinf(nl);
+                                slot = info >> 16;
+                            }
+                        }
+                        s_dh[p ^ 1][idx] = nh; s_dl[p ^ 1][idx] = nl;
+                    }
+                }
+                if (P.first) {
+                    // first arrivals per (region, sweep of the pass): the lanes that report for the same region add once
+                    for (int f = 0; f < 2; f++) {
+                        const bool arrived = f ? arr_l : arr_h;
+                        unsigned long long pend = __ballot(arrived);
+                        while (pend) {
+                            const int leader = __ffsll((long long)pend) - 1;
+                            const uint32_t ls = (uint32_t)__shfl((int)slot, leader);
+                            const unsigned long long same = __ballot(arrived && slot == ls);
+                            if ((int)__lane_id() == leader) {
+                                if (ls == 0xFFFFu) *P.err = 1;                        // a region without a table row moved: the caller gives up
+                                else atomicAdd(&P.arr[((int64_t)ls * 2 + f) * FT + j], (int32_t)__popcll(same));
+                            }
+                            pend &= ~same;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const int pf = T & 1;
+        for (int q = tid; q < FB * FB; q += FB_THREADS) {
+            const int li = FT + q / FB, lj = FT + q % FB, idx = li * FW + lj;
+            if (s_info[idx] & FI_GEN) {
+                const int32_t c = (i0 + li) * m + j0 + lj;
+                P.dh_out[c] = s_dh[pf][idx]; P.dl_out[c] = s_dl[pf][idx];
+            }
+        }
+        const int any = __syncthreads_or(changed ? 1 : 0);
+        if (P.first && any && tid < 9) {
+            const int ni = bi + tid / 3 - 1, nj = bj + tid % 3 - 1;
+            if (ni >= 0 && ni < P.nbi && nj >= 0 && nj < P.nbj) {
+                const int nb = ni * P.nbj + nj;
+                if (atomicExch(&P.bstamp[nb], P.pass_id + 1) != P.pass_id + 1) P.next_list[atomicAdd(P.next_count, 1)] = nb;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// the regions that are still sweeping get a row of the arrival table (from the cells of the current work list: a region that
+// still moves has cells on it)
+__global__ __launch_bounds__(256) void k_flat_table(CondArgs A, Regions R, const int32_t *__restrict__ wl, int32_t na, int sweep, int32_t *slot_of,
+                                                    int32_t *ar_id, int32_t *count, int32_t cap)
+{
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < na; q += gridDim.x * blockDim.x) {
+        const int32_t r = A.creg[wl[q]];
+        if (!(R.flags[r] & RF_GENERAL) || (R.done_hi[r] < sweep && R.done_lo[r] < sweep)) continue;
+        if (atomicCAS(&slot_of[r], -1, -2) == -1) {
+            const int32_t k = atomicAdd(count, 1);
+            if (k < cap) { ar_id[k] = r; slot_of[r] = k; }
+        }
+    }
+}
+
+// blocks of the first pass: every block with a listed cell within FT cells of its interior
+__global__ __launch_bounds__(256) void k_flat_blocks(const int32_t *__restrict__ wl, int32_t na, int n, int m, int nbj, int32_t *bstamp, int32_t pass_id,
+                                                     int32_t *list, int32_t *count)
+{
+    for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < na; q += gridDim.x * blockDim.x) {
+        const int32_t c = wl[q];
+        const int i = c / m, j = c - i * m;
+        int seen[4]; int ns = 0;
+        for (int k = 0; k < 4; k++) {
+            int ii = i + ((k & 1) ? FT : -FT), jj = j + ((k & 2) ? FT : -FT);
+            ii = ii < 0 ? 0 : (ii >= n ? n - 1 : ii); jj = jj < 0 ? 0 : (jj >= m ? m - 1 : jj);
+            const int b = (ii / FB) * nbj + jj / FB;
+            bool dup = false;
+            for (int u = 0; u < ns; u++) dup = dup || seen[u] == b;
+            if (dup) continue;
+            seen[ns++] = b;
+            if (atomicExch(&bstamp[b], pass_id) != pass_id) list[atomicAdd(count, 1)] = b;
+        }
+    }
+}
+
+// books the first arrivals of a pass: a region whose last cell arrived in sweep s0 + j stops there (done = that sweep, like
+// region_arrivals); out[0] = 1 when that happened before the last sweep of the pass (the pass is repeated for its blocks)
+__global__ __launch_bounds__(256) void k_flat_accept(Regions R, const int32_t *__restrict__ ar_id, const int32_t *__restrict__ count, int32_t cap,
+                                                     int32_t *arr, int s0, int T, int32_t *out)
+{
+    const int32_t nt = *count < cap ? *count : cap;
+    for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nt; k += gridDim.x * blockDim.x) {
+        const int32_t r = ar_id[k];
+        for (int f = 0; f < 2; f++) {
+            int32_t *rem = f ? R.rem_lo : R.rem_hi, *done = f ? R.done_lo : R.done_hi;
+            int32_t *a = arr + ((int64_t)k * 2 + f) * FT;
+            int32_t left = rem[r];
+            for (int j = 0; j < T; j++) {
+                const int32_t got = a[j];
+                a[j] = 0;
+                if (!got) continue;
+                left -= got;
+                if (left == 0 && done[r] >= s0) { done[r] = s0 + j; if (j < T - 1) out[0] = 1; }
+            }
+            rem[r] = left;
+        }
+    }
+}
+
 // the new surface between the uphill rim and the outlet (:376-380)
 __global__ void k_flat_interp(CondArgs A, Regions R, const double *__restrict__ dh, const double *__restrict__ dl)
 {
@@ -1050,8 +1292,75 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
         }
         static int cond_debug = -1;
         if (cond_debug < 0) { const char *e = getenv("PYDEM_COND_DEBUG"); cond_debug = e ? atoi(e) : 0; }
+        // several sweeps per pass from LDS (k_flat_batch) once the list is short enough that its blocks fit the device a few times over
+        static int batch_cells = -1, batch_regions = 4096, batch_T = FT;
+        if (batch_cells < 0) {
+            const char *e = getenv("PYDEM_FLAT_BATCH"); batch_cells = e ? atoi(e) : 16384;
+            if ((e = getenv("PYDEM_FLAT_BATCH_T"))) { batch_T = atoi(e); if (batch_T < 1 || batch_T > FT) batch_T = FT; }
+        }
+        const int nbi = (n + FB - 1) / FB, nbj = (m + FB - 1) / FB;
+        int32_t *b_slot = nullptr, *b_arid = nullptr, *b_arr = nullptr, *b_stamp = nullptr, *b_list[2] = {nullptr, nullptr};
+        int batch_limit = batch_cells;
+        int64_t batch_passes = 0, batch_repeats = 0, batch_blocks = 0;
         while (na > 0) {
             bool small_run = false;
+            if (batch_limit > 0 && sweep >= 2 && na <= batch_limit) {
+                if (!b_slot) {
+                    const size_t nblocks = (size_t)nbi * nbj;
+                    char *q = (char *)arena_take(&S.lease, (size_t)nreg * 4 + (size_t)batch_regions * 4 + (size_t)batch_regions * 2 * FT * 4 + 3 * nblocks * 4 + 1024);
+                    if (!q) return -1;
+                    b_slot = (int32_t *)q; q += (size_t)nreg * 4;
+                    b_arid = (int32_t *)q; q += (size_t)batch_regions * 4;
+                    b_arr = (int32_t *)q; q += (size_t)batch_regions * 2 * FT * 4;
+                    b_stamp = (int32_t *)q; q += nblocks * 4;
+                    b_list[0] = (int32_t *)q; q += nblocks * 4;
+                    b_list[1] = (int32_t *)q;
+                }
+                // cnt[16]: table rows, cnt[17]: repeat flag, cnt[18]: a region without a row moved, cnt[20 + k]: blocks of pass k % 2
+                const int q0 = (sweep - 1) & 1;                            // sweep `sweep` reads dh[q0] (the list al[q0])
+                HIP_TRY(hipMemsetAsync(b_slot, 0xFF, (size_t)nreg * 4, t->stream));
+                HIP_TRY(hipMemsetAsync(b_arr, 0, (size_t)batch_regions * 2 * FT * 4, t->stream));
+                HIP_TRY(hipMemsetAsync(b_stamp, 0, (size_t)nbi * nbj * 4, t->stream));
+                HIP_TRY(hipMemsetAsync(cnt + 16, 0, 8 * sizeof(int32_t), t->stream));
+                hipLaunchKernelGGL(k_flat_table, dim3(grid_of(na, 1024)), dim3(256), 0, t->stream, A, R, al[q0], na, sweep, b_slot, b_arid, cnt + 16, batch_regions);
+                hipLaunchKernelGGL(k_flat_blocks, dim3(grid_of(na, 1024)), dim3(256), 0, t->stream, al[q0], na, n, m, nbj, b_stamp, 1, b_list[0], cnt + 20);
+                HIP_TRY(hipMemcpyAsync(t->h_counters + 16, cnt + 16, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipStreamSynchronize(t->stream));
+                if (t->h_counters[16] > batch_regions) batch_limit = na / 2;      // too many regions still sweeping: more single sweeps first
+                else {
+                    int32_t nblk = t->h_counters[20];
+                    int bin = q0, lcur = 0, pass_id = 1;
+                    FlatBatch P;
+                    P.nbi = nbi; P.nbj = nbj; P.T = batch_T; P.slot_of = b_slot; P.arr = b_arr; P.bstamp = b_stamp; P.source_tol = source_tol; P.err = cnt + 18;
+                    while (nblk > 0) {
+                        P.dh_in = dh[bin]; P.dl_in = dl[bin]; P.dh_out = dh[bin ^ 1]; P.dl_out = dl[bin ^ 1];
+                        P.blocks = b_list[lcur]; P.nblk = nblk; P.s0 = sweep; P.first = 1;
+                        P.next_list = b_list[lcur ^ 1]; P.next_count = cnt + 20 + (lcur ^ 1); P.pass_id = pass_id;
+                        HIP_TRY(hipMemsetAsync(cnt + 20 + (lcur ^ 1), 0, sizeof(int32_t), t->stream));
+                        const int gb = nblk < 2048 ? nblk : 2048;
+                        hipLaunchKernelGGL(k_flat_batch, dim3(gb), dim3(FB_THREADS), 0, t->stream, A, R, P);
+                        hipLaunchKernelGGL(k_flat_accept, dim3(grid_of(t->h_counters[16], 64)), dim3(256), 0, t->stream, R, b_arid, cnt + 16, batch_regions, b_arr, sweep,
+                                           batch_T, cnt + 17);
+                        HIP_TRY(hipMemcpyAsync(t->h_counters + 16, cnt + 16, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+                        HIP_TRY(hipStreamSynchronize(t->stream));
+                        if (t->h_counters[18]) { pydem_set_error("fill_flats: a region outside the arrival table moved"); return -5; }
+                        if (t->h_counters[17]) {
+                            P.first = 0;
+                            hipLaunchKernelGGL(k_flat_batch, dim3(gb), dim3(FB_THREADS), 0, t->stream, A, R, P);
+                            HIP_TRY(hipMemsetAsync(cnt + 17, 0, sizeof(int32_t), t->stream));
+                            batch_repeats++;
+                        }
+                        batch_passes++; batch_blocks += nblk;
+                        sweep += batch_T; bin ^= 1; lcur ^= 1; pass_id++;
+                        nblk = t->h_counters[20 + lcur];
+                        if (sweep > sweep_cap + 256) { pydem_set_error("fill_flats: distance sweeps did not terminate"); return -5; }
+                    }
+                    pp = bin; na = 0;
+                    if (cond_debug) fprintf(stderr, "fill_flats: %lld passes of %d sweeps (%lld repeated), %lld block visits\n", (long long)batch_passes, batch_T,
+                                            (long long)batch_repeats, (long long)batch_blocks);
+                    break;
+                }
+            }
             if (na <= coop_cap && na > coop_min) {
                 HIP_TRY(hipMemsetAsync(cnt + 48, 0, sizeof(int32_t), t->stream));      // the barrier's arrival counter: a cache line of its own
                 hipLaunchKernelGGL(k_flat_sweep_coop, dim3((unsigned)(coop_xcd ? coop_wg * 8 : coop_wg)), dim3(256), 0, t->stream, A, R, al[0], al[1], cnt + 4, stamp,

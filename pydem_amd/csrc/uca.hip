@@ -635,9 +635,53 @@ __device__ __forceinline__ const double *in_edge_ptr(const SweepArgs &A, int32_t
 }
 __device__ __forceinline__ double in_edge(const SweepArgs &A, int32_t c, int m, int d) { return *in_edge_ptr(A, c, m, d); }
 
+// Addresses of a tile visit.  The visits issue half of their cycles (profiles/r04_pmc_sq_hot.csv), and a third of a round's
+// vector instructions were 64-bit address arithmetic: cell id (a quarter-rate 32-bit multiply) -> sign extension -> shift ->
+// 64-bit add, per access.  The tile is wavefront-uniform, so the five planes get one SCALAR base each -- the address of the
+// halo's first cell (i0 - 1, j0 - 1), which for a tile on the grid's edge lies in front of the plane and is only ever
+// used with offsets of cells that exist -- and a lane addresses a cell by `h` = halo row * m + halo column (24-bit
+// multiply: full rate; stage_sweep refuses tiles wider than 2^24 columns), scaled to a 32-bit unsigned byte offset: the
+// loads and stores take the SGPR base + VGPR offset form.
+struct TileBase {
+    const char *cinfo, *area, *contrib, *prop, *todo;
+    int32_t org;             // cell id of the halo's first cell (negative on the first row / column of the grid)
+};
+__device__ __forceinline__ TileBase tile_base(const SweepArgs &A, int i0, int j0)
+{
+    TileBase B;
+    const int64_t org = (int64_t)(i0 - 1) * A.m + (j0 - 1);
+    B.org = (int32_t)org;
+    B.cinfo = reinterpret_cast<const char *>(A.cinfo) + org * 4;
+    B.area = reinterpret_cast<const char *>(A.area) + org * 8;
+    B.contrib = reinterpret_cast<const char *>(A.contrib) + org * 16;
+    B.prop = reinterpret_cast<const char *>(A.prop) + org * 8;
+    B.todo = reinterpret_cast<const char *>(A.todo_work) + org;
+    return B;
+}
+template <typename T>
+__device__ __forceinline__ T ld_off(const char *base, uint32_t off) { return *reinterpret_cast<const T *>(base + (size_t)off); }
+template <typename T>
+__device__ __forceinline__ void st_off(const char *base, uint32_t off, T v) { *reinterpret_cast<T *>(const_cast<char *>(base) + (size_t)off) = v; }
+__device__ __forceinline__ uint32_t halo_cell(int li, int lj, int m) { return __umul24((uint32_t)li, (uint32_t)m) + (uint32_t)lj; }
+
+// byte offsets of the eight in-edges relative to a cell's entry of the contribution plane (one LDS table per workgroup,
+// filled at kernel start): neighbour d (0..7 = NW N NE W E SW S SE), the cardinal ones hand over their first share, the
+// diagonal ones their second
+__device__ __forceinline__ void fill_nbr16(int32_t *nbr16, int m)
+{
+    if (threadIdx.x < 8) {
+        const int d = threadIdx.x, q = d + (d >> 2), di = q / 3, dj = q - 3 * di;
+        nbr16[d] = ((di - 1) * m + (dj - 1)) * 16 + (((0x5A >> d) & 1) ? 0 : 8);
+    }
+}
+__device__ __forceinline__ double in_edge_h(const TileBase &B, const int32_t *nbr16, uint32_t h, int d)
+{
+    return ld_off<double>(B.contrib, h * 16u + (uint32_t)nbr16[d]);        // (the neighbour lies in the halo: the sum is >= 0)
+}
+
 // staging of a tile visit: the graph words of the tile (high half of L.cs, state bit "final before this pass" in the low
 // half) and the final bitmap of tile + halo
-__device__ __forceinline__ void tile_stage(const SweepArgs &A, TileW &L, uint32_t pass, int i0, int j0, int lane)
+__device__ __forceinline__ void tile_stage(const SweepArgs &A, const TileBase &B, TileW &L, uint32_t pass, int i0, int j0, int lane)
 {
     const int n = A.n, m = A.m;
     const int half = lane >> 5, l32 = lane & 31;
@@ -646,7 +690,7 @@ __device__ __forceinline__ void tile_stage(const SweepArgs &A, TileW &L, uint32_
     // loads), a few loads of a lane in flight at a time: the passes are latency-bound.  The "final before this pass"
     // bits come out of wave ballots, one 64-bit word per row.
     auto stage_word = [&](int gi, int gj) -> uint32_t {                  // 0xFFFFFFFF: outside the grid
-        return (gi >= 0 && gi < n && gj >= 0 && gj < m) ? A.cinfo[(int64_t)gi * m + gj] : 0xFFFFFFFFu;
+        return (gi >= 0 && gi < n && gj >= 0 && gj < m) ? ld_off<uint32_t>(B.cinfo, halo_cell(gi - i0 + 1, gj - j0 + 1, m) * 4u) : 0xFFFFFFFFu;
     };
     auto final_before = [&](uint32_t w) -> bool {                        // outside the grid: nothing drains from there
         if (w == 0xFFFFFFFFu) return true;
@@ -696,10 +740,11 @@ __device__ __forceinline__ void tile_stage(const SweepArgs &A, TileW &L, uint32_
 template <bool LISTED>
 __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uint32_t pass, int tiles_x, int tid, int lane,
                                                uint8_t *__restrict__ tile_done, int32_t &n_final, const TileNext &N,
-                                               int32_t *pend, int &npend)
+                                               int32_t *pend, int &npend, const int32_t *nbr16)
 {
     const int by = tid / tiles_x, bx = tid - by * tiles_x;
     const int i0 = by * TH, j0 = bx * TT, n = A.n, m = A.m;
+    const TileBase B = tile_base(A, i0, j0);
     const int half = lane >> 5, l32 = lane & 31;         // interior cell k of a lane: row 2k + half, column l32 of the tile
     // ready-list push; `consumed` = entries already processed (ring occupancy = tail - consumed)
     auto push_ready = [&](int cell, int consumed) {
@@ -718,7 +763,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
     if (lane == 0) { L.tail = 0; L.limit = INT32_MAX; }
     const double a0_row = (lane < TH && i0 + lane < n) ? A.a0[i0 + lane] : 0.0;       // lands in LDS once the final bitmap is no longer needed
     constexpr int NSET = TH * TT / 64;
-    tile_stage(A, L, pass, i0, j0, lane);
+    tile_stage(A, B, L, pass, i0, j0, lane);
     tile_wave_sync();
     if (prof) tk1 = wall_clock64();
     // ---- per-cell setup: how many upstream cells are still open = in-mask bits whose neighbour is not final (three row
@@ -752,14 +797,14 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
                 e0[k] = 0;
                 if (pitmask & (1u << (kb + k))) {
                     const int cell = lane + 64 * (kb + k);
-                    e0[k] = pit_stash(A, (i0 + (cell >> 5)) * m + j0 + (cell & 31)).x;
+                    e0[k] = ld_off<int2>(B.area, halo_cell((cell >> 5) + 1, (cell & 31) + 1, m) * 8u).x;
                 }
             }
 #pragma unroll
             for (int k = 0; k < PB; k++) {
                 if (!(pitmask & (1u << (kb + k)))) continue;
                 const int cell = lane + 64 * (kb + k);
-                const int32_t c = (i0 + (cell >> 5)) * m + j0 + (cell & 31);
+                const int32_t c = B.org + (int32_t)halo_cell((cell >> 5) + 1, (cell & 31) + 1, m);
                 const int idx = cell;
                 uint32_t pend = sp_of(L, idx);
                 for (int32_t e = e0[k];; e += 2) {                  // pit -> drain edges are short: most sources sit in this tile
@@ -815,31 +860,34 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
             const int cell = mycell;
             const int li = (cell >> 5) + 1, lj = (cell & 31) + 1, idx = cell;
             const int gi = i0 + li - 1, gj = j0 + lj - 1;
-            const int32_t c = gi * m + gj;
+            const uint32_t h = halo_cell(li, lj, m);                 // the cell in halo coordinates: offsets into the five planes
+            const int32_t c = B.org + (int32_t)h;
             const uint32_t cw = L.cs[idx] >> 16;
             // everything that only needs (c, cw): proportion, pit slots, the in-edge contributions (most cells have one
             // or two in-edges: walk the set bits, in ascending order like the reference's pull, four loads in flight)
             double pv = 0.0;
-            if (cw & (CI_OUT1 | CI_OUT2)) pv = A.prop[c];
+            if (cw & (CI_OUT1 | CI_OUT2)) pv = ld_off<double>(B.prop, h * 8u);
             int2 po = make_int2(0, 0);
-            if (cw & (CI_PIT_IN | CI_PIT_OUT)) po = pit_stash(A, c);
+            if (cw & (CI_PIT_IN | CI_PIT_OUT)) po = ld_off<int2>(B.area, h * 8u);
             uint32_t mm = cw & 0xFFu;
             double xs[4];
+            int dq[4]; uint32_t oq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { dq[q] = -1; if (mm) { dq[q] = __ffs(mm) - 1; mm &= mm - 1u; } }
+#pragma unroll
+            for (int q = 0; q < 4; q++) oq[q] = (uint32_t)nbr16[dq[q] & 7];          // (the four table reads go out together)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 xs[q] = 0.0;
-                if (mm) {
-                    const int d = __ffs(mm) - 1; mm &= mm - 1u;
-                    if (d == cd) xs[q] = cv; else xs[q] = in_edge(A, c, m, d);
-                }
+                if (dq[q] >= 0) { if (dq[q] == cd) xs[q] = cv; else xs[q] = ld_off<double>(B.contrib, h * 16u + oq[q]); }
             }
             double a = L.a0[li - 1];
-            bool td = (gi == 0 || gi == n - 1 || gj == 0 || gj == m - 1) && A.todo_work[c] != 0;
+            bool td = (gi == 0 || gi == n - 1 || gj == 0 || gj == m - 1) && ld_off<uint8_t>(B.todo, h) != 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) { a += fabs(xs[q]); td = td || (xs[q] < 0); }       // (+0.0 leaves the positive sum as it is)
             while (mm) {                                                                    // five and more in-edges: rare
                 const int d = __ffs(mm) - 1; mm &= mm - 1u;
-                const double x = (d == cd) ? cv : in_edge(A, c, m, d);
+                const double x = (d == cd) ? cv : in_edge_h(B, nbr16, h, d);
                 a += fabs(x); td = td || (x < 0);
             }
             if (cw & CI_PIT_IN)
@@ -852,10 +900,10 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
             if (cw & CI_OUT1) o.x = a * pv;
             if (cw & CI_OUT2) o.y = a * (1 - pv);
             if (td) { o.x = -o.x; o.y = -o.y; }
-            A.area[c] = a;
-            A.contrib[c] = o;
-            if (LISTED) A.cinfo[c] = ci_with_level(cw, pass);        // finished in this pass (other tiles treat levels < their pass as final)
-            if (td) A.todo_work[c] = 1;
+            st_off<double>(B.area, h * 8u, a);
+            st_off<double2>(B.contrib, h * 16u, o);
+            if (LISTED) st_off<uint32_t>(B.cinfo, h * 4u, ci_with_level(cw, pass));    // finished in this pass (other tiles treat levels < their pass as final)
+            if (td) st_off<uint8_t>(B.todo, h, (uint8_t)1);
             sp_of(L, idx) = (uint16_t)(2u << SP_STATE_SHIFT);
             finalized++;
             // release the targets inside the tile; targets in other tiles may be ready now: their tiles run in the
@@ -902,7 +950,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
         for (int k = 0; k < NSET; k++) {
             const int li = 2 * k + half + 1, idx = lane + 64 * k;
             const uint32_t w = L.cs[idx];
-            if (((w >> SP_STATE_SHIFT) & 3u) == 2u) A.cinfo[(int64_t)(i0 + li - 1) * m + j0 + l32] = ci_with_level(w >> 16, pass);
+            if (((w >> SP_STATE_SHIFT) & 3u) == 2u) st_off<uint32_t>(B.cinfo, halo_cell(li, l32 + 1, m) * 4u, ci_with_level(w >> 16, pass));
         }
     for (int off = 32; off > 0; off >>= 1) { finalized += __shfl_down(finalized, off); n_open += __shfl_down(n_open, off); }
     if (LISTED) {
@@ -952,6 +1000,9 @@ __global__ __launch_bounds__(64 * FWPB, 32 / FWPB) void k_sweep_tiles(SweepArgs 
 {
     __shared__ TileW L[FWPB];
     __shared__ int32_t s_pend[FWPB][TILE_PEND];
+    __shared__ int32_t s_nbr16[8];
+    fill_nbr16(s_nbr16, A.m);
+    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int32_t fin = 0;
     int npend = 0;
@@ -969,7 +1020,7 @@ __global__ __launch_bounds__(64 * FWPB, 32 / FWPB) void k_sweep_tiles(SweepArgs 
     const int per4 = (gridDim.x >> 3) * 4;
     for (int tid = (blockIdx.x & 7) * per4 + (blockIdx.x >> 3) * 4 + wave, once = 0; once < 1; once++) {
         if (tid < tiles_total && !tile_done[tid])
-            sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend);
+            sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend, s_nbr16);
     }
 #else
     const int per = (tiles_total + 7) >> 3;
@@ -983,7 +1034,7 @@ __global__ __launch_bounds__(64 * FWPB, 32 / FWPB) void k_sweep_tiles(SweepArgs 
             const int tid = xcd * per + q;
             if (q >= per || tid >= tiles_total) break;
             if (tile_done[tid]) continue;
-            sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend);
+            sweep_one_tile<LISTED>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend, s_nbr16);
             if (LISTED && npend > TILE_PEND - 10) flush();      // (a visit adds at most ten)
         }
     }
@@ -1016,6 +1067,9 @@ __global__ __launch_bounds__(64 * LWPB, (PYDEM_LISTED_OCC * 4) / LWPB) void k_sw
     // (the tile id is the same for the whole wavefront: as a scalar it keeps the tile's coordinates and every address
     // derived from them out of the vector registers)
     __shared__ int32_t s_pend[LWPB][TILE_PEND];
+    __shared__ int32_t s_nbr16[8];
+    fill_nbr16(s_nbr16, A.m);
+    __syncthreads();
     int32_t fin = 0;               // finished cells of all tiles of this wavefront: one add at the end
     int npend = 0;                 // tiles woken by this wavefront's visits that are not on the global list yet
     auto flush = [&]() {
@@ -1046,7 +1100,7 @@ __global__ __launch_bounds__(64 * LWPB, (PYDEM_LISTED_OCC * 4) / LWPB) void k_sw
         k = k * 8 + xcd;                   // interleaved: the list is in wake order, contiguous eighths would be regions of unequal work
         if (k >= nt) break;
 #endif
-        sweep_one_tile<true>(A, L[wave], pass, tiles_x, __builtin_amdgcn_readfirstlane(list_in[k]), lane, tile_done, fin, N, s_pend[wave], npend);
+        sweep_one_tile<true>(A, L[wave], pass, tiles_x, __builtin_amdgcn_readfirstlane(list_in[k]), lane, tile_done, fin, N, s_pend[wave], npend, s_nbr16);
         if (npend > TILE_PEND - 10) flush();            // (a visit adds at most ten)
     }
     if (npend) flush();
@@ -1175,7 +1229,7 @@ __device__ __forceinline__ void sweep_tile_resident(const SweepArgs &A, TileR &R
     constexpr int NSET = TH * TT / 64;
     if (lane == 0) L.tail = 0;
     const double a0_row = (lane < TH && i0 + lane < n) ? A.a0[i0 + lane] : 0.0;
-    tile_stage(A, L, pass, i0, j0, lane);
+    tile_stage(A, tile_base(A, i0, j0), L, pass, i0, j0, lane);
     tile_wave_sync();
     // ---- setup: open-upstream counts (as in the generic visit) and a slot per open cell
     uint32_t pitmask = 0;
@@ -1353,6 +1407,9 @@ __global__ __launch_bounds__(64) void k_sweep_tiles_resident(SweepArgs A, uint32
 {
     __shared__ TileR R;
     __shared__ int32_t s_pend[TILE_PEND];
+    __shared__ int32_t s_nbr16[8];
+    fill_nbr16(s_nbr16, A.m);
+    __syncthreads();
     const int lane = threadIdx.x;
     const int32_t nt = *n_in;
     if (blockIdx.x == 0 && lane == 0) *clear_count = 0;
@@ -1372,7 +1429,7 @@ __global__ __launch_bounds__(64) void k_sweep_tiles_resident(SweepArgs A, uint32
         if (__builtin_amdgcn_readfirstlane(A.tile_open[tid]) <= RCAP)
             sweep_tile_resident(A, R, pass, tiles_x, tid, lane, tile_done, fin, N, s_pend, npend);
         else
-            sweep_one_tile<true>(A, R.W, pass, tiles_x, tid, lane, tile_done, fin, N, s_pend, npend);
+            sweep_one_tile<true>(A, R.W, pass, tiles_x, tid, lane, tile_done, fin, N, s_pend, npend, s_nbr16);
         if (npend > TILE_PEND - 10) flush();
     }
     if (npend) flush();
@@ -2911,6 +2968,8 @@ static int64_t reseed_replay_host(std::vector<ReseedHost> &H, std::vector<uint8_
 int stage_sweep(pydem_tile *t, const pydem_options *opt)
 {
     const int n = (int)t->n, m = (int)t->m;
+    // (the tile visits address a tile + halo by 32-bit byte offsets from a scalar base: 34 rows of 16-byte entries)
+    if (m >= (1 << 22)) { pydem_set_error("uca: tiles wider than 4 194 303 columns are not supported (this one has %d)", m); return -2; }
     PYDEM_TRY(tile_alloc(t, &t->queue[0], (size_t)t->NN));
     PYDEM_TRY(tile_alloc(t, &t->queue[1], (size_t)t->NN));
     PYDEM_TRY(tile_alloc(t, &t->row_area, (size_t)t->n));
