@@ -871,16 +871,22 @@ __global__ __launch_bounds__(256) void k_flat_active(CondArgs A, Regions R, cons
 // runs as if no region stopped before its last sweep and counts the first arrivals per (region, sweep of the pass);
 // k_flat_accept then books them, and when a region turns out to have stopped in mid-pass the same pass runs once more over
 // the same input -- now with the stopping sweeps known -- for the blocks that hold cells of such a region.
-constexpr int FB = 32, FT = 8, FW = FB + 2 * FT;       // block edge, sweeps per pass = halo, edge of the loaded window
-constexpr int FB_THREADS = 512;
+#ifndef PYDEM_FLAT_T
+#define PYDEM_FLAT_T 8
+#endif
+constexpr int FB = 32, FT = PYDEM_FLAT_T, FW = FB + 2 * FT;       // block edge, sweeps per pass = halo (8: 81 KB of LDS, 16: 144 KB), edge of the loaded window
+static_assert(FT >= 1 && FT <= 16, "sweeps per pass");
+constexpr int FB_THREADS = FT > 8 ? 1024 : 512;
+constexpr uint32_t FI_NOSLOT = 0x3FFFu;                // (table rows: 14 bits)
 constexpr uint32_t FI_MASK = 1u, FI_CARD_H = 2u, FI_ALL_H = 4u, FI_CARD_L = 8u, FI_ALL_L = 16u, FI_GEN = 32u;
 struct FlatBatch {
     const double *dh_in, *dl_in;
     double *dh_out, *dl_out;
-    const int32_t *blocks; int32_t nblk;
+    const int32_t *blocks; const int32_t *nblk;      // (the count is read on the device: passes are queued without a look from the host)
     int nbi, nbj;                // blocks per column / row of the tile
     int s0, T;                   // first sweep of the pass, sweeps in it (<= FT)
     int first;                   // 1: the run that counts arrivals and lists the next blocks; 0: the repeat after k_flat_accept
+    const int32_t *again;        // the repeat only runs when k_flat_accept raised this flag
     const int32_t *slot_of;      // per region: row of the arrival table (-1: none)
     int32_t *arr;                // [slot][2][FT] first arrivals of the pass
     int32_t *bstamp, *next_list, *next_count; int32_t pass_id;
@@ -888,14 +894,22 @@ struct FlatBatch {
     int32_t *err;
 };
 
-__global__ __launch_bounds__(FB_THREADS) void k_flat_batch(CondArgs A, Regions R, FlatBatch P)
+struct FlatLds {
+    double dh[2][FW * FW], dl[2][FW * FW];
+    uint32_t info[FW * FW];      // FI_* bits, bits 8-12 / 13-17: sweeps of this pass the cell's region takes part in (hi / lo), bits 18-31 table row
+    int flag;
+};
+
+__device__ __forceinline__ void flat_batch_blocks(const CondArgs &A, const Regions &R, const FlatBatch &P, FlatLds &S, int wg, int nwg)
 {
-    __shared__ double s_dh[2][FW * FW], s_dl[2][FW * FW];
-    __shared__ uint32_t s_info[FW * FW];      // FI_* bits, bits 8-11 / 12-15: sweeps of this pass the cell's region takes part in (hi / lo), bits 16-31 table row
-    __shared__ int s_flag;
+    double (*s_dh)[FW * FW] = S.dh, (*s_dl)[FW * FW] = S.dl;
+    uint32_t *s_info = S.info;
+    int &s_flag = S.flag;
     double *s_z = s_dh[1];                    // elevations of the window while the seeds are worked out
     const int n = A.n, m = A.m, tid = (int)threadIdx.x, T = P.T;
-    for (int bq = blockIdx.x; bq < P.nblk; bq += gridDim.x) {
+    if (!P.first && !*P.again) return;
+    const int32_t nblk = *P.nblk;
+    for (int bq = wg; bq < nblk; bq += nwg) {
         const int b = P.blocks[bq];
         const int bi = b / P.nbj, bj = b - bi * P.nbj;
         const int i0 = bi * FB - FT, j0 = bj * FB - FT;
@@ -916,7 +930,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_flat_batch(CondArgs A, Regions R
             const int32_t c = (i0 + li) * m + j0 + lj;
             const int32_t r = A.creg[c];
             const int32_t fl = R.flags[r];
-            uint32_t info = FI_MASK, jlh = 0, jll = 0, slot = 0xFFFFu;
+            uint32_t info = FI_MASK, jlh = 0, jll = 0, slot = FI_NOSLOT;
             if (fl & RF_GENERAL) {
                 info |= FI_GEN;
                 const int32_t dH = R.done_hi[r], dL = R.done_lo[r];
@@ -924,7 +938,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_flat_batch(CondArgs A, Regions R
                 jll = dL >= P.s0 + T - 1 ? (uint32_t)T : (dL < P.s0 ? 0u : (uint32_t)(dL - P.s0 + 1));
                 if (jlh | jll) {
                     const int32_t sl = P.slot_of[r];
-                    slot = sl >= 0 ? (uint32_t)sl : 0xFFFFu;
+                    slot = sl >= 0 ? (uint32_t)sl : FI_NOSLOT;
                     const double level = region_level(A, c);
                     const double src_max = (fl & RF_SOURCE) ? dunkey(R.lowest_bits[r]) + P.source_tol : 0.0;
 #pragma unroll
@@ -946,7 +960,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_flat_batch(CondArgs A, Regions R
                 s_dh[0][idx] = P.dh_in[c]; s_dl[0][idx] = P.dl_in[c];
             }
             // (the FI_MASK bit the neighbours look at does not change; the word is complete before the barrier)
-            atomicExch(&s_info[idx], info | (jlh << 8) | (jll << 12) | (slot << 16));
+            atomicExch(&s_info[idx], info | (jlh << 8) | (jll << 13) | (slot << 18));
         }
         if (!P.first && needfix) s_flag = 1;
         __syncthreads();
@@ -957,12 +971,12 @@ __global__ __launch_bounds__(FB_THREADS) void k_flat_batch(CondArgs A, Regions R
             for (int base = 0; base < FW * FW; base += FB_THREADS) {      // (the trip count is the same for all lanes of a wavefront: ballots below)
                 const int idx = base + tid;
                 bool arr_h = false, arr_l = false;
-                uint32_t slot = 0xFFFFu;
+                uint32_t slot = FI_NOSLOT;
                 if (idx < FW * FW) {
                     const int li = idx / FW, lj = idx - li * FW;
                     const uint32_t info = s_info[idx];
                     if (li >= lo && li <= hi && lj >= lo && lj <= hi && (info & FI_GEN)) {
-                        const bool act_h = j < (int)((info >> 8) & 15u), act_l = j < (int)((info >> 12) & 15u);
+                        const bool act_h = j < (int)((info >> 8) & 31u), act_l = j < (int)((info >> 13) & 31u);
                         const double oh = s_dh[p][idx], ol = s_dl[p][idx];
                         double nh = oh, nl = ol;
                         if (act_h || act_l) {
@@ -995,7 +1009,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_flat_batch(CondArgs A, Regions R
                                 changed = changed || nh != oh || nl != ol;
                                 arr_h = act_h && isinf(oh) && !isinf(nh);
                                 arr_l = act_l && isinf(ol) && !isinf(nl);
-                                slot = info >> 16;
+                                slot = info >> 18;
                             }
                         }
                         s_dh[p ^ 1][idx] = nh; s_dl[p ^ 1][idx] = nl;
@@ -1011,7 +1025,7 @@ __global__ __launch_bounds__(FB_THREADS) void k_flat_batch(CondArgs A, Regions R
                             const uint32_t ls = (uint32_t)__shfl((int)slot, leader);
                             const unsigned long long same = __ballot(arrived && slot == ls);
                             if ((int)__lane_id() == leader) {
-                                if (ls == 0xFFFFu) *P.err = 1;                        // a region without a table row moved: the caller gives up
+                                if (ls == FI_NOSLOT) *P.err = 1;                        // a region without a table row moved: the caller gives up
                                 else atomicAdd(&P.arr[((int64_t)ls * 2 + f) * FT + j], (int32_t)__popcll(same));
                             }
                             pend &= ~same;
@@ -1039,6 +1053,12 @@ __global__ __launch_bounds__(FB_THREADS) void k_flat_batch(CondArgs A, Regions R
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(FB_THREADS) void k_flat_batch(CondArgs A, Regions R, FlatBatch P)
+{
+    __shared__ FlatLds S;
+    flat_batch_blocks(A, R, P, S, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // the regions that are still sweeping get a row of the arrival table (from the cells of the current work list: a region that
@@ -1079,11 +1099,10 @@ __global__ __launch_bounds__(256) void k_flat_blocks(const int32_t *__restrict__
 
 // books the first arrivals of a pass: a region whose last cell arrived in sweep s0 + j stops there (done = that sweep, like
 // region_arrivals); out[0] = 1 when that happened before the last sweep of the pass (the pass is repeated for its blocks)
-__global__ __launch_bounds__(256) void k_flat_accept(Regions R, const int32_t *__restrict__ ar_id, const int32_t *__restrict__ count, int32_t cap,
-                                                     int32_t *arr, int s0, int T, int32_t *out)
+__device__ __forceinline__ void flat_accept_rows(const Regions &R, const int32_t *__restrict__ ar_id, int32_t nt, int32_t *arr, int s0, int T, int32_t *out,
+                                                 int first, int stride)
 {
-    const int32_t nt = *count < cap ? *count : cap;
-    for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nt; k += gridDim.x * blockDim.x) {
+    for (int32_t k = first; k < nt; k += stride) {
         const int32_t r = ar_id[k];
         for (int f = 0; f < 2; f++) {
             int32_t *rem = f ? R.rem_lo : R.rem_hi, *done = f ? R.done_lo : R.done_hi;
@@ -1099,6 +1118,18 @@ __global__ __launch_bounds__(256) void k_flat_accept(Regions R, const int32_t *_
             rem[r] = left;
         }
     }
+}
+
+// (queued behind every pass: clears the block counter and the repeat flag of the pass after the next / the next one, counts
+// the passes that had blocks)
+__global__ __launch_bounds__(256) void k_flat_accept(Regions R, const int32_t *__restrict__ ar_id, const int32_t *__restrict__ count, int32_t cap,
+                                                     int32_t *arr, int s0, int T, int32_t *again, int32_t *again_next, const int32_t *nblk,
+                                                     int32_t *clear_count, int32_t *stats)
+{
+    if (*nblk == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *clear_count = 0; *again_next = 0; stats[0] += 1; stats[2] += *nblk; }
+    const int32_t nt = *count < cap ? *count : cap;
+    flat_accept_rows(R, ar_id, nt, arr, s0, T, again, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
 }
 
 // the new surface between the uphill rim and the outlet (:376-380)
@@ -1301,7 +1332,7 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
         const int nbi = (n + FB - 1) / FB, nbj = (m + FB - 1) / FB;
         int32_t *b_slot = nullptr, *b_arid = nullptr, *b_arr = nullptr, *b_stamp = nullptr, *b_list[2] = {nullptr, nullptr};
         int batch_limit = batch_cells;
-        int64_t batch_passes = 0, batch_repeats = 0, batch_blocks = 0;
+        int64_t batch_passes = 0, batch_blocks = 0;
         while (na > 0) {
             bool small_run = false;
             if (batch_limit > 0 && sweep >= 2 && na <= batch_limit) {
@@ -1316,48 +1347,50 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
                     b_list[0] = (int32_t *)q; q += nblocks * 4;
                     b_list[1] = (int32_t *)q;
                 }
-                // cnt[16]: table rows, cnt[17]: repeat flag, cnt[18]: a region without a row moved, cnt[20 + k]: blocks of pass k % 2
+                // cnt[16]: table rows, cnt[18]: a region without a row moved (the rest of cnt[16..31]: see below)
                 const int q0 = (sweep - 1) & 1;                            // sweep `sweep` reads dh[q0] (the list al[q0])
                 HIP_TRY(hipMemsetAsync(b_slot, 0xFF, (size_t)nreg * 4, t->stream));
                 HIP_TRY(hipMemsetAsync(b_arr, 0, (size_t)batch_regions * 2 * FT * 4, t->stream));
                 HIP_TRY(hipMemsetAsync(b_stamp, 0, (size_t)nbi * nbj * 4, t->stream));
-                HIP_TRY(hipMemsetAsync(cnt + 16, 0, 8 * sizeof(int32_t), t->stream));
+                HIP_TRY(hipMemsetAsync(cnt + 16, 0, 16 * sizeof(int32_t), t->stream));
                 hipLaunchKernelGGL(k_flat_table, dim3(grid_of(na, 1024)), dim3(256), 0, t->stream, A, R, al[q0], na, sweep, b_slot, b_arid, cnt + 16, batch_regions);
                 hipLaunchKernelGGL(k_flat_blocks, dim3(grid_of(na, 1024)), dim3(256), 0, t->stream, al[q0], na, n, m, nbj, b_stamp, 1, b_list[0], cnt + 20);
                 HIP_TRY(hipMemcpyAsync(t->h_counters + 16, cnt + 16, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
                 HIP_TRY(hipStreamSynchronize(t->stream));
                 if (t->h_counters[16] > batch_regions) batch_limit = na / 2;      // too many regions still sweeping: more single sweeps first
                 else {
-                    int32_t nblk = t->h_counters[20];
-                    int bin = q0, lcur = 0, pass_id = 1;
+                    // cnt[20..22]: block counts, rotating (pass k reads [k % 3], appends to [(k + 1) % 3], its k_flat_accept clears [(k + 2) % 3]);
+                    // cnt[28 + k % 2]: the repeat flag of pass k; cnt[24..26]: passes with blocks / (unused) / block visits.
+                    // The passes are queued CH at a time without a look from the host (a pass without blocks does nothing).
+                    int bin = q0;
                     FlatBatch P;
                     P.nbi = nbi; P.nbj = nbj; P.T = batch_T; P.slot_of = b_slot; P.arr = b_arr; P.bstamp = b_stamp; P.source_tol = source_tol; P.err = cnt + 18;
-                    while (nblk > 0) {
-                        P.dh_in = dh[bin]; P.dl_in = dl[bin]; P.dh_out = dh[bin ^ 1]; P.dl_out = dl[bin ^ 1];
-                        P.blocks = b_list[lcur]; P.nblk = nblk; P.s0 = sweep; P.first = 1;
-                        P.next_list = b_list[lcur ^ 1]; P.next_count = cnt + 20 + (lcur ^ 1); P.pass_id = pass_id;
-                        HIP_TRY(hipMemsetAsync(cnt + 20 + (lcur ^ 1), 0, sizeof(int32_t), t->stream));
-                        const int gb = nblk < 2048 ? nblk : 2048;
-                        hipLaunchKernelGGL(k_flat_batch, dim3(gb), dim3(FB_THREADS), 0, t->stream, A, R, P);
-                        hipLaunchKernelGGL(k_flat_accept, dim3(grid_of(t->h_counters[16], 64)), dim3(256), 0, t->stream, R, b_arid, cnt + 16, batch_regions, b_arr, sweep,
-                                           batch_T, cnt + 17);
-                        HIP_TRY(hipMemcpyAsync(t->h_counters + 16, cnt + 16, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
-                        HIP_TRY(hipStreamSynchronize(t->stream));
-                        if (t->h_counters[18]) { pydem_set_error("fill_flats: a region outside the arrival table moved"); return -5; }
-                        if (t->h_counters[17]) {
+                    const int CH = 16, gb = 256;
+                    const int sweep_first = sweep;
+                    int k = 0;
+                    for (;;) {
+                        for (int c = 0; c < CH; c++, k++) {
+                            const int pbin = bin ^ (k & 1);
+                            P.dh_in = dh[pbin]; P.dl_in = dl[pbin]; P.dh_out = dh[pbin ^ 1]; P.dl_out = dl[pbin ^ 1];
+                            P.blocks = b_list[k & 1]; P.nblk = cnt + 20 + k % 3; P.s0 = sweep_first + k * batch_T; P.first = 1; P.again = cnt + 28 + (k & 1);
+                            P.next_list = b_list[(k & 1) ^ 1]; P.next_count = cnt + 20 + (k + 1) % 3; P.pass_id = 1 + k;
+                            hipLaunchKernelGGL(k_flat_batch, dim3(gb), dim3(FB_THREADS), 0, t->stream, A, R, P);
+                            hipLaunchKernelGGL(k_flat_accept, dim3(grid_of(t->h_counters[16], 64)), dim3(256), 0, t->stream, R, b_arid, cnt + 16, batch_regions, b_arr,
+                                               P.s0, batch_T, cnt + 28 + (k & 1), cnt + 28 + ((k + 1) & 1), cnt + 20 + k % 3, cnt + 20 + (k + 2) % 3, cnt + 24);
                             P.first = 0;
                             hipLaunchKernelGGL(k_flat_batch, dim3(gb), dim3(FB_THREADS), 0, t->stream, A, R, P);
-                            HIP_TRY(hipMemsetAsync(cnt + 17, 0, sizeof(int32_t), t->stream));
-                            batch_repeats++;
                         }
-                        batch_passes++; batch_blocks += nblk;
-                        sweep += batch_T; bin ^= 1; lcur ^= 1; pass_id++;
-                        nblk = t->h_counters[20 + lcur];
-                        if (sweep > sweep_cap + 256) { pydem_set_error("fill_flats: distance sweeps did not terminate"); return -5; }
+                        HIP_TRY(hipMemcpyAsync(t->h_counters + 17, cnt + 17, 14 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+                        HIP_TRY(hipGetLastError());
+                        HIP_TRY(hipStreamSynchronize(t->stream));
+                        if (t->h_counters[18]) { pydem_set_error("fill_flats: a region outside the arrival table moved"); return -5; }
+                        if (t->h_counters[20 + k % 3] == 0) break;
+                        if (sweep_first + (int64_t)k * batch_T > sweep_cap + 256) { pydem_set_error("fill_flats: distance sweeps did not terminate"); return -5; }
                     }
+                    batch_passes = t->h_counters[24]; batch_blocks = t->h_counters[26];
+                    sweep = sweep_first + (int)batch_passes * batch_T; bin ^= (int)(batch_passes & 1);
                     pp = bin; na = 0;
-                    if (cond_debug) fprintf(stderr, "fill_flats: %lld passes of %d sweeps (%lld repeated), %lld block visits\n", (long long)batch_passes, batch_T,
-                                            (long long)batch_repeats, (long long)batch_blocks);
+                    if (cond_debug) fprintf(stderr, "fill_flats: %lld passes of %d sweeps, %lld block visits\n", (long long)batch_passes, batch_T, (long long)batch_blocks);
                     break;
                 }
             }

@@ -690,7 +690,7 @@ __device__ __forceinline__ void tile_stage(const SweepArgs &A, const TileBase &B
     // loads), a few loads of a lane in flight at a time: the passes are latency-bound.  The "final before this pass"
     // bits come out of wave ballots, one 64-bit word per row.
     auto stage_word = [&](int gi, int gj) -> uint32_t {                  // 0xFFFFFFFF: outside the grid
-        return (gi >= 0 && gi < n && gj >= 0 && gj < m) ? ld_off<uint32_t>(B.cinfo, halo_cell(gi - i0 + 1, gj - j0 + 1, m) * 4u) : 0xFFFFFFFFu;
+        return (gi >= 0 && gi < n && gj >= 0 && gj < m) ? A.cinfo[(int64_t)gi * m + gj] : 0xFFFFFFFFu;
     };
     auto final_before = [&](uint32_t w) -> bool {                        // outside the grid: nothing drains from there
         if (w == 0xFFFFFFFFu) return true;
@@ -871,15 +871,13 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
             if (cw & (CI_PIT_IN | CI_PIT_OUT)) po = ld_off<int2>(B.area, h * 8u);
             uint32_t mm = cw & 0xFFu;
             double xs[4];
-            int dq[4]; uint32_t oq[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) { dq[q] = -1; if (mm) { dq[q] = __ffs(mm) - 1; mm &= mm - 1u; } }
-#pragma unroll
-            for (int q = 0; q < 4; q++) oq[q] = (uint32_t)nbr16[dq[q] & 7];          // (the four table reads go out together)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 xs[q] = 0.0;
-                if (dq[q] >= 0) { if (dq[q] == cd) xs[q] = cv; else xs[q] = ld_off<double>(B.contrib, h * 16u + oq[q]); }
+                if (mm) {
+                    const int d = __ffs(mm) - 1; mm &= mm - 1u;
+                    if (d == cd) xs[q] = cv; else xs[q] = in_edge_h(B, nbr16, h, d);
+                }
             }
             double a = L.a0[li - 1];
             bool td = (gi == 0 || gi == n - 1 || gj == 0 || gj == m - 1) && ld_off<uint8_t>(B.todo, h) != 0;
@@ -950,7 +948,7 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
         for (int k = 0; k < NSET; k++) {
             const int li = 2 * k + half + 1, idx = lane + 64 * k;
             const uint32_t w = L.cs[idx];
-            if (((w >> SP_STATE_SHIFT) & 3u) == 2u) st_off<uint32_t>(B.cinfo, halo_cell(li, l32 + 1, m) * 4u, ci_with_level(w >> 16, pass));
+            if (((w >> SP_STATE_SHIFT) & 3u) == 2u) A.cinfo[(int64_t)(i0 + li - 1) * m + j0 + l32] = ci_with_level(w >> 16, pass);
         }
     for (int off = 32; off > 0; off >>= 1) { finalized += __shfl_down(finalized, off); n_open += __shfl_down(n_open, off); }
     if (LISTED) {
@@ -1053,7 +1051,7 @@ __global__ __launch_bounds__(64 * FWPB, 32 / FWPB) void k_sweep_tiles(SweepArgs 
 #define PYDEM_LISTED_WPB 2          // wavefronts (= tiles in flight) per workgroup of the listed passes (same-box A/B: 4: 30.36, 1: 29.83, 2: 29.68 ms of sweep)
 #endif
 constexpr int LWPB = PYDEM_LISTED_WPB;
-__global__ __launch_bounds__(64 * LWPB, (PYDEM_LISTED_OCC * 4) / LWPB) void k_sweep_tiles_listed(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
+__global__ __launch_bounds__(64 * LWPB, PYDEM_LISTED_OCC) void k_sweep_tiles_listed(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
                                                             const int32_t *n_in, uint8_t *__restrict__ tile_done, int32_t *n_final,
                                                             TileNext N, int32_t *clear_count, int32_t *work3)
 {
