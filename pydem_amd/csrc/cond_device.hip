@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void k_flat_active(CondArgs A, Regions R, cons
 // k_flat_accept then books them, and when a region turns out to have stopped in mid-pass the same pass runs once more over
 // the same input -- now with the stopping sweeps known -- for the blocks that hold cells of such a region.
 #ifndef PYDEM_FLAT_T
-#define PYDEM_FLAT_T 8
+#define PYDEM_FLAT_T 16
 #endif
 constexpr int FB = 32, FT = PYDEM_FLAT_T, FW = FB + 2 * FT;       // block edge, sweeps per pass = halo (8: 81 KB of LDS, 16: 144 KB), edge of the loaded window
 static_assert(FT >= 1 && FT <= 16, "sweeps per pass");

@@ -135,6 +135,9 @@ int ensure_fields(pydem_tile *t, std::initializer_list<int> fields);
 // pinned host memory of at least `bytes` that lives with the tile (grown on demand): every per-round transfer of the
 // conditioning stages goes through it -- asynchronous copies from / to pageable memory make the runtime pin and unpin
 // the pages behind the caller's back, and the NEXT GPU call then waits ~20 ms for that housekeeping
+// device blocks through the per-device free lists of tile.hip (planes of destroyed tiles are reused)
+void *plane_take(int device, size_t bytes);
+void plane_give(int device, void *q);
 int tile_pinned(pydem_tile *t, size_t bytes, void **out);
 
 // stage entry points implemented in the .hip files

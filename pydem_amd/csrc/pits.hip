@@ -1291,7 +1291,7 @@ __global__ void k_pit_gather(const uint64_t *__restrict__ keys, const int32_t *_
 template <typename T>
 int dev_realloc(pydem_tile *t, T **p, size_t count)
 {
-    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (*p) { plane_give(t->device, *p); *p = nullptr; }      // (back to the device's free list: tile.hip)
     return tile_alloc(t, p, count);
 }
 

@@ -16,18 +16,100 @@ void pydem_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+// ---- planes of destroyed tiles are kept for the next tile of the same shape ------------------------------------------
+// A fresh DEMProcessor per elevation file is how the reference is used, and a 16384^2 tile is a dozen 0.25-2 GiB planes:
+// mapping them anew costs the drop-in call more than its kernels (measured: ~240 ms of hipMalloc inside a 54-ms calc_twi).
+// Blocks of 1 MiB and more that tile_alloc handed out go on a per-device free list when their tile is destroyed and are
+// handed out again on an exact size match (the contents are whatever the last owner left: no stage relies on fresh
+// memory).  PYDEM_PLANE_CACHE_GB bounds what is kept per device (default 64, 0 = off); pydem_hip_release_scratch and a
+// failing hipMalloc empty the lists.
+#include <map>
+#include <mutex>
+#include <unordered_map>
+namespace {
+struct PlaneCache {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;
+    std::unordered_map<void *, size_t> live;          // blocks handed out by tile_alloc (size known at destroy time)
+    size_t kept = 0;
+};
+std::mutex g_pc_table;
+std::map<int, PlaneCache *> g_pc;
+PlaneCache *plane_cache(int device)
+{
+    std::lock_guard<std::mutex> g(g_pc_table);
+    PlaneCache *&c = g_pc[device];
+    if (!c) c = new PlaneCache();
+    return c;
+}
+size_t plane_cache_limit()
+{
+    static const size_t lim = [] { const char *e = getenv("PYDEM_PLANE_CACHE_GB"); return (size_t)(e ? atof(e) : 64.0) << 30; }();
+    return lim;
+}
+constexpr size_t PLANE_MIN = (size_t)1 << 20;
+void plane_cache_flush(int device)
+{
+    PlaneCache *c = plane_cache(device);
+    std::lock_guard<std::mutex> g(c->mu);
+    for (auto &kv : c->free_blocks) (void)hipFree(kv.second);
+    c->free_blocks.clear(); c->kept = 0;
+}
+}  // namespace
+
+void *plane_take(int device, size_t bytes)
+{
+    if (bytes >= PLANE_MIN && plane_cache_limit()) {
+        PlaneCache *c = plane_cache(device);
+        std::lock_guard<std::mutex> g(c->mu);
+        auto it = c->free_blocks.find(bytes);
+        if (it != c->free_blocks.end()) {
+            void *q = it->second;
+            c->free_blocks.erase(it); c->kept -= bytes;
+            c->live[q] = bytes;
+            return q;
+        }
+    }
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {                          // the free lists may hold what is missing
+        (void)hipGetLastError();
+        plane_cache_flush(device);
+        e = hipMalloc(&q, bytes);
+    }
+    if (e != hipSuccess) { pydem_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); return nullptr; }
+    if (bytes >= PLANE_MIN && plane_cache_limit()) {
+        PlaneCache *c = plane_cache(device);
+        std::lock_guard<std::mutex> g(c->mu);
+        c->live[q] = bytes;
+    }
+    return q;
+}
+
+void plane_give(int device, void *q)
+{
+    if (!q) return;
+    PlaneCache *c = plane_cache(device);
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        auto it = c->live.find(q);
+        if (it != c->live.end()) {
+            const size_t bytes = it->second;
+            c->live.erase(it);
+            if (c->kept + bytes <= plane_cache_limit()) { c->free_blocks.emplace(bytes, q); c->kept += bytes; return; }
+        }
+    }
+    (void)hipFree(q);
+}
+
 template <typename T>
 int tile_alloc(pydem_tile *t, T **p, size_t count)
 {
     if (*p) return 0;
-    void *q = nullptr;
     size_t bytes = count * sizeof(T);
     if (bytes == 0) bytes = sizeof(T);
-    hipError_t e = hipMalloc(&q, bytes);
-    if (e != hipSuccess) {
-        pydem_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
-        return -1;
-    }
+    void *q = plane_take(t->device, bytes);
+    if (!q) return -1;
     t->device_bytes += (int64_t)bytes;
     *p = (T *)q;
     return 0;
@@ -322,6 +404,12 @@ int pydem_hip_release_scratch(void)
         std::lock_guard<std::mutex> b(kv.second->busy);
         if (kv.second->p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second->p); kv.second->p = nullptr; kv.second->bytes = 0; }
     }
+    std::vector<int> devs;
+    {
+        std::lock_guard<std::mutex> g(g_pc_table);
+        for (auto &kv : g_pc) devs.push_back(kv.first);
+    }
+    for (int d : devs) { (void)hipSetDevice(d); plane_cache_flush(d); }
     return 0;
 }
 
@@ -380,7 +468,7 @@ int pydem_tile_destroy(pydem_tile *t)
                     t->pits.in_dst, t->pits.in_w, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w,
                     t->estamp, t->edelta, t->p_delta, t->s_data, t->p_flags, t->s_flags, t->line_stage, t->contrib,
                     t->eseed, t->lines_stage, t->pits.sort_buf, t->nd_rec, t->cond_mem};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) plane_give(t->device, p);          // (blocks that did not come from tile_alloc are freed)
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     if (t->h_strip_d) (void)hipHostFree(t->h_strip_d);
     if (t->h_stage) (void)hipHostFree(t->h_stage);
