@@ -86,7 +86,7 @@ int pydem_comm_begin(pydem_comm *c, int64_t n_doubles)
     HIP_TRY(hipSetDevice(c->device));
     if ((size_t)n_doubles > c->cap) {
         if (c->buf) HIP_TRY(hipFree(c->buf));
-        HIP_TRY(hipMalloc((void **)&c->buf, (size_t)n_doubles * 8));
+        HIP_TRY(dev_malloc((void **)&c->buf, (size_t)n_doubles * 8));
         c->cap = (size_t)n_doubles;
     }
     HIP_TRY(hipMemsetAsync(c->buf, 0, (size_t)n_doubles * 8, c->stream));
@@ -364,7 +364,7 @@ int pydem_board_create(int device, int n_tiles, int64_t n_doubles, pydem_board *
     b->device = device; b->n_tiles = n_tiles; b->cap = n_doubles;
     HIP_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&b->ev, hipEventDisableTiming));
-    HIP_TRY(hipMalloc((void **)&b->mb, (size_t)(n_doubles > 0 ? n_doubles : 1) * 8));
+    HIP_TRY(dev_malloc((void **)&b->mb, (size_t)(n_doubles > 0 ? n_doubles : 1) * 8));
     HIP_TRY(hipMemsetAsync(b->mb, 0, (size_t)(n_doubles > 0 ? n_doubles : 1) * 8, b->stream));
     HIP_TRY(hipMalloc((void **)&b->desc, (size_t)n_tiles * sizeof(pydem_board_desc)));
     HIP_TRY(hipMalloc((void **)&b->scal, (size_t)n_tiles * 8 * sizeof(unsigned long long)));
@@ -478,7 +478,7 @@ static int board_stage(pydem_board *b, int n_wave, const int *wave_tiles, bool s
     }
     if (total > b->wcap) {
         if (b->wb) HIP_TRY(hipFree(b->wb));
-        HIP_TRY(hipMalloc((void **)&b->wb, (size_t)total * 8));
+        HIP_TRY(dev_malloc((void **)&b->wb, (size_t)total * 8));
         b->wcap = total;
     }
     if (summed) HIP_TRY(hipMemsetAsync(b->wb, 0, (size_t)total * 8, b->stream));

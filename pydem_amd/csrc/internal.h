@@ -138,6 +138,7 @@ int ensure_fields(pydem_tile *t, std::initializer_list<int> fields);
 // device blocks through the per-device free lists of tile.hip (planes of destroyed tiles are reused)
 void *plane_take(int device, size_t bytes);
 void plane_give(int device, void *q);
+hipError_t dev_malloc(void **p, size_t bytes);      // hipMalloc; on failure the free lists are emptied and the call repeated
 int tile_pinned(pydem_tile *t, size_t bytes, void **out);
 
 // stage entry points implemented in the .hip files

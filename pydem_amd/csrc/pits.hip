@@ -1411,7 +1411,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             const size_t need = (size_t)gb * MAXD_LARGE * (4 + 8 + 8);
             if (t->scratch_bytes < need) {
                 if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->device_bytes -= (int64_t)t->scratch_bytes; }
-                HIP_TRY(hipMalloc(&t->scratch, need));
+                HIP_TRY(dev_malloc((void **)&t->scratch, need));
                 t->scratch_bytes = need; t->device_bytes += (int64_t)need;
             }
             double *g_dxy = (double *)t->scratch;
@@ -1455,7 +1455,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         const size_t need_sort = 4 * ne8 + 3 * ne4 + tmp_bytes + 256;
         if (t->pits.sort_bytes < need_sort) {
             if (t->pits.sort_buf) { HIP_TRY(hipFree(t->pits.sort_buf)); t->device_bytes -= (int64_t)t->pits.sort_bytes; }
-            HIP_TRY(hipMalloc(&t->pits.sort_buf, need_sort + need_sort / 4));
+            HIP_TRY(dev_malloc((void **)&t->pits.sort_buf, need_sort + need_sort / 4));
             t->pits.sort_bytes = need_sort + need_sort / 4; t->device_bytes += (int64_t)t->pits.sort_bytes;
         }
         char *sb = (char *)t->pits.sort_buf;

@@ -102,6 +102,19 @@ void plane_give(int device, void *q)
     (void)hipFree(q);
 }
 
+// hipMalloc for everything else the library maps on a device (scratch, arenas, record buffers): when it fails the free lists
+// of the current device are emptied and the call repeated
+hipError_t dev_malloc(void **p, size_t bytes)
+{
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        int device = 0;
+        (void)hipGetLastError();
+        if (hipGetDevice(&device) == hipSuccess) { plane_cache_flush(device); e = hipMalloc(p, bytes); }
+    }
+    return e;
+}
+
 template <typename T>
 int tile_alloc(pydem_tile *t, T **p, size_t count)
 {
@@ -152,7 +165,7 @@ void *arena_take(ArenaLease *L, size_t bytes)
     L->want += need ? need : 256;
     if (L->base && L->off + need <= L->bytes) { void *q = L->base + L->off; L->off += need ? need : 256; return q; }
     void *q = nullptr;
-    const hipError_t e = hipMalloc(&q, need ? need : 256);
+    const hipError_t e = dev_malloc(&q, need ? need : 256);
     if (e != hipSuccess) { pydem_set_error("hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e)); return nullptr; }
     L->extra.push_back(q);
     return q;
@@ -168,7 +181,7 @@ ArenaLease::~ArenaLease()
         if (a->p) (void)hipFree(a->p);
         a->p = nullptr; a->bytes = 0;
         void *q = nullptr;
-        if (hipMalloc(&q, want + want / 8) == hipSuccess) { a->p = q; a->bytes = want + want / 8; }
+        if (dev_malloc(&q, want + want / 8) == hipSuccess) { a->p = q; a->bytes = want + want / 8; }
     }
     a->busy.unlock();
 }
@@ -560,7 +573,7 @@ int pydem_tile_upload(pydem_tile *t, int field, const void *src, int dtype)
         const size_t bytes = (size_t)t->NN * ds;
         if (t->scratch_bytes < bytes) {
             if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->device_bytes -= (int64_t)t->scratch_bytes; }
-            HIP_TRY(hipMalloc(&t->scratch, bytes));
+            HIP_TRY(dev_malloc(&t->scratch, bytes));
             t->scratch_bytes = bytes; t->device_bytes += (int64_t)bytes;
         }
         PYDEM_TRY(tile_plane_copy(t, t->scratch, const_cast<void *>(src), bytes, false));
@@ -655,7 +668,7 @@ int pydem_tile_get_lines(pydem_tile *t, int count, const int *fields, const int 
     if (count > 0 && t->lines_cap < count) {
         if (t->lines_stage) { HIP_TRY(hipFree(t->lines_stage)); t->device_bytes -= (int64_t)((size_t)t->lines_cap * L * 8); }
         const int cap = count < 16 ? 16 : count;
-        HIP_TRY(hipMalloc(&t->lines_stage, (size_t)cap * L * 8));
+        HIP_TRY(dev_malloc(&t->lines_stage, (size_t)cap * L * 8));
         t->lines_cap = cap; t->device_bytes += (int64_t)((size_t)cap * L * 8);
     }
     void *pin_v = nullptr;                                  // (pinned staging: the callers' arrays are pageable)

@@ -2993,7 +2993,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     const size_t scratch_need = tiles_pad * (1 + 4 + 4 + 4 + 4);
     if (t->scratch_bytes < scratch_need) {
         if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->device_bytes -= (int64_t)t->scratch_bytes; }
-        HIP_TRY(hipMalloc(&t->scratch, scratch_need));
+        HIP_TRY(dev_malloc((void **)&t->scratch, scratch_need));
         t->scratch_bytes = scratch_need; t->device_bytes += (int64_t)scratch_need;
     }
     uint8_t *tile_done = (uint8_t *)t->scratch;
@@ -3081,7 +3081,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
                 if (unfinished > INT32_MAX / 2) { pydem_set_error("circular drainage: %lld unfinished cells", (long long)unfinished); return -5; }
                 const int32_t nU = (int32_t)unfinished;
                 void *d_tmp = nullptr;
-                HIP_TRY(hipMalloc(&d_tmp, (size_t)nU * (sizeof(ReseedCell) + sizeof(ReseedHost))));
+                HIP_TRY(dev_malloc((void **)&d_tmp, (size_t)nU * (sizeof(ReseedCell) + sizeof(ReseedHost))));
                 ReseedCell *U2 = (ReseedCell *)d_tmp;
                 ReseedHost *dH = (ReseedHost *)((char *)d_tmp + (size_t)nU * sizeof(ReseedCell));
                 HIP_TRY(hipMemsetAsync(rc, 0, 3 * sizeof(int32_t), t->stream));
@@ -3597,7 +3597,7 @@ static int einc_prepare(pydem_tile *t, IncArgs &E)
         if (nd > t->nd_cap) {
             if (t->nd_rec) { HIP_TRY(hipFree(t->nd_rec)); t->device_bytes -= t->nd_cap * (int64_t)sizeof(NDRec); }
             const int64_t cap = nd + nd / 8 + 1024;
-            HIP_TRY(hipMalloc(&t->nd_rec, (size_t)cap * sizeof(NDRec)));
+            HIP_TRY(dev_malloc((void **)&t->nd_rec, (size_t)cap * sizeof(NDRec)));
             t->nd_cap = cap; t->device_bytes += cap * (int64_t)sizeof(NDRec);
         }
         t->nd = (int32_t)nd;
@@ -3680,7 +3680,7 @@ static int cond_build(pydem_tile *t)
     CRecH *d_hr = reinterpret_cast<CRecH *>(t->queue[0]);
     void *d_tmp = nullptr;
     if ((int64_t)nd * (int64_t)sizeof(CRecH) > t->NN * 4) {       // (small tiles that are mostly 'not done': the queue buffer is too short)
-        HIP_TRY(hipMalloc(&d_tmp, (size_t)nd * sizeof(CRecH)));
+        HIP_TRY(dev_malloc((void **)&d_tmp, (size_t)nd * sizeof(CRecH)));
         d_hr = reinterpret_cast<CRecH *>(d_tmp);
     }
     hipLaunchKernelGGL(k_cond_extract, dim3(grid_for(nd, 1024)), dim3(256), 0, t->stream, C, d_hr);
@@ -3838,7 +3838,7 @@ static int cond_build(pydem_tile *t)
                  o_q0 = take((size_t)nw * 4), o_q1 = take((size_t)nw * 4), o_nan = take(nan_cap * 4), o_cnt = take(64);
     if (off > t->cond_bytes) {
         if (t->cond_mem) { HIP_TRY(hipFree(t->cond_mem)); t->device_bytes -= (int64_t)t->cond_bytes; t->cond_mem = nullptr; t->cond_bytes = 0; }
-        HIP_TRY(hipMalloc(&t->cond_mem, off + off / 8));
+        HIP_TRY(dev_malloc((void **)&t->cond_mem, off + off / 8));
         t->cond_bytes = off + off / 8; t->device_bytes += (int64_t)t->cond_bytes;
     }
     char *base = (char *)t->cond_mem;
