@@ -1111,19 +1111,25 @@ __global__ __launch_bounds__(64) void k_pits_wave_big(PitParams P, const int32_t
 }
 
 // workgroup-per-pit with the full-radius window in dynamic LDS (3 * 640*640/8 = 153.6 KB)
-__global__ __launch_bounds__(256) void k_pits_block(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits,
+// (threads per pit: the tier runs a few dozen plateau pits, one per CU, each for up to 300 rounds of bitmap scans over a window of
+// up to 12 800 words with a load per border cell -- the rounds are as long as a thread's share of the scan)
+#ifndef PYDEM_BLOCK_NT
+#define PYDEM_BLOCK_NT 512
+#endif
+constexpr int BLOCK_NT = PYDEM_BLOCK_NT;
+__global__ __launch_bounds__(BLOCK_NT) void k_pits_block(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits,
                                                     int32_t *g_dl, double *g_dxy, double *g_sv)
 {
     constexpr int WORDS = W_LARGE * W_LARGE / 32;
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
-    __shared__ double redd[4];
-    __shared__ int redi[4];
+    __shared__ double redd[BLOCK_NT / 64];
+    __shared__ int redi[BLOCK_NT / 64];
     __shared__ int flag[4];
     __shared__ PwFrame stk[16];
     int32_t chunk_base = 0, chunk_left = 0;
     const int32_t np = *npits;
     for (int32_t q = blockIdx.x; q < np; q += gridDim.x) {
-        solve_pit<256, W_LARGE, MAXD_LARGE>(P, pits[q], threadIdx.x, dyn, dyn + WORDS, dyn + 2 * WORDS,
+        solve_pit<BLOCK_NT, W_LARGE, MAXD_LARGE>(P, pits[q], threadIdx.x, dyn, dyn + WORDS, dyn + 2 * WORDS,
                                              g_dl + (size_t)blockIdx.x * MAXD_LARGE, g_dxy + (size_t)blockIdx.x * MAXD_LARGE,
                                              g_sv + (size_t)blockIdx.x * MAXD_LARGE, redd, redi, flag, chunk_base, chunk_left, stk);
         __syncthreads();
@@ -1418,7 +1424,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             double *g_sv = g_dxy + (size_t)gb * MAXD_LARGE;
             int32_t *g_dl = (int32_t *)(g_sv + (size_t)gb * MAXD_LARGE);
             P.overflow_list = nullptr; P.overflow_count = nullptr;
-            hipLaunchKernelGGL(k_pits_block, dim3(gb), dim3(256), dyn, t->stream, P, t->queue[0], cnt + 9, g_dl, g_dxy, g_sv);
+            hipLaunchKernelGGL(k_pits_block, dim3(gb), dim3(BLOCK_NT), dyn, t->stream, P, t->queue[0], cnt + 9, g_dl, g_dxy, g_sv);
             HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
         }
