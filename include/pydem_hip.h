@@ -99,7 +99,8 @@ int pydem_hip_device_memory(int device, int64_t *free_bytes, int64_t *total_byte
  * for the duration of a call (it grows to the largest request seen: ~6 GB + up to 17 GB for the large-window simulations
  * of a 8192 x 8192 tile); this returns every arena to the driver.  It also empties the per-device free lists on which
  * pydem_tile_destroy leaves the planes of a tile for the next tile of the same shape (PYDEM_PLANE_CACHE_GB, default 64;
- * a failing allocation empties them as well).  No counterpart in the reference (host arrays). */
+ * a failing allocation empties them as well) and the pinned chunks / streams of the whole-plane transfers.  No counterpart in
+ * the reference (host arrays). */
 int pydem_hip_release_scratch(void);
 
 int pydem_tile_create(int64_t n_rows, int64_t n_cols, int device, pydem_tile **out);

@@ -423,6 +423,25 @@ int pydem_hip_release_scratch(void)
         for (auto &kv : g_pc) devs.push_back(kv.first);
     }
     for (int d : devs) { (void)hipSetDevice(d); plane_cache_flush(d); }
+    // ... and the pinned chunks / streams of the whole-plane transfers (they come back with the next large transfer)
+    std::vector<std::pair<int, XferPool *>> pools;
+    {
+        std::lock_guard<std::mutex> g(g_xfer_table);
+        for (auto &kv : g_xfer) pools.push_back(kv);
+    }
+    for (auto &kv : pools) {
+        std::lock_guard<std::mutex> b(kv.second->busy);
+        (void)hipSetDevice(kv.first);
+        for (int k = 0; k < kv.second->ready; k++) {
+            XferLane &L = kv.second->lane[k];
+            for (int q = 0; q < 2; q++) {
+                if (L.pin[q]) { (void)hipHostFree(L.pin[q]); L.pin[q] = nullptr; }
+                if (L.ev[q]) { (void)hipEventDestroy(L.ev[q]); L.ev[q] = nullptr; }
+            }
+            if (L.stream) { (void)hipStreamDestroy(L.stream); L.stream = nullptr; }
+        }
+        kv.second->ready = 0;
+    }
     return 0;
 }
 

@@ -29,6 +29,8 @@ def test_plane_round_trip(shape, dtype):
     back = t.download(_ffi.ELEV)
     assert back.dtype == np.float64 and back.shape == shape
     assert np.array_equal(back, z.astype(np.float64), equal_nan=True)
+    _ffi.release_scratch()                              # drops the pinned chunks and streams: the next transfer sets them up again
+    assert np.array_equal(t.download(_ffi.ELEV), z.astype(np.float64), equal_nan=True)
     # a uint8 plane (1 byte per cell) of the same tile
     m = (rng.random(shape) < 0.3).astype(np.uint8)
     t.upload(_ffi.FLATS, m)
