@@ -618,6 +618,14 @@ __device__ __forceinline__ void tile_wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// orders LDS traffic of the wavefront only (the rounds have no global stores to wait for)
+__device__ __forceinline__ void tile_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 constexpr int TILE_PEND = 48;    // woken tiles a wavefront collects before it appends them to the next pass's list
 struct TileNext {            // LISTED passes: tiles that must run again in the next pass
     int32_t *flag;           // per tile: last pass it was listed for
@@ -681,7 +689,10 @@ __device__ __forceinline__ double in_edge_h(const TileBase &B, const int32_t *nb
 
 // staging of a tile visit: the graph words of the tile (high half of L.cs, state bit "final before this pass" in the low
 // half) and the final bitmap of tile + halo
-__device__ __forceinline__ void tile_stage(const SweepArgs &A, const TileBase &B, TileW &L, uint32_t pass, int i0, int j0, int lane)
+// (`hw`, when given: the graph words of the halo ring as well -- the symbolic visit K5f looks for its inlets there; ring
+// position: top row 0..TT+1, bottom row TT+2.., left column 2(TT+2).., right column 2(TT+2)+TH..)
+__device__ __forceinline__ void tile_stage(const SweepArgs &A, const TileBase &B, TileW &L, uint32_t pass, int i0, int j0, int lane,
+                                           uint32_t *hw = nullptr)
 {
     const int n = A.n, m = A.m;
     const int half = lane >> 5, l32 = lane & 31;
@@ -702,8 +713,13 @@ __device__ __forceinline__ void tile_stage(const SweepArgs &A, const TileBase &B
         const uint32_t wr = stage_word(half ? i0 + TH : i0 - 1, j0 + l32);          // top / bottom halo row
         uint32_t wk = 0xFFFFFFFFu;
         if (lane < 4) wk = stage_word((lane & 2) ? i0 + TH : i0 - 1, (lane & 1) ? j0 + TT : j0 - 1);   // corners
+        if (hw) {
+            hw[(half ? TT + 2 : 0) + l32 + 1] = wr;
+            if (lane < 4) hw[((lane & 2) ? TT + 2 : 0) + ((lane & 1) ? TT + 1 : 0)] = wk;
+        }
         if (TH == 32) {
             const uint32_t wc = stage_word(i0 + l32, half ? j0 + TT : j0 - 1);      // left / right halo column
+            if (hw) hw[2 * (TT + 2) + (half ? TH : 0) + l32] = wc;
             const unsigned long long bc = __ballot(final_before(wc));
             colL = bc & 0xFFFFFFFFull; colR = bc >> 32;
         } else {
@@ -981,6 +997,8 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
     tile_wave_sync();
 }
 
+#include "uca_sym.inl"
+
 // every tile that is not done yet (LISTED: also lists the tiles of the next pass).  Persistent wavefronts, XCD-contiguous
 // bands of tiles: workgroup b runs on XCD b % 8 and its wavefronts take the next tile of that XCD's band from the band's
 // counter -- a visit lasts 20 .. 100 rounds, and with four fixed tiles per workgroup the LDS of a workgroup (an eighth of
@@ -1053,9 +1071,10 @@ __global__ __launch_bounds__(64 * FWPB, 32 / FWPB) void k_sweep_tiles(SweepArgs 
 constexpr int LWPB = PYDEM_LISTED_WPB;
 __global__ __launch_bounds__(64 * LWPB, PYDEM_LISTED_OCC) void k_sweep_tiles_listed(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
                                                             const int32_t *n_in, uint8_t *__restrict__ tile_done, int32_t *n_final,
-                                                            TileNext N, int32_t *clear_count, int32_t *work3)
+                                                            TileNext N, int32_t *clear_count, int32_t *work3, SymArgs Y)
 {
     __shared__ TileW L[LWPB];
+    __shared__ SymLight SL[LWPB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t nt = *n_in;
 #ifdef PYDEM_LISTED_DYNAMIC
@@ -1098,7 +1117,10 @@ __global__ __launch_bounds__(64 * LWPB, PYDEM_LISTED_OCC) void k_sweep_tiles_lis
         k = k * 8 + xcd;                   // interleaved: the list is in wake order, contiguous eighths would be regions of unequal work
         if (k >= nt) break;
 #endif
-        sweep_one_tile<true>(A, L[wave], pass, tiles_x, __builtin_amdgcn_readfirstlane(list_in[k]), lane, tile_done, fin, N, s_pend[wave], npend, s_nbr16);
+        const int tid = __builtin_amdgcn_readfirstlane(list_in[k]);
+        const uint32_t blk = Y.tile_sym ? __builtin_amdgcn_readfirstlane(Y.tile_sym[tid]) : SYM_NONE;
+        if (blk != SYM_NONE) sym_light_visit(A, Y, SL[wave], pass, tiles_x, tid, lane, blk, fin, N, s_pend[wave], npend);     // (a tile that went symbolic, K5f)
+        else sweep_one_tile<true>(A, L[wave], pass, tiles_x, tid, lane, tile_done, fin, N, s_pend[wave], npend, s_nbr16);
         if (npend > TILE_PEND - 10) flush();            // (a visit adds at most ten)
     }
     if (npend) flush();
@@ -1199,14 +1221,6 @@ struct TileR {
     double Pd[RCAP];            // proportion
     uint32_t sm[RCAP];          // slot word
 };
-
-// orders LDS traffic of the wavefront only (the rounds have no global stores to wait for)
-__device__ __forceinline__ void tile_lds_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
 
 // tile-local id of the neighbour in-edge d (0..7 = NW N NE W E SW S SE) comes from
 __device__ __forceinline__ int nb_local(int cell, int d)
@@ -1401,9 +1415,10 @@ __device__ __forceinline__ void sweep_tile_resident(const SweepArgs &A, TileR &R
 // listed passes with few tiles: one wavefront (= one workgroup) per tile, resident visit when the tile's open cells fit
 __global__ __launch_bounds__(64) void k_sweep_tiles_resident(SweepArgs A, uint32_t pass, int tiles_x, const int32_t *__restrict__ list_in,
                                                              const int32_t *n_in, uint8_t *__restrict__ tile_done, int32_t *n_final,
-                                                             TileNext N, int32_t *clear_count)
+                                                             TileNext N, int32_t *clear_count, SymArgs Y)
 {
     __shared__ TileR R;
+    __shared__ SymLight SL;
     __shared__ int32_t s_pend[TILE_PEND];
     __shared__ int32_t s_nbr16[8];
     fill_nbr16(s_nbr16, A.m);
@@ -1424,7 +1439,9 @@ __global__ __launch_bounds__(64) void k_sweep_tiles_resident(SweepArgs A, uint32
     };
     for (int32_t k = blockIdx.x; k < nt; k += gridDim.x) {
         const int tid = __builtin_amdgcn_readfirstlane(list_in[k]);
-        if (__builtin_amdgcn_readfirstlane(A.tile_open[tid]) <= RCAP)
+        const uint32_t blk = Y.tile_sym ? __builtin_amdgcn_readfirstlane(Y.tile_sym[tid]) : SYM_NONE;
+        if (blk != SYM_NONE) sym_light_visit(A, Y, SL, pass, tiles_x, tid, lane, blk, fin, N, s_pend, npend);
+        else if (__builtin_amdgcn_readfirstlane(A.tile_open[tid]) <= RCAP)
             sweep_tile_resident(A, R, pass, tiles_x, tid, lane, tile_done, fin, N, s_pend, npend);
         else
             sweep_one_tile<true>(A, R.W, pass, tiles_x, tid, lane, tile_done, fin, N, s_pend, npend, s_nbr16);
@@ -2990,7 +3007,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     const int tiles_x = (int)cdiv(m, TT), tiles_total = tiles_x * (int)cdiv(n, TH);
     // scratch: tile_done bytes | per-tile "listed for pass" stamps | two tile lists | open cells per tile
     const size_t tiles_pad = ((size_t)tiles_total + 255) & ~(size_t)255;
-    const size_t scratch_need = tiles_pad * (1 + 4 + 4 + 4 + 4);
+    const size_t scratch_need = tiles_pad * (1 + 4 + 4 + 4 + 4 + 4) + 64 * sizeof(int32_t);     // ... | block offsets of the symbolic tiles | K5f counters
     if (t->scratch_bytes < scratch_need) {
         if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->device_bytes -= (int64_t)t->scratch_bytes; }
         HIP_TRY(dev_malloc((void **)&t->scratch, scratch_need));
@@ -3001,6 +3018,23 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     int32_t *tile_list[2] = {tile_flag + tiles_pad, tile_flag + 2 * tiles_pad};
     int32_t *cntT = t->counters + 56;          // rotating tile-list sizes
     A.tile_open = tile_flag + 3 * tiles_pad;
+    // K5f (two-level solve, uca_sym.inl): at the first look of the host that finds at most PYDEM_SWEEP_SYM tiles listed (0: never) ONE
+    // symbolic visit per unfinished tile replaces the repeated numeric visits of the later passes.  The pool of coefficients lives in the
+    // two queue buffers (idle in this schedule; the re-seed replay takes them over after k_sym_finish).
+    static int64_t sym_switch = -1;
+    if (sym_switch < 0) { const char *e = getenv("PYDEM_SWEEP_SYM"); sym_switch = e ? atoll(e) : 4096; if (sym_switch < 0) sym_switch = 0; }
+    SymArgs Y;
+    memset(&Y, 0, sizeof(Y));
+    int32_t *symc = tile_flag + 4 * tiles_pad + tiles_pad;      // 64 counters: [0..15] pool regions, [16..23] / [24..31] work counters of the two launches, [32..] statistics
+    const bool sym_on = sym_switch > 0 && TH == 32 && t->NN / 2 < ((int64_t)1 << 31);
+    if (sym_on) {
+        Y.pool0 = (double *)t->queue[0]; Y.pool1 = (double *)t->queue[1];
+        Y.nreg = t->NN >= ((int64_t)1 << 22) ? 16 : 2;
+        Y.reg_cap = (uint32_t)((t->NN / 2) / (Y.nreg / 2));
+        Y.ctr = symc; Y.tile_sym = (uint32_t *)(tile_flag + 4 * tiles_pad); Y.stat = symc + 32;
+        HIP_TRY(hipMemsetAsync(Y.tile_sym, 0xff, tiles_pad * 4, t->stream));
+        HIP_TRY(hipMemsetAsync(symc, 0, 64 * sizeof(int32_t), t->stream));
+    }
     HIP_TRY(hipMemsetAsync(tile_done, 0, tiles_pad * 5, t->stream));      // done bytes + stamps
     HIP_TRY(hipMemsetAsync(A.tile_open, 0x7f, tiles_pad * 4, t->stream));
     HIP_TRY(hipMemsetAsync(cntT, 0, 4 * sizeof(int32_t), t->stream));
@@ -3014,10 +3048,12 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
     // listed tile passes from pass p on (the list of pass p is in tile_list[p % 2] / cntT[p % 3]); returns the next pass number
     static int res_switch = -1;     // listed tiles at or below which the passes use resident visits (K5e)
     if (res_switch < 0) { const char *e = getenv("PYDEM_SWEEP_RESIDENT"); res_switch = e ? atoi(e) : 4096; }
-    auto run_listed = [&](int p, int64_t ntiles) -> int {
+    int64_t listed_left = 0;        // tiles listed for the pass run_listed returned (> 0 only when it stopped at `stop_at`)
+    auto run_listed = [&](int p, int64_t ntiles, int64_t stop_at) -> int {
         TileNext N;
         N.flag = tile_flag;
-        while (ntiles > 0) {
+        listed_left = ntiles;
+        while (ntiles > stop_at) {
             const int batch = ntiles < 2048 ? 16 : 8;    // passes between two looks at the list size (a look idles the GPU for ~30 us; the grid only shrinks below 8192 listed tiles)
 #ifndef PYDEM_LISTED_DYNAMIC
             const int grid = (int)(ntiles < 8192 ? (ntiles > 64 ? ntiles : 64) : 8192) * (4 / LWPB);
@@ -3031,16 +3067,17 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
                 if (resident)
                     hipLaunchKernelGGL(k_sweep_tiles_resident, dim3((unsigned)(ntiles > 256 ? ntiles : 256)), dim3(64), 0, t->stream, A, (uint32_t)p, tiles_x,
                                        (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
-                                       &cntT[(p + 2) % 3]);
+                                       &cntT[(p + 2) % 3], Y);
                 else
                     hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(64 * LWPB), (size_t)lds_pad, t->stream, A, (uint32_t)p, tiles_x,
                                        (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
-                                       &cntT[(p + 2) % 3], work3);
+                                       &cntT[(p + 2) % 3], work3, Y);
                 launches++;
             }
             if (hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream) != hipSuccess) return -1;
             if (hipStreamSynchronize(t->stream) != hipSuccess) return -1;
             ntiles = t->h_counters[56 + p % 3];
+            listed_left = ntiles;
             if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "listed tile pass %d: %lld tiles listed next, processed %d\n", p, (long long)ntiles, t->h_counters[3]);
             if (p > (int)CI_LEVEL_INF - 256) return -2;
         }
@@ -3177,11 +3214,47 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "tile passes %u-%u: %d cells of %lld, %d tiles listed\n", pb + 1, pb + 2, t->h_counters[3], (long long)t->NN, t->h_counters[56 + (pb + 3) % 3]);
-        const int p_end = run_listed((int)pb + 3, t->h_counters[56 + (pb + 3) % 3]);
+        int p_end = run_listed((int)pb + 3, t->h_counters[56 + (pb + 3) % 3], sym_on ? sym_switch : 0);
+        if (sym_on && p_end > 0 && listed_left > 0) {
+            // pass p_end = the symbolic visit of every tile that is not done (K5f (a)): a superset of the tiles listed for it
+            const uint32_t ps = (uint32_t)p_end;
+            TileNext N3; N3.flag = tile_flag; N3.list = tile_list[(ps + 1) % 2]; N3.count = &cntT[(ps + 1) % 3];
+            HIP_TRY(hipMemsetAsync(&cntT[(ps + 2) % 3], 0, sizeof(int32_t), t->stream));      // (a numeric pass clears the count of the list after the next one)
+            int32_t *cand = tile_list[ps % 2];      // (the list of this pass is not used: the candidates take its place)
+            hipLaunchKernelGGL(k_sym_candidates, dim3((unsigned)cdiv(tiles_total, 256)), dim3(256), 0, t->stream, (const uint8_t *)tile_done, (const int32_t *)A.tile_open,
+                               tiles_total, 256, cand, symc + 16);
+            // the three size classes side by side (each kernel lasts as long as its longest visits: 0.7 + 0.4 + 0.4 ms one after the other)
+            HIP_TRY(hipEventRecord(t->ev_fork, t->stream));
+            HIP_TRY(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
+            hipLaunchKernelGGL(k_sweep_sym<256>, dim3(256 * 9), dim3(64), 0, t->stream, A, Y, ps, tiles_x, tiles_total, tile_done, total, N3, (const int32_t *)cand, (const int32_t *)(symc + 16), 0, 0);
+            hipLaunchKernelGGL(k_sweep_sym<512>, dim3(256 * 6), dim3(64), 0, t->stream2, A, Y, ps, tiles_x, tiles_total, tile_done, total, N3, (const int32_t *)cand, (const int32_t *)(symc + 17), 1, 256);
+            hipLaunchKernelGGL(k_sweep_sym<1024>, dim3(256 * 3), dim3(64), 0, t->stream2, A, Y, ps, tiles_x, tiles_total, tile_done, total, N3, (const int32_t *)cand, (const int32_t *)(symc + 17), 1, 512);
+            HIP_TRY(hipEventRecord(t->ev_join, t->stream2));
+            HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0));
+            launches += 4;
+            HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            if (getenv("PYDEM_SWEEP_DEBUG")) fprintf(stderr, "symbolic pass %u: %d cells of %lld, %d tiles listed\n", ps, t->h_counters[3], (long long)t->NN, t->h_counters[56 + (ps + 1) % 3]);
+            p_end = run_listed((int)ps + 1, t->h_counters[56 + (ps + 1) % 3], 0);
+        }
         if (p_end == -1) { pydem_set_error("HIP error in the listed tile passes"); return -4; }
         if (p_end == -2) { pydem_set_error("flow paths longer than %u passes are not supported", CI_LEVEL_INF); return -5; }
         pass = (uint32_t)p_end;
         t->tm.sweep_tile_passes = (int64_t)pass;
+        if (sym_on) {
+            // K5f (c): the cells that still carry a symbolic header
+            hipLaunchKernelGGL(k_sym_finish, dim3((unsigned)std::min<int64_t>(tiles_total, 256 * 16)), dim3(64), 0, t->stream, A, Y, pass, tiles_x, tiles_total, total);
+            launches++;
+            if (getenv("PYDEM_SWEEP_DEBUG")) {
+                int32_t hs[64];
+                HIP_TRY(hipMemcpyAsync(hs, symc, sizeof(hs), hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipStreamSynchronize(t->stream));
+                int64_t used = 0;
+                for (int r = 0; r < Y.nreg; r++) used += hs[r];
+                fprintf(stderr, "two-level solve: %d symbolic tiles (%d fell back to numeric visits), %d outlets, %d symbolic cells, pool %lld of %lld doubles\n",
+                        hs[32], hs[33], hs[34], hs[35], (long long)used, (long long)Y.reg_cap * Y.nreg);
+            }
+        }
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         PYDEM_TRY(replay_unfinished(pass));
@@ -3246,7 +3319,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
                     N.list = tile_list[(p + 1) % 2]; N.count = &cntT[(p + 1) % 3];
                     hipLaunchKernelGGL(k_sweep_tiles_listed, dim3(grid), dim3(256), 0, t->stream, A, (uint32_t)p, tiles_x,
                                        (const int32_t *)tile_list[p % 2], (const int32_t *)&cntT[p % 3], tile_done, total, N,
-                                       &cntT[(p + 2) % 3], work3);
+                                       &cntT[(p + 2) % 3], work3, Y);
                     launches++;
                 }
                 HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));

@@ -1,5 +1,5 @@
-"""The alternative sweep schedules (the LDS-resident first pass, PYDEM_SWEEP_FIRST=lds; resident / generic visits) must give the
-same answers as the default tile-pass schedule.  The mode is read once per process, hence the subprocess.  The frontier-queue
+"""The alternative sweep schedules (the LDS-resident first pass, PYDEM_SWEEP_FIRST=lds; resident / generic visits; the two-level
+solve of the tail at several switch points, PYDEM_SWEEP_SYM) must give the same answers as the default tile-pass schedule.  The mode is read once per process, hence the subprocess.  The frontier-queue
 schedule (PYDEM_SWEEP_MODE=queue) only exists in a diagnostic build of the library (PYDEM_HIPCC_FLAGS=-DPYDEM_SWEEP_QUEUE: it
 refuses some valid inputs, so a product build ignores the variable); its cases run with PYDEM_TEST_SWEEP_QUEUE=1."""
 import os
@@ -38,6 +38,10 @@ needs_queue_build = pytest.mark.skipif(not QUEUE_BUILD, reason="the queue schedu
                                  pytest.param({'PYDEM_SWEEP_MODE': 'queue', 'PYDEM_TILE_PASSES': '3'}, marks=needs_queue_build),
                                  {'PYDEM_SWEEP_FIRST': 'lds'},           # pass 1 by the LDS-resident kernel (csrc/uca.hip K5a)
                                  {'PYDEM_SWEEP_DENSE': '3'},             # three dense level kernels ahead of the tile passes (K5d)
+                                 {'PYDEM_SWEEP_SYM': '0'},               # tile passes only: no two-level solve for the tail (K5f, csrc/uca_sym.inl)
+                                 {'PYDEM_SWEEP_SYM': '100000000'},       # the symbolic pass right after the two full passes
+                                 {'PYDEM_SWEEP_SYM': '40'},              # ... late: when at most 40 tiles are listed
+                                 {'PYDEM_SWEEP_SYM': '100000000', 'PYDEM_SWEEP_RESIDENT': '0'},
                                  {'PYDEM_SWEEP_RESIDENT': '0'},          # generic visits in every listed pass
                                  {'PYDEM_SWEEP_RESIDENT': '100000000'}]) # resident visits (K5e) from pass 3 on, tiles with > 256 open cells generic
 def test_queue_schedule_matches_oracle(env):
