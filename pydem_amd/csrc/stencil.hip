@@ -248,19 +248,21 @@ __global__ __launch_bounds__(256) void k_stencil_interior(const double *__restri
 // and produces 62 (lanes 0 and 63 are halo), rows are 512 B coalesced loads, no LDS.
 // ---------------------------------------------------------------------------------------------
 // lane shifts as DPP moves (v_mov_b32_dpp wave_shr:1 / wave_shl:1 -- gfx9 wavefront shifts; 2 VALU
-// moves per double, no LDS crossbar round trip).  The edge lanes keep their own value (halo lanes).
+// moves per double, no LDS crossbar round trip).  The lane without a neighbour (0 / 63: halo lanes, their results are
+// never stored) reads zero: with `bound_ctrl` the move has no tied old value, i.e. no copy of the source in front of
+// it (keeping the own value there cost a v_mov per dword: 16 of the 312 vector instructions of a row).
 __device__ __forceinline__ double lane_prev(double x)    // value held by lane-1 (column j-1)
 {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double lane_next(double x)    // value held by lane+1 (column j+1)
 {
     int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -352,6 +354,17 @@ struct BandCarry {
     double thAn, thBn;         // those angles (spacing row above)
     bool ex_top;               // NaN / huge elevations in the top row
 };
+// the row table of a band as VECTOR registers (broadcast loads through cx.rtv): as scalars the two rows in flight take 32
+// of the ~100 SGPRs, and the mask algebra then spills its lane masks into VGPR lanes (35 v_readlane / v_writelane per row)
+struct RowV { double dX, dY, hyp, thA, thB, rdX, rdY, rhyp; };
+__device__ __forceinline__ RowV rowv_load(const double *rtv, int r)
+{
+    const double4 *p = reinterpret_cast<const double4 *>(rtv + (size_t)r * 8);
+    const double4 a = p[0], b = p[1];
+    RowV v;
+    v.dX = a.x; v.dY = a.y; v.hyp = a.z; v.thA = a.w; v.thB = b.x; v.rdX = b.y; v.rdY = b.z; v.rhyp = b.w;
+    return v;
+}
 struct MarchCtx {
     const double *col; const RowTab *rowtab; const double *rtv; const double *atan_16;
     double *mag, *dir; uint8_t *flat0;
@@ -359,7 +372,7 @@ struct MarchCtx {
 };
 
 template <bool F32>
-__device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, RowTab &ts, const int b, const double zS, double &z_ahead)
+__device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, const RowV &ts, RowV &tnx, const int b, const double zS, double &z_ahead)
 {
     const int n = cx.n, m = cx.m;
     const int dead_hi = __double2hiint(-1.0);
@@ -367,9 +380,9 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, Row
     // software pipeline: the elevations of row b+2 and the spacing row b+1 are requested now and first touched in the
     // next band / at the very end of this one, so neither wait is exposed (the caller alternates two registers for the
     // row in flight: it is never copied before it has been used)
-    const RowTab tnx = cx.rowtab[(b + 1 <= n - 2) ? b + 1 : n - 2];
+    tnx = rowv_load(cx.rtv, (b + 1 <= n - 2) ? b + 1 : n - 2);      // (the caller alternates two register sets, like for the row in flight)
     z_ahead = cx.col[(size_t)((b + 2 <= n - 1) ? b + 2 : n - 1) * m];
-    const double thAs = cx.rtv[(size_t)b * 8 + 3], thBs = cx.rtv[(size_t)b * 8 + 4];
+    const double thAs = ts.thA, thBs = ts.thB;
     const double z0 = c.z0, hs1 = c.hs1, hsL1 = c.hsL1;
     const lmask Phs1 = c.Phs1, Nhs1 = c.Nhs1;
     // ---- row b+1 enters
@@ -513,7 +526,6 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, Row
     c.z0 = zS; c.ex_top = cx.exact_only || ex_bot;
     c.hs1 = hs; c.hsL1 = lane_prev(hs); c.Phs1 = LM(hs > 0); c.Nhs1 = LM(hs < 0);
     c.thAn = thAs; c.thBn = thBs;
-    ts = tnx;
 }
 
 // OCC = workgroups the compiler must fit on a CU: 1 = free choice (135 VGPRs: three wavefronts per SIMD), 4 = at most 128
@@ -547,7 +559,7 @@ __global__ __launch_bounds__(256, OCC) void k_stencil_march(const double *__rest
 
     // ---- the top row of the first band (row i0-1: not an output row of this wavefront, its north half is never used)
     BandCarry c;
-    RowTab ts = rowtab[i0 - 1];
+    RowV ts = rowv_load(cx.rtv, i0 - 1), tu;
     c.z0 = cx.col[(size_t)(i0 - 1) * m];
     c.ex_top = exact_only || LM(!(fabs(c.z0) < 0x1p500)) != 0;
     c.hs1 = div_row(zsub<F32>(c.z0, lane_next(c.z0)), ts.dX, ts.rdX);
@@ -558,10 +570,10 @@ __global__ __launch_bounds__(256, OCC) void k_stencil_march(const double *__rest
     double zP = cx.col[(size_t)i0 * m], zQ = 0.0;                  // the bottom row of a band alternates between zP and zQ
     int b = i0 - 1;
     for (; b + 1 < i1; b += 2) {
-        march_band<F32>(cx, c, ts, b, zP, zQ);
-        march_band<F32>(cx, c, ts, b + 1, zQ, zP);
+        march_band<F32>(cx, c, ts, tu, b, zP, zQ);
+        march_band<F32>(cx, c, tu, ts, b + 1, zQ, zP);
     }
-    if (b < i1) march_band<F32>(cx, c, ts, b, zP, zQ);
+    if (b < i1) march_band<F32>(cx, c, ts, tu, b, zP, zQ);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -703,8 +715,22 @@ static void launch_stencil(pydem_tile *t)
 #undef MARCH
 }
 
+// diagnostic (PYDEM_STENCIL_WARM): what the stencil -- the first kernel of a step -- pays for starting on a GPU that has been idle
+// or in the sweep's latency-bound tail: 1 = a few ms of fp64 arithmetic on every CU first (clocks), 2 = the output planes
+// touched first (TLB / page state), 3 = both
+__global__ __launch_bounds__(256) void k_warm_alu(double *sink, int iters)
+{
+    double a = threadIdx.x * 1e-3, b = 1.0000001, c = 1e-9;
+    for (int i = 0; i < iters; i++) { a = __builtin_fma(a, b, c); b = __builtin_fma(b, a, c); }
+    if (a + b == 12345.678) sink[0] = a;
+}
+
 int stage_stencil(pydem_tile *t)
 {
+    static int warm = -1;
+    if (warm < 0) { const char *e = getenv("PYDEM_STENCIL_WARM"); warm = e ? atoi(e) : 0; }
+    if (warm & 2) { HIP_TRY(hipMemsetAsync(t->mag, 0, (size_t)t->NN * 8, t->stream)); HIP_TRY(hipMemsetAsync(t->dir, 0, (size_t)t->NN * 8, t->stream)); }
+    if (warm & 1) hipLaunchKernelGGL(k_warm_alu, dim3(256 * 8), dim3(256), 0, t->stream, t->mag, 200000);
     HIP_TRY(hipEventRecord(t->ev[0], t->stream));
     launch_stencil(t);
     HIP_TRY(hipEventRecord(t->ev[1], t->stream));
