@@ -349,39 +349,82 @@ struct BandCarry {
     double z0;                 // elevations of the top row
     double hs1, hsL1;          // E-edge of the top row over the band's dX, own and left neighbour's
     lmask Phs1, Nhs1;          // hs1 > 0, hs1 < 0
-    double Mn, wn1, wn2;       // north half: squared magnitude, slopes of an interior winner ((1, 0) otherwise)
-    lmask Nk0, Nk1, NdA, NdB;  // north winner: bits of its facet number; diagonal with table angle thA / thB
+    double Mn;                 // north half: squared magnitude
+    lmask Nk0, Nk1, NdA, NdB, Nint;   // north winner: bits of its facet number; diagonal with table angle thA / thB; interior (r = atan2(s2, s1))
     double thAn, thBn;         // those angles (spacing row above)
     bool ex_top;               // NaN / huge elevations in the top row
 };
-// the row table of a band as VECTOR registers (broadcast loads through cx.rtv): as scalars the two rows in flight take 32
-// of the ~100 SGPRs, and the mask algebra then spills its lane masks into VGPR lanes (35 v_readlane / v_writelane per row)
+// the row table of a band as VECTOR registers: as scalars the two rows in flight take 32 of the ~100 SGPRs, and the mask
+// algebra then spills its lane masks into VGPR lanes (35 v_readlane / v_writelane per row).  The rows of the workgroup's
+// chunk are copied to LDS once (130 x 64 B) and read from there as broadcasts: a GLOBAL load per band would be counted by
+// vmcnt together with the band's stores, and the compiler's waits then sit out the store latency in every band.
 struct RowV { double dX, dY, hyp, thA, thB, rdX, rdY, rhyp; };
-__device__ __forceinline__ RowV rowv_load(const double *rtv, int r)
+__device__ __forceinline__ RowV rowv_load(const double *rtv, int r)      // rtv: the workgroup's copy of its rows' table in LDS
 {
-    const double4 *p = reinterpret_cast<const double4 *>(rtv + (size_t)r * 8);
+    const double4 *p = reinterpret_cast<const double4 *>(rtv + r * 8);
     const double4 a = p[0], b = p[1];
     RowV v;
     v.dX = a.x; v.dY = a.y; v.hyp = a.z; v.thA = a.w; v.thB = b.x; v.rdX = b.y; v.rdY = b.z; v.rhyp = b.w;
     return v;
 }
+// The slopes of the winning facet are FETCHED, not selected: every lane leaves the three quotients a band computes (hn, hs1, v)
+// in LDS, two bands deep; once the winner's facet number k is known (three mask bits) and whether it is an interior winner,
+// its two slopes are two ds_read_b64 at offsets from a 9-entry table (facet k -> which array, which lane, which of the two
+// bands; entry 8 = "not interior" -> the constants (1, 0), whose arctangent is exactly 0).  Carrying the candidates' slopes
+// through select chains instead (the north half's to the next band, then north against south) cost 32 v_cndmask per row
+// and four carried registers.
+constexpr int QS = 66;                         // lanes + one pad slot either side
+struct WaveQ { double a[2][3][QS]; double one[QS], zero[QS]; };      // a[band parity][0: hn, 1: hs1, 2: v]
 struct MarchCtx {
+    WaveQ *q; const uint16_t *tab;             // tab[parity of the running band][k][0 / 1]: byte offsets of s1 / s2 from &q->a[0][0][lane]
     const double *col; const RowTab *rowtab; const double *rtv; const double *atan_16;
     double *mag, *dir; uint8_t *flat0;
-    int n, m, j, i0, exact_only; bool writes;
+    int n, m, j, i0, r0, exact_only; bool writes;
 };
 
-template <bool F32>
+// The row in flight.  The compiler's own bookkeeping of vmcnt treats a load behind stores as "wait for everything": every band
+// then sat out the latency of its own stores (~2 us under load against 0.4 us of arithmetic; the vector ALUs idled 40 % of
+// the time with three wavefronts per SIMD).  The row is therefore requested by hand and waited for by hand: vmcnt counts in
+// issue order, the three stores of a band are issued AFTER the request, so "at most three still outstanding" at the end of
+// the band means the row has arrived and says nothing about the stores.  (The first band of a wavefront issues no stores:
+// it waits for everything.)
+__device__ __forceinline__ double row_request(const double *p)
+{
+    double v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int YOUNGER>
+__device__ __forceinline__ void row_arrived(double &v)
+{
+    if (YOUNGER == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(v) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory");
+}
+
+template <bool F32, int P, bool FIRST = false>
 __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, const RowV &ts, RowV &tnx, const int b, const double zS, double &z_ahead)
 {
+    const int lane = (int)(threadIdx.x & 63);
+#ifdef PYDEM_STENCIL_NOMATH     // memory-pattern experiment (NOT a product build): the loads and stores of the band, no arithmetic
+    {
+        z_ahead = row_request(cx.col + (size_t)((b + 2 <= cx.n - 1) ? b + 2 : cx.n - 1) * cx.m);
+        if (cx.writes && b >= cx.i0) {
+            const size_t cc = (size_t)b * cx.m + cx.j;
+            cx.mag[cc] = c.z0 + zS; cx.dir[cc] = c.z0 - zS; cx.flat0[cc] = zS > c.z0 ? 1 : 0;
+        }
+        c.z0 = zS; tnx = ts;
+        row_arrived<FIRST ? 0 : 3>(z_ahead);
+        return;
+    }
+#endif
     const int n = cx.n, m = cx.m;
     const int dead_hi = __double2hiint(-1.0);
     const double BIG = 0x1p500;
     // software pipeline: the elevations of row b+2 and the spacing row b+1 are requested now and first touched in the
     // next band / at the very end of this one, so neither wait is exposed (the caller alternates two registers for the
     // row in flight: it is never copied before it has been used)
-    tnx = rowv_load(cx.rtv, (b + 1 <= n - 2) ? b + 1 : n - 2);      // (the caller alternates two register sets, like for the row in flight)
-    z_ahead = cx.col[(size_t)((b + 2 <= n - 1) ? b + 2 : n - 1) * m];
+    tnx = rowv_load(cx.rtv, ((b + 1 <= n - 2) ? b + 1 : n - 2) - cx.r0);      // (the caller alternates two register sets, like for the row in flight)
+    z_ahead = row_request(cx.col + (size_t)((b + 2 <= n - 1) ? b + 2 : n - 1) * m);
     const double thAs = ts.thA, thBs = ts.thB;
     const double z0 = c.z0, hs1 = c.hs1, hsL1 = c.hsL1;
     const lmask Phs1 = c.Phs1, Nhs1 = c.Nhs1;
@@ -394,6 +437,7 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
     const double v = div_row(zsub<F32>(z0, zS), ts.dY, ts.rdY);
     const double se = div_row(zsub<F32>(z0, zES), ts.hyp, ts.rhyp);
     const double sw = div_row(zsub<F32>(z0, zWS), ts.hyp, ts.rhyp);
+    cx.q->a[P][0][1 + lane] = hn; cx.q->a[P][2][1 + lane] = v;
     const double hnL = lane_prev(hn), vL = lane_prev(v), vR = lane_next(v);
     const double seL = lane_prev(se), swR = lane_next(sw);
     const double q_v = v * v, q_vL = vL * vL, q_vR = vR * vR, q_hn = hn * hn, q_hnL = hnL * hnL, q_hs1 = hs1 * hs1, q_hsL1 = hsL1 * hsL1;
@@ -417,8 +461,8 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
     const lmask cd##k = (ak) & ~(bk);                                  /* I2: r = 0, mag = s1 */
 
     // ================= south half of row b, then the whole cell =================
-    double M, w1, w2;
-    lmask tAn, tBn, tAs, tBs, k0, k1, k2, flat;
+    double M;
+    lmask tAn, tBn, tAs, tBs, k0, k1, k2, flat, wint;
     if (__builtin_expect(!exact, 1)) {
         const lmask dSW = LM(sw > 0), dSE = LM(se > 0);
         STATES(4, from_left(Nhs1), from_left(Pv), LM(p_vL > -p_hsL), dSW)
@@ -440,10 +484,7 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
         const lmask north = LM(c.Mn >= Ms);                   // facets 0-3 come first: they keep a tie
         flat = LM(M < 0);                                     // no facet descends: mag = -1 (:1983-1984)
         const lmask s4 = h4 & ~north, s5 = h5 & ~(north | h4), s6 = h6 & ~(north | h4 | h5), s7 = h7 & ~(north | h4 | h5 | h6);
-        w1 = pick(north, c.wn1, 1.0);
-        w1 = pick(s4 & in4, hsL1, w1); w1 = pick((s5 & in5) | (s6 & in6), v, w1); w1 = pick(s7 & in7, hs1, w1);
-        w2 = pick(north, c.wn2, 0.0);
-        w2 = pick(s4 & in4, vL, w2); w2 = pick(s5 & in5, hnL, w2); w2 = pick(s6 & in6, hn, w2); w2 = pick(s7 & in7, vR, w2);
+        wint = (north & c.Nint) | (s4 & in4) | (s5 & in5) | (s6 & in6) | (s7 & in7);
         tAn = north & c.NdA; tBn = north & c.NdB; tAs = (s4 & dg4) | (s7 & dg7); tBs = (s5 & dg5) | (s6 & dg6);
         k0 = (north & c.Nk0) | s5 | s7; k1 = (north & c.Nk1) | s6 | s7; k2 = s4 | s5 | s6 | s7;
     } else {
@@ -459,9 +500,8 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
         flat = LM(acc.rad2 == -1.0);
         const int k = acc.code >> 2, kind = acc.code & 3;
         const bool south = acc.code >= 0, sin = south && kind == 3, sdg = south && kind == 2;
-        w1 = sin ? (k == 4 ? s1_4 : (k == 7 ? s1_7 : s1_5)) : (south ? 1.0 : c.wn1);
-        w2 = sin ? (k == 4 ? s2_4 : (k == 5 ? s2_5 : (k == 6 ? s2_6 : s2_7))) : (south ? 0.0 : c.wn2);
         const lmask sm = LM(south);
+        wint = LM(sin) | (~sm & c.Nint);
         tAn = ~sm & c.NdA; tBn = ~sm & c.NdB; tAs = LM(sdg && (k == 4 || k == 7)); tBs = LM(sdg && (k == 5 || k == 6));
         k0 = (~sm & c.Nk0) | LM(south && (k & 1)); k1 = (~sm & c.Nk1) | LM(south && (k & 2)); k2 = sm;
     }
@@ -469,9 +509,12 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
         // direction of the winner: r * ang[1] + ang[0] * pi / 2 (:1989).  r = atan2(s2, s1) for an interior winner (both
         // slopes positive there, so the un-negated quotients serve: |x|); every other lane runs the arctangent on (0, 1),
         // which is exactly 0 -- the r of a cardinal winner -- and a diagonal winner takes its table angle
+        const int k = (ON(k0) ? 1 : 0) | (ON(k1) ? 2 : 0) | (ON(k2) ? 4 : 0);
+        const uint16_t *te = cx.tab + (P * 9 + (ON(wint) ? k : 8)) * 2;
+        const char *lb = reinterpret_cast<const char *>(&cx.q->a[0][0][lane]);
+        const double w1 = *reinterpret_cast<const double *>(lb + te[0]), w2 = *reinterpret_cast<const double *>(lb + te[1]);
         double r = atan2_pos_fast(fabs(w2), fabs(w1), cx.atan_16);
         r = pick(tAn, c.thAn, r); r = pick(tBn, c.thBn, r); r = pick(tAs, thAs, r); r = pick(tBs, thBs, r);
-        const int k = (ON(k0) ? 1 : 0) | (ON(k1) ? 2 : 0) | (ON(k2) ? 4 : 0);
         const double rs = __hiloint2double(__double2hiint(r) ^ (int)((unsigned)k << 31), __double2loint(r));   // ang[1] = -1 for odd facets
         const double direction = rs + (double)((k + 1) >> 1) * (PI_D / 2);
         const size_t cc = (size_t)b * m + cx.j;
@@ -501,9 +544,7 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
         const lmask h3 = LM(kn3 == Mq) | LM(kc3 == Mq) | (dg3 & eNW);
         const lmask f0 = h0, f1 = h1 & ~h0, f2 = h2 & ~(h0 | h1), f3 = h3 & ~(h0 | h1 | h2);
         c.Mn = Mq;
-        double t1 = pick(f0 & in0, hn, 1.0); t1 = pick((f1 & in1) | (f2 & in2), v, t1); t1 = pick(f3 & in3, hnL, t1);
-        double t2 = pick(f0 & in0, vR, 0.0); t2 = pick(f1 & in1, hs1, t2); t2 = pick(f2 & in2, hsL1, t2); t2 = pick(f3 & in3, vL, t2);
-        c.wn1 = t1; c.wn2 = t2;
+        c.Nint = (f0 & in0) | (f1 & in1) | (f2 & in2) | (f3 & in3);
         c.Nk0 = f1 | f3; c.Nk1 = f2 | f3; c.NdA = (f0 & dg0) | (f3 & dg3); c.NdB = (f1 & dg1) | (f2 & dg2);
     } else {
         const double s1_0 = hn, s2_0 = -vR, s1_1 = -v, s2_1 = hs1, s2_2 = -hsL1, s1_3 = -hnL, s2_3 = -vL;
@@ -515,8 +556,7 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
         const int k = an.code >> 2, kind = an.code & 3;       // k = -1, kind = 0: no north facet descends
         const bool nin = kind == 3, ndg = kind == 2;
         c.Mn = an.rad2;
-        c.wn1 = nin ? (k == 0 ? s1_0 : (k == 3 ? s1_3 : s1_1)) : 1.0;
-        c.wn2 = nin ? (k == 0 ? s2_0 : (k == 1 ? s2_1 : (k == 2 ? s2_2 : s2_3))) : 0.0;
+        c.Nint = LM(nin);
         c.Nk0 = LM(k >= 0 && (k & 1)); c.Nk1 = LM(k >= 0 && (k & 2));
         c.NdA = LM(ndg && (k == 0 || k == 3)); c.NdB = LM(ndg && (k == 1 || k == 2));
     }
@@ -524,8 +564,10 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
     // ---- the E-edge of row b+1 over its own south spacing opens the next band
     const double hs = (b + 1 <= n - 2) ? div_row(dE, tnx.dX, tnx.rdX) : 0.0;
     c.z0 = zS; c.ex_top = cx.exact_only || ex_bot;
+    cx.q->a[1 - P][1][1 + lane] = hs;
     c.hs1 = hs; c.hsL1 = lane_prev(hs); c.Phs1 = LM(hs > 0); c.Nhs1 = LM(hs < 0);
     c.thAn = thAs; c.thBn = thBs;
+    row_arrived<FIRST ? 0 : 3>(z_ahead);
 }
 
 // OCC = workgroups the compiler must fit on a CU: 1 = free choice (135 VGPRs: three wavefronts per SIMD), 4 = at most 128
@@ -540,40 +582,71 @@ __global__ __launch_bounds__(256, OCC) void k_stencil_march(const double *__rest
     // the arctangent table sits in LDS: a global (vmcnt) load in the loop body would make every row wait for the
     // stores of the row before it as well
     __shared__ double s_atan[17];
+    __shared__ WaveQ s_q[4];
+    __shared__ uint16_t s_tab[2 * 9 * 2];
+    __shared__ double s_rt[(MARCH_ROWS + 2) * 8];
     if (threadIdx.x < 17) s_atan[threadIdx.x] = ATAN_16[threadIdx.x];
+    if (threadIdx.x < 36) {
+        // facet k: (array, lane offset) of s1 and s2 -- 0: hn(0) v(+1)  1: v(0) hs1(0)  2: v(0) hs1(-1)  3: hn(-1) v(-1)
+        //                                               4: hs1(-1) v(-1)  5: v(0) hn(-1)  6: v(0) hn(0)  7: hs1(0) v(+1)
+        // facets 0-3 were decided in the band before the running one (the other parity), 4-7 in the running band
+        const int par = threadIdx.x / 18, k = (threadIdx.x % 18) / 2, which = threadIdx.x & 1;
+        const int arr1[8] = {0, 2, 2, 0, 1, 2, 2, 1}, dl1[8] = {0, 0, 0, -1, -1, 0, 0, 0};
+        const int arr2[8] = {2, 1, 1, 2, 2, 0, 0, 2}, dl2[8] = {1, 0, -1, -1, -1, -1, 0, 1};
+        int off;
+        if (k == 8) off = (6 * QS + (which ? QS : 0) + 1) * 8;
+        else {
+            const int band = k < 4 ? 1 - par : par;
+            off = ((band * 3 + (which ? arr2[k] : arr1[k])) * QS + 1 + (which ? dl2[k] : dl1[k])) * 8;
+        }
+        s_tab[threadIdx.x] = (uint16_t)off;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wavefront id (scalar: row tables via s_load)
-    if (wid >= strips * chunks) return;
-    const int chunk = wid / strips, strip = wid - chunk * strips;  // consecutive waves walk along a row band
-    const int j = strip * 62 + lane;                                // this lane's column (lane 0 / 63 = halo)
+    // the four wavefronts of a workgroup march four neighbouring strips of ONE chunk of rows (strips4 = the strips padded to
+    // a multiple of four), so that they share the chunk's row table
+    const int strips4 = (strips + 3) & ~3;
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // wavefront id (scalar)
+    const int chunk = wid / strips4, strip = wid - chunk * strips4;  // consecutive waves walk along a row band
     const int i0 = 1 + chunk * rows_per_wave;                       // first output row
     const int i1 = (i0 + rows_per_wave < n - 1) ? i0 + rows_per_wave : n - 1;   // one past the last output row
-    int vzero;                                                      // a zero the compiler cannot see through: the per-row angles
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));                  // are fetched by a (broadcast) vector load straight into VGPRs
+    {
+        const int r_last = i1 < n - 2 ? i1 : n - 2;                 // table rows i0-1 .. r_last
+        const double2 *src = reinterpret_cast<const double2 *>(rowtab + (i0 - 1));
+        double2 *dst = reinterpret_cast<double2 *>(s_rt);
+        const int n16 = (r_last - (i0 - 1) + 1) * 4;
+        if (chunk < chunks) for (int q = threadIdx.x; q < n16; q += 256) dst[q] = src[q];
+    }
+    __syncthreads();
+    if (chunk >= chunks || strip >= strips) return;
+    const int j = strip * 62 + lane;                                // this lane's column (lane 0 / 63 = halo)
     MarchCtx cx;
-    cx.col = elev + ((j < m) ? j : m - 1); cx.rowtab = rowtab; cx.rtv = reinterpret_cast<const double *>(rowtab) + vzero;
+    cx.col = elev + ((j < m) ? j : m - 1); cx.rowtab = rowtab; cx.rtv = s_rt; cx.r0 = i0 - 1;
     cx.atan_16 = s_atan; cx.mag = mag; cx.dir = dir; cx.flat0 = flat0;
+    cx.q = &s_q[threadIdx.x >> 6]; cx.tab = s_tab;
+    cx.q->one[1 + lane] = 1.0; cx.q->zero[1 + lane] = 0.0;
     cx.n = n; cx.m = m; cx.j = j; cx.i0 = i0; cx.exact_only = exact_only;
     cx.writes = lane >= 1 && lane <= 62 && j >= 1 && j < m - 1;
 
     // ---- the top row of the first band (row i0-1: not an output row of this wavefront, its north half is never used)
     BandCarry c;
-    RowV ts = rowv_load(cx.rtv, i0 - 1), tu;
+    RowV ts = rowv_load(cx.rtv, 0), tu;
     c.z0 = cx.col[(size_t)(i0 - 1) * m];
     c.ex_top = exact_only || LM(!(fabs(c.z0) < 0x1p500)) != 0;
     c.hs1 = div_row(zsub<F32>(c.z0, lane_next(c.z0)), ts.dX, ts.rdX);
     c.hsL1 = lane_prev(c.hs1);
     c.Phs1 = LM(c.hs1 > 0); c.Nhs1 = LM(c.hs1 < 0);
-    c.Mn = -1.0; c.wn1 = 1.0; c.wn2 = 0.0; c.thAn = 0.0; c.thBn = 0.0;
-    c.Nk0 = 0; c.Nk1 = 0; c.NdA = 0; c.NdB = 0;
+    cx.q->a[0][1][1 + lane] = c.hs1;
+    c.Mn = -1.0; c.thAn = 0.0; c.thBn = 0.0;
+    c.Nk0 = 0; c.Nk1 = 0; c.NdA = 0; c.NdB = 0; c.Nint = 0;
     double zP = cx.col[(size_t)i0 * m], zQ = 0.0;                  // the bottom row of a band alternates between zP and zQ
     int b = i0 - 1;
-    for (; b + 1 < i1; b += 2) {
-        march_band<F32>(cx, c, ts, tu, b, zP, zQ);
-        march_band<F32>(cx, c, tu, ts, b + 1, zQ, zP);
+    march_band<F32, 0, true>(cx, c, ts, tu, b, zP, zQ);             // (row i0 - 1 is not an output row: no stores)
+    for (b++; b + 1 < i1; b += 2) {
+        march_band<F32, 1>(cx, c, tu, ts, b, zQ, zP);
+        march_band<F32, 0>(cx, c, ts, tu, b + 1, zP, zQ);
     }
-    if (b < i1) march_band<F32>(cx, c, ts, tu, b, zP, zQ);
+    if (b < i1) march_band<F32, 1>(cx, c, tu, ts, b, zQ, zP);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -704,7 +777,7 @@ static void launch_stencil(pydem_tile *t)
     int rows = MARCH_ROWS;            // every chunk re-reads two halo rows: long chunks on big tiles, enough wavefronts on small ones
     while (rows > 16 && (int64_t)strips * cdiv(t->n - 2, rows) < 12288) rows >>= 1;
     const int chunks = (int)cdiv(t->n - 2, rows);
-    const int waves = strips * chunks;
+    const int waves = ((strips + 3) & ~3) * chunks;
     const int exact_only = t->stencil_exact_only;   // set with the row tables: a spacing outside [2^-500, 2^500] (or PYDEM_STENCIL_EXACT=1)
     static int occ = -1;
     if (occ < 0) { const char *e = getenv("PYDEM_STENCIL_OCC"); occ = (e && atoi(e) == 4) ? 4 : 1; }
