@@ -259,6 +259,32 @@ def pmc_traffic(kernels, size, sources=()):
     return best
 
 
+def stencil_valu_insts(size):
+    """Vector instructions of ONE launch of the stencil kernel (SQ_INSTS_VALU summed over the chip) from the committed SQ pass
+    (profiles/r*_pmc_sq_stencil_16384.csv, tools/collect_profiles.sh), only from a profile stamped with the current stencil.hip
+    (<csv>.meta.json); None otherwise."""
+    import csv
+    import glob
+    if size != 16384:
+        return None
+    best = None
+    now = csrc_hashes()
+    for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_sq_stencil_16384.csv'))):
+        meta = fn[:-4] + '.meta.json'
+        if not os.path.exists(meta):
+            continue
+        then = json.load(open(meta)).get('csrc_sha256', {})
+        if any(then.get(f) != now.get(f) for f in ('stencil.hip', 'internal.h')):
+            continue
+        for row in csv.DictReader(open(fn)):
+            if 'k_stencil_march' in row['kernel'] and row['counter'] == 'SQ_INSTS_VALU' and int(row['dispatches']) > 1:
+                best = float(row['mean_per_dispatch_KB'])           # (the column holds plain counts for SQ counters)
+    return best
+
+
+N_SIMD, VALU_CYCLES_PER_INST, PEAK_CLOCK_HZ = 256 * 4, 4.0, 2.4e9      # MI355X: 256 CUs x 4 SIMD16s, a wave64 instruction = 4 cycles
+
+
 # stages of the step for `roofline_stages`: (name, kernels of the stage, algorithmic bytes per cell, timing key, what the bytes are,
 # source files of the kernels: `traffic` is only quoted from a PMC profile of these very sources)
 STAGES = [
@@ -395,6 +421,7 @@ def main():
                            "algorithmic_bytes": bpc * cells, "algorithmic_bytes_per_cell": bpc, "bytes_are": what,
                            "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(kernels, n, srcs)})
         dom = max(stages, key=lambda d: d["ms"])
+        valu = stencil_valu_insts(n)
         out = {
             "metric": "Mcells/s (slope+aspect+UCA+TWI end-to-end) per tile; % HBM roofline",
             "value": value, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -419,7 +446,11 @@ def main():
                                  "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_stencil_march", n, ('stencil.hip',)),
                                  "algorithmic_bytes": STENCIL_BYTES_PER_CELL * cells,
                                  "avg_kernel_ms": st_ms, "back_to_back_ms": st_b2b,
-                                 "algorithmic_bytes_per_cell": STENCIL_BYTES_PER_CELL},
+                                 "algorithmic_bytes_per_cell": STENCIL_BYTES_PER_CELL,
+                                 # the kernel is bound by its vector instructions (fp64, no packed forms): the same launch against the
+                                 # issue rate of the vector ALUs = instructions x 4 cycles / 1024 SIMDs / 2.4 GHz / measured time
+                                 "valu_insts": valu, "valu_roofline_frac": (valu * VALU_CYCLES_PER_INST / N_SIMD / PEAK_CLOCK_HZ / (st_ms * 1e-3)) if valu else None,
+                                 "valu_roofline_frac_back_to_back": (valu * VALU_CYCLES_PER_INST / N_SIMD / PEAK_CLOCK_HZ / (st_b2b * 1e-3)) if (valu and st_b2b) else None},
             "end_to_end_GBs": E2E_BYTES_PER_CELL * world * cells * args.steps / dt / 1e9,
             "stages_ms": dict({k: tm[k] for k in ('slopes_directions_ms', 'stencil_kernel_ms', 'flats_ms', 'graph_ms',
                                                    'pits_ms', 'sweep_ms', 'twi_ms')}, **phase),

@@ -312,10 +312,27 @@ __device__ __forceinline__ double div_pos(double a, double b)
     return __builtin_fma(rem, y, q);
 }
 
+// sqrt(x) for x in [2^-1000, 2^1000] (squared slopes: the window test keeps the slopes within 2^+-500): the compiler's
+// correctly rounded expansion (reciprocal square root seed, Goldschmidt step, two residual corrections) without the
+// exponent scaling and the zero / infinity special cases it wraps around it
+__device__ __forceinline__ double sqrt_window(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+
 __device__ __forceinline__ double atan2_pos_fast(double y, double x, const double *atan_16)
 {
     const bool swap = y > x;
-    const double num = swap ? x : y, den = swap ? y : x;
+    double num, den;                                       // (both positive, no NaN on this path: the plain minimum / maximum)
+    asm("v_min_f64 %0, %1, %2" : "=v"(num) : "v"(y), "v"(x));
+    asm("v_max_f64 %0, %1, %2" : "=v"(den) : "v"(y), "v"(x));
     const double kf = rint(num * __builtin_amdgcn_rcp(den) * 16.0);
     const double c = kf * 0.0625;
     const double u = div_pos(__builtin_fma(-c, den, num), __builtin_fma(c, num, den));
@@ -374,7 +391,7 @@ __device__ __forceinline__ RowV rowv_load(const double *rtv, int r)      // rtv:
 // through select chains instead (the north half's to the next band, then north against south) cost 32 v_cndmask per row
 // and four carried registers.
 constexpr int QS = 66;                         // lanes + one pad slot either side
-struct WaveQ { double a[2][3][QS]; double one[QS], zero[QS]; };      // a[band parity][0: hn, 1: hs1, 2: v]
+struct WaveQ { double a[2][3][QS]; double one[QS], zero[QS]; double dg[2][QS]; };      // a[band parity][0: hn, 1: hs1, 2: v]; dg: se, sw of the running band
 struct MarchCtx {
     WaveQ *q; const uint16_t *tab;             // tab[parity of the running band][k][0 / 1]: byte offsets of s1 / s2 from &q->a[0][0][lane]
     const double *col; const RowTab *rowtab; const double *rtv; const double *atan_16;
@@ -397,8 +414,21 @@ __device__ __forceinline__ double row_request(const double *p)
 template <int YOUNGER>
 __device__ __forceinline__ void row_arrived(double &v)
 {
+#ifdef PYDEM_STENCIL_NOSTORE
+    if (false) ;
+#else
     if (YOUNGER == 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(v) : : "memory");
+#endif
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory");
+}
+
+// between a lane's LDS store and its neighbours' loads of that slot: nothing for the hardware to do (the LDS operations of a
+// wavefront execute in order), but the compiler must not move a load of slot lane +- 1 above the store of slot lane
+__device__ __forceinline__ void lanes_published()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
 template <bool F32, int P, bool FIRST = false>
@@ -437,9 +467,12 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
     const double v = div_row(zsub<F32>(z0, zS), ts.dY, ts.rdY);
     const double se = div_row(zsub<F32>(z0, zES), ts.hyp, ts.rhyp);
     const double sw = div_row(zsub<F32>(z0, zWS), ts.hyp, ts.rhyp);
-    cx.q->a[P][0][1 + lane] = hn; cx.q->a[P][2][1 + lane] = v;
-    const double hnL = lane_prev(hn), vL = lane_prev(v), vR = lane_next(v);
-    const double seL = lane_prev(se), swR = lane_next(sw);
+    // the neighbours' copies of the quotients come back from the slots the lanes have just written (a ds_read_b64 each
+    // instead of two DPP moves: the kernel is bound by its vector instructions, the LDS port is idle)
+    cx.q->a[P][0][1 + lane] = hn; cx.q->a[P][2][1 + lane] = v; cx.q->dg[0][1 + lane] = se; cx.q->dg[1][1 + lane] = sw;
+    lanes_published();
+    const double hnL = cx.q->a[P][0][lane], vL = cx.q->a[P][2][lane], vR = cx.q->a[P][2][2 + lane];
+    const double seL = cx.q->dg[0][lane], swR = cx.q->dg[1][2 + lane];
     const double q_v = v * v, q_vL = vL * vL, q_vR = vR * vR, q_hn = hn * hn, q_hnL = hnL * hnL, q_hs1 = hs1 * hs1, q_hsL1 = hsL1 * hsL1;
     const double q_se = se * se, q_sw = sw * sw, q_seL = seL * seL, q_swR = swR * swR;
     const double n0 = q_hn + q_vR, n1 = q_v + q_hs1, n2 = q_v + q_hsL1, n3 = q_hnL + q_vL;     // s1^2 + s2^2 of the facets below
@@ -518,13 +551,20 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
         const double rs = __hiloint2double(__double2hiint(r) ^ (int)((unsigned)k << 31), __double2loint(r));   // ang[1] = -1 for odd facets
         const double direction = rs + (double)((k + 1) >> 1) * (PI_D / 2);
         const size_t cc = (size_t)b * m + cx.j;
+#ifdef PYDEM_STENCIL_NOSTORE            // timing experiment: the arithmetic without its stores
+        if (M == 1.2345e300) { cx.mag[cc] = direction; cx.dir[cc] = r; cx.flat0[cc] = ON(flat) ? 1 : 0; }
+        if (false) {
+#else
+        {
+#endif
 #ifdef PYDEM_STENCIL_CHEAP
         cx.mag[cc] = M > 0 ? M * __builtin_amdgcn_rsq(M) : M;
 #else
-        cx.mag[cc] = M > 0 ? sqrt(M) : M;                              // :1901
+        cx.mag[cc] = M > 0 ? sqrt_window(M) : M;                       // :1901
 #endif
         cx.dir[cc] = pick(flat, -1.0, direction);
         cx.flat0[cc] = ON(flat) ? 1 : 0;
+        }
     }
     // ================= north half of row b+1 =================
     if (__builtin_expect(!exact, 1)) {
@@ -565,7 +605,8 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
     const double hs = (b + 1 <= n - 2) ? div_row(dE, tnx.dX, tnx.rdX) : 0.0;
     c.z0 = zS; c.ex_top = cx.exact_only || ex_bot;
     cx.q->a[1 - P][1][1 + lane] = hs;
-    c.hs1 = hs; c.hsL1 = lane_prev(hs); c.Phs1 = LM(hs > 0); c.Nhs1 = LM(hs < 0);
+    lanes_published();
+    c.hs1 = hs; c.hsL1 = cx.q->a[1 - P][1][lane]; c.Phs1 = LM(hs > 0); c.Nhs1 = LM(hs < 0);
     c.thAn = thAs; c.thBn = thBs;
     row_arrived<FIRST ? 0 : 3>(z_ahead);
 }
