@@ -1400,6 +1400,18 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             for (int i = 0; i < nrec; i++) {
                 rounds.push_back(rec[4 * i]); border.push_back(rec[4 * i + 1]); reason[rec[4 * i + 2] & 3]++; tot_rounds += rec[4 * i];
             }
+            {   // who spends the rounds: pits by round count, how many of each class end with drains / without / handed on
+                const int edges[7] = {16, 32, 64, 128, 200, 299, 1 << 30};
+                long long cr[7] = {0}, cn[7] = {0}, cd[7] = {0}, cu[7] = {0}, co[7] = {0};
+                for (int i = 0; i < nrec; i++) {
+                    int b = 0; while (rec[4 * i] > edges[b]) b++;
+                    cr[b] += rec[4 * i]; cn[b]++;
+                    if (rec[4 * i + 2] & 3) co[b]++; else if (rec[4 * i + 3] >= 0) cd[b]++; else cu[b]++;
+                }
+                for (int b = 0; b < 7; b++)
+                    fprintf(stderr, "pits/wave: rounds <= %d: %lld pits, %lld rounds (%.1f %%); %lld drain, %lld end without a drain, %lld handed on\n",
+                            edges[b] == (1 << 30) ? 300 : edges[b], cn[b], cr[b], 100.0 * cr[b] / (tot_rounds ? tot_rounds : 1), cd[b], cu[b], co[b]);
+            }
             std::sort(rounds.begin(), rounds.end()); std::sort(border.begin(), border.end());
             auto pct = [&](std::vector<int> &v, double q) { return v.empty() ? 0 : v[(size_t)(q * (v.size() - 1))]; };
             fprintf(stderr, "pits/wave: %d pits, %lld rounds; rounds p50 %d p90 %d p99 %d max %d; last border p50 %d p90 %d p99 %d max %d; "
