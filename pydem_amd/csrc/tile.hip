@@ -21,15 +21,17 @@ void pydem_set_error(const char *fmt, ...)
 // mapping them anew costs the drop-in call more than its kernels (measured: ~240 ms of hipMalloc inside a 54-ms calc_twi).
 // Blocks of 1 MiB and more that tile_alloc handed out go on a per-device free list when their tile is destroyed and are
 // handed out again on an exact size match (the contents are whatever the last owner left: no stage relies on fresh
-// memory).  PYDEM_PLANE_CACHE_GB bounds what is kept per device (default 64, 0 = off); pydem_hip_release_scratch and a
+// memory).  PYDEM_PLANE_CACHE_GB bounds what is kept per device (default 32, 0 = off; the least recently returned blocks are evicted first); pydem_hip_release_scratch and a
 // failing hipMalloc empty the lists.
 #include <map>
 #include <mutex>
 #include <unordered_map>
 namespace {
+struct FreeBlock { void *p; uint64_t stamp; };      // stamp: when the block was given back (the oldest is evicted first)
 struct PlaneCache {
     std::mutex mu;
-    std::multimap<size_t, void *> free_blocks;
+    std::multimap<size_t, FreeBlock> free_blocks;
+    uint64_t clock = 0;
     std::unordered_map<void *, size_t> live;          // blocks handed out by tile_alloc (size known at destroy time)
     size_t kept = 0;
 };
@@ -44,15 +46,33 @@ PlaneCache *plane_cache(int device)
 }
 size_t plane_cache_limit()
 {
-    static const size_t lim = [] { const char *e = getenv("PYDEM_PLANE_CACHE_GB"); return (size_t)(e ? atof(e) : 64.0) << 30; }();
+    // default 32 GiB: the planes of one 16384^2 tile (24.7 GB) -- what the drop-in pattern "a fresh DEMProcessor per file" reuses;
+    // fractions of a GB are honoured, a negative value means 0 (off)
+    static const size_t lim = [] {
+        const char *e = getenv("PYDEM_PLANE_CACHE_GB");
+        const double gb = e ? atof(e) : 32.0;
+        return (size_t)((gb > 0.0 ? gb : 0.0) * (double)((size_t)1 << 30));
+    }();
     return lim;
+}
+// (c->mu held) free the least recently returned blocks until `room` more bytes fit under the limit
+void plane_cache_evict(PlaneCache *c, size_t room)
+{
+    const size_t lim = plane_cache_limit();
+    while (!c->free_blocks.empty() && c->kept + room > lim) {
+        auto old = c->free_blocks.begin();
+        for (auto it = c->free_blocks.begin(); it != c->free_blocks.end(); ++it) if (it->second.stamp < old->second.stamp) old = it;
+        (void)hipFree(old->second.p);
+        c->kept -= old->first;
+        c->free_blocks.erase(old);
+    }
 }
 constexpr size_t PLANE_MIN = (size_t)1 << 20;
 void plane_cache_flush(int device)
 {
     PlaneCache *c = plane_cache(device);
     std::lock_guard<std::mutex> g(c->mu);
-    for (auto &kv : c->free_blocks) (void)hipFree(kv.second);
+    for (auto &kv : c->free_blocks) (void)hipFree(kv.second.p);
     c->free_blocks.clear(); c->kept = 0;
 }
 }  // namespace
@@ -64,11 +84,14 @@ void *plane_take(int device, size_t bytes)
         std::lock_guard<std::mutex> g(c->mu);
         auto it = c->free_blocks.find(bytes);
         if (it != c->free_blocks.end()) {
-            void *q = it->second;
+            void *q = it->second.p;
             c->free_blocks.erase(it); c->kept -= bytes;
             c->live[q] = bytes;
             return q;
         }
+        // a size the lists do not hold (a tile of another shape): the blocks that have waited longest make room, so that
+        // dead sizes do not pile up beside the live ones
+        plane_cache_evict(c, bytes);
     }
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, bytes);
@@ -96,7 +119,11 @@ void plane_give(int device, void *q)
         if (it != c->live.end()) {
             const size_t bytes = it->second;
             c->live.erase(it);
-            if (c->kept + bytes <= plane_cache_limit()) { c->free_blocks.emplace(bytes, q); c->kept += bytes; return; }
+            if (bytes <= plane_cache_limit()) {
+                plane_cache_evict(c, bytes);
+                c->free_blocks.emplace(bytes, FreeBlock{q, ++c->clock}); c->kept += bytes;
+                return;
+            }
         }
     }
     (void)hipFree(q);
@@ -493,6 +520,9 @@ int pydem_tile_destroy(pydem_tile *t)
     if (!t) return 0;
     (void)hipSetDevice(t->device);
     (void)hipStreamSynchronize(t->stream);
+    // (a stage that returned early between the fork and the join of the side stream may have left kernels there that still
+    // write edge_todo / todo_work / prop: the planes go to the free lists -- i.e. to the next tile -- only once both streams are idle)
+    if (t->stream2) (void)hipStreamSynchronize(t->stream2);
     void *ptrs[] = {t->elev, t->mag, t->dir, t->prop, t->uca, t->twi, t->flats, t->edge_todo, t->edge_done,
                     t->flat0, t->section, t->dX, t->dY, t->dX2, t->dY2, t->rowtab, t->sec_theta, t->row_area, t->inmask,
                     t->gflags, t->todo_work, t->indeg, t->queue[0], t->queue[1], t->labels, t->flatlist,

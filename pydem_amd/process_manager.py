@@ -1091,7 +1091,10 @@ class ProcessManager(object):
             # cells, csrc/uca_cond.inl: ~25 ms of C++ per 16384^2 tile, the GIL is released): tiles of one process build side by side
             fresh = [a for a in mine if a not in built]
             built.update(mine)
-            kk = max(k, min(len(fresh), 8)) if len(fresh) > 1 else k
+            # (only when the user has not bounded the concurrency -- `tiles_in_flight` -- and the processor is ours: a custom
+            # processor class or transport need not be thread-safe, and every build allocates pinned staging)
+            widen = self.tiles_in_flight is None and self.processor_cls is DEMProcessor
+            kk = max(k, min(len(fresh), 8)) if (widen and len(fresh) > 1) else k
             if kk > 1 and len(mine) > 1:
                 from concurrent.futures import ThreadPoolExecutor
                 with ThreadPoolExecutor(max_workers=kk) as ex:
@@ -1119,9 +1122,10 @@ class ProcessManager(object):
         if prof is not None:
             import sys
             sys.stderr.write("edge fix-up wave loop (host ms): %s over %d waves\n" % (', '.join('%s %.1f' % (k2, v * 1e3) for k2, v in prof.items()), self.edge_waves))
-        if len(owned) > 1:                 # the interiors catch up: one latency-bound cascade per tile, side by side on their streams
+        kf = min(len(owned), 8) if (self.tiles_in_flight is None and self.processor_cls is DEMProcessor) else min(len(owned), self._in_flight())
+        if kf > 1:                         # the interiors catch up: one latency-bound cascade per tile, side by side on their streams
             from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=min(len(owned), 8)) as ex:
+            with ThreadPoolExecutor(max_workers=kf) as ex:
                 list(ex.map(lambda a: self.tiles[a].flush_edge_rounds(), owned))
         else:
             for a in owned:

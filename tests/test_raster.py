@@ -494,3 +494,38 @@ def test_lzw_encoder_emits_libtiffs_stream(dtype, tmp_path):
     fn2 = str(tmp_path / 'tiled.tif')
     raster.write_geotiff(fn2, a, (1.0, 0.0, 0.0, 0.0, -1.0, float(n)), compress='lzw', tile=32, bigtiff=True)
     assert np.array_equal(raster.read_geotiff(fn2).array, a)
+
+
+@pytest.mark.parametrize('kind', ['zeros_then_binary', 'zeros_then_4sym', 'periodic_then_binary', 'constant_then_noise'])
+def test_lzw_encoder_follows_libtiffs_ratio_checkpoints(kind, tmp_path):
+    """libtiff's encoder watches its compression ratio every 10000 input bytes and emits a ClearCode when it stopped
+    improving (tif_lzw.c: CHECK_GAP / CALCRATIO) -- e.g. a no-data area followed by low-entropy terrain inside one block (with
+    byte noise the table fills up and restarts the count before a checkpoint is reached).  The first three payloads make
+    libtiff reset on the ratio (an encoder without the checkpoints emits a different stream for them); the native encoder's
+    stream is libtiff's, byte for byte."""
+    PIL = pytest.importorskip('PIL')
+    from PIL import Image, features
+    if not features.check('libtiff'):
+        pytest.skip("Pillow without libtiff")
+    rng = np.random.default_rng(3)
+    m = 512
+    if kind == 'zeros_then_binary':
+        v = np.concatenate([np.zeros(60 * m, np.uint8), rng.integers(0, 2, 300 * m, dtype=np.uint8)])
+    elif kind == 'zeros_then_4sym':
+        v = np.concatenate([np.zeros(60 * m, np.uint8), rng.integers(0, 4, 300 * m, dtype=np.uint8)])
+    elif kind == 'periodic_then_binary':
+        v = np.concatenate([np.tile(np.arange(16, dtype=np.uint8), 60 * 32), rng.integers(0, 2, 200 * m, dtype=np.uint8)])
+    else:
+        v = np.concatenate([np.zeros(85 * m, np.uint8), rng.integers(0, 256, 171 * m, dtype=np.uint8)])
+    v = v.reshape(-1, m)
+    n = v.shape[0]
+    raw = v.tobytes()
+    ref_fn = str(tmp_path / 'ref.tif')
+    Image.fromarray(v).save(ref_fn, format='TIFF', compression='tiff_lzw', tiffinfo={278: n})
+    with Image.open(ref_fn) as im:
+        offs, cnts = im.tag_v2[273], im.tag_v2[279]
+        assert len(offs) == 1
+    ref_strip = open(ref_fn, 'rb').read()[offs[0]:offs[0] + cnts[0]]
+    mine = raster._lzw_encode(raw)
+    assert mine == ref_strip, "LZW stream differs from libtiff's (%d vs %d bytes)" % (len(mine), len(ref_strip))
+    assert raster._lzw_decode(mine, len(raw)) == raw
