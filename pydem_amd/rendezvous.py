@@ -16,6 +16,8 @@ Address: PYDEM_RDZV = "tcp://host:port" or "unix:<name>"; default on one node: a
 launcher's pid and MASTER_PORT (no port to collide on, gone when rank 0 exits); with MASTER_ADDR pointing at another
 host: tcp://MASTER_ADDR:(MASTER_PORT + 1).
 """
+import hashlib
+import hmac
 import os
 import pickle
 import socket
@@ -41,6 +43,16 @@ def _token():
     unpickles what a connected peer sends, so only peers that know the token may stay connected); the default only keeps
     unrelated jobs on one host apart."""
     return os.environ.get('PYDEM_RDZV_TOKEN') or 'job-%s' % os.environ.get('MASTER_PORT', '0')
+
+
+def _token_digest():
+    """What travels in the hello line instead of the token itself: a hex digest (any token -- blanks included -- becomes one
+    word of the line, and the secret is not written to the wire)."""
+    return hashlib.sha256(('pydem-rdzv:' + _token()).encode('utf-8', 'surrogateescape')).hexdigest()
+
+
+def _loopback(host):
+    return host in ('127.0.0.1', 'localhost', '::1')
 
 
 def _send(sock, payload):
@@ -75,6 +87,9 @@ class SocketGroup(object):
             return
         family, target = self._parse(self.address)
         if self.rank == 0:
+            if family == socket.AF_INET and not _loopback(target[0]) and not os.environ.get('PYDEM_RDZV_TOKEN'):
+                # rank 0 unpickles what a connected peer sends: beyond the loopback the guessable default token is no protection
+                raise RuntimeError("rendezvous: listening on %s needs a job secret: set PYDEM_RDZV_TOKEN in the launcher's environment" % self.address)
             ls = socket.socket(family, socket.SOCK_STREAM)
             if family == socket.AF_INET:
                 ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -93,8 +108,13 @@ class SocketGroup(object):
                 except (ConnectionError, socket.timeout):
                     r = None
                 if r is None or r in self.peers:
+                    try:
+                        _send(conn, b'pydem-rdzv no')         # (the peer waits for the verdict: it fails at once, with a reason)
+                    except OSError:
+                        pass
                     conn.close()
                     continue
+                _send(conn, b'pydem-rdzv ok')
                 self.peers[r] = conn
             for conn in self.peers.values():
                 conn.settimeout(None)          # the connect timeout must not outlive the rendezvous: a rank may lag minutes in a collective
@@ -110,21 +130,31 @@ class SocketGroup(object):
                     if time.time() > t_end:
                         raise TimeoutError("rendezvous: rank 0 is not listening on %s" % self.address)
                     time.sleep(0.05)
-            s.settimeout(None)
             if family == socket.AF_INET:
                 s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            _send(s, ('pydem-rdzv %s %d' % (_token(), self.rank)).encode())
+            s.settimeout(timeout)
+            _send(s, ('pydem-rdzv %d %s' % (self.rank, _token_digest())).encode())
+            try:
+                verdict = _recv(s, limit=64)
+            except (ConnectionError, socket.timeout) as exc:
+                s.close()
+                raise ConnectionError("rendezvous: no answer from rank 0 on %s (%s)" % (self.address, exc))
+            if verdict != b'pydem-rdzv ok':
+                s.close()
+                raise ConnectionError("rendezvous: rank 0 on %s refused rank %d (PYDEM_RDZV_TOKEN / MASTER_PORT differ between the "
+                                      "ranks, the rank is out of range or already connected)" % (self.address, self.rank))
+            s.settimeout(None)             # the connect timeout must not outlive the rendezvous
             self.sock = s
 
     def _check_hello(self, blob):
-        """Rank of a peer that presents the job's token (PYDEM_RDZV_TOKEN, default: derived from the address) and a rank in
-        1..world-1; None for anything else."""
+        """Rank of a peer that presents the digest of the job's token (PYDEM_RDZV_TOKEN, default: derived from MASTER_PORT) and
+        a rank in 1..world-1; None for anything else.  The line is "pydem-rdzv <rank> <hex digest>"."""
         try:
-            word, token, rank = blob.decode('ascii').split(' ')
+            word, rank, digest = blob.decode('ascii').split(' ', 2)
             rank = int(rank)
         except (UnicodeDecodeError, ValueError):
             return None
-        if word != 'pydem-rdzv' or token != _token() or not (1 <= rank < self.world):
+        if word != 'pydem-rdzv' or not hmac.compare_digest(digest, _token_digest()) or not (1 <= rank < self.world):
             return None
         return rank
 

@@ -50,3 +50,37 @@ def test_single_rank_group_is_a_no_op():
     g = SocketGroup(0, 1)
     assert g.all_gather_object(7) == [7] and g.broadcast_object('x') == 'x' and g.allreduce_max(3) == 3.0
     g.barrier(); g.close()
+
+
+def test_token_with_blanks_and_a_wrong_token():
+    """The hello carries a digest of the token, so a token with blanks works; a peer with another token is told so at once
+    (it used to be dropped silently and failed later with a closed connection, rank 0 with an accept timeout)."""
+    from pydem_amd.rendezvous import spawn_ranks
+    port = 29000 + os.getpid() % 800
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', PYDEM_RDZV_TOKEN='a secret with blanks')
+    rc, out = spawn_ranks([sys.executable, '-c', CHILD % {'root': ROOT}], 3, env=env, master_port=port, capture=True, timeout=120)
+    assert rc == 0 and out.count(' fine') == 3, out[-2000:]
+    wrong = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+from pydem_amd.rendezvous import SocketGroup
+rank = int(os.environ['RANK'])
+if rank == 1:
+    os.environ['PYDEM_RDZV_TOKEN'] = 'another job'
+try:
+    SocketGroup(rank, 2, timeout=5.0)
+    print('rank %%d is connected' %% rank)
+except Exception as exc:
+    print('rank %%d: %%s: %%s' %% (rank, type(exc).__name__, exc))
+'''
+    rc, out = spawn_ranks([sys.executable, '-c', wrong % {'root': ROOT}], 2, env=env, master_port=port + 1, capture=True, timeout=60)
+    assert 'rank 1: ConnectionError' in out and 'refused rank 1' in out, out[-2000:]
+    assert 'is connected' not in out, out[-2000:]
+
+
+def test_non_loopback_listener_needs_a_token(monkeypatch):
+    import pytest
+    from pydem_amd.rendezvous import SocketGroup
+    monkeypatch.delenv('PYDEM_RDZV_TOKEN', raising=False)
+    with pytest.raises(RuntimeError, match='PYDEM_RDZV_TOKEN'):
+        SocketGroup(0, 2, address='tcp://0.0.0.0:29990', timeout=1.0)
