@@ -1230,8 +1230,10 @@ __global__ __launch_bounds__(256) void k_compact_mask(const uint8_t *__restrict_
 // atomic per 1024 raw slots.
 __global__ __launch_bounds__(256) void k_pit_keys(const int32_t *__restrict__ src, const int32_t *__restrict__ dst, const double *__restrict__ w,
                                                   const double *__restrict__ elev, int32_t ne, uint64_t *key_out, uint64_t *key_in, int32_t *idx,
-                                                  int32_t *count)
+                                                  int32_t *count, int kb)
 {
+    // keys of 2 * kb bits (kb = bits of a cell id): the radix sorts run over 2 * kb bits instead of 64 (seven 8-bit passes
+    // instead of eight at 16384^2)
     constexpr int PER = 4;
     __shared__ int32_t wave_tot[4];
     __shared__ int32_t blk_base;
@@ -1269,8 +1271,8 @@ __global__ __launch_bounds__(256) void k_pit_keys(const int32_t *__restrict__ sr
 #pragma unroll
         for (int j = 0; j < PER; j++)
             if (keep & (1u << j)) {
-                key_out[o] = ((uint64_t)(uint32_t)sv[j] << 32) | (uint32_t)dv[j];
-                key_in[o] = ((uint64_t)(uint32_t)dv[j] << 32) | (uint32_t)sv[j];
+                key_out[o] = ((uint64_t)(uint32_t)sv[j] << kb) | (uint32_t)dv[j];
+                key_in[o] = ((uint64_t)(uint32_t)dv[j] << kb) | (uint32_t)sv[j];
                 idx[o] = (int32_t)(base + j * 256 + threadIdx.x);
                 o++;
             }
@@ -1279,7 +1281,7 @@ __global__ __launch_bounds__(256) void k_pit_keys(const int32_t *__restrict__ sr
 }
 
 __global__ void k_pit_gather(const uint64_t *__restrict__ keys, const int32_t *__restrict__ idx, const double *__restrict__ w,
-                             int32_t ne, int swap, int32_t *a, int32_t *b, double *wo, int32_t *dup)
+                             int32_t ne, int swap, int32_t *a, int32_t *b, double *wo, int32_t *dup, int kb)
 {
     for (int32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += gridDim.x * blockDim.x) {
         const uint64_t k = keys[e];
@@ -1287,7 +1289,7 @@ __global__ void k_pit_gather(const uint64_t *__restrict__ keys, const int32_t *_
         // the (scheduling-dependent) order of the compacted entries; counted so that a violation is an error, not a silent
         // change of the summation order
         if (dup && e > 0 && keys[e - 1] == k) atomicAdd(dup, 1);
-        const int32_t hi = (int32_t)(k >> 32), lo = (int32_t)(k & 0xffffffffu);
+        const int32_t hi = (int32_t)(k >> kb), lo = (int32_t)(k & ((1ull << kb) - 1ull));
         a[e] = swap ? lo : hi;      // a = src, b = dst in both views
         b[e] = swap ? hi : lo;
         wo[e] = w[idx[e]];
@@ -1480,22 +1482,24 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         uint64_t *k1 = (uint64_t *)sb, *k2 = (uint64_t *)(sb + ne8), *k1s = (uint64_t *)(sb + 2 * ne8), *k2s = (uint64_t *)(sb + 3 * ne8);
         int32_t *idx = (int32_t *)(sb + 4 * ne8), *i1 = (int32_t *)(sb + 4 * ne8 + ne4), *i2 = (int32_t *)(sb + 4 * ne8 + 2 * ne4);
         void *tmp = sb + 4 * ne8 + 3 * ne4;
+        int kb = 1;
+        while (((int64_t)1 << kb) < t->NN) kb++;          // bits of a cell id
         HIP_TRY(hipMemsetAsync(cnt + 10, 0, sizeof(int32_t), t->stream));
         hipLaunchKernelGGL(k_pit_keys, dim3((unsigned)(cdiv(ne, 1024) < 8192 ? cdiv(ne, 1024) : 8192)), dim3(256), 0, t->stream, t->pits.raw_src,
-                           t->pits.raw_dst, t->pits.raw_w, t->elev, ne, k1, k2, idx, cnt + 10);
+                           t->pits.raw_dst, t->pits.raw_w, t->elev, ne, k1, k2, idx, cnt + 10, kb);
         HIP_TRY(hipMemcpyAsync(t->h_counters, cnt + 10, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
         const int32_t nk = t->h_counters[0];        // kept edges
         if (nk > 0) {
             // (the temporary storage of both sorts is the tail of the persistent block, sized for ne >= nk entries)
             const int g = (int)(cdiv(nk, 256) < 1024 ? cdiv(nk, 256) : 1024);
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k1, k1s, idx, i1, nk, 0, 64, t->stream));
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k2, k2s, idx, i2, nk, 0, 64, t->stream));
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k1, k1s, idx, i1, nk, 0, 2 * kb, t->stream));
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k2, k2s, idx, i2, nk, 0, 2 * kb, t->stream));
             HIP_TRY(hipMemsetAsync(cnt + 11, 0, sizeof(int32_t), t->stream));
             hipLaunchKernelGGL(k_pit_gather, dim3(g), dim3(256), 0, t->stream, k1s, i1, t->pits.raw_w, nk, 0, t->pits.src, t->pits.dst,
-                               t->pits.w, cnt + 11);
+                               t->pits.w, cnt + 11, kb);
             hipLaunchKernelGGL(k_pit_gather, dim3(g), dim3(256), 0, t->stream, k2s, i2, t->pits.raw_w, nk, 1, t->pits.in_src,
-                               t->pits.in_dst, t->pits.in_w, (int32_t *)nullptr);
+                               t->pits.in_dst, t->pits.in_w, (int32_t *)nullptr, kb);
             HIP_TRY(hipMemcpyAsync(t->h_counters, cnt + 11, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
             if (t->h_counters[0] != 0) { pydem_set_error("pit search: %d duplicate pit -> drain edges", t->h_counters[0]); return -5; }

@@ -35,6 +35,7 @@ struct Best {
     double theta;  // table angle of the winning facet
     int k;         // winning facet
     int kind;      // 1: r = 0 (cardinal), 2: r = theta (diagonal), 3: r = atan2(s2, s1)
+    int tie;       // kind 3 with s2 * d1 == s1 * d2 exactly: atan2(s2, s1) IS theta (see STATES in march_band)
 };
 
 // One facet of _calc_direction (:1958-1989).  s1, s2, sd are the three slopes; d1, d2 the
@@ -49,17 +50,18 @@ __device__ __forceinline__ void facet(double s1, double s2, double sd, double d1
     const bool s1le = s1 <= 0, s2le = s2 <= 0, s1gt = s1 > 0, s2gt = s2 > 0;
     double rad2 = s1_2 + s2 * s2;
     int kind = 3;
-    bool rgt = false;
+    bool rgt = false, tie = false;
     if (s1gt && s2gt) {
         const double a = s2 * d1, c = s1 * d2;
         rgt = a > c;
-        if (fabs(a - c) <= 8.0 * DBL_EPSILON * fmax(a, c)) rgt = atan2(s2, s1) > theta;
+        tie = a == c;                                                   // slopes in the exact ratio of the spacings: r == theta, not greater
+        if (!tie && fabs(a - c) <= 8.0 * DBL_EPSILON * fmax(a, c)) rgt = atan2(s2, s1) > theta;
     }
     if ((s1le && s2gt) || rgt) { rad2 = sd * sd; kind = 2; }           // I1 :1973-1976
     if (s1gt && s2le) { rad2 = s1_2; kind = 1; }                       // I2 :1978-1981 (r < 0 implies s2 < 0)
     if (s1le && (s2le || (s2gt && sd <= 0))) rad2 = -1.0;              // I3 :1983-1984
     if (rad2 > b.rad2) {                                               // I4 :1986-1989
-        b.rad2 = rad2; b.s1 = s1; b.s2 = s2; b.theta = theta; b.k = k; b.kind = kind;
+        b.rad2 = rad2; b.s1 = s1; b.s2 = s2; b.theta = theta; b.k = k; b.kind = kind; b.tie = (kind == 3 && tie) ? 1 : 0;
     }
 }
 
@@ -94,8 +96,9 @@ __device__ __forceinline__ double atan2_pos(double y, double x)
 }
 
 // direction of the winner: r * ang[1] + ang[0] * pi / 2 (:1989); ang_adj table :184-193
-__device__ __forceinline__ double direction_of(int k, int kind, double s1, double s2, double theta)
+__device__ __forceinline__ double direction_of(int k, int kind, double s1, double s2, double theta, int tie = 0)
 {
+    if (tie) kind = 2;                             // (the arctangent of the winner equals the table angle exactly)
     if (k < 0) return -1.0;
     const int a0 = (k + 1) >> 1;                   // 0,1,1,2,2,3,3,4
     const double a1 = (k & 1) ? -1.0 : 1.0;        // 1,-1,1,-1,...
@@ -105,7 +108,7 @@ __device__ __forceinline__ double direction_of(int k, int kind, double s1, doubl
     return r * a1 + (double)a0 * PI_D / 2;
 }
 
-__device__ __forceinline__ double winner_direction(const Best &b) { return direction_of(b.k, b.kind, b.s1, b.s2, b.theta); }
+__device__ __forceinline__ double winner_direction(const Best &b) { return direction_of(b.k, b.kind, b.s1, b.s2, b.theta, b.tie); }
 
 // Lean facet for the marching kernel: only (rad2, code = 4*k + kind) is tracked; the winner's
 // slopes are re-selected once at the end.  Same decisions as facet() except that `r > theta` is the
@@ -175,7 +178,7 @@ __device__ __forceinline__ void eight_facets(double z0, double zN, double zS, do
 
 __device__ __forceinline__ Best best_init()
 {
-    Best b; b.rad2 = -1.0; b.s1 = 0; b.s2 = 0; b.theta = 0; b.k = -1; b.kind = 0;
+    Best b; b.rad2 = -1.0; b.s1 = 0; b.s2 = 0; b.theta = 0; b.k = -1; b.kind = 0; b.tie = 0;
     return b;
 }
 
@@ -547,6 +550,19 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
         const char *lb = reinterpret_cast<const char *>(&cx.q->a[0][0][lane]);
         const double w1 = *reinterpret_cast<const double *>(lb + te[0]), w2 = *reinterpret_cast<const double *>(lb + te[1]);
         double r = atan2_pos_fast(fabs(w2), fabs(w1), cx.atan_16);
+        // An interior winner whose cross products are EQUAL (s2 * d1 == s1 * d2: `r > theta` is false, the facet is not clamped,
+        // :1973) has r == theta exactly: the reference's arctangent of two slopes in the exact ratio of the spacings IS the table
+        // angle, the arctangent above may be an ulp off -- and an ulp across a section boundary is another section (soak case
+        // 900039: an int32 DEM with dX = 1, dY = 17).  The test is made on the winner alone (facets 0, 3, 4, 7: d1, d2 = dX, dY,
+        // the others dY, dX; spacings of the band the winner was decided in), the angle is the table angle of that facet.
+        {
+            const double2 dn = *reinterpret_cast<const double2 *>(cx.rtv + (b - 1 - cx.r0 > 0 ? b - 1 - cx.r0 : 0) * 8);     // dX, dY of the band above
+            const double dXw = pick(k2, ts.dX, dn.x), dYw = pick(k2, ts.dY, dn.y);
+            const double a1 = fabs(w1), a2 = fabs(w2);
+            const lmask famA = ~(k0 ^ k1);
+            const lmask tie = wint & ((famA & LM(a2 * dXw == a1 * dYw)) | (~famA & LM(a2 * dYw == a1 * dXw)));
+            tAn |= ~k2 & famA & tie; tBn |= ~k2 & ~famA & tie; tAs |= k2 & famA & tie; tBs |= k2 & ~famA & tie;
+        }
         r = pick(tAn, c.thAn, r); r = pick(tBn, c.thBn, r); r = pick(tAs, thAs, r); r = pick(tBs, thBs, r);
         const double rs = __hiloint2double(__double2hiint(r) ^ (int)((unsigned)k << 31), __double2loint(r));   // ang[1] = -1 for odd facets
         const double direction = rs + (double)((k + 1) >> 1) * (PI_D / 2);

@@ -3253,6 +3253,15 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
                 for (int r = 0; r < Y.nreg; r++) used += hs[r];
                 fprintf(stderr, "two-level solve: %d symbolic tiles (%d fell back to numeric visits), %d outlets, %d symbolic cells, pool %lld of %lld doubles\n",
                         hs[32], hs[33], hs[34], hs[35], (long long)used, (long long)Y.reg_cap * Y.nreg);
+#ifdef PYDEM_SYM_PROF
+                {
+                    const unsigned long long *acc = (const unsigned long long *)(hs + 40);
+                    const double v = acc[8] ? (double)acc[8] : 1.0;
+                    fprintf(stderr, "symbolic visits: %llu, %.1f open cells, %.1f rounds, %.1f pool entries each; us per visit: stage %.1f, inlets %.1f, set-up %.1f, constants %.1f, "
+                            "rounds %.1f (%.2f us per round), end %.1f\n", acc[8], acc[9] / v, acc[6] / v, acc[7] / v, acc[0] / v / 100, acc[1] / v / 100, acc[2] / v / 100,
+                            acc[3] / v / 100, acc[4] / v / 100, acc[6] ? acc[4] / 100.0 / (double)acc[6] : 0.0, acc[5] / v / 100);
+                }
+#endif
             }
         }
         HIP_TRY(hipMemcpyAsync(t->h_counters, t->counters, 64 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));

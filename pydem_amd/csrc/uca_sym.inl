@@ -144,9 +144,17 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
     const int half = lane >> 5, l32 = lane & 31;
     constexpr int NSET = TH * TT / 64;
     if (lane == 0) { S.tail = 0; S.nin = 0; S.fail = 0; }
+#ifdef PYDEM_SYM_PROF           // phase timers of the symbolic visit (10 ns ticks summed over the visits into Y.stat[8..]; a diagnostic build)
+    long long tk[8]; int nrounds = 0, nentries = 0;
+    tk[0] = wall_clock64();
+#define SYM_TICK(i) tk[i] = wall_clock64()
+#else
+#define SYM_TICK(i)
+#endif
     const double a0_row = (lane < TH && i0 + lane < n) ? A.a0[i0 + lane] : 0.0;
     tile_stage(A, tile_base(A, i0, j0), L, pass, i0, j0, lane, S.hw);
     tile_wave_sync();
+    SYM_TICK(1);
     // ---- inlets: open cells of the halo ring with an edge into the tile
     int nin = 0;
     for (int q0 = 0; q0 < NHALO; q0 += 64) {
@@ -176,6 +184,7 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
     if (lane == 0) S.nin = nin;
     tile_wave_sync();
     if (lane < nin) S.in_p[lane] = A.prop[S.in_id[lane]];
+    SYM_TICK(2);
     // ---- set-up: a slot per open cell, count = open upstream cells INSIDE the tile (an open inlet does not block)
     uint32_t pitmask = 0;
     int nslot = 0;
@@ -232,6 +241,7 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
     if (lane < TH) L.a0[lane] = a0_row;                  // (the final bitmap is dead now)
     tile_wave_sync();
     const int nin_all = S.nin < SYM_MAXIN ? S.nin : SYM_MAXIN;
+    SYM_TICK(3);
     // ---- the constant part of every open cell: all its loads in flight together
     for (int s = lane; s < nslot; s += 64) {
         const uint32_t smv = S.sm[s];
@@ -257,6 +267,7 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
         S.sm[s] = (smv & (SS_CELL | (0xFFu << SS_OPEN_SHIFT))) | (td ? SS_TAINT : 0u);
     }
     tile_wave_sync();
+    SYM_TICK(4);
     auto find_inlet = [&](int32_t sc) -> int {             // (a pit source outside the tile that was open at set-up)
         for (int j = 0; j < nin_all; j++) if (S.in_id[j] == sc) return j;
         return 0;
@@ -413,8 +424,12 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
         }
         head = tail < head + 64 ? tail : head + 64;
         tile_lds_sync();
+#ifdef PYDEM_SYM_PROF
+        nrounds++; nentries += (int)total;
+#endif
     }
     if (exhausted) return false;
+    SYM_TICK(5);
     // ---- the tile's block: inlets and outlets (a symbolic cell whose flow leaves the tile)
     int nout = 0, nsym = 0;
     for (int s0 = 0; s0 < nslot; s0 += 64) {
@@ -493,6 +508,15 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
     const unsigned long long bw = __ballot(win);
     if (win) pend[npend + __popcll(bw & ((1ull << lane) - 1ull))] = tt;
     npend += __popcll(bw);
+#ifdef PYDEM_SYM_PROF
+    if (lane == 0) {
+        SYM_TICK(6);
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(Y.stat + 8);
+        for (int q = 0; q < 6; q++) atomicAdd(acc + q, (unsigned long long)(tk[q + 1] - tk[q]));
+        atomicAdd(acc + 6, (unsigned long long)nrounds); atomicAdd(acc + 7, (unsigned long long)nentries);
+        atomicAdd(acc + 8, 1ull); atomicAdd(acc + 9, (unsigned long long)nslot);
+    }
+#endif
     if (lane == 0) {
         n_final += nfin;
         A.tile_open[tid] = nslot - nfin;

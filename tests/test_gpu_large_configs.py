@@ -168,3 +168,20 @@ def test_config4_mosaic_2048_against_oracle_checksums(tile):
         assert sha(np.asarray(pm.tile_result(i, 'edge_done'), np.uint8)) == w['edge_done_sha256'], (i, 'edge_done')
         check_float('tile %d uca_total' % i, pm.tile_result(i, 'uca_total'), w['uca_total'])
         check_float('tile %d twi' % i, pm.tile_result(i, 'twi'), w['twi'])
+    # cell by cell where an error of the fix-up (condensed rounds re-associate sums; strips travel between tiles) would live: the
+    # two outermost lines of every side of every tile against the oracle-backed flow (masks exactly, uca_total to 1e-9)
+    strips_fn = os.path.join(ROOT, 'tests', 'golden', 'config4_strips_8x%d.npz' % tile)
+    if os.path.exists(strips_fn):
+        S = np.load(strips_fn)
+        for i in range(8):
+            for name in ('uca_total', 'edge_todo', 'edge_done'):
+                a = np.asarray(pm.tile_result(i, name))
+                for side, line in (('r0', a[0]), ('r1', a[1]), ('rm2', a[-2]), ('rm1', a[-1]), ('c0', a[:, 0]), ('c1', a[:, 1]), ('cm2', a[:, -2]), ('cm1', a[:, -1])):
+                    want_line = S['t%d_%s_%s' % (i, name, side)]
+                    if name == 'uca_total':
+                        assert np.array_equal(np.isnan(line), np.isnan(want_line)), (i, name, side)
+                        assert np.allclose(line, want_line, rtol=1e-9, atol=0, equal_nan=True), (i, name, side, np.nanmax(np.abs(line - want_line) / np.abs(want_line)))
+                    else:
+                        assert np.array_equal(np.asarray(line, np.uint8), want_line), (i, name, side)
+    else:
+        assert tile != 2048, "tests/golden/config4_strips_8x2048.npz is missing (tools/gen_large_checksums.py 4)" 

@@ -21,6 +21,33 @@ def test_random_tiles_match_the_oracle(first):
         assert not errs, (rec, errs)
 
 
+def test_interior_winner_exactly_on_the_table_angle():
+    """Soak case 900039 (int32 DEM, dX = 1, dY = 17): a cell whose winning facet is interior with slopes in the exact ratio of
+    the spacings (s2 * d1 == s1 * d2: not clamped, pydem/dem_processing.py:1973) has the table angle as its direction, bit for
+    bit -- the device's own arctangent was an ulp off there, which moved the cell into the neighbouring section
+    (csrc/stencil.hip: the tie test on the winner)."""
+    import soak_parity
+    rec, errs = soak_parity.run_case(900039)
+    assert not errs, (rec, errs)
+    # the same situation by construction: dY / dX = 3, planes whose facet slopes are in exactly that ratio in many cells
+    import warnings
+    import numpy as np
+    from oracle import oracle as O
+    from pydem_amd import DEMProcessor
+    rng = np.random.default_rng(7)
+    ii, jj = np.mgrid[0:160, 0:200]
+    for sx, sy in ((4, 36), (2, 18), (12, 4), (6, 2)):
+        z = (10000 - sx * jj - sy * ii + rng.integers(0, 2, ii.shape) * 0).astype(np.int32)
+        z[40:60, 50:90] += rng.integers(-3, 4, (20, 40)).astype(np.int32)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            o = O.OracleDEM(z, dX=1.0, dY=3.0, drain_pits=False); o.calc_slopes_directions(); o.calc_uca()
+            dp = DEMProcessor(elev=z, dX=1.0, dY=3.0, fill_flats=False, drain_pits_path=False, drain_pits=False)
+            dp.calc_slopes_directions(); dp.calc_uca()
+        assert np.array_equal(dp.section, o.section), (sx, sy, int((np.asarray(dp.section) != o.section).sum()))
+        assert np.allclose(dp.direction, o.direction, rtol=1e-12, atol=1e-15, equal_nan=True)
+
+
 def test_random_mosaics_match_the_oracle_backed_directory_flow():
     import numpy as np
     import soak_pm
