@@ -98,8 +98,20 @@ struct TileS {
     double in_p[SYM_MAXIN];           // proportion of the halo inlets
     uint8_t hidx[NHALO];              // ring position -> inlet index (0xFF: none)
     uint16_t rt_incl[64], rt_slot[64];    // the round's table: per ready cell the inclusive prefix of (1 + entries) and its slot
-    int tail, nin, fail;
+    // pit edges of the open cells, read once at set-up (a walk of the global lists per round -- offsets, destinations, sources,
+    // their level stamps: three or four dependent trips -- was half of a round's 6.7 us):
+    static constexpr int PE = RC / 2, PO = RC / 2, LP = RC >= 1024 ? RC : 3 * RC;
+    uint16_t pe_code[PE];             // in-edges from sources that were open at set-up: slot of the source, or 0x8000 | inlet
+    double pe_w[PE];                  // their weights
+    uint16_t po_code[PO];             // out-edges: cell of this tile (< 1024), 1024 + neighbour tile (0..8), 0x8000 | index into far_tile
+    uint16_t pe_first[RC], po_first[RC];
+    uint8_t pe_n[RC], po_n[RC];
+    int32_t far_tile[32];
+    double lpool[LP];                 // the tile's first coefficients stay on chip until the visit ends (offsets with SYM_LOCAL); what
+                                      // does not fit goes straight to the global pool
+    int tail, nin, fail, npe, npo, nfar;
 };
+constexpr uint32_t SYM_LOCAL = 1u << 30;                   // offset into TileS::lpool (only while the visit runs)
 
 // ring position of a halo cell (halo coordinates: rows 0..HH-1, columns 0..TT+1)
 __device__ __forceinline__ int halo_pos(int hi, int hj)
@@ -143,7 +155,7 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
     const int i0 = by * TH, j0 = bx * TT, n = A.n, m = A.m;
     const int half = lane >> 5, l32 = lane & 31;
     constexpr int NSET = TH * TT / 64;
-    if (lane == 0) { S.tail = 0; S.nin = 0; S.fail = 0; }
+    if (lane == 0) { S.tail = 0; S.nin = 0; S.fail = 0; S.npe = 0; S.npo = 0; S.nfar = 0; }
 #ifdef PYDEM_SYM_PROF           // phase timers of the symbolic visit (10 ns ticks summed over the visits into Y.stat[8..]; a diagnostic build)
     long long tk[8]; int nrounds = 0, nentries = 0;
     tk[0] = wall_clock64();
@@ -186,7 +198,7 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
     if (lane < nin) S.in_p[lane] = A.prop[S.in_id[lane]];
     SYM_TICK(2);
     // ---- set-up: a slot per open cell, count = open upstream cells INSIDE the tile (an open inlet does not block)
-    uint32_t pitmask = 0;
+    uint32_t pitmask = 0, poutmask = 0;
     int nslot = 0;
 #pragma unroll 2
     for (int k = 0; k < NSET; k++) {
@@ -205,42 +217,17 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
             if (s < RC) {
                 S.map[idx] = (uint16_t)s;
                 S.sm[s] = (uint32_t)idx | ((im & ~nf) << SS_OPEN_SHIFT) | ((im & nf) << SS_FINAL_SHIFT);
-                if (w & (CI_PIT_IN << 16)) pitmask |= 1u << k;
+                if (w & (CI_PIT_OUT << 16)) poutmask |= 1u << k;
+                if (w & (CI_PIT_IN << 16)) pitmask |= 1u << k;               // (joins the ready list after its pit edges have been read)
                 else if (cnt == 0) S.list[atomicAdd(&S.tail, 1)] = (uint16_t)s;
             }
         }
         nslot += __popcll(bo);
     }
     if (nslot > RC) return false;
-    // pit in-edges of the lane's drains: sources open in this tile are released on chip; open sources elsewhere are inlets
-    if (pitmask) {
-#pragma unroll 1
-        for (int k = 0; k < NSET; k++) {
-            if (!(pitmask & (1u << k))) continue;
-            const int cell = lane + 64 * k;
-            const int32_t c = (i0 + (cell >> 5)) * m + j0 + (cell & 31);
-            uint32_t cnt = sp_of(L, cell);
-            for (int32_t e = pit_stash(A, c).x; e < A.n_pit && A.pin_dst[e] == c; e++) {
-                const int32_t sc = A.pin_src[e];
-                const int si = sc / m - i0, sj = sc % m - j0;
-                if (si >= 0 && si < TH && sj >= 0 && sj < TT) cnt += sp_state(L, si * TT + sj) ? 0u : 1u;
-                else {
-                    const uint32_t lv = ci_level(A.cinfo[sc]);
-                    if (!(lv >= 1 && lv < pass)) {
-                        const int j = atomicAdd(&S.nin, 1);
-                        if (j < SYM_MAXIN) S.in_id[j] = sc; else S.fail = 1;
-                    }
-                }
-            }
-            sp_of(L, cell) = (uint16_t)cnt;
-            if (cnt == 0) S.list[atomicAdd(&S.tail, 1)] = S.map[cell];
-        }
-    }
     tile_wave_sync();
-    if (S.fail) return false;
     if (lane < TH) L.a0[lane] = a0_row;                  // (the final bitmap is dead now)
     tile_wave_sync();
-    const int nin_all = S.nin < SYM_MAXIN ? S.nin : SYM_MAXIN;
     SYM_TICK(3);
     // ---- the constant part of every open cell: all its loads in flight together
     for (int s = lane; s < nslot; s += 64) {
@@ -265,17 +252,109 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
         while (mm) { const int d = __ffs(mm) - 1; mm &= mm - 1u; const double x = in_edge(A, c, m, d); K += fabs(x); td = td || (x < 0); }
         S.Kd[s] = K; S.Pd[s] = pv; S.mk[s] = 0ull; S.off[s] = 0u;
         S.sm[s] = (smv & (SS_CELL | (0xFFu << SS_OPEN_SHIFT))) | (td ? SS_TAINT : 0u);
+        S.pe_n[s] = 0; S.po_n[s] = 0;
     }
     tile_wave_sync();
+    // ---- pit edges of the open cells.  In-edges of the lane's drains: a source that is final adds to the constant part now; a
+    // source that is open in this tile is released on chip (entry: its slot); an open source elsewhere is an inlet
+    if (pitmask) {
+#pragma unroll 1
+        for (int k = 0; k < NSET; k++) {
+            if (!(pitmask & (1u << k))) continue;
+            const int cell = lane + 64 * k;
+            const int s = S.map[cell];
+            const int32_t c = (i0 + (cell >> 5)) * m + j0 + (cell & 31);
+            const int32_t e0 = pit_stash(A, c).x;
+            uint32_t cnt = sp_of(L, cell);
+            int ne = 0;
+            double kadd = 0.0;
+            bool td = false;
+            for (int32_t e = e0; e < A.n_pit && A.pin_dst[e] == c; e++) {
+                const int32_t sc = A.pin_src[e];
+                const int si = sc / m - i0, sj = sc % m - j0;
+                const bool inside = si >= 0 && si < TH && sj >= 0 && sj < TT;
+                bool open_src;
+                if (inside) { open_src = sp_state(L, si * TT + sj) == 0u; if (open_src) cnt++; }
+                else { const uint32_t lv = ci_level(A.cinfo[sc]); open_src = !(lv >= 1 && lv < pass); }
+                if (open_src) ne++;
+                else { kadd += A.area[sc] * A.pin_w[e]; td = td || (A.todo_work[sc] != 0); }
+            }
+            int base = 0;
+            if (ne) {
+                base = atomicAdd(&S.npe, ne);
+                if (base + ne > TileS<RC>::PE || ne > 255) { S.fail = 1; ne = 0; }
+            }
+            int q = 0;
+            if (ne)
+                for (int32_t e = e0; e < A.n_pit && A.pin_dst[e] == c; e++) {
+                    const int32_t sc = A.pin_src[e];
+                    const int si = sc / m - i0, sj = sc % m - j0;
+                    uint32_t code;
+                    if (si >= 0 && si < TH && sj >= 0 && sj < TT) {
+                        if (sp_state(L, si * TT + sj) != 0u) continue;
+                        code = S.map[si * TT + sj];
+                    } else {
+                        const uint32_t lv = ci_level(A.cinfo[sc]);
+                        if (lv >= 1 && lv < pass) continue;
+                        const int j = atomicAdd(&S.nin, 1);
+                        if (j < SYM_MAXIN) S.in_id[j] = sc; else S.fail = 1;
+                        code = 0x8000u | (uint32_t)(j & 63);
+                    }
+                    S.pe_code[base + q] = (uint16_t)code; S.pe_w[base + q] = A.pin_w[e]; q++;
+                }
+            S.pe_first[s] = (uint16_t)base; S.pe_n[s] = (uint8_t)ne;
+            S.Kd[s] += kadd;
+            if (td) S.sm[s] |= SS_TAINT;
+            sp_of(L, cell) = (uint16_t)cnt;
+            if (cnt == 0) S.list[atomicAdd(&S.tail, 1)] = (uint16_t)s;
+        }
+    }
+    // out-edges of the lane's open pits: where they drain to
+    if (poutmask) {
+#pragma unroll 1
+        for (int k = 0; k < NSET; k++) {
+            if (!(poutmask & (1u << k))) continue;
+            const int cell = lane + 64 * k;
+            const int s = S.map[cell];
+            const int32_t c = (i0 + (cell >> 5)) * m + j0 + (cell & 31);
+            const int32_t e0 = pit_stash(A, c).y;
+            int ne = 0;
+            for (int32_t e = e0; e < A.n_pit && A.pit_src[e] == c; e++) ne++;
+            int base = 0;
+            if (ne) {
+                base = atomicAdd(&S.npo, ne);
+                if (base + ne > TileS<RC>::PO || ne > 255) { S.fail = 1; ne = 0; }
+            }
+            for (int q = 0; q < ne; q++) {
+                const int32_t dc = A.pit_dst[e0 + q];
+                const int ti = dc / m - i0, tj = dc % m - j0;
+                uint32_t code;
+                if (ti >= 0 && ti < TH && tj >= 0 && tj < TT) code = (uint32_t)(ti * TT + tj);
+                else if (ti >= -TH && ti < 2 * TH && tj >= -TT && tj < 2 * TT) {
+                    const int dti = ti < 0 ? -1 : (ti >= TH ? 1 : 0), dtj = tj < 0 ? -1 : (tj >= TT ? 1 : 0);
+                    code = 1024u + (uint32_t)((dti + 1) * 3 + dtj + 1);
+                } else {
+                    const int f = atomicAdd(&S.nfar, 1);
+                    if (f < 32) S.far_tile[f] = (dc / m / TH) * tiles_x + (dc % m) / TT; else S.fail = 1;
+                    code = 0x8000u | (uint32_t)(f & 31);
+                }
+                S.po_code[base + q] = (uint16_t)code;
+            }
+            S.po_first[s] = (uint16_t)base; S.po_n[s] = (uint8_t)ne;
+        }
+    }
+    tile_wave_sync();
+    if (S.fail) return false;
+    const int nin_all = S.nin < SYM_MAXIN ? S.nin : SYM_MAXIN;
     SYM_TICK(4);
-    auto find_inlet = [&](int32_t sc) -> int {             // (a pit source outside the tile that was open at set-up)
-        for (int j = 0; j < nin_all; j++) if (S.in_id[j] == sc) return j;
-        return 0;
-    };
     // ---- rounds: counts and slots in LDS, coefficients in the pool (written in one round, read by this wavefront in a later one)
     uint32_t wake = 0;
     int head = 0;
-    bool exhausted = false;
+    bool exhausted = false, any_global = false;
+    uint32_t lused = 0;                                    // doubles of the LDS pool in use (wavefront-uniform)
+    auto coef_at = [&](uint32_t o, int k) -> double {      // entry k of the block at offset o
+        return (o & SYM_LOCAL) ? S.lpool[(o & (SYM_LOCAL - 1u)) + (uint32_t)k] : sym_ptr(Y, o)[k];
+    };
     for (;;) {
         const int tail = S.tail;
         if (head >= tail) break;
@@ -286,14 +365,11 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
         double a = 0.0;
         bool td = false;
         unsigned long long mask = 0ull;
-        int2 po = make_int2(0, 0);
-        int32_t c = 0;
         if (act) {
             s = S.list[idx]; smv = S.sm[s]; cell = smv & SS_CELL;
             cw = L.cs[cell] >> 16;
             a = S.Kd[s]; td = (smv & SS_TAINT) != 0u;
             const int r = cell >> 5, cc = cell & 31;
-            c = (i0 + r) * m + j0 + cc;
             om = outside_dirs(r, cc);
             opn = (smv >> SS_OPEN_SHIFT) & 0xFFu;
             uint32_t mm = opn;
@@ -310,25 +386,23 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
                     mask |= S.mk[ss];
                 }
             }
-            if (cw & (CI_PIT_IN | CI_PIT_OUT)) po = pit_stash(A, c);
-            if (cw & CI_PIT_IN)
-                for (int32_t e = po.x; e < A.n_pit && A.pin_dst[e] == c; e++) {
-                    const int32_t sc = A.pin_src[e];
-                    const int si = sc / m - i0, sj = sc % m - j0;
-                    if (si >= 0 && si < TH && sj >= 0 && sj < TT && sp_state(L, si * TT + sj) == 2u) {      // finished in this visit
-                        const int ss = S.map[si * TT + sj];
-                        a += S.Kd[ss] * A.pin_w[e]; td = td || (S.sm[ss] & SS_TAINT); mask |= S.mk[ss];
-                    } else {
-                        const bool inside = si >= 0 && si < TH && sj >= 0 && sj < TT;
-                        const uint32_t lv = inside ? 1u : ci_level(A.cinfo[sc]);
-                        if (inside || (lv >= 1 && lv < pass)) { a += A.area[sc] * A.pin_w[e]; td = td || (A.todo_work[sc] != 0); }
-                        else mask |= 1ull << find_inlet(sc);
-                    }
-                }
+            for (int q = 0, pf = S.pe_first[s], pn = S.pe_n[s]; q < pn; q++) {          // pit in-edges from sources open at set-up
+                const uint32_t code = S.pe_code[pf + q];
+                if (code & 0x8000u) mask |= 1ull << (code & 63u);
+                else { a += S.Kd[code] * S.pe_w[pf + q]; td = td || (S.sm[code] & SS_TAINT); mask |= S.mk[code]; }
+            }
         }
         const int nent = __popcll(mask);
-        uint32_t incl = 0, total = 0;
-        const uint32_t my = sym_alloc(Y, AL, (act && nent) ? (uint32_t)nent + 1u : 0u, lane, incl, total);
+        uint32_t incl = 0, total = 0, my;
+        {
+            const uint32_t need = (act && nent) ? (uint32_t)nent + 1u : 0u;
+            uint32_t inc2 = need;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(inc2, d); if (lane >= d) inc2 += v; }
+            const uint32_t tot2 = __builtin_amdgcn_readfirstlane(__shfl(inc2, 63));
+            if (lused + tot2 <= (uint32_t)TileS<RC>::LP) { incl = inc2; total = tot2; my = SYM_LOCAL | (lused + inc2 - need); lused += tot2; }
+            else { my = sym_alloc(Y, AL, need, lane, incl, total); any_global = true; }
+        }
         if (my == SYM_NONE) { exhausted = true; break; }
         S.rt_incl[lane] = (uint16_t)incl;
         if (act) {
@@ -356,17 +430,22 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
             const int li = cell >> 5, lj = cell & 31;
             if (cw & CI_OUT1) release(li + fe1r(sct), lj + fe1c(sct));
             if (cw & CI_OUT2) release(li + fe2r(sct), lj + fe2c(sct));
-            if (cw & CI_PIT_OUT)
-                for (int32_t e = po.y; e < A.n_pit && A.pit_src[e] == c; e++) {
-                    const int32_t dc = A.pit_dst[e];
-                    release(dc / m - i0, dc % m - j0);
+            for (int q = 0, pf = S.po_first[s], pn = S.po_n[s]; q < pn; q++) {          // pit out-edges
+                const uint32_t code = S.po_code[pf + q];
+                if (code < 1024u) { if (sp_dec(L, (int)code) == 1u) S.list[atomicAdd(&S.tail, 1)] = S.map[code]; }
+                else if (code < 0x8000u) wk |= 1u << (code - 1024u);
+                else if (nent) wk |= 1u << 9;
+                else {
+                    const int tt = S.far_tile[code & 31u];
+                    if (atomicExch(&N.flag[tt], (int32_t)pass + 1) != (int32_t)pass + 1) N.list[atomicAdd(N.count, 1)] = tt;
                 }
+            }
             if (nent) smw |= wk << SS_WAKE_SHIFT; else wake |= wk & 0x1FFu;
             S.sm[s] = smw;
         }
-        // (the stores of the previous round's coefficients must have landed before this round reads them: waiting for them
-        // HERE lets the wait overlap with the LDS work above; the end of a round only orders LDS traffic)
-        tile_wave_sync();
+        // (the stores of the previous round's coefficients must have landed before this round reads them -- only once the
+        // global pool is in play; the wait then overlaps with the LDS work above, the end of a round only orders LDS traffic)
+        if (any_global) tile_wave_sync(); else tile_lds_sync();
         // ---- the coefficients of the round's cells, ONE lane per (cell, inlet): a cell's entries are sums over its open
         // in-edges of weight x the source's coefficient for the same inlet -- every lane has its own few loads in flight, the
         // round costs one trip to the pool however many entries its cells have (a lane walking its cell's entries one
@@ -377,7 +456,8 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
             const int so = S.rt_slot[lo];
             const unsigned long long mo = S.mk[so];
             const int k = (int)(e - ((uint32_t)S.rt_incl[lo] - (uint32_t)__popcll(mo) - 1u));
-            double *dst = sym_ptr(Y, S.off[so]);
+            const uint32_t oo = S.off[so];
+            double *dst = (oo & SYM_LOCAL) ? &S.lpool[oo & (SYM_LOCAL - 1u)] : sym_ptr(Y, oo);
             if (k == 0) { dst[0] = __longlong_as_double((long long)mo); continue; }
             unsigned long long mj = mo;
             for (int q = 1; q < k; q++) mj &= mj - 1ull;
@@ -385,7 +465,7 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
             const unsigned long long below = (1ull << j) - 1ull;
             const uint32_t smo = S.sm[so];
             const int ocell = smo & SS_CELL, r = ocell >> 5, cc = ocell & 31;
-            const uint32_t ocw = L.cs[ocell] >> 16, oom = outside_dirs(r, cc);
+            const uint32_t oom = outside_dirs(r, cc);
             double cf = 0.0;
             uint32_t mm = (smo >> SS_OPEN_SHIFT) & 0xFFu;
             while (mm) {
@@ -399,25 +479,16 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
                     const unsigned long long ms = S.mk[ss];
                     if ((ms >> j) & 1ull) {
                         const double ps = S.Pd[ss];
-                        cf += (((0x5A >> d) & 1) ? ps : 1 - ps) * sym_ptr(Y, S.off[ss])[1 + __popcll(ms & below)];
+                        cf += (((0x5A >> d) & 1) ? ps : 1 - ps) * coef_at(S.off[ss], 1 + __popcll(ms & below));
                     }
                 }
             }
-            if (ocw & CI_PIT_IN) {
-                const int32_t oc = (i0 + r) * m + j0 + cc;
-                for (int32_t pe = pit_stash(A, oc).x; pe < A.n_pit && A.pin_dst[pe] == oc; pe++) {
-                    const int32_t sc = A.pin_src[pe];
-                    const int si = sc / m - i0, sj = sc % m - j0;
-                    if (si >= 0 && si < TH && sj >= 0 && sj < TT) {
-                        if (sp_state(L, si * TT + sj) != 2u) continue;
-                        const int ss = S.map[si * TT + sj];
-                        if (!(S.sm[ss] & SS_FIN) || ss == so) continue;
-                        const unsigned long long ms = S.mk[ss];
-                        if ((ms >> j) & 1ull) cf += A.pin_w[pe] * sym_ptr(Y, S.off[ss])[1 + __popcll(ms & below)];
-                    } else {
-                        const uint32_t lv = ci_level(A.cinfo[sc]);
-                        if (!(lv >= 1 && lv < pass) && find_inlet(sc) == j) cf += A.pin_w[pe];
-                    }
+            for (int q = 0, pf = S.pe_first[so], pn = S.pe_n[so]; q < pn; q++) {
+                const uint32_t code = S.pe_code[pf + q];
+                if (code & 0x8000u) { if ((int)(code & 63u) == j) cf += S.pe_w[pf + q]; }
+                else {
+                    const unsigned long long ms = S.mk[code];
+                    if ((ms >> j) & 1ull) cf += S.pe_w[pf + q] * coef_at(S.off[code], 1 + __popcll(ms & below));
                 }
             }
             dst[k] = cf;
@@ -440,13 +511,16 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
         nsym += __popcll(__ballot(sym));
     }
     if (nout > 64) return false;
-    uint32_t blk = SYM_NONE;
+    uint32_t blk = SYM_NONE, lbase = 0;
     if (nsym) {
-        const uint32_t need = 2u + (uint32_t)((nin_all + 1) / 2) + 4u * (uint32_t)nout;
+        const uint32_t hdr = 2u + (uint32_t)((nin_all + 1) / 2) + 4u * (uint32_t)nout;
         uint32_t incl_b = 0, total_b = 0;
-        blk = sym_alloc(Y, AL, lane == 0 ? need : 0u, lane, incl_b, total_b);
+        blk = sym_alloc(Y, AL, lane == 0 ? hdr + lused : 0u, lane, incl_b, total_b);     // the block, then the coefficients that stayed on chip
         blk = __builtin_amdgcn_readfirstlane(__shfl(blk, 0));
         if (blk == SYM_NONE) return false;
+        lbase = blk + hdr;
+        double *G = sym_ptr(Y, lbase);
+        for (uint32_t q = (uint32_t)lane; q < lused; q += 64u) G[q] = S.lpool[q];
         double *B = sym_ptr(Y, blk);
         if (lane == 0) {
             B[0] = __longlong_as_double((long long)((unsigned long long)nin_all | ((unsigned long long)nout << 8)));
@@ -481,7 +555,7 @@ __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, Ti
                 A.cinfo[c] = ci_with_level(cw, pass);
                 nfin++;
             } else {
-                const uint32_t goff = S.off[s];
+                const uint32_t goff = (S.off[s] & SYM_LOCAL) ? lbase + (S.off[s] & (SYM_LOCAL - 1u)) : S.off[s];
                 const unsigned long long hb = (unsigned long long)goff | ((smv & SS_TAINT) ? (1ull << 32) : 0ull);
                 A.contrib[c] = make_double2(a, __longlong_as_double((long long)hb));
                 A.cinfo[c] = ci_with_level(cw, CI_LEVEL_SYM);
