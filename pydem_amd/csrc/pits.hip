@@ -633,8 +633,11 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
 #pragma unroll
         for (int j = 0; j < W2_SLOTS; j++) {
             const int k = lane + 64 * j;
-            e[j] = (j * 64 < nb && k < nb) ? L.le[k] : INFINITY;                 // free slots hold +inf
-            mn = min_f64(mn, e[j]);
+            e[j] = INFINITY;
+            if (j * 64 < nb) {                                                   // (wave-uniform: half of the rounds have a border of <= 64 cells)
+                if (k < nb) e[j] = L.le[k];                                      // free slots hold +inf
+                mn = min_f64(mn, e[j]);
+            }
         }
         mn = wave_min(mn);
         // ... and pit_area += border[eborder == emin] (:1322-1323): out of the list, slots recycled
