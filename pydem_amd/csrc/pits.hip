@@ -515,8 +515,10 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_fmin(double v)
 {
     const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    // (every lane has a source lane under these permutations: with bound_ctrl the move needs no tied old value, i.e. no copy of
+    // the operand in front of it -- two v_mov per call otherwise)
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return min_f64(v, __hiloint2double(hi2, lo2));
 }
 // minimum over the wavefront: butterflies inside each row of 16 lanes on the DPP crossbar, then the four
@@ -526,13 +528,14 @@ __device__ __forceinline__ double wave_min(double v)
     v = dpp_fmin<0xB1>(v);        // quad_perm [1,0,3,2]
     v = dpp_fmin<0x4E>(v);        // quad_perm [2,3,0,1]
     v = dpp_fmin<0x141>(v);       // row_half_mirror
-    v = dpp_fmin<0x140>(v);       // row_mirror
+    v = dpp_fmin<0x140>(v);       // row_mirror: every lane of a row holds the row's minimum
+    // across the rows with the gfx9 row broadcasts: lane 15 of row k-1 into row k, then lane 31 into rows 2 and 3 -- lane 63
+    // ends up with the minimum of all four (the zeros bound_ctrl puts where there is no source land in lanes that are not
+    // read); two readlanes instead of eight and no minimum on values that came back through scalar registers
+    v = dpp_fmin<0x142>(v);       // row_bcast:15
+    v = dpp_fmin<0x143>(v);       // row_bcast:31
     const int lo = __double2loint(v), hi = __double2hiint(v);
-    double r = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
-    r = min_f64(r, __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16)));
-    r = min_f64(r, __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)));
-    r = min_f64(r, __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48)));
-    return r;
+    return __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
 }
 __device__ __forceinline__ void wave_sync()
 {
