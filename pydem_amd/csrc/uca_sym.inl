@@ -149,7 +149,7 @@ template <int RC>
 __device__ bool sym_visit(const SweepArgs &A, const SymArgs &Y, SymAlloc &AL, TileS<RC> &S, uint32_t pass, int tiles_x, int tid, int lane,
                           uint8_t *__restrict__ tile_done, int32_t &n_final, const TileNext &N, int32_t *pend, int &npend)
 {
-    static_assert(TH == 32, "the slot word holds 10 bits of cell id");
+    if (TH != 32) return false;        // (the slot word holds 10 bits of cell id; stage_sweep only turns the two-level solve on for 32-row tiles)
     TileW &L = S.W;
     const int by = tid / tiles_x, bx = tid - by * tiles_x;
     const int i0 = by * TH, j0 = bx * TT, n = A.n, m = A.m;
