@@ -3227,8 +3227,7 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
             HIP_TRY(hipEventRecord(t->ev_fork, t->stream));
             HIP_TRY(hipStreamWaitEvent(t->stream2, t->ev_fork, 0));
             hipLaunchKernelGGL(k_sweep_sym<256>, dim3(256 * 32), dim3(64), 0, t->stream, A, Y, ps, tiles_x, tiles_total, tile_done, total, N3, (const int32_t *)cand, (const int32_t *)(symc + 16), 0, 0);
-            hipLaunchKernelGGL(k_sweep_sym<512>, dim3(256 * 16), dim3(64), 0, t->stream2, A, Y, ps, tiles_x, tiles_total, tile_done, total, N3, (const int32_t *)cand, (const int32_t *)(symc + 17), 1, 256);
-            hipLaunchKernelGGL(k_sweep_sym<1024>, dim3(256 * 8), dim3(64), 0, t->stream2, A, Y, ps, tiles_x, tiles_total, tile_done, total, N3, (const int32_t *)cand, (const int32_t *)(symc + 17), 1, 512);
+            hipLaunchKernelGGL(k_sweep_sym<1024>, dim3(256 * 16), dim3(64), 0, t->stream2, A, Y, ps, tiles_x, tiles_total, tile_done, total, N3, (const int32_t *)cand, (const int32_t *)(symc + 17), 1, 256);
             HIP_TRY(hipEventRecord(t->ev_join, t->stream2));
             HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0));
             launches += 4;
