@@ -292,8 +292,8 @@ STAGES = [
      ('stencil.hip',)),
     ('pits', ('k_pits_', 'k_pitmask', 'k_pit_keys', 'k_pit_gather', 'radix_sort'), 9.4, 'pits_ms',
      'read elev 8 + flats 1 per cell + write 16 B per pit edge (6.49 M edges on the bench tile: 0.4 B/cell)', ('pits.hip',)),
-    ('sweep', ('k_sweep_tiles', 'k_pit_stash', 'k_uca_finalize'), 40.0, 'sweep_ms',
-     'read graph word 4 + proportion 8, write area 8 + two contributions 16 + level stamp 4 per cell', ('uca.hip',)),
+    ('sweep', ('k_sweep_tiles', 'k_sweep_sym', 'k_sym_candidates', 'k_sym_finish', 'k_pit_stash', 'k_uca_finalize'), 40.0, 'sweep_ms',
+     'read graph word 4 + proportion 8, write area 8 + two contributions 16 + level stamp 4 per cell', ('uca.hip', 'uca_sym.inl')),
     ('twi', ('k_twi',), 24.0, 'twi_ms', 'read uca 8 + mag 8, write twi 8', ('uca.hip',)),
 ]
 
