@@ -101,6 +101,8 @@ struct PitParams {
     int32_t *overflow_list;     // pits to re-run with the next larger window
     int32_t *overflow_count;
     int32_t *lane_overflow;     // pits the lane version hands to the wavefront version (count: out_count[4])
+    uint32_t *lane_state;       // 12 words per handed-over pit (same index as lane_overflow): iterations done, epit_border, the REGION as a
+                                // 16 x 16 bitmap -- the wavefront version starts from the lane version's region instead of from the pit
     int32_t *work_next;         // next unclaimed entry of the pit list (lane version)
     int32_t *dbg;               // PYDEM_PITS_DEBUG=2: per-pit {rounds, last border size, hand-over reason, drains}
     unsigned long long *prof;   // PYDEM_PITS_DEBUG=3: cycles per phase of the lane pass
@@ -481,6 +483,7 @@ __device__ void solve_pit(const PitParams &P, int32_t pit, int gl, uint32_t *reg
 #define PYDEM_WV_CAP 256
 #endif
 constexpr int WV_MAXD = 64;       // drain list capacity
+constexpr int LN_W16 = 16;        // window edge of the lane version (LN_W below; its hand-over records are read here)
 
 // Two instances: <128, 256, uint16_t> for the bulk (positions fit 14 bits, bit 14 = pit flag; 6.4 KB of LDS and 80 VGPRs:
 // six wavefronts per SIMD instead of five with a 384-cell list -- 18 of 397 678 pits of the 16384^2 bench tile then need the
@@ -545,7 +548,7 @@ __device__ __forceinline__ void wave_sync()
 
 template <int W2, int W2_CAP, typename PosT>
 __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLds<W2, W2_CAP, PosT> &L, int32_t &chunk_base,
-                               int32_t &chunk_left)
+                               int32_t &chunk_left, const uint32_t *state = nullptr)
 {
     constexpr int W2_SLOTS = W2_CAP / 64;
     constexpr PosT W2_HOLE = WaveLds<W2, W2_CAP, PosT>::HOLE, W2_PITBIT = WaveLds<W2, W2_CAP, PosT>::PITBIT;
@@ -607,22 +610,48 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
         }
         wave_sync();
     };
-    if (lane == 0) {                                                             // pit_area = [pit] (:1289-1292)
+    int it0 = 0, nq0 = 1;
+    if (state) {
+        // the lane version grew this pit for `it0` iterations before its 16 x 16 window or its 32-cell list overflowed: the
+        // region it reached is marked, and ONE expansion of all its cells rebuilds the border (the drain tests of the border
+        // cells are evaluated as they enter, like always) -- instead of replaying those iterations one round each
+        it0 = (int)state[0];
+        epit_border = __hiloint2double((int)state[3], (int)state[2]);
+        int lr0 = ipit - LN_W16 / 2, lc0 = jpit - LN_W16 / 2;                   // the lane version's window (same clipping)
+        if (lr0 > n - LN_W16) lr0 = n - LN_W16;
+        if (lc0 > m - LN_W16) lc0 = m - LN_W16;
+        if (lr0 < 0) lr0 = 0;
+        if (lc0 < 0) lc0 = 0;
+        const int dpos = (lr0 - r0) * W2 + (lc0 - c0);
+        nq0 = 0;
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) {
+            const int cidx = lane + 64 * j;                                      // cell of the 16 x 16 window
+            const bool in = (state[4 + 2 * j + (lane >> 5)] >> (lane & 31)) & 1u;
+            const unsigned long long bal = __ballot(in);
+            if (in) {
+                const int pos = dpos + (cidx >> 4) * W2 + (cidx & 15);
+                atomicOr(&L.seen[pos >> 5], 1u << (pos & 31));
+                L.u.pq[nq0 + __popcll(bal & lt)] = (PosT)pos;
+            }
+            nq0 += __popcll(bal);
+        }
+    } else if (lane == 0) {                                                      // pit_area = [pit] (:1289-1292)
         const int pos = (ipit - r0) * W2 + (jpit - c0);
         L.seen[pos >> 5] = 1u << (pos & 31);
         L.u.pq[0] = (PosT)pos;
     }
     wave_sync();
-    expand(1);
-    if (P.min_border) {                                                          // :1294-1295
+    expand(nq0);
+    if (!state && P.min_border) {                                                // :1294-1295
         double mn = INFINITY;
         for (int k = lane; k < nb; k += 64) mn = min_f64(mn, L.le[k]);
         mn = wave_min(mn);
         if (nb) epit_border = mn;
         has_np = false;                                                          // nothing is below the minimum
     }
-    int mode = 0, ndrain = -1, it_used = 0;
-    for (int it = 0; it < P.max_iter; it++) {                                    // :1300
+    int mode = 0, ndrain = -1, it_used = it0;
+    for (int it = it0; it < P.max_iter; it++) {                                  // :1300
         if (over) break;
         if (n_alive == 0) break;                                                 // :1304-1305
         // numpy's min propagates NaN: with a nodata cell on the border there is no non-pit drain and no growth
@@ -723,6 +752,7 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
 // capacity go to the wavefront version.
 // ---------------------------------------------------------------------------------------------
 constexpr int LN_W = 16;          // window edge
+static_assert(LN_W == LN_W16, "hand-over records");
 #ifndef PYDEM_LN_B
 #define PYDEM_LN_B 32
 #endif
@@ -825,9 +855,9 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
             const bool in_a = (pos >> 5) == wa;
             const uint32_t wd = in_a ? va : vb;
             if (wd & bit) continue;
+            if (nb == LN_B) { over = true; continue; }        // (not marked: the bitmap stays "region + listed border" for the hand-over)
             if (in_a) va |= bit; else vb |= bit;
             if (wb == wa) vb = va;
-            if (nb == LN_B) { over = true; continue; }
             lp[nb * LN_T] = (uint8_t)pos;
             nb++;
         }
@@ -1064,7 +1094,21 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
             int32_t obase = 0;
             if (lane == 0) obase = atomicAdd(&P.out_count[4], __popcll(b_ov));
             obase = __shfl(obase, 0);
-            if (status == 3) P.lane_overflow[obase + __popcll(b_ov & lt)] = pit;
+            if (status == 3) {
+                const int32_t slot = obase + __popcll(b_ov & lt);
+                P.lane_overflow[slot] = pit;
+                if (P.lane_state) {
+                // the region = bitmap minus the cells still on the border list.  The round that overflowed had taken its
+                // minimum cells out of the list already (they belong to the region) and has been counted in `it`; the border
+                // is recomputed by the wavefront version as "unseen neighbours of the region"
+                for (int k = 0; k < nb; k++) { const int pos = lp[k * LN_T]; seen[(pos >> 5) * LN_T] &= ~(1u << (pos & 31)); }
+                uint32_t *rec = P.lane_state + (size_t)slot * 12;
+                rec[0] = (uint32_t)it; rec[1] = 0;                                 // (the round that overflowed has been counted)
+                rec[2] = (uint32_t)__double2loint(epit_border); rec[3] = (uint32_t)__double2hiint(epit_border);
+#pragma unroll
+                for (int w = 0; w < 8; w++) rec[4 + w] = seen[w * LN_T];
+                }
+            }
         }
         if (prof) acc_c += clock64() - tk2;
     }
@@ -1086,7 +1130,7 @@ __global__ __launch_bounds__(256, PYDEM_WV_OCC) void k_pits_wave(PitParams P, co
     int32_t chunk_base = 0, chunk_left = 0;
 #ifdef PYDEM_WV_STATIC
     for (int32_t q = blockIdx.x * 4 + wave; q < np; q += gridDim.x * 4) {
-        solve_pit_wave(P, pits[q], lane, s_l[wave], chunk_base, chunk_left);
+        solve_pit_wave(P, pits[q], lane, s_l[wave], chunk_base, chunk_left, P.lane_state ? P.lane_state + (size_t)q * 12 : nullptr);
         wave_sync();
     }
 #else
@@ -1097,7 +1141,7 @@ __global__ __launch_bounds__(256, PYDEM_WV_OCC) void k_pits_wave(PitParams P, co
         if (lane == 0) q = atomicAdd(P.work_next, 1);
         q = __shfl(q, 0);
         if (q >= np) break;
-        solve_pit_wave(P, pits[q], lane, s_l[wave], chunk_base, chunk_left);
+        solve_pit_wave(P, pits[q], lane, s_l[wave], chunk_base, chunk_left, P.lane_state ? P.lane_state + (size_t)q * 12 : nullptr);
         wave_sync();
     }
 #endif
@@ -1360,6 +1404,12 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         P.out_count = cnt + 1; P.out_cap = (int32_t)(t->pits.raw_cap < INT32_MAX ? t->pits.raw_cap : INT32_MAX);
         P.overflow_list = t->labels; P.overflow_count = cnt + 3;
         P.lane_overflow = t->queue[0];
+        {   // hand-over records: 12 words per pit the lane version gives up on (at most every pit); PYDEM_PITS_HANDOVER=0: restart from the pit
+            static int handover = -1;
+            if (handover < 0) { const char *e = getenv("PYDEM_PITS_HANDOVER"); handover = e ? atoi(e) : 1; }
+            P.lane_state = nullptr;
+            if (handover && (int64_t)npits * 12 <= t->NN) { PYDEM_TRY(tile_alloc(t, &t->queue[1], (size_t)t->NN)); P.lane_state = (uint32_t *)t->queue[1]; }
+        }
         // pass 1: a lane per pit (16x16 window); pass 2: a wavefront per pit it handed over (64x64)
         HIP_TRY(hipMemsetAsync(cnt + 10, 0, sizeof(int32_t), t->stream));
         P.work_next = cnt + 10;
@@ -1468,10 +1518,14 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
     t->tm.n_pit_edges = ne;
     if (ne > 0) {
         if (t->pits.sorted_cap < ne) {
-            PYDEM_TRY(dev_realloc(t, &t->pits.src, (size_t)ne)); PYDEM_TRY(dev_realloc(t, &t->pits.dst, (size_t)ne));
-            PYDEM_TRY(dev_realloc(t, &t->pits.w, (size_t)ne)); PYDEM_TRY(dev_realloc(t, &t->pits.in_src, (size_t)ne));
-            PYDEM_TRY(dev_realloc(t, &t->pits.in_dst, (size_t)ne)); PYDEM_TRY(dev_realloc(t, &t->pits.in_w, (size_t)ne));
-            t->pits.sorted_cap = ne;
+            // `ne` counts the partly used chunks of the wavefronts as well and moves by a few hundred from run to run: sized in
+            // steps of 64 Ki entries, or every run of the same tile would ask the plane cache (exact sizes, tile.hip) for
+            // blocks of a size it has not seen
+            const size_t sc = ((size_t)ne + 65535) & ~(size_t)65535;
+            PYDEM_TRY(dev_realloc(t, &t->pits.src, sc)); PYDEM_TRY(dev_realloc(t, &t->pits.dst, sc));
+            PYDEM_TRY(dev_realloc(t, &t->pits.w, sc)); PYDEM_TRY(dev_realloc(t, &t->pits.in_src, sc));
+            PYDEM_TRY(dev_realloc(t, &t->pits.in_dst, sc)); PYDEM_TRY(dev_realloc(t, &t->pits.in_w, sc));
+            t->pits.sorted_cap = (int64_t)sc;
         }
         // one persistent scratch block (allocating and freeing eight buffers per call costs more than the sorts)
         size_t tmp_bytes = 0;

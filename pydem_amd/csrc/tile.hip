@@ -95,6 +95,10 @@ void *plane_take(int device, size_t bytes)
     }
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, bytes);
+    {   // PYDEM_PLANE_DEBUG=1: one line per block that is mapped anew (a steady state maps nothing)
+        static const bool dbg = [] { const char *d = getenv("PYDEM_PLANE_DEBUG"); return d && atoi(d) > 0; }();
+        if (dbg) fprintf(stderr, "[pydem] plane_take: hipMalloc(%zu)\n", bytes);
+    }
     if (e != hipSuccess) {                          // the free lists may hold what is missing
         (void)hipGetLastError();
         plane_cache_flush(device);
