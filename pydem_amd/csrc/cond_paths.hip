@@ -20,6 +20,11 @@
 // loop (cond_host.cpp: pydem_cond_pit_paths) on the untouched surface.  The soak tools count how often
 // that happens.
 //
+// A pit that has to wait is NOT simulated again as long as nothing it read has changed: its footprint, chain and chain
+// values stay where they are (storage belongs to the pit, not to its place in the round's window), every commit stamps the
+// cells it rewrites with the round (wround), and a waiting pit whose footprint holds no stamp >= the round of its simulation
+// only renews its reservations (kept_simulation) -- on the 8192^2 SRTM-like tile 2.5 simulations per pit otherwise.
+//
 // A simulation is a wavefront: membership of region + rim in a window bitmap in LDS (64 x 64 cells; pits that leave
 // it are re-run in a 256 x 256 window, those that leave that one too in a 640 x 640 window -- 300 iterations cannot
 // leave that one; a pit remembers the window it needs, and the medium / large-window simulations of such pits run on
@@ -67,7 +72,37 @@ struct PathArgs {
     int32_t *flags;          // [0] a simulation met a cell written by a later pit, [1] capacity exceeded, [2] first pit of the order whose
                              // simulation left the window of its tier in this round (nobody from it on may commit; INT_MAX: none)
     const int32_t *tier;     // per slot: 0 small window, 1 medium, 2 large (what earlier rounds learned about the pit)
+    // simulations that outlive their round
+    int round;               // 1, 2, ...
+    int count_kept;          // debug: count the kept simulations (flags[4]) and the stale ones (flags[5])
+    int32_t *wround;         // [NN] round of the last commit that rewrote the cell (0: never)
+    int32_t *simround;       // per slot: round of the simulation whose results the slot holds (<= 0: none)
+    const int32_t *home;     // per slot: the pit's block of the small-window footprint / chain arrays (it keeps it while it waits)
+    const int32_t *src;      // per slot: the slot the pit had in the previous round (-1: new, or it sat that round out)
+    const int32_t *o_status, *o_nF, *o_nC, *o_iters, *o_simround;      // the previous round's per-slot state (carried over by k_paths_slots)
 };
+
+// The slot holds a finished simulation and no commit has rewritten a cell it read since: the simulation is what a new one
+// would compute, cell for cell.  Its reservations (released at the end of every round) are made again.
+__device__ bool kept_simulation(const PathArgs &A, int slot, int lane)
+{
+    const int sr = A.simround[slot], st = A.status[slot];
+    if (sr <= 0 || (st != ST_FAILED && st != ST_PATH)) return false;
+    const int32_t *F = A.Fp[slot];
+    const int nF = A.nF[slot];
+    bool stale = false;
+    for (int q = lane; q < nF; q += 64) if (A.wround[F[q]] >= sr) stale = true;
+    if (__any(stale)) { if (A.count_kept && lane == 0) atomicAdd(&A.flags[5], 1); return false; }
+    if (A.count_kept && lane == 0) atomicAdd(&A.flags[4], 1);
+    const int k = A.window[slot];
+    for (int q = lane; q < nF; q += 64) atomicMin(&A.rown[F[q]], k);
+    if (st == ST_PATH) {
+        const int32_t *C = A.Cp[slot];
+        const int nC = A.nC[slot];
+        for (int q = lane; q < nC; q += 64) atomicMin(&A.wown[C[q]], k);
+    }
+    return true;
+}
 
 __device__ __forceinline__ double wave_min(double v)
 {
@@ -120,6 +155,7 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
     const int oi = pi - WIN / 2, oj = pj - WIN / 2;          // window origin (may be negative)
     constexpr int WORDS = WIN * WIN / 32;
     PPROF(0, for (int w = lane; w < WORDS; w += 64) { seen[w] = 0; freshmap[w] = 0; });
+    if (lane == 0) A.simround[slot] = A.round;
     __builtin_amdgcn_wave_barrier();
     // the rim is an unordered list with HOLES: a cell that leaves it (promoted into the region) frees its slot (rim = -1,
     // height +inf), the slot goes on a stack and the next cell that joins takes it -- nothing is compacted per iteration.
@@ -407,6 +443,7 @@ __global__ __launch_bounds__(256, PYDEM_SMALL_WAVES) void k_paths_small(PathArgs
     const int q = blockIdx.x * 4 + wv;
     if (q >= nslots) return;
     if (A.tier[q] > 0) return;       // known to leave the small window: its medium / large-window simulation runs beside this kernel
+    if (kept_simulation(A, q, lane)) return;
     simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_holes[wv], s_flist[wv], s_trail[wv], STCAP);
 #else
     // persistent wavefronts take the next slot from a counter (flags[3], cleared by k_paths_slots): a simulation lasts 1 .. 300
@@ -417,6 +454,7 @@ __global__ __launch_bounds__(256, PYDEM_SMALL_WAVES) void k_paths_small(PathArgs
         q = __shfl(q, 0);
         if (q >= nslots) break;
         if (A.tier[q] > 0) continue;     // known to leave the small window: its medium / large-window simulation runs beside this kernel
+        if (kept_simulation(A, q, lane)) continue;
         simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_holes[wv], s_flist[wv], s_trail[wv], STCAP);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -441,6 +479,7 @@ __global__ __launch_bounds__(64) void k_paths_big(PathArgs A, const int32_t *__r
     const int q = blockIdx.x;
     if (q >= nslots) return;
     const int slot = slots[q];
+    if (kept_simulation(A, slot, (int)threadIdx.x)) return;
     simulate_pit<WIN, RCAP>(A, slot, seen, fresh, rim, rimz, holes, flist, bigtrail + (int64_t)qidx[q] * trail_cap, (int)trail_cap);
     if (close_round && threadIdx.x == 0 && A.status[slot] == ST_OVERFLOW) atomicMin(&A.flags[2], A.window[slot]);
 }
@@ -502,7 +541,7 @@ __global__ __launch_bounds__(256) void k_paths_commit(PathArgs A, int32_t *done,
     if (__any(clash)) { if (lane == 0) atomicOr(&A.flags[0], 1); return; }
     if (st == ST_PATH) {
         const double *CV = A.CVp[slot];
-        for (int q = lane; q < nC; q += 64) { A.e[C[q]] = CV[q]; atomicMax(&A.wstamp[C[q]], k); }
+        for (int q = lane; q < nC; q += 64) { A.e[C[q]] = CV[q]; atomicMax(&A.wstamp[C[q]], k); A.wround[C[q]] = A.round; }
     }
     for (int q = lane; q < nF; q += 64) atomicMax(&A.rstamp[F[q]], k);
     if (lane == 0) {
@@ -534,19 +573,28 @@ __global__ void k_paths_slots(PathArgs A, int32_t *F, int32_t *C, double *CV, in
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) { A.flags[2] = 0x7FFFFFFF; A.flags[3] = 0; }
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < A.nw; s += gridDim.x * blockDim.x) {
-        A.Fp[s] = F + (int64_t)s * fcap; A.Cp[s] = C + (int64_t)s * ccap; A.CVp[s] = CV + (int64_t)s * ccap;
+        const int64_t h = A.home[s];
+        A.Fp[s] = F + h * fcap; A.Cp[s] = C + h * ccap; A.CVp[s] = CV + h * ccap;
         A.fcap[s] = fcap; A.ccap[s] = ccap;
+        const int src = A.src[s];
+        if (src >= 0) {
+            A.status[s] = A.o_status[src]; A.nF[s] = A.o_nF[src]; A.nC[s] = A.o_nC[src]; A.iters[s] = A.o_iters[src];
+            A.simround[s] = A.o_simround[src];
+        } else {
+            A.status[s] = ST_PENDING; A.nF[s] = 0; A.nC[s] = 0; A.iters[s] = 0; A.simround[s] = -1;
+        }
     }
 }
 
-__global__ void k_paths_bigslots(PathArgs A, const int32_t *slots, const int32_t *qidx, int nb, int32_t *F, int32_t *C, double *CV, int64_t fcap, int64_t ccap)
+// keep: the blocks belong to their pits (medium window) -- a slot that carries a finished simulation keeps its state
+__global__ void k_paths_bigslots(PathArgs A, const int32_t *slots, const int32_t *qidx, int nb, int32_t *F, int32_t *C, double *CV, int64_t fcap, int64_t ccap, int keep)
 {
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nb; q += gridDim.x * blockDim.x) {
         const int s = slots[q];
         const int64_t blk = qidx[q];             // block of the scratch arrays
         A.Fp[s] = F + blk * fcap; A.Cp[s] = C + blk * ccap; A.CVp[s] = CV + blk * ccap;
         A.fcap[s] = (int32_t)fcap; A.ccap[s] = (int32_t)ccap;
-        A.status[s] = ST_PENDING;
+        if (!(keep && A.simround[s] > 0)) { A.status[s] = ST_PENDING; A.simround[s] = -1; }
     }
 }
 
@@ -668,24 +716,27 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     const int64_t MIDF = std::min<int64_t>((int64_t)MWIN * MWIN, t->NN);    // ... of a medium-window one
     ArenaLease lease;
     PYDEM_TRY(arena_acquire(t->device, &lease));
-    Buf b_bown, b_rstamp, b_tent, b_tier;
+    Buf b_bown, b_rstamp, b_tent, b_tier, b_wround, b_home, b_src, b_status2, b_nF2, b_nC2, b_iters2, b_sim, b_sim2;
     Buf b_order, b_window, b_rown, b_wown, b_stamp, b_status, b_nF, b_nC, b_iters, b_F, b_C, b_CV, b_flags, b_done, b_counts, b_slots,
         b_backup, b_bigtrail, b_bigF, b_bigC, b_bigCV, b_midtrail, b_midF, b_midC, b_midCV, b_Fp, b_Cp, b_CVp, b_fcap, b_ccap;
     PYDEM_TRY(b_order.get(lease, (size_t)npits * 4)); PYDEM_TRY(b_window.get(lease, (size_t)W * 4));
     PYDEM_TRY(b_rown.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_wown.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_stamp.get(lease, (size_t)t->NN * 4));
     PYDEM_TRY(b_bown.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_rstamp.get(lease, (size_t)t->NN * 4)); PYDEM_TRY(b_tent.get(lease, (size_t)W * 4)); PYDEM_TRY(b_tier.get(lease, (size_t)W * 4));
     PYDEM_TRY(b_status.get(lease, (size_t)W * 4)); PYDEM_TRY(b_nF.get(lease, (size_t)W * 4)); PYDEM_TRY(b_nC.get(lease, (size_t)W * 4)); PYDEM_TRY(b_iters.get(lease, (size_t)W * 4));
+    PYDEM_TRY(b_status2.get(lease, (size_t)W * 4)); PYDEM_TRY(b_nF2.get(lease, (size_t)W * 4)); PYDEM_TRY(b_nC2.get(lease, (size_t)W * 4)); PYDEM_TRY(b_iters2.get(lease, (size_t)W * 4));
+    PYDEM_TRY(b_sim.get(lease, (size_t)W * 4)); PYDEM_TRY(b_sim2.get(lease, (size_t)W * 4)); PYDEM_TRY(b_home.get(lease, (size_t)W * 4)); PYDEM_TRY(b_src.get(lease, (size_t)W * 4));
+    PYDEM_TRY(b_wround.get(lease, (size_t)t->NN * 4));
     PYDEM_TRY(b_F.get(lease, (size_t)W * FCAP * 4)); PYDEM_TRY(b_C.get(lease, (size_t)W * CCAP * 4)); PYDEM_TRY(b_CV.get(lease, (size_t)W * CCAP * 8));
     PYDEM_TRY(b_Fp.get(lease, (size_t)W * 8)); PYDEM_TRY(b_Cp.get(lease, (size_t)W * 8)); PYDEM_TRY(b_CVp.get(lease, (size_t)W * 8));
     PYDEM_TRY(b_fcap.get(lease, (size_t)W * 4)); PYDEM_TRY(b_ccap.get(lease, (size_t)W * 4));
-    PYDEM_TRY(b_flags.get(lease, 16)); PYDEM_TRY(b_done.get(lease, (size_t)W * 4)); PYDEM_TRY(b_counts.get(lease, 16)); PYDEM_TRY(b_slots.get(lease, (size_t)W * 16 + 64));
+    PYDEM_TRY(b_flags.get(lease, 32)); PYDEM_TRY(b_done.get(lease, (size_t)W * 4)); PYDEM_TRY(b_counts.get(lease, 16)); PYDEM_TRY(b_slots.get(lease, (size_t)W * 16 + 64));
     PYDEM_TRY(b_backup.get(lease, (size_t)t->NN * 8));
     HIP_TRY(hipMemcpyAsync(b_backup.p, t->elev, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
     // pinned staging: [order | window | status | done | tiers | (slot, block) lists of the medium / large simulations: known, fresh, re-run]
     void *pin_v = nullptr;
-    PYDEM_TRY(tile_pinned(t, ((size_t)npits + 8 * (size_t)W + 64) * 4, &pin_v));
+    PYDEM_TRY(tile_pinned(t, ((size_t)npits + 10 * (size_t)W + 64) * 4, &pin_v));
     int32_t *pin_order = (int32_t *)pin_v, *pin_window = pin_order + npits, *pin_status = pin_window + W, *pin_done = pin_status + W, *pin_tier = pin_done + W,
-            *pin_slots = pin_tier + W;
+            *pin_home = pin_tier + W, *pin_src = pin_home + W, *pin_slots = pin_src + W;
     memcpy(pin_order, order_host, (size_t)npits * 4);
     HIP_TRY(hipMemcpyAsync(b_order.p, pin_order, (size_t)npits * 4, hipMemcpyHostToDevice, t->stream));
     const int gN = gridp(t->NN, 8192);
@@ -694,8 +745,9 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     hipLaunchKernelGGL(k_fill_i32, dim3(gN), dim3(256), 0, t->stream, (int32_t *)b_stamp.p, t->NN, -1);
     hipLaunchKernelGGL(k_fill_i32, dim3(gN), dim3(256), 0, t->stream, (int32_t *)b_rstamp.p, t->NN, -1);
     hipLaunchKernelGGL(k_fill_i32, dim3(gN), dim3(256), 0, t->stream, (int32_t *)b_bown.p, t->NN, 0x7FFFFFFF);
-    HIP_TRY(hipMemsetAsync(b_flags.p, 0, 16, t->stream));
+    HIP_TRY(hipMemsetAsync(b_flags.p, 0, 32, t->stream));
     HIP_TRY(hipMemsetAsync(b_counts.p, 0, 16, t->stream));
+    HIP_TRY(hipMemsetAsync(b_wround.p, 0, (size_t)t->NN * 4, t->stream));
     PathArgs A;
     A.e = t->elev; A.n = n; A.m = m; A.order = (const int32_t *)b_order.p; A.window = (const int32_t *)b_window.p; A.nw = 0;
     A.dX = t->dX; A.dY = t->dY; A.ndX = n - 1; A.max_iter = max_iter; A.max_dist = max_dist; A.max_dist_XY = max_dist_XY;
@@ -706,6 +758,17 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     A.status = (int32_t *)b_status.p; A.nF = (int32_t *)b_nF.p; A.nC = (int32_t *)b_nC.p; A.iters = (int32_t *)b_iters.p;
     A.Fp = (int32_t **)b_Fp.p; A.Cp = (int32_t **)b_Cp.p; A.CVp = (double **)b_CVp.p; A.fcap = (int32_t *)b_fcap.p; A.ccap = (int32_t *)b_ccap.p;
     A.flags = (int32_t *)b_flags.p; A.tier = (const int32_t *)b_tier.p;
+    A.wround = (int32_t *)b_wround.p; A.home = (const int32_t *)b_home.p; A.src = (const int32_t *)b_src.p; A.round = 0; A.count_kept = getenv("PYDEM_PATHS_DEBUG") != nullptr;
+    // per-slot state in two sets: a round's set is filled from the previous round's (k_paths_slots) for the pits that wait
+    int32_t *const set_status[2] = {(int32_t *)b_status.p, (int32_t *)b_status2.p}, *const set_nF[2] = {(int32_t *)b_nF.p, (int32_t *)b_nF2.p},
+                  *const set_nC[2] = {(int32_t *)b_nC.p, (int32_t *)b_nC2.p}, *const set_iters[2] = {(int32_t *)b_iters.p, (int32_t *)b_iters2.p},
+                  *const set_sim[2] = {(int32_t *)b_sim.p, (int32_t *)b_sim2.p};
+    static int keep_env = -1;         // PYDEM_PATHS_KEEP=0: every waiting pit is simulated again every round (the behaviour up to round 4)
+    if (keep_env < 0) { const char *e = getenv("PYDEM_PATHS_KEEP"); keep_env = e ? atoi(e) : 1; }
+    // what belongs to a pending pit (parallel to `pending`): its block of the small-window arrays, its block of the medium-window
+    // pool (-1: none), its slot in the previous round (-1: none)
+    std::vector<int32_t> p_home, p_block, p_src, w_home, w_block, w_src, free_home((size_t)W), free_block;
+    for (int h = 0; h < W; h++) free_home[(size_t)h] = W - 1 - h;
     std::vector<int32_t> pending, win, h_status((size_t)W), h_done((size_t)W), big;
     std::vector<uint8_t> tier((size_t)npits, 0);            // what earlier rounds learned: 1 = the pit leaves the small window, 2 = the medium one too
     std::vector<uint8_t> proven((size_t)npits, 0);          // a medium-window simulation of the pit has completed
@@ -727,7 +790,10 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     HIP_TRY(hipStreamSynchronize(t->stream));
     const double ms_setup = now_ms() - (ts0.tv_sec * 1e3 + ts0.tv_nsec * 1e-6);
     while (!pending.empty() || next < npits) {
-        while ((int)pending.size() < W && next < npits) pending.push_back((int32_t)next++);
+        while ((int)pending.size() < W && next < npits) {
+            pending.push_back((int32_t)next++);
+            p_home.push_back(free_home.back()); free_home.pop_back(); p_block.push_back(-1); p_src.push_back(-1);
+        }
         // only as many large-window pits as one launch holds can take part in a round, and nobody after the first one
         // left out may commit (k_limit below): the pits behind it are not worth simulating this round
         int nw = (int)pending.size();
@@ -737,10 +803,23 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
                 if (tier[(size_t)pending[(size_t)s2]] && ++seen_big > big_max) { nw = s2; break; }
         }
         A.nw = nw;
+        A.round = (int)rounds + 1;
+        {
+            const int cur = (int)(rounds & 1);
+            A.status = set_status[cur]; A.nF = set_nF[cur]; A.nC = set_nC[cur]; A.iters = set_iters[cur]; A.simround = set_sim[cur];
+            A.o_status = set_status[cur ^ 1]; A.o_nF = set_nF[cur ^ 1]; A.o_nC = set_nC[cur ^ 1]; A.o_iters = set_iters[cur ^ 1]; A.o_simround = set_sim[cur ^ 1];
+        }
+        // a pit that sits this round out gives its medium-window block back (the round's participants need at most big_max)
+        for (size_t s2 = (size_t)nw; s2 < pending.size(); s2++)
+            if (p_block[s2] >= 0) { free_block.push_back(p_block[s2]); p_block[s2] = -1; }
         memcpy(pin_window, pending.data(), (size_t)nw * 4);
+        memcpy(pin_home, p_home.data(), (size_t)nw * 4);
         for (int s2 = 0; s2 < nw; s2++) pin_tier[s2] = tier[(size_t)pending[(size_t)s2]];
+        for (int s2 = 0; s2 < nw; s2++) pin_src[s2] = keep_env ? p_src[(size_t)s2] : -1;
         HIP_TRY(hipMemcpyAsync(b_window.p, pin_window, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemcpyAsync(b_tier.p, pin_tier, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(b_home.p, pin_home, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(b_src.p, pin_src, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemsetAsync(b_done.p, 0, (size_t)nw * 4, t->stream));
         const double t_a = now_ms();
         small_runs += nw;
@@ -748,7 +827,7 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         // the medium / large-window simulations of a round: entry q of `big` owns block q of the scratch arrays.  Those of
         // the pits whose tier is known run on the side stream BESIDE the small-window kernel (all simulations of a round read
         // the same committed surface); what the small-window kernel newly sends on follows on the main stream.
-        int k_limit = 0x7FFFFFFF, mid_used = 0, large_used = 0;      // blocks of the two scratch pools handed out in this round
+        int k_limit = 0x7FFFFFFF, large_used = 0;      // (blocks of the large-window pool handed out in this round; a medium-window block belongs to its pit)
         auto launch_large = [&](const std::vector<int> &qs, size_t stage_at, hipStream_t st, int close_round) -> int {
             if (!big_ready) {
                 // scratch blocks (trail, footprint, chain, chain values) sized by window: one pool per tier
@@ -757,6 +836,7 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
                 PYDEM_TRY(b_bigC.get(lease, (size_t)large_max * (BIGF + 1) * 4));
                 PYDEM_TRY(b_bigCV.get(lease, (size_t)large_max * (BIGF + 1) * 8));
                 if (use_mid) {
+                    for (int bq = big_max - 1; bq >= 0; bq--) free_block.push_back(bq);
                     PYDEM_TRY(b_midtrail.get(lease, (size_t)big_max * MIDF * 4));
                     PYDEM_TRY(b_midF.get(lease, (size_t)big_max * MIDF * 4));
                     PYDEM_TRY(b_midC.get(lease, (size_t)big_max * (MIDF + 1) * 4));
@@ -779,7 +859,13 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
             nm = 0;
             for (int q : qs) {
                 const int slot = big[(size_t)q], kk = pending[(size_t)slot];
-                if (tier[(size_t)kk] == 1) { ms[nm] = slot; mq[nm++] = mid_used++; }
+                if (tier[(size_t)kk] == 1) {
+                    if (p_block[(size_t)slot] < 0) {
+                        if (free_block.empty()) { pydem_set_error("pit drain paths: medium-window pool exhausted"); return -5; }
+                        p_block[(size_t)slot] = free_block.back(); free_block.pop_back();
+                    }
+                    ms[nm] = slot; mq[nm++] = p_block[(size_t)slot];
+                }
                 else if (nl < nl_take) { ls[nl] = slot; lq[nl++] = large_used++; }
                 else { ds[nd] = slot; dq[nd++] = 0; if (kk < k_limit) k_limit = kk; }
             }
@@ -787,11 +873,11 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
             HIP_TRY(hipMemcpyAsync(d_ms, ms, (size_t)nb * 8, hipMemcpyHostToDevice, st));
             const int32_t *d_mq = d_ms + nm, *d_ls = d_mq + nm, *d_lq = d_ls + nl, *d_ds = d_lq + nl, *d_dq = d_ds + nd;
             if (nm) hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nm, 64)), dim3(256), 0, st, A, (const int32_t *)d_ms, d_mq, nm, (int32_t *)b_midF.p,
-                                       (int32_t *)b_midC.p, (double *)b_midCV.p, MIDF, MIDF + 1);
+                                       (int32_t *)b_midC.p, (double *)b_midCV.p, MIDF, MIDF + 1, 1);
             if (nl) hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nl, 64)), dim3(256), 0, st, A, d_ls, d_lq, nl, (int32_t *)b_bigF.p,
-                                       (int32_t *)b_bigC.p, (double *)b_bigCV.p, BIGF, BIGF + 1);
+                                       (int32_t *)b_bigC.p, (double *)b_bigCV.p, BIGF, BIGF + 1, 0);
             if (nd) hipLaunchKernelGGL(k_paths_bigslots, dim3(gridp(nd, 64)), dim3(256), 0, st, A, d_ds, d_dq, nd, (int32_t *)b_bigF.p,      // (state "pending": not simulated)
-                                       (int32_t *)b_bigC.p, (double *)b_bigCV.p, BIGF, BIGF + 1);
+                                       (int32_t *)b_bigC.p, (double *)b_bigCV.p, BIGF, BIGF + 1, 0);
             if (nl) hipLaunchKernelGGL((k_paths_big<BWIN, BRCAP>), dim3(nl), dim3(64), big_lds, st, A, d_ls, d_lq, nl, (int32_t *)b_bigtrail.p, BIGF, 0);
             if (nm) hipLaunchKernelGGL((k_paths_big<MWIN, MRCAP>), dim3(nm), dim3(64), mid_lds, st, A, (const int32_t *)d_ms, d_mq, nm, (int32_t *)b_midtrail.p, MIDF,
                                        close_round);
@@ -822,7 +908,7 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
 #else
         hipLaunchKernelGGL(k_paths_small, dim3((unsigned)std::min<int64_t>(cdiv(nw, 4), 256 * PYDEM_SMALL_WAVES)), dim3(256), 0, t->stream, A, nw);
 #endif
-        HIP_TRY(hipMemcpyAsync(pin_status, b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(pin_status, A.status, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(t->stream));
         memcpy(h_status.data(), pin_status, (size_t)nw * 4);
@@ -846,13 +932,17 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         }
         if (n_known) HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_join, 0));
         if (check) {
-            HIP_TRY(hipMemcpyAsync(pin_status, b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipMemcpyAsync(pin_status, A.status, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
             qs.clear();
             for (int q = 0; q < nb_all; q++) {
                 const int kk = pending[(size_t)big[(size_t)q]];
                 if (tier[(size_t)kk] != 1) continue;
-                if (pin_status[big[(size_t)q]] == ST_OVERFLOW) { tier[(size_t)kk] = 2; qs.push_back(q); }
+                if (pin_status[big[(size_t)q]] == ST_OVERFLOW) {
+                    tier[(size_t)kk] = 2; qs.push_back(q);
+                    int32_t &blk = p_block[(size_t)big[(size_t)q]];
+                    if (blk >= 0) { free_block.push_back(blk); blk = -1; }
+                }
                 else proven[(size_t)kk] = 1;
             }
             PYDEM_TRY(launch_large(qs, (size_t)nb_all, t->stream, 0));
@@ -865,8 +955,8 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         hipLaunchKernelGGL(k_paths_commit, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A, (int32_t *)b_done.p, (int32_t *)b_counts.p);
         hipLaunchKernelGGL(k_paths_release, dim3((unsigned)cdiv(nw, 4)), dim3(256), 0, t->stream, A);
         HIP_TRY(hipMemcpyAsync(pin_done, b_done.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
-        HIP_TRY(hipMemcpyAsync(pin_status, b_status.p, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
-        HIP_TRY(hipMemcpyAsync(t->h_counters, b_flags.p, 16, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(pin_status, A.status, (size_t)nw * 4, hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->h_counters, b_flags.p, 32, hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(t->stream));
         memcpy(h_done.data(), pin_done, (size_t)nw * 4);
@@ -876,12 +966,12 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         if (prof) {
             int ncommit = 0;
             for (int s2 = 0; s2 < nw; s2++) ncommit += h_done[(size_t)s2] ? 1 : 0;
-            fprintf(stderr, "  round %lld: window %d, medium + large-window %d, committed %d; ms small %.2f large %.2f commit %.2f\n", (long long)rounds, nw, (int)big.size(),
-                    ncommit, t_b - t_a, t_c - t_b, now_ms() - t_c);
+            fprintf(stderr, "  round %lld: window %d, medium + large-window %d, committed %d; ms small %.2f large %.2f commit %.2f; kept so far %d, found stale %d\n", (long long)rounds, nw, (int)big.size(),
+                    ncommit, t_b - t_a, t_c - t_b, now_ms() - t_c, t->h_counters[4], t->h_counters[5]);
         }
         if (getenv("PYDEM_PATHS_DEBUG") && atoi(getenv("PYDEM_PATHS_DEBUG")) >= 2) {
             std::vector<int32_t> h_it((size_t)nw);
-            HIP_TRY(hipMemcpy(h_it.data(), b_iters.p, (size_t)nw * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(h_it.data(), A.iters, (size_t)nw * 4, hipMemcpyDeviceToHost));
             for (int s2 = 0; s2 < nw; s2++)
                 if (h_done[(size_t)s2]) fprintf(stderr, "  commit k=%d cell=%d status=%d iters=%d\n", pending[(size_t)s2], order_host[pending[(size_t)s2]],
                                                  h_status[(size_t)s2], h_it[(size_t)s2]);
@@ -891,15 +981,26 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         for (int s : big)
             if (h_status[(size_t)s] == ST_OVERFLOW) {
                 uint8_t &tr = tier[(size_t)pending[(size_t)s]];
-                if (tr == 1) { tr = 2; escalated = true; }       // left the medium window: the large one from the next round on
+                if (tr == 1) {                                   // left the medium window: the large one from the next round on
+                    tr = 2; escalated = true;
+                    if (p_block[(size_t)s] >= 0) { free_block.push_back(p_block[(size_t)s]); p_block[(size_t)s] = -1; }
+                }
                 else stuck = true;                               // does not even fit the large window
             }
         if (stuck) { fallback = true; break; }
-        win.clear();
-        for (int s = 0; s < nw; s++) if (!h_done[(size_t)s]) win.push_back(pending[(size_t)s]);
+        win.clear(); w_home.clear(); w_block.clear(); w_src.clear();
+        for (int s = 0; s < nw; s++) {
+            if (!h_done[(size_t)s]) { win.push_back(pending[(size_t)s]); w_home.push_back(p_home[(size_t)s]); w_block.push_back(p_block[(size_t)s]); w_src.push_back(s); }
+            else {
+                free_home.push_back(p_home[(size_t)s]);
+                if (p_block[(size_t)s] >= 0) free_block.push_back(p_block[(size_t)s]);
+            }
+        }
         if ((int)win.size() == nw && !escalated) { fallback = true; break; }          // (cannot happen: the first pit always commits)
-        for (size_t s = (size_t)nw; s < pending.size(); s++) win.push_back(pending[s]);   // the part of the window that sat this round out
-        pending.swap(win);
+        for (size_t s = (size_t)nw; s < pending.size(); s++) {                        // the part of the window that sat this round out
+            win.push_back(pending[s]); w_home.push_back(p_home[s]); w_block.push_back(p_block[s]); w_src.push_back(-1);
+        }
+        pending.swap(win); p_home.swap(w_home); p_block.swap(w_block); p_src.swap(w_src);
     }
     if (rounds_out) *rounds_out = rounds;
 #ifdef PYDEM_PATHS_PROF

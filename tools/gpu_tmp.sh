@@ -1,4 +1,4 @@
 mkdir -p gpurun_out
-KEEP=B bash tools/gpu_ab_lib.sh > gpurun_out/ab_pits.txt 2>&1
-PYDEM_PITS_HANDOVER=1 timeout 300 python tools/leak_probe.py 10 2>&1 | tail -6 > gpurun_out/leak_ab.txt
-timeout 900 python -m pytest tests/test_gpu_pits.py tests/test_gpu_soak.py -m gpu -x -q 2>&1 | tail -4 > gpurun_out/pits_tests.txt
+timeout 1200 python -m pytest tests/test_gpu_conditioning.py tests/test_gpu_large_configs.py tests/test_gpu_parity.py -m gpu -x -q -k "not config4" 2>&1 </dev/null | tail -5 > gpurun_out/cond_tests.txt
+SOAK_NAN=1 timeout 200 python tools/soak_conditioning_device.py 90 790000 2>&1 </dev/null | tail -2 > gpurun_out/soak_cond.txt
+timeout 200 python tools/soak_conditioning_device.py 90 800000 2>&1 </dev/null | tail -2 >> gpurun_out/soak_cond.txt
