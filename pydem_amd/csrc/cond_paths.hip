@@ -703,10 +703,12 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     if (max_iter > 300) return 1;                             // the large window is sized for the reference's 300 iterations
     // speculation window and large-window simulations per round: measured on the 8192^2 SRTM-like tile (341 090 pits, 4885 of
     // them plateau pits): 32768 / 256 -> 56 rounds, 247 ms; 131072 / 2048 -> 26 rounds, 170 ms; larger does not pay.  With the medium
-    // window (its scratch blocks are 65 k entries instead of 410 k): 131072 / 4096 is 3 ms faster than / 2048, 8192 no better
+    // window (its scratch blocks are 65 k entries instead of 410 k): 131072 / 4096 is 3 ms faster than / 2048, 8192 no better.
+    // Round 5, with simulations that outlive their round (a waiting pit costs a look at its footprint, not a simulation): the
+    // whole order in the first window, 524288 / 8192 -> 24 rounds, 55-57 ms against 60-62 with 131072 / 4096 on the same box
     static int win_cap = -1, big_env = -1;
-    if (win_cap < 0) { const char *e = getenv("PYDEM_PATHS_WINDOW"); win_cap = e ? atoi(e) : 131072; if (win_cap < 64) win_cap = 64; }
-    if (big_env < 0) { const char *e = getenv("PYDEM_PATHS_BIG"); big_env = e ? atoi(e) : 4096; if (big_env < 1) big_env = 1; }
+    if (win_cap < 0) { const char *e = getenv("PYDEM_PATHS_WINDOW"); win_cap = e ? atoi(e) : 524288; if (win_cap < 64) win_cap = 64; }
+    if (big_env < 0) { const char *e = getenv("PYDEM_PATHS_BIG"); big_env = e ? atoi(e) : 8192; if (big_env < 1) big_env = 1; }
     int big_max = big_env;
     struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
     const int W = (int)(npits < win_cap ? npits : win_cap);

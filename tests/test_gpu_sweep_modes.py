@@ -66,7 +66,9 @@ def test_circular_drainage_replay_in_queue_schedule():
                                  {'PYDEM_FLAT_COOP': '1000000', 'PYDEM_FLAT_COOP_WG': '7'},     # resident workgroups from the second look on
                                  {'PYDEM_PATHS_MID': '0'},                       # pit drain paths without the medium window
                                  {'PYDEM_PATHS_WINDOW': '64', 'PYDEM_PATHS_BIG': '2'},          # tiny speculation windows: many rounds, capped large simulations
-                                 {'PYDEM_PATHS_BIG': '8', 'PYDEM_PATHS_LARGE': '1'}])           # one large-window simulation per round: the others wait
+                                 {'PYDEM_PATHS_BIG': '8', 'PYDEM_PATHS_LARGE': '1'},            # one large-window simulation per round: the others wait
+                                 {'PYDEM_PATHS_KEEP': '0'},                      # every waiting pit simulated again every round (rounds 1-4)
+                                 {'PYDEM_PATHS_WINDOW': '131072', 'PYDEM_PATHS_BIG': '3'}])   # kept simulations with a medium-window pool of three blocks
 def test_conditioning_schedules_match_the_host_twin(env):
     """The schedule switches of the device conditioning (csrc/cond_device.hip, csrc/cond_paths.hip) change how the work is
     cut, never the result: the conditioning tests once more per setting (read once per process, hence the subprocess)."""
