@@ -264,6 +264,24 @@ int pydem_board_refresh(pydem_board *b, pydem_comm *c, int n_wave, const int *wa
 int pydem_board_refresh_stage(pydem_board *b, int n_wave, const int *wave_tiles, double *host_out, int64_t cap, int64_t *n_doubles);
 int pydem_board_refresh_unstage(pydem_board *b, int n_wave, const int *wave_tiles, const double *host_in, int64_t n_doubles);
 int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *full, unsigned long long *out);
+/* Up to k_waves (<= 64) waves of the same schedule queued back to back WITHOUT a look from the manager (the reference's manager
+ * loop, pydem/process_manager.py:1214-1246, polls its workers and re-ranks after every completion; for a mosaic of at most
+ * 2 * n_workers tiles the ranking :1177-1188 selects every tile with a positive metric, so the wave can be chosen by a
+ * kernel): per wave a selection kernel (candidates = positive metric or 'todo' pixels dropped on the mosaic border, strips
+ * changed since the tile's last round), for every tile of this rank a condensed round + the gather of its lines gated by the
+ * wave's member word, one ncclAllReduce(sum) of the whole staging buffer when `c` is given, the copy to the board and the
+ * evaluation of the tiles that read the wave's lines.  `state`: 520 64-bit words in and out --
+ *   [0] bit per tile: its rounds may be queued (a candidate without the bit stops the batch BEFORE its wave: the host runs
+ *   that wave, e.g. a tile's first round, which builds its fix-up state), [1] out: 0 = all k_waves ran, 1 = no candidate
+ *   left (the host applies the tie-break rule :274 or ends the fix-up), 2 = a candidate needs the host, 3 = wave limit,
+ *   [2] out: waves run, [3] waves allowed, [8+a] / [72+a] metric numerator / denominator of tile a as the schedule holds
+ *   them (stale for diagonal neighbours like check_mets :1116-1136), [136+a] / [200+a] strip hash of a's last round / whether
+ *   it has one, [264+a] bit mask of the tiles reading a line of a, [328+a] a and its four side neighbours, [392+w] out: the
+ *   members of wave w, [7] out: the waves ran as captured hipGraphs (one launch per wave; PYDEM_EDGE_GRAPH=0: plain launches),
+ *   [456+a] scratch (round stamps).  `scal_out` as `out` of pydem_board_eval.  pydem_tile_edge_queue_ready: 1 when the tile's rounds can
+ *   be queued (condensed fix-up state built by its first round, strips buffers attached by pydem_board_set_desc). */
+int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned long long *state, unsigned long long *scal_out);
+int pydem_tile_edge_queue_ready(pydem_tile *t);
 int pydem_board_download(pydem_board *b, double *out);
 
 /* ---- elevation conditioning: host-side inner loops (no device work; pydem_amd/conditioning.py keeps the

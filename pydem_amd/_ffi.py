@@ -106,6 +106,8 @@ SYMBOLS = {
     'pydem_board_refresh_unstage': (C.c_int, [_P, C.c_int, _P, _P, C.c_int64]),
     'pydem_board_eval': (C.c_int, [_P, C.c_int, _P, _P, _P]),
     'pydem_board_download': (C.c_int, [_P, _P]),
+    'pydem_board_run_waves': (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    'pydem_tile_edge_queue_ready': (C.c_int, [_P]),
 }
 
 _lib = None
@@ -286,6 +288,10 @@ class Tile(object):
     def uca_edge_flush(self):
         check(self.lib.pydem_uca_edge_flush(self._h))
 
+    def edge_queue_ready(self):
+        """Can the next rounds of this tile be queued behind a device-side wave selection (Board.run_waves)?"""
+        return bool(self.lib.pydem_tile_edge_queue_ready(self._h))
+
     def uca_edge_round_dev(self, opt):
         """Incremental edge round with the strips the edge board wrote into the tile's buffers."""
         check(self.lib.pydem_uca_edge_round_inc_dev(self._h, C.byref(opt)))
@@ -392,6 +398,18 @@ class Board(object):
         out = np.empty(self.n_doubles, np.float64)
         check(self.lib.pydem_board_download(self._h, out.ctypes.data_as(_P)))
         return out
+
+    # layout of the queued waves' state (csrc/comm.hip, SCH_*)
+    SCH_OK, SCH_STOP, SCH_NWAVES, SCH_LIMIT, SCH_GRAPH, SCH_ND, SCH_PD, SCH_HASH, SCH_HAS, SCH_READERS, SCH_NBRS, SCH_LOG, SCH_WORDS = \
+        0, 1, 2, 3, 7, 8, 72, 136, 200, 264, 328, 392, 520
+
+    def run_waves(self, comm, k_waves, state):
+        """Up to k_waves waves without a host look (pydem_board_run_waves); `state` (uint64[520]) is updated in place; returns the
+        scalars of all tiles like eval()."""
+        assert state.dtype == np.uint64 and state.size == self.SCH_WORDS and state.flags.c_contiguous
+        check(self.lib.pydem_board_run_waves(self._h, comm._h if comm is not None else None, int(k_waves), state.ctypes.data_as(_P),
+                                             self._out.ctypes.data_as(_P)))
+        return self._out
 
 
 class Comm(object):

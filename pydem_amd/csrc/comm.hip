@@ -9,6 +9,7 @@
 #include "internal.h"
 #include <rccl/rccl.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 struct pydem_comm {
@@ -216,9 +217,34 @@ struct pydem_board {
     unsigned long long *scal = nullptr, *h_scal = nullptr;   // [n_tiles][8]
     // per tile: where its lines live in the board, and (tiles of this rank) how to gather them from the tile
     struct TileLines { int64_t mb_start = 0, size = 0; pydem_tile *tile = nullptr; int count = 0; pydem_pack_line *lines = nullptr;
+                       std::vector<pydem_pack_line> h_lines;
                        std::vector<std::pair<int, int64_t>> where; };      // (axis, index) of the lines: the tile's condensed edge rounds watch them
     std::vector<TileLines> tl;
+    // queued waves (pydem_board_run_waves): the schedule's state on the device + a pinned copy
+    unsigned long long *sched = nullptr, *h_sched = nullptr;
+    void *q_tiles = nullptr; void *q_lines = nullptr; int q_count = 0, q_nlines = 0; int64_t q_nper = 1;   // tables of the queued rounds / packs
+    hipGraphExec_t wave_exec[2] = {nullptr, nullptr};   // one wave, captured: before / after the collective (one graph without one)
+    unsigned long long wave_ok = 0; bool wave_comm = false; hipStream_t wave_stream = nullptr;   // what the graphs were captured for
+    bool graph_failed = false, tables_valid = false;
 };
+
+// ---- queued waves: layout of the schedule's state (64-bit words; the same table on the host, pydem_amd/_ffi.py) ----
+// [0] tiles whose rounds may be queued (bit per tile)   [1] out: why the batch stopped (0 = it did not)
+// [2] out: waves run                                    [3] waves allowed
+// [4] tiles whose metric is read again before the next selection (the last wave + its side neighbours)
+// [5] members of the current wave                       [6] tiles the current wave's lines are read by
+// [8 + a] metric numerator / [72 + a] denominator of tile a as the host schedule holds them (a diagonal neighbour keeps its
+// old numbers, process_manager.py:1116-1136)            [136 + a] strip hash of a's last round, [200 + a] whether it has one
+// [264 + a] tiles that read a line of a                 [328 + a] a and its four side neighbours
+// [392 + w] members of wave w of the batch
+// [456 + a] the tile's round counter when the batch began (seed stamps)   [7] out: the waves ran as captured graphs
+enum { SCH_OK = 0, SCH_STOP = 1, SCH_NWAVES = 2, SCH_LIMIT = 3, SCH_CHECK = 4, SCH_WAVE = 5, SCH_AFFECTED = 6, SCH_GRAPH = 7, SCH_ND = 8,
+       SCH_PD = 72, SCH_HASH = 136, SCH_HAS = 200, SCH_READERS = 264, SCH_NBRS = 328, SCH_LOG = 392, SCH_ROUND = 456, SCH_WORDS = 520 };
+
+static void board_drop_graphs(pydem_board *b)
+{
+    for (auto &e : b->wave_exec) if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
+}
 
 namespace {
 
@@ -230,9 +256,11 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
 
 // one thread per (side, position) of one tile
 __global__ __launch_bounds__(256) void k_board_eval(const double *__restrict__ mb, const pydem_board_desc *__restrict__ descs,
-                                                    pydem_board_list Lst, unsigned long long *__restrict__ scal)
+                                                    pydem_board_list Lst, unsigned long long *__restrict__ scal,
+                                                    const unsigned long long *__restrict__ gate)
 {
     const int tile = Lst.tile[blockIdx.y], full = Lst.full[blockIdx.y];
+    if (gate && !((*gate >> tile) & 1ull)) return;      // queued waves: only the tiles that read a line of the wave
     const pydem_board_desc D = descs[tile];
     const int n = D.n, m = D.m;
     const int64_t total = 2 * (int64_t)n + 2 * (int64_t)m;
@@ -347,6 +375,89 @@ __global__ void k_board_scatter(const double *__restrict__ wb, double *__restric
     }
 }
 
+// ---- queued waves -------------------------------------------------------------------------------------------------
+// One wave of ProcessManager._process_uca_edges_pool_device chosen on the device (one thread per tile, one workgroup): the
+// candidates are the tiles whose metric is positive or that still drop 'todo' pixels on the mosaic border, and whose
+// strips changed since their last round; with at most 2 * n_workers tiles the ranking selects every candidate, so the
+// wave IS the candidate set.  The batch stops when there is no candidate (the host decides about the tie-break rule), when a
+// candidate's round cannot be queued (its first round builds the fix-up state on the host) or at the wave limit.
+__global__ void k_sched_select(unsigned long long *__restrict__ S, unsigned long long *__restrict__ scal, int n_tiles)
+{
+    const int a = threadIdx.x;
+    __shared__ unsigned long long s_wave, s_aff, s_chk;
+    if (a == 0) { s_wave = 0; s_aff = 0; s_chk = 0; }
+    __syncthreads();
+    const bool live = S[SCH_STOP] == 0;
+    bool cand = false;
+    if (live && a < n_tiles) {
+        if ((S[SCH_CHECK] >> a) & 1ull) { S[SCH_ND + a] = scal[(size_t)a * 8 + 0]; S[SCH_PD + a] = scal[(size_t)a * 8 + 1]; }
+        cand = (S[SCH_ND + a] > 0 || scal[(size_t)a * 8 + 2] != 0) && !(S[SCH_HAS + a] && S[SCH_HASH + a] == scal[(size_t)a * 8 + 5]);
+        if (cand) atomicOr(&s_wave, 1ull << a);
+    }
+    __syncthreads();
+    const unsigned long long wave = s_wave;
+    int stop = 0;
+    if (live) {
+        if (S[SCH_NWAVES] >= S[SCH_LIMIT]) stop = 3;
+        else if (wave == 0) stop = 1;
+        else if (wave & ~S[SCH_OK]) stop = 2;
+    }
+    const bool run = live && stop == 0;
+    if (run && cand) {
+        S[SCH_HASH + a] = scal[(size_t)a * 8 + 5]; S[SCH_HAS + a] = 1;
+        atomicOr(&s_aff, S[SCH_READERS + a]);
+        atomicOr(&s_chk, S[SCH_NBRS + a]);
+    }
+    __syncthreads();
+    // the evaluation kernel accumulates into the scalars of the tiles it visits
+    if (run && a < n_tiles && ((s_aff >> a) & 1ull))
+        for (int j = 0; j < 8; j++) scal[(size_t)a * 8 + j] = 0ull;
+    if (a == 0) {
+        if (run) { S[SCH_LOG + S[SCH_NWAVES]] = wave; S[SCH_NWAVES] += 1; S[SCH_WAVE] = wave; S[SCH_AFFECTED] = s_aff; S[SCH_CHECK] = s_chk; }
+        else { S[SCH_WAVE] = 0; S[SCH_AFFECTED] = 0; S[SCH_CHECK] = 0; if (live) S[SCH_STOP] = (unsigned long long)stop; }
+    }
+}
+
+// end of a batch: the metrics of the last wave's neighbourhood, as the next selection would read them
+__global__ void k_sched_settle(unsigned long long *__restrict__ S, const unsigned long long *__restrict__ scal, int n_tiles)
+{
+    const int a = threadIdx.x;
+    if (a < n_tiles && ((S[SCH_CHECK] >> a) & 1ull)) { S[SCH_ND + a] = scal[(size_t)a * 8 + 0]; S[SCH_PD + a] = scal[(size_t)a * 8 + 1]; }
+    __syncthreads();
+    if (a == 0) S[SCH_CHECK] = 0;
+}
+
+// the lines of all tiles of this rank -> staging at the board's own offsets, for the members of the wave (blockIdx.y = line)
+struct pydem_pack_line_q { pydem_pack_line P; int64_t abs; int32_t tile, pad; };
+__global__ void k_board_pack_gated(const pydem_pack_line_q *__restrict__ lines, int nlines, double *__restrict__ wb,
+                                   const unsigned long long *__restrict__ gate)
+{
+    const unsigned long long wave = *gate;
+    for (int l = blockIdx.y; l < nlines; l += gridDim.y) {
+        const pydem_pack_line_q Q = lines[l];
+        if (!((wave >> Q.tile) & 1ull)) continue;
+        const pydem_pack_line &P = Q.P;
+        double *dst = wb + Q.abs;
+        if (P.bytes == 8) {
+            const double *src = (const double *)P.src;
+            for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < P.count; k += (int64_t)gridDim.x * blockDim.x) dst[k] = src[k * P.stride];
+        } else {
+            const uint8_t *src = (const uint8_t *)P.src;
+            for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < P.count; k += (int64_t)gridDim.x * blockDim.x) dst[k] = (double)src[k * P.stride];
+        }
+    }
+}
+
+// staging -> board for the members of the wave (blockIdx.y = tile; segment s of S belongs to tile s)
+__global__ void k_board_scatter_gated(const double *__restrict__ wb, double *__restrict__ mb, pydem_board_segs S,
+                                      const unsigned long long *__restrict__ gate)
+{
+    const int s = blockIdx.y;
+    if (!((*gate >> s) & 1ull)) return;
+    const int64_t src = S.src[s], dst = S.dst[s], cnt = S.cnt[s];
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * blockDim.x) mb[dst + k] = wb[src + k];
+}
+
 __global__ void k_board_zero(unsigned long long *scal, pydem_board_list Lst)
 {
     const int k = threadIdx.x >> 3, j = threadIdx.x & 7;
@@ -382,6 +493,11 @@ int pydem_board_destroy(pydem_board *b)
     for (void *p : {(void *)b->mb, (void *)b->wb, (void *)b->desc, (void *)b->scal}) if (p) (void)hipFree(p);
     for (auto &T : b->tl) if (T.lines) (void)hipFree(T.lines);
     if (b->h_scal) (void)hipHostFree(b->h_scal);
+    if (b->sched) (void)hipFree(b->sched);
+    if (b->h_sched) (void)hipHostFree(b->h_sched);
+    board_drop_graphs(b);
+    if (b->q_tiles) (void)hipFree(b->q_tiles);
+    if (b->q_lines) (void)hipFree(b->q_lines);
     if (b->ev) (void)hipEventDestroy(b->ev);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -456,6 +572,7 @@ int pydem_board_set_lines(pydem_board *b, int index, int64_t mb_start, int64_t s
     HIP_TRY(hipMemcpyAsync(T.lines, h.data(), (size_t)count * sizeof(pydem_pack_line), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     T.count = count;
+    T.h_lines = h;
     return 0;
 }
 
@@ -570,7 +687,7 @@ int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *ful
         }
         const int g = (int)(cdiv(most, 256) < 64 ? cdiv(most, 256) : 64);
         hipLaunchKernelGGL(k_board_zero, dim3(1), dim3(512), 0, b->stream, b->scal, Lst);
-        hipLaunchKernelGGL(k_board_eval, dim3(g, Lst.n), dim3(256), 0, b->stream, b->mb, b->desc, Lst, b->scal);
+        hipLaunchKernelGGL(k_board_eval, dim3(g, Lst.n), dim3(256), 0, b->stream, b->mb, b->desc, Lst, b->scal, (const unsigned long long *)nullptr);
     }
     HIP_TRY(hipMemcpyAsync(b->h_scal, b->scal, (size_t)b->n_tiles * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipGetLastError());
@@ -578,6 +695,148 @@ int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *ful
     memcpy(out, b->h_scal, (size_t)b->n_tiles * 8 * sizeof(unsigned long long));
     return 0;
 }
+
+// Up to `k_waves` waves of the fix-up queued back to back without a look from the host (process_manager.py:1214-1246 as
+// deterministic waves; for a mosaic of at most 2 * n_workers tiles, where the ranking selects every candidate): per wave
+// the selection kernel, for every tile of this rank a condensed round and the gather of its lines (both gated by the
+// wave's member word, on the tile's stream), the sum over the ranks when `c` is given (the WHOLE staging buffer: its size
+// must not depend on the wave), the copy to the board and the evaluation of the tiles that read the wave's lines.
+// `state` (SCH_WORDS 64-bit words, layout above) carries the schedule in and out; `scal_out` as in pydem_board_eval.
+// Every tile of this rank must satisfy tile_edge_queue_ready (the caller asks pydem_tile_edge_queue_ready first) unless its
+// bit in state[0] is clear: a candidate without the bit stops the batch before its wave.
+int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned long long *state, unsigned long long *scal_out)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->n_tiles > 64) { pydem_set_error("pydem_board_run_waves: at most 64 tiles"); return -2; }
+    if (k_waves < 1 || k_waves > SCH_ROUND - SCH_LOG) { pydem_set_error("pydem_board_run_waves: 1..64 waves per batch"); return -2; }
+    if ((int)b->tl.size() != b->n_tiles) { pydem_set_error("pydem_board_run_waves: pydem_board_set_lines first"); return -2; }
+    if (!b->sched) {
+        HIP_TRY(hipMalloc((void **)&b->sched, SCH_WORDS * sizeof(unsigned long long)));
+        HIP_TRY(hipHostMalloc((void **)&b->h_sched, SCH_WORDS * sizeof(unsigned long long)));
+    }
+    if (b->cap > b->wcap) {
+        if (b->wb) HIP_TRY(hipFree(b->wb));
+        HIP_TRY(dev_malloc((void **)&b->wb, (size_t)b->cap * 8));
+        b->wcap = b->cap;
+        board_drop_graphs(b); b->tables_valid = false;   // (they hold the old staging buffer)
+    }
+    pydem_board_segs S;
+    pydem_board_list Lst;
+    S.n = b->n_tiles; Lst.n = b->n_tiles;
+    int64_t most = 1;
+    std::vector<int> mine;
+    const unsigned long long ok = state[SCH_OK];
+    for (int i = 0; i < b->n_tiles; i++) {
+        pydem_board::TileLines &T = b->tl[(size_t)i];
+        S.src[i] = T.mb_start; S.dst[i] = T.mb_start; S.cnt[i] = T.size;
+        Lst.tile[i] = i; Lst.full[i] = 0;
+        const pydem_board_desc &D = b->h_desc[(size_t)i];
+        most = std::max<int64_t>(most, 2 * (int64_t)D.n + 2 * (int64_t)D.m);
+        state[SCH_ROUND + i] = 0;
+        if (!T.tile || !((ok >> i) & 1ull)) continue;
+        mine.push_back(i);
+        if (!tile_edge_queue_ready(T.tile)) { pydem_set_error("pydem_board_run_waves: tile %d cannot queue its rounds", i); return -3; }
+        for (const auto &ln : T.where)             // (a line registered after the tile's condensed graph was built)
+            if (!tile_line_watched(T.tile, ln.first, ln.second)) { pydem_set_error("pydem_board_run_waves: tile %d: a board line is not watched", i); return -3; }
+        state[SCH_ROUND + i] = tile_edge_round_counter(T.tile);
+    }
+    const int g_eval = (int)(cdiv(most, 256) < 64 ? cdiv(most, 256) : 64);
+    // The whole batch runs on ONE stream (a single tile's own, otherwise the board's: the tiles' streams are idle -- every
+    // host-driven wave ends with a synchronised evaluation), and a wave is a fixed handful of launches whatever the number
+    // of tiles: the rounds and the gathers go through device tables (entry = tile), gated by the wave's member word.
+    hipStream_t bs = mine.size() == 1 ? b->tl[(size_t)mine[0]].tile->stream : b->stream;
+    const bool rebuild = !b->tables_valid || b->wave_ok != ok;
+    if (rebuild) {
+        HIP_TRY(hipStreamSynchronize(bs));
+        board_drop_graphs(b);
+        if (b->q_tiles) { HIP_TRY(hipFree(b->q_tiles)); b->q_tiles = nullptr; }
+        if (b->q_lines) { HIP_TRY(hipFree(b->q_lines)); b->q_lines = nullptr; }
+        const size_t qb = tile_edge_queue_desc_bytes();
+        std::vector<char> hq(qb * std::max<size_t>(mine.size(), 1));
+        std::vector<pydem_pack_line_q> hl;
+        b->q_nper = 1;
+        for (size_t k = 0; k < mine.size(); k++) {
+            const int i = mine[k];
+            pydem_board::TileLines &T = b->tl[(size_t)i];
+            int64_t nper = 0;
+            PYDEM_TRY(tile_edge_queue_desc(T.tile, hq.data() + k * qb, b->sched + SCH_WAVE, i, b->sched + SCH_ROUND + i, b->sched + SCH_NWAVES, &nper));
+            b->q_nper = std::max(b->q_nper, nper);
+            for (const auto &P : T.h_lines) { pydem_pack_line_q Q; Q.P = P; Q.abs = T.mb_start + P.rel; Q.tile = i; Q.pad = 0; hl.push_back(Q); }
+        }
+        b->q_count = (int)mine.size(); b->q_nlines = (int)hl.size();
+        if (b->q_count) {
+            HIP_TRY(hipMalloc(&b->q_tiles, hq.size()));
+            HIP_TRY(hipMemcpy(b->q_tiles, hq.data(), hq.size(), hipMemcpyHostToDevice));
+        }
+        if (b->q_nlines) {
+            HIP_TRY(hipMalloc(&b->q_lines, hl.size() * sizeof(pydem_pack_line_q)));
+            HIP_TRY(hipMemcpy(b->q_lines, hl.data(), hl.size() * sizeof(pydem_pack_line_q), hipMemcpyHostToDevice));
+        }
+        b->tables_valid = true; b->wave_ok = ok;
+    }
+    // One wave, in two parts around the collective.  Everything a launch needs is read on the device (member words, round
+    // stamps), so the parts can be captured once and replayed wave after wave.
+    auto issue = [&](int part) -> int {
+        if (part == 0) {
+            hipLaunchKernelGGL(k_sched_select, dim3(1), dim3(64), 0, bs, b->sched, b->scal, b->n_tiles);
+            if (c) HIP_TRY(hipMemsetAsync(b->wb, 0, (size_t)b->cap * 8, bs));
+            PYDEM_TRY(stage_edge_rounds_queued(bs, b->q_tiles, b->q_count, b->q_nper));
+            if (b->q_nlines > 0)
+                hipLaunchKernelGGL(k_board_pack_gated, dim3(8, b->q_nlines), dim3(256), 0, bs, (const pydem_pack_line_q *)b->q_lines, b->q_nlines,
+                                   b->wb, b->sched + SCH_WAVE);
+        } else {
+            hipLaunchKernelGGL(k_board_scatter_gated, dim3(16, b->n_tiles), dim3(256), 0, bs, b->wb, b->mb, S, b->sched + SCH_WAVE);
+            hipLaunchKernelGGL(k_board_eval, dim3(g_eval, b->n_tiles), dim3(256), 0, bs, b->mb, b->desc, Lst, b->scal, b->sched + SCH_AFFECTED);
+        }
+        return 0;
+    };
+    // ---- the wave as a graph (PYDEM_EDGE_GRAPH=0: plain launches): one launch per wave instead of six
+    static int use_graph = -1;
+    if (use_graph < 0) { const char *e = getenv("PYDEM_EDGE_GRAPH"); use_graph = e ? atoi(e) : 1; }
+    const int n_parts = c ? 2 : 1;                   // (without a collective both parts are one graph)
+    if (use_graph && !b->graph_failed && (!b->wave_exec[0] || b->wave_comm != (c != nullptr) || b->wave_stream != bs)) {
+        board_drop_graphs(b);
+        HIP_TRY(hipStreamSynchronize(bs));
+        for (int part = 0; part < n_parts && !b->graph_failed; part++) {
+            hipGraph_t g = nullptr;
+            if (hipStreamBeginCapture(bs, hipStreamCaptureModeRelaxed) != hipSuccess) { b->graph_failed = true; break; }
+            int rc = issue(part);
+            if (rc == 0 && !c) rc = issue(1);
+            const hipError_t ec = hipStreamEndCapture(bs, &g);
+            if (rc != 0 || ec != hipSuccess || !g || hipGraphInstantiate(&b->wave_exec[part], g, nullptr, nullptr, 0) != hipSuccess)
+                b->graph_failed = true;
+            if (g) (void)hipGraphDestroy(g);
+        }
+        if (b->graph_failed) { (void)hipGetLastError(); board_drop_graphs(b); }
+        b->wave_comm = c != nullptr; b->wave_stream = bs;
+    }
+    const bool graphs = use_graph && !b->graph_failed && b->wave_exec[0];
+    state[SCH_STOP] = 0; state[SCH_NWAVES] = 0; state[SCH_CHECK] = 0; state[SCH_WAVE] = 0; state[SCH_AFFECTED] = 0;
+    if (state[SCH_LIMIT] > (unsigned long long)k_waves) state[SCH_LIMIT] = (unsigned long long)k_waves;
+    memcpy(b->h_sched, state, SCH_WORDS * sizeof(unsigned long long));
+    HIP_TRY(hipStreamSynchronize(b->stream));       // (the evaluations of the host-driven waves ran there)
+    HIP_TRY(hipMemcpyAsync(b->sched, b->h_sched, SCH_WORDS * sizeof(unsigned long long), hipMemcpyHostToDevice, bs));
+    for (int w = 0; w < k_waves; w++) {
+        if (graphs) HIP_TRY(hipGraphLaunch(b->wave_exec[0], bs)); else PYDEM_TRY(issue(0));
+        if (c) NCCL_TRY(ncclAllReduce(b->wb, b->wb, (size_t)b->cap, ncclDouble, ncclSum, c->comm, bs));
+        if (graphs) { if (c) HIP_TRY(hipGraphLaunch(b->wave_exec[1], bs)); }
+        else PYDEM_TRY(issue(1));
+    }
+    // the metrics of the last wave's neighbourhood, as the next selection would read them
+    hipLaunchKernelGGL(k_sched_settle, dim3(1), dim3(64), 0, bs, b->sched, b->scal, b->n_tiles);
+    HIP_TRY(hipMemcpyAsync(b->h_sched, b->sched, SCH_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, bs));
+    HIP_TRY(hipMemcpyAsync(b->h_scal, b->scal, (size_t)b->n_tiles * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, bs));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(bs));
+    memcpy(state, b->h_sched, SCH_WORDS * sizeof(unsigned long long));
+    memcpy(scal_out, b->h_scal, (size_t)b->n_tiles * 8 * sizeof(unsigned long long));
+    for (int i : mine) tile_edge_rounds_ran(b->tl[(size_t)i].tile, (int)state[SCH_NWAVES]);
+    state[SCH_GRAPH] = graphs ? 1 : 0;
+    return 0;
+}
+
+// may the rounds of this tile be queued (pydem_board_run_waves)?  1 / 0
+int pydem_tile_edge_queue_ready(pydem_tile *t) { return t && tile_edge_queue_ready(t) ? 1 : 0; }
 
 // debugging / tests: a copy of the board
 int pydem_board_download(pydem_board *b, double *out)

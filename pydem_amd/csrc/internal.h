@@ -156,6 +156,14 @@ int stage_edge_flush(pydem_tile *t);
 // condensed incremental rounds: the interior of the tile catches up with the watched lines (no-op otherwise); reads of the
 // edge fields that are not watched lines call it first
 int stage_edge_catchup(pydem_tile *t);
+// queued waves of the fix-up (comm.hip: pydem_board_run_waves): a condensed round gated by a device word
+bool tile_edge_queue_ready(const pydem_tile *t);
+size_t tile_edge_queue_desc_bytes();
+int tile_edge_queue_desc(pydem_tile *t, void *out, const unsigned long long *gate, int bit, const unsigned long long *round_base,
+                         const unsigned long long *round_add, int64_t *nper);
+int stage_edge_rounds_queued(hipStream_t s, const void *d_q, int count, int64_t max_nper);
+unsigned long long tile_edge_round_counter(const pydem_tile *t);
+void tile_edge_rounds_ran(pydem_tile *t, int waves);
 void tile_watch_line(pydem_tile *t, int axis, int64_t index);
 bool tile_line_watched(const pydem_tile *t, int axis, int64_t index);
 int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double source_tol, int peaks, int pits, int artefacts_only);

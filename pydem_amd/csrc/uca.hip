@@ -3725,6 +3725,7 @@ static int cond_args(pydem_tile *t, CondArgsE &X)
     PYDEM_TRY(cinc_args(t, X.C));
     X.node = (CNode *)t->cond_node; X.nw = t->cond_nw; X.edge = (const CEdge *)t->cond_edge; X.slot = t->cond_slot;
     X.q0 = t->cond_q0; X.q1 = t->cond_q1; X.nanq = t->cond_nanq; X.nan_cap = t->cond_nan_cap; X.cnt = t->cond_cnt;
+    X.gate = nullptr; X.gate_bit = 0; X.round_base = nullptr; X.round_add = nullptr;
     return 0;
 }
 
@@ -4064,6 +4065,54 @@ int stage_edge_round_inc(pydem_tile *t, const pydem_options *opt, const double *
     }
 #endif
     return 0;
+}
+
+// Queued waves of the fix-up (pydem_board_run_waves, comm.hip): can this tile's next round be queued without the host knowing
+// whether it will run?  Only the condensed form qualifies (two launches, no host look), after the tile's first round has
+// built it.
+bool tile_edge_queue_ready(const pydem_tile *t)
+{
+    return t->einc_ready && t->einc_compact && t->cond_live && t->circular_cells == 0 && t->s_data && t->s_flags;
+}
+
+// Entry of the queued waves' tile table (opaque to comm.hip): the condensed round of tile t, run only while bit `bit` of the
+// device word *gate is set (the members of a queued wave are chosen on the device); the strips are in the tile's buffers
+// (written by the board's evaluation kernel).  The seed stamp is *round_base + *round_add + 1 (mod 65535), both read on the
+// device: the launches can be captured in a graph and replayed wave after wave.  The caller advances the tile's round
+// counter by the waves it ran (tile_edge_rounds_ran).
+size_t tile_edge_queue_desc_bytes() { return sizeof(QTile); }
+
+int tile_edge_queue_desc(pydem_tile *t, void *out, const unsigned long long *gate, int bit, const unsigned long long *round_base,
+                         const unsigned long long *round_add, int64_t *nper)
+{
+    if (!tile_edge_queue_ready(t)) { pydem_set_error("queued edge round: the tile's condensed fix-up state is not built"); return -3; }
+    const int n = (int)t->n, m = (int)t->m;
+    QTile q;
+    memset(&q, 0, sizeof(q));
+    PYDEM_TRY(cond_args(t, q.X));
+    q.X.gate = gate; q.X.gate_bit = bit; q.X.round_base = round_base; q.X.round_add = round_add;
+    q.sdata = t->s_data; q.sflags = t->s_flags; q.L = n > m ? n : m;
+    q.nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
+    *nper = q.nper;
+    memcpy(out, &q, sizeof(q));
+    return 0;
+}
+
+// the rounds of `count` tiles (device table d_q), two launches on stream s
+int stage_edge_rounds_queued(hipStream_t s, const void *d_q, int count, int64_t max_nper)
+{
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(k_cond_seed_q, dim3((unsigned)cdiv(max_nper, 128), (unsigned)count), dim3(128), 0, s, (const QTile *)d_q);
+    hipLaunchKernelGGL(k_cond_run_q, dim3((unsigned)count), dim3(COND_THREADS), 0, s, (const QTile *)d_q);
+    return 0;
+}
+
+unsigned long long tile_edge_round_counter(const pydem_tile *t) { return (unsigned long long)t->einc_round; }
+
+void tile_edge_rounds_ran(pydem_tile *t, int waves)
+{
+    t->einc_round += waves;
+    if (waves > 0) t->cond_pending = true;
 }
 
 int stage_edge_flush(pydem_tile *t)

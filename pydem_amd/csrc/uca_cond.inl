@@ -59,7 +59,23 @@ struct CondArgsE {
     int32_t *q0, *q1;            // level queues (nw entries each)
     int32_t *nanq; int32_t nan_cap;   // NaN flood list (every edge can enter it once per flood)
     int32_t *cnt;                // [0] first level, [1] NaN seeds
+    // queued waves (pydem_board_run_waves): the round runs only when bit `gate_bit` of *gate is set -- the wave's members are
+    // chosen on the device, the host has queued the round for every tile (gate == nullptr: an ordinary round)
+    const unsigned long long *gate; int32_t gate_bit;
+    // ... and its seed stamp is read on the device as well (the queued wave is a captured graph: no per-wave kernel argument):
+    // the tile's round counter when the batch began + the number of the wave in the batch
+    const unsigned long long *round_base, *round_add;
 };
+
+__device__ __forceinline__ bool cond_gated_off(const CondArgsE &X)
+{
+    return X.gate != nullptr && !((*X.gate >> X.gate_bit) & 1ull);
+}
+__device__ __forceinline__ uint32_t cond_round16(const CondArgsE &X)
+{
+    return X.round_base ? (uint32_t)((*X.round_base + *X.round_add) % 65535ull) + 1u : X.C.round16;
+}
+
 
 __device__ __forceinline__ int32_t cond_wid(const CIncArgs &E, int32_t c)
 {
@@ -70,13 +86,13 @@ __device__ __forceinline__ int32_t cond_wid(const CIncArgs &E, int32_t c)
 __device__ __forceinline__ CEdge cond_edge(const CondArgsE &X, const CNode &N, int e) { return e < 2 ? N.e_inl[e] : X.edge[N.out_base + e - 2]; }
 
 // strips -> events on the perimeter, exactly k_cinc_seed with the watched nodes in place of the records
-__global__ void k_cond_seed(CondArgsE X, const double *__restrict__ sdata, const uint8_t *__restrict__ sdone,
-                            const uint8_t *__restrict__ stodo, int L)
+__device__ __forceinline__ void cond_seed_cell(const CondArgsE &X, const double *__restrict__ sdata, const uint8_t *__restrict__ sdone,
+                                               const uint8_t *__restrict__ stodo, int L, int64_t p)
 {
     const CIncArgs &E = X.C;
+    const uint32_t round16 = cond_round16(X);
     const int n = E.G.n, m = E.G.m;
     const int64_t nper = 2 * (int64_t)m + 2 * (int64_t)(n - 2);
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nper) return;
     int i, j;
     perim_cell(p, n, m, i, j);
@@ -94,7 +110,7 @@ __global__ void k_cond_seed(CondArgsE X, const double *__restrict__ sdata, const
         const double d = E.flats[c] ? NAN : init - E.uca[c];
         E.uca[c] += d;
         E.edge_todo[c] = 0;
-        if (w >= 0 && !own_done) X.node[w].seed_round = E.round16;
+        if (w >= 0 && !own_done) X.node[w].seed_round = round16;
         if (w >= 0 && !own_done && !(X.node[w].flag & NF_FINAL)) {
             CNode &N = X.node[w];
             N.delta = d;
@@ -117,6 +133,25 @@ __global__ void k_cond_seed(CondArgsE X, const double *__restrict__ sdata, const
     }
 }
 
+__global__ void k_cond_seed(CondArgsE X, const double *__restrict__ sdata, const uint8_t *__restrict__ sdone,
+                            const uint8_t *__restrict__ stodo, int L)
+{
+    cond_seed_cell(X, sdata, sdone, stodo, L, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Queued waves (pydem_board_run_waves): the rounds of ALL tiles of this rank in one launch each -- blockIdx.y (seeds) /
+// blockIdx.x (cascade) = entry of a device table, a tile takes part when its bit of the wave's member word is set.
+struct QTile { CondArgsE X; const double *sdata; const uint8_t *sflags; int64_t nper; int32_t L, pad; };
+
+__global__ void k_cond_seed_q(const QTile *__restrict__ Q)
+{
+    const QTile q = Q[blockIdx.y];
+    if (cond_gated_off(q.X)) return;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= q.nper) return;
+    cond_seed_cell(q.X, q.sdata, q.sflags, q.sflags + (size_t)4 * q.L, q.L, p);
+}
+
 // the final flush: the remaining inlets let go of the outside (k_cinc_release_todo)
 __global__ void k_cond_release_todo(CondArgsE X)
 {
@@ -136,9 +171,10 @@ __global__ void k_cond_release_todo(CondArgsE X)
 
 // ONE workgroup: the NaN flood of the round (k_cinc_nan_flood on the condensed graph), then the cascade level after level
 // (cinc_cell on nodes).  No host look in between: a wave of the fix-up is seed kernel + this kernel + the board's pack.
-__global__ __launch_bounds__(COND_THREADS) void k_cond_run(CondArgsE X)
+__device__ __forceinline__ void cond_run_block(const CondArgsE &X)
 {
     const CIncArgs &E = X.C;
+    const uint32_t round16 = cond_round16(X);
     __shared__ int32_t s_tail, s_cnt[3];
     // ---- NaN flood
     if (threadIdx.x == 0) s_tail = X.cnt[1];
@@ -149,7 +185,7 @@ __global__ __launch_bounds__(COND_THREADS) void k_cond_run(CondArgsE X)
         while (head < tail) {
             for (int32_t q = head + threadIdx.x; q < tail; q += blockDim.x) {
                 CNode &N = X.node[X.nanq[q]];
-                if (q >= n_origin && N.seed_round == E.round16) continue;            // a seed of this round keeps its value
+                if (q >= n_origin && N.seed_round == round16) continue;            // a seed of this round keeps its value
                 if (atomicOr(&N.flag, NF_NAN | CF_NANPASS) & NF_NAN) continue;          // flooded in an earlier round
                 E.uca[N.cell] = NAN;
                 for (int e = 0; e < N.n_out; e++) {
@@ -226,6 +262,18 @@ __global__ __launch_bounds__(COND_THREADS) void k_cond_run(CondArgsE X)
         if (E.set_done) E.edge_done[N.cell] = 1;
     }
     if (threadIdx.x == 0) { X.cnt[0] = 0; X.cnt[1] = 0; X.cnt[2] = r; }
+}
+
+__global__ __launch_bounds__(COND_THREADS) void k_cond_run(CondArgsE X)
+{
+    cond_run_block(X);
+}
+
+__global__ __launch_bounds__(COND_THREADS) void k_cond_run_q(const QTile *__restrict__ Q)
+{
+    const CondArgsE X = Q[blockIdx.x].X;
+    if (cond_gated_off(X)) return;
+    cond_run_block(X);
 }
 
 // catch-up, step 1: the watched nodes that are done hand their state to their compact records and enter the records'

@@ -1043,14 +1043,74 @@ class ProcessManager(object):
                 mets[a] = (nd / (1e-16 + float(scal[a, 1])), nd)
 
         refresh_mets(range(n_t))
-        prof = {'select': 0.0, 'rounds': 0.0, 'refresh': 0.0, 'eval': 0.0} if os.environ.get('PYDEM_EDGE_PROFILE') else None
+        prof = {'select': 0.0, 'rounds': 0.0, 'refresh': 0.0, 'eval': 0.0, 'queued': 0.0} if os.environ.get('PYDEM_EDGE_PROFILE') else None
         tp = time.perf_counter()
 
         def lap(key):                      # PYDEM_EDGE_PROFILE=1: host wall-clock of the wave loop by part
             nonlocal tp
             if prof is not None:
                 now = time.perf_counter(); prof[key] += now - tp; tp = now
+        # ---- queued waves (pydem_board_run_waves): with at most `width` tiles the ranking selects every candidate, so a kernel
+        # can choose the wave and K waves run back to back behind one another with ONE look from the host per batch -- the
+        # manager's poll / re-rank loop (:1214-1246) is off the critical path.  The host still runs: a tile's first round (it
+        # builds the tile's fix-up state), rounds that are not in the condensed form, and the tie-break rule when no
+        # candidate is left.  Same waves, same rounds (tests/test_gpu_process_manager.py holds both loops against each other).
+        k_queue = int(os.environ.get('PYDEM_EDGE_QUEUE', '16'))
+        queue = (k_queue > 0 and n_t <= min(width, 64) and not checking and not self.keep_first_pass_uca and host_sum is None
+                 and all(hasattr(self.tiles[i]._tile, 'edge_queue_ready') for i in owned))
+        k_queue = min(k_queue, 64)
+        ran = set()                        # tiles that have run a round (on any rank: the waves are the same everywhere)
+        ran_ok = {}                        # len(ran) -> every rank can queue the rounds of its tiles in `ran`
+        host_next = False                  # the last batch stopped in front of a wave only the host can run
+        self.edge_wave_graphs = False      # the queued waves ran as captured hipGraphs
+        self.edge_host_looks = 1           # times the host waited for the device inside the wave loop (+ the first evaluation)
+        S = _ffi.Board
+        sched = np.zeros(S.SCH_WORDS, np.uint64)
+        if queue:
+            for a in range(n_t):
+                sched[S.SCH_READERS + a] = sum(1 << int(r) for r in readers[a])
+                sched[S.SCH_NBRS + a] = sum(1 << int(r) for r in set(self._neighbours(a)))
+
+        def queued_batch():
+            """Run up to k_queue waves on the device; True if the host has to run the next wave itself."""
+            nonlocal scal
+            sched[S.SCH_OK] = sum(1 << a for a in ran)
+            sched[S.SCH_LIMIT] = max(0, int(self.max_edge_rounds) - int(self.edge_waves))
+            for a in range(n_t):
+                sched[S.SCH_ND + a] = int(mets[a, 1])
+                sched[S.SCH_HAS + a] = int(a in last_hash)
+                sched[S.SCH_HASH + a] = last_hash.get(a, 0)
+            for a in range(n_t):           # (the denominator the host's metric was formed with; only carried, never compared)
+                sched[S.SCH_PD + a] = pd_host[a]
+            scal = board.run_waves(comm, k_queue, sched)
+            self.edge_host_looks += 1
+            self.edge_wave_graphs = bool(sched[S.SCH_GRAPH])
+            for w in range(int(sched[S.SCH_NWAVES])):
+                members = [a for a in range(n_t) if (int(sched[S.SCH_LOG + w]) >> a) & 1]
+                for a in members:
+                    if self.transport.owns(a):
+                        self.edge_round_log.append((self.edge_waves, a, 0.0))
+                self.edge_rounds += len(members)
+                self.edge_waves += 1
+            for a in range(n_t):
+                nd, pd = int(sched[S.SCH_ND + a]), int(sched[S.SCH_PD + a])
+                pd_host[a] = pd
+                mets[a] = (float(nd) / (1e-16 + float(pd)), float(nd))
+                if int(sched[S.SCH_HAS + a]):
+                    last_hash[a] = int(sched[S.SCH_HASH + a])
+            return int(sched[S.SCH_STOP]) in (1, 2)
+
+        pd_host = [int(scal[a, 1]) for a in range(n_t)]
         while self.edge_waves < self.max_edge_rounds:
+            if queue and ran and not host_next:
+                if len(ran) not in ran_ok:
+                    mine_ok = all(self.tiles[a]._tile.edge_queue_ready() for a in ran if self.transport.owns(a))
+                    ran_ok[len(ran)] = self.transport.allreduce_max(0.0 if mine_ok else 1.0) == 0.0
+                if ran_ok[len(ran)]:
+                    host_next = queued_batch()
+                    lap('queued')
+                    continue
+            host_next = False
             eff = np.zeros_like(mets)
             cand = []
             for a in range(n_t):
@@ -1119,9 +1179,10 @@ class ProcessManager(object):
             for a in wave:                      # like check_mets (:1116-1136): the tiles that ran and their four side
                 check.update(self._neighbours(a))   # neighbours; a diagonal neighbour keeps its old metric until then
             refresh_mets(sorted(check))
-        if prof is not None:
-            import sys
-            sys.stderr.write("edge fix-up wave loop (host ms): %s over %d waves\n" % (', '.join('%s %.1f' % (k2, v * 1e3) for k2, v in prof.items()), self.edge_waves))
+            for a in sorted(check):
+                pd_host[a] = int(scal[a, 1])
+            ran.update(wave)
+            self.edge_host_looks += 1
         kf = min(len(owned), 8) if (self.tiles_in_flight is None and self.processor_cls is DEMProcessor) else min(len(owned), self._in_flight())
         if kf > 1:                         # the interiors catch up: one latency-bound cascade per tile, side by side on their streams
             from concurrent.futures import ThreadPoolExecutor
@@ -1130,6 +1191,14 @@ class ProcessManager(object):
         else:
             for a in owned:
                 self.tiles[a].flush_edge_rounds()
+        if prof is not None:
+            import sys
+            for a in owned:
+                self.tiles[a]._tile.synchronize()
+            prof['flush'] = time.perf_counter() - tp
+            self.edge_profile = dict((k2, v * 1e3) for k2, v in prof.items())
+            sys.stderr.write("edge fix-up wave loop (host ms): %s over %d waves, %d host looks\n"
+                             % (', '.join('%s %.1f' % (k2, v * 1e3) for k2, v in prof.items()), self.edge_waves, self.edge_host_looks))
         self._mets = mets.copy()
         board.close()
         return mets

@@ -253,3 +253,53 @@ def test_two_rank_pool_mode_over_rccl(name, world, tmp_path):
                           env=env, master_port=29300 + (os.getpid() % 300), capture=True, timeout=900)
     assert rc == 0, out[-3000:]
     assert out.count(' ok: ') == world, out[-3000:]
+
+
+@pytest.mark.parametrize('name', ['pm_fractal_2x3_ov1', 'pm_fractal_2x2_ov2', 'pm_nansea_2x2_ov2'])
+@pytest.mark.parametrize('k', [1, 3, 16])
+def test_queued_waves_equal_host_driven_waves(name, k, tmp_path, monkeypatch):
+    """The waves chosen by a kernel and queued k at a time (pydem_board_run_waves) against the host-driven wave loop
+    (PYDEM_EDGE_QUEUE=0): the same members wave by wave, the same tie-breaks, masks and areas identical bit for bit (the
+    rounds are the same kernels in the same order), and fewer looks from the host."""
+    from test_process_manager_cpu import run_pm
+    g = load_golden(name)
+    monkeypatch.setenv('PYDEM_EDGE_QUEUE', '0')
+    p0, c0, _ = run_pm(g, str(tmp_path / 'host'), n_workers=8, tiles_in_flight=2)
+    monkeypatch.setenv('PYDEM_EDGE_QUEUE', str(k))
+    pk, ck, _ = run_pm(g, str(tmp_path / 'queued'), n_workers=8, tiles_in_flight=2)
+    assert (pk.edge_waves, pk.edge_rounds, pk.edge_tiebreaks) == (p0.edge_waves, p0.edge_rounds, p0.edge_tiebreaks)
+    assert sorted((w, a) for w, a, _ in pk.edge_round_log) == sorted((w, a) for w, a, _ in p0.edge_round_log)    # (rounds of a wave finish in any order)
+    assert p0.edge_host_looks == p0.edge_waves + 1
+    assert pk.edge_host_looks <= p0.edge_host_looks    # (small mosaics: a tile's first round and every tie-break still go to the host)
+    for i in range(pk.n_inputs):
+        for key in ('edge_todo', 'edge_done'):
+            assert np.array_equal(pk.tile_result(i, key), p0.tile_result(i, key)), (i, key)
+        assert np.array_equal(pk.tile_result(i, 'uca_total'), p0.tile_result(i, 'uca_total'), equal_nan=True), i
+    for key in ck:
+        assert np.array_equal(ck[key], c0[key], equal_nan=True), key
+
+
+def test_queued_waves_respect_the_wave_limit(tmp_path, monkeypatch):
+    """max_edge_rounds cuts a batch of queued waves where it cuts the host-driven loop."""
+    from test_process_manager_grid import write_tiles
+    from pydem_amd import process_manager
+    g = load_golden('pm_fractal_2x3_ov1')
+    dkw = {k: v for k, v in g['kwargs'].items() if k not in ('ny_grid', 'nx_grid', 'overlap')}
+    out = []
+    for q in ('0', '16'):
+        monkeypatch.setenv('PYDEM_EDGE_QUEUE', q)
+        d = str(tmp_path / q)
+        write_tiles(g, d, key='elev')
+        process_manager.DEBUG = True
+        try:
+            pm = process_manager.ProcessManager(in_path=d, dem_proc_kwargs=dkw, elev_conditioned=True, n_workers=8)
+            pm.max_edge_rounds = 3
+            pm.process_twi()
+        finally:
+            process_manager.DEBUG = False
+        out.append(pm)
+    assert out[0].edge_waves == out[1].edge_waves == 3
+    assert out[0].edge_rounds == out[1].edge_rounds
+    for i in range(out[0].n_inputs):
+        assert np.array_equal(out[0].tile_result(i, 'uca_total'), out[1].tile_result(i, 'uca_total'), equal_nan=True), i
+        assert np.array_equal(out[0].tile_result(i, 'edge_done'), out[1].tile_result(i, 'edge_done')), i
