@@ -740,7 +740,7 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
             if (!tile_line_watched(T.tile, ln.first, ln.second)) { pydem_set_error("pydem_board_run_waves: tile %d: a board line is not watched", i); return -3; }
         state[SCH_ROUND + i] = tile_edge_round_counter(T.tile);
     }
-    const int g_eval = (int)(cdiv(most, 256) < 64 ? cdiv(most, 256) : 64);
+    const int g_eval = (int)(cdiv(most, 256) < 256 ? cdiv(most, 256) : 256);   // (one position per thread up to 65536: the kernel is a chain of dependent reads)
     // The whole batch runs on ONE stream (a single tile's own, otherwise the board's: the tiles' streams are idle -- every
     // host-driven wave ends with a synchronised evaluation), and a wave is a fixed handful of launches whatever the number
     // of tiles: the rounds and the gathers go through device tables (entry = tile), gated by the wave's member word.
@@ -781,11 +781,12 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
             hipLaunchKernelGGL(k_sched_select, dim3(1), dim3(64), 0, bs, b->sched, b->scal, b->n_tiles);
             if (c) HIP_TRY(hipMemsetAsync(b->wb, 0, (size_t)b->cap * 8, bs));
             PYDEM_TRY(stage_edge_rounds_queued(bs, b->q_tiles, b->q_count, b->q_nper));
+            // (without a collective the lines go straight to the board: the staging buffer exists to be summed over the ranks)
             if (b->q_nlines > 0)
-                hipLaunchKernelGGL(k_board_pack_gated, dim3(8, b->q_nlines), dim3(256), 0, bs, (const pydem_pack_line_q *)b->q_lines, b->q_nlines,
-                                   b->wb, b->sched + SCH_WAVE);
+                hipLaunchKernelGGL(k_board_pack_gated, dim3(16, b->q_nlines), dim3(256), 0, bs, (const pydem_pack_line_q *)b->q_lines, b->q_nlines,
+                                   c ? b->wb : b->mb, b->sched + SCH_WAVE);
         } else {
-            hipLaunchKernelGGL(k_board_scatter_gated, dim3(16, b->n_tiles), dim3(256), 0, bs, b->wb, b->mb, S, b->sched + SCH_WAVE);
+            if (c) hipLaunchKernelGGL(k_board_scatter_gated, dim3(128, b->n_tiles), dim3(256), 0, bs, b->wb, b->mb, S, b->sched + SCH_WAVE);
             hipLaunchKernelGGL(k_board_eval, dim3(g_eval, b->n_tiles), dim3(256), 0, bs, b->mb, b->desc, Lst, b->scal, b->sched + SCH_AFFECTED);
         }
         return 0;
