@@ -23,6 +23,9 @@
 // The pointwise kernels are bounded by HBM; the sweeps by dependent memory latency times the tiles / cells in flight.
 #include "internal.h"
 #include <algorithm>
+#include <functional>
+#include <memory>
+#include <thread>
 #include <vector>
 #include <math.h>
 #include <stdlib.h>
@@ -3767,7 +3770,10 @@ static int cond_build(pydem_tile *t)
     }
     hipLaunchKernelGGL(k_cond_extract, dim3(grid_for(nd, 1024)), dim3(256), 0, t->stream, C, d_hr);
     void *pin_v = nullptr;
-    PYDEM_TRY(tile_pinned(t, (size_t)nd * sizeof(CRecH) + 64, &pin_v));
+    // (pinned staging: the records' extract, and behind it room for the nodes -- at most one per cell of a watched line)
+    const size_t hr_bytes = (((size_t)nd * sizeof(CRecH) + 64) + 127) & ~(size_t)127;
+    const size_t nw_bound = (size_t)std::min<int64_t>((int64_t)nd, (int64_t)(4 + t->watch.size()) * (int64_t)std::max(n, m));
+    PYDEM_TRY(tile_pinned(t, hr_bytes + nw_bound * sizeof(CNode), &pin_v));
     const CRecH *hr = reinterpret_cast<const CRecH *>((char *)pin_v + 64);
     int32_t *h_npe = reinterpret_cast<int32_t *>(pin_v);
     HIP_TRY(hipMemcpyAsync(h_npe, d_npe, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
@@ -3780,49 +3786,93 @@ static int cond_build(pydem_tile *t)
     if (npe) HIP_TRY(hipMemcpy(pe.data(), d_pe, (size_t)npe * sizeof(CPitEdge), hipMemcpyDeviceToHost));
     const double t_copied = host_now_ms();
     std::sort(pe.begin(), pe.end(), [](const CPitEdge &a, const CPitEdge &b) { return a.src != b.src ? a.src < b.src : a.dst < b.dst; });
+    // The counting passes of the host part run on a few threads (PYDEM_COND_THREADS, default 8 or the machine's count; 1 = the
+    // serial form), the order of the watched nodes on a thread of its own beside them.
+    static int n_thr = -1;
+    if (n_thr < 0) {
+        const char *e = getenv("PYDEM_COND_THREADS");
+        const int hw = (int)std::thread::hardware_concurrency();
+        n_thr = e ? atoi(e) : std::min(8, hw > 0 ? hw : 1);
+        n_thr = std::max(1, std::min(n_thr, 16));
+    }
+    const int T = nd < 20000 ? 1 : n_thr;
+    auto par_for = [&](int64_t count, const std::function<void(int64_t, int64_t, int)> &fn) {
+        if (T == 1 || count < 4096) { fn(0, count, 0); return; }
+        std::vector<std::thread> th;
+        for (int q = 1; q < T; q++) th.emplace_back(fn, count * q / T, count * (q + 1) / T, q);
+        fn(0, count / T, 0);
+        for (auto &x : th) x.join();
+    };
+    // ---- watched records in ascending cell order (on its own thread beside the adjacency)
+    std::vector<int32_t> wrec, wid((size_t)nd, -1);
+    auto node_order = [&]() {
+        std::vector<std::pair<int32_t, int32_t>> key;
+        for (int32_t k = 0; k < nd; k++) if (hr[k].wid == -2) key.emplace_back(hr[k].cell, k);
+        std::sort(key.begin(), key.end());
+        wrec.resize(key.size());
+        for (size_t w = 0; w < key.size(); w++) { wrec[w] = key[w].second; wid[(size_t)key[w].second] = (int32_t)w; }
+    };
+    std::thread th_order;
+    if (T > 1) th_order = std::thread(node_order);
+    struct JoinGuard { std::thread &t; ~JoinGuard() { if (t.joinable()) t.join(); } } guard_order{th_order};
     // ---- out-edges per record (regular ones first, then the pit edges), in-degrees, predecessor lists
     std::vector<int32_t> ob((size_t)nd + 1, 0);
-    for (int32_t k = 0; k < nd; k++) ob[(size_t)k + 1] = (hr[k].out_id[0] >= 0) + (hr[k].out_id[1] >= 0);
+    par_for(nd, [&](int64_t k0, int64_t k1, int) { for (int64_t k = k0; k < k1; k++) ob[(size_t)k + 1] = (hr[k].out_id[0] >= 0) + (hr[k].out_id[1] >= 0); });
     for (const auto &e : pe) ob[(size_t)e.src + 1]++;
     for (int32_t k = 0; k < nd; k++) ob[(size_t)k + 1] += ob[(size_t)k];
     const int64_t n_out = ob[(size_t)nd];
     std::vector<int32_t> ot((size_t)n_out); std::vector<double> ow((size_t)n_out);
-    {
-        std::vector<int32_t> fill(ob.begin(), ob.end() - 1);
-        for (int32_t k = 0; k < nd; k++)
-            for (int j = 0; j < 2; j++)
-                if (hr[k].out_id[j] >= 0) { ot[(size_t)fill[(size_t)k]] = hr[k].out_id[j]; ow[(size_t)fill[(size_t)k]++] = hr[k].out_w[j]; }
-        for (const auto &e : pe) { ot[(size_t)fill[(size_t)e.src]] = e.dst; ow[(size_t)fill[(size_t)e.src]++] = e.w; }
-    }
     std::vector<int32_t> indeg((size_t)nd, 0), pb((size_t)nd + 1, 0);
-    for (int64_t e = 0; e < n_out; e++) { if (ot[(size_t)e] < 0 || ot[(size_t)e] >= nd) return 0; indeg[(size_t)ot[(size_t)e]]++; }
+    bool bad_target = false;
+    par_for(nd, [&](int64_t k0, int64_t k1, int) {
+        const CPitEdge *q = std::lower_bound(pe.data(), pe.data() + pe.size(), (int32_t)k0, [](const CPitEdge &a, int32_t v) { return a.src < v; });
+        const CPitEdge *qe = pe.data() + pe.size();
+        for (int64_t k = k0; k < k1; k++) {
+            int32_t f = ob[(size_t)k];
+            for (int j = 0; j < 2; j++)
+                if (hr[k].out_id[j] >= 0) { ot[(size_t)f] = hr[k].out_id[j]; ow[(size_t)f++] = hr[k].out_w[j]; }
+            for (; q != qe && q->src == (int32_t)k; q++) { ot[(size_t)f] = q->dst; ow[(size_t)f++] = q->w; }
+            for (int32_t e = ob[(size_t)k]; e < f; e++) {
+                const int32_t tg = ot[(size_t)e];
+                if (tg < 0 || tg >= nd) { bad_target = true; continue; }
+                __atomic_fetch_add(&indeg[(size_t)tg], 1, __ATOMIC_RELAXED);
+            }
+        }
+    });
+    if (bad_target) return 0;
     for (int32_t k = 0; k < nd; k++) pb[(size_t)k + 1] = pb[(size_t)k] + indeg[(size_t)k];
     std::vector<int32_t> pred((size_t)n_out);
     {
         std::vector<int32_t> fill(pb.begin(), pb.end() - 1);
-        for (int32_t k = 0; k < nd; k++)
-            for (int32_t e = ob[(size_t)k]; e < ob[(size_t)k + 1]; e++) pred[(size_t)fill[(size_t)ot[(size_t)e]]++] = k;
+        par_for(nd, [&](int64_t k0, int64_t k1, int) {
+            for (int64_t k = k0; k < k1; k++)
+                for (int32_t e = ob[(size_t)k]; e < ob[(size_t)k + 1]; e++)
+                    pred[(size_t)__atomic_fetch_add(&fill[(size_t)ot[(size_t)e]], 1, __ATOMIC_RELAXED)] = (int32_t)k;
+        });
     }
     const double t_csr = host_now_ms();
-    // ---- watched records in ascending cell order
-    std::vector<int32_t> wrec;
-    for (int32_t k = 0; k < nd; k++) if (hr[k].wid == -2) wrec.push_back(k);
-    std::sort(wrec.begin(), wrec.end(), [&](int32_t a, int32_t b) { return hr[a].cell < hr[b].cell; });
+    if (T > 1) th_order.join(); else node_order();
     const int32_t nw = (int32_t)wrec.size();
-    std::vector<int32_t> wid((size_t)nd, -1);
-    for (int32_t w = 0; w < nw; w++) wid[(size_t)wrec[(size_t)w]] = w;
     const double t_wsort = host_now_ms();
     // ---- reverse topological order: X(k) = the watched cells the water of k reaches next, with the path weights, kept as
     // scale[k] * V(rep[k]): a cell with ONE out-edge shares the vector of its target (rep < 0: the unit vector of watched
-    // node -1 - rep), only the cells where the flow splits merge two (sorted) vectors into a new one in the arena
+    // node -1 - rep), only the cells where the flow splits merge two (sorted) vectors into a new one.  Vectors live in
+    // chunks that never move; vref[id] = where vector id is.
     typedef std::pair<int32_t, double> Ent;
-    std::vector<Ent> arena;
-    std::vector<int64_t> vbeg(1, 0);                     // vector v = arena[vbeg[v] .. vbeg[v + 1])
-    arena.reserve((size_t)nd * 2);
+    struct VecRef { const Ent *p; int64_t n; };
+    std::unique_ptr<VecRef[]> vref(new VecRef[(size_t)nd + 1]);
+    int32_t n_vec = 0;
+    int64_t n_ent = 0;
     std::vector<int32_t> rep((size_t)nd, INT32_MIN);     // INT32_MIN: the empty vector (the water ends inside the tile)
     std::vector<double> scale((size_t)nd, 0.0);
+    // (the sweep itself stays on one thread: the graph of the records is a bundle of rivers, narrow and thousands of records
+    // deep -- a Kahn pass shared by 4 / 8 threads over a common ready list measured 100-150 ms against 12: every record then
+    // costs a few cache-line transfers between cores.  Last in, first out: a river is walked while its lines are warm.)
     std::vector<int32_t> out_left((size_t)nd), stack;
     for (int32_t k = 0; k < nd; k++) { out_left[(size_t)k] = ob[(size_t)k + 1] - ob[(size_t)k]; if (!out_left[(size_t)k]) stack.push_back(k); }
+    constexpr size_t CHUNK = (size_t)1 << 18;
+    std::vector<std::unique_ptr<Ent[]>> chunks;
+    Ent *cur = nullptr; size_t cur_left = 0;
     int64_t processed = 0;
     std::vector<Ent> acc, nxt;
     // the vector of target tg as seen through an edge of weight w: (rep, factor)
@@ -3833,7 +3883,7 @@ static int cond_build(pydem_tile *t)
     auto add_into = [&](int32_t r, double f) {            // acc += f * V(r), both sorted by node
         if (r == INT32_MIN) return;
         Ent unit(-1 - r, 1.0);
-        const Ent *vb = r < 0 ? &unit : arena.data() + vbeg[(size_t)r], *ve = r < 0 ? &unit + 1 : arena.data() + vbeg[(size_t)r + 1];
+        const Ent *vb = r < 0 ? &unit : vref[(size_t)r].p, *ve = r < 0 ? &unit + 1 : vref[(size_t)r].p + vref[(size_t)r].n;
         nxt.clear();
         size_t i = 0;
         for (const Ent *p = vb; p != ve; p++) {
@@ -3853,10 +3903,17 @@ static int cond_build(pydem_tile *t)
             acc.clear();
             for (int32_t e = e0; e < e1; e++) { int32_t r; double f; through(ot[(size_t)e], ow[(size_t)e], r, f); add_into(r, f); }
             if (!acc.empty()) {
-                rep[(size_t)k] = (int32_t)vbeg.size() - 1; scale[(size_t)k] = 1.0;
-                arena.insert(arena.end(), acc.begin(), acc.end());
-                vbeg.push_back((int64_t)arena.size());
-                if (arena.size() > ((size_t)1 << 27)) return 0;    // (a pathological fan: keep the cell-by-cell rounds)
+                if (acc.size() > cur_left) {
+                    const size_t sz = std::max(CHUNK, acc.size());
+                    chunks.emplace_back(new Ent[sz]);
+                    cur = chunks.back().get(); cur_left = sz;
+                }
+                std::copy(acc.begin(), acc.end(), cur);
+                vref[(size_t)n_vec].p = cur; vref[(size_t)n_vec].n = (int64_t)acc.size();
+                cur += acc.size(); cur_left -= acc.size();
+                rep[(size_t)k] = n_vec++; scale[(size_t)k] = 1.0;
+                n_ent += (int64_t)acc.size();
+                if (n_ent > ((int64_t)1 << 27)) return 0;    // (a pathological fan: keep the cell-by-cell rounds)
             }
         }
         for (int32_t e = pb[(size_t)k]; e < pb[(size_t)k + 1]; e++) if (--out_left[(size_t)pred[(size_t)e]] == 0) stack.push_back(pred[(size_t)e]);
@@ -3864,8 +3921,9 @@ static int cond_build(pydem_tile *t)
     if (processed != nd) return 0;                                   // a cycle among the records: not a DAG, plain cascade
     const double t_swept = host_now_ms();
     // ---- nodes, edges, slots
-    std::vector<CNode> nodes((size_t)nw);
-    auto vsize = [&](int32_t r) -> int64_t { return r == INT32_MIN ? 0 : (r < 0 ? 1 : vbeg[(size_t)r + 1] - vbeg[(size_t)r]); };
+    if ((size_t)nw > nw_bound) { pydem_set_error("condensed edge rounds: %d watched nodes, expected at most %zu", nw, nw_bound); return -5; }
+    CNode *nodes = reinterpret_cast<CNode *>((char *)pin_v + hr_bytes);
+    auto vsize = [&](int32_t r) -> int64_t { return r == INT32_MIN ? 0 : (r < 0 ? 1 : vref[(size_t)r].n); };
     int64_t ne_all = 0;
     for (int32_t w = 0; w < nw; w++) ne_all += vsize(rep[(size_t)wrec[(size_t)w]]);
     if (ne_all > INT32_MAX / 2) return 0;
@@ -3880,7 +3938,7 @@ static int cond_build(pydem_tile *t)
             const double f = scale[(size_t)k];
             if (r != INT32_MIN && r < 0) { e_dst[(size_t)e] = -1 - r; e_w[(size_t)e] = f; e++; }
             else if (r != INT32_MIN)
-                for (int64_t q = vbeg[(size_t)r]; q < vbeg[(size_t)r + 1]; q++) { e_dst[(size_t)e] = arena[(size_t)q].first; e_w[(size_t)e] = f * arena[(size_t)q].second; e++; }
+                for (int64_t q = 0; q < vref[(size_t)r].n; q++) { e_dst[(size_t)e] = vref[(size_t)r].p[q].first; e_w[(size_t)e] = f * vref[(size_t)r].p[q].second; e++; }
             ebeg[(size_t)w + 1] = (int32_t)e;
         }
         for (int64_t q = 0; q < ne_all; q++) n_in[(size_t)e_dst[(size_t)q]]++;
@@ -3928,7 +3986,7 @@ static int cond_build(pydem_tile *t)
     t->cond_q0 = (int32_t *)(base + o_q0); t->cond_q1 = (int32_t *)(base + o_q1); t->cond_nanq = (int32_t *)(base + o_nan);
     t->cond_cnt = (int32_t *)(base + o_cnt); t->cond_nw = nw; t->cond_nan_cap = (int32_t)std::min<size_t>(nan_cap, (size_t)INT32_MAX);
     HIP_TRY(hipMemsetAsync(base + o_slot, 0, off - o_slot, t->stream));
-    if (nw) HIP_TRY(hipMemcpyAsync(t->cond_node, nodes.data(), (size_t)nw * sizeof(CNode), hipMemcpyHostToDevice, t->stream));
+    if (nw) HIP_TRY(hipMemcpyAsync(t->cond_node, nodes, (size_t)nw * sizeof(CNode), hipMemcpyHostToDevice, t->stream));
     if (ne) HIP_TRY(hipMemcpyAsync(t->cond_edge, edges.data(), (size_t)ne * sizeof(CEdge), hipMemcpyHostToDevice, t->stream));
     CondArgsE X;
     t->cond_live = true;                  // (cond_args reads the fields set above)
@@ -3941,7 +3999,7 @@ static int cond_build(pydem_tile *t)
         fprintf(stderr, "condensed edge rounds: %d records -> %d watched nodes, %lld edges (%d pit edges among the records); %.2f ms "
                 "(copy %.2f, adjacency %.2f, node order %.2f, reverse sweep %.2f [%zu vectors, %zu entries], nodes + upload %.2f)\n",
                 nd, nw, (long long)ne_all, npe, host_now_ms() - t_begin, t_copied - t_begin, t_csr - t_copied, t_wsort - t_csr, t_swept - t_wsort,
-                vbeg.size() - 1, arena.size(), host_now_ms() - t_swept);
+                (size_t)n_vec, (size_t)n_ent, host_now_ms() - t_swept);
     return 0;
 }
 

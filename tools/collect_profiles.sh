@@ -22,8 +22,11 @@ timeout 600 python bench.py --drain-pits 0 --cpu-sample 0 --host-to-host 0 > gpu
 timeout 300 python bench.py --config 2 > gpurun_out/prof/bench_config2.json 2> gpurun_out/prof/bench_config2.err
 timeout 600 python bench.py --config 5 > gpurun_out/prof/bench_config5.json 2> gpurun_out/prof/bench_config5.err
 cat gpurun_out/prof/bench_*.json
-PYDEM_EDGE_SYNC=1 PM_WORKERS=8 PM_EDGE_MODE=pool timeout 900 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/prof/pm_pool_8x16384.log 2>&1
-PYDEM_EDGE_COND=0 PM_WORKERS=8 PM_EDGE_MODE=pool timeout 900 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/prof/pm_pool_8x16384_cell_by_cell.log 2>&1
-PM_WORKERS=8 PM_EDGE_MODE=pool timeout 900 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/prof/pm_pool_8x16384_async.log 2>&1
+# the fix-up of 8 tiles on one GPU: the default (waves chosen on the device, queued 16 at a time) with the host's wall clock by part;
+# the host-driven wave loop with every round waited for (per-round times); the round-3 cascade; no waiting; the reference's serial order
+PYDEM_EDGE_PROFILE=1 PYDEM_EDGE_DEBUG=1 PM_WORKERS=8 PM_EDGE_MODE=pool timeout 900 python tools/pm_multitile_timing.py 16384 8 2>&1 | grep -v "condensed edge round: [0-9]" > gpurun_out/prof/pm_pool_8x16384_queued.log
+PYDEM_EDGE_QUEUE=0 PYDEM_EDGE_PROFILE=1 PYDEM_EDGE_SYNC=1 PM_WORKERS=8 PM_EDGE_MODE=pool timeout 900 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/prof/pm_pool_8x16384.log 2>&1
+PYDEM_EDGE_QUEUE=0 PYDEM_EDGE_COND=0 PM_WORKERS=8 PM_EDGE_MODE=pool timeout 900 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/prof/pm_pool_8x16384_cell_by_cell.log 2>&1
+PYDEM_EDGE_QUEUE=0 PM_WORKERS=8 PM_EDGE_MODE=pool timeout 900 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/prof/pm_pool_8x16384_async.log 2>&1
 PM_WORKERS=1 PM_EDGE_MODE=reference timeout 900 python tools/pm_multitile_timing.py 16384 8 > gpurun_out/prof/pm_serial_8x16384.log 2>&1
-tail -2 gpurun_out/prof/pm_pool_8x16384.log | cut -c1-200; tail -2 gpurun_out/prof/pm_serial_8x16384.log | cut -c1-200
+grep -v "per wave" gpurun_out/prof/pm_pool_8x16384_queued.log | tail -5 | cut -c1-300; tail -2 gpurun_out/prof/pm_pool_8x16384.log | cut -c1-200; tail -2 gpurun_out/prof/pm_serial_8x16384.log | cut -c1-200
