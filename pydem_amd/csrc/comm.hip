@@ -255,7 +255,7 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x)
 }
 
 // one thread per (side, position) of one tile
-__global__ __launch_bounds__(256) void k_board_eval(const double *__restrict__ mb, const pydem_board_desc *__restrict__ descs,
+__global__ __launch_bounds__(1024) void k_board_eval(const double *__restrict__ mb, const pydem_board_desc *__restrict__ descs,
                                                     pydem_board_list Lst, unsigned long long *__restrict__ scal,
                                                     const unsigned long long *__restrict__ gate)
 {
@@ -338,16 +338,25 @@ __global__ __launch_bounds__(256) void k_board_eval(const double *__restrict__ m
         h = mix64(h ^ ((unsigned long long)q * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)done << 1) ^ (unsigned long long)td_adopt);
         a_hash += h;
     }
-    // block reduction, one atomic per block and value
-    __shared__ unsigned long long red[6][256];
-    const unsigned long long v[6] = {a_ndone, a_pdone, a_dself, a_dfull, a_seeds, a_hash};
-    for (int j = 0; j < 6; j++) red[j][threadIdx.x] = v[j];
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) for (int j = 0; j < 6; j++) red[j][threadIdx.x] += red[j][threadIdx.x + s];
-        __syncthreads();
+    // reduction: lanes of a wavefront by shuffles, the wavefronts of the block through LDS, one atomic per block and value
+    // (blocks of 1024 threads, at most 16 per tile: with 64-256 small blocks the same-address atomics of a tile were half of the
+    // kernel's time)
+    __shared__ unsigned long long red[6][16];
+    unsigned long long v[6] = {a_ndone, a_pdone, a_dself, a_dfull, a_seeds, a_hash};
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        unsigned long long x = v[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+        if (lane == 0) red[j][wv] = x;
     }
-    if (threadIdx.x == 0) for (int j = 0; j < 6; j++) atomicAdd(&scal[(size_t)tile * 8 + j], red[j][0]);
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        unsigned long long x = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) x += red[threadIdx.x][w];
+        atomicAdd(&scal[(size_t)tile * 8 + threadIdx.x], x);
+    }
 }
 
 // all lines of one tile -> wave staging (blockIdx.y = line)
@@ -685,9 +694,9 @@ int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *ful
             const int64_t total = 2 * (int64_t)D.n + 2 * (int64_t)D.m;
             if (total > most) most = total;
         }
-        const int g = (int)(cdiv(most, 256) < 64 ? cdiv(most, 256) : 64);
+        const int g = (int)(cdiv(most, 4096) < 16 ? cdiv(most, 4096) : 16);
         hipLaunchKernelGGL(k_board_zero, dim3(1), dim3(512), 0, b->stream, b->scal, Lst);
-        hipLaunchKernelGGL(k_board_eval, dim3(g, Lst.n), dim3(256), 0, b->stream, b->mb, b->desc, Lst, b->scal, (const unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_board_eval, dim3(g, Lst.n), dim3(1024), 0, b->stream, b->mb, b->desc, Lst, b->scal, (const unsigned long long *)nullptr);
     }
     HIP_TRY(hipMemcpyAsync(b->h_scal, b->scal, (size_t)b->n_tiles * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipGetLastError());
@@ -740,7 +749,7 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
             if (!tile_line_watched(T.tile, ln.first, ln.second)) { pydem_set_error("pydem_board_run_waves: tile %d: a board line is not watched", i); return -3; }
         state[SCH_ROUND + i] = tile_edge_round_counter(T.tile);
     }
-    const int g_eval = (int)(cdiv(most, 256) < 256 ? cdiv(most, 256) : 256);   // (one position per thread up to 65536: the kernel is a chain of dependent reads)
+    const int g_eval = (int)(cdiv(most, 4096) < 16 ? cdiv(most, 4096) : 16);
     // The whole batch runs on ONE stream (a single tile's own, otherwise the board's: the tiles' streams are idle -- every
     // host-driven wave ends with a synchronised evaluation), and a wave is a fixed handful of launches whatever the number
     // of tiles: the rounds and the gathers go through device tables (entry = tile), gated by the wave's member word.
@@ -787,7 +796,7 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
                                    c ? b->wb : b->mb, b->sched + SCH_WAVE);
         } else {
             if (c) hipLaunchKernelGGL(k_board_scatter_gated, dim3(128, b->n_tiles), dim3(256), 0, bs, b->wb, b->mb, S, b->sched + SCH_WAVE);
-            hipLaunchKernelGGL(k_board_eval, dim3(g_eval, b->n_tiles), dim3(256), 0, bs, b->mb, b->desc, Lst, b->scal, b->sched + SCH_AFFECTED);
+            hipLaunchKernelGGL(k_board_eval, dim3(g_eval, b->n_tiles), dim3(1024), 0, bs, b->mb, b->desc, Lst, b->scal, b->sched + SCH_AFFECTED);
         }
         return 0;
     };

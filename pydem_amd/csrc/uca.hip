@@ -4190,7 +4190,13 @@ int stage_edge_flush(pydem_tile *t)
         hipLaunchKernelGGL(k_cond_run, dim3(1), dim3(COND_THREADS), 0, t->stream, X);
         PYDEM_TRY(cond_catchup(t, 0));
         t->einc_ready = false; t->cond_live = false;
-        if (getenv("PYDEM_EDGE_DEBUG")) { HIP_TRY(hipStreamSynchronize(t->stream)); fprintf(stderr, "condensed edge rounds: flush (interior cascade) %.3f ms\n", host_now_ms() - t_flush0); }
+        if (getenv("PYDEM_EDGE_DEBUG")) {
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            int32_t tot[6];
+            HIP_TRY(hipMemcpy(tot, t->cond_cnt, sizeof(tot), hipMemcpyDeviceToHost));
+            fprintf(stderr, "condensed edge rounds: flush (interior cascade) %.3f ms; %d rounds ran on the watched graph, %d levels, %d nodes finished\n",
+                    host_now_ms() - t_flush0, tot[4], tot[3], tot[5]);
+        }
         return 0;
     }
     HIP_TRY(hipMemsetAsync(t->counters, 0, 16 * sizeof(int32_t), t->stream));

@@ -240,8 +240,27 @@ __device__ __forceinline__ void cond_run_block(const CondArgsE &X)
             // (the cell's area and mask are written after the cascade, all cells at once: a read-modify-write of the area
             // plane inside the level would make every level's barrier wait for an HBM round trip)
             X.nanq[agg_slot(&s_done)] = (k < COND_QCAP ? lc[k] : qc[k]) | ((f & NF_FINAL) ? (int32_t)0x40000000 : 0);
-            for (int e = 0; e < V.n_out; e++) {
-                const CEdge ed = e < 2 ? V.e_inl[e] : X.edge[V.out_base + e - 2];
+            // the two edges that travel with the node: both hand-overs, then both count-downs back to back (a count-down is a
+            // round trip to the L2; tested one after the other they were half of a narrow level), then the releases
+            int32_t old_cnt[2] = {0, 0};
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+                if (e < V.n_out) {
+                    const CEdge ed = V.e_inl[e];
+                    if (ed.slot < 0) X.node[ed.dst].in_inl[-1 - ed.slot] = delta * ed.w;
+                    else X.slot[ed.slot] = delta * ed.w;
+                }
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+                if (e < V.n_out) old_cnt[e] = atomicSub(&X.node[V.e_inl[e].dst].cnt, 1);
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+                if (e < V.n_out && old_cnt[e] == 1) {
+                    const int32_t sl = agg_slot(cn);
+                    if (sl < COND_QCAP) ln[sl] = V.e_inl[e].dst; else qn[sl] = V.e_inl[e].dst;
+                }
+            for (int e = 2; e < V.n_out; e++) {
+                const CEdge ed = X.edge[V.out_base + e - 2];
                 if (ed.slot < 0) X.node[ed.dst].in_inl[-1 - ed.slot] = delta * ed.w;
                 else X.slot[ed.slot] = delta * ed.w;
                 if (atomicSub(&X.node[ed.dst].cnt, 1) == 1) {
@@ -261,7 +280,7 @@ __device__ __forceinline__ void cond_run_block(const CondArgsE &X)
         if (!(e & 0x40000000)) E.uca[N.cell] += N.delta;                             // (a seed took its value when the strip arrived)
         if (E.set_done) E.edge_done[N.cell] = 1;
     }
-    if (threadIdx.x == 0) { X.cnt[0] = 0; X.cnt[1] = 0; X.cnt[2] = r; }
+    if (threadIdx.x == 0) { X.cnt[0] = 0; X.cnt[1] = 0; X.cnt[2] = r; X.cnt[3] += r; X.cnt[4] += 1; X.cnt[5] += s_done; }   // ([3..5]: levels / rounds / nodes finished so far, PYDEM_EDGE_DEBUG)
 }
 
 __global__ __launch_bounds__(COND_THREADS) void k_cond_run(CondArgsE X)
