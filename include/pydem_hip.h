@@ -270,16 +270,18 @@ int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *ful
  * kernel): per wave a selection kernel (candidates = positive metric or 'todo' pixels dropped on the mosaic border, strips
  * changed since the tile's last round), for every tile of this rank a condensed round + the gather of its lines gated by the
  * wave's member word, one ncclAllReduce(sum) of the whole staging buffer when `c` is given, the copy to the board and the
- * evaluation of the tiles that read the wave's lines.  `state`: 520 64-bit words in and out --
+ * evaluation of the tiles that read the wave's lines.  `state`: 528 64-bit words in and out --
  *   [0] bit per tile: its rounds may be queued (a candidate without the bit stops the batch BEFORE its wave: the host runs
- *   that wave, e.g. a tile's first round, which builds its fix-up state), [1] out: 0 = all k_waves ran, 1 = no candidate
- *   left (the host applies the tie-break rule :274 or ends the fix-up), 2 = a candidate needs the host, 3 = wave limit,
+ *   that wave, e.g. a tile's first round, which builds its fix-up state), [1] out: 0 = all k_waves ran, 1 = the fix-up
+ *   is over (no candidate, and no tile drops a 'todo' pixel under rule :274 everywhere -- while one does, the tile that
+ *   drops the most runs alone with its strips evaluated under that rule: the tie-break wave of the schedule, also chosen by the
+ *   kernel), 2 = a candidate needs the host, 3 = wave limit,
  *   [2] out: waves run, [3] waves allowed, [8+a] / [72+a] metric numerator / denominator of tile a as the schedule holds
  *   them (stale for diagonal neighbours like check_mets :1116-1136), [136+a] / [200+a] strip hash of a's last round / whether
  *   it has one, [264+a] bit mask of the tiles reading a line of a, [328+a] a and its four side neighbours, [392+w] out: the
  *   members of wave w, [7] out: the waves ran as captured hipGraphs (one launch per wave; PYDEM_EDGE_GRAPH=0: plain launches),
- *   [456+a] scratch (round stamps).  `scal_out` as `out` of pydem_board_eval.  pydem_tile_edge_queue_ready: 1 when the tile's rounds can
- *   be queued (condensed fix-up state built by its first round, strips buffers attached by pydem_board_set_desc). */
+ *   [456+a] scratch (round stamps), [521] out: tie-break waves of the batch, [522] out: bit w = wave w was one.
+ *   `scal_out` as `out` of pydem_board_eval.  pydem_tile_edge_queue_ready: 1 when the tile's rounds can be queued (condensed fix-up state built by its first round, strips buffers attached by pydem_board_set_desc). */
 int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned long long *state, unsigned long long *scal_out);
 int pydem_tile_edge_queue_ready(pydem_tile *t);
 int pydem_board_download(pydem_board *b, double *out);

@@ -400,11 +400,11 @@ class Board(object):
         return out
 
     # layout of the queued waves' state (csrc/comm.hip, SCH_*)
-    SCH_OK, SCH_STOP, SCH_NWAVES, SCH_LIMIT, SCH_GRAPH, SCH_ND, SCH_PD, SCH_HASH, SCH_HAS, SCH_READERS, SCH_NBRS, SCH_LOG, SCH_WORDS = \
-        0, 1, 2, 3, 7, 8, 72, 136, 200, 264, 328, 392, 520
+    SCH_OK, SCH_STOP, SCH_NWAVES, SCH_LIMIT, SCH_GRAPH, SCH_ND, SCH_PD, SCH_HASH, SCH_HAS, SCH_READERS, SCH_NBRS, SCH_LOG, SCH_NTB, SCH_TBLOG, SCH_WORDS = \
+        0, 1, 2, 3, 7, 8, 72, 136, 200, 264, 328, 392, 521, 522, 528
 
     def run_waves(self, comm, k_waves, state):
-        """Up to k_waves waves without a host look (pydem_board_run_waves); `state` (uint64[520]) is updated in place; returns the
+        """Up to k_waves waves without a host look (pydem_board_run_waves); `state` (uint64[528]) is updated in place; returns the
         scalars of all tiles like eval()."""
         assert state.dtype == np.uint64 and state.size == self.SCH_WORDS and state.flags.c_contiguous
         check(self.lib.pydem_board_run_waves(self._h, comm._h if comm is not None else None, int(k_waves), state.ctypes.data_as(_P),

@@ -221,7 +221,7 @@ struct pydem_board {
                        std::vector<std::pair<int, int64_t>> where; };      // (axis, index) of the lines: the tile's condensed edge rounds watch them
     std::vector<TileLines> tl;
     // queued waves (pydem_board_run_waves): the schedule's state on the device + a pinned copy
-    unsigned long long *sched = nullptr, *h_sched = nullptr;
+    unsigned long long *sched = nullptr, *h_sched = nullptr, *scal_tb = nullptr;
     void *q_tiles = nullptr; void *q_lines = nullptr; int q_count = 0, q_nlines = 0; int64_t q_nper = 1;   // tables of the queued rounds / packs
     hipGraphExec_t wave_exec[2] = {nullptr, nullptr};   // one wave, captured: before / after the collective (one graph without one)
     unsigned long long wave_ok = 0; bool wave_comm = false; hipStream_t wave_stream = nullptr;   // what the graphs were captured for
@@ -238,8 +238,11 @@ struct pydem_board {
 // [264 + a] tiles that read a line of a                 [328 + a] a and its four side neighbours
 // [392 + w] members of wave w of the batch
 // [456 + a] the tile's round counter when the batch began (seed stamps)   [7] out: the waves ran as captured graphs
+// [520] the tile whose strips are evaluated again with rule :274 everywhere before this wave (tie-break), as a bit
+// [521] out: tie-breaks of the batch   [522] out: bit w = wave w of the batch was a tie-break
 enum { SCH_OK = 0, SCH_STOP = 1, SCH_NWAVES = 2, SCH_LIMIT = 3, SCH_CHECK = 4, SCH_WAVE = 5, SCH_AFFECTED = 6, SCH_GRAPH = 7, SCH_ND = 8,
-       SCH_PD = 72, SCH_HASH = 136, SCH_HAS = 200, SCH_READERS = 264, SCH_NBRS = 328, SCH_LOG = 392, SCH_ROUND = 456, SCH_WORDS = 520 };
+       SCH_PD = 72, SCH_HASH = 136, SCH_HAS = 200, SCH_READERS = 264, SCH_NBRS = 328, SCH_LOG = 392, SCH_ROUND = 456, SCH_TB = 520,
+       SCH_NTB = 521, SCH_TBLOG = 522, SCH_WORDS = 528 };
 
 static void board_drop_graphs(pydem_board *b)
 {
@@ -393,8 +396,9 @@ __global__ void k_board_scatter(const double *__restrict__ wb, double *__restric
 __global__ void k_sched_select(unsigned long long *__restrict__ S, unsigned long long *__restrict__ scal, int n_tiles)
 {
     const int a = threadIdx.x;
-    __shared__ unsigned long long s_wave, s_aff, s_chk;
+    __shared__ unsigned long long s_wave, s_aff, s_chk, s_drop[64];
     if (a == 0) { s_wave = 0; s_aff = 0; s_chk = 0; }
+    s_drop[a] = 0;
     __syncthreads();
     const bool live = S[SCH_STOP] == 0;
     bool cand = false;
@@ -402,18 +406,29 @@ __global__ void k_sched_select(unsigned long long *__restrict__ S, unsigned long
         if ((S[SCH_CHECK] >> a) & 1ull) { S[SCH_ND + a] = scal[(size_t)a * 8 + 0]; S[SCH_PD + a] = scal[(size_t)a * 8 + 1]; }
         cand = (S[SCH_ND + a] > 0 || scal[(size_t)a * 8 + 2] != 0) && !(S[SCH_HAS + a] && S[SCH_HASH + a] == scal[(size_t)a * 8 + 5]);
         if (cand) atomicOr(&s_wave, 1ull << a);
+        s_drop[a] = scal[(size_t)a * 8 + 3];
     }
     __syncthreads();
-    const unsigned long long wave = s_wave;
-    int stop = 0;
+    unsigned long long wave = s_wave;
+    int stop = 0, tb = -1;
     if (live) {
         if (S[SCH_NWAVES] >= S[SCH_LIMIT]) stop = 3;
-        else if (wave == 0) stop = 1;
+        else if (wave == 0) {
+            // no candidate: the tile that would drop the most 'todo' pixels under rule :274 everywhere runs alone, its strips
+            // evaluated with that rule (lowest index first); none: the fix-up is over
+            unsigned long long best = 0;
+            for (int q = 0; q < n_tiles; q++) if (s_drop[q] > best) { best = s_drop[q]; tb = q; }
+            if (tb < 0) stop = 1;
+            else if (!((S[SCH_OK] >> tb) & 1ull)) stop = 2;
+            else wave = 1ull << tb;
+        }
         else if (wave & ~S[SCH_OK]) stop = 2;
     }
     const bool run = live && stop == 0;
-    if (run && cand) {
-        S[SCH_HASH + a] = scal[(size_t)a * 8 + 5]; S[SCH_HAS + a] = 1;
+    const bool member = run && a < n_tiles && ((wave >> a) & 1ull);
+    if (member) {
+        if (tb < 0) { S[SCH_HASH + a] = scal[(size_t)a * 8 + 5]; S[SCH_HAS + a] = 1; }
+        else S[SCH_HAS + a] = 0;                               // (a tie-break forgets the tile's last strips)
         atomicOr(&s_aff, S[SCH_READERS + a]);
         atomicOr(&s_chk, S[SCH_NBRS + a]);
     }
@@ -422,8 +437,11 @@ __global__ void k_sched_select(unsigned long long *__restrict__ S, unsigned long
     if (run && a < n_tiles && ((s_aff >> a) & 1ull))
         for (int j = 0; j < 8; j++) scal[(size_t)a * 8 + j] = 0ull;
     if (a == 0) {
-        if (run) { S[SCH_LOG + S[SCH_NWAVES]] = wave; S[SCH_NWAVES] += 1; S[SCH_WAVE] = wave; S[SCH_AFFECTED] = s_aff; S[SCH_CHECK] = s_chk; }
-        else { S[SCH_WAVE] = 0; S[SCH_AFFECTED] = 0; S[SCH_CHECK] = 0; if (live) S[SCH_STOP] = (unsigned long long)stop; }
+        if (run) {
+            if (tb >= 0) { S[SCH_TBLOG] |= 1ull << S[SCH_NWAVES]; S[SCH_NTB] += 1; }
+            S[SCH_LOG + S[SCH_NWAVES]] = wave; S[SCH_NWAVES] += 1; S[SCH_WAVE] = wave; S[SCH_AFFECTED] = s_aff; S[SCH_CHECK] = s_chk;
+            S[SCH_TB] = tb >= 0 ? wave : 0ull;
+        } else { S[SCH_WAVE] = 0; S[SCH_AFFECTED] = 0; S[SCH_CHECK] = 0; S[SCH_TB] = 0; if (live) S[SCH_STOP] = (unsigned long long)stop; }
     }
 }
 
@@ -503,6 +521,7 @@ int pydem_board_destroy(pydem_board *b)
     for (auto &T : b->tl) if (T.lines) (void)hipFree(T.lines);
     if (b->h_scal) (void)hipHostFree(b->h_scal);
     if (b->sched) (void)hipFree(b->sched);
+    if (b->scal_tb) (void)hipFree(b->scal_tb);
     if (b->h_sched) (void)hipHostFree(b->h_sched);
     board_drop_graphs(b);
     if (b->q_tiles) (void)hipFree(b->q_tiles);
@@ -722,6 +741,7 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
     if (!b->sched) {
         HIP_TRY(hipMalloc((void **)&b->sched, SCH_WORDS * sizeof(unsigned long long)));
         HIP_TRY(hipHostMalloc((void **)&b->h_sched, SCH_WORDS * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void **)&b->scal_tb, 64 * 8 * sizeof(unsigned long long)));
     }
     if (b->cap > b->wcap) {
         if (b->wb) HIP_TRY(hipFree(b->wb));
@@ -730,15 +750,15 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
         board_drop_graphs(b); b->tables_valid = false;   // (they hold the old staging buffer)
     }
     pydem_board_segs S;
-    pydem_board_list Lst;
-    S.n = b->n_tiles; Lst.n = b->n_tiles;
+    pydem_board_list Lst, LstFull;
+    S.n = b->n_tiles; Lst.n = b->n_tiles; LstFull.n = b->n_tiles;
     int64_t most = 1;
     std::vector<int> mine;
     const unsigned long long ok = state[SCH_OK];
     for (int i = 0; i < b->n_tiles; i++) {
         pydem_board::TileLines &T = b->tl[(size_t)i];
         S.src[i] = T.mb_start; S.dst[i] = T.mb_start; S.cnt[i] = T.size;
-        Lst.tile[i] = i; Lst.full[i] = 0;
+        Lst.tile[i] = i; Lst.full[i] = 0; LstFull.tile[i] = i; LstFull.full[i] = 1;
         const pydem_board_desc &D = b->h_desc[(size_t)i];
         most = std::max<int64_t>(most, 2 * (int64_t)D.n + 2 * (int64_t)D.m);
         state[SCH_ROUND + i] = 0;
@@ -788,6 +808,8 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
     auto issue = [&](int part) -> int {
         if (part == 0) {
             hipLaunchKernelGGL(k_sched_select, dim3(1), dim3(64), 0, bs, b->sched, b->scal, b->n_tiles);
+            // (a tie-break wave: the strips of its tile once more, rule :274 everywhere; the numbers go to a scratch row)
+            hipLaunchKernelGGL(k_board_eval, dim3(g_eval, b->n_tiles), dim3(1024), 0, bs, b->mb, b->desc, LstFull, b->scal_tb, b->sched + SCH_TB);
             if (c) HIP_TRY(hipMemsetAsync(b->wb, 0, (size_t)b->cap * 8, bs));
             PYDEM_TRY(stage_edge_rounds_queued(bs, b->q_tiles, b->q_count, b->q_nper));
             // (without a collective the lines go straight to the board: the staging buffer exists to be summed over the ranks)
@@ -822,6 +844,7 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
     }
     const bool graphs = use_graph && !b->graph_failed && b->wave_exec[0];
     state[SCH_STOP] = 0; state[SCH_NWAVES] = 0; state[SCH_CHECK] = 0; state[SCH_WAVE] = 0; state[SCH_AFFECTED] = 0;
+    state[SCH_TB] = 0; state[SCH_NTB] = 0; state[SCH_TBLOG] = 0;
     if (state[SCH_LIMIT] > (unsigned long long)k_waves) state[SCH_LIMIT] = (unsigned long long)k_waves;
     memcpy(b->h_sched, state, SCH_WORDS * sizeof(unsigned long long));
     HIP_TRY(hipStreamSynchronize(b->stream));       // (the evaluations of the host-driven waves ran there)

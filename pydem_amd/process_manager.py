@@ -1052,9 +1052,10 @@ class ProcessManager(object):
                 now = time.perf_counter(); prof[key] += now - tp; tp = now
         # ---- queued waves (pydem_board_run_waves): with at most `width` tiles the ranking selects every candidate, so a kernel
         # can choose the wave and K waves run back to back behind one another with ONE look from the host per batch -- the
-        # manager's poll / re-rank loop (:1214-1246) is off the critical path.  The host still runs: a tile's first round (it
-        # builds the tile's fix-up state), rounds that are not in the condensed form, and the tie-break rule when no
-        # candidate is left.  Same waves, same rounds (tests/test_gpu_process_manager.py holds both loops against each other).
+        # manager's poll / re-rank loop (:1214-1246) is off the critical path; the tie-break wave (no candidate left: the tile
+        # that drops the most 'todo' pixels under rule :274 runs alone) is chosen by the same kernel.  The host still runs a
+        # tile's first round (it builds the tile's fix-up state) and rounds that are not in the condensed form.  Same waves,
+        # same rounds (tests/test_gpu_process_manager.py holds both loops against each other).
         k_queue = int(os.environ.get('PYDEM_EDGE_QUEUE', '16'))
         queue = (k_queue > 0 and n_t <= min(width, 64) and not checking and not self.keep_first_pass_uca and host_sum is None
                  and all(hasattr(self.tiles[i]._tile, 'edge_queue_ready') for i in owned))
@@ -1092,12 +1093,15 @@ class ProcessManager(object):
                         self.edge_round_log.append((self.edge_waves, a, 0.0))
                 self.edge_rounds += len(members)
                 self.edge_waves += 1
+            self.edge_tiebreaks += int(sched[S.SCH_NTB])
             for a in range(n_t):
                 nd, pd = int(sched[S.SCH_ND + a]), int(sched[S.SCH_PD + a])
                 pd_host[a] = pd
                 mets[a] = (float(nd) / (1e-16 + float(pd)), float(nd))
                 if int(sched[S.SCH_HAS + a]):
                     last_hash[a] = int(sched[S.SCH_HASH + a])
+                else:
+                    last_hash.pop(a, None)            # (a tie-break wave forgot the tile's last strips)
             return int(sched[S.SCH_STOP]) in (1, 2)
 
         pd_host = [int(scal[a, 1]) for a in range(n_t)]

@@ -17,6 +17,10 @@ cp gpurun_out/prof/pmc_fetch_write.meta.json gpurun_out/prof/pmc_sq_stencil.meta
 cp gpurun_out/prof/ks/t_kernel_stats.csv gpurun_out/prof/kernel_stats.csv
 rm -f gpurun_out/prof/*/t_kernel_trace.csv gpurun_out/prof/*/t_counter_collection.csv
 head -14 gpurun_out/prof/kernel_stats.csv; head -8 gpurun_out/prof/pmc_fetch_write.csv; cat gpurun_out/prof/pmc_sq_stencil.csv
+# the bench lines quote `traffic` from the committed PMC files while their stamp matches the kernel sources: file the fresh ones first
+R=${ROUND_TAG:-r05}
+cp gpurun_out/prof/pmc_fetch_write.csv profiles/${R}_pmc_fetch_write_16384.csv; cp gpurun_out/prof/pmc_fetch_write.meta.json profiles/${R}_pmc_fetch_write_16384.meta.json
+cp gpurun_out/prof/pmc_sq_stencil.csv profiles/${R}_pmc_sq_stencil_16384.csv; cp gpurun_out/prof/pmc_sq_stencil.meta.json profiles/${R}_pmc_sq_stencil_16384.meta.json
 timeout 600 python bench.py > gpurun_out/prof/bench_default.json 2> gpurun_out/prof/bench_default.err
 timeout 600 python bench.py --drain-pits 0 --cpu-sample 0 --host-to-host 0 > gpurun_out/prof/bench_nopits.json 2> gpurun_out/prof/bench_nopits.err
 timeout 300 python bench.py --config 2 > gpurun_out/prof/bench_config2.json 2> gpurun_out/prof/bench_config2.err
