@@ -769,11 +769,14 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
             if (!tile_line_watched(T.tile, ln.first, ln.second)) { pydem_set_error("pydem_board_run_waves: tile %d: a board line is not watched", i); return -3; }
         state[SCH_ROUND + i] = tile_edge_round_counter(T.tile);
     }
-    const int g_eval = (int)(cdiv(most, 4096) < 16 ? cdiv(most, 4096) : 16);
-    // The whole batch runs on ONE stream (a single tile's own, otherwise the board's: the tiles' streams are idle -- every
-    // host-driven wave ends with a synchronised evaluation), and a wave is a fixed handful of launches whatever the number
-    // of tiles: the rounds and the gathers go through device tables (entry = tile), gated by the wave's member word.
-    hipStream_t bs = mine.size() == 1 ? b->tl[(size_t)mine[0]].tile->stream : b->stream;
+    static int eval_blocks = -1;                     // PYDEM_EVAL_BLOCKS: blocks of 1024 threads per tile in the evaluation (default 16)
+    if (eval_blocks < 0) { const char *e = getenv("PYDEM_EVAL_BLOCKS"); eval_blocks = e ? std::max(1, std::min(atoi(e), 256)) : 16; }
+    const int g_eval = (int)std::min<int64_t>(cdiv(most, 1024), eval_blocks);
+    // The whole batch runs on ONE stream, the board's (the tiles' streams are idle: every host-driven wave ends with a
+    // synchronised evaluation), and a wave is a fixed handful of launches whatever the number of tiles: the rounds and the
+    // gathers go through device tables (entry = tile), gated by the wave's member word.  One tile per rank and eight tiles of
+    // one process take the same path (the second is what a single GPU can test).
+    hipStream_t bs = b->stream;
     const bool rebuild = !b->tables_valid || b->wave_ok != ok;
     if (rebuild) {
         HIP_TRY(hipStreamSynchronize(bs));
