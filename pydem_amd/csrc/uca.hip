@@ -3786,16 +3786,21 @@ static int cond_build(pydem_tile *t)
     if (npe) HIP_TRY(hipMemcpy(pe.data(), d_pe, (size_t)npe * sizeof(CPitEdge), hipMemcpyDeviceToHost));
     const double t_copied = host_now_ms();
     std::sort(pe.begin(), pe.end(), [](const CPitEdge &a, const CPitEdge &b) { return a.src != b.src ? a.src < b.src : a.dst < b.dst; });
-    // The counting passes of the host part run on a few threads (PYDEM_COND_THREADS, default 8 or the machine's count; 1 = the
-    // serial form), the order of the watched nodes on a thread of its own beside them.
+    // The order of the watched nodes is formed on a thread of its own beside the adjacency.  The counting passes of the
+    // adjacency CAN run on several threads (PYDEM_COND_THREADS=<n>), but the default is one: on the two-socket hosts of the
+    // GPU boxes the arrays the workers touch first land on their memory nodes, and the reverse sweep that follows (one thread,
+    // random access into exactly those arrays) loses more (12-13 -> 14-25 ms) than the passes gain (8 -> 5 ms).
+    // (Also measured and not kept: the sweep as a depth-first post-order over the out-edges alone, without predecessor lists --
+    // adjacency 8 -> 5 ms, sweep 12.5 -> 17 ms: every record is visited twice and its targets' states once more.)
     static int n_thr = -1;
     if (n_thr < 0) {
         const char *e = getenv("PYDEM_COND_THREADS");
         const int hw = (int)std::thread::hardware_concurrency();
-        n_thr = e ? atoi(e) : std::min(8, hw > 0 ? hw : 1);
-        n_thr = std::max(1, std::min(n_thr, 16));
+        n_thr = e ? atoi(e) : 1;
+        n_thr = std::max(1, std::min(n_thr, std::min(16, hw > 0 ? hw : 1)));
     }
     const int T = nd < 20000 ? 1 : n_thr;
+    const bool order_thread = nd >= 20000;
     auto par_for = [&](int64_t count, const std::function<void(int64_t, int64_t, int)> &fn) {
         if (T == 1 || count < 4096) { fn(0, count, 0); return; }
         std::vector<std::thread> th;
@@ -3813,7 +3818,7 @@ static int cond_build(pydem_tile *t)
         for (size_t w = 0; w < key.size(); w++) { wrec[w] = key[w].second; wid[(size_t)key[w].second] = (int32_t)w; }
     };
     std::thread th_order;
-    if (T > 1) th_order = std::thread(node_order);
+    if (order_thread) th_order = std::thread(node_order);
     struct JoinGuard { std::thread &t; ~JoinGuard() { if (t.joinable()) t.join(); } } guard_order{th_order};
     // ---- out-edges per record (regular ones first, then the pit edges), in-degrees, predecessor lists
     std::vector<int32_t> ob((size_t)nd + 1, 0);
@@ -3851,7 +3856,7 @@ static int cond_build(pydem_tile *t)
         });
     }
     const double t_csr = host_now_ms();
-    if (T > 1) th_order.join(); else node_order();
+    if (order_thread) th_order.join(); else node_order();
     const int32_t nw = (int32_t)wrec.size();
     const double t_wsort = host_now_ms();
     // ---- reverse topological order: X(k) = the watched cells the water of k reaches next, with the path weights, kept as
