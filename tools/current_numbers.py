@@ -49,7 +49,7 @@ def main():
         tail = d.get('tail') if isinstance(d.get('tail'), str) else ''
         line = {'ms_per_step': p.get('ms_per_step'), 'value': p.get('value'), 'stages_ms': grab(tail, 'stages_ms'), 'roofline_stencil': grab(tail, 'roofline_stencil')}
         out.append(row('driver, round %s (`%s`)' % (re.search(r'r(\d+)', os.path.basename(fn)).group(1).lstrip('0'), os.path.basename(fn)), line))
-    for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_16384.json'))):
+    for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_16384.json')) + glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_16384_other_box.json'))):
         rnd = re.search(r'r(\d+)_', os.path.basename(fn)).group(1)
         if os.path.exists(os.path.join(ROOT, 'BENCH_r%s.json' % rnd)):
             continue                                   # the driver's line of that round is above
@@ -57,7 +57,8 @@ def main():
             line = json.load(open(fn))
         except ValueError:
             continue
-        out.append(row("builder's own run, round %s (`profiles/%s`)" % (rnd.lstrip('0'), os.path.basename(fn)), line))
+        who = "builder's own run" + (", another box" if 'other_box' in fn else "")
+        out.append(row("%s, round %s (`profiles/%s`)" % (who, rnd.lstrip('0'), os.path.basename(fn)), line))
     text = '\n'.join(out)
     if '--write' in sys.argv:
         fn = os.path.join(ROOT, 'DESIGN.md')
