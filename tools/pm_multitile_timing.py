@@ -28,8 +28,11 @@ for rep in range(2):
     if os.environ.get('PICKS'): print('picks', picks); del picks[:]
     waves = {}
     for w, i, ms in pm.edge_round_log: waves.setdefault(w, []).append(ms)
-    print('   rounds: sum %.1f ms; sum over waves of the slowest round %.1f ms (critical path with one tile per GPU); per wave (tiles, max ms): %s'
-          % (sum(ms for _, _, ms in pm.edge_round_log), sum(max(v) for v in waves.values()), ' '.join('%d:%.1f' % (len(v), max(v)) for v in waves.values())))
+    queued = getattr(pm, 'edge_host_looks', len(waves) + 1) < len(waves) + 1
+    print('   rounds: sum %.1f ms; sum over waves of the slowest round %.1f ms (%s); per wave (tiles, max ms): %s'
+          % (sum(ms for _, _, ms in pm.edge_round_log), sum(max(v) for v in waves.values()),
+             'HOST-DRIVEN waves only: the queued waves have no per-round times, see the "queued" part of PYDEM_EDGE_PROFILE=1' if queued
+             else 'critical path with one tile per GPU', ' '.join('%d:%.1f' % (len(v), max(v)) for v in waves.values())))
     print('   host looks inside the wave loop: %s (queued waves as graphs: %s)' % (getattr(pm, 'edge_host_looks', 'n/a'), getattr(pm, 'edge_wave_graphs', 'n/a')))
     print('n=%d tiles=%d: tiles %.1f ms, edge fix-up %.1f ms (%d rounds in %d waves), twi %.1f ms' % (n, nt, (t1-t0)*1e3, (t2-t1)*1e3, pm.edge_rounds, pm.edge_waves, (t3-t2)*1e3))
 if len(sys.argv) > 3:
