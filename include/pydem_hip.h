@@ -240,7 +240,9 @@ int pydem_comm_allreduce(pydem_comm *c, int64_t n_doubles, int op /* 0 sum, 1 ma
  *                         points the tile at its own line), cnr_1ov[4] (check_1overlap :286-293); `tile` = the
  *                         resident tile whose strip buffers the evaluation fills (NULL: a tile of another rank)
  *   pydem_board_set_lines which part of the board holds the lines of tile `index` (mb_start, size) and, for a tile of
- *                         this rank, the lines to gather from it (field / axis / index -> rel_offset inside that part)
+ *                         this rank, the lines to gather from it (field / axis / index -> rel_offset inside that part); for a
+ *                         tile of another rank (`tile` NULL) the same list gives the layout only (which lines are areas, which
+ *                         masks: the queued waves carry masks as bytes through the collective)
  *   pydem_board_refresh   after a wave (the same tile list on every rank): the tiles of this rank gather their lines
  *                         into the wave staging buffer, one ncclAllReduce(sum) over disjoint fills when `c` is given,
  *                         then the staging buffer is copied into the board
@@ -269,7 +271,8 @@ int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *ful
  * 2 * n_workers tiles the ranking :1177-1188 selects every tile with a positive metric, so the wave can be chosen by a
  * kernel): per wave a selection kernel (candidates = positive metric or 'todo' pixels dropped on the mosaic border, strips
  * changed since the tile's last round), for every tile of this rank a condensed round + the gather of its lines gated by the
- * wave's member word, one ncclAllReduce(sum) of the whole staging buffer when `c` is given, the copy to the board and the
+ * wave's member word, one ncclAllReduce(sum, bytes) of the whole staging buffer (areas as doubles, masks as bytes) when `c` is
+ * given, the unpacking onto the board and the
  * evaluation of the tiles that read the wave's lines.  `state`: 528 64-bit words in and out --
  *   [0] bit per tile: its rounds may be queued (a candidate without the bit stops the batch BEFORE its wave: the host runs
  *   that wave, e.g. a tile's first round, which builds its fix-up state), [1] out: 0 = all k_waves ran, 1 = the fix-up

@@ -218,11 +218,14 @@ struct pydem_board {
     // per tile: where its lines live in the board, and (tiles of this rank) how to gather them from the tile
     struct TileLines { int64_t mb_start = 0, size = 0; pydem_tile *tile = nullptr; int count = 0; pydem_pack_line *lines = nullptr;
                        std::vector<pydem_pack_line> h_lines;
+                       struct Lay { int64_t rel, count; int32_t bytes; };
+                       std::vector<Lay> layout;          // every line of the tile (also of another rank's tile): where on the board, how long, 8 = area / 1 = mask
                        std::vector<std::pair<int, int64_t>> where; };      // (axis, index) of the lines: the tile's condensed edge rounds watch them
     std::vector<TileLines> tl;
     // queued waves (pydem_board_run_waves): the schedule's state on the device + a pinned copy
     unsigned long long *sched = nullptr, *h_sched = nullptr, *scal_tb = nullptr;
-    void *q_tiles = nullptr; void *q_lines = nullptr; int q_count = 0, q_nlines = 0; int64_t q_nper = 1;   // tables of the queued rounds / packs
+    void *q_tiles = nullptr; void *q_lines = nullptr; void *q_unpack = nullptr; int q_count = 0, q_nlines = 0, q_nunpack = 0; int64_t q_nper = 1;   // tables of the queued rounds / gathers / the unpacking after the collective
+    int64_t q_stage_bytes = 0; bool q_staged_ok = false;   // staging layout of the queued collective (areas as doubles, masks as bytes), known for every tile
     hipGraphExec_t wave_exec[2] = {nullptr, nullptr};   // one wave, captured: before / after the collective (one graph without one)
     unsigned long long wave_ok = 0; bool wave_comm = false; hipStream_t wave_stream = nullptr;   // what the graphs were captured for
     bool graph_failed = false, tables_valid = false;
@@ -455,34 +458,44 @@ __global__ void k_sched_settle(unsigned long long *__restrict__ S, const unsigne
 }
 
 // the lines of all tiles of this rank -> staging at the board's own offsets, for the members of the wave (blockIdx.y = line)
-struct pydem_pack_line_q { pydem_pack_line P; int64_t abs; int32_t tile, pad; };
-__global__ void k_board_pack_gated(const pydem_pack_line_q *__restrict__ lines, int nlines, double *__restrict__ wb,
-                                   const unsigned long long *__restrict__ gate)
+struct pydem_pack_line_q { pydem_pack_line P; int64_t abs, st; int32_t tile, pad; };      // abs: board offset (doubles); st: staging offset (bytes)
+// staged == 0: straight to the board (no collective); staged == 1: into the staging buffer the collective carries -- areas as
+// doubles, masks as BYTES (a sum over ranks of disjoint fills is exact byte by byte as well: x + 0)
+__global__ void k_board_pack_gated(const pydem_pack_line_q *__restrict__ lines, int nlines, double *__restrict__ mb, unsigned char *__restrict__ wb,
+                                   int staged, const unsigned long long *__restrict__ gate)
 {
     const unsigned long long wave = *gate;
     for (int l = blockIdx.y; l < nlines; l += gridDim.y) {
         const pydem_pack_line_q Q = lines[l];
         if (!((wave >> Q.tile) & 1ull)) continue;
         const pydem_pack_line &P = Q.P;
-        double *dst = wb + Q.abs;
+        const int64_t k0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, dk = (int64_t)gridDim.x * blockDim.x;
         if (P.bytes == 8) {
             const double *src = (const double *)P.src;
-            for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < P.count; k += (int64_t)gridDim.x * blockDim.x) dst[k] = src[k * P.stride];
+            double *dst = staged ? reinterpret_cast<double *>(wb + Q.st) : mb + Q.abs;
+            for (int64_t k = k0; k < P.count; k += dk) dst[k] = src[k * P.stride];
         } else {
             const uint8_t *src = (const uint8_t *)P.src;
-            for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < P.count; k += (int64_t)gridDim.x * blockDim.x) dst[k] = (double)src[k * P.stride];
+            if (staged) { unsigned char *dst = wb + Q.st; for (int64_t k = k0; k < P.count; k += dk) dst[k] = src[k * P.stride] != 0; }
+            else { double *dst = mb + Q.abs; for (int64_t k = k0; k < P.count; k += dk) dst[k] = (double)src[k * P.stride]; }
         }
     }
 }
 
-// staging -> board for the members of the wave (blockIdx.y = tile; segment s of S belongs to tile s)
-__global__ void k_board_scatter_gated(const double *__restrict__ wb, double *__restrict__ mb, pydem_board_segs S,
-                                      const unsigned long long *__restrict__ gate)
+// staging -> board after the collective: the lines of ALL tiles that are members of the wave (blockIdx.y = line)
+struct pydem_unpack_line { int64_t st, abs, count; int32_t bytes, tile; };
+__global__ void k_board_unpack_gated(const pydem_unpack_line *__restrict__ lines, int nlines, const unsigned char *__restrict__ wb,
+                                     double *__restrict__ mb, const unsigned long long *__restrict__ gate)
 {
-    const int s = blockIdx.y;
-    if (!((*gate >> s) & 1ull)) return;
-    const int64_t src = S.src[s], dst = S.dst[s], cnt = S.cnt[s];
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * blockDim.x) mb[dst + k] = wb[src + k];
+    const unsigned long long wave = *gate;
+    for (int l = blockIdx.y; l < nlines; l += gridDim.y) {
+        const pydem_unpack_line U = lines[l];
+        if (!((wave >> U.tile) & 1ull)) continue;
+        const int64_t k0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, dk = (int64_t)gridDim.x * blockDim.x;
+        double *dst = mb + U.abs;
+        if (U.bytes == 8) { const double *src = reinterpret_cast<const double *>(wb + U.st); for (int64_t k = k0; k < U.count; k += dk) dst[k] = src[k]; }
+        else { const unsigned char *src = wb + U.st; for (int64_t k = k0; k < U.count; k += dk) dst[k] = (double)src[k]; }
+    }
 }
 
 __global__ void k_board_zero(unsigned long long *scal, pydem_board_list Lst)
@@ -526,6 +539,7 @@ int pydem_board_destroy(pydem_board *b)
     board_drop_graphs(b);
     if (b->q_tiles) (void)hipFree(b->q_tiles);
     if (b->q_lines) (void)hipFree(b->q_lines);
+    if (b->q_unpack) (void)hipFree(b->q_unpack);
     if (b->ev) (void)hipEventDestroy(b->ev);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
@@ -567,7 +581,17 @@ int pydem_board_set_lines(pydem_board *b, int index, int64_t mb_start, int64_t s
     if (mb_start < 0 || mb_start + size > b->cap) { pydem_set_error("pydem_board_set_lines: lines beyond the board"); return -2; }
     if ((int)b->tl.size() != b->n_tiles) b->tl.resize((size_t)b->n_tiles);
     pydem_board::TileLines &T = b->tl[(size_t)index];
-    T.mb_start = mb_start; T.size = size; T.tile = tile; T.count = 0; T.where.clear();
+    T.mb_start = mb_start; T.size = size; T.tile = tile; T.count = 0; T.where.clear(); T.layout.clear();
+    // the layout of the tile's lines, for tiles of other ranks too when the caller lists them (the queued waves carry masks as
+    // bytes through the collective and need to know which lines are masks)
+    for (int k = 0; k < count; k++) {
+        const pydem_board_desc &D = b->h_desc[(size_t)index];
+        if (axes[k] != 0 && axes[k] != 1) { pydem_set_error("pydem_board_set_lines: axis"); return -2; }
+        pydem_board::TileLines::Lay L;
+        L.rel = rel_offsets[k]; L.count = axes[k] == 0 ? D.m : D.n; L.bytes = fields[k] == PYDEM_UCA ? 8 : 1;
+        if (L.rel < 0 || L.rel + L.count > size) { pydem_set_error("pydem_board_set_lines: line beyond the tile's board segment"); return -2; }
+        T.layout.push_back(L);
+    }
     if (!tile) return 0;
     if (tile->device != b->device) { pydem_set_error("pydem_board_set_lines: tile lives on another device"); return -2; }
     std::vector<pydem_pack_line> h((size_t)count);
@@ -749,15 +773,13 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
         b->wcap = b->cap;
         board_drop_graphs(b); b->tables_valid = false;   // (they hold the old staging buffer)
     }
-    pydem_board_segs S;
     pydem_board_list Lst, LstFull;
-    S.n = b->n_tiles; Lst.n = b->n_tiles; LstFull.n = b->n_tiles;
+    Lst.n = b->n_tiles; LstFull.n = b->n_tiles;
     int64_t most = 1;
     std::vector<int> mine;
     const unsigned long long ok = state[SCH_OK];
     for (int i = 0; i < b->n_tiles; i++) {
         pydem_board::TileLines &T = b->tl[(size_t)i];
-        S.src[i] = T.mb_start; S.dst[i] = T.mb_start; S.cnt[i] = T.size;
         Lst.tile[i] = i; Lst.full[i] = 0; LstFull.tile[i] = i; LstFull.full[i] = 1;
         const pydem_board_desc &D = b->h_desc[(size_t)i];
         most = std::max<int64_t>(most, 2 * (int64_t)D.n + 2 * (int64_t)D.m);
@@ -783,6 +805,25 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
         board_drop_graphs(b);
         if (b->q_tiles) { HIP_TRY(hipFree(b->q_tiles)); b->q_tiles = nullptr; }
         if (b->q_lines) { HIP_TRY(hipFree(b->q_lines)); b->q_lines = nullptr; }
+        if (b->q_unpack) { HIP_TRY(hipFree(b->q_unpack)); b->q_unpack = nullptr; }
+        // staging layout of the collective: every line of every tile at a byte offset (8-byte aligned), areas as doubles, masks as
+        // bytes -- a fifth of the board's size.  Needs the line list of the other ranks' tiles too (pydem_board_set_lines).
+        std::vector<std::vector<int64_t>> st_off((size_t)b->n_tiles);
+        std::vector<pydem_unpack_line> hu;
+        int64_t st = 0;
+        b->q_staged_ok = true;
+        for (int i = 0; i < b->n_tiles; i++) {
+            const pydem_board::TileLines &T = b->tl[(size_t)i];
+            if (T.size > 0 && T.layout.empty()) b->q_staged_ok = false;
+            for (const auto &L : T.layout) {
+                st_off[(size_t)i].push_back(st);
+                pydem_unpack_line U; U.st = st; U.abs = T.mb_start + L.rel; U.count = L.count; U.bytes = L.bytes; U.tile = i;
+                hu.push_back(U);
+                st += (L.count * L.bytes + 7) & ~(int64_t)7;
+            }
+        }
+        b->q_stage_bytes = st;
+        if (st > b->wcap * 8) b->q_staged_ok = false;
         const size_t qb = tile_edge_queue_desc_bytes();
         std::vector<char> hq(qb * std::max<size_t>(mine.size(), 1));
         std::vector<pydem_pack_line_q> hl;
@@ -793,9 +834,15 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
             int64_t nper = 0;
             PYDEM_TRY(tile_edge_queue_desc(T.tile, hq.data() + k * qb, b->sched + SCH_WAVE, i, b->sched + SCH_ROUND + i, b->sched + SCH_NWAVES, &nper));
             b->q_nper = std::max(b->q_nper, nper);
-            for (const auto &P : T.h_lines) { pydem_pack_line_q Q; Q.P = P; Q.abs = T.mb_start + P.rel; Q.tile = i; Q.pad = 0; hl.push_back(Q); }
+            if (T.h_lines.size() != T.layout.size()) b->q_staged_ok = false;
+            for (size_t l = 0; l < T.h_lines.size(); l++) {
+                const pydem_pack_line &P = T.h_lines[l];
+                pydem_pack_line_q Q; Q.P = P; Q.abs = T.mb_start + P.rel; Q.tile = i; Q.pad = 0;
+                Q.st = l < st_off[(size_t)i].size() ? st_off[(size_t)i][l] : 0;
+                hl.push_back(Q);
+            }
         }
-        b->q_count = (int)mine.size(); b->q_nlines = (int)hl.size();
+        b->q_count = (int)mine.size(); b->q_nlines = (int)hl.size(); b->q_nunpack = (int)hu.size();
         if (b->q_count) {
             HIP_TRY(hipMalloc(&b->q_tiles, hq.size()));
             HIP_TRY(hipMemcpy(b->q_tiles, hq.data(), hq.size(), hipMemcpyHostToDevice));
@@ -804,8 +851,13 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
             HIP_TRY(hipMalloc(&b->q_lines, hl.size() * sizeof(pydem_pack_line_q)));
             HIP_TRY(hipMemcpy(b->q_lines, hl.data(), hl.size() * sizeof(pydem_pack_line_q), hipMemcpyHostToDevice));
         }
+        if (b->q_nunpack) {
+            HIP_TRY(hipMalloc(&b->q_unpack, hu.size() * sizeof(pydem_unpack_line)));
+            HIP_TRY(hipMemcpy(b->q_unpack, hu.data(), hu.size() * sizeof(pydem_unpack_line), hipMemcpyHostToDevice));
+        }
         b->tables_valid = true; b->wave_ok = ok;
     }
+    if (c && !b->q_staged_ok) { pydem_set_error("pydem_board_run_waves: with a communicator every tile needs its line list (pydem_board_set_lines, also for tiles of other ranks)"); return -3; }
     // One wave, in two parts around the collective.  Everything a launch needs is read on the device (member words, round
     // stamps), so the parts can be captured once and replayed wave after wave.
     auto issue = [&](int part) -> int {
@@ -813,14 +865,16 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
             hipLaunchKernelGGL(k_sched_select, dim3(1), dim3(64), 0, bs, b->sched, b->scal, b->n_tiles);
             // (a tie-break wave: the strips of its tile once more, rule :274 everywhere; the numbers go to a scratch row)
             hipLaunchKernelGGL(k_board_eval, dim3(g_eval, b->n_tiles), dim3(1024), 0, bs, b->mb, b->desc, LstFull, b->scal_tb, b->sched + SCH_TB);
-            if (c) HIP_TRY(hipMemsetAsync(b->wb, 0, (size_t)b->cap * 8, bs));
+            if (c) HIP_TRY(hipMemsetAsync(b->wb, 0, (size_t)b->q_stage_bytes, bs));
             PYDEM_TRY(stage_edge_rounds_queued(bs, b->q_tiles, b->q_count, b->q_nper));
             // (without a collective the lines go straight to the board: the staging buffer exists to be summed over the ranks)
             if (b->q_nlines > 0)
                 hipLaunchKernelGGL(k_board_pack_gated, dim3(16, b->q_nlines), dim3(256), 0, bs, (const pydem_pack_line_q *)b->q_lines, b->q_nlines,
-                                   c ? b->wb : b->mb, b->sched + SCH_WAVE);
+                                   b->mb, reinterpret_cast<unsigned char *>(b->wb), c ? 1 : 0, b->sched + SCH_WAVE);
         } else {
-            if (c) hipLaunchKernelGGL(k_board_scatter_gated, dim3(128, b->n_tiles), dim3(256), 0, bs, b->wb, b->mb, S, b->sched + SCH_WAVE);
+            if (c && b->q_nunpack > 0)
+                hipLaunchKernelGGL(k_board_unpack_gated, dim3(16, b->q_nunpack), dim3(256), 0, bs, (const pydem_unpack_line *)b->q_unpack, b->q_nunpack,
+                                   reinterpret_cast<const unsigned char *>(b->wb), b->mb, b->sched + SCH_WAVE);
             hipLaunchKernelGGL(k_board_eval, dim3(g_eval, b->n_tiles), dim3(1024), 0, bs, b->mb, b->desc, Lst, b->scal, b->sched + SCH_AFFECTED);
         }
         return 0;
@@ -854,7 +908,7 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
     HIP_TRY(hipMemcpyAsync(b->sched, b->h_sched, SCH_WORDS * sizeof(unsigned long long), hipMemcpyHostToDevice, bs));
     for (int w = 0; w < k_waves; w++) {
         if (graphs) HIP_TRY(hipGraphLaunch(b->wave_exec[0], bs)); else PYDEM_TRY(issue(0));
-        if (c) NCCL_TRY(ncclAllReduce(b->wb, b->wb, (size_t)b->cap, ncclDouble, ncclSum, c->comm, bs));
+        if (c) NCCL_TRY(ncclAllReduce(b->wb, b->wb, (size_t)b->q_stage_bytes, ncclUint8, ncclSum, c->comm, bs));   // (disjoint fills: x + 0 byte by byte)
         if (graphs) { if (c) HIP_TRY(hipGraphLaunch(b->wave_exec[1], bs)); }
         else PYDEM_TRY(issue(1));
     }

@@ -1000,8 +1000,9 @@ class ProcessManager(object):
             if self.transport.owns(t):
                 board.set_lines(t, start[t], size[t], self.tiles[t]._tile,
                                 [(_FIELD_OF[req[1]], req[2], req[3], layout[req] - start[t]) for req in sorted(interest.get(t, ()))])
-            else:
-                board.set_lines(t, start[t], size[t])
+            else:                          # (a tile of another rank: only the layout of its lines -- which are areas, which masks)
+                board.set_lines(t, start[t], size[t], None,
+                                [(_FIELD_OF[req[1]], req[2], req[3], layout[req] - start[t]) for req in sorted(interest.get(t, ()))])
 
         host_sum = None if (comm is not None or type(self.transport) is EdgeTransport) else self.transport.sum_inplace
 
