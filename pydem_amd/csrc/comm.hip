@@ -879,7 +879,7 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
         }
         return 0;
     };
-    // ---- the wave as a graph (PYDEM_EDGE_GRAPH=0: plain launches): one launch per wave instead of six
+    // ---- the wave as a graph (PYDEM_EDGE_GRAPH=0: plain launches): one launch per wave (two around a collective) instead of seven
     static int use_graph = -1;
     if (use_graph < 0) { const char *e = getenv("PYDEM_EDGE_GRAPH"); use_graph = e ? atoi(e) : 1; }
     const int n_parts = c ? 2 : 1;                   // (without a collective both parts are one graph)
