@@ -338,20 +338,32 @@ def main():
                                         edge_mode=('pool' if world > 1 else 'reference'))
     exchange = "in-process"
     group = None
+    rccl_ranks = None
     if world > 1:
+        shared = os.environ.get('PYDEM_BENCH_SHARED_GPU') == '1'
+        if ndev < world and not shared:
+            # RCCL refuses two ranks on one device, and a communicator that half of the ranks could not join hangs the others:
+            # say so before anything is started
+            raise SystemExit("bench: --gpus %d needs %d GPUs, this box has %d (one rank per GPU over RCCL).  PYDEM_BENCH_SHARED_GPU=1 runs "
+                             "the ranks on the GPUs there are with the strips summed over sockets -- a functional check of the "
+                             "multi-rank path, not a scaling number." % (world, world, ndev))
         # process-group plumbing only (hands the RCCL id around: pydem_amd/rendezvous.py); the strips travel over RCCL
         from pydem_amd import parallel, rendezvous
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         group = rendezvous.SocketGroup(rank, world)
         rccl = None
-        try:
-            rccl = parallel.make_rccl_transport(pm, device, group)
-        except Exception as e:      # keep the scaling run alive and say so in the JSON line
-            sys.stderr.write("bench: rank %d: RCCL transport unavailable (%s)\n" % (rank, e))
+        if not shared:
+            try:
+                rccl = parallel.make_rccl_transport(pm, device, group)
+            except Exception as e:      # keep the scaling run alive and say so in the JSON line
+                sys.stderr.write("bench: rank %d: RCCL transport unavailable (%s)\n" % (rank, e))
         # every rank must take the same path: one failed communicator sends all of them to the host fallback
         if all(group.all_gather_object(rccl is not None)):
             pm.transport = rccl
             exchange = "rccl"
+            rccl_ranks = rccl.comm.count()
+            if rccl_ranks != world:
+                raise SystemExit("bench: rank %d: the RCCL communicator has %d ranks, WORLD_SIZE is %d" % (rank, rccl_ranks, world))
         else:
             pm.transport = parallel.DistTransport(pm, group)
             exchange = "socket-host-fallback"
@@ -387,9 +399,20 @@ def main():
             pm.transport.barrier()
 
     stencil_ms, stage_ms = [], {}
+    pm.edge_board_digest = world > 1          # (warm-up only: a download of the replicated edge board per fix-up)
     for _ in range(args.warmup):
         step()
     barrier()
+    pm.edge_board_digest = False
+    per_rank = None
+    if world > 1:
+        # Every rank runs the SAME schedule from replicated numbers (the wave selection is a kernel on every rank): before the
+        # timed region the ranks compare what the warm-up left behind -- waves / rounds / tie-breaks and the replicated board --
+        # and stop with a message instead of drifting apart inside a collective later.
+        mine_state = (getattr(pm, 'edge_schedule_digest', None), getattr(pm, 'edge_board_sha256', None) if args.warmup > 0 else None)
+        states = group.all_gather_object(mine_state)
+        if any(st != states[0] for st in states):
+            raise SystemExit("bench: the ranks disagree after the warm-up: (waves, rounds, tie-breaks), sha256 of the edge board per rank = %r" % (states,))
     del stencil_ms[:]
     stage_ms.clear()
     t0 = time.perf_counter()
@@ -399,6 +422,10 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         dt = pm.transport.allreduce_max(dt)
+        per_rank = group.all_gather_object({"rank": rank, "edge_waves": int(pm.edge_waves), "edge_rounds_run_here": len(pm.edge_round_log),
+                                            "edge_host_looks": int(getattr(pm, 'edge_host_looks', 0)),
+                                            "edge_queued_batches": int(getattr(pm, 'edge_queued_batches', 0)),
+                                            "edge_fixup_ms": phase.get('edge_fixup_ms'), "tile_ms": phase.get('tile_ms')})
     tile = pm.tiles[mine[0]]._tile
     tm = tile.timings()
     if tm['n_unresolved']:
@@ -459,6 +486,10 @@ def main():
                       "edge_waves": pm.edge_waves, "edge_mode": 'pool' if world > 1 else 'reference'},
             "device_bytes": tile.device_bytes(),
         }
+        if world > 1:
+            out["rccl_ranks"] = rccl_ranks          # ncclCommCount of the communicator the strips travelled over (None: socket fallback)
+            out["per_rank"] = per_rank
+            out["sweep"]["edge_wave_graphs"] = bool(getattr(pm, 'edge_wave_graphs', False))
         if args.cpu_sample:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample, 1, args.drain_pits)
         if world == 1 and args.host_to_host:

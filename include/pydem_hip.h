@@ -98,7 +98,7 @@ int pydem_hip_device_memory(int device, int64_t *free_bytes, int64_t *total_byte
 /* The conditioning stages (pydem_fill_flats, pydem_pit_candidates_read, pydem_pit_paths) lease one scratch arena per device
  * for the duration of a call (it grows to the largest request seen: ~6 GB + up to 17 GB for the large-window simulations
  * of a 8192 x 8192 tile); this returns every arena to the driver.  It also empties the per-device free lists on which
- * pydem_tile_destroy leaves the planes of a tile for the next tile of the same shape (PYDEM_PLANE_CACHE_GB, default 64;
+ * pydem_tile_destroy leaves the planes of a tile for the next tile of the same shape (PYDEM_PLANE_CACHE_GB, default 32;
  * a failing allocation empties them as well) and the pinned chunks / streams of the whole-plane transfers.  No counterpart in
  * the reference (host arrays). */
 int pydem_hip_release_scratch(void);
@@ -282,10 +282,30 @@ int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *ful
  *   [2] out: waves run, [3] waves allowed, [8+a] / [72+a] metric numerator / denominator of tile a as the schedule holds
  *   them (stale for diagonal neighbours like check_mets :1116-1136), [136+a] / [200+a] strip hash of a's last round / whether
  *   it has one, [264+a] bit mask of the tiles reading a line of a, [328+a] a and its four side neighbours, [392+w] out: the
- *   members of wave w, [7] out: the waves ran as captured hipGraphs (one launch per wave; PYDEM_EDGE_GRAPH=0: plain launches),
+ *   members of wave w, [7] out: the waves ran as captured hipGraphs (one launch per wave; default without a communicator, plain launches with one; PYDEM_EDGE_GRAPH=0 / 1 forces either),
  *   [456+a] scratch (round stamps), [521] out: tie-break waves of the batch, [522] out: bit w = wave w was one.
  *   `scal_out` as `out` of pydem_board_eval.  pydem_tile_edge_queue_ready: 1 when the tile's rounds can be queued (condensed fix-up state built by its first round, strips buffers attached by pydem_board_set_desc). */
 int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned long long *state, unsigned long long *scal_out);
+/* A batch contains collectives, so everything that can fail on ONE rank alone is a call of its own:
+ *   pydem_board_prepare_waves  checks / builds what a batch over the tiles `ok_tiles` (bit per tile, = state[0]) needs -- the
+ *       tiles' fix-up state, watched lines, the staging layout (`staged` != 0: the batch sums its staging buffer over the ranks)
+ *       and the device tables -- and enqueues nothing.  With several ranks the caller lets the ranks agree on its verdict
+ *       (one allreduce) before any of them calls pydem_board_run_waves; that call then only enqueues.  (A single process may
+ *       skip it: run_waves prepares what is not prepared.)
+ *   pydem_board_run_waves_ex   the same batch with the sum over the ranks done by the CALLER (`exchange`, not RCCL: processes
+ *       sharing one GPU, transports without RCCL): per wave the staging buffer goes to the host, exchange(ctx, 0, bytes, n)
+ *       sums it byte-wise in place, and -- what RCCL cannot do -- exchange(ctx, 1, doubles, 8) (maximum in place) first
+ *       checks that every rank selected the SAME wave (-8 and a message otherwise).  One host look per wave: the tested
+ *       restatement of the queued path (every rank runs the selection kernel from replicated numbers), not the fast one.
+ * A batch that does not come back within PYDEM_EDGE_TIMEOUT seconds (default 300, 0 = wait for ever) returns -7 with the last
+ * wave selected on this rank in the message and aborts the communicator (ncclCommAbort): ranks whose schedules disagree
+ * would otherwise sit in ncclAllReduce without a word.  Replaces the manager's poll loop, process_manager.py:1214-1246.
+ *   pydem_comm_count           ranks behind the communicator (ncclCommCount) */
+typedef int (*pydem_exchange_fn)(void *ctx, int op, void *buf, int64_t n);
+int pydem_board_prepare_waves(pydem_board *b, int staged, unsigned long long ok_tiles);
+int pydem_board_run_waves_ex(pydem_board *b, pydem_comm *c, int k_waves, unsigned long long *state, unsigned long long *scal_out,
+                             pydem_exchange_fn exchange, void *ctx);
+int pydem_comm_count(pydem_comm *c, int *count);
 int pydem_tile_edge_queue_ready(pydem_tile *t);
 int pydem_board_download(pydem_board *b, double *out);
 

@@ -107,6 +107,9 @@ SYMBOLS = {
     'pydem_board_eval': (C.c_int, [_P, C.c_int, _P, _P, _P]),
     'pydem_board_download': (C.c_int, [_P, _P]),
     'pydem_board_run_waves': (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    'pydem_board_prepare_waves': (C.c_int, [_P, C.c_int, C.c_uint64]),
+    'pydem_board_run_waves_ex': (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P]),
+    'pydem_comm_count': (C.c_int, [_P, _P]),
     'pydem_tile_edge_queue_ready': (C.c_int, [_P]),
 }
 
@@ -403,12 +406,41 @@ class Board(object):
     SCH_OK, SCH_STOP, SCH_NWAVES, SCH_LIMIT, SCH_GRAPH, SCH_ND, SCH_PD, SCH_HASH, SCH_HAS, SCH_READERS, SCH_NBRS, SCH_LOG, SCH_NTB, SCH_TBLOG, SCH_WORDS = \
         0, 1, 2, 3, 7, 8, 72, 136, 200, 264, 328, 392, 521, 522, 528
 
-    def run_waves(self, comm, k_waves, state):
+    def prepare_waves(self, staged, ok_tiles):
+        """Everything a batch of queued waves over the tiles `ok_tiles` (bit mask) needs that can fail on this rank alone
+        (pydem_board_prepare_waves); nothing is enqueued.  Raises HipError; with several ranks the caller lets the ranks agree on
+        the outcome before any of them calls run_waves."""
+        check(self.lib.pydem_board_prepare_waves(self._h, 1 if staged else 0, C.c_uint64(int(ok_tiles))))
+
+    _EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int64)
+
+    def run_waves(self, comm, k_waves, state, exchange=None):
         """Up to k_waves waves without a host look (pydem_board_run_waves); `state` (uint64[528]) is updated in place; returns the
-        scalars of all tiles like eval()."""
+        scalars of all tiles like eval().  `exchange` (instead of a communicator): an object with sum_bytes_inplace(uint8 array)
+        and max_inplace(float64 array) that reduce over the ranks -- the staging buffer then goes through the host once per
+        wave (pydem_board_run_waves_ex; the multi-process tests on one GPU)."""
         assert state.dtype == np.uint64 and state.size == self.SCH_WORDS and state.flags.c_contiguous
-        check(self.lib.pydem_board_run_waves(self._h, comm._h if comm is not None else None, int(k_waves), state.ctypes.data_as(_P),
-                                             self._out.ctypes.data_as(_P)))
+        if exchange is None:
+            check(self.lib.pydem_board_run_waves(self._h, comm._h if comm is not None else None, int(k_waves), state.ctypes.data_as(_P),
+                                                 self._out.ctypes.data_as(_P)))
+            return self._out
+        failure = []
+
+        def cb(_ctx, op, buf, n):
+            try:
+                if op == 0:
+                    exchange.sum_bytes_inplace(np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_uint8)), shape=(int(n),)))
+                else:
+                    exchange.max_inplace(np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(int(n),)))
+                return 0
+            except Exception as exc:          # (an exception must not unwind through the C frames)
+                failure.append(exc)
+                return 1
+        fn = self._EXCHANGE(cb)
+        rc = self.lib.pydem_board_run_waves_ex(self._h, None, int(k_waves), state.ctypes.data_as(_P), self._out.ctypes.data_as(_P), fn, None)
+        if failure:
+            raise failure[0]
+        check(rc)
         return self._out
 
 
@@ -426,6 +458,12 @@ class Comm(object):
         buf = C.create_string_buffer(128)
         check(load().pydem_comm_unique_id(buf))
         return buf.raw
+
+    def count(self):
+        """Ranks behind the communicator as RCCL reports them (ncclCommCount)."""
+        n = C.c_int(0)
+        check(self.lib.pydem_comm_count(self._h, C.byref(n)))
+        return int(n.value)
 
     def close(self):
         if self._h:

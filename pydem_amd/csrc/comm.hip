@@ -229,6 +229,11 @@ struct pydem_board {
     hipGraphExec_t wave_exec[2] = {nullptr, nullptr};   // one wave, captured: before / after the collective (one graph without one)
     unsigned long long wave_ok = 0; bool wave_comm = false; hipStream_t wave_stream = nullptr;   // what the graphs were captured for
     bool graph_failed = false, tables_valid = false;
+    bool prepared = false; unsigned long long prepared_ok = 0; bool prepared_staged = false;   // pydem_board_prepare_waves passed for this set of tiles
+    std::vector<int> q_mine;                             // this rank's tiles of the prepared set
+    int g_eval = 1;
+    unsigned long long *h_progress = nullptr;            // pinned, written by the selection kernel: [0] waves selected so far in the batch, [1] members of the last one
+    unsigned char *h_stage = nullptr; size_t h_stage_bytes = 0;   // pinned copy of the staging buffer (batches whose sum over the ranks is the caller's: run_waves_ex)
 };
 
 // ---- queued waves: layout of the schedule's state (64-bit words; the same table on the host, pydem_amd/_ffi.py) ----
@@ -396,7 +401,7 @@ __global__ void k_board_scatter(const double *__restrict__ wb, double *__restric
 // strips changed since their last round; with at most 2 * n_workers tiles the ranking selects every candidate, so the
 // wave IS the candidate set.  The batch stops when there is no candidate (the host decides about the tie-break rule), when a
 // candidate's round cannot be queued (its first round builds the fix-up state on the host) or at the wave limit.
-__global__ void k_sched_select(unsigned long long *__restrict__ S, unsigned long long *__restrict__ scal, int n_tiles)
+__global__ void k_sched_select(unsigned long long *__restrict__ S, unsigned long long *__restrict__ scal, int n_tiles, unsigned long long *progress)
 {
     const int a = threadIdx.x;
     __shared__ unsigned long long s_wave, s_aff, s_chk, s_drop[64];
@@ -444,6 +449,8 @@ __global__ void k_sched_select(unsigned long long *__restrict__ S, unsigned long
             if (tb >= 0) { S[SCH_TBLOG] |= 1ull << S[SCH_NWAVES]; S[SCH_NTB] += 1; }
             S[SCH_LOG + S[SCH_NWAVES]] = wave; S[SCH_NWAVES] += 1; S[SCH_WAVE] = wave; S[SCH_AFFECTED] = s_aff; S[SCH_CHECK] = s_chk;
             S[SCH_TB] = tb >= 0 ? wave : 0ull;
+            // (host memory: what the watchdog of pydem_board_run_waves names when a batch does not come back)
+            if (progress) { __hip_atomic_store(&progress[1], wave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&progress[0], S[SCH_NWAVES], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
         } else { S[SCH_WAVE] = 0; S[SCH_AFFECTED] = 0; S[SCH_CHECK] = 0; S[SCH_TB] = 0; if (live) S[SCH_STOP] = (unsigned long long)stop; }
     }
 }
@@ -536,6 +543,8 @@ int pydem_board_destroy(pydem_board *b)
     if (b->sched) (void)hipFree(b->sched);
     if (b->scal_tb) (void)hipFree(b->scal_tb);
     if (b->h_sched) (void)hipHostFree(b->h_sched);
+    if (b->h_progress) (void)hipHostFree(b->h_progress);
+    if (b->h_stage) (void)hipHostFree(b->h_stage);
     board_drop_graphs(b);
     if (b->q_tiles) (void)hipFree(b->q_tiles);
     if (b->q_lines) (void)hipFree(b->q_lines);
@@ -754,18 +763,23 @@ int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *ful
 // wave's member word, on the tile's stream), the sum over the ranks when `c` is given (the WHOLE staging buffer: its size
 // must not depend on the wave), the copy to the board and the evaluation of the tiles that read the wave's lines.
 // `state` (SCH_WORDS 64-bit words, layout above) carries the schedule in and out; `scal_out` as in pydem_board_eval.
-// Every tile of this rank must satisfy tile_edge_queue_ready (the caller asks pydem_tile_edge_queue_ready first) unless its
-// bit in state[0] is clear: a candidate without the bit stops the batch before its wave.
-int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned long long *state, unsigned long long *scal_out)
+//
+// Two calls, because a batch contains collectives: pydem_board_prepare_waves does everything that can FAIL on one rank alone
+// (the tiles' fix-up state, watched lines, staging layout, the device tables and their allocations) and enqueues nothing;
+// the caller lets the ranks agree on its verdict (one allreduce) and only then calls pydem_board_run_waves, which -- for
+// the prepared set of tiles -- only enqueues.  A rank that found a problem after the others had entered the batch's first
+// ncclAllReduce would leave them there for good.
+static int board_prepare(pydem_board *b, bool staged, unsigned long long ok)
 {
-    HIP_TRY(hipSetDevice(b->device));
     if (b->n_tiles > 64) { pydem_set_error("pydem_board_run_waves: at most 64 tiles"); return -2; }
-    if (k_waves < 1 || k_waves > SCH_ROUND - SCH_LOG) { pydem_set_error("pydem_board_run_waves: 1..64 waves per batch"); return -2; }
     if ((int)b->tl.size() != b->n_tiles) { pydem_set_error("pydem_board_run_waves: pydem_board_set_lines first"); return -2; }
+    b->prepared = false;
     if (!b->sched) {
         HIP_TRY(hipMalloc((void **)&b->sched, SCH_WORDS * sizeof(unsigned long long)));
         HIP_TRY(hipHostMalloc((void **)&b->h_sched, SCH_WORDS * sizeof(unsigned long long)));
         HIP_TRY(hipMalloc((void **)&b->scal_tb, 64 * 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipHostMalloc((void **)&b->h_progress, 2 * sizeof(unsigned long long)));
+        b->h_progress[0] = b->h_progress[1] = 0;
     }
     if (b->cap > b->wcap) {
         if (b->wb) HIP_TRY(hipFree(b->wb));
@@ -773,36 +787,27 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
         b->wcap = b->cap;
         board_drop_graphs(b); b->tables_valid = false;   // (they hold the old staging buffer)
     }
-    pydem_board_list Lst, LstFull;
-    Lst.n = b->n_tiles; LstFull.n = b->n_tiles;
     int64_t most = 1;
     std::vector<int> mine;
-    const unsigned long long ok = state[SCH_OK];
     for (int i = 0; i < b->n_tiles; i++) {
         pydem_board::TileLines &T = b->tl[(size_t)i];
-        Lst.tile[i] = i; Lst.full[i] = 0; LstFull.tile[i] = i; LstFull.full[i] = 1;
         const pydem_board_desc &D = b->h_desc[(size_t)i];
         most = std::max<int64_t>(most, 2 * (int64_t)D.n + 2 * (int64_t)D.m);
-        state[SCH_ROUND + i] = 0;
         if (!T.tile || !((ok >> i) & 1ull)) continue;
         mine.push_back(i);
         if (!tile_edge_queue_ready(T.tile)) { pydem_set_error("pydem_board_run_waves: tile %d cannot queue its rounds", i); return -3; }
         for (const auto &ln : T.where)             // (a line registered after the tile's condensed graph was built)
             if (!tile_line_watched(T.tile, ln.first, ln.second)) { pydem_set_error("pydem_board_run_waves: tile %d: a board line is not watched", i); return -3; }
-        state[SCH_ROUND + i] = tile_edge_round_counter(T.tile);
     }
     static int eval_blocks = -1;                     // PYDEM_EVAL_BLOCKS: blocks of 1024 threads per tile in the evaluation (default 16)
     if (eval_blocks < 0) { const char *e = getenv("PYDEM_EVAL_BLOCKS"); eval_blocks = e ? std::max(1, std::min(atoi(e), 256)) : 16; }
-    const int g_eval = (int)std::min<int64_t>(cdiv(most, 1024), eval_blocks);
-    // The whole batch runs on ONE stream, the board's (the tiles' streams are idle: every host-driven wave ends with a
-    // synchronised evaluation), and a wave is a fixed handful of launches whatever the number of tiles: the rounds and the
-    // gathers go through device tables (entry = tile), gated by the wave's member word.  One tile per rank and eight tiles of
-    // one process take the same path (the second is what a single GPU can test).
+    b->g_eval = (int)std::min<int64_t>(cdiv(most, 1024), eval_blocks);
     hipStream_t bs = b->stream;
     const bool rebuild = !b->tables_valid || b->wave_ok != ok;
     if (rebuild) {
         HIP_TRY(hipStreamSynchronize(bs));
         board_drop_graphs(b);
+        b->tables_valid = false;
         if (b->q_tiles) { HIP_TRY(hipFree(b->q_tiles)); b->q_tiles = nullptr; }
         if (b->q_lines) { HIP_TRY(hipFree(b->q_lines)); b->q_lines = nullptr; }
         if (b->q_unpack) { HIP_TRY(hipFree(b->q_unpack)); b->q_unpack = nullptr; }
@@ -857,31 +862,101 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
         }
         b->tables_valid = true; b->wave_ok = ok;
     }
-    if (c && !b->q_staged_ok) { pydem_set_error("pydem_board_run_waves: with a communicator every tile needs its line list (pydem_board_set_lines, also for tiles of other ranks)"); return -3; }
+    if (staged && !b->q_staged_ok) { pydem_set_error("pydem_board_run_waves: with a communicator every tile needs its line list (pydem_board_set_lines, also for tiles of other ranks)"); return -3; }
+    b->q_mine = mine;
+    b->prepared = true; b->prepared_ok = ok; b->prepared_staged = staged;
+    return 0;
+}
+
+// `staged` != 0: the batch will sum its staging buffer over the ranks (a communicator, or the caller's exchange)
+int pydem_board_prepare_waves(pydem_board *b, int staged, unsigned long long ok_tiles)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    return board_prepare(b, staged != 0, ok_tiles);
+}
+
+// wait for the batch on stream s, at most PYDEM_EDGE_TIMEOUT seconds (default 300; 0 = for ever): a rank whose schedule
+// disagrees with the others' would otherwise sit in a collective without a word
+static int board_wait(pydem_board *b, hipStream_t s, pydem_comm *c)
+{
+    static double limit_s = -1.0;
+    if (limit_s < 0.0) { const char *e = getenv("PYDEM_EDGE_TIMEOUT"); limit_s = e ? atof(e) : 300.0; if (limit_s < 0.0) limit_s = 0.0; }
+    if (limit_s == 0.0) { HIP_TRY(hipStreamSynchronize(s)); return 0; }
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) { pydem_set_error("pydem_board_run_waves: %s", hipGetErrorString(e)); return -1; }
+        if ((++spins & 1023u) == 0) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const double dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+            if (dt > limit_s) {
+                const unsigned long long nw = b->h_progress ? b->h_progress[0] : 0ull, wave = b->h_progress ? b->h_progress[1] : 0ull;
+                pydem_set_error("pydem_board_run_waves: the batch did not come back within %.0f s (PYDEM_EDGE_TIMEOUT); the last wave selected on this rank was "
+                                "wave %llu of the batch, members 0x%llx%s", limit_s, nw, wave,
+                                c ? " -- the ranks' schedules disagree or a rank left the job; the RCCL communicator is aborted" : "");
+                if (c && c->comm) { (void)ncclCommAbort(c->comm); c->comm = nullptr; }
+                return -7;
+            }
+        }
+    }
+}
+
+// exchange(ctx, op, buf, n): op 0 = sum the n BYTES at buf over the ranks, byte by byte, in place; op 1 = maximum of the n
+// doubles at buf over the ranks, in place.  Returns 0.  (The staging buffer of a batch summed by the caller instead of RCCL:
+// processes that share one GPU -- RCCL refuses two ranks on one device -- and transports without RCCL.  One host look per
+// wave: this is the tested restatement of the queued path, not the fast one.)
+int pydem_board_run_waves_ex(pydem_board *b, pydem_comm *c, int k_waves, unsigned long long *state, unsigned long long *scal_out,
+                             pydem_exchange_fn exchange, void *ctx)
+{
+    HIP_TRY(hipSetDevice(b->device));
+    if (k_waves < 1 || k_waves > SCH_ROUND - SCH_LOG) { pydem_set_error("pydem_board_run_waves: 1..64 waves per batch"); return -2; }
+    if (c && exchange) { pydem_set_error("pydem_board_run_waves: a communicator or an exchange function, not both"); return -2; }
+    const bool staged = c != nullptr || exchange != nullptr;
+    const unsigned long long ok = state[SCH_OK];
+    // (callers that did not prepare -- a single process -- get it here; with several ranks the verdict must have been agreed on)
+    if (!(b->prepared && b->prepared_ok == ok && b->prepared_staged == staged && b->tables_valid)) PYDEM_TRY(board_prepare(b, staged, ok));
+    pydem_board_list Lst, LstFull;
+    Lst.n = b->n_tiles; LstFull.n = b->n_tiles;
+    for (int i = 0; i < b->n_tiles; i++) { Lst.tile[i] = i; Lst.full[i] = 0; LstFull.tile[i] = i; LstFull.full[i] = 1; state[SCH_ROUND + i] = 0; }
+    const std::vector<int> &mine = b->q_mine;
+    for (int i : mine) state[SCH_ROUND + i] = tile_edge_round_counter(b->tl[(size_t)i].tile);
+    const int g_eval = b->g_eval;
+    // The whole batch runs on ONE stream, the board's (the tiles' streams are idle: every host-driven wave ends with a
+    // synchronised evaluation), and a wave is a fixed handful of launches whatever the number of tiles: the rounds and the
+    // gathers go through device tables (entry = tile), gated by the wave's member word.  One tile per rank and eight tiles of
+    // one process take the same path (the second is what a single GPU can test).
+    hipStream_t bs = b->stream;
     // One wave, in two parts around the collective.  Everything a launch needs is read on the device (member words, round
     // stamps), so the parts can be captured once and replayed wave after wave.
     auto issue = [&](int part) -> int {
         if (part == 0) {
-            hipLaunchKernelGGL(k_sched_select, dim3(1), dim3(64), 0, bs, b->sched, b->scal, b->n_tiles);
+            hipLaunchKernelGGL(k_sched_select, dim3(1), dim3(64), 0, bs, b->sched, b->scal, b->n_tiles, b->h_progress);
             // (a tie-break wave: the strips of its tile once more, rule :274 everywhere; the numbers go to a scratch row)
             hipLaunchKernelGGL(k_board_eval, dim3(g_eval, b->n_tiles), dim3(1024), 0, bs, b->mb, b->desc, LstFull, b->scal_tb, b->sched + SCH_TB);
-            if (c) HIP_TRY(hipMemsetAsync(b->wb, 0, (size_t)b->q_stage_bytes, bs));
+            if (staged) HIP_TRY(hipMemsetAsync(b->wb, 0, (size_t)b->q_stage_bytes, bs));
             PYDEM_TRY(stage_edge_rounds_queued(bs, b->q_tiles, b->q_count, b->q_nper));
             // (without a collective the lines go straight to the board: the staging buffer exists to be summed over the ranks)
             if (b->q_nlines > 0)
                 hipLaunchKernelGGL(k_board_pack_gated, dim3(16, b->q_nlines), dim3(256), 0, bs, (const pydem_pack_line_q *)b->q_lines, b->q_nlines,
-                                   b->mb, reinterpret_cast<unsigned char *>(b->wb), c ? 1 : 0, b->sched + SCH_WAVE);
+                                   b->mb, reinterpret_cast<unsigned char *>(b->wb), staged ? 1 : 0, b->sched + SCH_WAVE);
         } else {
-            if (c && b->q_nunpack > 0)
+            if (staged && b->q_nunpack > 0)
                 hipLaunchKernelGGL(k_board_unpack_gated, dim3(16, b->q_nunpack), dim3(256), 0, bs, (const pydem_unpack_line *)b->q_unpack, b->q_nunpack,
                                    reinterpret_cast<const unsigned char *>(b->wb), b->mb, b->sched + SCH_WAVE);
             hipLaunchKernelGGL(k_board_eval, dim3(g_eval, b->n_tiles), dim3(1024), 0, bs, b->mb, b->desc, Lst, b->scal, b->sched + SCH_AFFECTED);
         }
         return 0;
     };
-    // ---- the wave as a graph (PYDEM_EDGE_GRAPH=0: plain launches): one launch per wave (two around a collective) instead of seven
-    static int use_graph = -1;
-    if (use_graph < 0) { const char *e = getenv("PYDEM_EDGE_GRAPH"); use_graph = e ? atoi(e) : 1; }
+    // ---- the wave as a captured graph: one launch per wave instead of seven.  PYDEM_EDGE_GRAPH=0 / 1 forces plain launches /
+    // graphs; the default is graphs WITHOUT a collective and plain launches with one: measured equal once a wave was down to
+    // six launches (27.5 against 26.0 ms for 126 waves), and graph capture around ncclAllReduce is one more thing that has
+    // never run with more than one rank
+    static int graph_env = -2;
+    if (graph_env == -2) { const char *e = getenv("PYDEM_EDGE_GRAPH"); graph_env = e ? (atoi(e) != 0) : -1; }
+    const int use_graph = exchange ? 0 : (graph_env >= 0 ? graph_env : (c ? 0 : 1));
     const int n_parts = c ? 2 : 1;                   // (without a collective both parts are one graph)
     if (use_graph && !b->graph_failed && (!b->wave_exec[0] || b->wave_comm != (c != nullptr) || b->wave_stream != bs)) {
         board_drop_graphs(b);
@@ -904,24 +979,66 @@ int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned l
     state[SCH_TB] = 0; state[SCH_NTB] = 0; state[SCH_TBLOG] = 0;
     if (state[SCH_LIMIT] > (unsigned long long)k_waves) state[SCH_LIMIT] = (unsigned long long)k_waves;
     memcpy(b->h_sched, state, SCH_WORDS * sizeof(unsigned long long));
+    b->h_progress[0] = b->h_progress[1] = 0;
     HIP_TRY(hipStreamSynchronize(b->stream));       // (the evaluations of the host-driven waves ran there)
     HIP_TRY(hipMemcpyAsync(b->sched, b->h_sched, SCH_WORDS * sizeof(unsigned long long), hipMemcpyHostToDevice, bs));
+    if (exchange && b->h_stage_bytes < (size_t)b->q_stage_bytes + 64) {
+        if (b->h_stage) { HIP_TRY(hipHostFree(b->h_stage)); b->h_stage = nullptr; b->h_stage_bytes = 0; }
+        HIP_TRY(hipHostMalloc((void **)&b->h_stage, (size_t)b->q_stage_bytes + 64));
+        b->h_stage_bytes = (size_t)b->q_stage_bytes + 64;
+    }
     for (int w = 0; w < k_waves; w++) {
         if (graphs) HIP_TRY(hipGraphLaunch(b->wave_exec[0], bs)); else PYDEM_TRY(issue(0));
         if (c) NCCL_TRY(ncclAllReduce(b->wb, b->wb, (size_t)b->q_stage_bytes, ncclUint8, ncclSum, c->comm, bs));   // (disjoint fills: x + 0 byte by byte)
+        bool stop_now = false;
+        if (exchange) {
+            // the caller's sum, and before it the check RCCL cannot make: every rank must have selected the SAME wave (the
+            // schedule runs on every rank from replicated numbers) -- maximum and minimum of (members, wave count, stop) agree
+            HIP_TRY(hipMemcpyAsync(b->h_stage, b->wb, (size_t)b->q_stage_bytes, hipMemcpyDeviceToHost, bs));
+            HIP_TRY(hipMemcpyAsync(b->h_sched, b->sched, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, bs));
+            PYDEM_TRY(board_wait(b, bs, nullptr));
+            const unsigned long long wv = b->h_sched[SCH_WAVE], nwv = b->h_sched[SCH_NWAVES], stp = b->h_sched[SCH_STOP];
+            double probe[8] = {(double)(wv & 0xFFFFFFFFull), -(double)(wv & 0xFFFFFFFFull), (double)(wv >> 32), -(double)(wv >> 32),
+                               (double)nwv, -(double)nwv, (double)stp, -(double)stp};
+            if (exchange(ctx, 1, probe, 8) != 0) { pydem_set_error("pydem_board_run_waves: the exchange function failed"); return -6; }
+            for (int q = 0; q < 8; q += 2)
+                if (probe[q] != -probe[q + 1]) {
+                    pydem_set_error("pydem_board_run_waves: the ranks disagree on wave %d of the batch (this rank: members 0x%llx, %llu waves so far, stop %llu)",
+                                    w, wv, nwv, stp);
+                    return -8;
+                }
+            if (exchange(ctx, 0, b->h_stage, b->q_stage_bytes) != 0) { pydem_set_error("pydem_board_run_waves: the exchange function failed"); return -6; }
+            HIP_TRY(hipMemcpyAsync(b->wb, b->h_stage, (size_t)b->q_stage_bytes, hipMemcpyHostToDevice, bs));
+            stop_now = stp != 0;                     // (agreed on above: every rank leaves the batch here)
+        }
         if (graphs) { if (c) HIP_TRY(hipGraphLaunch(b->wave_exec[1], bs)); }
         else PYDEM_TRY(issue(1));
+        if (stop_now) break;
     }
     // the metrics of the last wave's neighbourhood, as the next selection would read them
     hipLaunchKernelGGL(k_sched_settle, dim3(1), dim3(64), 0, bs, b->sched, b->scal, b->n_tiles);
     HIP_TRY(hipMemcpyAsync(b->h_sched, b->sched, SCH_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, bs));
     HIP_TRY(hipMemcpyAsync(b->h_scal, b->scal, (size_t)b->n_tiles * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, bs));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(bs));
+    PYDEM_TRY(board_wait(b, bs, c));
     memcpy(state, b->h_sched, SCH_WORDS * sizeof(unsigned long long));
     memcpy(scal_out, b->h_scal, (size_t)b->n_tiles * 8 * sizeof(unsigned long long));
     for (int i : mine) tile_edge_rounds_ran(b->tl[(size_t)i].tile, (int)state[SCH_NWAVES]);
     state[SCH_GRAPH] = graphs ? 1 : 0;
+    b->prepared = false;                             // (a tile's state may change before the next batch: the caller prepares again or run_waves does)
+    return 0;
+}
+
+int pydem_board_run_waves(pydem_board *b, pydem_comm *c, int k_waves, unsigned long long *state, unsigned long long *scal_out)
+{
+    return pydem_board_run_waves_ex(b, c, k_waves, state, scal_out, nullptr, nullptr);
+}
+
+// RCCL ranks behind a communicator (1 for a single process)
+int pydem_comm_count(pydem_comm *c, int *count)
+{
+    if (!c || !c->comm) { pydem_set_error("pydem_comm_count: no communicator"); return -2; }
+    NCCL_TRY(ncclCommCount(c->comm, count));
     return 0;
 }
 

@@ -101,6 +101,7 @@ struct pydem_tile {
     void *cond_mem = nullptr; size_t cond_bytes = 0;
     void *cond_node = nullptr, *cond_edge = nullptr; double *cond_slot = nullptr;
     int32_t *cond_q0 = nullptr, *cond_q1 = nullptr, *cond_nanq = nullptr, *cond_cnt = nullptr;
+    void *cb_mem[3] = {nullptr, nullptr, nullptr}; size_t cb_bytes[3] = {0, 0, 0};   // scratch of the device build of that graph (uca_cbuild.inl), kept with the tile
     double *h_strip_d = nullptr; uint8_t *h_strip_f = nullptr; size_t h_strip_cap = 0;   // pinned strip staging
     void *h_stage = nullptr; size_t h_stage_bytes = 0;      // pinned host staging of the conditioning stages (tile_pinned)
     int32_t etodo_prev = 0;         // cells whose edge_done byte the previous round cleared (tlist = flatlist)

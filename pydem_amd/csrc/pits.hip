@@ -526,6 +526,9 @@ __device__ __forceinline__ double dpp_fmin(double v)
 }
 // minimum over the wavefront: butterflies inside each row of 16 lanes on the DPP crossbar, then the four
 // row values through scalar registers
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "wave_min uses the gfx9 DPP row broadcasts (row_bcast:15 / row_bcast:31, removed in gfx10+): this library is built for gfx950 only"
+#endif
 __device__ __forceinline__ double wave_min(double v)
 {
     v = dpp_fmin<0xB1>(v);        // quad_perm [1,0,3,2]
@@ -537,6 +540,8 @@ __device__ __forceinline__ double wave_min(double v)
     // read); two readlanes instead of eight and no minimum on values that came back through scalar registers
     v = dpp_fmin<0x142>(v);       // row_bcast:15
     v = dpp_fmin<0x143>(v);       // row_bcast:31
+    // (after the two broadcasts ONLY lane 63 holds the minimum -- rows 0 and 1 took min(v, 0) from the lanes without a source;
+    // the function hands out lane 63's value as a wavefront-uniform scalar, so no caller can pick up another lane's)
     const int lo = __double2loint(v), hi = __double2hiint(v);
     return __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
 }

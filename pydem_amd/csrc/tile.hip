@@ -55,14 +55,15 @@ size_t plane_cache_limit()
     }();
     return lim;
 }
-// (c->mu held) free the least recently returned blocks until `room` more bytes fit under the limit
-void plane_cache_evict(PlaneCache *c, size_t room)
+// (c->mu held) take the least recently returned blocks off the lists until `room` more bytes fit under the limit; the caller
+// frees them AFTER it has let go of the lock (hipFree synchronises the device)
+void plane_cache_evict(PlaneCache *c, size_t room, std::vector<void *> &victims)
 {
     const size_t lim = plane_cache_limit();
     while (!c->free_blocks.empty() && c->kept + room > lim) {
         auto old = c->free_blocks.begin();
         for (auto it = c->free_blocks.begin(); it != c->free_blocks.end(); ++it) if (it->second.stamp < old->second.stamp) old = it;
-        (void)hipFree(old->second.p);
+        victims.push_back(old->second.p);
         c->kept -= old->first;
         c->free_blocks.erase(old);
     }
@@ -89,9 +90,9 @@ void *plane_take(int device, size_t bytes)
             c->live[q] = bytes;
             return q;
         }
-        // a size the lists do not hold (a tile of another shape): the blocks that have waited longest make room, so that
-        // dead sizes do not pile up beside the live ones
-        plane_cache_evict(c, bytes);
+        // (a size the lists do not hold: nothing is evicted here -- the blocks on the lists are those of the tile destroyed
+        // last, i.e. what the tile being built asks for next; dead sizes leave when plane_give needs their room, and a failing
+        // hipMalloc empties the lists)
     }
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, bytes);
@@ -117,6 +118,8 @@ void plane_give(int device, void *q)
 {
     if (!q) return;
     PlaneCache *c = plane_cache(device);
+    std::vector<void *> victims;
+    bool kept = false;
     {
         std::lock_guard<std::mutex> g(c->mu);
         auto it = c->live.find(q);
@@ -124,13 +127,14 @@ void plane_give(int device, void *q)
             const size_t bytes = it->second;
             c->live.erase(it);
             if (bytes <= plane_cache_limit()) {
-                plane_cache_evict(c, bytes);
+                plane_cache_evict(c, bytes, victims);
                 c->free_blocks.emplace(bytes, FreeBlock{q, ++c->clock}); c->kept += bytes;
-                return;
+                kept = true;
             }
         }
     }
-    (void)hipFree(q);
+    for (void *v : victims) (void)hipFree(v);
+    if (!kept) (void)hipFree(q);
 }
 
 // hipMalloc for everything else the library maps on a device (scratch, arenas, record buffers): when it fails the free lists
@@ -533,7 +537,7 @@ int pydem_tile_destroy(pydem_tile *t)
                     t->counters, t->scratch, t->pits.src, t->pits.dst, t->pits.w, t->pits.in_src,
                     t->pits.in_dst, t->pits.in_w, t->pits.raw_src, t->pits.raw_dst, t->pits.raw_w,
                     t->estamp, t->edelta, t->p_delta, t->s_data, t->p_flags, t->s_flags, t->line_stage, t->contrib,
-                    t->eseed, t->lines_stage, t->pits.sort_buf, t->nd_rec, t->cond_mem};
+                    t->eseed, t->lines_stage, t->pits.sort_buf, t->nd_rec, t->cond_mem, t->cb_mem[0], t->cb_mem[1], t->cb_mem[2]};
     for (void *p : ptrs) if (p) plane_give(t->device, p);          // (blocks that did not come from tile_alloc are freed)
     if (t->h_counters) (void)hipHostFree(t->h_counters);
     if (t->h_strip_d) (void)hipHostFree(t->h_strip_d);

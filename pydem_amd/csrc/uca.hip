@@ -22,6 +22,7 @@
 //   K6  calc_twi :1647-1677.
 // The pointwise kernels are bounded by HBM; the sweeps by dependent memory latency times the tiles / cells in flight.
 #include "internal.h"
+#include <hipcub/hipcub.hpp>      // scans / radix sorts of the device operator build (uca_cbuild.inl)
 #include <algorithm>
 #include <functional>
 #include <memory>
@@ -2842,6 +2843,7 @@ __global__ __launch_bounds__(256) void k_cinc_apply(CIncArgs E)
 int grid_for(int64_t work, int cap) { const int64_t g = cdiv(work, 256); return (int)(g < cap ? (g > 0 ? g : 1) : cap); }
 
 #include "uca_cond.inl"
+#include "uca_cbuild.inl"
 
 }  // namespace
 
@@ -3732,16 +3734,12 @@ static int cond_args(pydem_tile *t, CondArgsE &X)
     return 0;
 }
 
-// Build the condensed graph of the watched cells from the compact records (just linked by einc_prepare).  Returns 0 and
-// leaves cond_live false when the tile does not qualify (switched off, too many records, a cycle among the records).
-static int cond_build(pydem_tile *t)
+// Build the condensed graph of the watched cells from the compact records (just linked by einc_prepare) ON THE HOST: the
+// build of rounds 4-5, since round 6 the fall-back and the checker of the device build (cond_build_device below).  Returns 0
+// and leaves cond_live false when the tile does not qualify (a cycle among the records, a pathological fan).
+static int cond_build_host(pydem_tile *t)
 {
     t->cond_live = false; t->cond_pending = false;
-    static int enabled = -1;
-    if (enabled < 0) { const char *e = getenv("PYDEM_EDGE_COND"); enabled = e ? atoi(e) : 1; }
-    int64_t max_nd = 1 << 20;
-    { const char *e = getenv("PYDEM_EDGE_COND_MAX"); if (e) max_nd = atoll(e); }
-    if (!enabled || !t->einc_compact || t->nd <= 0 || t->nd > max_nd) return 0;
     const double t_begin = host_now_ms();
     const int32_t nd = t->nd;
     const int n = (int)t->n, m = (int)t->m;
@@ -4005,6 +4003,270 @@ static int cond_build(pydem_tile *t)
                 "(copy %.2f, adjacency %.2f, node order %.2f, reverse sweep %.2f [%zu vectors, %zu entries], nodes + upload %.2f)\n",
                 nd, nw, (long long)ne_all, npe, host_now_ms() - t_begin, t_copied - t_begin, t_csr - t_copied, t_wsort - t_csr, t_swept - t_wsort,
                 (size_t)n_vec, (size_t)n_ent, host_now_ms() - t_swept);
+    return 0;
+}
+
+// ---- the same graph built on the device (kernels in uca_cbuild.inl) ---------------------------------------------------
+static int cb_reserve(pydem_tile *t, int which, size_t bytes)
+{
+    if (t->cb_bytes[which] >= bytes) return 0;
+    if (t->cb_mem[which]) { HIP_TRY(hipStreamSynchronize(t->stream)); HIP_TRY(hipFree(t->cb_mem[which])); t->device_bytes -= (int64_t)t->cb_bytes[which]; t->cb_mem[which] = nullptr; t->cb_bytes[which] = 0; }
+    const size_t want = (bytes + bytes / 4 + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);     // (headroom + 1 MiB steps: run-to-run sizes move by a few records)
+    HIP_TRY(dev_malloc(&t->cb_mem[which], want));
+    t->cb_bytes[which] = want; t->device_bytes += (int64_t)want;
+    return 0;
+}
+
+struct CBump {
+    char *base; size_t off = 0;
+    explicit CBump(void *b) : base((char *)b) {}
+    template <typename T> T *take(size_t count) { T *p = base ? (T *)(base + off) : nullptr; off += (count * sizeof(T) + 255) & ~(size_t)255; return p; }
+};
+
+// *status: 1 built (cond_live), 0 the tile does not qualify (a cycle among the records: the host build would say the same),
+// -1 the device build gave up (more than CB_MAXD out-edges, pool overflow): try the host build
+static int cond_build_device(pydem_tile *t, int *status)
+{
+    *status = -1;
+    t->cond_live = false; t->cond_pending = false;
+    const double t_begin = host_now_ms();
+    const int32_t nd = t->nd;
+    const int n = (int)t->n, m = (int)t->m;
+    CBArgs B;
+    memset(&B, 0, sizeof(B));
+    PYDEM_TRY(cinc_args(t, B.C));
+    const CIncArgs &C = B.C;
+    auto mark = [&](int axis, int64_t index) {
+        const int64_t count = axis == 0 ? m : n;
+        hipLaunchKernelGGL(k_cond_mark, dim3((unsigned)std::min<int64_t>(cdiv(count, 256), 64)), dim3(256), 0, t->stream, C, axis, index);
+    };
+    mark(0, 0); mark(0, n - 1); mark(1, 0); mark(1, m - 1);
+    for (const auto &w : t->watch) mark(w.first, w.second);
+    const size_t nw_bound = (size_t)std::min<int64_t>((int64_t)nd, (int64_t)(4 + t->watch.size()) * (int64_t)std::max(n, m));
+    const int nd1 = nd + 1;
+    size_t tmp_scan = 0, tmp_sortw = 0;
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, (int32_t *)nullptr, (int32_t *)nullptr, nd1, t->stream));
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sortw, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
+                                               (int)nw_bound, 0, 32, t->stream));
+    const size_t tmp1 = std::max(tmp_scan, tmp_sortw) + 256;
+    // ---- phase 1: per-record state, counts
+    void *tmp_a = nullptr;
+    auto lay1 = [&](void *base) {
+        CBump A(base);
+        B.rv = A.take<CBVal>((size_t)nd); B.ri = A.take<CBRec>((size_t)nd);
+        B.pred_cnt = A.take<int32_t>((size_t)nd1); B.pit_cnt = A.take<int32_t>((size_t)nd1);
+        B.pred_beg = A.take<int32_t>((size_t)nd1); B.pit_beg = A.take<int32_t>((size_t)nd1);
+        B.q0 = A.take<int32_t>((size_t)nd * 2); B.q1 = A.take<int32_t>((size_t)nd * 2);      // (second halves: retry lists of k_cb_sweep)
+        B.wcell = A.take<int32_t>(nw_bound); B.wrec = A.take<int32_t>(nw_bound);
+        B.wcell_s = A.take<int32_t>(nw_bound); B.wrec_s = A.take<int32_t>(nw_bound);
+        B.ctr = A.take<int32_t>(CBC_WORDS);
+        tmp_a = A.take<char>(tmp1);
+        return A.off;
+    };
+    PYDEM_TRY(cb_reserve(t, 0, lay1(nullptr)));
+    lay1(t->cb_mem[0]);
+    B.w_cap = (int32_t)nw_bound;
+    B.w_sorted = t->pits.w;
+    HIP_TRY(hipMemsetAsync(B.ctr, 0, CBC_WORDS * sizeof(int32_t), t->stream));
+    const int g_nd = grid_for(nd, 1024);
+    hipLaunchKernelGGL(k_cb_count, dim3(g_nd), dim3(256), 0, t->stream, B);
+    { size_t tb = tmp1; HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp_a, tb, B.pred_cnt, B.pred_beg, nd1, t->stream)); }
+    { size_t tb = tmp1; HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp_a, tb, B.pit_cnt, B.pit_beg, nd1, t->stream)); }
+    int32_t *h = t->h_counters;
+    HIP_TRY(hipMemcpyAsync(h, B.ctr, CBC_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(h + 16, B.pred_beg + nd, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(h + 17, B.pit_beg + nd, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    const int32_t nw = h[CBC_NW], n_pred = h[16], n_pit = h[17];
+    if (h[CBC_FAIL] & 2) { pydem_set_error("condensed edge rounds: inconsistent in-edge count of a record"); return -5; }
+    if ((size_t)nw > nw_bound) { pydem_set_error("condensed edge rounds: %d watched nodes, expected at most %zu", nw, nw_bound); return -5; }
+    const double t_counted = host_now_ms();
+    // ---- phase 2: lists, node order, the reverse sweep
+    const int64_t pool_cap = std::min<int64_t>((int64_t)8 * nd + 65536, (int64_t)1 << 27);
+    const int nw1 = nw + 1;
+    auto lay2 = [&](void *base) {
+        CBump A(base);
+        B.pred = A.take<int32_t>((size_t)n_pred + 1); B.pit = A.take<CBPit>((size_t)n_pit + 1);
+        B.pool = A.take<CBEnt>((size_t)pool_cap);
+        B.nout_c = A.take<int32_t>((size_t)nw1); B.nout = A.take<int32_t>((size_t)nw1);
+        B.n_in = A.take<int32_t>((size_t)nw1); B.in_first = A.take<int32_t>((size_t)nw1);
+        B.exc_in_c = A.take<int32_t>((size_t)nw1); B.exc_in = A.take<int32_t>((size_t)nw1);
+        B.exc_out_c = A.take<int32_t>((size_t)nw1); B.exc_out = A.take<int32_t>((size_t)nw1);
+        return A.off;
+    };
+    PYDEM_TRY(cb_reserve(t, 1, lay2(nullptr)));
+    lay2(t->cb_mem[1]);
+    B.pool_cap = (int32_t)pool_cap; B.nw = nw;
+    hipLaunchKernelGGL(k_cb_fill, dim3(g_nd), dim3(256), 0, t->stream, B);
+    int cell_bits = 1;
+    while (((int64_t)1 << cell_bits) < t->NN) cell_bits++;
+    if (nw > 0) {
+        size_t tb = tmp1;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp_a, tb, B.wcell, B.wcell_s, B.wrec, B.wrec_s, nw, 0, cell_bits, t->stream));
+        hipLaunchKernelGGL(k_cb_wid, dim3(grid_for(nw, 256)), dim3(256), 0, t->stream, B);
+    }
+    // the levels: while the frontier is wide, one launch per level over the whole chip (small batches, one look from the host per
+    // batch); the narrow remainder in ONE workgroup without launches in between (PYDEM_CB_WIDE: the width at which it takes over)
+    static int wide = -1;
+    if (wide < 0) { const char *e = getenv("PYDEM_CB_WIDE"); wide = e ? atoi(e) : 8192; }
+    int levels_run = 0;
+    for (;;) {
+        HIP_TRY(hipMemcpyAsync(h, B.ctr, CBC_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        if (h[CBC_Q + levels_run % 3] <= wide || (h[CBC_FAIL] & 1)) break;
+        for (int b = 0; b < 4; b++, levels_run++)
+            hipLaunchKernelGGL(k_cb_level, dim3(CB_GRID), dim3(CB_LANES), 0, t->stream, B, levels_run);
+        if (levels_run > (1 << 22)) { pydem_set_error("condensed edge rounds: flow paths too long"); return -5; }
+    }
+    const int levels_wide = levels_run;
+    hipLaunchKernelGGL(k_cb_sweep, dim3(1), dim3(1024), 0, t->stream, B, levels_run);
+    hipLaunchKernelGGL(k_cb_nout, dim3(grid_for(nw1, 256)), dim3(256), 0, t->stream, B);
+    { size_t tb = tmp1; HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp_a, tb, B.nout_c, B.nout, nw1, t->stream)); }
+    HIP_TRY(hipMemcpyAsync(h, B.ctr, CBC_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(h + 16, B.nout + nw, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    const double t_swept = host_now_ms();
+    const int32_t ne_all = h[16], levels = h[CBC_LEVELS], pool_used = h[CBC_POOL], n_slow = h[CBC_SLOW];
+    if (h[CBC_FAIL] & 1) return 0;                              // (*status == -1: the host build takes over)
+    if (h[CBC_PROC] != nd) { *status = 0; return 0; }           // a cycle among the records: not a DAG, plain cascade
+    if (ne_all > INT32_MAX / 2) { *status = 0; return 0; }
+    // ---- phase 3: edges, slots, nodes -- straight into the round's arrays (one allocation: nodes | edges | slots | two queues |
+    // NaN list | counters; edge / slot arrays sized by the bound ne_all)
+    size_t tmp_sorte = 0, tmp_scanw = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sorte, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
+                                               (int)std::max(ne_all, 1), 0, 32, t->stream));
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scanw, (int32_t *)nullptr, (int32_t *)nullptr, nw1, t->stream));
+    const size_t tmp3 = std::max(tmp_sorte, tmp_scanw) + 256;
+    void *tmp_c = nullptr;
+    auto lay3 = [&](void *base) {
+        CBump A(base);
+        const size_t ne1 = (size_t)ne_all + 1;
+        B.e_dst = A.take<int32_t>(ne1); B.e_q = A.take<int32_t>(ne1); B.e_dst_s = A.take<int32_t>(ne1); B.e_q_s = A.take<int32_t>(ne1);
+        B.e_slot = A.take<int32_t>(ne1); B.e_w = A.take<double>(ne1);
+        tmp_c = A.take<char>(tmp3);
+        return A.off;
+    };
+    PYDEM_TRY(cb_reserve(t, 2, lay3(nullptr)));
+    lay3(t->cb_mem[2]);
+    const size_t nan_cap = (size_t)ne_all + (size_t)nw + 64;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_node = take((size_t)nw * sizeof(CNode)), o_edge = take((size_t)(ne_all + 1) * sizeof(CEdge)), o_slot = take((size_t)(ne_all + 1) * 8),
+                 o_q0 = take((size_t)nw * 4), o_q1 = take((size_t)nw * 4), o_nan = take(nan_cap * 4), o_cnt = take(64);
+    if (off > t->cond_bytes) {
+        if (t->cond_mem) { HIP_TRY(hipFree(t->cond_mem)); t->device_bytes -= (int64_t)t->cond_bytes; t->cond_mem = nullptr; t->cond_bytes = 0; }
+        const size_t want = (off + off / 4 + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+        HIP_TRY(dev_malloc((void **)&t->cond_mem, want));
+        t->cond_bytes = want; t->device_bytes += (int64_t)t->cond_bytes;
+    }
+    char *base = (char *)t->cond_mem;
+    t->cond_node = base + o_node; t->cond_edge = base + o_edge; t->cond_slot = (double *)(base + o_slot);
+    t->cond_q0 = (int32_t *)(base + o_q0); t->cond_q1 = (int32_t *)(base + o_q1); t->cond_nanq = (int32_t *)(base + o_nan);
+    t->cond_cnt = (int32_t *)(base + o_cnt); t->cond_nw = nw; t->cond_nan_cap = (int32_t)std::min<size_t>(nan_cap, (size_t)INT32_MAX);
+    B.node = (CNode *)t->cond_node; B.edge = (CEdge *)t->cond_edge;
+    HIP_TRY(hipMemsetAsync(base + o_slot, 0, off - o_slot, t->stream));
+    if (nw > 0) {
+        const int g_nw = grid_for(nw1, 256);
+        hipLaunchKernelGGL(k_cb_edges, dim3(g_nw), dim3(256), 0, t->stream, B);
+        hipLaunchKernelGGL(k_cb_excess, dim3(g_nw), dim3(256), 0, t->stream, B);
+        { size_t tb = tmp3; HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp_c, tb, B.n_in, B.in_first, nw1, t->stream)); }
+        { size_t tb = tmp3; HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp_c, tb, B.exc_in_c, B.exc_in, nw1, t->stream)); }
+        { size_t tb = tmp3; HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp_c, tb, B.exc_out_c, B.exc_out, nw1, t->stream)); }
+        if (ne_all > 0) {
+            int node_bits = 1;
+            while (((int64_t)1 << node_bits) < nw) node_bits++;
+            size_t tb = tmp3;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp_c, tb, B.e_dst, B.e_dst_s, B.e_q, B.e_q_s, ne_all, 0, node_bits, t->stream));
+            hipLaunchKernelGGL(k_cb_slots, dim3(grid_for(ne_all, 256)), dim3(256), 0, t->stream, B, ne_all);
+        }
+        hipLaunchKernelGGL(k_cb_nodes, dim3(g_nw), dim3(256), 0, t->stream, B);
+    }
+    CondArgsE X;
+    t->cond_live = true;                  // (cond_args reads the fields set above)
+    PYDEM_TRY(cond_args(t, X));
+    if (nw) hipLaunchKernelGGL(k_cond_attach, dim3(grid_for(nw, 256)), dim3(256), 0, t->stream, X);
+    HIP_TRY(hipGetLastError());
+    t->watch_built = t->watch.size();
+    *status = 1;
+    if (getenv("PYDEM_EDGE_DEBUG")) {
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        fprintf(stderr, "condensed edge rounds (device build): %d records -> %d watched nodes, %d edges (%d pit edges among the records); %.2f ms "
+                "(lists %.2f, reverse sweep %.2f [%d levels, %d of them as launches over the chip, %d pool entries, %d merges from the pool], nodes %.2f)\n",
+                nd, nw, ne_all, n_pit, host_now_ms() - t_begin, t_counted - t_begin, t_swept - t_counted, levels, levels_wide, pool_used, n_slow, host_now_ms() - t_swept);
+    }
+    return 0;
+}
+
+// PYDEM_COND_BUILD=check: the device build against the host build, node by node (same nodes, counts, edges and slots;
+// weights to 1e-12 relative: the host sorts the pit edges of one pit by record id, the device by drain cell)
+static int cond_build_check(pydem_tile *t)
+{
+    int st = -1;
+    PYDEM_TRY(cond_build_device(t, &st));
+    if (st != 1) { PYDEM_TRY(cond_build_host(t)); if (st == 0 && t->cond_live) { pydem_set_error("condensed build check: the device build found a cycle, the host build none"); return -5; } return 0; }
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    const int32_t nw = t->cond_nw;
+    std::vector<CNode> dn((size_t)std::max(nw, 1));
+    std::vector<CEdge> de;
+    auto grab = [&](std::vector<CNode> &nodes, std::vector<CEdge> &edges) -> int {
+        nodes.resize((size_t)std::max(t->cond_nw, 1));
+        if (t->cond_nw) HIP_TRY(hipMemcpy(nodes.data(), t->cond_node, (size_t)t->cond_nw * sizeof(CNode), hipMemcpyDeviceToHost));
+        int64_t ne = 0;
+        for (int32_t w = 0; w < t->cond_nw; w++) ne = std::max<int64_t>(ne, (int64_t)nodes[(size_t)w].out_base + std::max(0, nodes[(size_t)w].n_out - 2));
+        edges.resize((size_t)std::max<int64_t>(ne, 1));
+        if (ne) HIP_TRY(hipMemcpy(edges.data(), t->cond_edge, (size_t)ne * sizeof(CEdge), hipMemcpyDeviceToHost));
+        return 0;
+    };
+    PYDEM_TRY(grab(dn, de));
+    // (the device build has attached the nodes to their records: undo that before the host build reads them again)
+    std::vector<CNode> hn; std::vector<CEdge> he;
+    {
+        CondArgsE X; PYDEM_TRY(cond_args(t, X));
+        if (nw) hipLaunchKernelGGL(k_cond_detach, dim3(grid_for(nw, 256)), dim3(256), 0, t->stream, X);
+    }
+    PYDEM_TRY(cond_build_host(t));
+    if (!t->cond_live) { pydem_set_error("condensed build check: the host build gave up where the device build did not"); return -5; }
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    PYDEM_TRY(grab(hn, he));
+    if (t->cond_nw != nw) { pydem_set_error("condensed build check: %d nodes on the device, %d on the host", nw, t->cond_nw); return -5; }
+    double worst = 0.0;
+    for (int32_t w = 0; w < nw; w++) {
+        const CNode &a = dn[(size_t)w], &b = hn[(size_t)w];
+        if (a.cell != b.cell || a.cw != b.cw || a.cnt != b.cnt || a.n_in != b.n_in || a.n_out != b.n_out || a.in_base != b.in_base || a.out_base != b.out_base) {
+            pydem_set_error("condensed build check: node %d (cell %d / %d): cnt %d / %d, in %d / %d, out %d / %d, bases %d %d / %d %d", w, a.cell, b.cell, a.cnt, b.cnt,
+                            a.n_in, b.n_in, a.n_out, b.n_out, a.in_base, a.out_base, b.in_base, b.out_base);
+            return -5;
+        }
+        for (int e = 0; e < a.n_out; e++) {
+            const CEdge &x = e < 2 ? a.e_inl[e] : de[(size_t)(a.out_base + e - 2)], &y = e < 2 ? b.e_inl[e] : he[(size_t)(b.out_base + e - 2)];
+            if (x.dst != y.dst || x.slot != y.slot) { pydem_set_error("condensed build check: node %d edge %d: dst %d / %d, slot %d / %d", w, e, x.dst, y.dst, x.slot, y.slot); return -5; }
+            const double d = fabs(x.w - y.w) / (fabs(y.w) > 0 ? fabs(y.w) : 1.0);
+            if (!(d <= 1e-12)) { pydem_set_error("condensed build check: node %d edge %d: weight %.17g / %.17g", w, e, x.w, y.w); return -5; }
+            worst = std::max(worst, d);
+        }
+    }
+    if (getenv("PYDEM_EDGE_DEBUG")) fprintf(stderr, "condensed build check: %d nodes identical, weights within %.3g relative\n", nw, worst);
+    return 0;
+}
+
+// Build the condensed graph of the watched cells from the compact records (just linked by einc_prepare).  Returns 0 and
+// leaves cond_live false when the tile does not qualify (switched off, too many records, a cycle among the records).
+static int cond_build(pydem_tile *t)
+{
+    t->cond_live = false; t->cond_pending = false;
+    static int enabled = -1;
+    if (enabled < 0) { const char *e = getenv("PYDEM_EDGE_COND"); enabled = e ? atoi(e) : 1; }
+    int64_t max_nd = 1 << 20;
+    { const char *e = getenv("PYDEM_EDGE_COND_MAX"); if (e) max_nd = atoll(e); }
+    if (!enabled || !t->einc_compact || t->nd <= 0 || t->nd > max_nd) return 0;
+    const char *how = getenv("PYDEM_COND_BUILD");           // (read per build: the tests switch it) device (default) | host | check
+    if (how && !strcmp(how, "host")) return cond_build_host(t);
+    if (how && !strcmp(how, "check")) return cond_build_check(t);
+    int st = -1;
+    PYDEM_TRY(cond_build_device(t, &st));
+    if (st < 0) return cond_build_host(t);
     return 0;
 }
 

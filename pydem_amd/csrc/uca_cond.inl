@@ -404,3 +404,13 @@ __global__ void k_cond_attach(CondArgsE X)
         R.cnt += W_BARRIER;
     }
 }
+
+// (PYDEM_COND_BUILD=check: the host build reads the records again after the device build attached its nodes)
+__global__ void k_cond_detach(CondArgsE X)
+{
+    for (int32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < X.nw; w += gridDim.x * blockDim.x) {
+        NDRec &R = X.C.rec[X.node[w].rec];
+        R.wid = -1;
+        R.cnt -= W_BARRIER;
+    }
+}

@@ -53,6 +53,14 @@ class DistTransport(EdgeTransport):
         cannot travel by RCCL: ProcessManager._process_uca_edges_pool_device)."""
         self.group.sum_inplace(arr)
 
+    def sum_bytes_inplace(self, arr):
+        """Byte-wise sum of a uint8 array over all ranks, in place (the staging buffer of a QUEUED batch of the fix-up: the
+        socket restatement of the RCCL path's ncclAllReduce(ncclUint8), ProcessManager._process_uca_edges_pool_device)."""
+        self.group.sum_bytes_inplace(arr)
+
+    def max_inplace(self, arr):
+        self.group.max_inplace(arr)
+
     def barrier(self):
         self.group.barrier()
 

@@ -753,6 +753,7 @@ class ProcessManager(object):
         self.edge_rounds_skipped = 0
         self.edge_waves = 0
         self.edge_round_log = []           # (wave, tile, host ms) of every round this process ran
+        self.edge_queued_batches = 0       # batches of waves chosen on the device and queued (pydem_board_run_waves)
         self._edge_line_memo = {}
         self._mets = None
         self._edge_cache = {}
@@ -1058,8 +1059,18 @@ class ProcessManager(object):
         # tile's first round (it builds the tile's fix-up state) and rounds that are not in the condensed form.  Same waves,
         # same rounds (tests/test_gpu_process_manager.py holds both loops against each other).
         k_queue = int(os.environ.get('PYDEM_EDGE_QUEUE', '16'))
-        queue = (k_queue > 0 and n_t <= min(width, 64) and not checking and not self.keep_first_pass_uca and host_sum is None
+        # (a transport without RCCL that can sum bytes -- the socket group -- drives the SAME queued path with the staging buffer
+        # summed on the host once per wave: slower than its host-driven loop, but it is how the per-rank wave selection is tested
+        # with more than one rank on one GPU; PYDEM_EDGE_QUEUE_HOST=0 keeps such transports on the host-driven loop)
+        exchange = None
+        if host_sum is not None and hasattr(self.transport, 'sum_bytes_inplace') and os.environ.get('PYDEM_EDGE_QUEUE_HOST', '1') != '0':
+            exchange = self.transport
+        # (`keep_first_pass_uca` does not stand in the way: a tile's FIRST round is always run by the host loop below -- it builds
+        # the tile's fix-up state -- and that is where the first-pass area is put aside)
+        queue = (k_queue > 0 and n_t <= min(width, 64) and not checking
+                 and (host_sum is None or exchange is not None)
                  and all(hasattr(self.tiles[i]._tile, 'edge_queue_ready') for i in owned))
+        staged = comm is not None or exchange is not None
         k_queue = min(k_queue, 64)
         ran = set()                        # tiles that have run a round (on any rank: the waves are the same everywhere)
         ran_ok = {}                        # len(ran) -> every rank can queue the rounds of its tiles in `ran`
@@ -1073,9 +1084,12 @@ class ProcessManager(object):
                 sched[S.SCH_READERS + a] = sum(1 << int(r) for r in readers[a])
                 sched[S.SCH_NBRS + a] = sum(1 << int(r) for r in set(self._neighbours(a)))
 
+        queued_batches = [0]
+
         def queued_batch():
             """Run up to k_queue waves on the device; True if the host has to run the next wave itself."""
             nonlocal scal
+            queued_batches[0] += 1
             sched[S.SCH_OK] = sum(1 << a for a in ran)
             sched[S.SCH_LIMIT] = max(0, int(self.max_edge_rounds) - int(self.edge_waves))
             for a in range(n_t):
@@ -1084,8 +1098,11 @@ class ProcessManager(object):
                 sched[S.SCH_HASH + a] = last_hash.get(a, 0)
             for a in range(n_t):           # (the denominator the host's metric was formed with; only carried, never compared)
                 sched[S.SCH_PD + a] = pd_host[a]
-            scal = board.run_waves(comm, k_queue, sched)
-            self.edge_host_looks += 1
+            # (while tiles are still missing their first round a batch ends early -- stop 2 -- and, with a communicator, its
+            # remaining waves are no-op collectives of the whole staging buffer: short batches until every tile has run)
+            kq = k_queue if len(ran) >= n_t else min(k_queue, 4)
+            scal = board.run_waves(comm, kq, sched, exchange=exchange)
+            self.edge_host_looks += 1 if exchange is None else int(sched[S.SCH_NWAVES]) + 1
             self.edge_wave_graphs = bool(sched[S.SCH_GRAPH])
             for w in range(int(sched[S.SCH_NWAVES])):
                 members = [a for a in range(n_t) if (int(sched[S.SCH_LOG + w]) >> a) & 1]
@@ -1109,7 +1126,15 @@ class ProcessManager(object):
         while self.edge_waves < self.max_edge_rounds:
             if queue and ran and not host_next:
                 if len(ran) not in ran_ok:
+                    # everything that can fail on one rank alone happens HERE, and the ranks agree on the outcome, before any of
+                    # them enters a batch (its collectives would wait for ever for a rank that backed out)
                     mine_ok = all(self.tiles[a]._tile.edge_queue_ready() for a in ran if self.transport.owns(a))
+                    if mine_ok:
+                        try:
+                            board.prepare_waves(staged, sum(1 << a for a in ran))
+                        except _ffi.HipError as exc:
+                            logger.warning("queued edge waves: %s -- host-driven waves instead", exc)
+                            mine_ok = False
                     ran_ok[len(ran)] = self.transport.allreduce_max(0.0 if mine_ok else 1.0) == 0.0
                 if ran_ok[len(ran)]:
                     host_next = queued_batch()
@@ -1205,6 +1230,13 @@ class ProcessManager(object):
             sys.stderr.write("edge fix-up wave loop (host ms): %s over %d waves, %d host looks\n"
                              % (', '.join('%s %.1f' % (k2, v * 1e3) for k2, v in prof.items()), self.edge_waves, self.edge_host_looks))
         self._mets = mets.copy()
+        self.edge_queued_batches = queued_batches[0]
+        # what every rank must agree on when the fix-up is over: the waves as they ran (members wave by wave: the log of this
+        # rank's rounds + the counts) and -- `edge_board_digest = True`, bench.py's warm-up -- the replicated board itself
+        self.edge_schedule_digest = (int(self.edge_waves), int(self.edge_rounds), int(self.edge_tiebreaks))
+        if getattr(self, 'edge_board_digest', False):
+            import hashlib
+            self.edge_board_sha256 = hashlib.sha256(board.download().tobytes()).hexdigest()
         board.close()
         return mets
 

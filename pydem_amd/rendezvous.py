@@ -15,6 +15,11 @@ The reference has no counterpart: its workers share an on-disk zarr store and a 
 Address: PYDEM_RDZV = "tcp://host:port" or "unix:<name>"; default on one node: an abstract unix socket named after the
 launcher's pid and MASTER_PORT (no port to collide on, gone when rank 0 exits); with MASTER_ADDR pointing at another
 host: tcp://MASTER_ADDR:(MASTER_PORT + 1).
+
+Several nodes: rank 0 unpickles what its peers send, so a listener beyond the loopback REQUIRES a job secret,
+PYDEM_RDZV_TOKEN, in the environment of EVERY rank (each rank checks that before it connects or listens).  The secret never
+travels: rank 0 greets a connection with a fresh random nonce and the peer answers HMAC-SHA256(token, nonce | rank) -- an
+observed hello cannot be replayed against another connection.
 """
 import hashlib
 import hmac
@@ -45,10 +50,11 @@ def _token():
     return os.environ.get('PYDEM_RDZV_TOKEN') or 'job-%s' % os.environ.get('MASTER_PORT', '0')
 
 
-def _token_digest():
-    """What travels in the hello line instead of the token itself: a hex digest (any token -- blanks included -- becomes one
-    word of the line, and the secret is not written to the wire)."""
-    return hashlib.sha256(('pydem-rdzv:' + _token()).encode('utf-8', 'surrogateescape')).hexdigest()
+def _answer(nonce, rank):
+    """The peer's proof that it knows the job's token: HMAC-SHA256 keyed with the token over (nonce, rank), as hex.  The nonce
+    is rank 0's, fresh per connection, so the answer is worth nothing on any other connection."""
+    key = ('pydem-rdzv:' + _token()).encode('utf-8', 'surrogateescape')
+    return hmac.new(key, nonce + b'|' + str(int(rank)).encode('ascii'), hashlib.sha256).hexdigest()
 
 
 def _loopback(host):
@@ -86,10 +92,13 @@ class SocketGroup(object):
         if self.world <= 1:
             return
         family, target = self._parse(self.address)
+        if family == socket.AF_INET and not _loopback(target[0]) and not os.environ.get('PYDEM_RDZV_TOKEN'):
+            # rank 0 unpickles what a connected peer sends: beyond the loopback the guessable default token is no protection.
+            # Checked on EVERY rank before it connects: a peer without the secret fails here, at once, instead of waiting for a
+            # rank 0 that refused to listen.
+            raise RuntimeError("rendezvous: %s is not a loopback address, the job needs a secret: set PYDEM_RDZV_TOKEN in the "
+                               "environment of every rank" % self.address)
         if self.rank == 0:
-            if family == socket.AF_INET and not _loopback(target[0]) and not os.environ.get('PYDEM_RDZV_TOKEN'):
-                # rank 0 unpickles what a connected peer sends: beyond the loopback the guessable default token is no protection
-                raise RuntimeError("rendezvous: listening on %s needs a job secret: set PYDEM_RDZV_TOKEN in the launcher's environment" % self.address)
             ls = socket.socket(family, socket.SOCK_STREAM)
             if family == socket.AF_INET:
                 ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -102,10 +111,12 @@ class SocketGroup(object):
                 conn.settimeout(timeout)
                 if family == socket.AF_INET:
                     conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                # the hello is a fixed text line (token, rank) -- nothing is unpickled from a peer that has not shown the token
+                # challenge, then a fixed text line (rank, answer) -- nothing is unpickled from a peer that has not proved the token
+                nonce = os.urandom(32)
                 try:
-                    r = self._check_hello(_recv(conn, limit=256))
-                except (ConnectionError, socket.timeout):
+                    _send(conn, b'pydem-rdzv nonce ' + nonce.hex().encode('ascii'))
+                    r = self._check_hello(_recv(conn, limit=256), nonce)
+                except (OSError, socket.timeout):          # (ConnectionError is an OSError)
                     r = None
                 if r is None or r in self.peers:
                     try:
@@ -114,7 +125,11 @@ class SocketGroup(object):
                         pass
                     conn.close()
                     continue
-                _send(conn, b'pydem-rdzv ok')
+                try:
+                    _send(conn, b'pydem-rdzv ok')
+                except OSError:                              # a peer that dropped after a valid hello: it may come back
+                    conn.close()
+                    continue
                 self.peers[r] = conn
             for conn in self.peers.values():
                 conn.settimeout(None)          # the connect timeout must not outlive the rendezvous: a rank may lag minutes in a collective
@@ -133,10 +148,14 @@ class SocketGroup(object):
             if family == socket.AF_INET:
                 s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout)
-            _send(s, ('pydem-rdzv %d %s' % (self.rank, _token_digest())).encode())
             try:
+                greeting = _recv(s, limit=256).split(b' ')
+                if len(greeting) != 3 or greeting[0] != b'pydem-rdzv' or greeting[1] != b'nonce':
+                    raise ConnectionError("unexpected greeting")
+                nonce = bytes.fromhex(greeting[2].decode('ascii'))
+                _send(s, ('pydem-rdzv %d %s' % (self.rank, _answer(nonce, self.rank))).encode())
                 verdict = _recv(s, limit=64)
-            except (ConnectionError, socket.timeout) as exc:
+            except (OSError, ValueError, socket.timeout) as exc:
                 s.close()
                 raise ConnectionError("rendezvous: no answer from rank 0 on %s (%s)" % (self.address, exc))
             if verdict != b'pydem-rdzv ok':
@@ -146,15 +165,16 @@ class SocketGroup(object):
             s.settimeout(None)             # the connect timeout must not outlive the rendezvous
             self.sock = s
 
-    def _check_hello(self, blob):
-        """Rank of a peer that presents the digest of the job's token (PYDEM_RDZV_TOKEN, default: derived from MASTER_PORT) and
-        a rank in 1..world-1; None for anything else.  The line is "pydem-rdzv <rank> <hex digest>"."""
+    def _check_hello(self, blob, nonce):
+        """Rank of a peer that answers this connection's nonce with the HMAC of the job's token (PYDEM_RDZV_TOKEN, default:
+        derived from MASTER_PORT) and names a rank in 1..world-1; None for anything else.  The line is
+        "pydem-rdzv <rank> <hex hmac>"."""
         try:
-            word, rank, digest = blob.decode('ascii').split(' ', 2)
+            word, rank, answer = blob.decode('ascii').split(' ', 2)
             rank = int(rank)
         except (UnicodeDecodeError, ValueError):
             return None
-        if word != 'pydem-rdzv' or not hmac.compare_digest(digest, _token_digest()) or not (1 <= rank < self.world):
+        if word != 'pydem-rdzv' or not (1 <= rank < self.world) or not hmac.compare_digest(answer, _answer(nonce, rank)):
             return None
         return rank
 
@@ -195,6 +215,23 @@ class SocketGroup(object):
         total = np.array(parts[0], dtype=np.float64, copy=True)
         for p in parts[1:]:
             total += p
+        arr[...] = total
+
+    def sum_bytes_inplace(self, arr):
+        """Byte-wise sum (mod 256) of a contiguous uint8 array over all ranks, in place -- the staging buffer of a queued batch
+        of the edge fix-up (disjoint fills: x + 0), what ncclAllReduce(ncclUint8, ncclSum) does on the RCCL path."""
+        parts = self.all_gather_object(np.ascontiguousarray(arr, dtype=np.uint8))
+        total = np.array(parts[0], dtype=np.uint8, copy=True)
+        for p in parts[1:]:
+            total += p
+        arr[...] = total
+
+    def max_inplace(self, arr):
+        """Element-wise maximum of a contiguous float64 array over all ranks, in place."""
+        parts = self.all_gather_object(np.ascontiguousarray(arr, dtype=np.float64))
+        total = np.array(parts[0], dtype=np.float64, copy=True)
+        for p in parts[1:]:
+            np.maximum(total, p, out=total)
         arr[...] = total
 
     def barrier(self):

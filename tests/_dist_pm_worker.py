@@ -56,6 +56,13 @@ def main():
         assert pm.edge_waves < pm.edge_rounds
         if on_device:        # the strips stayed on the device: replicated edge board, staging buffer summed over the ranks
             assert pm._device_board_usable() and pm1._device_board_usable()
+            if os.environ.get('PYDEM_EXPECT_QUEUED') == '1':
+                # the QUEUED path ran on every rank (wave selection by a kernel per rank, staging buffer summed byte-wise over the
+                # socket group, agreement on the selected wave checked wave by wave): same waves as the single process
+                assert pm.edge_queued_batches > 0 and pm1.edge_queued_batches > 0, (pm.edge_queued_batches, pm1.edge_queued_batches)
+                assert pm.edge_tiebreaks == pm1.edge_tiebreaks
+            elif os.environ.get('PYDEM_EXPECT_QUEUED') == '0':
+                assert pm.edge_queued_batches == 0
             if use_rccl:
                 assert hasattr(pm.transport.comm, '_h') and pm.transport.world == world
         for i in range(pm.n_inputs):

@@ -129,6 +129,8 @@ def test_config4_mosaic_against_oracle_backed_flow(n_workers, tmp_path):
                                             n_workers=n_workers, processor_cls=OracleProcessor)
         po.process_twi()
     assert (pm.edge_rounds, pm.edge_waves) == (po.edge_rounds, po.edge_waves)
+    if n_workers == 8:
+        assert pm.edge_queued_batches > 0           # (8 tiles <= 2 * n_workers: the waves were chosen on the device and queued)
     for i in range(8):
         assert np.array_equal(pm.tile_result(i, 'edge_todo'), po.tile_result(i, 'edge_todo')), i
         assert np.array_equal(pm.tile_result(i, 'edge_done'), po.tile_result(i, 'edge_done')), i
@@ -163,6 +165,7 @@ def test_config4_mosaic_2048_against_oracle_checksums(tile):
                                             dem_proc_kwargs={'drain_pits': True}, n_workers=want['n_workers'])
         pm.process_twi()
     assert (pm.edge_rounds, pm.edge_waves) == (want['edge_rounds'], want['edge_waves'])
+    assert pm.edge_queued_batches > 0               # (pool width 8: queued waves, device-built operators)
     for i, w in enumerate(want['tiles']):
         assert sha(np.asarray(pm.tile_result(i, 'edge_todo'), np.uint8)) == w['edge_todo_sha256'], (i, 'edge_todo')
         assert sha(np.asarray(pm.tile_result(i, 'edge_done'), np.uint8)) == w['edge_done_sha256'], (i, 'edge_done')

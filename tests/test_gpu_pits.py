@@ -80,13 +80,16 @@ def test_hip_pits_vs_oracle_synthetic(shape, seed, quant):
     _close(twi, o.twi / 10, 'twi')
 
 
-def test_hip_pits_vs_oracle_bench_tile_4096():
-    """The bench generator at 4096^2 (seed 1): 400 k pit edges, ~10 % of the pits outgrow the lane pass and
-    run through the wavefront pass, ~1500 pits never drain.  (tools/check_pits_large.py runs the same check
-    at the full 16384^2 size: 6 491 367 identical assignments, 5 min of oracle time.)"""
+@pytest.mark.parametrize('seed', [1, 0])
+def test_hip_pits_vs_oracle_bench_tile_4096(seed):
+    """The bench generator at 4096^2 (seed 1: 400 k pit edges, ~10 % of the pits outgrow the lane pass and
+    run through the wavefront pass, ~1500 pits never drain; seed 0: BASELINE config 2's exact tile, `bench.py --config 2`).
+    Slope magnitude and direction cell by cell -- the 3 x 3 stencil config 2 times -- then pit assignments and UCA.
+    (tools/check_pits_large.py runs the same check at the full 16384^2 size: 6 491 367 identical assignments, 5 min of
+    oracle time.)"""
     from oracle import oracle as O
     from pydem_amd import DEMProcessor
-    z = O.synth_fractal(4096, 4096, seed=1)
+    z = O.synth_fractal(4096, 4096, seed=seed)
     o = O.OracleDEM(z, dX=30.0, dY=30.0, drain_pits=True)
     o.calc_uca()
     dp = DEMProcessor(elev=z, dX=30.0, dY=30.0, fill_flats=False, drain_pits_path=False, drain_pits=True)
@@ -95,6 +98,9 @@ def test_hip_pits_vs_oracle_bench_tile_4096():
         warnings.simplefilter('ignore')
         dp.calc_slopes_directions()
         dp.calc_uca()
+    _close(dp.mag, o.mag, 'mag')
+    _close(dp.direction, o.direction, 'direction')
+    assert np.array_equal(dp.section, o.section)
     _check_pits(dp, o.pit_i, o.pit_j, o.pit_prop)
     assert dp.timings['n_pits_undrained'] == o.n_warn
     _close(dp.uca, o.uca, 'uca')

@@ -233,6 +233,60 @@ def test_two_rank_pool_mode_with_device_board(name, world, tmp_path):
     assert out.count(' ok: ') == world, out[-3000:]
 
 
+@pytest.mark.parametrize('name,world', [('pm_fractal_2x2_ov2', 2), ('pm_nansea_2x2_ov2', 2), ('pm_fractal_2x3_ov1', 8), ('pm_fractal_2x2_ov2', 8)])
+def test_multi_rank_queued_waves_over_the_socket_group(name, world, tmp_path):
+    """The QUEUED waves of the fix-up (pydem_board_run_waves_ex) with more than one rank on this box's one GPU: every rank
+    runs the wave-selection kernel from its replica of the board, the byte staging buffer is summed over the socket group
+    where the RCCL path calls ncclAllReduce(ncclUint8), and before every sum the ranks check that they selected the SAME
+    wave.  Mosaics of at most 2 * world tiles (the queue's condition); the worker holds waves, rounds, tie-breaks and
+    every owned tile against the single-process pool run and asserts that batches were queued on its rank (reference: the
+    manager loop pydem/process_manager.py:1214-1246)."""
+    import sys
+    from conftest import ROOT
+    from test_process_manager_grid import write_tiles
+    g = load_golden(name)
+    write_tiles(g, str(tmp_path), key='elev')
+    from pydem_amd.rendezvous import spawn_ranks
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1', PYDEM_EXPECT_QUEUED='1')
+    rc, out = spawn_ranks([sys.executable, os.path.join(ROOT, 'tests', '_dist_pm_worker.py'), name, str(tmp_path), 'pool', 'device'], world,
+                          env=env, master_port=29900 + (os.getpid() % 90), capture=True, timeout=900)
+    assert rc == 0, out[-3000:]
+    assert out.count(' ok: ') == world, out[-3000:]
+
+
+def test_ranks_that_disagree_on_a_wave_stop_with_a_message(tmp_path):
+    """pydem_board_run_waves_ex compares the selected wave over the ranks before it sums the staging buffer: an exchange whose
+    maximum reports a wave this rank did not select makes the batch return an error that names the wave, instead of queueing
+    on (with RCCL such ranks would sit in ncclAllReduce; there the watchdog PYDEM_EDGE_TIMEOUT ends the wait)."""
+    import warnings
+    from test_process_manager_grid import write_tiles
+    from pydem_amd import _ffi, process_manager
+    g = load_golden('pm_fractal_2x2_ov2')
+    dkw = {k: v for k, v in g['kwargs'].items() if k not in ('ny_grid', 'nx_grid', 'overlap')}
+
+    class Liar(process_manager.EdgeTransport):
+        # a transport of one rank whose "maximum over the ranks" claims that somebody selected another wave
+        def sum_inplace(self, arr):
+            pass
+
+        def sum_bytes_inplace(self, arr):
+            pass
+
+        def max_inplace(self, arr):
+            arr[0] += 1.0
+    write_tiles(g, str(tmp_path), key='elev')
+    process_manager.DEBUG = True
+    try:
+        pm = process_manager.ProcessManager(in_path=str(tmp_path), dem_proc_kwargs=dkw, elev_conditioned=True, n_workers=8, transport=False)
+        pm.transport = Liar(pm)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            with pytest.raises(_ffi.HipError, match='disagree on wave'):
+                pm.process_twi()
+    finally:
+        process_manager.DEBUG = False
+
+
 @pytest.mark.parametrize('world', [2, 8])
 @pytest.mark.parametrize('name', ['pm_fractal_2x3_ov1', 'pm_cone32_4x5_ov3'])
 def test_two_rank_pool_mode_over_rccl(name, world, tmp_path):
@@ -269,8 +323,13 @@ def test_queued_waves_equal_host_driven_waves(name, k, tmp_path, monkeypatch):
     pk, ck, _ = run_pm(g, str(tmp_path / 'queued'), n_workers=8, tiles_in_flight=2)
     assert (pk.edge_waves, pk.edge_rounds, pk.edge_tiebreaks) == (p0.edge_waves, p0.edge_rounds, p0.edge_tiebreaks)
     assert sorted((w, a) for w, a, _ in pk.edge_round_log) == sorted((w, a) for w, a, _ in p0.edge_round_log)    # (rounds of a wave finish in any order)
-    assert p0.edge_host_looks == p0.edge_waves + 1
-    assert pk.edge_host_looks <= p0.edge_host_looks    # (small mosaics: a tile's first round and every tie-break still go to the host)
+    assert p0.edge_host_looks == p0.edge_waves + 1 and p0.edge_queued_batches == 0
+    # (until round 6 the queue was silently off under the default keep_first_pass_uca=True and this test compared the host loop
+    # with itself: the batches are counted now)
+    assert pk.edge_queued_batches > 0
+    if k > 1:
+        assert pk.edge_host_looks <= p0.edge_host_looks    # (small mosaics: a tile's first round still goes to the host; batches
+                                                           #  of ONE wave pay a look per wave plus one per batch that stops for the host)
     for i in range(pk.n_inputs):
         for key in ('edge_todo', 'edge_done'):
             assert np.array_equal(pk.tile_result(i, key), p0.tile_result(i, key)), (i, key)
@@ -300,6 +359,7 @@ def test_queued_waves_respect_the_wave_limit(tmp_path, monkeypatch):
         out.append(pm)
     assert out[0].edge_waves == out[1].edge_waves == 3
     assert out[0].edge_rounds == out[1].edge_rounds
+    assert out[0].edge_queued_batches == 0
     for i in range(out[0].n_inputs):
         assert np.array_equal(out[0].tile_result(i, 'uca_total'), out[1].tile_result(i, 'uca_total'), equal_nan=True), i
         assert np.array_equal(out[0].tile_result(i, 'edge_done'), out[1].tile_result(i, 'edge_done')), i

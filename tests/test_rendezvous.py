@@ -84,3 +84,28 @@ def test_non_loopback_listener_needs_a_token(monkeypatch):
     monkeypatch.delenv('PYDEM_RDZV_TOKEN', raising=False)
     with pytest.raises(RuntimeError, match='PYDEM_RDZV_TOKEN'):
         SocketGroup(0, 2, address='tcp://0.0.0.0:29990', timeout=1.0)
+
+
+def test_every_rank_checks_the_token_requirement(monkeypatch):
+    """A peer of a multi-node job without the secret fails before it connects (it used to spin until 'rank 0 is not listening')."""
+    import pytest
+    from pydem_amd.rendezvous import SocketGroup
+    monkeypatch.delenv('PYDEM_RDZV_TOKEN', raising=False)
+    with pytest.raises(RuntimeError, match='every rank'):
+        SocketGroup(1, 2, address='tcp://192.0.2.1:29991', timeout=1.0)
+
+
+def test_hello_is_a_challenge_response():
+    """The answer to one connection's nonce is worthless for another nonce (an observed hello cannot be replayed), and
+    names its rank (it cannot be used to take another rank's place)."""
+    import os as _os
+    from pydem_amd import rendezvous as R
+    g = R.SocketGroup(0, 1)
+    g.world = 4
+    n1, n2 = _os.urandom(32), _os.urandom(32)
+    line = ('pydem-rdzv 2 %s' % R._answer(n1, 2)).encode()
+    assert g._check_hello(line, n1) == 2
+    assert g._check_hello(line, n2) is None                              # replayed against another connection
+    assert g._check_hello(('pydem-rdzv 3 %s' % R._answer(n1, 2)).encode(), n1) is None      # another rank's place
+    assert g._check_hello(('pydem-rdzv 7 %s' % R._answer(n1, 7)).encode(), n1) is None      # out of range
+    assert g._check_hello(b'\xff\xfe garbage', n1) is None

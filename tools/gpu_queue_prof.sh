@@ -9,7 +9,7 @@ python - <<'P' > gpurun_out/queue/kt_edge.txt
 import csv
 for r in csv.DictReader(open('gpurun_out/queue/kt/t_kernel_stats.csv')):
     n = r['Name']
-    if any(k in n for k in ('k_cond', 'k_board', 'k_sched', 'k_cinc', 'k_nd_', 'k_einc', 'k_pit_offsets')):
+    if any(k in n for k in ('k_cond', 'k_cb_', 'k_board', 'k_sched', 'k_cinc', 'k_nd_', 'k_einc', 'k_pit_offsets', 'Scan', 'scan', 'sort', 'Sort')):
         short = n.split('(anonymous namespace)::')[-1] if n.startswith('(anonymous') else n
         short = short.replace('(anonymous namespace)::', '')
         print('%-70s %6s calls  total %9.1f us  mean %8.2f us  max %9.1f us' % (short[:70], r['Calls'], int(r['TotalDurationNs']) / 1e3, float(r['AverageNs']) / 1e3, int(r['MaxNs']) / 1e3))

@@ -6,7 +6,7 @@ from pydem_amd import process_manager
 n = int(sys.argv[1]); nt = int(sys.argv[2])
 pm = process_manager.ProcessManager(elev_source_files=bench.tile_specs(nt, n, n), elev_conditioned=True,
                                     dem_proc_kwargs={'drain_pits': os.environ.get('PM_DRAIN', '1') == '1'}, devices=[0], keep_first_pass_uca=False,
-                                    tiles_in_flight=int(os.environ.get('PM_IN_FLIGHT', '1')),
+                                    tiles_in_flight=(None if os.environ.get('PM_IN_FLIGHT') == 'auto' else int(os.environ.get('PM_IN_FLIGHT', '1'))),   # auto = the manager's default: builds / flushes of the fix-up side by side
                                     n_workers=int(os.environ.get('PM_WORKERS', '1')), edge_mode=os.environ.get('PM_EDGE_MODE') or None)
 if os.environ.get('PM_RCCL'):      # the RCCL strip transport with a single rank: its per-round overhead against the in-process one
     from pydem_amd import _ffi
