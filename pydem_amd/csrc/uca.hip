@@ -2772,13 +2772,13 @@ __global__ __launch_bounds__(256) void k_cinc_level(CIncArgs E, const QE *__rest
     }
 }
 
-__global__ __launch_bounds__(1024) void k_cinc_small(CIncArgs E, QE *q0, QE *q1, int32_t *cnt3, int r_start, int32_t *state)
+__global__ __launch_bounds__(1024) void k_cinc_small(CIncArgs E, QE *q0, QE *q1, int32_t *cnt3, int r_start, int32_t *state, int cap)
 {
     __shared__ QE s_q[2][SMALL_CAP];
     __shared__ int32_t s_cnt[3];     // pushes of level r go to s_cnt[(r + 1) % 3]; s_cnt[(r + 2) % 3] is zeroed meanwhile: ONE barrier per level
     int r = r_start;
     int32_t nq = cnt3[r % 3];
-    if (nq > 0 && nq <= SMALL_CAP) {
+    if (nq > 0 && nq <= cap) {
         const QE *qc = (r % 2) ? q1 : q0;
         for (int32_t k = threadIdx.x; k < nq; k += blockDim.x) s_q[r % 2][k] = qc[k];
     }
@@ -2787,7 +2787,7 @@ __global__ __launch_bounds__(1024) void k_cinc_small(CIncArgs E, QE *q0, QE *q1,
     long long prof_t[4] = {0, 0, 0, 0}; int prof_n[4] = {0, 0, 0, 0};
 #endif
     __syncthreads();
-    while (nq > 0 && nq <= SMALL_CAP) {
+    while (nq > 0 && nq <= cap) {
 #ifdef PYDEM_EINC_PROF
         const long long t0 = wall_clock64();
         const int cls = nq <= 8 ? 0 : (nq <= 64 ? 1 : (nq <= 512 ? 2 : 3));
@@ -2812,7 +2812,7 @@ __global__ __launch_bounds__(1024) void k_cinc_small(CIncArgs E, QE *q0, QE *q1,
         prof_t[cls] += wall_clock64() - t0; prof_n[cls]++;
 #endif
     }
-    if (nq > SMALL_CAP && r > r_start) {
+    if (nq > cap && r > r_start) {
         // the frontier outgrew the workgroup: the level kernels take over from the global queue, whose head is still in LDS
         QE *qg = (r % 2) ? q1 : q0;
         for (int32_t k = threadIdx.x; k < SMALL_CAP; k += blockDim.x) qg[k] = s_q[r % 2][k];
@@ -3632,7 +3632,10 @@ static int cinc_cascade(pydem_tile *t, const CIncArgs &E, int *levels)
     for (;;) {
         static int cinc_block = -1;
         if (cinc_block < 0) { const char *e = getenv("PYDEM_EINC_BLOCK"); cinc_block = e ? atoi(e) : 1024; }
-        hipLaunchKernelGGL(k_cinc_small, dim3(1), dim3(cinc_block), 0, t->stream, E, q0, q1, cnt3, r, state);
+        // (PYDEM_CINC_SMALL: the frontier width up to which ONE workgroup walks the levels; wider levels are launches over the chip)
+        static int cinc_cap = -1;
+        if (cinc_cap < 0) { const char *e = getenv("PYDEM_CINC_SMALL"); cinc_cap = e ? std::max(1, std::min(atoi(e), SMALL_CAP)) : 1024; }      // (measured on the flush of 8 x 16384^2: 4096 -> 1024 -0.8 ms per tile, 256 the same)
+        hipLaunchKernelGGL(k_cinc_small, dim3(1), dim3(cinc_block), 0, t->stream, E, q0, q1, cnt3, r, state, cinc_cap);
         // (the usual case: the frontier stayed small and the cascade is over -- the records go to the tile right away,
         // ONE host synchronisation per round; cells finished so far are applied either way)
         hipLaunchKernelGGL(k_cinc_apply, dim3(grid_for(E.nd, 1024)), dim3(256), 0, t->stream, E);
@@ -3642,7 +3645,7 @@ static int cinc_cascade(pydem_tile *t, const CIncArgs &E, int *levels)
         int32_t last = t->h_counters[r % 3];
         if (last == 0) break;
         bool wide = false;
-        while (last > SMALL_CAP) {
+        while (last > cinc_cap) {
             wide = true;
             const int batch = last > 65536 ? 4 : 16;
             const int grid = grid_for(last, 1024);
@@ -4024,7 +4027,7 @@ struct CBump {
 };
 
 // *status: 1 built (cond_live), 0 the tile does not qualify (a cycle among the records: the host build would say the same),
-// -1 the device build gave up (more than CB_MAXD out-edges, pool overflow): try the host build
+// -1 the device build gave up (a vector of more than CB_RUN entries, pool overflow): try the host build
 static int cond_build_device(pydem_tile *t, int *status)
 {
     *status = -1;
@@ -4056,7 +4059,8 @@ static int cond_build_device(pydem_tile *t, int *status)
         B.rv = A.take<CBVal>((size_t)nd); B.ri = A.take<CBRec>((size_t)nd);
         B.pred_cnt = A.take<int32_t>((size_t)nd1); B.pit_cnt = A.take<int32_t>((size_t)nd1);
         B.pred_beg = A.take<int32_t>((size_t)nd1); B.pit_beg = A.take<int32_t>((size_t)nd1);
-        B.q0 = A.take<int32_t>((size_t)nd * 2); B.q1 = A.take<int32_t>((size_t)nd * 2);      // (second halves: retry lists of k_cb_sweep)
+        B.q0 = A.take<int32_t>((size_t)nd * CB_NQ); B.q1 = A.take<int32_t>((size_t)nd * CB_NQ);     // (CB_NQ sub-queues each: any of them may hold a whole level)
+        B.qcnt = A.take<int32_t>((size_t)3 * CB_NQ * CB_PAD); B.poolc = A.take<int32_t>((size_t)CB_NQ * CB_PAD);
         B.wcell = A.take<int32_t>(nw_bound); B.wrec = A.take<int32_t>(nw_bound);
         B.wcell_s = A.take<int32_t>(nw_bound); B.wrec_s = A.take<int32_t>(nw_bound);
         B.ctr = A.take<int32_t>(CBC_WORDS);
@@ -4068,6 +4072,8 @@ static int cond_build_device(pydem_tile *t, int *status)
     B.w_cap = (int32_t)nw_bound;
     B.w_sorted = t->pits.w;
     HIP_TRY(hipMemsetAsync(B.ctr, 0, CBC_WORDS * sizeof(int32_t), t->stream));
+    HIP_TRY(hipMemsetAsync(B.qcnt, 0, (size_t)4 * CB_NQ * CB_PAD * sizeof(int32_t), t->stream));      // (qcnt and, behind it, poolc)
+    B.qcap = nd;
     const int g_nd = grid_for(nd, 1024);
     hipLaunchKernelGGL(k_cb_count, dim3(g_nd), dim3(256), 0, t->stream, B);
     { size_t tb = tmp1; HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp_a, tb, B.pred_cnt, B.pred_beg, nd1, t->stream)); }
@@ -4083,12 +4089,12 @@ static int cond_build_device(pydem_tile *t, int *status)
     if ((size_t)nw > nw_bound) { pydem_set_error("condensed edge rounds: %d watched nodes, expected at most %zu", nw, nw_bound); return -5; }
     const double t_counted = host_now_ms();
     // ---- phase 2: lists, node order, the reverse sweep
-    const int64_t pool_cap = std::min<int64_t>((int64_t)8 * nd + 65536, (int64_t)1 << 27);
+    const int64_t pool_cap = std::min<int64_t>((int64_t)nd + 16384, (int64_t)1 << 24);       // entries per region (CB_NQ regions: 16 x nd in all, ~8 x what the merges of a 16384^2 tile take)
     const int nw1 = nw + 1;
     auto lay2 = [&](void *base) {
         CBump A(base);
         B.pred = A.take<int32_t>((size_t)n_pred + 1); B.pit = A.take<CBPit>((size_t)n_pit + 1);
-        B.pool = A.take<CBEnt>((size_t)pool_cap);
+        B.pool = A.take<CBEnt>((size_t)pool_cap * CB_NQ);
         B.nout_c = A.take<int32_t>((size_t)nw1); B.nout = A.take<int32_t>((size_t)nw1);
         B.n_in = A.take<int32_t>((size_t)nw1); B.in_first = A.take<int32_t>((size_t)nw1);
         B.exc_in_c = A.take<int32_t>((size_t)nw1); B.exc_in = A.take<int32_t>((size_t)nw1);
@@ -4106,21 +4112,42 @@ static int cond_build_device(pydem_tile *t, int *status)
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp_a, tb, B.wcell, B.wcell_s, B.wrec, B.wrec_s, nw, 0, cell_bits, t->stream));
         hipLaunchKernelGGL(k_cb_wid, dim3(grid_for(nw, 256)), dim3(256), 0, t->stream, B);
     }
-    // the levels: while the frontier is wide, one launch per level over the whole chip (small batches, one look from the host per
-    // batch); the narrow remainder in ONE workgroup without launches in between (PYDEM_CB_WIDE: the width at which it takes over)
-    static int wide = -1;
-    if (wide < 0) { const char *e = getenv("PYDEM_CB_WIDE"); wide = e ? atoi(e) : 8192; }
+    // the levels: one launch per level over the whole chip, in batches; one look from the host per batch (the launches behind the
+    // end of the sweep find empty sub-queues and return at once)
+    static int cb_grid = -1, cb_chain = -1;
+    if (cb_grid < 0) { const char *e = getenv("PYDEM_CB_GRID"); cb_grid = e ? std::max(1, std::min(atoi(e), 65536)) : CB_GRID; cb_grid = ((cb_grid + CB_NQ - 1) / CB_NQ) * CB_NQ; }
+    if (cb_chain < 0) { const char *e = getenv("PYDEM_CB_CHAIN"); cb_chain = e ? std::max(0, atoi(e)) : 4; }
+    B.max_chain = cb_chain;
+    int32_t *d_dbg = nullptr;                              // PYDEM_CB_DEBUG=1: per-level statistics of the sweep to stderr (diagnostic, one extra allocation)
+    const int dbg_levels = 4096;
+    if (getenv("PYDEM_CB_DEBUG")) { HIP_TRY(hipMalloc((void **)&d_dbg, (size_t)dbg_levels * 4 * sizeof(int32_t))); HIP_TRY(hipMemsetAsync(d_dbg, 0, (size_t)dbg_levels * 4 * sizeof(int32_t), t->stream)); }
+    B.dbg = d_dbg; B.level = 0;
     int levels_run = 0;
+    void *pin_q = nullptr;
+    PYDEM_TRY(tile_pinned(t, (size_t)3 * CB_NQ * CB_PAD * sizeof(int32_t), &pin_q));
+    const int32_t *hq = (const int32_t *)pin_q;
     for (;;) {
+        for (int b = 0; b < 64; b++, levels_run++) {
+            B.level = levels_run < dbg_levels ? levels_run : dbg_levels - 1;
+            hipLaunchKernelGGL(k_cb_level, dim3(cb_grid), dim3(CB_LANES), 0, t->stream, B, levels_run);
+        }
         HIP_TRY(hipMemcpyAsync(h, B.ctr, CBC_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipMemcpyAsync(pin_q, B.qcnt, (size_t)3 * CB_NQ * CB_PAD * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
-        if (h[CBC_Q + levels_run % 3] <= wide || (h[CBC_FAIL] & 1)) break;
-        for (int b = 0; b < 4; b++, levels_run++)
-            hipLaunchKernelGGL(k_cb_level, dim3(CB_GRID), dim3(CB_LANES), 0, t->stream, B, levels_run);
+        int64_t left = 0;
+        for (int q = 0; q < CB_NQ; q++) left += hq[((levels_run % 3) * CB_NQ + q) * CB_PAD];
+        if (left == 0 || (h[CBC_FAIL] & 1)) break;
         if (levels_run > (1 << 22)) { pydem_set_error("condensed edge rounds: flow paths too long"); return -5; }
     }
-    const int levels_wide = levels_run;
-    hipLaunchKernelGGL(k_cb_sweep, dim3(1), dim3(1024), 0, t->stream, B, levels_run);
+    if (d_dbg) {
+        std::vector<int32_t> hd((size_t)dbg_levels * 4);
+        HIP_TRY(hipMemcpy(hd.data(), d_dbg, hd.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(d_dbg));
+        fprintf(stderr, "cb levels (frontier / largest merge / entries merged / deepest chain):");
+        for (int l = 0; l < levels_run && l < dbg_levels; l++) { if (l % 8 == 0) fprintf(stderr, "\n  %4d:", l); fprintf(stderr, " %d/%d/%d/%d", hd[4 * l], hd[4 * l + 1], hd[4 * l + 2], hd[4 * l + 3]); }
+        fprintf(stderr, "\n");
+        B.dbg = nullptr;
+    }
     hipLaunchKernelGGL(k_cb_nout, dim3(grid_for(nw1, 256)), dim3(256), 0, t->stream, B);
     { size_t tb = tmp1; HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp_a, tb, B.nout_c, B.nout, nw1, t->stream)); }
     HIP_TRY(hipMemcpyAsync(h, B.ctr, CBC_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
@@ -4128,7 +4155,7 @@ static int cond_build_device(pydem_tile *t, int *status)
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(t->stream));
     const double t_swept = host_now_ms();
-    const int32_t ne_all = h[16], levels = h[CBC_LEVELS], pool_used = h[CBC_POOL], n_slow = h[CBC_SLOW];
+    const int32_t ne_all = h[16], levels = h[CBC_LEVELS], n_slow = h[CBC_SLOW];
     if (h[CBC_FAIL] & 1) return 0;                              // (*status == -1: the host build takes over)
     if (h[CBC_PROC] != nd) { *status = 0; return 0; }           // a cycle among the records: not a DAG, plain cascade
     if (ne_all > INT32_MAX / 2) { *status = 0; return 0; }
@@ -4193,8 +4220,8 @@ static int cond_build_device(pydem_tile *t, int *status)
     if (getenv("PYDEM_EDGE_DEBUG")) {
         HIP_TRY(hipStreamSynchronize(t->stream));
         fprintf(stderr, "condensed edge rounds (device build): %d records -> %d watched nodes, %d edges (%d pit edges among the records); %.2f ms "
-                "(lists %.2f, reverse sweep %.2f [%d levels, %d of them as launches over the chip, %d pool entries, %d merges from the pool], nodes %.2f)\n",
-                nd, nw, ne_all, n_pit, host_now_ms() - t_begin, t_counted - t_begin, t_swept - t_counted, levels, levels_wide, pool_used, n_slow, host_now_ms() - t_swept);
+                "(lists %.2f, reverse sweep %.2f [%d levels, %d launches, %d merges from the pool], nodes %.2f)\n",
+                nd, nw, ne_all, n_pit, host_now_ms() - t_begin, t_counted - t_begin, t_swept - t_counted, levels, levels_run, n_slow, host_now_ms() - t_swept);
     }
     return 0;
 }

@@ -22,36 +22,41 @@
 //   3. k_cb_nout .. k_cb_nodes: the watched records' vectors become the nodes' out-edges; in-slots in ascending source
 //      order through one stable radix sort by target.
 //
-// The host build stays as the fall-back (a record with more than CB_MAXD out-edges, a pool that overflows) and as the
+// The host build stays as the fall-back (a vector of more than CB_RUN entries, a pool region that overflows) and as the
 // checker (PYDEM_COND_BUILD=check builds both and compares node by node; =host forces it).
 // (hipcub is included at the top of uca.hip: this file sits inside its anonymous namespace)
 
 constexpr int32_t CB_EMPTY = INT32_MIN;      // the empty vector: the water ends inside the tile
 constexpr int32_t CB_CHAIN = INT32_MIN;      // bit 31 of a predecessor entry: that record has one out-edge
-constexpr int CB_MAXD = 16;                  // out-edges of a record the device merge handles (2 + pit edges)
-constexpr int CB_GRID = 256;                 // workgroups of a level launch (grid-stride over the frontier)
+constexpr int CB_GRID = 4096;                // workgroups (= wavefronts = records in flight) of a level launch (PYDEM_CB_GRID)
+// Every frontier is CB_NQ sub-queues and the pool CB_NQ regions, each with a counter on a line of its own: with one queue and one
+// pool the 3000 wave-aggregated atomics of a 6000-record level queued up at two addresses of the fabric (~25 ns each: 90 us
+// for the level, 13 ns per record at every width).  A workgroup consumes, fills and allocates from sub-queue / region blockIdx % CB_NQ.
+constexpr int CB_NQ = 16, CB_PAD = 32;
 constexpr int CB_LANES = 64;                 // a workgroup of the level kernel is one wavefront
-constexpr int CB_POOL_LEVEL = 2560;          // its LDS staging for the inputs of the lanes' merges (entries, 30 KB)
-constexpr int CB_POOL_SWEEP = 4700;          // ... of the one-workgroup kernel (56 KB)
 
 struct CBVal { int32_t rep, vbeg, vn, wid; double scale; int32_t out_left, pad; };     // rep >= 0: owner record of the shared vector (vbeg, vn copied); < 0: unit vector of node -1 - rep
 static_assert(sizeof(CBVal) == 32, "four records per line");
 struct CBRec { int32_t pred_beg, pred_cnt, pit_beg, pit_cnt; };
 struct CBEnt { int32_t node, pad; double w; };
 struct CBPit { int32_t dst, pad; double w; };
-enum { CBC_NW = 1, CBC_POOL = 4, CBC_FAIL = 5, CBC_PROC = 6, CBC_LEVELS = 7, CBC_SLOW = 9, CBC_Q = 10 /* .. 12: rotating frontier sizes */, CBC_WORDS = 16 };
+enum { CBC_NW = 1, CBC_FAIL = 5, CBC_PROC = 6, CBC_LEVELS = 7, CBC_SLOW = 9, CBC_WORDS = 16 };
 
 struct CBArgs {
     CIncArgs C;
     CBVal *rv; CBRec *ri;
     int32_t *pred_cnt, *pit_cnt, *pred_beg, *pit_beg;      // [nd + 1]: counts, their exclusive sums
     int32_t *pred; CBPit *pit;
-    CBEnt *pool; int32_t pool_cap;
-    int32_t *q0, *q1;
+    CBEnt *pool; int32_t pool_cap;       // pool_cap: entries of ONE of the CB_NQ regions of the pool
+    int32_t *q0, *q1; int32_t qcap;      // CB_NQ sub-queues of qcap entries each
+    int32_t *qcnt, *poolc;               // [3][CB_NQ][CB_PAD] rotating sub-queue sizes; [CB_NQ][CB_PAD] bump counters of the pool regions
     int32_t *wcell, *wrec, *wcell_s, *wrec_s; int32_t w_cap;
     int32_t *ctr;
     const double *w_sorted;              // pit weights in (src, dst) order (PitGraph::w)
     int32_t nw;
+    int32_t max_chain;                   // links of a chain one lane finishes in passing
+    int32_t *dbg;                        // PYDEM_CB_DEBUG: per level (frontier, largest merge, entries merged, deepest chain)
+    int32_t level;
     int32_t *nout_c, *nout, *n_in, *in_first, *exc_in_c, *exc_in, *exc_out_c, *exc_out;      // [nw + 1]: counts / exclusive sums
     int32_t *e_dst, *e_q, *e_dst_s, *e_q_s, *e_slot; double *e_w;
     CNode *node; CEdge *edge;
@@ -117,7 +122,10 @@ __global__ __launch_bounds__(256) void k_cb_fill(CBArgs B)
                 const int32_t kt = E.cid[A.pit_dst[e]] - 1;
                 if (kt >= 0) { CBPit q; q.dst = kt; q.pad = 0; q.w = B.w_sorted[e]; B.pit[f++] = q; }
             }
-        if ((R.out_id[0] >= 0) + (R.out_id[1] >= 0) + ri.pit_cnt == 0) B.q0[agg_slot(&B.ctr[CBC_Q])] = k;      // a sink: first level
+        if ((R.out_id[0] >= 0) + (R.out_id[1] >= 0) + ri.pit_cnt == 0) {                                       // a sink: first level
+            const int sq = blockIdx.x % CB_NQ;
+            B.q0[(size_t)sq * B.qcap + agg_slot(&B.qcnt[sq * CB_PAD])] = k;
+        }
     }
 }
 
@@ -127,290 +135,210 @@ __global__ void k_cb_wid(CBArgs B)
 }
 
 // ---- 2. reverse topological sweep -----------------------------------------------------------------------------------
-// One launch per level over the whole chip: the levels are WIDE (322 k records in 450-850 levels at 16384^2, thousands in the
-// first ones) -- one workgroup walking them (the first build) took 23-47 ms, longer than the host.  A workgroup is ONE
-// wavefront with an LDS staging area for the inputs of its lanes' merges: the entries of the vectors a lane merges are fetched
-// in one round trip (independent loads), the products formed, and the merge of the sorted runs reads LDS; only when the area
-// is full does a merge walk the pool entry by entry.
-template <int N> struct CBStageLds { static constexpr int CAP = N; int32_t id[N]; double v[N]; int32_t used; };
+// One launch per level over the whole chip, ONE WAVEFRONT PER RECORD.  What was measured on the way (8 x 16384^2, 322 k records in
+// 340-590 levels per tile; profiles/r06_cb_levels_16384.txt): one workgroup walking all levels 23-47 ms (one CU's memory
+// parallelism against ~1000 records x 8 dependent accesses per level); one lane per record, 64 records per wavefront, one launch
+// per level 12-20 ms -- the lanes of a wavefront run in lock step, so every wavefront paid for its longest merge and its longest
+// chain, and ONE frontier counter + ONE pool counter took ~3000 wave-aggregated atomics per level at ~25 ns each; 16 sub-queues /
+// pool regions and 1-4 records per wavefront 6.5-12.8 ms, a level now as long as its LARGEST merge walked by one lane (60-130
+// entries, ~24 us).  Here the wavefront shares one record's work: the predecessors count down one per lane, the entries of the
+// vectors to merge are fetched lane-strided into LDS (one round trip), two sorted runs are merged by RANK (every lane finds its
+// element's place in the other run by binary search; equal nodes are summed, acc + f * entry like the host build's add_into,
+// edge after edge), the result leaves lane-strided.
+#ifndef PYDEM_CB_RUN
+#define PYDEM_CB_RUN 512
+#endif
+constexpr int CB_RUN = PYDEM_CB_RUN;         // entries a merge may stage (inputs; two intermediate runs of the same size): 18 KB of LDS, 8 wavefronts per CU
+                                             // (the largest merge of the 16384^2 bench mosaic stages 136; more than CB_RUN: the host build takes the tile)
+struct CBWaveLds { int32_t id[3 * CB_RUN]; double v[3 * CB_RUN]; int32_t off[CB_LANES + 1]; };
 
-// returns false when the record has to wait for room in the staging area (DEFER: the caller runs it again after the level's
-// other records; nothing has been allocated or written by then)
-template <bool DEFER, typename Stage, typename Push>
-__device__ __forceinline__ bool cb_process(const CBArgs &B, int32_t r, Stage &S, Push push, int32_t &n_chain)
+__device__ __forceinline__ void cb_wave_sync() { __syncthreads(); }          // (a workgroup is one wavefront)
+
+// merged = A (+) Bv, both sorted by node with distinct nodes inside a run; to LDS at x0 (pool == nullptr) or to the pool; returns the count
+__device__ __forceinline__ int32_t cb_merge_wave(CBWaveLds &S, int32_t a0, int32_t na, int32_t b0, int32_t nb, int32_t x0, CBEnt *pool)
 {
-    constexpr int CB_POOL_LDS = Stage::CAP;
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    auto lower = [&](int32_t base, int32_t n, int32_t key) { int32_t lo = 0, hi = n; while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (S.id[base + mid] < key) lo = mid + 1; else hi = mid; } return lo; };
+    auto emit = [&](int32_t pos, int32_t id, double v) {
+        if (pool) { CBEnt t; t.node = id; t.pad = 0; t.w = v; pool[pos] = t; }
+        else { S.id[x0 + pos] = id; S.v[x0 + pos] = v; }
+    };
+    int32_t dups = 0;
+    for (int32_t base = 0; base < na; base += CB_LANES) {                       // the elements of A: their own index + the elements of B in front of them that are not their twins
+        const int32_t i = base + lane;
+        const bool valid = i < na;
+        int32_t ida = 0, cb = 0; bool twin = false; double v = 0.0;
+        if (valid) {
+            ida = S.id[a0 + i]; v = S.v[a0 + i];
+            cb = lower(b0, nb, ida);
+            twin = cb < nb && S.id[b0 + cb] == ida;
+            if (twin) v = v + S.v[b0 + cb];                                    // acc + f * entry
+        }
+        const unsigned long long tm = __ballot(twin);
+        if (valid) emit(i + cb - (dups + __popcll(tm & lt)), ida, v);
+        dups += __popcll(tm);
+    }
+    int32_t dups_b = 0;
+    for (int32_t base = 0; base < nb; base += CB_LANES) {                       // the elements of B without a twin in A
+        const int32_t j = base + lane;
+        const bool valid = j < nb;
+        int32_t idb = 0, ca = 0; bool twin = false;
+        if (valid) { idb = S.id[b0 + j]; ca = lower(a0, na, idb); twin = ca < na && S.id[a0 + ca] == idb; }
+        const unsigned long long tm = __ballot(twin);
+        if (valid && !twin) emit(j + ca - (dups_b + __popcll(tm & lt)), idb, S.v[b0 + j]);
+        dups_b += __popcll(tm);
+    }
+    return na + nb - dups;
+}
+
+// the predecessors of a record count down, one per lane; those this releases enter the next frontier, except ONE with a single
+// out-edge (bit 31 of its entry), which is returned: the caller finishes it on the spot
+__device__ __forceinline__ int32_t cb_countdown_wave(const CBArgs &B, const CBRec &rr, int32_t *qn, int32_t *cn)
+{
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int32_t next = -1;
+    for (int32_t base = 0; base < rr.pred_cnt; base += CB_LANES) {
+        const int32_t e = base + lane;
+        int32_t p = -1; bool released = false, chain = false;
+        if (e < rr.pred_cnt) {
+            const int32_t pe = B.pred[rr.pred_beg + e];
+            p = pe & ~CB_CHAIN; chain = (pe & CB_CHAIN) != 0;
+            released = atomicSub(&B.rv[p].out_left, 1) == 1;
+        }
+        const unsigned long long cm = __ballot(released && chain);
+        int keep = -1;
+        if (next < 0 && cm) { keep = __ffsll((long long)cm) - 1; next = __shfl(p, keep); }
+        const bool topush = released && lane != keep;
+        const unsigned long long pm = __ballot(topush);
+        if (pm) {
+            const int leader = __ffsll((long long)pm) - 1;
+            int32_t slot0 = 0;
+            if (lane == leader) slot0 = atomicAdd(cn, (int32_t)__popcll(pm));
+            slot0 = __shfl(slot0, leader);
+            if (topush) qn[slot0 + __popcll(pm & lt)] = p;
+        }
+    }
+    return next;
+}
+
+__device__ __forceinline__ void cb_record_wave(const CBArgs &B, int32_t r, CBWaveLds &S, int32_t *poolc, int32_t pool_base, int32_t *qn, int32_t *cn, int32_t &n_chain)
+{
+    const int lane = threadIdx.x;
     const NDRec &R = B.C.rec[r];
     const int32_t o0 = R.out_id[0], o1 = R.out_id[1];
     const double w0 = R.out_w[0], w1 = R.out_w[1];
-    CBRec ri = B.ri[r];
+    const CBRec ri = B.ri[r];
     const int deg = (o0 >= 0) + (o1 >= 0) + ri.pit_cnt;
+    // the count-downs first: whoever they release runs in a later launch and finds this record finished (see the file's head)
+    int32_t next = cb_countdown_wave(B, ri, qn, cn);
     int32_t rep = CB_EMPTY, vbeg = 0, vn = 0;
     double scale = 0.0;
-    auto edge = [&](int e, int32_t &tg, double &w) {                 // the e-th out-edge in the fixed order
+    auto edge = [&](int e, int32_t &tg, double &w) {                 // the e-th out-edge in the fixed order: first target, second target, pit edges by drain cell
         if (o0 >= 0) { if (e == 0) { tg = o0; w = w0; return; } e--; }
         if (o1 >= 0) { if (e == 0) { tg = o1; w = w1; return; } e--; }
         const CBPit p = B.pit[ri.pit_beg + e];
         tg = p.dst; w = p.w;
     };
-    bool generic = deg > 4 && deg <= CB_MAXD;
     if (deg == 1) {
         int32_t tg; double w;
         edge(0, tg, w);
         const CBVal T = B.rv[tg];
         if (T.wid >= 0) { rep = -1 - T.wid; scale = w; }
         else { rep = T.rep; scale = w * T.scale; vbeg = T.vbeg; vn = T.vn; }
-    } else if (deg > CB_MAXD) {
-        atomicOr(&B.ctr[CBC_FAIL], 1);
-    } else if (deg >= 2 && deg <= 4) {
-        // The common case, entirely in registers (arrays indexed by unrolled constants; the generic path below keeps its cursors
-        // in scratch memory, a memory round trip per access: the first build spent 40 us per level there).  The host build's
-        // own order: acc = f0 * V0, then acc = merge(acc, f_e * V_e) edge after edge, sums formed as acc + f_e * entry.
-        int32_t eb[4], en[4];                                        // eb < 0: the unit vector of node -1 - eb
-        double ef[4];
-        int total = 0;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            eb[e] = 0; en[e] = 0; ef[e] = 0.0;
-            if (e < deg) {
-                int32_t tg; double w;
-                edge(e, tg, w);
-                const CBVal T = B.rv[tg];
-                if (T.wid >= 0) { eb[e] = -1 - T.wid; en[e] = 1; ef[e] = w; }
-                else if (T.rep == CB_EMPTY) { }
-                else if (T.rep < 0) { eb[e] = T.rep; en[e] = 1; ef[e] = w * T.scale; }
-                else { eb[e] = T.vbeg; en[e] = T.vn; ef[e] = w * T.scale; }
-                total += en[e];
-            }
-        }
-        const int need = deg == 2 ? total : 3 * total;               // the inputs (+ two intermediate runs when there is more than one merge)
-        const int32_t so = total == 0 ? 0 : (need <= CB_POOL_LDS ? atomicAdd(&S.used, need) : CB_POOL_LDS);
-        if (total > 0 && so + need > CB_POOL_LDS) {                  // no room in the staging area
-            if (DEFER && need <= CB_POOL_LDS) return false;          // ... this time
-            generic = true;                                          // ... ever: the generic path, from the pool
-        } else if (total > 0) {
-            const int32_t base = atomicAdd(&B.ctr[CBC_POOL], total);
-            if ((int64_t)base + total > (int64_t)B.pool_cap) atomicOr(&B.ctr[CBC_FAIL], 1);
-            else {
-                // the inputs side by side in LDS, every product formed (one round trip to the pool: the loads are independent)
-                int32_t rb[5];
-                int o = so;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    rb[e] = o;
-                    if (en[e] == 1 && eb[e] < 0) { S.id[o] = -1 - eb[e]; S.v[o] = ef[e]; o++; }       // (f * 1.0)
-                    else for (int q = 0; q < en[e]; q++, o++) { const CBEnt t = B.pool[eb[e] + q]; S.id[o] = t.node; S.v[o] = ef[e] * t.w; }
-                }
-                rb[4] = o;
-                int32_t a0 = rb[0], a1 = rb[1];
-                int32_t no = 0;
-                bool flip = false;
-#pragma unroll
-                for (int e = 1; e < 4; e++) {
-                    if (e < deg) {
-                        const bool last = e == deg - 1;
-                        const int32_t ob = so + (flip ? 2 : 1) * total;
-                        int32_t oo = ob;
-                        int32_t i = a0, j = rb[e];
-                        const int32_t j1 = rb[e + 1];
-                        int32_t ida = i < a1 ? S.id[i] : INT32_MAX, idb = j < j1 ? S.id[j] : INT32_MAX;
-                        while (ida != INT32_MAX || idb != INT32_MAX) {
-                            int32_t id; double v;
-                            if (ida < idb) { id = ida; v = S.v[i]; i++; ida = i < a1 ? S.id[i] : INT32_MAX; }
-                            else if (idb < ida) { id = idb; v = S.v[j]; j++; idb = j < j1 ? S.id[j] : INT32_MAX; }
-                            else { id = ida; v = S.v[i] + S.v[j]; i++; j++; ida = i < a1 ? S.id[i] : INT32_MAX; idb = j < j1 ? S.id[j] : INT32_MAX; }
-                            if (last) { CBEnt t; t.node = id; t.pad = 0; t.w = v; B.pool[base + no++] = t; }
-                            else { S.id[oo] = id; S.v[oo] = v; oo++; }
-                        }
-                        if (!last) { a0 = ob; a1 = oo; flip = !flip; }
-                    }
-                }
-                if (no > 0) { rep = r; scale = 1.0; vbeg = base; vn = no; }
-            }
-        }
-    }
-    if (generic) {
-        int32_t eb[CB_MAXD], en[CB_MAXD];                            // eb < 0: the unit vector of node -1 - eb
-        double ef[CB_MAXD];
-        int total = 0;
+    } else if (deg > CB_LANES) {
+        if (lane == 0) atomicOr(&B.ctr[CBC_FAIL], 1);
+    } else if (deg >= 2) {
+        // ---- the runs side by side in LDS, every product formed (f * entry, the host build's operands)
+        int32_t o = 0;
+        bool fits = true;
         for (int e = 0; e < deg; e++) {
             int32_t tg; double w;
             edge(e, tg, w);
             const CBVal T = B.rv[tg];
-            if (T.wid >= 0) { eb[e] = -1 - T.wid; en[e] = 1; ef[e] = w; }
-            else if (T.rep == CB_EMPTY) { eb[e] = 0; en[e] = 0; ef[e] = 0.0; }
-            else if (T.rep < 0) { eb[e] = T.rep; en[e] = 1; ef[e] = w * T.scale; }
-            else { eb[e] = T.vbeg; en[e] = T.vn; ef[e] = w * T.scale; }
-            total += en[e];
-        }
-        if (total > 0) {
-            const int32_t base = atomicAdd(&B.ctr[CBC_POOL], total);
-            if ((int64_t)base + total > (int64_t)B.pool_cap) atomicOr(&B.ctr[CBC_FAIL], 1);
+            if (lane == 0) S.off[e] = o;
+            if (T.wid >= 0) { if (lane == 0 && o < CB_RUN) { S.id[o] = T.wid; S.v[o] = w; } o += 1; }                                 // (f * 1.0)
+            else if (T.rep == CB_EMPTY) { }
+            else if (T.rep < 0) { if (lane == 0 && o < CB_RUN) { S.id[o] = -1 - T.rep; S.v[o] = w * T.scale; } o += 1; }
             else {
-                int32_t no = 0;
-                // room in the workgroup's LDS staging (bump allocation per launch: few lanes of a wavefront merge, so one of them
-                // may take hundreds of entries)
-                const int32_t so = total <= CB_POOL_LDS ? atomicAdd(&S.used, total) : CB_POOL_LDS;
-                if (so + total <= CB_POOL_LDS) {
-                    // the inputs side by side in LDS, every product formed (f * entry, the host build's operands), then a merge of
-                    // the deg sorted runs
-                    int32_t off[CB_MAXD + 1];
-                    int o = so;
-                    for (int e = 0; e < deg; e++) {
-                        off[e] = o;
-                        if (en[e] == 1 && eb[e] < 0) { S.id[o] = -1 - eb[e]; S.v[o] = ef[e]; o++; }       // (f * 1.0)
-                        else for (int q = 0; q < en[e]; q++, o++) { const CBEnt t = B.pool[eb[e] + q]; S.id[o] = t.node; S.v[o] = ef[e] * t.w; }
-                    }
-                    off[deg] = o;
-                    int32_t cur[CB_MAXD];
-                    for (int e = 0; e < deg; e++) cur[e] = off[e];
-                    for (;;) {
-                        int32_t mn = INT32_MAX;
-                        for (int e = 0; e < deg; e++) if (cur[e] < off[e + 1]) { const int32_t id = S.id[cur[e]]; mn = id < mn ? id : mn; }
-                        if (mn == INT32_MAX) break;
-                        double acc = 0.0; bool first = true;
-                        for (int e = 0; e < deg; e++)
-                            if (cur[e] < off[e + 1] && S.id[cur[e]] == mn) { const double v = S.v[cur[e]]; acc = first ? v : acc + v; first = false; cur[e]++; }
-                        CBEnt t; t.node = mn; t.pad = 0; t.w = acc;
-                        B.pool[base + no++] = t;
-                    }
-                } else {
-                    // no room: straight from the pool, one head per run
-                    atomicAdd(&B.ctr[CBC_SLOW], 1);
-                    int32_t cur[CB_MAXD], hid[CB_MAXD];
-                    double hv[CB_MAXD];
-                    auto head = [&](int e) {
-                        if (cur[e] >= en[e]) { hid[e] = INT32_MAX; return; }
-                        if (eb[e] < 0) { hid[e] = -1 - eb[e]; hv[e] = ef[e]; }
-                        else { const CBEnt t = B.pool[eb[e] + cur[e]]; hid[e] = t.node; hv[e] = ef[e] * t.w; }
-                    };
-                    for (int e = 0; e < deg; e++) { cur[e] = 0; head(e); }
-                    for (;;) {
-                        int32_t mn = INT32_MAX;
-                        for (int e = 0; e < deg; e++) mn = hid[e] < mn ? hid[e] : mn;
-                        if (mn == INT32_MAX) break;
-                        double acc = 0.0; bool first = true;
-                        for (int e = 0; e < deg; e++)
-                            if (hid[e] == mn) { acc = first ? hv[e] : acc + hv[e]; first = false; cur[e]++; head(e); }
-                        CBEnt t; t.node = mn; t.pad = 0; t.w = acc;
-                        B.pool[base + no++] = t;
-                    }
+                const double f = w * T.scale;
+                if (o + T.vn <= CB_RUN)
+                    for (int32_t q = lane; q < T.vn; q += CB_LANES) { const CBEnt t = B.pool[T.vbeg + q]; S.id[o + q] = t.node; S.v[o + q] = f * t.w; }
+                o += T.vn;
+            }
+            if (o > CB_RUN) fits = false;
+        }
+        if (lane == 0) S.off[deg] = o;
+        const int32_t total = o;
+        if (B.dbg && lane == 0) { atomicMax(&B.dbg[4 * B.level + 1], total); atomicAdd(&B.dbg[4 * B.level + 2], total); }
+        if (!fits) { if (lane == 0) { atomicOr(&B.ctr[CBC_FAIL], 1); atomicAdd(&B.ctr[CBC_SLOW], 1); } }       // (a vector of more than CB_RUN entries: the host build)
+        else if (total > 0) {
+            int32_t base_rel = 0;
+            if (lane == 0) base_rel = atomicAdd(poolc, total);
+            base_rel = __shfl(base_rel, 0);
+            if ((int64_t)base_rel + total > (int64_t)B.pool_cap) { if (lane == 0) atomicOr(&B.ctr[CBC_FAIL], 1); }
+            else {
+                cb_wave_sync();
+                // acc = run 0, then acc = merge(acc, run e) edge after edge; the last merge writes the pool
+                int32_t a0 = S.off[0], na = S.off[1] - S.off[0], no = 0;
+                bool flip = false;
+                for (int e = 1; e < deg; e++) {
+                    const int32_t b0 = S.off[e], nb = S.off[e + 1] - S.off[e];
+                    const bool last = e == deg - 1;
+                    const int32_t x0 = (flip ? 2 : 1) * CB_RUN;
+                    const int32_t n = cb_merge_wave(S, a0, na, b0, nb, x0, last ? B.pool + pool_base + base_rel : nullptr);
+                    cb_wave_sync();
+                    if (last) no = n; else { a0 = x0; na = n; flip = !flip; }
                 }
-                if (no > 0) { rep = r; scale = 1.0; vbeg = base; vn = no; }
+                if (no > 0) { rep = r; scale = 1.0; vbeg = pool_base + base_rel; vn = no; }
             }
         }
     }
-    // ---- the record is finished; its predecessors count down.  A predecessor with ONE out-edge that this releases is finished
-    // on the spot (its vector is this record's, scaled: no merge, nothing to wait for) and the walk goes on from there -- a
-    // chain of such records costs one dependent load per link instead of one launch per link.
+    // ---- the record is finished; then the chain it released, link by link (each link: its vector is the finished record's, scaled)
     int32_t wid_r = B.rv[r].wid;
+    int n_links = 0;
     for (;;) {
-        CBVal &V = B.rv[r];
-        V.rep = rep; V.vbeg = vbeg; V.vn = vn; V.scale = scale;       // (wid / out_left stay)
-        int32_t next = -1;
-        for (int32_t e = 0; e < ri.pred_cnt; e++) {
-            const int32_t pe = B.pred[ri.pred_beg + e];
-            const int32_t p = pe & ~CB_CHAIN;
-            if (atomicSub(&B.rv[p].out_left, 1) == 1) {
-                if ((pe & CB_CHAIN) && next < 0) next = p;
-                else push(p);
-            }
-        }
+        if (lane == 0) { CBVal &V = B.rv[r]; V.rep = rep; V.vbeg = vbeg; V.vn = vn; V.scale = scale; }       // (wid / out_left stay)
         if (next < 0) break;
-        // `next` has one out-edge, and it ends in r: through(r, w)
+        if (n_links >= B.max_chain) {                                  // (the rest of a long chain enters the next level as ordinary records)
+            if (lane == 0) qn[atomicAdd(cn, 1)] = next;
+            break;
+        }
+        n_links++;
         const NDRec &Rn = B.C.rec[next];
         const CBRec rin = B.ri[next];
         const int32_t wid_n = B.rv[next].wid;
+        const int32_t after = cb_countdown_wave(B, rin, qn, cn);
         double w;
         if (Rn.out_id[0] >= 0) w = Rn.out_w[0]; else if (Rn.out_id[1] >= 0) w = Rn.out_w[1]; else w = B.pit[rin.pit_beg].w;
         if (wid_r >= 0) { rep = -1 - wid_r; scale = w; vbeg = 0; vn = 0; }
         else scale = w * scale;                                        // (rep, vbeg, vn: r's)
-        r = next; ri = rin; wid_r = wid_n;
+        r = next; wid_r = wid_n; next = after;
         n_chain++;
     }
-    return true;
+    if (B.dbg && lane == 0) atomicMax(&B.dbg[4 * B.level + 3], n_links);
+    cb_wave_sync();                                                    // (the staging area is the next record's)
 }
 
-// level r: the frontier is q[r & 1][0 .. ctr[CBC_Q + r % 3]), the next one goes to q[(r + 1) & 1]
+// level r: the frontier is the sub-queues of q[r & 1] (sizes qcnt[r % 3]), the next one goes to q[(r + 1) & 1]; gridDim.x is a multiple of CB_NQ
 __global__ __launch_bounds__(CB_LANES) void k_cb_level(CBArgs B, int r)
 {
-    __shared__ CBStageLds<CB_POOL_LEVEL> S;
-    if (threadIdx.x == 0) S.used = 0;
-    __syncthreads();
-    const int32_t nq = B.ctr[CBC_Q + r % 3];
+    __shared__ CBWaveLds S;
+    const int sq = blockIdx.x % CB_NQ, part = blockIdx.x / CB_NQ, nparts = gridDim.x / CB_NQ;
+    const int32_t nq = B.qcnt[((r % 3) * CB_NQ + sq) * CB_PAD];
     // (the size of the level after the next is cleared by EVERY launch, also by those behind the end of the sweep: the counters
     // rotate, and a launch that returned without clearing would leave the size of level r - 1 where level r + 2 looks)
-    if (blockIdx.x == 0 && threadIdx.x == 0) B.ctr[CBC_Q + (r + 2) % 3] = 0;
+    if (part == 0 && threadIdx.x == 0) B.qcnt[(((r + 2) % 3) * CB_NQ + sq) * CB_PAD] = 0;
     if (nq == 0) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { atomicAdd(&B.ctr[CBC_PROC], nq); B.ctr[CBC_LEVELS] = r + 1; }
-    const int32_t *qc = (r & 1) ? B.q1 : B.q0;
-    int32_t *qn = (r & 1) ? B.q0 : B.q1;
-    int32_t *cn = &B.ctr[CBC_Q + (r + 1) % 3];
+    if (part == 0 && threadIdx.x == 0) { atomicAdd(&B.ctr[CBC_PROC], nq); B.ctr[CBC_LEVELS] = r + 1; if (B.dbg) atomicAdd(&B.dbg[4 * r], nq); }
+    const int32_t *qc = ((r & 1) ? B.q1 : B.q0) + (size_t)sq * B.qcap;
+    int32_t *qn = ((r & 1) ? B.q0 : B.q1) + (size_t)sq * B.qcap;
+    int32_t *cn = &B.qcnt[(((r + 1) % 3) * CB_NQ + sq) * CB_PAD];
     int32_t n_chain = 0;
-    auto push = [&](int32_t p) { qn[agg_slot(cn)] = p; };
-    for (int32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nq; k += gridDim.x * blockDim.x)
-        (void)cb_process<false>(B, qc[k], S, push, n_chain);
-    if (n_chain) atomicAdd(&B.ctr[CBC_PROC], n_chain);               // (records finished in passing never enter a frontier)
-}
-
-// The narrow remainder: ONE workgroup, level after level without a launch in between (the cascade's own pattern: level queues in
-// LDS, one barrier per level).  A launch boundary leaves every XCD's L2 cold for what the others wrote -- each of a level's six
-// or seven dependent round trips then goes to the fabric (measured: 30 us per level with one launch per level, whatever its
-// width) -- while one CU keeps reading its own XCD's L2.  Starts at level r0 with the frontier in q[r0 & 1] / ctr[CBC_Q + r0 % 3].
-constexpr int CB_QCAP = 1024;
-__global__ __launch_bounds__(1024) void k_cb_sweep(CBArgs B, int r0)
-{
-    __shared__ int32_t s_q[2][CB_QCAP];
-    __shared__ CBStageLds<CB_POOL_SWEEP> S;
-    __shared__ int32_t s_cnt[3], s_proc, s_retry[2];
-    int r = r0;
-    if (threadIdx.x == 0) { s_cnt[r % 3] = B.ctr[CBC_Q + r % 3]; s_cnt[(r + 1) % 3] = 0; s_cnt[(r + 2) % 3] = 0; S.used = 0; s_proc = 0; s_retry[0] = 0; s_retry[1] = 0; }
-    __syncthreads();
-    int32_t nq = s_cnt[r % 3];
-    {
-        const int32_t *q = (r & 1) ? B.q1 : B.q0;
-        for (int32_t k = threadIdx.x; k < nq && k < CB_QCAP; k += blockDim.x) s_q[r & 1][k] = q[k];
-    }
-    __syncthreads();
-    int32_t n_chain = 0;
-    while (nq > 0) {
-        const int32_t *qc = (r & 1) ? B.q1 : B.q0;
-        int32_t *qn = (r & 1) ? B.q0 : B.q1;
-        const int32_t *lc = s_q[r & 1];
-        int32_t *ln = s_q[(r + 1) & 1];
-        int32_t *cn = &s_cnt[(r + 1) % 3];
-        if (threadIdx.x == 0) { s_cnt[(r + 2) % 3] = 0; s_proc += nq; }
-        auto push = [&](int32_t p) { const int32_t sl = agg_slot(cn); if (sl < CB_QCAP) ln[sl] = p; else qn[sl] = p; };
-        // records whose merge found no room in the staging area wait in a list (behind the frontier queues' nd entries: q0 / q1
-        // have 2 * nd) and run again, with the area handed out anew, after the others
-        int32_t *rl[2] = {B.q0 + B.C.nd, B.q1 + B.C.nd};
-        for (int32_t k = threadIdx.x; k < nq; k += blockDim.x) {
-            const int32_t rec = k < CB_QCAP ? lc[k] : qc[k];
-            if (!cb_process<true>(B, rec, S, push, n_chain)) rl[0][agg_slot(&s_retry[0])] = rec;
-        }
-        __syncthreads();
-        int pass = 0;
-        while (s_retry[pass & 1] > 0) {                               // (uniform: read between two barriers)
-            const int32_t nr = s_retry[pass & 1];
-            __syncthreads();
-            if (threadIdx.x == 0) { S.used = 0; s_retry[(pass + 1) & 1] = 0; }
-            __syncthreads();
-            for (int32_t k = threadIdx.x; k < nr; k += blockDim.x) {
-                const int32_t rec = rl[pass & 1][k];
-                if (!cb_process<true>(B, rec, S, push, n_chain)) rl[(pass + 1) & 1][agg_slot(&s_retry[(pass + 1) & 1])] = rec;
-            }
-            __syncthreads();
-            pass++;
-        }
-        nq = *cn;
-        r++;
-        // (the staging area is handed out anew every level; its users of this level are past the barrier)
-        __syncthreads();
-        if (threadIdx.x == 0) { S.used = 0; s_retry[0] = 0; s_retry[1] = 0; }
-        __syncthreads();
-    }
-    if (n_chain) atomicAdd(&B.ctr[CBC_PROC], n_chain);
-    if (threadIdx.x == 0) { atomicAdd(&B.ctr[CBC_PROC], s_proc); B.ctr[CBC_LEVELS] = r; B.ctr[CBC_Q] = 0; B.ctr[CBC_Q + 1] = 0; B.ctr[CBC_Q + 2] = 0; }
+    for (int32_t k = part; k < nq; k += nparts)
+        cb_record_wave(B, qc[k], S, &B.poolc[sq * CB_PAD], sq * B.pool_cap, qn, cn, n_chain);
+    if (n_chain && threadIdx.x == 0) atomicAdd(&B.ctr[CBC_PROC], n_chain);      // (records finished in passing never enter a frontier)
 }
 
 // ---- 3. nodes -----------------------------------------------------------------------------------------------------------
