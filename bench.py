@@ -276,13 +276,33 @@ def stencil_valu_insts(size):
         then = json.load(open(meta)).get('csrc_sha256', {})
         if any(then.get(f) != now.get(f) for f in ('stencil.hip', 'internal.h')):
             continue
+        got = {}
         for row in csv.DictReader(open(fn)):
-            if 'k_stencil_march' in row['kernel'] and row['counter'] == 'SQ_INSTS_VALU' and int(row['dispatches']) > 1:
-                best = float(row['mean_per_dispatch_KB'])           # (the column holds plain counts for SQ counters)
+            if 'k_stencil_march' in row['kernel'] and row['counter'] in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU') and int(row['dispatches']) > 1:
+                got[row['counter']] = float(row['mean_per_dispatch_KB'])           # (the column holds plain counts for SQ counters)
+        if 'SQ_INSTS_VALU' in got:
+            best = got
     return best
 
 
-N_SIMD, VALU_CYCLES_PER_INST, PEAK_CLOCK_HZ = 256 * 4, 4.0, 2.4e9      # MI355X: 256 CUs x 4 SIMD16s, a wave64 instruction = 4 cycles
+def stencil_issue_model():
+    """Issue cycles per vector instruction of the marching loop from the committed instruction histogram
+    (profiles/r*_stencil_isa_histogram.txt, tools/stencil_isa_histogram.sh: 64-bit / fp64 instructions 4 cycles, 32-bit ones 2,
+    fp64 transcendentals 8 -- MI355X_MICROARCH.md, SIMD-32), only from a histogram of the current stencil.hip; None otherwise."""
+    import glob
+    import hashlib
+    now = hashlib.sha256(open(os.path.join(ROOT, 'pydem_amd', 'csrc', 'stencil.hip'), 'rb').read()).hexdigest()
+    best = None
+    for fn in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_stencil_isa_histogram.txt'))):
+        for line in open(fn):
+            if line.startswith('#json '):
+                d = json.loads(line[6:])
+                if d.get('stencil_sha256') == now:
+                    best = d
+    return best
+
+
+N_CU, N_SIMD, VALU_CYCLES_PER_INST, PEAK_CLOCK_HZ = 256, 256 * 4, 4.0, 2.4e9      # MI355X: 256 CUs x 4 SIMDs; a wave64 fp64 instruction issues over 4 cycles (32-bit ones over 2: stencil_issue_model)
 
 
 # stages of the step for `roofline_stages`: (name, kernels of the stage, algorithmic bytes per cell, timing key, what the bytes are,
@@ -448,7 +468,12 @@ def main():
                            "algorithmic_bytes": bpc * cells, "algorithmic_bytes_per_cell": bpc, "bytes_are": what,
                            "achieved": gbs, "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic(kernels, n, srcs)})
         dom = max(stages, key=lambda d: d["ms"])
-        valu = stencil_valu_insts(n)
+        sq = stencil_valu_insts(n) or {}
+        valu, salu = sq.get('SQ_INSTS_VALU'), sq.get('SQ_INSTS_SALU')
+        model = stencil_issue_model()
+        cpi = model['valu_cycles_per_inst'] if model else VALU_CYCLES_PER_INST      # (no histogram of this stencil.hip: every instruction charged as fp64)
+        valu_floor_ms = valu * cpi / N_SIMD / PEAK_CLOCK_HZ * 1e3 if valu else None
+        salu_floor_ms = salu / N_CU / PEAK_CLOCK_HZ * 1e3 if salu else None        # one scalar instruction per CU and cycle
         out = {
             "metric": "Mcells/s (slope+aspect+UCA+TWI end-to-end) per tile; % HBM roofline",
             "value": value, "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -476,8 +501,14 @@ def main():
                                  "algorithmic_bytes_per_cell": STENCIL_BYTES_PER_CELL,
                                  # the kernel is bound by its vector instructions (fp64, no packed forms): the same launch against the
                                  # issue rate of the vector ALUs = instructions x 4 cycles / 1024 SIMDs / 2.4 GHz / measured time
-                                 "valu_insts": valu, "valu_roofline_frac": (valu * VALU_CYCLES_PER_INST / N_SIMD / PEAK_CLOCK_HZ / (st_ms * 1e-3)) if valu else None,
-                                 "valu_roofline_frac_back_to_back": (valu * VALU_CYCLES_PER_INST / N_SIMD / PEAK_CLOCK_HZ / (st_b2b * 1e-3)) if (valu and st_b2b) else None},
+                                 # (since round 6 with the cycles of the instruction mix -- 32-bit vector instructions issue over 2 cycles, fp64 over 4 --
+                                 # and with the SCALAR unit beside it: the mask algebra runs there, the kernel is bound by both issue ports)
+                                 "valu_insts": valu, "valu_cycles_per_inst": cpi if valu else None, "valu_floor_ms": valu_floor_ms,
+                                 "valu_roofline_frac": (valu_floor_ms / st_ms) if valu else None,
+                                 "valu_roofline_frac_back_to_back": (valu_floor_ms / st_b2b) if (valu and st_b2b) else None,
+                                 "salu_insts": salu, "salu_floor_ms": salu_floor_ms,
+                                 "salu_roofline_frac": (salu_floor_ms / st_ms) if salu else None,
+                                 "salu_roofline_frac_back_to_back": (salu_floor_ms / st_b2b) if (salu and st_b2b) else None},
             "end_to_end_GBs": E2E_BYTES_PER_CELL * world * cells * args.steps / dt / 1e9,
             "stages_ms": dict({k: tm[k] for k in ('slopes_directions_ms', 'stencil_kernel_ms', 'flats_ms', 'graph_ms',
                                                    'pits_ms', 'sweep_ms', 'twi_ms')}, **phase),

@@ -4116,7 +4116,7 @@ static int cond_build_device(pydem_tile *t, int *status)
     // end of the sweep find empty sub-queues and return at once)
     static int cb_grid = -1, cb_chain = -1;
     if (cb_grid < 0) { const char *e = getenv("PYDEM_CB_GRID"); cb_grid = e ? std::max(1, std::min(atoi(e), 65536)) : CB_GRID; cb_grid = ((cb_grid + CB_NQ - 1) / CB_NQ) * CB_NQ; }
-    if (cb_chain < 0) { const char *e = getenv("PYDEM_CB_CHAIN"); cb_chain = e ? std::max(0, atoi(e)) : 4; }
+    if (cb_chain < 0) { const char *e = getenv("PYDEM_CB_CHAIN"); cb_chain = e ? std::max(0, atoi(e)) : 2; }
     B.max_chain = cb_chain;
     int32_t *d_dbg = nullptr;                              // PYDEM_CB_DEBUG=1: per-level statistics of the sweep to stderr (diagnostic, one extra allocation)
     const int dbg_levels = 4096;

@@ -28,7 +28,7 @@
 
 constexpr int32_t CB_EMPTY = INT32_MIN;      // the empty vector: the water ends inside the tile
 constexpr int32_t CB_CHAIN = INT32_MIN;      // bit 31 of a predecessor entry: that record has one out-edge
-constexpr int CB_GRID = 4096;                // workgroups (= wavefronts = records in flight) of a level launch (PYDEM_CB_GRID)
+constexpr int CB_GRID = 8192;                // workgroups (= wavefronts = records in flight) of a level launch (PYDEM_CB_GRID)
 // Every frontier is CB_NQ sub-queues and the pool CB_NQ regions, each with a counter on a line of its own: with one queue and one
 // pool the 3000 wave-aggregated atomics of a 6000-record level queued up at two addresses of the fabric (~25 ns each: 90 us
 // for the level, 13 ns per record at every width).  A workgroup consumes, fills and allocates from sub-queue / region blockIdx % CB_NQ.

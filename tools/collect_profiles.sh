@@ -11,14 +11,14 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/prof/pf -o t --output-forma
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/prof/pw -o t --output-format csv -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 --host-to-host 0 --roof-iters 2 > gpurun_out/prof/pw.log 2>&1
 python tools/pmc_aggregate.py gpurun_out/prof/pf gpurun_out/prof/pw > gpurun_out/prof/pmc_fetch_write.csv
 python tools/csrc_stamp.py > gpurun_out/prof/pmc_fetch_write.meta.json      # identity of the kernels the counters belong to (bench.py: pmc_traffic)
-timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES --kernel-include-regex 'k_stencil' -d gpurun_out/prof/sq -o t --output-format csv -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 --host-to-host 0 --roof-iters 2 > gpurun_out/prof/sq.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-include-regex 'k_stencil' -d gpurun_out/prof/sq -o t --output-format csv -- python bench.py --steps 1 --warmup 0 --cpu-sample 0 --host-to-host 0 --roof-iters 2 > gpurun_out/prof/sq.log 2>&1
 python tools/pmc_aggregate.py gpurun_out/prof/sq > gpurun_out/prof/pmc_sq_stencil.csv
 cp gpurun_out/prof/pmc_fetch_write.meta.json gpurun_out/prof/pmc_sq_stencil.meta.json      # (bench.py: stencil_valu_insts)
 cp gpurun_out/prof/ks/t_kernel_stats.csv gpurun_out/prof/kernel_stats.csv
 rm -f gpurun_out/prof/*/t_kernel_trace.csv gpurun_out/prof/*/t_counter_collection.csv
 head -14 gpurun_out/prof/kernel_stats.csv; head -8 gpurun_out/prof/pmc_fetch_write.csv; cat gpurun_out/prof/pmc_sq_stencil.csv
 # the bench lines quote `traffic` from the committed PMC files while their stamp matches the kernel sources: file the fresh ones first
-R=${ROUND_TAG:-r05}
+R=${ROUND_TAG:-r06}
 cp gpurun_out/prof/pmc_fetch_write.csv profiles/${R}_pmc_fetch_write_16384.csv; cp gpurun_out/prof/pmc_fetch_write.meta.json profiles/${R}_pmc_fetch_write_16384.meta.json
 cp gpurun_out/prof/pmc_sq_stencil.csv profiles/${R}_pmc_sq_stencil_16384.csv; cp gpurun_out/prof/pmc_sq_stencil.meta.json profiles/${R}_pmc_sq_stencil_16384.meta.json
 timeout 600 python bench.py > gpurun_out/prof/bench_default.json 2> gpurun_out/prof/bench_default.err
