@@ -92,7 +92,9 @@ void *plane_take(int device, size_t bytes)
         }
         // (a size the lists do not hold: nothing is evicted here -- the blocks on the lists are those of the tile destroyed
         // last, i.e. what the tile being built asks for next; dead sizes leave when plane_give needs their room, and a failing
-        // hipMalloc empties the lists)
+        // hipMalloc empties the lists.  PYDEM_PLANE_EVICT_ON_MISS=1: the round-5 behaviour, for A/B runs)
+        static const bool on_miss = [] { const char *e = getenv("PYDEM_PLANE_EVICT_ON_MISS"); return e && atoi(e) > 0; }();
+        if (on_miss) { std::vector<void *> victims; plane_cache_evict(c, bytes, victims); for (void *v : victims) (void)hipFree(v); }
     }
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, bytes);

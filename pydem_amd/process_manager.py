@@ -436,12 +436,24 @@ class ProcessManager(object):
         return self.processor_cls(**kw)
 
     def _in_flight(self):
-        """Worker threads for the per-tile phases: the configured number, or one per GPU that holds tiles of this process."""
+        """Worker threads for the per-tile phases: the configured number; by default one per GPU that holds tiles of this process
+        and, since round 6, TWO per GPU that holds at least two of them: the stages of a tile are bound by different things (the pit
+        search by instruction issue, the sweep by dependent latencies and traffic), so two tiles whose pipelines drift apart share
+        the chip better than one -- measured on eight resident 16384^2 tiles: 395 -> 356 ms for the per-tile phases (two tiles:
+        98.8 -> 91.5 ms, profiles/r06_two_tiles_in_flight_16384.txt).  Only with the device processor (a custom processor class
+        need not be thread-safe)."""
         if self.tiles_in_flight is not None:
             return max(1, int(self.tiles_in_flight))
-        devs = set(getattr(self.tiles[i], '_device', None) for i in self._owned() if self.tiles[i] is not None)
-        devs.discard(None)
-        return max(1, len(devs))
+        per_dev = {}
+        for i in self._owned():
+            dev = getattr(self.tiles[i], '_device', None) if self.tiles[i] is not None else None
+            if dev is not None:
+                per_dev[dev] = per_dev.get(dev, 0) + 1
+        if not per_dev:
+            return 1
+        if self.processor_cls is DEMProcessor:
+            return sum(2 if n >= 2 else 1 for n in per_dev.values())
+        return len(per_dev)
 
     def _per_tile(self, fn):
         """Run fn(i) for every owned tile: one after the other, or `tiles_in_flight` at a time from worker threads
