@@ -230,7 +230,15 @@ __device__ __forceinline__ void cond_run_block(const CondArgsE &X)
                 double acc = (V.cw & ND_FLAT) ? NAN : 0.0;                           // :815
                 acc += V.in_inl[0];                                                  // fixed order: ascending source (empty slots hold 0)
                 acc += V.in_inl[1];
-                for (int s2 = 2; s2 < V.n_in; s2++) acc += X.slot[V.in_base + s2 - 2];
+                // (slots 2.. in batches of eight loads, then added in slot order: a watched cell below a confluence has up to ~200
+                // in-edges, and one dependent load per slot made such a node the whole level's duration)
+                for (int s2 = 2; s2 < V.n_in; s2 += 8) {
+                    double tv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) tv[u] = s2 + u < V.n_in ? X.slot[V.in_base + s2 + u - 2] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (s2 + u < V.n_in) acc += tv[u];
+                }
                 delta = acc;
                 N.delta = acc;
                 N.flag = (f & (NF_NAN | CF_NANPASS | CF_NANINT)) | NF_FINAL | NF_DONE | NF_APPLIED;
@@ -259,14 +267,28 @@ __device__ __forceinline__ void cond_run_block(const CondArgsE &X)
                     const int32_t sl = agg_slot(cn);
                     if (sl < COND_QCAP) ln[sl] = V.e_inl[e].dst; else qn[sl] = V.e_inl[e].dst;
                 }
-            for (int e = 2; e < V.n_out; e++) {
-                const CEdge ed = X.edge[V.out_base + e - 2];
-                if (ed.slot < 0) X.node[ed.dst].in_inl[-1 - ed.slot] = delta * ed.w;
-                else X.slot[ed.slot] = delta * ed.w;
-                if (atomicSub(&X.node[ed.dst].cnt, 1) == 1) {
-                    const int32_t sl = agg_slot(cn);
-                    if (sl < COND_QCAP) ln[sl] = ed.dst; else qn[sl] = ed.dst;
-                }
+            // the other out-edges (a quarter of the nodes have some, a few hundred per tile 17-70) eight at a time: the edges loaded
+            // together, the hand-overs stored, the count-downs issued back to back, then the releases -- two dependent round trips per
+            // eight edges instead of two per edge
+            for (int e = 2; e < V.n_out; e += 8) {
+                CEdge ex[8];
+                int32_t oldx[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (e + u < V.n_out) ex[u] = X.edge[V.out_base + e + u - 2];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (e + u < V.n_out) {
+                        if (ex[u].slot < 0) X.node[ex[u].dst].in_inl[-1 - ex[u].slot] = delta * ex[u].w;
+                        else X.slot[ex[u].slot] = delta * ex[u].w;
+                    }
+#pragma unroll
+                for (int u = 0; u < 8; u++) oldx[u] = e + u < V.n_out ? atomicSub(&X.node[ex[u].dst].cnt, 1) : 0;
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (e + u < V.n_out && oldx[u] == 1) {
+                        const int32_t sl = agg_slot(cn);
+                        if (sl < COND_QCAP) ln[sl] = ex[u].dst; else qn[sl] = ex[u].dst;
+                    }
             }
         }
         __syncthreads();

@@ -363,3 +363,55 @@ def test_queued_waves_respect_the_wave_limit(tmp_path, monkeypatch):
     for i in range(out[0].n_inputs):
         assert np.array_equal(out[0].tile_result(i, 'uca_total'), out[1].tile_result(i, 'uca_total'), equal_nan=True), i
         assert np.array_equal(out[0].tile_result(i, 'edge_done'), out[1].tile_result(i, 'edge_done')), i
+
+
+@pytest.mark.parametrize('name', ['pm_fractal_2x3_ov1', 'pm_nansea_2x2_ov2'])
+def test_device_operator_build_matches_host_build(name, tmp_path, monkeypatch):
+    """The condensed operator of a tile's fix-up (csrc/uca_cond.inl) built on the device (csrc/uca_cbuild.inl, the default since
+    round 6) against the host build of rounds 4-5: PYDEM_COND_BUILD=check builds both for every tile and compares node by node
+    (cells, counts, edges and in-slots exactly, weights to 1e-12 -- the host orders the pit edges of one pit by record id, the
+    device by drain cell) and fails the round on a difference; PYDEM_COND_BUILD=host must give the same waves and masks as the
+    default (reference: the round pydem/dem_processing.py:778-862 behind pydem/process_manager.py:224-284)."""
+    from test_process_manager_cpu import run_pm
+    g = load_golden(name)
+    runs = {}
+    for how in ('device', 'check', 'host'):
+        monkeypatch.setenv('PYDEM_COND_BUILD', how)
+        runs[how] = run_pm(g, str(tmp_path / how), n_workers=8)[0]
+    d = runs['device']
+    assert d.edge_queued_batches > 0
+    for how in ('check', 'host'):
+        p = runs[how]
+        assert (p.edge_waves, p.edge_rounds, p.edge_tiebreaks) == (d.edge_waves, d.edge_rounds, d.edge_tiebreaks), how
+        for i in range(d.n_inputs):
+            for key in ('edge_todo', 'edge_done'):
+                assert np.array_equal(p.tile_result(i, key), d.tile_result(i, key)), (how, i, key)
+            a, b = p.tile_result(i, 'uca_total'), d.tile_result(i, 'uca_total')
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (how, i)
+            assert np.allclose(a, b, rtol=1e-12, atol=0, equal_nan=True), (how, i)
+
+
+def test_bench_with_two_ranks_on_this_box(tmp_path):
+    """bench.py --gpus 2 (it starts its own ranks): without two GPUs it must refuse at once with a message, not hang in a
+    communicator; with PYDEM_BENCH_SHARED_GPU=1 the two ranks share the GPU, the strips travel over sockets, every rank chooses the
+    waves on its own replica of the board (queued batches on both), the ranks compare schedule and board after the warm-up, and the
+    line carries per-rank numbers."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from pydem_amd import _ffi
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29700 + os.getpid() % 200))
+    env.pop('PYDEM_BENCH_SHARED_GPU', None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--size', '1024', '--steps', '1', '--warmup', '1', '--cpu-sample', '0', '--roof-iters', '0']
+    if _ffi.device_count() < 2:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and 'needs 2 GPUs' in (r.stderr + r.stdout), (r.returncode, r.stderr[-500:])
+    r = subprocess.run(cmd, env=dict(env, PYDEM_BENCH_SHARED_GPU='1', MASTER_PORT=str(29400 + os.getpid() % 200)), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['rccl_ranks'] is None and line['config']['edge_exchange'] == 'socket-host-fallback'
+    ranks = line['per_rank']
+    assert [p['rank'] for p in ranks] == [0, 1]
+    assert ranks[0]['edge_waves'] == ranks[1]['edge_waves'] > 0
+    assert all(p['edge_queued_batches'] > 0 for p in ranks)

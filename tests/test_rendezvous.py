@@ -23,6 +23,15 @@ a = np.full(5000, float(rank + 1)); a[rank] = np.nan if rank == 1 else a[rank]
 g.sum_inplace(a)
 want = np.full(5000, float(sum(range(1, world + 1)))); want[1] = np.nan
 assert np.array_equal(a, want, equal_nan=True)
+b = np.zeros(4096, np.uint8); b[rank::world] = (np.arange(b[rank::world].size) %% 251 + 1).astype(np.uint8)     # disjoint fills, like the staging buffer of a queued batch
+g.sum_bytes_inplace(b)
+wantb = np.zeros(4096, np.uint8)
+for r in range(world):
+    wantb[r::world] = (np.arange(wantb[r::world].size) %% 251 + 1).astype(np.uint8)
+assert b.dtype == np.uint8 and np.array_equal(b, wantb)
+m = np.array([float(rank), -float(rank), 7.0, np.inf if rank == 0 else 1.0])
+g.max_inplace(m)
+assert np.array_equal(m, [world - 1.0, 0.0, 7.0, np.inf])
 for _ in range(20):
     g.barrier()
 g.close()
