@@ -395,7 +395,16 @@ __device__ __forceinline__ RowV rowv_load(const double *rtv, int r)      // rtv:
 // and four carried registers.
 constexpr int QS = 66;                         // lanes + one pad slot either side
 struct WaveQ { double a[2][3][QS]; double one[QS], zero[QS]; double dg[2][QS]; };      // a[band parity][0: hn, 1: hs1, 2: v]; dg: se, sw of the running band
+// Producer / store split (round 6 experiment, PYDEM_STENCIL_SPLIT=1; k_stencil_march_split): a compute wavefront leaves the
+// (mag, direction, flat0) of a finished row in a small ring in LDS instead of storing it; ONE more wavefront per workgroup drains the
+// rings of its eleven producers into HBM.  prod / cons count rows of the chunk; a producer may be SR_ROWS rows ahead.
+#ifndef PYDEM_SPLIT_ROWS
+#define PYDEM_SPLIT_ROWS 4
+#endif
+constexpr int SR_ROWS = PYDEM_SPLIT_ROWS;
+struct StoreRing { double mag[SR_ROWS][64]; double dir[SR_ROWS][64]; uint8_t flat[SR_ROWS][64]; int prod, cons, pad[2]; };
 struct MarchCtx {
+    StoreRing *ring;                           // (split kernel only)
     WaveQ *q; const uint16_t *tab;             // tab[parity of the running band][k][0 / 1]: byte offsets of s1 / s2 from &q->a[0][0][lane]
     const double *col; const RowTab *rowtab; const double *rtv; const double *atan_16;
     double *mag, *dir; uint8_t *flat0;
@@ -434,7 +443,7 @@ __device__ __forceinline__ void lanes_published()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 
-template <bool F32, int P, bool FIRST = false>
+template <bool F32, int P, bool FIRST = false, bool SPLIT = false>
 __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, const RowV &ts, RowV &tnx, const int b, const double zS, double &z_ahead)
 {
     const int lane = (int)(threadIdx.x & 63);
@@ -576,11 +585,29 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
 #ifdef PYDEM_STENCIL_CHEAP
         cx.mag[cc] = M > 0 ? M * __builtin_amdgcn_rsq(M) : M;
 #else
+        if (SPLIT) {
+            StoreRing &R = *cx.ring;
+            const int slot = (b - cx.i0) & (SR_ROWS - 1);
+            R.mag[slot][lane] = M > 0 ? sqrt_window(M) : M;
+            R.dir[slot][lane] = pick(flat, -1.0, direction);
+            R.flat[slot][lane] = ON(flat) ? 1 : 0;
+        } else {
         cx.mag[cc] = M > 0 ? sqrt_window(M) : M;                       // :1901
 #endif
         cx.dir[cc] = pick(flat, -1.0, direction);
         cx.flat0[cc] = ON(flat) ? 1 : 0;
+#ifndef PYDEM_STENCIL_CHEAP
         }
+#endif
+        }
+    }
+    if (SPLIT && b >= cx.i0) {
+        // the row is in the ring: tell the store wavefront (LDS operations of a wavefront execute in order; the fence is for the
+        // compiler), then make sure the slot of the row after the next SR_ROWS - 1 is free before anybody writes it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __atomic_store_n(&cx.ring->prod, b - cx.i0 + 1, __ATOMIC_RELAXED);
+        const int need = b - cx.i0 + 2 - SR_ROWS;                       // rows that must have left before row b + 1 is written
+        if (need > 0) while (__atomic_load_n(&cx.ring->cons, __ATOMIC_RELAXED) < need) __builtin_amdgcn_s_sleep(1);
     }
     // ================= north half of row b+1 =================
     if (__builtin_expect(!exact, 1)) {
@@ -624,7 +651,7 @@ __device__ __forceinline__ void march_band(const MarchCtx &cx, BandCarry &c, con
     lanes_published();
     c.hs1 = hs; c.hsL1 = cx.q->a[1 - P][1][lane]; c.Phs1 = LM(hs > 0); c.Nhs1 = LM(hs < 0);
     c.thAn = thAs; c.thBn = thBs;
-    row_arrived<FIRST ? 0 : 3>(z_ahead);
+    row_arrived<(FIRST || SPLIT) ? 0 : 3>(z_ahead);
 }
 
 // OCC = workgroups the compiler must fit on a CU: 1 = free choice (135 VGPRs: three wavefronts per SIMD), 4 = at most 128
@@ -704,6 +731,130 @@ __global__ __launch_bounds__(256, OCC) void k_stencil_march(const double *__rest
         march_band<F32, 0>(cx, c, ts, tu, b + 1, zP, zQ);
     }
     if (b < i1) march_band<F32, 1>(cx, c, tu, ts, b, zQ, zP);
+}
+
+// Producer / store split (see StoreRing): NCW compute wavefronts + one store wavefront per workgroup = twelve wavefronts, the CU's
+// whole allowance at the kernel's 135 VGPRs (three per SIMD) -- eleven compute wavefronts per CU instead of twelve.  LDS is carved
+// from the dynamic allocation (114 KB: above the 64 KB a static allocation may take).
+#ifndef PYDEM_SPLIT_NCW
+#define PYDEM_SPLIT_NCW 11
+#endif
+constexpr int SPLIT_NCW = PYDEM_SPLIT_NCW;
+struct SplitLds {
+    double atan16[18];
+    double rt[(MARCH_ROWS + 2) * 8];
+    WaveQ q[SPLIT_NCW];
+    StoreRing ring[SPLIT_NCW];
+    uint16_t tab[2 * 9 * 2 + 4];
+};
+
+template <bool F32>
+__global__ __launch_bounds__(64 * (SPLIT_NCW + 1), 1) void k_stencil_march_split(const double *__restrict__ elev, int n, int m,
+                                                       const RowTab *__restrict__ rowtab,
+                                                       double *__restrict__ mag, double *__restrict__ dir,
+                                                       uint8_t *__restrict__ flat0, int strips, int chunks, int rows_per_wave,
+                                                       int exact_only)
+{
+    extern __shared__ __align__(16) char dyn_lds[];
+    SplitLds &L = *reinterpret_cast<SplitLds *>(dyn_lds);
+    if (threadIdx.x < 17) L.atan16[threadIdx.x] = ATAN_16[threadIdx.x];
+    if (threadIdx.x < 36) {
+        const int par = threadIdx.x / 18, k = (threadIdx.x % 18) / 2, which = threadIdx.x & 1;
+        const int arr1[8] = {0, 2, 2, 0, 1, 2, 2, 1}, dl1[8] = {0, 0, 0, -1, -1, 0, 0, 0};
+        const int arr2[8] = {2, 1, 1, 2, 2, 0, 0, 2}, dl2[8] = {1, 0, -1, -1, -1, -1, 0, 1};
+        int off;
+        if (k == 8) off = (6 * QS + (which ? QS : 0) + 1) * 8;
+        else {
+            const int band = k < 4 ? 1 - par : par;
+            off = ((band * 3 + (which ? arr2[k] : arr1[k])) * QS + 1 + (which ? dl2[k] : dl1[k])) * 8;
+        }
+        L.tab[threadIdx.x] = (uint16_t)off;
+    }
+    if (threadIdx.x < SPLIT_NCW) { L.ring[threadIdx.x].prod = 0; L.ring[threadIdx.x].cons = 0; }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int groups = (strips + SPLIT_NCW - 1) / SPLIT_NCW;           // workgroups per chunk of rows
+    const int chunk = blockIdx.x / groups, strip0 = (blockIdx.x - chunk * groups) * SPLIT_NCW;
+    const int i0 = 1 + chunk * rows_per_wave;
+    const int i1 = (i0 + rows_per_wave < n - 1) ? i0 + rows_per_wave : n - 1;
+    {
+        const int r_last = i1 < n - 2 ? i1 : n - 2;
+        const double2 *src = reinterpret_cast<const double2 *>(rowtab + (i0 - 1));
+        double2 *dst = reinterpret_cast<double2 *>(L.rt);
+        const int n16 = (r_last - (i0 - 1) + 1) * 4;
+        if (chunk < chunks) for (int q = threadIdx.x; q < n16; q += blockDim.x) dst[q] = src[q];
+    }
+    __syncthreads();
+    if (chunk >= chunks) return;
+    if (wave == SPLIT_NCW) {
+        // ---- the store wavefront: drain the producers' rings row by row
+        const int rows = i1 - i0;
+        int c[SPLIT_NCW];
+        unsigned wmask = 0;
+        int left = 0;
+#pragma unroll
+        for (int w = 0; w < SPLIT_NCW; w++) {
+            c[w] = 0;
+            const int strip = strip0 + w, j = strip * 62 + lane;
+            const bool live = strip < strips;
+            if (live) left += rows;
+            if (live && lane >= 1 && lane <= 62 && j >= 1 && j < m - 1) wmask |= 1u << w;
+        }
+        while (left > 0) {
+            bool progress = false;
+#pragma unroll
+            for (int w = 0; w < SPLIT_NCW; w++) {
+                if (strip0 + w >= strips) continue;
+                const int p = __atomic_load_n(&L.ring[w].prod, __ATOMIC_RELAXED);
+                if (c[w] >= p) continue;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                while (c[w] < p) {
+                    const int slot = c[w] & (SR_ROWS - 1);
+                    const double mv = L.ring[w].mag[slot][lane], dv = L.ring[w].dir[slot][lane];
+                    const uint8_t fv = L.ring[w].flat[slot][lane];
+                    if ((wmask >> w) & 1u) {
+                        const size_t cc = (size_t)(i0 + c[w]) * m + ((strip0 + w) * 62 + lane);
+                        mag[cc] = mv; dir[cc] = dv; flat0[cc] = fv;
+                    }
+                    c[w]++; left--;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __atomic_store_n(&L.ring[w].cons, c[w], __ATOMIC_RELAXED);
+                progress = true;
+            }
+            if (!progress) __builtin_amdgcn_s_sleep(2);
+        }
+        return;
+    }
+    const int strip = strip0 + wave;
+    if (strip >= strips) return;
+    const int j = strip * 62 + lane;
+    MarchCtx cx;
+    cx.ring = &L.ring[wave];
+    cx.col = elev + ((j < m) ? j : m - 1); cx.rowtab = rowtab; cx.rtv = L.rt; cx.r0 = i0 - 1;
+    cx.atan_16 = L.atan16; cx.mag = mag; cx.dir = dir; cx.flat0 = flat0;
+    cx.q = &L.q[wave]; cx.tab = L.tab;
+    cx.q->one[1 + lane] = 1.0; cx.q->zero[1 + lane] = 0.0;
+    cx.n = n; cx.m = m; cx.j = j; cx.i0 = i0; cx.exact_only = exact_only;
+    cx.writes = lane >= 1 && lane <= 62 && j >= 1 && j < m - 1;
+    BandCarry c;
+    RowV ts = rowv_load(cx.rtv, 0), tu;
+    c.z0 = cx.col[(size_t)(i0 - 1) * m];
+    c.ex_top = exact_only || LM(!(fabs(c.z0) < 0x1p500)) != 0;
+    c.hs1 = div_row(zsub<F32>(c.z0, lane_next(c.z0)), ts.dX, ts.rdX);
+    c.hsL1 = lane_prev(c.hs1);
+    c.Phs1 = LM(c.hs1 > 0); c.Nhs1 = LM(c.hs1 < 0);
+    cx.q->a[0][1][1 + lane] = c.hs1;
+    c.Mn = -1.0; c.thAn = 0.0; c.thBn = 0.0;
+    c.Nk0 = 0; c.Nk1 = 0; c.NdA = 0; c.NdB = 0; c.Nint = 0;
+    double zP = cx.col[(size_t)i0 * m], zQ = 0.0;
+    int b = i0 - 1;
+    march_band<F32, 0, true, true>(cx, c, ts, tu, b, zP, zQ);
+    for (b++; b + 1 < i1; b += 2) {
+        march_band<F32, 1, false, true>(cx, c, tu, ts, b, zQ, zP);
+        march_band<F32, 0, false, true>(cx, c, ts, tu, b + 1, zP, zQ);
+    }
+    if (b < i1) march_band<F32, 1, false, true>(cx, c, tu, ts, b, zQ, zP);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -836,6 +987,27 @@ static void launch_stencil(pydem_tile *t)
     const int chunks = (int)cdiv(t->n - 2, rows);
     const int waves = ((strips + 3) & ~3) * chunks;
     const int exact_only = t->stencil_exact_only;   // set with the row tables: a spacing outside [2^-500, 2^500] (or PYDEM_STENCIL_EXACT=1)
+    // PYDEM_STENCIL_SPLIT=1 (read per launch: the tests switch it): the producer / store split, a round-6 experiment that LOSES
+    // (3.58 against 2.77 ms back to back, profiles/r06_stencil_split_ab.txt) and is kept as such, never the default
+    int split = 0;
+    { const char *e = getenv("PYDEM_STENCIL_SPLIT"); split = e ? atoi(e) : 0; }
+    if (split) {
+        static int attr_ok = -1;
+        if (attr_ok < 0)
+            attr_ok = hipFuncSetAttribute((const void *)k_stencil_march_split<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SplitLds)) == hipSuccess &&
+                      hipFuncSetAttribute((const void *)k_stencil_march_split<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SplitLds)) == hipSuccess;
+        if (!attr_ok) { (void)hipGetLastError(); split = 0; }
+    }
+    if (split) {
+        const int groups = (strips + SPLIT_NCW - 1) / SPLIT_NCW;
+        if (t->elev_f32)
+            hipLaunchKernelGGL((k_stencil_march_split<true>), dim3((unsigned)(groups * chunks)), dim3(64 * (SPLIT_NCW + 1)), sizeof(SplitLds), t->stream, t->elev,
+                               (int)t->n, (int)t->m, t->rowtab, t->mag, t->dir, t->flat0, strips, chunks, rows, exact_only);
+        else
+            hipLaunchKernelGGL((k_stencil_march_split<false>), dim3((unsigned)(groups * chunks)), dim3(64 * (SPLIT_NCW + 1)), sizeof(SplitLds), t->stream, t->elev,
+                               (int)t->n, (int)t->m, t->rowtab, t->mag, t->dir, t->flat0, strips, chunks, rows, exact_only);
+        return;
+    }
     static int occ = -1;
     if (occ < 0) { const char *e = getenv("PYDEM_STENCIL_OCC"); occ = (e && atoi(e) == 4) ? 4 : 1; }
 #define MARCH(F32, OCC) hipLaunchKernelGGL((k_stencil_march<F32, OCC>), dim3((unsigned)cdiv(waves, 4)), dim3(256), 0, t->stream, t->elev, \

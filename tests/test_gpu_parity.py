@@ -256,6 +256,30 @@ def test_stencil_mask_path_equals_exact_path(dtype, monkeypatch):
     assert (outs[0][0] == -1).any() and (outs[0][0] > 0).any()
 
 
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_stencil_store_split_equals_default_kernel(dtype, monkeypatch):
+    """The producer / store split of the marching stencil (csrc/stencil.hip: k_stencil_march_split, PYDEM_STENCIL_SPLIT=1 -- a
+    round-6 experiment that is slower and not the default, profiles/r06_stencil_split_ab.txt) computes with the same band code and
+    must return the same bits as the default kernel: terraces, a plateau, a row-dependent spacing, a tile wider than eleven strips
+    and a ragged last strip / chunk."""
+    from pydem_amd import DEMProcessor
+    rng = np.random.default_rng(12)
+    n, m = 401, 1031
+    z = np.cumsum(np.cumsum(rng.normal(size=(n, m)), 0), 1) * 0.05
+    z[40:90, 100:200] = np.round(z[40:90, 100:200])
+    z[200:230, 300:360] = z[200, 300]
+    z = z.astype(dtype)
+    dX = np.linspace(25.0, 35.0, n - 1); dY = np.full(n - 1, 30.0)
+    outs = []
+    for split in ('0', '1'):
+        monkeypatch.setenv('PYDEM_STENCIL_SPLIT', split)
+        dp = DEMProcessor(elev=z.copy(), dX=dX, dY=dY, fill_flats=False, drain_pits_path=False)
+        mag, direction = dp.calc_slopes_directions()
+        outs.append((np.array(mag), np.array(direction), np.array(dp.flats)))
+    for k, what in enumerate(('mag', 'direction', 'flats')):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), what
+
+
 def test_config1_cone256_device_vs_reference_pinned_oracle():
     """BASELINE.json config 1 on the device: the reference's 256 x 256 cone with default options (conditioning on).  The
     oracle pipeline of tests/test_oracle_golden.py::test_config1_cone256_matches_reference_checksums is bit-identical to
