@@ -4199,6 +4199,7 @@ static int cond_build_device(pydem_tile *t, int *status)
     const double t_swept = host_now_ms();
     const int32_t ne_all = h[16], levels = h[CBC_LEVELS], n_slow = h[CBC_SLOW];
     if (h[CBC_FAIL] & 1) return 0;                              // (*status == -1: the host build takes over)
+    { const char *e = getenv("PYDEM_CB_FORCE_FALLBACK"); if (e && atoi(e) > 0) return 0; }      // (tests: the hand-over to the host build after a finished sweep)
     if (h[CBC_PROC] != nd) { *status = 0; return 0; }           // a cycle among the records: not a DAG, plain cascade
     if (ne_all > INT32_MAX / 2) { *status = 0; return 0; }
     // ---- phase 3: edges, slots, nodes -- straight into the round's arrays (one allocation: nodes | edges | slots | two queues |

@@ -375,12 +375,15 @@ def test_device_operator_build_matches_host_build(name, tmp_path, monkeypatch):
     from test_process_manager_cpu import run_pm
     g = load_golden(name)
     runs = {}
-    for how in ('device', 'check', 'host'):
-        monkeypatch.setenv('PYDEM_COND_BUILD', how)
+    for how in ('device', 'check', 'host', 'fallback'):
+        # ('fallback': the device build gives up after its sweep -- as it would on a merge larger than its staging area or a pool
+        # region that overflows -- and the host build takes the tile over)
+        monkeypatch.setenv('PYDEM_COND_BUILD', 'device' if how == 'fallback' else how)
+        monkeypatch.setenv('PYDEM_CB_FORCE_FALLBACK', '1' if how == 'fallback' else '0')
         runs[how] = run_pm(g, str(tmp_path / how), n_workers=8)[0]
     d = runs['device']
     assert d.edge_queued_batches > 0
-    for how in ('check', 'host'):
+    for how in ('check', 'host', 'fallback'):
         p = runs[how]
         assert (p.edge_waves, p.edge_rounds, p.edge_tiebreaks) == (d.edge_waves, d.edge_rounds, d.edge_tiebreaks), how
         for i in range(d.n_inputs):
