@@ -9,6 +9,7 @@
 #include "internal.h"
 #include <rccl/rccl.h>
 #include <string.h>
+#include <time.h>
 #include <algorithm>
 #include <vector>
 
@@ -29,6 +30,34 @@ struct pydem_comm {
             return -6;                                                                             \
         }                                                                                          \
     } while (0)
+
+// Wait for stream s, but not for ever when a collective may be in it: after PYDEM_EDGE_TIMEOUT seconds (default 300, 0 = wait for
+// ever) the call fails with a message that names what it waited for and aborts the communicator -- a rank that never arrived
+// (or ranks whose call sequences differ) would otherwise leave the others in ncclAllReduce without a word.
+static int collective_wait(hipStream_t s, pydem_comm *c, const char *what)
+{
+    static double limit_s = -1.0;
+    if (limit_s < 0.0) { const char *e = getenv("PYDEM_EDGE_TIMEOUT"); limit_s = e ? atof(e) : 300.0; if (limit_s < 0.0) limit_s = 0.0; }
+    if (limit_s == 0.0 || !c) { HIP_TRY(hipStreamSynchronize(s)); return 0; }
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) { pydem_set_error("%s: %s", what, hipGetErrorString(e)); return -1; }
+        if ((++spins & 1023u) == 0) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            const double dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+            if (dt > limit_s) {
+                pydem_set_error("%s: the collective did not come back within %.0f s (PYDEM_EDGE_TIMEOUT) on rank %d of %d -- a rank left the job or the ranks "
+                                "issue different collectives; the RCCL communicator is aborted", what, limit_s, c->rank, c->world);
+                if (c->comm) { (void)ncclCommAbort(c->comm); c->comm = nullptr; }
+                return -7;
+            }
+        }
+    }
+}
 
 namespace {
 
@@ -158,9 +187,10 @@ int pydem_comm_allreduce(pydem_comm *c, int64_t n_doubles, int op, double *host_
 {
     HIP_TRY(hipSetDevice(c->device));
     if ((size_t)n_doubles > c->cap) { pydem_set_error("pydem_comm_allreduce: staging buffer too small"); return -2; }
+    if (!c->comm) { pydem_set_error("pydem_comm_allreduce: the communicator was aborted"); return -6; }
     NCCL_TRY(ncclAllReduce(c->buf, c->buf, (size_t)n_doubles, ncclDouble, op == 1 ? ncclMax : ncclSum, c->comm, c->stream));   // also for world == 1
     if (host_out) HIP_TRY(hipMemcpyAsync(host_out, c->buf, (size_t)n_doubles * 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    PYDEM_TRY(collective_wait(c->stream, c, "pydem_comm_allreduce"));
     return 0;
 }
 
@@ -229,6 +259,7 @@ struct pydem_board {
     hipGraphExec_t wave_exec[2] = {nullptr, nullptr};   // one wave, captured: before / after the collective (one graph without one)
     unsigned long long wave_ok = 0; bool wave_comm = false; hipStream_t wave_stream = nullptr;   // what the graphs were captured for
     bool graph_failed = false, tables_valid = false;
+    pydem_comm *last_comm = nullptr;                     // communicator of the last refresh (the evaluation that follows waits for its collective: with the watchdog)
     bool prepared = false; unsigned long long prepared_ok = 0; bool prepared_staged = false;   // pydem_board_prepare_waves passed for this set of tiles
     std::vector<int> q_mine;                             // this rank's tiles of the prepared set
     int g_eval = 1;
@@ -682,6 +713,8 @@ int pydem_board_refresh(pydem_board *b, pydem_comm *c, int n_wave, const int *wa
     pydem_board_segs S;
     int64_t total = 0;
     PYDEM_TRY(board_stage(b, n_wave, wave_tiles, c != nullptr, S, total));
+    b->last_comm = c;
+    if (c && !c->comm) { pydem_set_error("pydem_board_refresh: the communicator was aborted"); return -6; }
     if (c) NCCL_TRY(ncclAllReduce(b->wb, b->wb, (size_t)total, ncclDouble, ncclSum, c->comm, b->stream));   // also for world == 1
     hipLaunchKernelGGL(k_board_scatter, dim3(16, n_wave), dim3(256), 0, b->stream, b->wb, b->mb, S);
     HIP_TRY(hipGetLastError());
@@ -752,7 +785,7 @@ int pydem_board_eval(pydem_board *b, int count, const int *tiles, const int *ful
     }
     HIP_TRY(hipMemcpyAsync(b->h_scal, b->scal, (size_t)b->n_tiles * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    PYDEM_TRY(collective_wait(b->stream, b->last_comm, "pydem_board_eval (behind pydem_board_refresh)"));
     memcpy(out, b->h_scal, (size_t)b->n_tiles * 8 * sizeof(unsigned long long));
     return 0;
 }
@@ -914,6 +947,7 @@ int pydem_board_run_waves_ex(pydem_board *b, pydem_comm *c, int k_waves, unsigne
     HIP_TRY(hipSetDevice(b->device));
     if (k_waves < 1 || k_waves > SCH_ROUND - SCH_LOG) { pydem_set_error("pydem_board_run_waves: 1..64 waves per batch"); return -2; }
     if (c && exchange) { pydem_set_error("pydem_board_run_waves: a communicator or an exchange function, not both"); return -2; }
+    if (c && !c->comm) { pydem_set_error("pydem_board_run_waves: the communicator was aborted"); return -6; }
     const bool staged = c != nullptr || exchange != nullptr;
     const unsigned long long ok = state[SCH_OK];
     // (callers that did not prepare -- a single process -- get it here; with several ranks the verdict must have been agreed on)
