@@ -80,6 +80,7 @@ void plane_cache_flush(int device)
 
 void *plane_take(int device, size_t bytes)
 {
+    std::vector<void *> victims;                     // (PYDEM_PLANE_EVICT_ON_MISS only; freed once the lock is released)
     if (bytes >= PLANE_MIN && plane_cache_limit()) {
         PlaneCache *c = plane_cache(device);
         std::lock_guard<std::mutex> g(c->mu);
@@ -94,8 +95,9 @@ void *plane_take(int device, size_t bytes)
         // last, i.e. what the tile being built asks for next; dead sizes leave when plane_give needs their room, and a failing
         // hipMalloc empties the lists.  PYDEM_PLANE_EVICT_ON_MISS=1: the round-5 behaviour, for A/B runs)
         static const bool on_miss = [] { const char *e = getenv("PYDEM_PLANE_EVICT_ON_MISS"); return e && atoi(e) > 0; }();
-        if (on_miss) { std::vector<void *> victims; plane_cache_evict(c, bytes, victims); for (void *v : victims) (void)hipFree(v); }
+        if (on_miss) plane_cache_evict(c, bytes, victims);
     }
+    for (void *v : victims) (void)hipFree(v);
     void *q = nullptr;
     hipError_t e = hipMalloc(&q, bytes);
     {   // PYDEM_PLANE_DEBUG=1: one line per block that is mapped anew (a steady state maps nothing)
