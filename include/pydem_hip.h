@@ -86,6 +86,10 @@ typedef struct pydem_timings {
     int64_t n_pits_undrained;     /* the reference's "pits had no place to drain" count */
     int64_t n_unresolved;         /* cells still unfinished after the re-seed loop (circular drainage, dem_processing.py:951-964) */
     int64_t sweep_tile_passes;    /* LDS tile-local passes run before the queue rounds */
+    int64_t n_pits;               /* pit candidates of the last pit search (all of them enter the lane pass)              */
+    int64_t n_pits_row;           /* ... that entered the row pass (16 lanes per pit; 0: pass not run, PYDEM_PITS_ROW=0)  */
+    int64_t n_pits_wave;          /* ... that entered the wavefront pass (128 x 128 window)                               */
+    int64_t n_pits_big;           /* ... that entered the 256 x 256 wavefront pass or the workgroup pass behind it        */
 } pydem_timings;
 
 const char *pydem_hip_last_error(void);

@@ -37,7 +37,8 @@ class Timings(C.Structure):
                 ('flats_ms', C.c_double), ('graph_ms', C.c_double), ('pits_ms', C.c_double),
                 ('sweep_ms', C.c_double), ('twi_ms', C.c_double), ('sweep_rounds', C.c_int64),
                 ('sweep_kernel_launches', C.c_int64), ('n_flats', C.c_int64), ('n_pit_edges', C.c_int64),
-                ('n_pits_undrained', C.c_int64), ('n_unresolved', C.c_int64), ('sweep_tile_passes', C.c_int64)]
+                ('n_pits_undrained', C.c_int64), ('n_unresolved', C.c_int64), ('sweep_tile_passes', C.c_int64),
+                ('n_pits', C.c_int64), ('n_pits_row', C.c_int64), ('n_pits_wave', C.c_int64), ('n_pits_big', C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

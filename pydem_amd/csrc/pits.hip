@@ -104,6 +104,11 @@ struct PitParams {
     uint32_t *lane_state;       // 12 words per handed-over pit (same index as lane_overflow): iterations done, epit_border, the REGION as a
                                 // 16 x 16 bitmap -- the wavefront version starts from the lane version's region instead of from the pit
     int32_t *work_next;         // next unclaimed entry of the pit list (lane version)
+    int32_t *row_overflow;      // entries of the hand-over list the row version (pits_row.inl) passes on to the wavefront version
+    int32_t *row_overflow_count;
+    int rw_target;              // row version: entries the head is refilled with
+    int2 *row_rec;              // row version: per entry of the hand-over list (first output slot, candidate drains) for k_pits_row_finish
+    const int32_t *wave_index;  // wavefront version: entry q of its input is entry wave_index[q] of the hand-over list (nullptr: q itself)
     int32_t *dbg;               // PYDEM_PITS_DEBUG=2: per-pit {rounds, last border size, hand-over reason, drains}
     unsigned long long *prof;   // PYDEM_PITS_DEBUG=3: cycles per phase of the lane pass
 };
@@ -744,6 +749,8 @@ __device__ void solve_pit_wave(const PitParams &P, int32_t pit, int lane, WaveLd
     finish_pit_wave(P, pit, ipit, jpit, epit, ndrain, L.u.fin.dl, L.u.fin.dxy, L.u.fin.sv, chunk_base, chunk_left, lane);
 }
 
+#include "pits_row.inl"
+
 // ---------------------------------------------------------------------------------------------
 // Lane version (first pass over ALL pits).  The wavefront version spends ~700 VALU issues per round
 // with 64 lanes serving a border of ~10-20 cells, so it is instruction-bound with most lanes idle.
@@ -1127,18 +1134,13 @@ __global__ __launch_bounds__(LN_T) void k_pits_lane(PitParams P, const int32_t *
 constexpr int W_LARGE = 640, MAXD_LARGE = 2048;
 
 // wave-per-pit: 4 pits per 256-thread block
-__global__ __launch_bounds__(256, PYDEM_WV_OCC) void k_pits_wave(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits)
+template <int CAP, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_pits_wave(PitParams P, const int32_t *__restrict__ pits, const int32_t *npits)
 {
-    __shared__ WaveLds<128, PYDEM_WV_CAP, uint16_t> s_l[4];
+    __shared__ WaveLds<128, CAP, uint16_t> s_l[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int32_t np = *npits;
     int32_t chunk_base = 0, chunk_left = 0;
-#ifdef PYDEM_WV_STATIC
-    for (int32_t q = blockIdx.x * 4 + wave; q < np; q += gridDim.x * 4) {
-        solve_pit_wave(P, pits[q], lane, s_l[wave], chunk_base, chunk_left, P.lane_state ? P.lane_state + (size_t)q * 12 : nullptr);
-        wave_sync();
-    }
-#else
     // persistent wavefronts take the next pit from a counter: a pit needs 5 .. 300 rounds, and with a fixed stride the four
     // wavefronts of a workgroup (one LDS allocation) wait for the one that drew the long pits
     for (;;) {
@@ -1146,10 +1148,10 @@ __global__ __launch_bounds__(256, PYDEM_WV_OCC) void k_pits_wave(PitParams P, co
         if (lane == 0) q = atomicAdd(P.work_next, 1);
         q = __shfl(q, 0);
         if (q >= np) break;
+        if (P.wave_index) q = P.wave_index[q];
         solve_pit_wave(P, pits[q], lane, s_l[wave], chunk_base, chunk_left, P.lane_state ? P.lane_state + (size_t)q * 12 : nullptr);
         wave_sync();
     }
-#endif
 }
 
 // the same with a 256x256 window and room for 2048 border cells: one pit per 64-thread workgroup
@@ -1382,6 +1384,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
     HIP_TRY(hipStreamSynchronize(t->stream));
     const int32_t npits = t->h_counters[0];
     t->tm.n_pit_edges = 0; t->tm.n_pits_undrained = 0;
+    t->tm.n_pits = npits; t->tm.n_pits_row = 0; t->tm.n_pits_wave = 0; t->tm.n_pits_big = 0;
     t->pits.n_edges = 0;
     if (npits == 0) { t->tm.pits_ms = 0; return 0; }
 
@@ -1398,7 +1401,7 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         PitParams P;
         P.dbg = nullptr; P.prof = nullptr;
         const char *dbg_env = getenv("PYDEM_PITS_DEBUG");
-        if (dbg_env && atoi(dbg_env) == 3) { HIP_TRY(hipMalloc(&P.prof, 64)); HIP_TRY(hipMemsetAsync(P.prof, 0, 64, t->stream)); }
+        if (dbg_env && atoi(dbg_env) == 3) { HIP_TRY(hipMalloc(&P.prof, 128)); HIP_TRY(hipMemsetAsync(P.prof, 0, 128, t->stream)); }
         if (dbg_env && atoi(dbg_env) >= 2) HIP_TRY(hipMalloc(&P.dbg, (size_t)npits * 16));
         HIP_TRY(hipMemsetAsync(t->pits.raw_src, 0xFF, (size_t)t->pits.raw_cap * 4, t->stream));   // -1 = unused slot
         P.elev = t->elev; P.pitmask = t->flat0; P.dX = t->dX; P.dY = t->dY; P.mag = t->mag; P.flats = t->flats;
@@ -1429,31 +1432,70 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
             HIP_TRY(hipMemcpy(h, P.prof, 64, hipMemcpyDeviceToHost));
             fprintf(stderr, "pits/lane: %llu loop trips over all wavefronts, %.1f busy lanes per trip; cycles: refill %llu, growth %llu, drain selection %llu, output %llu\n",
                     h[4], h[4] ? (double)h[3] / (double)h[4] : 0.0, h[0], h[5], h[1], h[2]);
-            (void)hipFree(P.prof); P.prof = nullptr;
         }
-        if (n_lane_over > 0) {
-#ifdef PYDEM_WV_STATIC
-            const int gw = (int)(cdiv(n_lane_over, 4) < 16384 ? cdiv(n_lane_over, 4) : 16384);
-#else
-            const int gw = (int)(cdiv(n_lane_over, 4) < 256 * PYDEM_WV_OCC ? cdiv(n_lane_over, 4) : 256 * PYDEM_WV_OCC);     // resident: every CU full
+        // pass 1b: a ROW of 16 lanes per handed-over pit (64x64 window, bucketed border: pits_row.inl) + the arithmetic of its drains a
+        // lane per pit; pass 2: a wavefront per pit that outgrew the row (index list; 128x128 window, 512 border cells: only a few
+        // thousand pits come this far, room matters more than occupancy); pass 3: 256x256 / 2048 cells.  The three passes read their
+        // counts on the device: launched back to back, ONE host synchronisation behind them.
+        int32_t n_row_over = -1, n_wave_over = 0, n_over = 0;
+        P.wave_index = nullptr; P.row_overflow = nullptr; P.row_overflow_count = nullptr; P.row_rec = nullptr; P.rw_target = PYDEM_RW_TARGET;
+        const char *row_env = getenv("PYDEM_PITS_ROW");                        // (read per call: the tests switch it)
+        const int use_row = row_env ? atoi(row_env) : 1;
+        if (use_row && n_lane_over > 0 && 8 * (int64_t)n_lane_over + 64 <= t->NN) {
+            HIP_TRY(hipMemsetAsync(cnt + 9, 0, 4 * sizeof(int32_t), t->stream));                           // [9] pass 3's hand-over count, [10] work counter, [12] pass 1b's
+            P.row_overflow = t->labels; P.row_overflow_count = cnt + 12;
+            P.row_rec = (int2 *)(t->labels + (((size_t)t->NN / 2) & ~(size_t)63));                         // (the lists of passes 1b / 2 stay below NN / 4)
+            const char *tgt_env = getenv("PYDEM_RW_TARGET");
+            P.rw_target = tgt_env && atoi(tgt_env) > 0 ? atoi(tgt_env) : PYDEM_RW_TARGET;
+            // (16 + 192 border cells, 4 wavefronts per SIMD, one wavefront per workgroup: same-box 16384^2, row + wavefront pass:
+            // 16 + 128 cells 4.1 + 2.2 ms, 16 + 160 4.5 + 1.0, 16 + 192 4.9 + 0.5; 128-thread workgroups 0.1 ms slower)
+            constexpr int per = RW_NT / 16, gr_cap = 256 * (RW_OCC * 256 / RW_NT);                         // resident: every CU full
+            const int gr = (int)(cdiv(n_lane_over, per) < gr_cap ? cdiv(n_lane_over, per) : gr_cap);
+            hipLaunchKernelGGL((k_pits_row<RW_CAP, RW_OCC, RW_NT>), dim3(gr), dim3(RW_NT), 0, t->stream, P, t->queue[0], cnt + 5);
+            hipLaunchKernelGGL(k_pits_row_finish, dim3((unsigned)(cdiv(n_lane_over, 256) < 2048 ? cdiv(n_lane_over, 256) : 2048)), dim3(256), 0,
+                               t->stream, P, t->queue[0], cnt + 5, P.row_rec);
+            if (P.prof) {
+                unsigned long long h[16];
+                HIP_TRY(hipMemcpy(h, P.prof, 128, hipMemcpyDeviceToHost));
+                fprintf(stderr, "pits/row: %llu loop trips over all wavefronts, %.2f busy / %.2f growing rows per trip, %llu refills; cycles: refill %llu, rounds %llu, drain selection %llu, output %llu\n",
+                        h[12], h[12] ? (double)h[13] / (double)h[12] : 0.0, h[12] ? (double)h[14] / (double)h[12] : 0.0, h[15], h[8], h[9], h[10], h[11]);
+            }
+            P.wave_index = t->labels;
+            P.overflow_list = t->labels + (((size_t)n_lane_over + 63) & ~(size_t)63);                      // (pass 2's own hand-over list behind the index list)
             HIP_TRY(hipMemsetAsync(cnt + 10, 0, sizeof(int32_t), t->stream));
-#endif
-            hipLaunchKernelGGL(k_pits_wave, dim3(gw), dim3(256), 0, t->stream, P, t->queue[0], cnt + 5);
-            HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipStreamSynchronize(t->stream));
-        }
-        const int32_t n_wave_over = t->h_counters[3];
-        int32_t n_over = 0;
-        if (n_wave_over > 0) {
-            // pass 3: the wavefront solver with a 256x256 window / 2048 border cells for what outgrew pass 2
-            HIP_TRY(hipMemsetAsync(cnt + 9, 0, sizeof(int32_t), t->stream));
-            P.overflow_list = t->queue[0]; P.overflow_count = cnt + 9;
-            hipLaunchKernelGGL(k_pits_wave_big, dim3(n_wave_over < 4096 ? n_wave_over : 4096), dim3(64), 0, t->stream, P, t->labels, cnt + 3);
+            const int gw = (int)(cdiv(n_lane_over, 4) < 256 * 4 ? cdiv(n_lane_over, 4) : 256 * 4);
+            hipLaunchKernelGGL((k_pits_wave<512, 4>), dim3(gw), dim3(256), 0, t->stream, P, t->queue[0], cnt + 12);
+            const int32_t *big_in = P.overflow_list;
+            P.overflow_list = t->queue[0]; P.overflow_count = cnt + 9;                                     // (the hand-over list of pass 1 is dead by then)
+            P.wave_index = nullptr;
+            hipLaunchKernelGGL(k_pits_wave_big, dim3(256), dim3(64), 0, t->stream, P, big_in, cnt + 3);
             HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
-            n_over = t->h_counters[9];
+            n_row_over = t->h_counters[12]; n_wave_over = t->h_counters[3]; n_over = t->h_counters[9];
+        } else {
+            if (n_lane_over > 0) {
+                const int gw = (int)(cdiv(n_lane_over, 4) < 256 * PYDEM_WV_OCC ? cdiv(n_lane_over, 4) : 256 * PYDEM_WV_OCC);     // resident: every CU full
+                HIP_TRY(hipMemsetAsync(cnt + 10, 0, sizeof(int32_t), t->stream));
+                hipLaunchKernelGGL((k_pits_wave<PYDEM_WV_CAP, PYDEM_WV_OCC>), dim3(gw), dim3(256), 0, t->stream, P, t->queue[0], cnt + 5);
+                HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipStreamSynchronize(t->stream));
+            }
+            n_wave_over = t->h_counters[3];
+            if (n_wave_over > 0) {
+                // pass 3: the wavefront solver with a 256x256 window / 2048 border cells for what outgrew pass 2
+                HIP_TRY(hipMemsetAsync(cnt + 9, 0, sizeof(int32_t), t->stream));
+                P.overflow_list = t->queue[0]; P.overflow_count = cnt + 9;
+                hipLaunchKernelGGL(k_pits_wave_big, dim3(n_wave_over < 4096 ? n_wave_over : 4096), dim3(64), 0, t->stream, P, t->labels, cnt + 3);
+                HIP_TRY(hipMemcpyAsync(t->h_counters, cnt, 16 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
+                HIP_TRY(hipStreamSynchronize(t->stream));
+                n_over = t->h_counters[9];
+            }
         }
-        if (dbg_env) fprintf(stderr, "pits: %d candidates, %d left the 16x16 lane window, %d left the 128x128 / 256-cell pass, %d left the 256x256 / 2048-cell pass, %d edge slots, %d undrained\n", npits, n_lane_over, n_wave_over, n_over, t->h_counters[1], t->h_counters[2]);
+        if (P.prof) { (void)hipFree(P.prof); P.prof = nullptr; }
+        t->tm.n_pits_row = n_row_over >= 0 ? n_lane_over : 0;
+        t->tm.n_pits_wave = n_row_over >= 0 ? n_row_over : n_lane_over;
+        t->tm.n_pits_big = n_wave_over;
+        if (dbg_env) fprintf(stderr, "pits: %d candidates, %d left the 16x16 lane window, %d left the 64x64 row pass (-1: not run), %d left the 128x128 wavefront pass, %d left the 256x256 / 2048-cell pass, %d edge slots, %d undrained\n", npits, n_lane_over, n_row_over, n_wave_over, n_over, t->h_counters[1], t->h_counters[2]);
         if (P.dbg) {
             const int nrec = t->h_counters[7];
             std::vector<int32_t> rec((size_t)nrec * 4);

@@ -155,6 +155,64 @@ def test_hip_pits_with_nodata_vs_oracle(seed):
     assert np.array_equal(dp.edge_todo, o.edge_todo) and np.array_equal(dp.edge_done, o.edge_done)
 
 
+def _edges_and_patches(z, env):
+    """pit edges (sorted by pit, drain), patched mag / flats and the tier counts of one search under `env`"""
+    import os
+    import warnings
+    from pydem_amd import DEMProcessor
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            dp = DEMProcessor(elev=z, dX=30.0, dY=30.0, fill_flats=False, drain_pits_path=False, drain_pits=True)
+            dp.calc_slopes_directions()
+            dp.calc_uca()
+        src, dst, w = dp._tile.pit_edges()
+        order = np.lexsort((dst, src))
+        tm = dp.timings
+        return (src[order], dst[order], w[order], dp.mag.copy(), dp.flats.copy(), dp.uca.copy(),
+                {k: tm[k] for k in ('n_pits', 'n_pits_row', 'n_pits_wave', 'n_pits_big', 'n_pits_undrained', 'n_pit_edges')})
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize('kind', ['fractal', 'plateaus', 'nodata'])
+def test_row_pass_equals_the_wavefront_pass(kind):
+    """The row pass (16 lanes per pit, bucketed border: csrc/pits_row.inl) against the search without it, and with refill targets
+    that force its corner paths: 1 (a refill nearly every round), 16 (the head fills up: entries are turned away and the
+    threshold drops), 200 (everything moves to the head at once, more than 16 ties hand the pit on).  Same edges, weights
+    bit for bit, same patched mag / flats, same uca; and the pass did run."""
+    from pydem_amd import synth, conditioning
+    import warnings
+    if kind == 'fractal':
+        z = synth.fractal(1024, 1536, seed=41, top_shift=7, n_octaves=7)
+    elif kind == 'plateaus':
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            z = conditioning.fill_flats(synth.srtm_int16(768, 768, seed=5))
+    else:
+        z = synth.fractal(700, 900, seed=43, top_shift=7, n_octaves=7)
+        rng = np.random.default_rng(43)
+        z[200:260, 300:420] = np.nan
+        for _ in range(200):
+            z[rng.integers(0, 700), rng.integers(0, 900)] = np.nan
+    base = _edges_and_patches(z, {'PYDEM_PITS_ROW': '0'})
+    assert base[6]['n_pits_row'] == 0 and base[6]['n_pits_wave'] > 0, base[6]
+    for env in ({'PYDEM_PITS_ROW': '1'}, {'PYDEM_PITS_ROW': '1', 'PYDEM_RW_TARGET': '1'},
+                {'PYDEM_PITS_ROW': '1', 'PYDEM_RW_TARGET': '16'}, {'PYDEM_PITS_ROW': '1', 'PYDEM_RW_TARGET': '200'}):
+        got = _edges_and_patches(z, env)
+        assert got[6]['n_pits_row'] == base[6]['n_pits_wave'] and got[6]['n_pits_wave'] < got[6]['n_pits_row'], (env, got[6])
+        for k in ('n_pits', 'n_pits_undrained', 'n_pit_edges'):
+            assert got[6][k] == base[6][k], (env, k, got[6], base[6])
+        for a, b, what in zip(got[:6], base[:6], ('pit', 'drain', 'weight', 'mag', 'flats', 'uca')):
+            assert np.array_equal(a, b, equal_nan=True), (env, what)
+
+
 def test_repeated_steps_do_not_leak_device_memory():
     """A tile that is recomputed step after step (bench.py, a directory run that revisits its tiles) must reach a steady
     device footprint: every buffer of the terrain path is persistent or freed.  (Round 2 found a per-call allocation of
