@@ -772,11 +772,14 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     std::vector<int32_t> p_home, p_block, p_src, w_home, w_block, w_src, free_home((size_t)W), free_block;
     for (int h = 0; h < W; h++) free_home[(size_t)h] = W - 1 - h;
     std::vector<int32_t> pending, win, h_status((size_t)W), h_done((size_t)W), big;
+    // (the lists of a round are rebuilt by push_back: without the room reserved the first rounds -- 341 k pits on the SRTM-like
+    // tile -- spend milliseconds growing eight vectors)
+    for (std::vector<int32_t> *v : {&pending, &win, &p_home, &p_block, &p_src, &w_home, &w_block, &w_src}) v->reserve((size_t)W);
     std::vector<uint8_t> tier((size_t)npits, 0);            // what earlier rounds learned: 1 = the pit leaves the small window, 2 = the medium one too
     std::vector<uint8_t> proven((size_t)npits, 0);          // a medium-window simulation of the pit has completed
     int64_t next = 0;                 // first pit of the order that has not entered a window yet
     int64_t rounds = 0, big_runs = 0, small_runs = 0;
-    double ms_small = 0, ms_big = 0, ms_commit = 0;
+    double ms_small = 0, ms_big = 0, ms_commit = 0, ms_prep = 0, ms_post = 0;
     const bool prof = getenv("PYDEM_PATHS_DEBUG") != nullptr;
     auto now_ms = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     bool fallback = false;
@@ -792,6 +795,7 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     HIP_TRY(hipStreamSynchronize(t->stream));
     const double ms_setup = now_ms() - (ts0.tv_sec * 1e3 + ts0.tv_nsec * 1e-6);
     while (!pending.empty() || next < npits) {
+        const double t_p = now_ms();
         while ((int)pending.size() < W && next < npits) {
             pending.push_back((int32_t)next++);
             p_home.push_back(free_home.back()); free_home.pop_back(); p_block.push_back(-1); p_src.push_back(-1);
@@ -816,14 +820,18 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
             if (p_block[s2] >= 0) { free_block.push_back(p_block[s2]); p_block[s2] = -1; }
         memcpy(pin_window, pending.data(), (size_t)nw * 4);
         memcpy(pin_home, p_home.data(), (size_t)nw * 4);
-        for (int s2 = 0; s2 < nw; s2++) pin_tier[s2] = tier[(size_t)pending[(size_t)s2]];
-        for (int s2 = 0; s2 < nw; s2++) pin_src[s2] = keep_env ? p_src[(size_t)s2] : -1;
+        {
+            const int32_t *pd = pending.data(), *ps = p_src.data();
+            const uint8_t *tr = tier.data();
+            for (int s2 = 0; s2 < nw; s2++) { pin_tier[s2] = tr[pd[s2]]; pin_src[s2] = keep_env ? ps[s2] : -1; }
+        }
         HIP_TRY(hipMemcpyAsync(b_window.p, pin_window, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemcpyAsync(b_tier.p, pin_tier, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemcpyAsync(b_home.p, pin_home, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemcpyAsync(b_src.p, pin_src, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemsetAsync(b_done.p, 0, (size_t)nw * 4, t->stream));
         const double t_a = now_ms();
+        ms_prep += t_a - t_p;
         small_runs += nw;
         hipLaunchKernelGGL(k_paths_slots, dim3(gridp(nw, 256)), dim3(256), 0, t->stream, A, (int32_t *)b_F.p, (int32_t *)b_C.p, (double *)b_CV.p, FCAP, CCAP);
         // the medium / large-window simulations of a round: entry q of `big` owns block q of the scratch arrays.  Those of
@@ -964,7 +972,8 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         memcpy(h_done.data(), pin_done, (size_t)nw * 4);
         memcpy(h_status.data(), pin_status, (size_t)nw * 4);
         rounds++;
-        ms_commit += now_ms() - t_c;
+        const double t_d = now_ms();
+        ms_commit += t_d - t_c;
         if (prof) {
             int ncommit = 0;
             for (int s2 = 0; s2 < nw; s2++) ncommit += h_done[(size_t)s2] ? 1 : 0;
@@ -990,19 +999,26 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
                 else stuck = true;                               // does not even fit the large window
             }
         if (stuck) { fallback = true; break; }
-        win.clear(); w_home.clear(); w_block.clear(); w_src.clear();
-        for (int s = 0; s < nw; s++) {
-            if (!h_done[(size_t)s]) { win.push_back(pending[(size_t)s]); w_home.push_back(p_home[(size_t)s]); w_block.push_back(p_block[(size_t)s]); w_src.push_back(s); }
-            else {
-                free_home.push_back(p_home[(size_t)s]);
-                if (p_block[(size_t)s] >= 0) free_block.push_back(p_block[(size_t)s]);
+        win.resize(pending.size()); w_home.resize(pending.size()); w_block.resize(pending.size()); w_src.resize(pending.size());
+        size_t nk = 0;                                         // pits that stay
+        {
+            const int32_t *hd = h_done.data(), *pd = pending.data(), *ph = p_home.data(), *pb = p_block.data();
+            int32_t *ow = win.data(), *oh = w_home.data(), *ob = w_block.data(), *os = w_src.data();
+            for (int s = 0; s < nw; s++) {
+                if (!hd[s]) { ow[nk] = pd[s]; oh[nk] = ph[s]; ob[nk] = pb[s]; os[nk] = s; nk++; }
+                else {
+                    free_home.push_back(ph[s]);
+                    if (pb[s] >= 0) free_block.push_back(pb[s]);
+                }
             }
         }
+        win.resize(nk); w_home.resize(nk); w_block.resize(nk); w_src.resize(nk);
         if ((int)win.size() == nw && !escalated) { fallback = true; break; }          // (cannot happen: the first pit always commits)
         for (size_t s = (size_t)nw; s < pending.size(); s++) {                        // the part of the window that sat this round out
             win.push_back(pending[s]); w_home.push_back(p_home[s]); w_block.push_back(p_block[s]); w_src.push_back(-1);
         }
         pending.swap(win); p_home.swap(w_home); p_block.swap(w_block); p_src.swap(w_src);
+        ms_post += now_ms() - t_d;
     }
     if (rounds_out) *rounds_out = rounds;
 #ifdef PYDEM_PATHS_PROF
@@ -1017,8 +1033,8 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
 #endif
     if (getenv("PYDEM_PATHS_DEBUG"))
         fprintf(stderr, "pit drain paths: %lld pits, %lld rounds, %lld small-window, %lld medium-window and %lld large-window simulations; ms: small %.1f, medium + large %.1f, "
-                        "commit %.1f, buffers %.1f%s\n", (long long)npits, (long long)rounds, (long long)small_runs, (long long)mid_runs, (long long)big_runs, ms_small, ms_big, ms_commit,
-                ms_setup, fallback ? " -> host loop" : "");
+                        "commit %.1f, buffers %.1f, host before / after a round %.1f / %.1f, whole call %.1f%s\n", (long long)npits, (long long)rounds, (long long)small_runs, (long long)mid_runs, (long long)big_runs, ms_small, ms_big, ms_commit,
+                ms_setup, ms_prep, ms_post, now_ms() - (ts0.tv_sec * 1e3 + ts0.tv_nsec * 1e-6), fallback ? " -> host loop" : "");
     if (fallback) {
         HIP_TRY(hipMemcpyAsync(t->elev, b_backup.p, (size_t)t->NN * 8, hipMemcpyDeviceToDevice, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));

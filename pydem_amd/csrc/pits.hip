@@ -1439,8 +1439,13 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         // counts on the device: launched back to back, ONE host synchronisation behind them.
         int32_t n_row_over = -1, n_wave_over = 0, n_over = 0;
         P.wave_index = nullptr; P.row_overflow = nullptr; P.row_overflow_count = nullptr; P.row_rec = nullptr; P.rw_target = PYDEM_RW_TARGET;
-        const char *row_env = getenv("PYDEM_PITS_ROW");                        // (read per call: the tests switch it)
-        const int use_row = row_env ? atoi(row_env) : 1;
+        // PYDEM_PITS_ROW: 0 never, 2 whenever there is a pit for it, 1 (default) when the pits outnumber the wavefronts the
+        // chip holds: four pits per wavefront buy throughput, and a few thousand pits (plateau terrain: config 5 hands 5362 pits
+        // on, 5263 of which outgrow the row pass) all run at once either way -- the pass would only add its serial chain
+        // (same-box, config 5: pit search 9.8 ms without, 11.3 ms with it).  Read per call: the tests switch it.
+        const char *row_env = getenv("PYDEM_PITS_ROW");
+        const int row_mode = row_env ? atoi(row_env) : 1;
+        const bool use_row = row_mode == 2 || (row_mode == 1 && n_lane_over >= 4 * 256 * PYDEM_WV_OCC);
         if (use_row && n_lane_over > 0 && 8 * (int64_t)n_lane_over + 64 <= t->NN) {
             HIP_TRY(hipMemsetAsync(cnt + 9, 0, 4 * sizeof(int32_t), t->stream));                           // [9] pass 3's hand-over count, [10] work counter, [12] pass 1b's
             P.row_overflow = t->labels; P.row_overflow_count = cnt + 12;

@@ -75,6 +75,11 @@ def test_config3_full_path_against_oracle_checksums(size):
                                          drain_pits=True)
         dp.run_twi()
     check_fields(dp, SUMS[key], 900.0)
+    if size == 16384:
+        # the pit pairs above came through every pass of the search: the row pass (16 lanes per pit) ran by its default rule
+        # (pits beyond the lane pass outnumber the resident wavefronts) and left only a small part to the wavefront pass
+        tm = dp.timings
+        assert tm['n_pits_row'] > 100000 and 0 < tm['n_pits_wave'] < tm['n_pits_row'] // 20, tm
 
 
 @pytest.mark.parametrize('size', [1024, 8192])

@@ -186,7 +186,8 @@ def test_row_pass_equals_the_wavefront_pass(kind):
     """The row pass (16 lanes per pit, bucketed border: csrc/pits_row.inl) against the search without it, and with refill targets
     that force its corner paths: 1 (a refill nearly every round), 16 (the head fills up: entries are turned away and the
     threshold drops), 200 (everything moves to the head at once, more than 16 ties hand the pit on).  Same edges, weights
-    bit for bit, same patched mag / flats, same uca; and the pass did run."""
+    bit for bit, same patched mag / flats, same uca; and the pass did run (PYDEM_PITS_ROW=2: also for the few pits of a small
+    tile; by default it runs when the pits outnumber the resident wavefronts, as on the 16384^2 tiles of test_gpu_large_configs)."""
     from pydem_amd import synth, conditioning
     import warnings
     if kind == 'fractal':
@@ -203,8 +204,8 @@ def test_row_pass_equals_the_wavefront_pass(kind):
             z[rng.integers(0, 700), rng.integers(0, 900)] = np.nan
     base = _edges_and_patches(z, {'PYDEM_PITS_ROW': '0'})
     assert base[6]['n_pits_row'] == 0 and base[6]['n_pits_wave'] > 0, base[6]
-    for env in ({'PYDEM_PITS_ROW': '1'}, {'PYDEM_PITS_ROW': '1', 'PYDEM_RW_TARGET': '1'},
-                {'PYDEM_PITS_ROW': '1', 'PYDEM_RW_TARGET': '16'}, {'PYDEM_PITS_ROW': '1', 'PYDEM_RW_TARGET': '200'}):
+    for env in ({'PYDEM_PITS_ROW': '2'}, {'PYDEM_PITS_ROW': '2', 'PYDEM_RW_TARGET': '1'},
+                {'PYDEM_PITS_ROW': '2', 'PYDEM_RW_TARGET': '16'}, {'PYDEM_PITS_ROW': '2', 'PYDEM_RW_TARGET': '200'}):
         got = _edges_and_patches(z, env)
         assert got[6]['n_pits_row'] == base[6]['n_pits_wave'] and got[6]['n_pits_wave'] < got[6]['n_pits_row'], (env, got[6])
         for k in ('n_pits', 'n_pits_undrained', 'n_pit_edges'):

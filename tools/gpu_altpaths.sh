@@ -13,3 +13,5 @@ run edge_queue0 PYDEM_EDGE_QUEUE=0
 run edge_cond0 PYDEM_EDGE_COND=0
 run cb_chain0 PYDEM_CB_CHAIN=0
 run stencil_split PYDEM_STENCIL_SPLIT=1
+run pits_row_always PYDEM_PITS_ROW=2
+run pits_row_never PYDEM_PITS_ROW=0
