@@ -42,8 +42,17 @@
 namespace {
 
 #ifdef PYDEM_PATHS_PROF
-__device__ unsigned long long g_paths_prof[8];     // ticks of the large-window simulations: clear, min scan, fresh pass, emit, ring, footprint, path, iterations
-#define PPROF(i, expr) do { const long long t0_ = wall_clock64(); expr; if (WIN > 64 && lane == 0) atomicAdd(&g_paths_prof[i], (unsigned long long)(wall_clock64() - t0_)); } while (0)
+// profiling build (tools/gpu_c5prof.sh): 10 ns ticks of the phases of a simulation, summed per window class (0 small, 1 medium / large)
+// in 64 banks (the sums of a simulation leave in one go when it ends): 0 clear, 1 min scan, 2 fresh pass, 3 emit, 4 ring, 5 footprint,
+// 6 path (one lane), 7 iterations, 8 whole simulation, 9 reservations, 10 simulations, 11 kept checks (ticks), 12 kept checks (count),
+// 13 the longest simulation
+__device__ unsigned long long g_paths_prof[2][64][16];
+struct PProf {
+    unsigned long long v[16]; int cls, bank, lane;
+    __device__ PProf(int cls_, int bank_, int lane_) : cls(cls_), bank(bank_ & 63), lane(lane_) { for (int i = 0; i < 16; i++) v[i] = 0; }
+    __device__ ~PProf() { if (lane == 0) { for (int i = 0; i < 16; i++) if (v[i] && i != 13) atomicAdd(&g_paths_prof[cls][bank][i], v[i]); atomicMax(&g_paths_prof[cls][bank][13], v[8]); } }
+};
+#define PPROF(i, expr) do { const long long t0_ = wall_clock64(); expr; pp_.v[i] += (unsigned long long)(wall_clock64() - t0_); } while (0)
 #else
 #define PPROF(i, expr) do { expr; } while (0)
 #endif
@@ -154,6 +163,12 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
     const int pi = pit / m, pj = pit - pi * m;
     const int oi = pi - WIN / 2, oj = pj - WIN / 2;          // window origin (may be negative)
     constexpr int WORDS = WIN * WIN / 32;
+#ifdef PYDEM_PATHS_PROF
+    PProf pp_(WIN > 64 ? 1 : 0, slot, lane);
+    pp_.v[10] = 1;
+    const long long tsim0_ = wall_clock64();
+    struct SimEnd { PProf &p; long long t0; __device__ ~SimEnd() { p.v[8] += (unsigned long long)(wall_clock64() - t0); } } simend_{pp_, tsim0_};
+#endif
     PPROF(0, for (int w = lane; w < WORDS; w += 64) { seen[w] = 0; freshmap[w] = 0; });
     if (lane == 0) A.simround[slot] = A.round;
     __builtin_amdgcn_wave_barrier();
@@ -242,6 +257,7 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
     later = __any(later);
     bool found = false;
     int it = 0, n_out = 0;
+    double lowest_out = 0.0;     // the height of the outlet candidates
     int32_t *outlet = rim;       // the outlet candidates overwrite the rim list once the growth is over
     if (!overflow) {
         for (it = 0; it < A.max_iter; it++) {
@@ -281,7 +297,7 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
             n_alive -= nfresh;
             __builtin_amdgcn_wave_barrier();
 #ifdef PYDEM_PATHS_PROF
-            if (WIN > 64 && lane == 0) atomicAdd(&g_paths_prof[2], (unsigned long long)(wall_clock64() - tf0_));
+            pp_.v[2] += (unsigned long long)(wall_clock64() - tf0_);
 #endif
             // ascending cell order (:470): up to 64 cells by rank (one cell per lane), more through the window bitmap
             auto emit_fresh = [&](int32_t *dst, int start, int cap) -> int {
@@ -306,7 +322,7 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
             if (lowest < floor_) {                           // the first lower rim cells: outlet candidates (:471-473)
                 const int got = emit_fresh(outlet, 0, RCAP);
                 if (got < 0) overflow = true;
-                n_out = nfresh; found = true;
+                n_out = nfresh; found = true; lowest_out = lowest;
                 break;
             }
             if (nfresh > tcap - ntrail) { overflow = true; break; }
@@ -316,7 +332,7 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
             PPROF(4, add_ring(trail + first, nfresh));
             if (overflow) break;
 #ifdef PYDEM_PATHS_PROF
-            if (WIN > 64 && lane == 0) atomicAdd(&g_paths_prof[7], 1ull);
+            pp_.v[7] += 1ull;
 #endif
         }
     }
@@ -334,6 +350,10 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
     double *CV = A.CVp[slot];
     const int ccap = A.ccap[slot];
     int nC = 0, st = found ? ST_PATH : ST_FAILED;
+    int32_t end = -1;
+#ifdef PYDEM_PATHS_PROF
+    const long long tpath0_ = wall_clock64();
+#endif
     if (lane == 0 && found) {
         int no = n_out;
         if (A.max_dist) {                                    // index-space reach (:485-493)
@@ -347,7 +367,7 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
             no = w;
         }
         const bool use_xy = A.max_dist_XY != 0 && !isnan(A.max_dist_XY);
-        int valid = 0; double best = INFINITY; int32_t end = -1;
+        int valid = 0; double best = INFINITY;
         for (int q = 0; q < no; q++) {                       // metric reach (:494-512)
             const double r = pit_reach(A, pi, pj, outlet[q]);
             if (use_xy && !(r <= A.max_dist_XY)) continue;
@@ -363,45 +383,61 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
                 if (r == best) { end = outlet[q]; break; }
             }
         }
+#ifdef PYDEM_PATHS_PROF
+        pp_.v[14] += (unsigned long long)(wall_clock64() - tpath0_);
+#endif
         if (st == ST_PATH) {
-            // prune the trail, walking back from the outlet, to an 8-connected chain (:516-532): an entry stays when it
-            // touches the entry kept after it.  Built backwards, then reversed.
+            // prune the trail, walking back from the outlet, to an 8-connected chain (:516-532): an entry stays when it touches the
+            // entry kept after it.  The walk is one lane's and stays in the trail's own storage (LDS for the small window): the w-th
+            // entry kept goes to trail[ntrail - w] -- never below the entry being read, since at most ntrail - q entries are kept
+            // when entry q is read -- so the chain ends up in path order at trail[ntrail - nC + 1 .. ntrail].  (It was written
+            // backwards into the slot's chain in global memory and reversed there, load after store, by the same lane: a quarter of
+            // a simulation's time.)
             if (ntrail + 1 > ccap) st = ST_TOOBIG;
             else {
                 int w = 0;
-                C[w++] = end;
+                trail[ntrail - w++] = end;
                 int bi = row_of(end), bj = end - bi * m;                 // the entry kept last
                 for (int q = ntrail - 1; q >= 1; q--) {
                     const int32_t a = trail[q];
                     const int ai = row_of(a), aj = a - ai * m;
                     const int dii = ai > bi ? ai - bi : bi - ai, djj = aj > bj ? aj - bj : bj - aj;
-                    if (dii <= 1 && djj <= 1) { C[w++] = a; bi = ai; bj = aj; }
+                    if (dii <= 1 && djj <= 1) { trail[ntrail - w++] = a; bi = ai; bj = aj; }
                 }
-                C[w++] = pit;
-                for (int a = 0, b = w - 1; a < b; a++, b--) { const int32_t tt = C[a]; C[a] = C[b]; C[b] = tt; }
+                trail[ntrail - w++] = pit;
                 nC = w;
-                // elevations fall linearly along the chain (:535-539)
-                double base = A.e[pit];
-                const double e_end = A.e[end];
-                if (base < e_end) {
-                    double mn = INFINITY;
-                    for (int q = 0; q < nC; q++) { const double z = A.e[C[q]]; if (z > e_end && z < mn) mn = z; }
-                    base = mn;
-                }
-                // (a float32 surface takes the difference in float32, :537; the stored values get the array's dtype, :539)
-                const double drop = A.dtype_mode == 2 ? (double)((float)e_end - (float)base) : e_end - base;
-                const double step = 1.0 / (double)(nC - 1);  // np.linspace(0, 1, L): arange * step, last = 1
-                for (int q = 0; q < nC; q++) {
-                    const double f = (q == nC - 1) ? 1.0 : (double)q * step;
-                    double v = base + f * drop;
-                    if (A.dtype_mode == 1) v = trunc(v);
-                    else if (A.dtype_mode == 2) v = (double)(float)v;
-                    CV[q] = v;
-                }
             }
         }
     }
     nC = __shfl(nC, 0); st = __shfl(st, 0);
+#ifdef PYDEM_PATHS_PROF
+    pp_.v[15] += (unsigned long long)(wall_clock64() - tpath0_);
+#endif
+    if (st == ST_PATH) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // elevations fall linearly along the chain (:535-539), every lane its entries.  The outlet was taken off the rim at the
+        // height `lowest` < the pit's height `floor_` (both read from the surface this round simulates on): the reference's
+        // "the pit lies below the outlet" branch (:536) cannot be taken here.
+        const double base = floor_, e_end = lowest_out;
+        // (a float32 surface takes the difference in float32, :537; the stored values get the array's dtype, :539)
+        const double drop = A.dtype_mode == 2 ? (double)((float)e_end - (float)base) : e_end - base;
+        const double step = 1.0 / (double)(nC - 1);  // np.linspace(0, 1, L): arange * step, last = 1
+        const int32_t *chain = trail + (ntrail - nC + 1);
+        for (int q = lane; q < nC; q += 64) {
+            const double f = (q == nC - 1) ? 1.0 : (double)q * step;
+            double v = base + f * drop;
+            if (A.dtype_mode == 1) v = trunc(v);
+            else if (A.dtype_mode == 2) v = (double)(float)v;
+            C[q] = chain[q];
+            CV[q] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+#ifdef PYDEM_PATHS_PROF
+    pp_.v[6] += (unsigned long long)(wall_clock64() - tpath0_);
+#endif
     if (lane == 0) {
         if (st == ST_TOOBIG) { st = ST_OVERFLOW; }
         A.status[slot] = st; A.nF[slot] = st == ST_OVERFLOW ? 0 : nF; A.nC[slot] = st == ST_PATH ? nC : 0;
@@ -409,8 +445,10 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
     st = __shfl(st, 0);
     __builtin_amdgcn_wave_barrier();
     if (st == ST_OVERFLOW) return;
+    PPROF(9, {
     for (int q = lane; q < nF; q += 64) atomicMin(&A.rown[F[q]], k);
     if (st == ST_PATH) for (int q = lane; q < nC; q += 64) atomicMin(&A.wown[C[q]], k);
+    });
 }
 
 // small window: rim / trail capacities and the wavefronts per SIMD the kernel is compiled for.  Measured on the 8192^2
@@ -421,6 +459,9 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
 #define PYDEM_SRCAP 256
 #define PYDEM_STCAP 512
 #define PYDEM_SMALL_WAVES 4
+#endif
+#ifndef PYDEM_PATHS_CHUNK
+#define PYDEM_PATHS_CHUNK 4
 #endif
 constexpr int SWIN = 64, SRCAP = PYDEM_SRCAP, STCAP = PYDEM_STCAP;
 #ifndef PYDEM_MWIN
@@ -434,7 +475,7 @@ constexpr int BWIN = 640, BRCAP = 4096;                    // 102 + 56 KB: one p
 __global__ __launch_bounds__(256, PYDEM_SMALL_WAVES) void k_paths_small(PathArgs A, int nslots)
 {
     __shared__ uint32_t s_seen[4][SWIN * SWIN / 32], s_fresh[4][SWIN * SWIN / 32];
-    __shared__ int32_t s_rim[4][SRCAP], s_trail[4][STCAP];
+    __shared__ int32_t s_rim[4][SRCAP], s_trail[4][STCAP + 1];      // (+1: the chain is pruned in place and ends one past the trail)
     __shared__ double s_rimz[4][SRCAP];
     __shared__ int32_t s_flist[4][64];
     __shared__ uint16_t s_holes[4][SRCAP];
@@ -448,16 +489,30 @@ __global__ __launch_bounds__(256, PYDEM_SMALL_WAVES) void k_paths_small(PathArgs
 #else
     // persistent wavefronts take the next slot from a counter (flags[3], cleared by k_paths_slots): a simulation lasts 1 .. 300
     // iterations, and with four fixed slots per workgroup its LDS waits for the longest of the four
+    // (PYDEM_PATHS_CHUNK slots per claim: the counter is ONE address, and from the second round on most slots are a look at a kept
+    // simulation -- a claim per slot made the counter the bound of those rounds)
     for (;;) {
-        int q = 0;
-        if (lane == 0) q = atomicAdd(&A.flags[3], 1);
-        q = __shfl(q, 0);
-        if (q >= nslots) break;
-        if (A.tier[q] > 0) continue;     // known to leave the small window: its medium / large-window simulation runs beside this kernel
-        if (kept_simulation(A, q, lane)) continue;
-        simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_holes[wv], s_flist[wv], s_trail[wv], STCAP);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&A.flags[3], PYDEM_PATHS_CHUNK);
+        base = __shfl(base, 0);
+        if (base >= nslots) break;
+        const int stop = base + PYDEM_PATHS_CHUNK < nslots ? base + PYDEM_PATHS_CHUNK : nslots;
+        for (int q = base; q < stop; q++) {
+            if (A.tier[q] > 0) continue;     // known to leave the small window: its medium / large-window simulation runs beside this kernel
+#ifdef PYDEM_PATHS_PROF
+            {
+                const long long tk0_ = wall_clock64();
+                const bool kept_ = kept_simulation(A, q, lane);
+                if (lane == 0) { atomicAdd(&g_paths_prof[0][q & 63][11], (unsigned long long)(wall_clock64() - tk0_)); atomicAdd(&g_paths_prof[0][q & 63][12], 1ull); }
+                if (kept_) continue;
+            }
+#else
+            if (kept_simulation(A, q, lane)) continue;
+#endif
+            simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_holes[wv], s_flist[wv], s_trail[wv], STCAP);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 #endif
 }
@@ -769,14 +824,15 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     if (keep_env < 0) { const char *e = getenv("PYDEM_PATHS_KEEP"); keep_env = e ? atoi(e) : 1; }
     // what belongs to a pending pit (parallel to `pending`): its block of the small-window arrays, its block of the medium-window
     // pool (-1: none), its slot in the previous round (-1: none)
-    std::vector<int32_t> p_home, p_block, p_src, w_home, w_block, w_src, free_home((size_t)W), free_block;
+    // The host lists of the rounds live as long as the thread: 341 k pits make each of them 1.3 MB, and a fresh allocation of that
+    // size is a mapping the first round pays for page by page (1 ms of zero fill in round 1, more in the setup).
+    static thread_local std::vector<int32_t> p_home, p_block, p_src, w_home, w_block, w_src, free_home, free_block, pending, win, h_status, h_done, big;
+    static thread_local std::vector<uint8_t> tier, proven;
+    for (std::vector<int32_t> *v : {&pending, &win, &p_home, &p_block, &p_src, &w_home, &w_block, &w_src, &free_block, &big}) { v->clear(); v->reserve((size_t)W); }
+    free_home.resize((size_t)W); h_status.resize((size_t)W); h_done.resize((size_t)W);
     for (int h = 0; h < W; h++) free_home[(size_t)h] = W - 1 - h;
-    std::vector<int32_t> pending, win, h_status((size_t)W), h_done((size_t)W), big;
-    // (the lists of a round are rebuilt by push_back: without the room reserved the first rounds -- 341 k pits on the SRTM-like
-    // tile -- spend milliseconds growing eight vectors)
-    for (std::vector<int32_t> *v : {&pending, &win, &p_home, &p_block, &p_src, &w_home, &w_block, &w_src}) v->reserve((size_t)W);
-    std::vector<uint8_t> tier((size_t)npits, 0);            // what earlier rounds learned: 1 = the pit leaves the small window, 2 = the medium one too
-    std::vector<uint8_t> proven((size_t)npits, 0);          // a medium-window simulation of the pit has completed
+    tier.assign((size_t)npits, 0);                          // what earlier rounds learned: 1 = the pit leaves the small window, 2 = the medium one too
+    proven.assign((size_t)npits, 0);                        // a medium-window simulation of the pit has completed
     int64_t next = 0;                 // first pit of the order that has not entered a window yet
     int64_t rounds = 0, big_runs = 0, small_runs = 0;
     double ms_small = 0, ms_big = 0, ms_commit = 0, ms_prep = 0, ms_post = 0;
@@ -796,10 +852,16 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
     const double ms_setup = now_ms() - (ts0.tv_sec * 1e3 + ts0.tv_nsec * 1e-6);
     while (!pending.empty() || next < npits) {
         const double t_p = now_ms();
-        while ((int)pending.size() < W && next < npits) {
-            pending.push_back((int32_t)next++);
-            p_home.push_back(free_home.back()); free_home.pop_back(); p_block.push_back(-1); p_src.push_back(-1);
+        if ((int)pending.size() < W && next < npits) {          // (in bulk: a push_back per list and pit was 4.4 ms of the first round)
+            const size_t have = pending.size(), room = (size_t)W - have, left = (size_t)(npits - next), add = room < left ? room : left;
+            pending.resize(have + add); p_home.resize(have + add); p_block.resize(have + add, -1); p_src.resize(have + add, -1);
+            int32_t *pd = pending.data() + have, *ph = p_home.data() + have;
+            const int32_t *fh = free_home.data() + free_home.size() - 1;
+            for (size_t i = 0; i < add; i++) { pd[i] = (int32_t)(next + (int64_t)i); ph[i] = *(fh - i); }
+            free_home.resize(free_home.size() - add);
+            next += (int64_t)add;
         }
+        const double t_p1 = now_ms();
         // only as many large-window pits as one launch holds can take part in a round, and nobody after the first one
         // left out may commit (k_limit below): the pits behind it are not worth simulating this round
         int nw = (int)pending.size();
@@ -818,6 +880,7 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         // a pit that sits this round out gives its medium-window block back (the round's participants need at most big_max)
         for (size_t s2 = (size_t)nw; s2 < pending.size(); s2++)
             if (p_block[s2] >= 0) { free_block.push_back(p_block[s2]); p_block[s2] = -1; }
+        const double t_p2 = now_ms();
         memcpy(pin_window, pending.data(), (size_t)nw * 4);
         memcpy(pin_home, p_home.data(), (size_t)nw * 4);
         {
@@ -825,6 +888,7 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
             const uint8_t *tr = tier.data();
             for (int s2 = 0; s2 < nw; s2++) { pin_tier[s2] = tr[pd[s2]]; pin_src[s2] = keep_env ? ps[s2] : -1; }
         }
+        const double t_p3 = now_ms();
         HIP_TRY(hipMemcpyAsync(b_window.p, pin_window, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemcpyAsync(b_tier.p, pin_tier, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
         HIP_TRY(hipMemcpyAsync(b_home.p, pin_home, (size_t)nw * 4, hipMemcpyHostToDevice, t->stream));
@@ -832,6 +896,7 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         HIP_TRY(hipMemsetAsync(b_done.p, 0, (size_t)nw * 4, t->stream));
         const double t_a = now_ms();
         ms_prep += t_a - t_p;
+        if (prof && rounds < 4) fprintf(stderr, "    host before: fill %.2f, cut %.2f, staging %.2f, copies issued %.2f ms\n", t_p1 - t_p, t_p2 - t_p1, t_p3 - t_p2, t_a - t_p3);
         small_runs += nw;
         hipLaunchKernelGGL(k_paths_slots, dim3(gridp(nw, 256)), dim3(256), 0, t->stream, A, (int32_t *)b_F.p, (int32_t *)b_C.p, (double *)b_CV.p, FCAP, CCAP);
         // the medium / large-window simulations of a round: entry q of `big` owns block q of the scratch arrays.  Those of
@@ -980,6 +1045,20 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
             fprintf(stderr, "  round %lld: window %d, medium + large-window %d, committed %d; ms small %.2f large %.2f commit %.2f; kept so far %d, found stale %d\n", (long long)rounds, nw, (int)big.size(),
                     ncommit, t_b - t_a, t_c - t_b, now_ms() - t_c, t->h_counters[4], t->h_counters[5]);
         }
+#ifdef PYDEM_PATHS_PROF
+        {
+            static unsigned long long h[2][64][16], last[2][16];
+            if (rounds == 1) memset(last, 0, sizeof(last));
+            HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_paths_prof), sizeof(h)));
+            for (int c = 0; c < 2; c++) {
+                unsigned long long v[16] = {0};
+                for (int b = 0; b < 64; b++) for (int i = 0; i < 16; i++) { if (i == 13) v[i] = h[c][b][i] > v[i] ? h[c][b][i] : v[i]; else v[i] += h[c][b][i]; }
+                fprintf(stderr, "    %s: %llu simulations, %llu iterations, %.1f ms of wavefront time (path %.1f, ring %.1f), kept checks %llu in %.1f ms; longest simulation so far %.3f ms\n", c ? "medium / large" : "small",
+                        v[10] - last[c][10], v[7] - last[c][7], (v[8] - last[c][8]) * 1e-5, (v[6] - last[c][6]) * 1e-5, (v[4] - last[c][4]) * 1e-5, v[12] - last[c][12], (v[11] - last[c][11]) * 1e-5, v[13] * 1e-5);
+                memcpy(last[c], v, sizeof(v));
+            }
+        }
+#endif
         if (getenv("PYDEM_PATHS_DEBUG") && atoi(getenv("PYDEM_PATHS_DEBUG")) >= 2) {
             std::vector<int32_t> h_it((size_t)nw);
             HIP_TRY(hipMemcpy(h_it.data(), A.iters, (size_t)nw * 4, hipMemcpyDeviceToHost));
@@ -999,18 +1078,22 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
                 else stuck = true;                               // does not even fit the large window
             }
         if (stuck) { fallback = true; break; }
+        const double t_q1 = now_ms();
         win.resize(pending.size()); w_home.resize(pending.size()); w_block.resize(pending.size()); w_src.resize(pending.size());
+        const double t_q2 = now_ms();
         size_t nk = 0;                                         // pits that stay
         {
             const int32_t *hd = h_done.data(), *pd = pending.data(), *ph = p_home.data(), *pb = p_block.data();
             int32_t *ow = win.data(), *oh = w_home.data(), *ob = w_block.data(), *os = w_src.data();
+            // (every entry is written where the next survivor goes and the index moves on only for a survivor: the 40 / 60 branch on
+            // "committed" was 4.5 ns per slot; homes go back on their stack only while pits still wait to enter a window)
             for (int s = 0; s < nw; s++) {
-                if (!hd[s]) { ow[nk] = pd[s]; oh[nk] = ph[s]; ob[nk] = pb[s]; os[nk] = s; nk++; }
-                else {
-                    free_home.push_back(ph[s]);
-                    if (pb[s] >= 0) free_block.push_back(pb[s]);
-                }
+                const int32_t d = hd[s];
+                ow[nk] = pd[s]; oh[nk] = ph[s]; ob[nk] = pb[s]; os[nk] = s;
+                nk += d ? 0 : 1;
+                if (d && pb[s] >= 0) free_block.push_back(pb[s]);
             }
+            if (next < npits) for (int s = 0; s < nw; s++) if (hd[s]) free_home.push_back(ph[s]);
         }
         win.resize(nk); w_home.resize(nk); w_block.resize(nk); w_src.resize(nk);
         if ((int)win.size() == nw && !escalated) { fallback = true; break; }          // (cannot happen: the first pit always commits)
@@ -1019,16 +1102,21 @@ int stage_pit_paths(pydem_tile *t, const int32_t *order_host, int64_t npits, int
         }
         pending.swap(win); p_home.swap(w_home); p_block.swap(w_block); p_src.swap(w_src);
         ms_post += now_ms() - t_d;
+        if (prof && rounds <= 4) fprintf(stderr, "    host after: checks %.2f, resize %.2f, compaction %.2f ms\n", t_q1 - t_d, t_q2 - t_q1, now_ms() - t_q2);
     }
     if (rounds_out) *rounds_out = rounds;
 #ifdef PYDEM_PATHS_PROF
     {
-        unsigned long long h[8];
+        static unsigned long long h[2][64][16];
         HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_paths_prof), sizeof(h)));
-        fprintf(stderr, "large-window simulations, 10 ns ticks summed over %lld of them: clear %llu, min scan %llu, fresh pass %llu, emit %llu, ring %llu, footprint %llu; %llu iterations\n",
-                (long long)big_runs, h[0], h[1], h[2], h[3], h[4], h[5], h[7]);
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_paths_prof), z, sizeof(z)));
+        for (int c = 0; c < 2; c++) {
+            unsigned long long v[16] = {0};
+            for (int b = 0; b < 64; b++) for (int i = 0; i < 16; i++) v[i] += h[c][b][i];
+            fprintf(stderr, "%s simulations: %llu, %llu iterations; 10 ns ticks summed: whole %llu = clear %llu, min scan %llu, fresh pass %llu, emit %llu, ring %llu, footprint %llu, path %llu, "
+                            "reservations %llu; kept checks %llu in %llu ticks; of the path: outlet choice %llu, + pruning %llu\n", c ? "medium / large-window" : "small-window", v[10], v[7], v[8], v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[9], v[12], v[11], v[14], v[15]);
+        }
+        memset(h, 0, sizeof(h));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_paths_prof), h, sizeof(h)));
     }
 #endif
     if (getenv("PYDEM_PATHS_DEBUG"))
