@@ -1328,6 +1328,7 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
         if (batch_cells < 0) {
             const char *e = getenv("PYDEM_FLAT_BATCH"); batch_cells = e ? atoi(e) : 16384;
             if ((e = getenv("PYDEM_FLAT_BATCH_T"))) { batch_T = atoi(e); if (batch_T < 1 || batch_T > FT) batch_T = FT; }
+            if ((e = getenv("PYDEM_FLAT_BATCH_REGIONS"))) { batch_regions = atoi(e); if (batch_regions < 1 || batch_regions >= (int)FI_NOSLOT) batch_regions = (int)FI_NOSLOT - 1; }
         }
         const int nbi = (n + FB - 1) / FB, nbj = (m + FB - 1) / FB;
         int32_t *b_slot = nullptr, *b_arid = nullptr, *b_arr = nullptr, *b_stamp = nullptr, *b_list[2] = {nullptr, nullptr};
@@ -1357,6 +1358,7 @@ int stage_fill_flats(pydem_tile *t, double max_pit_area, int below_sea, double s
                 hipLaunchKernelGGL(k_flat_blocks, dim3(grid_of(na, 1024)), dim3(256), 0, t->stream, al[q0], na, n, m, nbj, b_stamp, 1, b_list[0], cnt + 20);
                 HIP_TRY(hipMemcpyAsync(t->h_counters + 16, cnt + 16, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
                 HIP_TRY(hipStreamSynchronize(t->stream));
+                if (cond_debug > 1) fprintf(stderr, "fill_flats: sweep %d, list %d: %d regions still sweeping, %d blocks\n", sweep, na, t->h_counters[16], t->h_counters[20]);
                 if (t->h_counters[16] > batch_regions) batch_limit = na / 2;      // too many regions still sweeping: more single sweeps first
                 else {
                     // cnt[20..22]: block counts, rotating (pass k reads [k % 3], appends to [(k + 1) % 3], its k_flat_accept clears [(k + 2) % 3]);
