@@ -151,10 +151,37 @@ __device__ double pit_reach(const PathArgs &A, int pi, int pj, int32_t t)
     return sqrt(run * run + rise * rise);
 }
 
+// the same for the small window, whose rows of dX / dY were staged in LDS when the simulation began (rows[0 .. 63] = dX[oi ..],
+// rows[64 .. 127] = dY[oi ..]): the outlet lies in the window, so every row between it and the pit does; at most 32 addends, numpy's
+// pairwise order (np_sum_dev without its recursion above 128), no 64-bit division
+__device__ __forceinline__ double np_sum_le128(const double *a, int n)
+{
+    if (n < 8) { double r = 0.; for (int i = 0; i < n; i++) r += a[i]; return r; }
+    double r[8];
+    for (int k = 0; k < 8; k++) r[k] = a[k];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int k = 0; k < 8; k++) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+__device__ double pit_reach_rows(const PathArgs &A, int pi, int pj, int ti, int tj, const double *rows, int oi)
+{
+    const int lo = pi < ti ? pi : ti, hi = pi < ti ? ti : pi;
+    double dxm;
+    if (pi == ti) dxm = rows[(pi < A.ndX - 1 ? pi : A.ndX - 1) - oi];           // _get_dX_mean :1993-1997
+    else dxm = np_sum_le128(rows + (lo - oi), hi - lo) / (double)(hi - lo);
+    const double run = dxm * (double)(pj - tj);
+    const double rise = np_sum_le128(rows + 64 + (lo - oi), hi - lo);
+    return sqrt(run * run + rise * rise);
+}
+
 // One pit, one wavefront.  WIN: window edge, RCAP: rim capacity; the trail lives in LDS for the small window and in
 // global scratch for the large one.
 template <int WIN, int RCAP>
-__device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32_t *freshmap, int32_t *rim, double *rimz, uint16_t *holes, int32_t *flist, int32_t *trail, int tcap)
+__device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32_t *freshmap, int32_t *rim, double *rimz, uint16_t *holes, int32_t *flist, int32_t *trail, int tcap,
+                             double *rows = nullptr)
 {
     const int lane = (int)(threadIdx.x & 63);
     const int k = A.window[slot];
@@ -171,6 +198,11 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
 #endif
     PPROF(0, for (int w = lane; w < WORDS; w += 64) { seen[w] = 0; freshmap[w] = 0; });
     if (lane == 0) A.simround[slot] = A.round;
+    if (WIN == 64 && rows) {                                 // the window's rows of dX / dY (the choice of the outlet sums over them)
+        const int r = oi + lane;
+        const bool in = r >= 0 && r < A.ndX;
+        rows[lane] = in ? A.dX[r] : 0.0; rows[64 + lane] = in ? A.dY[r] : 0.0;
+    }
     __builtin_amdgcn_wave_barrier();
     // the rim is an unordered list with HOLES: a cell that leaves it (promoted into the region) frees its slot (rim = -1,
     // height +inf), the slot goes on a stack and the next cell that joins takes it -- nothing is compacted per iteration.
@@ -368,8 +400,12 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
         }
         const bool use_xy = A.max_dist_XY != 0 && !isnan(A.max_dist_XY);
         int valid = 0; double best = INFINITY;
+        auto reach = [&](int32_t t) -> double {
+            if (WIN == 64 && rows) { const int tr = row_of(t); return pit_reach_rows(A, pi, pj, tr, t - tr * m, rows, oi); }
+            return pit_reach(A, pi, pj, t);
+        };
         for (int q = 0; q < no; q++) {                       // metric reach (:494-512)
-            const double r = pit_reach(A, pi, pj, outlet[q]);
+            const double r = reach(outlet[q]);
             if (use_xy && !(r <= A.max_dist_XY)) continue;
             if (valid == 0) end = outlet[q];
             valid++;
@@ -378,7 +414,7 @@ __device__ void simulate_pit(const PathArgs &A, int slot, uint32_t *seen, uint32
         if (valid == 0) st = ST_FAILED;
         else if (valid > 1) {
             for (int q = 0; q < no; q++) {
-                const double r = pit_reach(A, pi, pj, outlet[q]);
+                const double r = reach(outlet[q]);
                 if (use_xy && !(r <= A.max_dist_XY)) continue;
                 if (r == best) { end = outlet[q]; break; }
             }
@@ -479,13 +515,14 @@ __global__ __launch_bounds__(256, PYDEM_SMALL_WAVES) void k_paths_small(PathArgs
     __shared__ double s_rimz[4][SRCAP];
     __shared__ int32_t s_flist[4][64];
     __shared__ uint16_t s_holes[4][SRCAP];
+    __shared__ double s_rows[4][2 * SWIN];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #ifdef PYDEM_PATHS_STATIC
     const int q = blockIdx.x * 4 + wv;
     if (q >= nslots) return;
     if (A.tier[q] > 0) return;       // known to leave the small window: its medium / large-window simulation runs beside this kernel
     if (kept_simulation(A, q, lane)) return;
-    simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_holes[wv], s_flist[wv], s_trail[wv], STCAP);
+    simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_holes[wv], s_flist[wv], s_trail[wv], STCAP, s_rows[wv]);
 #else
     // persistent wavefronts take the next slot from a counter (flags[3], cleared by k_paths_slots): a simulation lasts 1 .. 300
     // iterations, and with four fixed slots per workgroup its LDS waits for the longest of the four
@@ -509,7 +546,7 @@ __global__ __launch_bounds__(256, PYDEM_SMALL_WAVES) void k_paths_small(PathArgs
 #else
             if (kept_simulation(A, q, lane)) continue;
 #endif
-            simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_holes[wv], s_flist[wv], s_trail[wv], STCAP);
+            simulate_pit<SWIN, SRCAP>(A, q, s_seen[wv], s_fresh[wv], s_rim[wv], s_rimz[wv], s_holes[wv], s_flist[wv], s_trail[wv], STCAP, s_rows[wv]);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
         }
