@@ -3099,7 +3099,9 @@ int stage_sweep(pydem_tile *t, const pydem_options *opt)
         N.flag = tile_flag;
         listed_left = ntiles;
         while (ntiles > stop_at) {
-            const int batch = ntiles < 2048 ? 16 : 8;    // passes between two looks at the list size (a look idles the GPU for ~30 us; the grid only shrinks below 8192 listed tiles)
+            static int dbg_each = -1;                        // PYDEM_SWEEP_DEBUG=2: a look (and a line) after every pass
+            if (dbg_each < 0) { const char *e = getenv("PYDEM_SWEEP_DEBUG"); dbg_each = (e && atoi(e) >= 2) ? 1 : 0; }
+            const int batch = dbg_each ? 1 : ntiles < 2048 ? 16 : 8;    // passes between two looks at the list size (a look idles the GPU for ~30 us; the grid only shrinks below 8192 listed tiles)
 #ifndef PYDEM_LISTED_DYNAMIC
             const int grid = (int)(ntiles < 8192 ? (ntiles > 64 ? ntiles : 64) : 8192) * (4 / LWPB);
 #else
