@@ -688,7 +688,14 @@ __device__ __forceinline__ void fill_nbr16(int32_t *nbr16, int m)
 }
 __device__ __forceinline__ double in_edge_h(const TileBase &B, const int32_t *nbr16, uint32_t h, int d)
 {
+#ifdef PYDEM_EXP_AREAONLY      // timing experiment (taint is lost: results differ): the share formed from the upstream cell's area and proportion
+    const uint32_t off16 = h * 16u + (uint32_t)nbr16[d];
+    const uint32_t uo = (off16 >> 4) * 8u;
+    const double ua = ld_off<double>(B.area, uo), up = ld_off<double>(B.prop, uo);
+    return (off16 & 8u) ? ua * (1 - up) : ua * up;
+#else
     return ld_off<double>(B.contrib, h * 16u + (uint32_t)nbr16[d]);        // (the neighbour lies in the halo: the sum is >= 0)
+#endif
 }
 
 // staging of a tile visit: the graph words of the tile (high half of L.cs, state bit "final before this pass" in the low
@@ -919,7 +926,9 @@ __device__ __forceinline__ void sweep_one_tile(const SweepArgs &A, TileW &L, uin
             if (cw & CI_OUT2) o.y = a * (1 - pv);
             if (td) { o.x = -o.x; o.y = -o.y; }
             st_off<double>(B.area, h * 8u, a);
+#ifndef PYDEM_EXP_NOCONTRIB      // timing experiment: the tile visits without their 16-byte contribution stores
             st_off<double2>(B.contrib, h * 16u, o);
+#endif
             if (LISTED) st_off<uint32_t>(B.cinfo, h * 4u, ci_with_level(cw, pass));    // finished in this pass (other tiles treat levels < their pass as final)
             if (td) st_off<uint8_t>(B.todo, h, (uint8_t)1);
             sp_of(L, idx) = (uint16_t)(2u << SP_STATE_SHIFT);
