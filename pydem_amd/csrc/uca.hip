@@ -88,13 +88,15 @@ __global__ __launch_bounds__(256) void k_section_proportion(const double *__rest
         const int mod2 = sec0 & 1;                                               // python % 2
         int sec = sec0 * 2 + ((quadrant > theta) && mod2 == 0) + ((quadrant > (PI_D / 2 - theta)) && mod2 == 1);  // :1040-1043
         sec = (int)(int8_t)sec;
-        double p = NAN;
         const bool I1 = sec == 0 || sec == 1 || sec == 4 || sec == 5;           // :1050
         const double cth = PI_D / 2 - theta;
-        if (I1 && quadrant <= theta) p = quadrant / theta;                       // :1052-1053
-        if (I1 && quadrant > theta) p = (quadrant - theta) / cth;                // :1054-1056
-        if (!I1 && quadrant <= cth) p = quadrant / cth;                          // :1057-1059
-        if (!I1 && quadrant > cth) p = (quadrant - cth) / theta;                 // :1060-1062
+        // the four cases of :1052-1062 -- I1: quadrant / theta or (quadrant - theta) / cth, else: quadrant / cth or (quadrant - cth) / theta --
+        // exclude each other: operands selected first, ONE division (a wavefront holds cells of all four cases, and the four
+        // predicated fp64 divisions were most of this kernel's instructions); a NaN direction fails both tests and stays NaN
+        const double t1 = I1 ? theta : cth, t2 = I1 ? cth : theta;
+        const bool lo = quadrant <= t1, hi = quadrant > t1;
+        const double num = lo ? quadrant : quadrant - t1, den = lo ? t1 : t2;
+        double p = (lo || hi) ? num / den : NAN;
         if (flats[c]) { sec = -1; p = NAN; }                                     // :1064-1065
         if (sec == 8) sec = 0;                                                   // :1067
         const int a = (sec & 1) ? -1 : 1;                                        // adjust[section], negative wraps
