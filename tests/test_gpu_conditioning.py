@@ -243,3 +243,37 @@ def test_device_pit_paths_keep_the_arrays_dtype(dtype):
         assert (res[0], res[1]) == (bad, used)
         done += 1
     assert done >= 10
+
+
+def test_device_pit_paths_trail_capacity_boundary():
+    """Flat-floored basins whose flood holds 504 .. 529 cells when it meets its outlet -- around the 512 trail entries of the
+    small-window simulation (the chain is pruned in place at the END of the trail, one entry past it): 512 fits exactly, 513 goes
+    on to the medium window (trail in global memory, pruned in place as well).  Each basin: a pit one unit below the floor in the
+    middle, a sink hole five units below it diagonally outside the corner the rings reach last (itself a pit that fails)."""
+    from pydem_amd import DEMProcessor, conditioning as C
+    n = m = 420
+    ii, jj = np.meshgrid(np.arange(n, dtype=np.float64), np.arange(m, dtype=np.float64), indexing='ij')
+    z = 5000.0 + 0.5 * ii + 0.3 * jj                                  # a tilted plane: no pits of its own
+    sizes = [(21, 24), (22, 23), (15, 34), (16, 32), (19, 27), (23, 23)]
+    expect = []
+    for q, (rows, cols) in enumerate(sizes):
+        r0, c0 = 40 + 130 * (q // 3), 40 + 130 * (q % 3)
+        f = 1000.0 + 50.0 * q
+        z[r0:r0 + rows, c0:c0 + cols] = f
+        z[r0 + rows // 2, c0 + cols // 2] = f - 1.0
+        z[r0 - 1, c0 - 1] = f - 5.0
+        expect.append((r0 + rows // 2, c0 + cols // 2, r0 - 1, c0 - 1, rows * cols))
+    dX = np.full(n - 1, 30.0); dY = np.full(n - 1, 30.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        want, bad, used = C.pit_drain_paths(z.copy(), dX, dY)
+        dp = DEMProcessor(elev=z.copy(), dX=dX, dY=dY)
+        res = dp._pit_paths_on_device()
+    assert res is not None, "fell back to the host loop"
+    got = np.asarray(dp.elev)
+    assert np.array_equal(got, want), "paths differ on %d cells" % int((got != want).sum())
+    assert (res[0], res[1]) == (bad, used)
+    for pi, pj, si, sj, cells in expect:                               # every basin's pit got its path to the sink hole
+        changed = (want != z)[pi - 40:pi + 40, pj - 40:pj + 40].sum()
+        assert changed >= 8, (cells, changed)
+        assert want[si, sj] == z[si, sj]
