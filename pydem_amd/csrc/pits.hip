@@ -1584,7 +1584,8 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr,
                                                    (int32_t *)nullptr, ne, 0, 64, t->stream));
         const size_t ne8 = ((size_t)ne * 8 + 255) & ~(size_t)255, ne4 = ((size_t)ne * 4 + 255) & ~(size_t)255;
-        const size_t need_sort = 4 * ne8 + 3 * ne4 + tmp_bytes + 256;
+        const size_t tmp_al = (tmp_bytes + 255) & ~(size_t)255;
+        const size_t need_sort = 4 * ne8 + 3 * ne4 + 2 * tmp_al + 256;          // (two scratch areas: the sorts run side by side)
         if (t->pits.sort_bytes < need_sort) {
             if (t->pits.sort_buf) { HIP_TRY(hipFree(t->pits.sort_buf)); t->device_bytes -= (int64_t)t->pits.sort_bytes; }
             HIP_TRY(dev_malloc((void **)&t->pits.sort_buf, need_sort + need_sort / 4));
@@ -1605,13 +1606,19 @@ int stage_pits(pydem_tile *t, const pydem_options *opt)
         if (nk > 0) {
             // (the temporary storage of both sorts is the tail of the persistent block, sized for ne >= nk entries)
             const int g = (int)(cdiv(nk, 256) < 1024 ? cdiv(nk, 256) : 1024);
+            // the two sorts share nothing but their read-only inputs (the host has just waited for k_pit_keys): the (dst, src) one and its
+            // gather go to the side stream -- behind the graph kernels if those still run, which the main stream waits for anyway --
+            // and the main stream waits for them before the host looks at the duplicate counter
+            void *tmp2 = (char *)tmp + tmp_al;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp2, tmp_bytes, k2, k2s, idx, i2, nk, 0, 2 * kb, t->stream2));
+            hipLaunchKernelGGL(k_pit_gather, dim3(g), dim3(256), 0, t->stream2, k2s, i2, t->pits.raw_w, nk, 1, t->pits.in_src,
+                               t->pits.in_dst, t->pits.in_w, (int32_t *)nullptr, kb);
+            HIP_TRY(hipEventRecord(t->ev_snap, t->stream2));
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k1, k1s, idx, i1, nk, 0, 2 * kb, t->stream));
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k2, k2s, idx, i2, nk, 0, 2 * kb, t->stream));
             HIP_TRY(hipMemsetAsync(cnt + 11, 0, sizeof(int32_t), t->stream));
             hipLaunchKernelGGL(k_pit_gather, dim3(g), dim3(256), 0, t->stream, k1s, i1, t->pits.raw_w, nk, 0, t->pits.src, t->pits.dst,
                                t->pits.w, cnt + 11, kb);
-            hipLaunchKernelGGL(k_pit_gather, dim3(g), dim3(256), 0, t->stream, k2s, i2, t->pits.raw_w, nk, 1, t->pits.in_src,
-                               t->pits.in_dst, t->pits.in_w, (int32_t *)nullptr, kb);
+            HIP_TRY(hipStreamWaitEvent(t->stream, t->ev_snap, 0));
             HIP_TRY(hipMemcpyAsync(t->h_counters, cnt + 11, sizeof(int32_t), hipMemcpyDeviceToHost, t->stream));
             HIP_TRY(hipStreamSynchronize(t->stream));
             if (t->h_counters[0] != 0) { pydem_set_error("pit search: %d duplicate pit -> drain edges", t->h_counters[0]); return -5; }
