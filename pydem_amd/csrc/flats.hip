@@ -30,6 +30,11 @@ __global__ void k_flats_extend(const int32_t *__restrict__ list, const int32_t *
         const int i = c / m + d / 3 - 1, j = c % m + d % 3 - 1;
         if (i < 0 || i >= n || j < 0 || j >= m) continue;
         const int32_t J = i * m + j;
+        // A cell that is not flat itself can only become true through a neighbouring region whose root has ITS elevation, and the
+        // threads of that region's cells get past this test: a thread whose own region cannot set J leaves J (false from the copy
+        // of flat0) to them -- on fractal terrain that is nearly every thread, and it saves the scan of J's eight neighbours.
+        // (A flat J always takes the full path: its value is rewritten as the reference rewrites it.)
+        if (!flat0[J] && !(elev[J] == elev[labels[c]])) continue;
         int32_t best = -1;
         for (int dd = 0; dd < 9; dd++) {
             if (dd == 4) continue;
