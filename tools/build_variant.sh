@@ -3,8 +3,9 @@
 # -> pydem_amd/lib/libpydem_hip.so.<tag> = the product objects with the named units recompiled under the extra flags
 set -e
 TAG=$1; FLAGS=$2; shift 2
-cd "$(dirname "$0")/../pydem_amd"
-python -m pydem_amd.build > /dev/null 2>&1 || (cd .. && python -m pydem_amd.build > /dev/null)
+cd "$(dirname "$0")/.."
+python -m pydem_amd.build > /dev/null          # the product objects the variant is linked from
+cd pydem_amd
 EXCL=""; OBJS=""
 for u in "$@"; do
   o=/tmp/variant_${TAG}_${u%.*}.o
